@@ -1,0 +1,972 @@
+/*
+ * fcd_oracle.c -- CPU restatement of nanoporetech/fast-ctc-decode (v0.3.7) search algorithms.
+ *
+ * TEST INFRASTRUCTURE ONLY (see fcd_oracle.h).  Plain C99, single-threaded per read.
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (oracle/Makefile) -- f32 arithmetic must not
+ * be contracted into FMAs: the reference multiplies and adds in separate roundings.
+ *
+ * Citations are path:line relative to /root/reference.
+ */
+#include "fcd_oracle.h"
+
+#include <math.h>
+#include <pthread.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define FCDO_PANIC 100 /* the reference would panic (= abort, Cargo.toml:40) on this input */
+
+/* ------------------------------------------------------------------------------------------
+ * Suffix tree: src/tree.rs:4-194 + src/vec2d.rs.  Append-only arena; node index == creation
+ * order (tree.rs:129), children row of n_labels i32 per node initialised to -1 (tree.rs:143),
+ * root children kept apart (tree.rs:40-43).  `data` is the usize payload of the 1D searches
+ * (creation time); the duplex searches keep their payload in a parallel array.
+ * ---------------------------------------------------------------------------------------- */
+struct fcdo_tree {
+    int64_t n_labels;
+    int64_t len, cap;
+    int32_t *parent;
+    int32_t *label;
+    int64_t *data;
+    int32_t *children; /* len * n_labels */
+    int32_t *root_children;
+};
+
+fcdo_tree *fcdo_tree_new(int64_t n_labels) {
+    fcdo_tree *t = (fcdo_tree *)calloc(1, sizeof(*t));
+    t->n_labels = n_labels;
+    t->cap = 1024;
+    t->parent = (int32_t *)malloc(sizeof(int32_t) * t->cap);
+    t->label = (int32_t *)malloc(sizeof(int32_t) * t->cap);
+    t->data = (int64_t *)malloc(sizeof(int64_t) * t->cap);
+    t->children = (int32_t *)malloc(sizeof(int32_t) * t->cap * (n_labels > 0 ? n_labels : 1));
+    t->root_children = (int32_t *)malloc(sizeof(int32_t) * (n_labels > 0 ? n_labels : 1));
+    for (int64_t i = 0; i < n_labels; ++i) t->root_children[i] = -1;
+    return t;
+}
+
+void fcdo_tree_free(fcdo_tree *t) {
+    if (!t) return;
+    free(t->parent);
+    free(t->label);
+    free(t->data);
+    free(t->children);
+    free(t->root_children);
+    free(t);
+}
+
+/* tree.rs:125-145 */
+int32_t fcdo_tree_add_node(fcdo_tree *t, int32_t parent, int64_t label, int64_t data) {
+    if (t->len == t->cap) {
+        t->cap *= 2;
+        t->parent = (int32_t *)realloc(t->parent, sizeof(int32_t) * t->cap);
+        t->label = (int32_t *)realloc(t->label, sizeof(int32_t) * t->cap);
+        t->data = (int64_t *)realloc(t->data, sizeof(int64_t) * t->cap);
+        t->children = (int32_t *)realloc(t->children, sizeof(int32_t) * t->cap * t->n_labels);
+    }
+    int32_t idx = (int32_t)t->len;
+    if (parent == -1)
+        t->root_children[label] = idx;
+    else
+        t->children[(int64_t)parent * t->n_labels + label] = idx;
+    t->parent[idx] = parent;
+    t->label[idx] = (int32_t)label;
+    t->data[idx] = data;
+    for (int64_t i = 0; i < t->n_labels; ++i) t->children[(int64_t)idx * t->n_labels + i] = -1;
+    t->len++;
+    return idx;
+}
+
+/* tree.rs:147-161 */
+int32_t fcdo_tree_get_child(const fcdo_tree *t, int32_t node, int64_t label) {
+    int32_t idx = (node == -1) ? t->root_children[label]
+                               : t->children[(int64_t)node * t->n_labels + label];
+    return idx >= 0 ? idx : -1;
+}
+
+/* tree.rs:104-110 */
+int64_t fcdo_tree_label(const fcdo_tree *t, int32_t node) {
+    return node >= 0 ? t->label[node] : -1;
+}
+int32_t fcdo_tree_parent(const fcdo_tree *t, int32_t node) { return t->parent[node]; }
+int64_t fcdo_tree_data(const fcdo_tree *t, int32_t node) { return t->data[node]; }
+int64_t fcdo_tree_len(const fcdo_tree *t) { return t->len; }
+
+/* ------------------------------------------------------------------------------------------
+ * phred: src/search.rs:31-36
+ * ---------------------------------------------------------------------------------------- */
+static uint32_t sat_u32(float q) { /* Rust `as u32`: saturating, NaN -> 0 */
+    if (!(q == q)) return 0;
+    if (q <= 0.0f) return 0;
+    if (q >= 4294967296.0f) return 4294967295u;
+    return (uint32_t)q;
+}
+
+static uint32_t phred_code(float prob, float qscale, float qbias) {
+    const float max = 1e-4f;
+    float om = 1.0f - prob;
+    float p = (om < max) ? max : om;
+    float q = -10.0f * log10f(p) * qscale + qbias;
+    return sat_u32(roundf(q)) + 33u; /* f32::round = half away from zero = roundf */
+}
+
+char fcdo_phred(float prob, float qscale, float qbias) {
+    return (char)phred_code(prob, qscale, qbias);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * viterbi_search: src/search.rs:303-383
+ * ---------------------------------------------------------------------------------------- */
+int fcdo_viterbi_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                        int collapse_repeats, float qscale, float qbias,
+                        int32_t *labels, int64_t *path, uint32_t *quals, int64_t *n_out) {
+    if (T <= 0 || N <= 0) return FCDO_PANIC; /* assert!(!network_output.is_empty()) :329 */
+    int64_t n = 0, nq = 0;
+    int64_t last_label = -1;
+    int64_t count = 0;
+    float total = 0.0f;
+    for (int64_t t = 0; t < T; ++t) {
+        const float *pr = x + t * rs;
+        /* find_max :303-318: strict '>' so the first maximum wins; a NaN in column 0 sticks */
+        int64_t label = 0;
+        float prob = pr[0];
+        for (int64_t j = 1; j < N; ++j) {
+            float v = pr[j * cs];
+            if (v > prob) {
+                label = j;
+                prob = v;
+            }
+        }
+        if (label != 0 && (!collapse_repeats || last_label != label)) { /* :347 */
+            if (count > 0) {
+                if (quals) quals[nq] = phred_code(total / (float)count, qscale, qbias);
+                nq++;
+                total = 0.0f;
+                count = 0;
+            }
+            labels[n] = (int32_t)label;
+            path[n] = t;
+            n++;
+        }
+        if (label != 0) { /* :362-365 */
+            total += prob;
+            count++;
+        }
+        last_label = label;
+    }
+    if (count > 0) { /* :370-376 */
+        if (quals) quals[nq] = phred_code(total / (float)count, qscale, qbias);
+        nq++;
+    }
+    *n_out = n;
+    return FCDO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * 1D beam search: src/search.rs:7-28 (SearchPoint), :159-301 (beam_search), :38-157 (crf)
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    int32_t node;
+    int64_t state;
+    float label_prob;
+    float gap_prob;
+} sp1;
+
+static inline float sp1_prob(const sp1 *p) { return p->label_prob + p->gap_prob; } /* :25-27 */
+
+typedef struct {
+    sp1 *v;
+    int64_t len, cap;
+} sp1vec;
+
+static void sp1_push(sp1vec *b, sp1 p) {
+    if (b->len == b->cap) {
+        b->cap = b->cap ? b->cap * 2 : 64;
+        b->v = (sp1 *)realloc(b->v, sizeof(sp1) * b->cap);
+    }
+    b->v[b->len++] = p;
+}
+
+/*
+ * Stable sorts.  Rust's sort_by_key (:245) is stable; sort_unstable_by (:262) on <= 20 elements
+ * is an insertion sort (behaves stably); above 20 it is pdqsort whose tie order is
+ * implementation-defined -- PARITY UNPINNED, this restatement stays stable.
+ */
+#define DEFINE_STABLE_SORT(NAME, TYPE, LESS)                                              \
+    static void NAME##_insertion(TYPE *v, int64_t n) {                                    \
+        for (int64_t i = 1; i < n; ++i) {                                                 \
+            TYPE x = v[i];                                                                \
+            int64_t j = i;                                                                \
+            while (j > 0 && LESS(&x, &v[j - 1])) {                                        \
+                v[j] = v[j - 1];                                                          \
+                --j;                                                                      \
+            }                                                                             \
+            v[j] = x;                                                                     \
+        }                                                                                 \
+    }                                                                                     \
+    static void NAME##_merge(TYPE *v, TYPE *tmp, int64_t n) {                             \
+        if (n <= 20) {                                                                    \
+            NAME##_insertion(v, n);                                                       \
+            return;                                                                       \
+        }                                                                                 \
+        int64_t h = n / 2;                                                                \
+        NAME##_merge(v, tmp, h);                                                          \
+        NAME##_merge(v + h, tmp, n - h);                                                  \
+        memcpy(tmp, v, sizeof(TYPE) * h);                                                 \
+        int64_t i = 0, j = h, k = 0;                                                      \
+        while (i < h && j < n) {                                                          \
+            if (LESS(&v[j], &tmp[i]))                                                     \
+                v[k++] = v[j++];                                                          \
+            else                                                                          \
+                v[k++] = tmp[i++];                                                        \
+        }                                                                                 \
+        while (i < h) v[k++] = tmp[i++];                                                  \
+    }                                                                                     \
+    static void NAME(TYPE *v, int64_t n, TYPE **tmp, int64_t *tmpcap) {                   \
+        if (n <= 20) {                                                                    \
+            NAME##_insertion(v, n);                                                       \
+            return;                                                                       \
+        }                                                                                 \
+        if (*tmpcap < n) {                                                                \
+            *tmpcap = n * 2;                                                              \
+            *tmp = (TYPE *)realloc(*tmp, sizeof(TYPE) * (*tmpcap));                       \
+        }                                                                                 \
+        NAME##_merge(v, *tmp, n);                                                         \
+    }
+
+#define SP1_NODE_LESS(a, b) ((a)->node < (b)->node)
+#define SP1_PROB_GREATER(a, b) (sp1_prob(a) > sp1_prob(b)) /* descending :263-265 */
+DEFINE_STABLE_SORT(sp1_sort_node, sp1, SP1_NODE_LESS)
+DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
+
+/*
+ * Shared tail of every 1D step: :245-282 (== :105-142).  Returns FCDO_* status.
+ */
+static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *tmpcap) {
+    sp1_sort_node(beam->v, beam->len, tmp, tmpcap); /* :245 stable */
+    /* :246-260 fold equal nodes into the first occurrence, then retain */
+    int64_t w = 0;
+    for (int64_t i = 0; i < beam->len; ++i) {
+        if (w > 0 && beam->v[w - 1].node == beam->v[i].node) {
+            beam->v[w - 1].label_prob += beam->v[i].label_prob;
+            beam->v[w - 1].gap_prob += beam->v[i].gap_prob;
+        } else {
+            beam->v[w++] = beam->v[i];
+        }
+    }
+    beam->len = w;
+    /* :261-272 every element of a >= 2 element slice takes part in >= 1 partial_cmp, so any
+     * NaN probability sets has_nans */
+    if (beam->len >= 2) {
+        for (int64_t i = 0; i < beam->len; ++i) {
+            float p = sp1_prob(&beam->v[i]);
+            if (p != p) return FCDO_INCOMPARABLE;
+        }
+    }
+    sp1_sort_prob(beam->v, beam->len, tmp, tmpcap);
+    if (beam->len > beam_size) beam->len = beam_size; /* :273 */
+    if (beam->len == 0) return FCDO_RAN_OUT_OF_BEAM;  /* :274-277 */
+    float top = sp1_prob(&beam->v[0]);                /* :278-282 */
+    for (int64_t i = 0; i < beam->len; ++i) {
+        beam->v[i].label_prob /= top;
+        beam->v[i].gap_prob /= top;
+    }
+    return FCDO_OK;
+}
+
+/* :285-300: walk leaf -> root, then reverse */
+static int64_t tree_walk_1d(const fcdo_tree *tree, int32_t node, int32_t *labels, int64_t *path) {
+    int64_t n = 0;
+    for (int32_t cur = node; cur >= 0; cur = tree->parent[cur]) {
+        labels[n] = tree->label[cur] + 1;
+        if (path) path[n] = tree->data[cur];
+        n++;
+    }
+    for (int64_t i = 0; i < n / 2; ++i) {
+        int32_t tl = labels[i];
+        labels[i] = labels[n - 1 - i];
+        labels[n - 1 - i] = tl;
+        if (path) {
+            int64_t tp = path[i];
+            path[i] = path[n - 1 - i];
+            path[n - 1 - i] = tp;
+        }
+    }
+    return n;
+}
+
+int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                     int64_t beam_size, float thr, int collapse_repeats,
+                     int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out) {
+    int64_t alphabet_size = N - 1; /* :167 */
+    fcdo_tree *tree = fcdo_tree_new(alphabet_size);
+    sp1vec beam = {0}, next = {0};
+    sp1 *tmp = NULL;
+    int64_t tmpcap = 0;
+    int status = FCDO_OK;
+    sp1 root = {-1, 0, 0.0f, 1.0f}; /* :170-175 */
+    sp1_push(&beam, root);
+
+    for (int64_t idx = 0; idx < T; ++idx) { /* :178 */
+        const float *pr = x + idx * rs;
+        next.len = 0;
+        float pr0 = pr[0];
+        for (int64_t bi = 0; bi < beam.len; ++bi) {
+            sp1 b = beam.v[bi];
+            int64_t tip_label = fcdo_tree_label(tree, b.node); /* :187 */
+            if (pr0 > thr) {                                   /* :191-198 */
+                sp1 c = {b.node, b.state, 0.0f, (b.label_prob + b.gap_prob) * pr0};
+                sp1_push(&next, c);
+            }
+            for (int64_t label = 0; label < alphabet_size; ++label) { /* :200 */
+                float pr_b = pr[(label + 1) * cs];
+                if (pr_b < thr) continue; /* :201 */
+                if (collapse_repeats && label == tip_label) { /* :205 */
+                    sp1 stay = {b.node, b.state, b.label_prob * pr_b, 0.0f};
+                    sp1_push(&next, stay);
+                    int32_t child = fcdo_tree_get_child(tree, b.node, label);
+                    if (child < 0 && b.gap_prob > 0.0f) /* :212-218 */
+                        child = fcdo_tree_add_node(tree, b.node, label, idx);
+                    if (child >= 0) { /* :220-227 */
+                        sp1 c = {child, b.state, b.gap_prob * pr_b, 0.0f};
+                        sp1_push(&next, c);
+                    }
+                } else { /* :228-239 */
+                    int32_t child = fcdo_tree_get_child(tree, b.node, label);
+                    if (child < 0) child = fcdo_tree_add_node(tree, b.node, label, idx);
+                    sp1 c = {child, b.state, (b.label_prob + b.gap_prob) * pr_b, 0.0f};
+                    sp1_push(&next, c);
+                }
+            }
+        }
+        sp1vec t = beam; /* :242 swap */
+        beam = next;
+        next = t;
+        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap);
+        if (status != FCDO_OK) break;
+    }
+
+    if (status == FCDO_OK) *n_out = tree_walk_1d(tree, beam.v[0].node, labels, path);
+    if (n_nodes_out) *n_nodes_out = tree->len;
+    free(beam.v);
+    free(next.v);
+    free(tmp);
+    fcdo_tree_free(tree);
+    return status;
+}
+
+/* ndarray-stats QuantileExt::argmax / max (Cargo.toml:12): first maximum wins, NaN -> Err ->
+ * unwrap() -> panic (src/search.rs:56,58) */
+static int argmax_strided(const float *v, int64_t n, int64_t s, int64_t *arg, float *mx) {
+    if (n <= 0) return FCDO_PANIC;
+    int64_t a = 0;
+    float m = v[0];
+    if (m != m) return FCDO_PANIC;
+    for (int64_t i = 1; i < n; ++i) {
+        float e = v[i * s];
+        if (e != e) return FCDO_PANIC;
+        if (e > m) {
+            m = e;
+            a = i;
+        }
+    }
+    *arg = a;
+    *mx = m;
+    return FCDO_OK;
+}
+
+int fcdo_crf_beam_search(const float *x, int64_t T, int64_t S, int64_t N,
+                         int64_t s0, int64_t s1, int64_t s2,
+                         const float *init, int64_t n_init, int64_t is0,
+                         int64_t beam_size, float thr,
+                         int32_t *labels, int64_t *path, int64_t *n_out) {
+    if (T <= 0 || S <= 0 || N <= 0) return FCDO_PANIC; /* :46 */
+    int64_t n_state = S, n_base = N - 1;               /* :50-51 */
+    int64_t st0;
+    float mx;
+    if (argmax_strided(init, n_init, is0, &st0, &mx) != FCDO_OK) return FCDO_PANIC;
+    fcdo_tree *tree = fcdo_tree_new(n_base);
+    sp1vec beam = {0}, next = {0};
+    sp1 *tmp = NULL;
+    int64_t tmpcap = 0;
+    int status = FCDO_OK;
+    sp1 root = {-1, st0, mx, init[0]}; /* :54-59 */
+    sp1_push(&beam, root);
+
+    for (int64_t idx = 0; idx < T && status == FCDO_OK; ++idx) { /* :62 */
+        next.len = 0;
+        for (int64_t bi = 0; bi < beam.len; ++bi) {
+            sp1 b = beam.v[bi];
+            if (b.state < 0 || b.state >= n_state) { /* ndarray OOB panic :72 */
+                status = FCDO_PANIC;
+                break;
+            }
+            const float *pr = x + idx * s0 + b.state * s1;
+            if (pr[0] > thr) { /* :75-82 */
+                sp1 c = {b.node, b.state, 0.0f, (b.label_prob + b.gap_prob) * pr[0]};
+                sp1_push(&next, c);
+            }
+            for (int64_t label = 0; label < n_base; ++label) { /* :84 */
+                float pr_b = pr[(label + 1) * s2];
+                if (pr_b < thr) continue;
+                int32_t child = fcdo_tree_get_child(tree, b.node, label);
+                if (child < 0) child = fcdo_tree_add_node(tree, b.node, label, idx);
+                sp1 c = {child, (b.state * n_base) % n_state + label, /* :97 */
+                         (b.label_prob + b.gap_prob) * pr_b, 0.0f};
+                sp1_push(&next, c);
+            }
+        }
+        if (status != FCDO_OK) break;
+        sp1vec t = beam;
+        beam = next;
+        next = t;
+        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap); /* :104-142 */
+    }
+    if (status == FCDO_OK) *n_out = tree_walk_1d(tree, beam.v[0].node, labels, path);
+    free(beam.v);
+    free(next.v);
+    free(tmp);
+    fcdo_tree_free(tree);
+    return status;
+}
+
+/* src/search.rs:385-423 */
+int fcdo_crf_greedy_search(const float *x, int64_t T, int64_t S, int64_t N,
+                           int64_t s0, int64_t s1, int64_t s2,
+                           const float *init, int64_t n_init, int64_t is0,
+                           float qscale, float qbias,
+                           int32_t *labels, int64_t *path, uint32_t *quals, int64_t *n_out) {
+    if (T <= 0 || S <= 0 || N <= 0) return FCDO_PANIC;
+    int64_t n_state = S, n_base = N - 1;
+    int64_t state;
+    float mx;
+    if (argmax_strided(init, n_init, is0, &state, &mx) != FCDO_OK) return FCDO_PANIC;
+    int64_t n = 0;
+    for (int64_t idx = 0; idx < T; ++idx) {
+        if (state < 0 || state >= n_state) return FCDO_PANIC;
+        const float *pr = x + idx * s0 + state * s1;
+        int64_t label;
+        float prob;
+        if (argmax_strided(pr, N, s2, &label, &prob) != FCDO_OK) return FCDO_PANIC;
+        if (label > 0) {
+            path[n] = idx;
+            labels[n] = (int32_t)label;
+            if (quals) quals[n] = phred_code(prob, qscale, qbias);
+            n++;
+            state = (state * n_base) % n_state + (label - 1); /* :415 */
+        }
+    }
+    *n_out = n;
+    return FCDO_OK;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Duplex (2D) search: src/duplex.rs
+ * ---------------------------------------------------------------------------------------- */
+static const float NEG_INF = -INFINITY;
+
+/* LogSpace::add, src/duplex.rs:42-63.  mode MAX reproduces the `fastexp` default feature,
+ * whose exp() returns 0.0 for every input on little-endian targets (src/fastexp.rs:33-58:
+ * the f32 view of the i64 union reads the low 32 bits of `i << 52`), so
+ * big + ln_1p(0.0) == big. */
+float fcdo_logspace_add(float a, float b, int mode) {
+    float big, small;
+    if (a <= b) {
+        big = b;
+        small = a;
+    } else {
+        big = a;
+        small = b;
+    }
+    if (small == NEG_INF) return big;
+    if (mode == FCDO_LOGADD_MAX) return big + 0.0f; /* big + ln_1p(+-0.0) */
+    return big + log1pf(expf(small - big));
+}
+#define LADD(a, b) fcdo_logspace_add((a), (b), mode)
+static inline float lmax(float self, float other) { return (self < other) ? other : self; } /* :33-39 */
+
+typedef struct {
+    float label, gap;
+} ppair; /* ProbPair :82-126 */
+
+static const ppair PP_ZERO = {-INFINITY, -INFINITY};
+
+typedef struct { /* SecondaryProbs :152-210 */
+    int64_t offset;
+    ppair *probs;
+    int64_t len, cap;
+    float max_prob;
+} secprobs;
+
+static void sec_push(secprobs *s, ppair p) {
+    if (s->len == s->cap) {
+        s->cap = s->cap ? s->cap * 2 : 16;
+        s->probs = (ppair *)realloc(s->probs, sizeof(ppair) * s->cap);
+    }
+    s->probs[s->len++] = p;
+}
+
+static ppair sec_get(const secprobs *s, int64_t at) { /* :167-179 */
+    int64_t index = at - s->offset;
+    if (index < 0 || index >= s->len) return PP_ZERO;
+    return s->probs[index];
+}
+
+static void sec_discard_until(secprobs *s, int64_t keep_from) { /* :181-191 */
+    if (keep_from > s->offset) {
+        int64_t first = keep_from - s->offset;
+        if (first < s->len) {
+            memmove(s->probs, s->probs + first, sizeof(ppair) * (s->len - first));
+            s->len -= first;
+        } else {
+            s->len = 0;
+        }
+        s->offset = keep_from;
+    }
+}
+
+static int64_t clampi(int64_t v, int64_t lo, int64_t hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+static float pairs_update_max(const ppair *probs, int64_t len, int64_t offset, int64_t lower,
+                              int64_t upper, int mode) { /* :193-204 */
+    /* (lower - offset) can overflow for the isize::MIN/MAX KAT; do it in saturating form */
+    int64_t begin, end;
+    if (lower <= offset) begin = 0;
+    else begin = clampi(lower - offset, 0, len);
+    if (upper <= offset) end = begin;
+    else {
+        /* upper - offset may overflow when offset < 0 and upper == INT64_MAX */
+        int64_t d = (offset < 0 && upper > INT64_MAX + offset) ? INT64_MAX : upper - offset;
+        end = clampi(d, begin, len);
+    }
+    float m = NEG_INF;
+    for (int64_t i = begin; i < end; ++i) m = lmax(m, LADD(probs[i].label, probs[i].gap));
+    return m;
+}
+
+/* white-box hooks for KAT K18 */
+void fcdo_secondary_get(const float *pairs, int64_t len, int64_t offset, int64_t at,
+                        float *label_out, float *gap_out) {
+    secprobs s = {offset, (ppair *)pairs, len, len, NEG_INF};
+    ppair p = sec_get(&s, at);
+    *label_out = p.label;
+    *gap_out = p.gap;
+}
+float fcdo_secondary_update_max(const float *pairs, int64_t len, int64_t offset, int64_t lower,
+                                int64_t upper, int mode) {
+    return pairs_update_max((const ppair *)pairs, len, offset, lower, upper, mode);
+}
+
+typedef struct {
+    const float *x; /* log-space copy, C-contiguous */
+    int64_t T, S, N;
+} lognet;
+
+static inline const float *lognet_row(const lognet *n, int64_t t, int64_t state) {
+    return n->x + (t * n->S + state) * n->N;
+}
+
+/* One recurrence step shared by build/extend (:233-246, :373-385 and crf :275-287,:320-334). */
+static inline ppair sec_step(const float *row, ppair last, ppair prev_parent, int64_t label,
+                             int is_repeat, int mode) {
+    ppair r;
+    r.gap = LADD(last.label, last.gap) + row[0];
+    if (is_repeat)
+        r.label = row[label + 1] + LADD(last.label, prev_parent.gap);
+    else
+        r.label = row[label + 1] + LADD(last.label, LADD(prev_parent.label, prev_parent.gap));
+    return r;
+}
+
+/* build_secondary_probs :212-249 / crf_build_secondary_probs :251-291 (is_repeat = 0) */
+static secprobs sec_build(const lognet *n2, const secprobs *parent, int64_t label, int is_repeat,
+                          int64_t tstate, int64_t lower, int64_t upper, int mode) {
+    secprobs s = {lower, NULL, 0, 0, NEG_INF};
+    s.cap = upper - lower;
+    s.probs = (ppair *)malloc(sizeof(ppair) * (s.cap > 0 ? s.cap : 1));
+    ppair last = PP_ZERO;
+    for (int64_t idx = lower; idx < upper; ++idx) {
+        last = sec_step(lognet_row(n2, idx, tstate), last, sec_get(parent, idx - 1), label,
+                        is_repeat, mode);
+        sec_push(&s, last);
+        s.max_prob = lmax(s.max_prob, LADD(last.label, last.gap));
+    }
+    return s;
+}
+
+/* extend_secondary_probs :338-387 / crf_extend_secondary_probs :293-336 */
+static void sec_extend(secprobs *s, const lognet *n2, const secprobs *parent, int64_t label,
+                       int is_repeat, int64_t tstate, int64_t lower, int64_t upper, int mode) {
+    if (lower > s->offset) { /* :351-359 */
+        sec_discard_until(s, lower - 1);
+        if (s->len == 0) s->offset = lower;
+        s->max_prob = pairs_update_max(s->probs, s->len, s->offset, lower, upper, mode);
+    }
+    int64_t current_end = s->offset + s->len;
+    ppair last = s->len > 0 ? s->probs[s->len - 1] : PP_ZERO;
+    for (int64_t idx = current_end; idx < upper; ++idx) {
+        last = sec_step(lognet_row(n2, idx, tstate), last, sec_get(parent, idx - 1), label,
+                        is_repeat, mode);
+        sec_push(s, last);
+        s->max_prob = lmax(s->max_prob, LADD(last.label, last.gap));
+    }
+}
+
+typedef struct { /* duplex SearchPoint :128-150 */
+    int32_t node;
+    int64_t state;
+    ppair prob_1;
+    float prob_2_max;
+} sp2;
+
+typedef struct {
+    sp2 *v;
+    int64_t len, cap;
+} sp2vec;
+
+static void sp2_push(sp2vec *b, sp2 p) {
+    if (b->len == b->cap) {
+        b->cap = b->cap ? b->cap * 2 : 64;
+        b->v = (sp2 *)realloc(b->v, sizeof(sp2) * b->cap);
+    }
+    b->v[b->len++] = p;
+}
+
+typedef struct {
+    sp2 p;
+    float prob; /* cached probability() for the final sort */
+} sp2k;
+
+#define SP2_NODE_LESS(a, b) ((a)->node < (b)->node)
+#define SP2K_PROB_GREATER(a, b) ((a)->prob > (b)->prob)
+DEFINE_STABLE_SORT(sp2_sort_node, sp2, SP2_NODE_LESS)
+DEFINE_STABLE_SORT(sp2k_sort_prob, sp2k, SP2K_PROB_GREATER)
+
+typedef struct {
+    secprobs *v;
+    int64_t len, cap;
+} secvec;
+
+static void secvec_push(secvec *d, secprobs s) {
+    if (d->len == d->cap) {
+        d->cap = d->cap ? d->cap * 2 : 256;
+        d->v = (secprobs *)realloc(d->v, sizeof(secprobs) * d->cap);
+    }
+    d->v[d->len++] = s;
+}
+
+static float *to_logspace(const float *x, int64_t T, int64_t S, int64_t N, int64_t s0, int64_t s1,
+                          int64_t s2) { /* LogSpace::new = ln :24-26, :452-453 */
+    float *o = (float *)malloc(sizeof(float) * (size_t)(T * S * N > 0 ? T * S * N : 1));
+    for (int64_t t = 0; t < T; ++t)
+        for (int64_t s = 0; s < S; ++s)
+            for (int64_t j = 0; j < N; ++j)
+                o[(t * S + s) * N + j] = logf(x[t * s0 + s * s1 + j * s2]);
+    return o;
+}
+
+/*
+ * Common driver for duplex::beam_search (:443-650, crf = 0) and duplex::crf_beam_search
+ * (:652-834, crf = 1).
+ */
+static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init_state_1,
+                       int64_t init_state_2, const uint64_t *envelope, int64_t e0, int64_t e1,
+                       int64_t beam_size, float thr_real, int collapse_repeats, int mode,
+                       int32_t *labels, int64_t *n_out) {
+    const int64_t N = n1->N, n_base = N - 1, n_state = n1->S;
+    const float thr = logf(thr_real); /* :454 */
+    int status = FCDO_OK;
+    if (n1->T <= 0) return FCDO_PANIC; /* envelope[(0,1)] out of bounds :477 */
+
+    fcdo_tree *tree = fcdo_tree_new(n_base);
+    secvec data = {0}; /* node payloads, index == node index */
+    sp2vec beam = {0}, next = {0};
+    sp2 *tmp = NULL;
+    int64_t tmpcap = 0;
+    sp2k *keyed = NULL, *ktmp = NULL;
+    int64_t keyedcap = 0, ktmpcap = 0;
+
+    sp2 root = {-1, init_state_1, {NEG_INF, 0.0f}, 0.0f}; /* :464-473 */
+    sp2_push(&beam, root);
+
+    /* root_probs :389-409 / crf_root_probs :411-441 */
+    secprobs rootp = {-1, NULL, 0, 0, 0.0f};
+    {
+        uint64_t ub = envelope[0 * e0 + 1 * e1];
+        if (ub > (uint64_t)n2->T) { /* slice(s![..upper_bound]) panics */
+            status = FCDO_PANIC;
+            goto done;
+        }
+        float cur = 0.0f;
+        ppair p = {NEG_INF, cur};
+        sec_push(&rootp, p);
+        int64_t state = init_state_2;
+        for (uint64_t t = 0; t < ub; ++t) {
+            if (state < 0 || state >= n2->S) {
+                status = FCDO_PANIC;
+                goto done;
+            }
+            cur = cur + lognet_row(n2, (int64_t)t, state)[0];
+            ppair q = {NEG_INF, cur};
+            sec_push(&rootp, q);
+            if (crf) state = (state * n_base) % n_state; /* :437 */
+        }
+    }
+
+    int64_t last_upper = 0; /* :480 */
+    for (int64_t t1 = 0; t1 < n1->T; ++t1) {
+        next.len = 0;
+        uint64_t lo_u = envelope[t1 * e0], hi_u = envelope[t1 * e0 + e1];
+        int64_t upper_t = hi_u > (uint64_t)n2->T ? n2->T : (int64_t)hi_u; /* :485 */
+        if (lo_u >= (uint64_t)upper_t || lo_u > (uint64_t)last_upper) {   /* :486-488 */
+            status = FCDO_INVALID_ENVELOPE;
+            break;
+        }
+        int64_t lower_t = (int64_t)lo_u;
+
+        if (upper_t > last_upper) { /* :490-522 */
+            sp2_sort_node(beam.v, beam.len, &tmp, &tmpcap); /* parents before children :493 */
+            for (int64_t bi = 0; bi < beam.len; ++bi) {
+                int32_t node = beam.v[bi].node;
+                if (node < 0) continue;
+                int32_t par = tree->parent[node];
+                int64_t lab = tree->label[node];
+                const secprobs *pp = par >= 0 ? &data.v[par] : &rootp;
+                int is_repeat = 0;
+                int64_t tstate = 0;
+                if (crf) {
+                    tstate = beam.v[bi].state; /* :708,:725-728 */
+                    if (tstate < 0 || tstate >= n2->S) {
+                        status = FCDO_PANIC;
+                        break;
+                    }
+                } else {
+                    is_repeat = (par >= 0 && tree->label[par] == lab); /* :512 */
+                }
+                sec_extend(&data.v[node], n2, pp, lab, is_repeat, tstate, lower_t, upper_t, mode);
+            }
+            if (status != FCDO_OK) break;
+        }
+        last_upper = upper_t; /* :524 */
+
+        for (int64_t bi = 0; bi < beam.len && status == FCDO_OK; ++bi) { /* :526 */
+            sp2 tip = beam.v[bi];
+            int64_t tip_label = fcdo_tree_label(tree, tip.node);
+            const float *row;
+            if (crf) {
+                if (tip.state < 0 || tip.state >= n1->S) {
+                    status = FCDO_PANIC;
+                    break;
+                }
+                row = lognet_row(n1, t1, tip.state); /* :749 */
+            } else {
+                row = lognet_row(n1, t1, 0);
+            }
+            float tip_total = LADD(tip.prob_1.label, tip.prob_1.gap);
+            if (row[0] > thr) { /* :529-534 */
+                sp2 c = tip;
+                c.prob_1.label = NEG_INF;
+                c.prob_1.gap = tip_total + row[0];
+                sp2_push(&next, c);
+            }
+            for (int64_t label = 0; label < n_base; ++label) { /* :536 */
+                float prob = row[label + 1];
+                if (prob < thr) continue;
+                const secprobs *pp = tip.node >= 0 ? &data.v[tip.node] : &rootp;
+                if (!crf && collapse_repeats && label == tip_label) { /* :540-570 */
+                    sp2 stay = tip;
+                    stay.prob_1.label = tip.prob_1.label + prob;
+                    stay.prob_1.gap = NEG_INF;
+                    sp2_push(&next, stay);
+                    int32_t child = fcdo_tree_get_child(tree, tip.node, label);
+                    if (child < 0 && tip.prob_1.gap > NEG_INF) { /* :546 */
+                        secprobs s = sec_build(n2, pp, label, 1, 0, lower_t, upper_t, mode);
+                        child = fcdo_tree_add_node(tree, tip.node, label, 0);
+                        secvec_push(&data, s);
+                    }
+                    if (child >= 0) {
+                        sp2 c = tip;
+                        c.node = child;
+                        c.prob_1.label = tip.prob_1.gap + prob;
+                        c.prob_1.gap = NEG_INF;
+                        sp2_push(&next, c);
+                    }
+                } else { /* :571-592 / crf :764-786 */
+                    int32_t child = fcdo_tree_get_child(tree, tip.node, label);
+                    if (child < 0) {
+                        int64_t tstate = 0;
+                        if (crf) {
+                            tstate = tip.state; /* :772 */
+                            if (tstate >= n2->S) {
+                                status = FCDO_PANIC;
+                                break;
+                            }
+                        }
+                        secprobs s = sec_build(n2, pp, label, 0, tstate, lower_t, upper_t, mode);
+                        child = fcdo_tree_add_node(tree, tip.node, label, 0);
+                        secvec_push(&data, s);
+                        pp = tip.node >= 0 ? &data.v[tip.node] : &rootp; /* data.v may move */
+                    }
+                    sp2 c = tip;
+                    c.node = child;
+                    if (crf) c.state = (tip.state * n_base) % n_state + label; /* :782 */
+                    c.prob_1.label = tip_total + prob;
+                    c.prob_1.gap = NEG_INF;
+                    sp2_push(&next, c);
+                }
+            }
+        }
+        if (status != FCDO_OK) break;
+
+        sp2vec sw = beam; /* :595 */
+        beam = next;
+        next = sw;
+
+        sp2_sort_node(beam.v, beam.len, &tmp, &tmpcap); /* :598 */
+        int64_t w = 0;
+        for (int64_t i = 0; i < beam.len; ++i) { /* :599-612 */
+            if (w > 0 && beam.v[w - 1].node == beam.v[i].node) {
+                beam.v[w - 1].prob_1.label = LADD(beam.v[w - 1].prob_1.label, beam.v[i].prob_1.label);
+                beam.v[w - 1].prob_1.gap = LADD(beam.v[w - 1].prob_1.gap, beam.v[i].prob_1.gap);
+            } else {
+                beam.v[w++] = beam.v[i];
+            }
+        }
+        beam.len = w;
+        if (keyedcap < beam.len) {
+            keyedcap = beam.len * 2;
+            keyed = (sp2k *)realloc(keyed, sizeof(sp2k) * keyedcap);
+        }
+        int has_nan = 0;
+        for (int64_t i = 0; i < beam.len; ++i) { /* :613-618 */
+            if (beam.v[i].node >= 0) beam.v[i].prob_2_max = data.v[beam.v[i].node].max_prob;
+            keyed[i].p = beam.v[i];
+            keyed[i].prob = LADD(beam.v[i].prob_1.label, beam.v[i].prob_1.gap) + beam.v[i].prob_2_max;
+            if (keyed[i].prob != keyed[i].prob) has_nan = 1;
+        }
+        if (beam.len >= 2 && has_nan) { /* :619-631 */
+            status = FCDO_INCOMPARABLE;
+            break;
+        }
+        sp2k_sort_prob(keyed, beam.len, &ktmp, &ktmpcap);
+        if (beam.len > beam_size) beam.len = beam_size; /* :632 */
+        if (beam.len == 0) {                            /* :633-636 */
+            status = FCDO_RAN_OUT_OF_BEAM;
+            break;
+        }
+        for (int64_t i = 0; i < beam.len; ++i) beam.v[i] = keyed[i].p;
+    }
+
+    if (status == FCDO_OK) *n_out = tree_walk_1d(tree, beam.v[0].node, labels, NULL); /* :638-649 */
+
+done:
+    for (int64_t i = 0; i < data.len; ++i) free(data.v[i].probs);
+    free(data.v);
+    free(rootp.probs);
+    free(beam.v);
+    free(next.v);
+    free(tmp);
+    free(keyed);
+    free(ktmp);
+    fcdo_tree_free(tree);
+    return status;
+}
+
+int fcdo_beam_search_duplex(const float *x1, int64_t T1, int64_t rs1, int64_t cs1,
+                            const float *x2, int64_t T2, int64_t rs2, int64_t cs2,
+                            int64_t N, const uint64_t *envelope, int64_t e0, int64_t e1,
+                            int64_t beam_size, float thr, int collapse_repeats,
+                            int logadd_mode, int32_t *labels, int64_t *n_out) {
+    float *l1 = to_logspace(x1, T1, 1, N, rs1, 0, cs1);
+    float *l2 = to_logspace(x2, T2, 1, N, rs2, 0, cs2);
+    lognet n1 = {l1, T1, 1, N}, n2 = {l2, T2, 1, N};
+    int st = duplex_core(&n1, &n2, 0, 0, 0, envelope, e0, e1, beam_size, thr, collapse_repeats,
+                         logadd_mode, labels, n_out);
+    free(l1);
+    free(l2);
+    return st;
+}
+
+int fcdo_crf_beam_search_duplex(const float *x1, int64_t T1, const int64_t *st1,
+                                const float *init1, int64_t n_init1, int64_t i1s,
+                                const float *x2, int64_t T2, const int64_t *st2,
+                                const float *init2, int64_t n_init2, int64_t i2s,
+                                int64_t S, int64_t N,
+                                const uint64_t *envelope, int64_t e0, int64_t e1,
+                                int64_t beam_size, float thr,
+                                int logadd_mode, int32_t *labels, int64_t *n_out) {
+    int64_t a1, a2;
+    float m;
+    if (argmax_strided(init1, n_init1, i1s, &a1, &m) != FCDO_OK) return FCDO_PANIC; /* :679 */
+    if (argmax_strided(init2, n_init2, i2s, &a2, &m) != FCDO_OK) return FCDO_PANIC; /* :691 */
+    float *l1 = to_logspace(x1, T1, S, N, st1[0], st1[1], st1[2]);
+    float *l2 = to_logspace(x2, T2, S, N, st2[0], st2[1], st2[2]);
+    lognet n1 = {l1, T1, S, N}, n2 = {l2, T2, S, N};
+    int st = duplex_core(&n1, &n2, 1, a1, a2, envelope, e0, e1, beam_size, thr, 0, logadd_mode,
+                         labels, n_out);
+    free(l1);
+    free(l2);
+    return st;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Batch drivers (CPU baseline + differential tests).  One read per task, pthreads.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct {
+    const float *x;
+    int64_t n_reads, T, N, beam_size;
+    float thr;
+    int collapse, kind; /* kind 0 = beam, 1 = viterbi */
+    int32_t *labels;
+    int64_t *path, *lens;
+    int32_t *status;
+    volatile int64_t *next;
+} batch_job;
+
+static void *batch_worker(void *arg) {
+    batch_job *j = (batch_job *)arg;
+    for (;;) {
+        int64_t r = __sync_fetch_and_add(j->next, 1);
+        if (r >= j->n_reads) break;
+        const float *x = j->x + r * j->T * j->N;
+        int64_t n = 0;
+        int st;
+        if (j->kind == 0)
+            st = fcdo_beam_search(x, j->T, j->N, j->N, 1, j->beam_size, j->thr, j->collapse,
+                                  j->labels + r * j->T, j->path + r * j->T, &n, NULL);
+        else
+            st = fcdo_viterbi_search(x, j->T, j->N, j->N, 1, j->collapse, 1.0f, 0.0f,
+                                     j->labels + r * j->T, j->path + r * j->T, NULL, &n);
+        j->lens[r] = (st == FCDO_OK) ? n : 0;
+        if (j->status) j->status[r] = st;
+    }
+    return NULL;
+}
+
+static int run_batch(batch_job *job, int n_threads) {
+    volatile int64_t next = 0;
+    job->next = &next;
+    if (n_threads <= 1) {
+        batch_worker(job);
+        return 0;
+    }
+    pthread_t *th = (pthread_t *)malloc(sizeof(pthread_t) * n_threads);
+    for (int i = 0; i < n_threads; ++i) pthread_create(&th[i], NULL, batch_worker, job);
+    for (int i = 0; i < n_threads; ++i) pthread_join(th[i], NULL);
+    free(th);
+    return 0;
+}
+
+int fcdo_beam_search_batch(const float *x, int64_t n_reads, int64_t T, int64_t N,
+                           int64_t beam_size, float thr, int collapse,
+                           int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
+                           int n_threads) {
+    batch_job job = {x, n_reads, T, N, beam_size, thr, collapse, 0, labels, path, lens, status, NULL};
+    return run_batch(&job, n_threads);
+}
+
+int fcdo_viterbi_batch(const float *x, int64_t n_reads, int64_t T, int64_t N, int collapse,
+                       int32_t *labels, int64_t *path, int64_t *lens, int n_threads) {
+    batch_job job = {x, n_reads, T, N, 0, 0.0f, collapse, 1, labels, path, lens, NULL, NULL};
+    return run_batch(&job, n_threads);
+}
