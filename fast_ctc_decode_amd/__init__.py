@@ -1,0 +1,26 @@
+"""fast_ctc_decode_amd -- MI355X-native (gfx950 / CDNA4) batched CTC decoding behind
+fast_ctc_decode's Python API.
+
+    from fast_ctc_decode_amd import beam_search, viterbi_search          # drop-in, one read
+    from fast_ctc_decode_amd import beam_search_batch, viterbi_search_batch  # many reads per launch
+
+All searching runs in hand-written HIP kernels reached through the C ABI in include/fcd.h;
+importing this package never touches a CPU fallback (there is none).
+"""
+from .api import (  # noqa: F401
+    BatchResult,
+    __version__,
+    beam_search,
+    beam_search_batch,
+    beam_search_batch_raw,
+    beam_search_duplex,
+    crf_beam_search,
+    crf_beam_search_batch,
+    crf_beam_search_batch_raw,
+    crf_beam_search_duplex,
+    crf_greedy_search,
+    viterbi_search,
+    viterbi_search_batch,
+    viterbi_search_batch_raw,
+)
+from ._native import KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE  # noqa: F401

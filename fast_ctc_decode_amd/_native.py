@@ -1,0 +1,166 @@
+"""ctypes binding of the C ABI (include/fcd.h) exported by libfcd_hip.so.
+
+There is NO CPU fallback: if the library is missing it is built with hipcc (cross-compiles
+without a GPU); if it cannot be loaded, or no gfx950 device is visible when a search is
+requested, the call fails loudly.
+"""
+import ctypes as C
+import os
+import threading
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libfcd_hip.so")
+
+OK = 0
+E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
+ST_OK, ST_RAN_OUT_OF_BEAM, ST_INCOMPARABLE, ST_INVALID_ENVELOPE, ST_BAD_STATE, ST_INTERNAL = range(6)
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE = 0, 1, 2
+LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
+
+# every symbol include/fcd.h declares (tests/test_capi_symbols.py checks the .so against this
+# list AND against the header text)
+SYMBOLS = [
+    "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream",
+    "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit",
+    "fcd_last_kernel_ms",
+    "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
+    "fcd_beam_search_dev", "fcd_beam_search_host",
+    "fcd_crf_beam_search_dev", "fcd_crf_beam_search_host",
+    "fcd_crf_greedy_search_dev", "fcd_crf_greedy_search_host",
+    "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
+    "fcd_phred",
+]
+
+
+class Batch(C.Structure):
+    _fields_ = [
+        ("post", C.c_void_p), ("n_reads", C.c_int64), ("T", C.c_int64), ("S", C.c_int64),
+        ("N", C.c_int64), ("stride_read", C.c_int64), ("stride_t", C.c_int64),
+        ("stride_s", C.c_int64), ("stride_n", C.c_int64), ("lengths", C.c_void_p),
+    ]
+
+
+class Result(C.Structure):
+    _fields_ = [
+        ("labels", C.c_void_p), ("path", C.c_void_p), ("qual", C.c_void_p),
+        ("out_len", C.c_void_p), ("status", C.c_void_p), ("out_stride", C.c_int64),
+    ]
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+_lib = None
+_lib_lock = threading.Lock()
+
+
+def load():
+    """Load (building first if needed) libfcd_hip.so.  Raises if that is impossible."""
+    global _lib
+    with _lib_lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            from . import build as _build
+            _build.build()
+        # PyTorch-ROCm wheels bundle their own HIP runtime (torch/lib/libamdhip64.so, SONAME
+        # libamdhip64.so.7).  Two HIP runtimes in one process cannot both own the GPU, and device
+        # pointers are only meaningful inside the runtime that made them, so when torch is
+        # installed it must be loaded FIRST: our NEEDED libamdhip64.so.7 then binds to torch's.
+        if os.environ.get("FCD_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
+        try:
+            lib = C.CDLL(LIB_PATH)
+        except OSError as e:  # no silent fallback
+            raise NativeError("cannot load %s: %s" % (LIB_PATH, e))
+        P, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+        BP, RP = C.POINTER(Batch), C.POINTER(Result)
+        lib.fcd_version.restype = i32
+        lib.fcd_device_count.restype = i32
+        lib.fcd_create.argtypes = [i32, C.POINTER(P)]
+        lib.fcd_destroy.argtypes = [P]
+        lib.fcd_set_stream.argtypes = [P, P]
+        lib.fcd_synchronize.argtypes = [P]
+        lib.fcd_last_error.argtypes = [P]
+        lib.fcd_last_error.restype = C.c_char_p
+        lib.fcd_status_string.argtypes = [i32]
+        lib.fcd_status_string.restype = C.c_char_p
+        lib.fcd_set_workspace_limit.argtypes = [P, i64]
+        lib.fcd_last_kernel_ms.argtypes = [P]
+        lib.fcd_last_kernel_ms.restype = C.c_double
+        for sfx in ("dev", "host"):
+            getattr(lib, "fcd_viterbi_search_" + sfx).argtypes = [P, BP, i32, RP]
+            getattr(lib, "fcd_beam_search_" + sfx).argtypes = [P, BP, i64, f32, i32, i32, RP]
+            getattr(lib, "fcd_crf_beam_search_" + sfx).argtypes = [P, BP, P, i64, i64, i64, f32, RP]
+            getattr(lib, "fcd_crf_greedy_search_" + sfx).argtypes = [P, BP, P, i64, i64, RP]
+            getattr(lib, "fcd_beam_search_duplex_" + sfx).argtypes = [
+                P, BP, BP, P, i64, i64, f32, i32, i32, RP]
+        lib.fcd_phred.argtypes = [f32, f32, f32]
+        lib.fcd_phred.restype = C.c_uint32
+        _lib = lib
+        return lib
+
+
+class Handle:
+    """Owns one fcd_handle (device binding, stream, workspace)."""
+
+    def __init__(self, device=0):
+        self.lib = load()
+        self.ptr = C.c_void_p()
+        rc = self.lib.fcd_create(int(device), C.byref(self.ptr))
+        if rc != OK:
+            raise NativeError(
+                "fcd_create(device=%d) failed with %d: no usable gfx950 device -- this library has "
+                "no CPU fallback" % (device, rc))
+        self.device = int(device)
+
+    def check(self, rc):
+        if rc != OK:
+            msg = self.lib.fcd_last_error(self.ptr)
+            raise NativeError("libfcd_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+
+    def set_stream(self, stream_ptr):
+        self.check(self.lib.fcd_set_stream(self.ptr, C.c_void_p(stream_ptr or None)))
+
+    def synchronize(self):
+        self.check(self.lib.fcd_synchronize(self.ptr))
+
+    def last_kernel_ms(self):
+        return float(self.lib.fcd_last_kernel_ms(self.ptr))
+
+    def set_workspace_limit(self, nbytes):
+        self.check(self.lib.fcd_set_workspace_limit(self.ptr, int(nbytes)))
+
+    def close(self):
+        if self.ptr:
+            self.lib.fcd_destroy(self.ptr)
+            self.ptr = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+_tls = threading.local()
+
+
+def default_handle(device=0):
+    """One handle per (thread, device): the reference's functions are re-entrant and release the
+    GIL (src/lib.rs:199), so concurrent callers must not share a stream/workspace."""
+    cache = getattr(_tls, "handles", None)
+    if cache is None:
+        cache = _tls.handles = {}
+    h = cache.get(device)
+    if h is None:
+        h = cache[device] = Handle(device)
+    return h
+
+
+def status_string(st):
+    return load().fcd_status_string(int(st)).decode()

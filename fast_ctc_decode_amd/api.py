@@ -1,0 +1,424 @@
+"""Host-side mirror of fast_ctc_decode's Python surface (/root/reference/src/lib.rs:142-628)
+over the HIP C ABI (include/fcd.h).
+
+Single-read functions keep the reference's names, argument order, defaults, validation order,
+exception types and messages, so they are a drop-in.  The `*_batch` functions are additive:
+they decode many reads per launch (numpy -> staged through the C ABI's *_host entry points;
+torch tensors on an AMD GPU -> zero-copy through the *_dev entry points on the tensor's
+current stream).  All searching happens on the GPU: there is no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _native as nat
+
+__version__ = "0.3.7"  # the reference version this surface mirrors (Cargo.toml:3)
+
+
+# ---------------------------------------------------------------------------------------------
+# argument conversion / validation, as the PyO3 wrappers do it
+# ---------------------------------------------------------------------------------------------
+def _seq_to_vec(alphabet):
+    """src/lib.rs:143-146: PySequence -> tuple -> str() of every element."""
+    try:
+        return [str(x) for x in tuple(alphabet)]
+    except TypeError:
+        raise TypeError("alphabet must be a sequence")
+
+
+def _as_f32(a, ndim, name):
+    """PyO3 extracts &PyArrayN<f32>; anything else is a TypeError (no implicit casts)."""
+    if not isinstance(a, np.ndarray):
+        raise TypeError("argument '%s': expected numpy.ndarray, got %s" % (name, type(a).__name__))
+    if a.dtype != np.float32 or a.ndim != ndim:
+        raise TypeError("argument '%s': expected a %d-dimensional float32 array, got %d-dimensional %s"
+                        % (name, ndim, a.ndim, a.dtype))
+    return a
+
+
+def _check_beam_args(n_alpha, inner, beam_size, thr):
+    """src/lib.rs:331-349 -- the order of these checks is part of the behaviour."""
+    if isinstance(beam_size, bool) or not isinstance(beam_size, (int, np.integer)):
+        raise TypeError("argument 'beam_size': expected an integer")
+    if beam_size < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    f32 = np.float32
+    max_beam_cut = f32(1.0) / f32(n_alpha) if n_alpha else f32(np.inf)
+    if n_alpha != inner:
+        raise ValueError("alphabet size %d does not match probability matrix inner dimension %d"
+                         % (n_alpha, inner))
+    if beam_size == 0:
+        raise ValueError("beam_size cannot be 0")
+    if f32(thr) < f32(-0.0):
+        raise ValueError("beam_cut_threshold must be at least 0.0")
+    if f32(thr) >= max_beam_cut:
+        raise ValueError("beam_cut_threshold cannot be more than %s" % max_beam_cut)
+
+
+def _check_greedy_alphabet(n_alpha, inner):
+    """src/lib.rs:190-195,227-232,264-269"""
+    if n_alpha == 0:
+        raise ValueError("Empty alphabet given")
+    if n_alpha != inner:
+        raise ValueError("alphabet size does not match probability matrix dimensions")
+
+
+def _raise_status(st):
+    if st != nat.ST_OK:
+        raise RuntimeError(nat.status_string(st))  # src/lib.rs:363 map_err -> PyRuntimeError
+
+
+def _estrides(a):
+    return [s // a.itemsize for s in a.strides]
+
+
+def _dense(a):
+    """The C ABI's host staging copies one contiguous span; negative strides need a copy."""
+    if any(s < 0 for s in a.strides):
+        return np.ascontiguousarray(a)
+    return a
+
+
+# ---------------------------------------------------------------------------------------------
+# low-level batched calls (host numpy buffers)
+# ---------------------------------------------------------------------------------------------
+class _HostOut:
+    def __init__(self, B, T, want_path=True, want_qual=False):
+        w = max(int(T), 1)
+        self.labels = np.zeros((B, w), np.uint8)
+        self.path = np.zeros((B, w), np.uint32) if want_path else None
+        self.qual = np.zeros((B, w), np.float32) if want_qual else None
+        self.out_len = np.zeros(B, np.uint32)
+        self.status = np.zeros(B, np.int32)
+        self.res = nat.Result(
+            self.labels.ctypes.data, self.path.ctypes.data if want_path else None,
+            self.qual.ctypes.data if want_qual else None, self.out_len.ctypes.data,
+            self.status.ctypes.data, w)
+
+
+def _host_batch(x, crf, lengths=None):
+    """x: (B,T,N) or (B,T,S,N) numpy f32 view -> nat.Batch (keeps x alive via the caller)."""
+    st = _estrides(x)
+    if crf:
+        B, T, S, N = x.shape
+        b = nat.Batch(x.ctypes.data, B, T, S, N, st[0], st[1], st[2], st[3], None)
+    else:
+        B, T, N = x.shape
+        b = nat.Batch(x.ctypes.data, B, T, 1, N, st[0], st[1], 0, st[2], None)
+    if lengths is not None:
+        b.lengths = lengths.ctypes.data
+    return b
+
+
+def _np_lengths(lengths, B):
+    if lengths is None:
+        return None
+    l = np.ascontiguousarray(np.asarray(lengths), np.int64)
+    if l.shape != (B,):
+        raise ValueError("lengths must have shape (n_reads,)")
+    return l
+
+
+# ---------------------------------------------------------------------------------------------
+# drop-in single-read API
+# ---------------------------------------------------------------------------------------------
+def _qual_chars(probs, qscale, qbias):
+    lib = nat.load()
+    return "".join(chr(lib.fcd_phred(float(p), float(qscale), float(qbias))) for p in probs)
+
+
+def viterbi_search(network_output, alphabet, qstring=False, qscale=1.0, qbias=0.0,
+                   collapse_repeats=True):
+    """Greedy (best-path) CTC decode.  Mirrors src/lib.rs:170-212 -> search.rs:320-383.
+
+    Returns (str, list[int]): the sequence (with the quality string appended when `qstring`)
+    and the row index of every emitted label."""
+    x = _as_f32(network_output, 2, "network_output")
+    alpha = _seq_to_vec(alphabet)
+    _check_greedy_alphabet(len(alpha), x.shape[1])
+    if x.shape[0] == 0:
+        raise RuntimeError("network_output is empty (the reference asserts and aborts here)")
+    x = _dense(x)
+    h = nat.default_handle()
+    out = _HostOut(1, x.shape[0], want_qual=bool(qstring))
+    b = _host_batch(x[None], False)
+    h.check(h.lib.fcd_viterbi_search_host(h.ptr, C.byref(b), int(bool(collapse_repeats)),
+                                          C.byref(out.res)))
+    n = int(out.out_len[0])
+    seq = "".join(alpha[l] for l in out.labels[0, :n])
+    if qstring:
+        seq += _qual_chars(out.qual[0, :n], qscale, qbias)
+    return seq, [int(p) for p in out.path[0, :n]]
+
+
+def beam_search(network_output, alphabet, beam_size=5, beam_cut_threshold=0.0,
+                collapse_repeats=True):
+    """CTC prefix beam search.  Mirrors src/lib.rs:318-365 -> search.rs:159-301."""
+    x = _as_f32(network_output, 2, "network_output")
+    alpha = _seq_to_vec(alphabet)
+    _check_beam_args(len(alpha), x.shape[1], beam_size, beam_cut_threshold)
+    x = _dense(x)
+    h = nat.default_handle()
+    out = _HostOut(1, x.shape[0])
+    b = _host_batch(x[None], False)
+    h.check(h.lib.fcd_beam_search_host(h.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
+                                       int(bool(collapse_repeats)), nat.KERNEL_AUTO,
+                                       C.byref(out.res)))
+    _raise_status(int(out.status[0]))
+    n = int(out.out_len[0])
+    return "".join(alpha[l] for l in out.labels[0, :n]), [int(p) for p in out.path[0, :n]]
+
+
+def crf_beam_search(network_output, init_state, alphabet, beam_size=5, beam_cut_threshold=0.0):
+    """Mirrors src/lib.rs:252-286 -> search.rs:38-157 (this wrapper validates only the alphabet)."""
+    x = _as_f32(network_output, 3, "network_output")
+    init = _as_f32(init_state, 1, "init_state")
+    alpha = _seq_to_vec(alphabet)
+    _check_greedy_alphabet(len(alpha), x.shape[2])
+    if x.size == 0 or init.size == 0:
+        raise RuntimeError("network_output/init_state is empty (the reference asserts and aborts here)")
+    if beam_size < 1:
+        raise RuntimeError(nat.status_string(nat.ST_RAN_OUT_OF_BEAM))  # truncate(0) -> empty beam
+    x = _dense(x)
+    init = np.ascontiguousarray(init)
+    h = nat.default_handle()
+    out = _HostOut(1, x.shape[0])
+    b = _host_batch(x[None], True)
+    h.check(h.lib.fcd_crf_beam_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[0],
+                                           init.shape[0], int(beam_size), float(beam_cut_threshold),
+                                           C.byref(out.res)))
+    _raise_status(int(out.status[0]))
+    n = int(out.out_len[0])
+    labels = out.labels[0, :n]
+    # search.rs:146-156: labels are appended leaf->root and the CHARACTERS reversed at the end
+    seq = "".join(alpha[l] for l in labels[::-1])[::-1]
+    return seq, [int(p) for p in out.path[0, :n]]
+
+
+def crf_greedy_search(network_output, init_state, alphabet, qstring=False, qscale=1.0, qbias=0.0):
+    """Mirrors src/lib.rs:214-250 -> search.rs:385-423."""
+    x = _as_f32(network_output, 3, "network_output")
+    init = _as_f32(init_state, 1, "init_state")
+    alpha = _seq_to_vec(alphabet)
+    _check_greedy_alphabet(len(alpha), x.shape[2])
+    if x.size == 0 or init.size == 0:
+        raise RuntimeError("network_output/init_state is empty (the reference asserts and aborts here)")
+    x = _dense(x)
+    init = np.ascontiguousarray(init)
+    h = nat.default_handle()
+    out = _HostOut(1, x.shape[0], want_qual=bool(qstring))
+    b = _host_batch(x[None], True)
+    h.check(h.lib.fcd_crf_greedy_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[0],
+                                             init.shape[0], C.byref(out.res)))
+    _raise_status(int(out.status[0]))
+    n = int(out.out_len[0])
+    seq = "".join(alpha[l] for l in out.labels[0, :n])
+    if qstring:
+        seq += _qual_chars(out.qual[0, :n], qscale, qbias)
+    return seq, [int(p) for p in out.path[0, :n]]
+
+
+def beam_search_duplex(network_output_1, network_output_2, alphabet, envelope=None, beam_size=5,
+                       beam_cut_threshold=0.0, collapse_repeats=True):
+    """Mirrors src/lib.rs:401-488 -> duplex.rs:443-650."""
+    x1 = _as_f32(network_output_1, 2, "network_output_1")
+    x2 = _as_f32(network_output_2, 2, "network_output_2")
+    alpha = _seq_to_vec(alphabet)
+    if x1.shape[1] != x2.shape[1]:
+        raise ValueError("inner axes of the network outputs do not match")
+    _check_beam_args(len(alpha), x1.shape[1], beam_size, beam_cut_threshold)
+    if envelope is not None:
+        if not isinstance(envelope, np.ndarray) or envelope.dtype != np.uint64 or envelope.ndim != 2:
+            raise TypeError("argument 'envelope': expected a 2-dimensional uint64 array")
+        if envelope.shape[0] != x1.shape[0]:
+            raise ValueError("the lengths of network_output_1 and envelope do not match")
+        if envelope.shape[1] != 2:
+            raise ValueError("the inner axis of envelope must have size 2")
+    raise NotImplementedError("beam_search_duplex: the HIP duplex kernel is not built yet")
+
+
+def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, init_state_2,
+                           alphabet, envelope=None, beam_size=5, beam_cut_threshold=0.0):
+    """Mirrors src/lib.rs:490-578 -> duplex.rs:652-834 (outside BASELINE.json's north star)."""
+    raise NotImplementedError("crf_beam_search_duplex is out of scope for this build (SURVEY.md 8f.3)")
+
+
+# ---------------------------------------------------------------------------------------------
+# additive batch API
+# ---------------------------------------------------------------------------------------------
+def _is_torch_cuda(x):
+    return hasattr(x, "data_ptr") and hasattr(x, "is_cuda") and bool(x.is_cuda)
+
+
+class BatchResult:
+    """Raw outcome of a batched search: label indices, paths, lengths and per-read status.
+    Arrays are numpy for host inputs, torch tensors (same device) for device inputs."""
+
+    def __init__(self, labels, path, out_len, status, qual=None):
+        self.labels, self.path, self.out_len, self.status, self.qual = labels, path, out_len, status, qual
+
+    def cpu(self):
+        def c(a):
+            return a if a is None or isinstance(a, np.ndarray) else a.cpu().numpy()
+        return BatchResult(c(self.labels), c(self.path), c(self.out_len), c(self.status), c(self.qual))
+
+    def sequences(self, alphabet, raise_on_error=True):
+        """-> list of (str, list[int]) exactly as the single-read functions would return."""
+        r = self.cpu()
+        alpha = _seq_to_vec(alphabet)
+        table = np.array(alpha, dtype=object)
+        out = []
+        for i in range(len(r.out_len)):
+            st = int(r.status[i]) if r.status is not None else 0
+            if st != nat.ST_OK:
+                if raise_on_error:
+                    raise RuntimeError("read %d: %s" % (i, nat.status_string(st)))
+                out.append(None)
+                continue
+            n = int(r.out_len[i])
+            seq = "".join(table[r.labels[i, :n]]) if n else ""
+            out.append((seq, r.path[i, :n].astype(np.int64).tolist() if r.path is not None else None))
+        return out
+
+
+def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path=True,
+                need_status=True):
+    import torch
+
+    if x.dtype != torch.float32:
+        raise TypeError("device posteriors must be float32")
+    dev = x.device.index or 0
+    h = nat.default_handle(dev)
+    if crf:
+        B, T, S, N = x.shape
+        st = x.stride()
+        b = nat.Batch(x.data_ptr(), B, T, S, N, st[0], st[1], st[2], st[3], None)
+    else:
+        B, T, N = x.shape
+        st = x.stride()
+        b = nat.Batch(x.data_ptr(), B, T, 1, N, st[0], st[1], 0, st[2], None)
+    if lengths is not None:
+        lengths = torch.as_tensor(lengths, dtype=torch.int64, device=x.device).contiguous()
+        b.lengths = lengths.data_ptr()
+    w = max(int(T), 1)
+    labels = torch.empty((B, w), dtype=torch.uint8, device=x.device)
+    path = torch.empty((B, w), dtype=torch.int32, device=x.device) if want_path else None
+    qual = torch.empty((B, w), dtype=torch.float32, device=x.device) if want_qual else None
+    out_len = torch.zeros(B, dtype=torch.int32, device=x.device)
+    status = torch.zeros(B, dtype=torch.int32, device=x.device)
+    res = nat.Result(labels.data_ptr(), path.data_ptr() if want_path else None,
+                     qual.data_ptr() if want_qual else None, out_len.data_ptr(),
+                     status.data_ptr(), w)
+    h.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
+    fn = getattr(h.lib, fn_name)
+    h.check(fn(h.ptr, C.byref(b), *extra_args, C.byref(res)))
+    r = BatchResult(labels, path, out_len, status, qual)
+    r._handle = h
+    r._keep = (x, lengths)
+    return r
+
+
+def _stack_host(x, ndim):
+    if isinstance(x, np.ndarray):
+        a = x
+    else:
+        a = np.stack([np.asarray(v) for v in x])
+    if a.dtype != np.float32 or a.ndim != ndim:
+        raise TypeError("expected a float32 array of rank %d" % ndim)
+    return _dense(a)
+
+
+def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
+                          collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO):
+    """Decode a (B,T,N) batch with search::beam_search semantics; returns a BatchResult."""
+    if _is_torch_cuda(network_outputs):
+        return _torch_call("fcd_beam_search_dev", network_outputs, False, lengths,
+                           (int(beam_size), float(beam_cut_threshold),
+                            int(bool(collapse_repeats)), int(kernel)))
+    x = _stack_host(network_outputs, 3)
+    B, T, N = x.shape
+    h = nat.default_handle()
+    out = _HostOut(B, T)
+    l = _np_lengths(lengths, B)
+    b = _host_batch(x, False, l)
+    h.check(h.lib.fcd_beam_search_host(h.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
+                                       int(bool(collapse_repeats)), int(kernel), C.byref(out.res)))
+    return BatchResult(out.labels, out.path, out.out_len, out.status)
+
+
+def beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold=0.0,
+                      collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO):
+    """Batched beam_search: element i equals beam_search(network_outputs[i][:lengths[i]], ...)."""
+    alpha = _seq_to_vec(alphabet)
+    _check_beam_args(len(alpha), network_outputs.shape[-1], beam_size, beam_cut_threshold)
+    r = beam_search_batch_raw(network_outputs, beam_size, beam_cut_threshold, collapse_repeats,
+                              lengths, kernel)
+    return r.sequences(alpha)
+
+
+def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=None, qual=False):
+    if _is_torch_cuda(network_outputs):
+        return _torch_call("fcd_viterbi_search_dev", network_outputs, False, lengths,
+                           (int(bool(collapse_repeats)),), want_qual=qual)
+    x = _stack_host(network_outputs, 3)
+    B, T, N = x.shape
+    h = nat.default_handle()
+    out = _HostOut(B, T, want_qual=qual)
+    l = _np_lengths(lengths, B)
+    b = _host_batch(x, False, l)
+    h.check(h.lib.fcd_viterbi_search_host(h.ptr, C.byref(b), int(bool(collapse_repeats)),
+                                          C.byref(out.res)))
+    return BatchResult(out.labels, out.path, out.out_len, out.status, out.qual)
+
+
+def viterbi_search_batch(network_outputs, alphabet, qstring=False, qscale=1.0, qbias=0.0,
+                         collapse_repeats=True, lengths=None):
+    alpha = _seq_to_vec(alphabet)
+    _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
+    r = viterbi_search_batch_raw(network_outputs, collapse_repeats, lengths, qual=qstring).cpu()
+    res = r.sequences(alpha)
+    if qstring:
+        res = [(s + _qual_chars(r.qual[i, :len(p)], qscale, qbias), p) for i, (s, p) in enumerate(res)]
+    return res
+
+
+def crf_beam_search_batch_raw(network_outputs, init_states, beam_size=5, beam_cut_threshold=0.0,
+                              lengths=None):
+    """(B,T,S,N) posteriors + (B,n_init) initial state scores -> BatchResult."""
+    if _is_torch_cuda(network_outputs):
+        import torch
+        init = torch.as_tensor(init_states, dtype=torch.float32,
+                               device=network_outputs.device).contiguous()
+        r = _torch_call("fcd_crf_beam_search_dev", network_outputs, True, lengths,
+                        (C.c_void_p(init.data_ptr()), int(init.shape[1]), int(init.shape[1]),
+                         int(beam_size), float(beam_cut_threshold)))
+        r._keep = r._keep + (init,)
+        return r
+    x = _stack_host(network_outputs, 4)
+    init = np.ascontiguousarray(np.asarray(init_states, np.float32))
+    B, T, S, N = x.shape
+    if init.shape[0] != B or init.ndim != 2:
+        raise ValueError("init_states must have shape (n_reads, n_init)")
+    h = nat.default_handle()
+    out = _HostOut(B, T)
+    l = _np_lengths(lengths, B)
+    b = _host_batch(x, True, l)
+    h.check(h.lib.fcd_crf_beam_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[1],
+                                           init.shape[1], int(beam_size), float(beam_cut_threshold),
+                                           C.byref(out.res)))
+    return BatchResult(out.labels, out.path, out.out_len, out.status)
+
+
+def crf_beam_search_batch(network_outputs, init_states, alphabet, beam_size=5,
+                          beam_cut_threshold=0.0, lengths=None):
+    alpha = _seq_to_vec(alphabet)
+    _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
+    r = crf_beam_search_batch_raw(network_outputs, init_states, beam_size, beam_cut_threshold,
+                                  lengths).cpu()
+    out = []
+    for i, item in enumerate(r.sequences(alpha)):
+        n = int(r.out_len[i])
+        labels = r.labels[i, :n]
+        out.append(("".join(alpha[l] for l in labels[::-1])[::-1], item[1]))
+    return out

@@ -1,0 +1,64 @@
+"""Builds libfcd_hip.so (the C-ABI library, include/fcd.h) in-tree with hipcc for gfx950.
+
+    python -m fast_ctc_decode_amd.build [--force]
+
+hipcc cross-compiles without a GPU.  Flags that matter for parity with the reference:
+  -ffp-contract=off                       no FMA contraction: the reference rounds mul and add separately
+  -fhip-fp32-correctly-rounded-divide-sqrt  IEEE f32 division for the per-step renormalisation
+  (no -fgpu-flush-denormals-to-zero)      f32 subnormals are kept, as on the CPU
+"""
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB = os.path.join(HERE, "libfcd_hip.so")
+SOURCES = ["capi.hip", "beam_generic.hip", "beam_wave.hip", "viterbi.hip"]
+HEADERS = ["fcd_internal.h", "device_utils.h", os.path.join("..", "..", "include", "fcd.h")]
+FLAGS = [
+    "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+    "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
+]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    return "hipcc"
+
+
+def needs_build():
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES + HEADERS] + [os.path.abspath(__file__)]
+    return any(os.path.exists(d) and os.path.getmtime(d) > t for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return LIB
+    objs = []
+    procs = []
+    for s in SOURCES:
+        o = os.path.join(CSRC, s.replace(".hip", ".o"))
+        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        if verbose:
+            print(" ".join(cmd))
+        procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+        objs.append(o)
+    for s, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (s, out.decode()))
+        if verbose and out:
+            print(out.decode())
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,373 @@
+// beam_generic.hip -- LDS-resident CTC prefix beam search, one read per wavefront.
+//
+// Covers search::beam_search (/root/reference/src/search.rs:159-301) and
+// search::crf_beam_search (:38-157) for ANY beam_size / alphabet / CRF state count that fits
+// the per-wave LDS budget.  It is the fallback and the correctness workhorse; the
+// register-resident kernel in beam_wave.hip is the fast path for beam_size <= 8, N <= 7.
+//
+// Mapping (CDNA4, wave64): one 64-thread workgroup == one wavefront == one read, so all
+// synchronisation is wave-local.  The beam lives in LDS as a structure of arrays, double
+// buffered.  Every timestep the wave evaluates B*N "slots" (beam entry i, k): k == 0 is the
+// entry's own node (blank + repeat-stay + the extension arriving from its parent if that parent
+// is in the beam too), k >= 1 is the child reached by label k-1.  This yields each distinct tree
+// node exactly once, already merged, which is what the reference gets by sorting the raw
+// candidates by node and folding duplicates (:245-260); at most two non-zero f32 addends meet
+// in any sum, so the merged value is independent of the reference's fold order.
+// Pruning ranks the slots by a 64-bit key (probability desc, node asc) -- exact, no sort.
+//
+// The prefix tree is an append-only per-read arena in HBM (tree.rs:125-161): node ids are
+// handed out in the reference's creation order (beam order, then label order) with a
+// ballot/popcount prefix sum, so ties resolve exactly as in the reference.
+#include "device_utils.h"
+#include "fcd_internal.h"
+
+namespace fcd {
+
+namespace {
+
+struct GenericParams {
+    BatchDesc in;
+    BeamArgs a;
+    GenericArena arena;
+    ResultDesc out;
+    int64_t read_begin;
+};
+
+// LDS carve-up (all 4-byte words unless noted).  BC = beam_size, NL = N-1, C = BC*N.
+struct Lds {
+    int *b_node[2];
+    float *b_lp[2];
+    float *b_gp[2];
+    int *b_tip[2];
+    int *b_par[2];
+    int *b_state[2];
+    int *b_depth[2];
+    int *b_child[2];  // BC*NL
+    uint64_t *c_key;  // C, 8-byte aligned
+    float *c_lp;
+    float *c_gp;
+    int *c_id;
+    int *c_new;
+    int *nb_src;   // BC
+    float *row;    // N (non-CRF staging of the current posterior row)
+    float *top;    // 1
+};
+
+__host__ __device__ inline size_t lds_words(int BC, int N) {
+    int NL = N - 1;
+    size_t C = (size_t)BC * N;
+    size_t w = 0;
+    w += 2 * (size_t)BC * (7 + NL);
+    w += 2 * C;  // keys (u64)
+    w += 4 * C;  // lp, gp, id, new
+    w += BC;     // nb_src
+    w += N;      // row
+    w += 2;      // top + pad
+    return w;
+}
+
+__device__ inline Lds carve(int *smem, int BC, int N) {
+    Lds L;
+    int NL = N - 1;
+    size_t C = (size_t)BC * N;
+    uint64_t *k = reinterpret_cast<uint64_t *>(smem);
+    L.c_key = k;
+    int *p = smem + 2 * C;
+    L.c_lp = reinterpret_cast<float *>(p); p += C;
+    L.c_gp = reinterpret_cast<float *>(p); p += C;
+    L.c_id = p; p += C;
+    L.c_new = p; p += C;
+    for (int b = 0; b < 2; ++b) {
+        L.b_node[b] = p; p += BC;
+        L.b_lp[b] = reinterpret_cast<float *>(p); p += BC;
+        L.b_gp[b] = reinterpret_cast<float *>(p); p += BC;
+        L.b_tip[b] = p; p += BC;
+        L.b_par[b] = p; p += BC;
+        L.b_state[b] = p; p += BC;
+        L.b_depth[b] = p; p += BC;
+        L.b_child[b] = p; p += (size_t)BC * NL;
+    }
+    L.nb_src = p; p += BC;
+    L.row = reinterpret_cast<float *>(p); p += N;
+    L.top = reinterpret_cast<float *>(p);
+    return L;
+}
+
+__device__ __forceinline__ void fail(const GenericParams &p, int64_t r, int code) {
+    if (threadIdx.x == 0) {
+        p.out.status[r] = code;
+        p.out.out_len[r] = 0;
+    }
+}
+
+__global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x;
+    const int64_t r = p.read_begin + blockIdx.x;
+    const int N = p.in.N, NL = N - 1, S = p.in.S;
+    const int BC = p.a.beam_size;
+    const bool crf = p.a.crf != 0;
+    const bool collapse = p.a.collapse != 0;
+    const float thr = p.a.thr;
+    Lds L = carve(smem, BC, N);
+
+    int64_t T = p.in.T;
+    if (p.in.lengths) {
+        int64_t t = p.in.lengths[r];
+        T = t < 0 ? 0 : (t < T ? t : T);
+    }
+    const float *post = p.in.post + r * p.in.stride_read;
+    const int64_t st_t = p.in.stride_t, st_s = p.in.stride_s, st_n = p.in.stride_n;
+    int4 *rec = p.arena.rec + (int64_t)blockIdx.x * p.arena.cap_nodes;
+    int32_t *rows = p.arena.rows + (int64_t)blockIdx.x * p.arena.cap_nodes * NL;
+
+    // ---- initial beam: search.rs:170-175 / :54-59 ----
+    int cur = 0;
+    int B = 1;
+    if (lane == 0) {
+        int st0 = 0;
+        float lp0 = 0.0f, gp0 = 1.0f;
+        bool bad = false;
+        if (crf) {
+            // ndarray-stats argmax/max: first maximum wins, NaN -> Err -> unwrap panics
+            const float *init = p.a.init + r * p.a.init_stride;
+            float m = init[0];
+            bad = (p.a.n_init <= 0) || (m != m);
+            for (int64_t j = 1; j < p.a.n_init && !bad; ++j) {
+                float e = init[j];
+                if (e != e) bad = true;
+                if (e > m) {
+                    m = e;
+                    st0 = (int)j;
+                }
+            }
+            lp0 = m;
+            gp0 = init[0];
+        }
+        L.b_node[0][0] = -1;
+        L.b_lp[0][0] = lp0;
+        L.b_gp[0][0] = gp0;
+        L.b_tip[0][0] = -1;
+        L.b_par[0][0] = -2;
+        L.b_state[0][0] = bad ? -1 : st0;
+        L.b_depth[0][0] = 0;
+    }
+    for (int j = lane; j < NL; j += kWave) L.b_child[0][j] = -1;
+    if (!crf && T > 0)
+        for (int j = lane; j < N; j += kWave) L.row[j] = post[j * st_n];
+    __syncthreads();
+
+    int nn = 0;  // nodes in this read's tree (wave-uniform)
+
+    for (int64_t t = 0; t < T; ++t) {
+        int *b_node = L.b_node[cur], *b_tip = L.b_tip[cur], *b_par = L.b_par[cur];
+        int *b_state = L.b_state[cur], *b_depth = L.b_depth[cur], *b_child = L.b_child[cur];
+        float *b_lp = L.b_lp[cur], *b_gp = L.b_gp[cur];
+        const int nslots = B * N;
+        const float *frame = post + t * st_t;
+
+        int n_valid = 0;
+        bool any_nan = false, bad_state = false;
+
+        // ---- phase A: evaluate every (entry, k) slot; number the new nodes ----
+        for (int base = 0; base < nslots; base += kWave) {
+            const int c = base + lane;
+            const bool act = c < nslots;
+            const int i = act ? c / N : 0;
+            const int k = act ? c - i * N : 0;
+            const int node = b_node[i];
+            const float lp = b_lp[i], gp = b_gp[i];
+            const int tip = b_tip[i];
+            const int st = b_state[i];
+            bool valid = false, is_new = false;
+            float clp = 0.0f, cgp = 0.0f;
+            int cid = -2;
+            if (act) {
+                bool ok_state = !crf || (st >= 0 && st < S);
+                if (!ok_state) {
+                    bad_state = true;
+                } else if (k == 0) {
+                    // the entry's own node: blank (:191-198) + repeat-stay (:206-211)
+                    const float pr0 = crf ? frame[st * st_s] : L.row[0];
+                    const bool blank = pr0 > thr;
+                    cgp = blank ? (lp + gp) * pr0 : 0.0f;
+                    bool stay = !crf && collapse && tip >= 0;
+                    if (stay) {
+                        const float pt = L.row[tip + 1];
+                        stay = !(pt < thr);
+                        clp = stay ? lp * pt : 0.0f;
+                    }
+                    // extension arriving from this node's parent, if the parent is in the beam
+                    bool inc = false;
+                    if (node >= 0) {
+                        const int par = b_par[i];
+                        for (int j = 0; j < B; ++j) {
+                            if (b_node[j] == par) {
+                                const int stj = b_state[j];
+                                if (crf && (stj < 0 || stj >= S)) {
+                                    bad_state = true;
+                                    break;
+                                }
+                                const float pl = crf ? frame[stj * st_s + (tip + 1) * st_n]
+                                                     : L.row[tip + 1];
+                                if (!(pl < thr)) {  // :201 skip only if pr_b < thr
+                                    const bool rep = !crf && collapse && b_tip[j] == tip;
+                                    const float lpj = b_lp[j], gpj = b_gp[j];
+                                    const float contrib = rep ? gpj * pl : (lpj + gpj) * pl;
+                                    clp = clp + contrib;
+                                    inc = true;
+                                }
+                                break;
+                            }
+                        }
+                    }
+                    valid = blank || stay || inc;
+                    cid = node;
+                } else {
+                    // child by label k-1 (:200-239 / crf :84-99)
+                    const int l = k - 1;
+                    const float pk = crf ? frame[st * st_s + k * st_n] : L.row[k];
+                    const bool pass = !(pk < thr);
+                    const bool rep = !crf && collapse && l == tip;
+                    const float contrib = rep ? gp * pk : (lp + gp) * pk;
+                    const int ch = b_child[i * NL + l];
+                    const bool exists = ch >= 0;
+                    valid = pass && (exists || !rep || gp > 0.0f);  // :212-218
+                    if (valid && exists) {
+                        // child already in the beam: its own slot absorbs this extension
+                        for (int j = 0; j < B; ++j)
+                            if (b_node[j] == ch) {
+                                valid = false;
+                                break;
+                            }
+                    }
+                    is_new = valid && !exists;
+                    clp = contrib;
+                    cid = ch;
+                }
+            }
+            // tree.rs:125-145 add_node, ids in (beam order, label order)
+            const uint64_t m_new = __ballot(is_new);
+            if (is_new) {
+                cid = nn + popc64(m_new & lanemask_lt());
+                if (cid < p.arena.cap_nodes) {
+                    const int l = k - 1;
+                    rec[cid] = make_int4(node, (int)t, l, b_depth[i] + 1);
+                    for (int j = 0; j < NL; ++j) rows[(int64_t)cid * NL + j] = -1;
+                    if (node >= 0) rows[(int64_t)node * NL + l] = cid;
+                    b_child[i * NL + l] = cid;
+                }
+            }
+            nn += popc64(m_new);
+            const float prob = clp + cgp;
+            if (act) {
+                L.c_lp[c] = clp;
+                L.c_gp[c] = cgp;
+                L.c_id[c] = cid;
+                L.c_new[c] = is_new ? 1 : 0;
+                // a NaN key is only ever ranked when it is the lone candidate (never compared, :262)
+                L.c_key[c] = valid ? (prob == prob ? make_key(prob, cid) : 1ull) : 0ull;
+            }
+            n_valid += popc64(__ballot(valid));
+            any_nan = any_nan || (__ballot(valid && prob != prob) != 0ull);
+        }
+        bad_state = __ballot(bad_state) != 0ull;
+        if (bad_state) return fail(p, r, FCD_ST_BAD_STATE);
+        if (nn > p.arena.cap_nodes) return fail(p, r, FCD_ST_INTERNAL);
+        // search.rs:261-277: any NaN among >= 2 candidates -> IncomparableValues, then empty -> RanOutOfBeam
+        if (n_valid >= 2 && any_nan) return fail(p, r, FCD_ST_INCOMPARABLE);
+        if (n_valid == 0) return fail(p, r, FCD_ST_RAN_OUT_OF_BEAM);
+        __syncthreads();
+
+        // ---- phase B: exact rank of every slot; the top beam_size build the next beam ----
+        const int nxt = cur ^ 1;
+        const int Bn = n_valid < BC ? n_valid : BC;
+        for (int base = 0; base < nslots; base += kWave) {
+            const int c = base + lane;
+            if (c >= nslots) continue;
+            const uint64_t key = L.c_key[c];
+            if (key == 0ull) continue;
+            int rank = 0;
+            for (int j = 0; j < nslots; ++j) rank += (L.c_key[j] > key) ? 1 : 0;
+            if (rank < BC) {
+                const int i = c / N, k = c - i * N;
+                L.b_node[nxt][rank] = L.c_id[c];
+                L.b_lp[nxt][rank] = L.c_lp[c];
+                L.b_gp[nxt][rank] = L.c_gp[c];
+                if (k == 0) {
+                    L.b_tip[nxt][rank] = b_tip[i];
+                    L.b_par[nxt][rank] = b_par[i];
+                    L.b_state[nxt][rank] = b_state[i];
+                    L.b_depth[nxt][rank] = b_depth[i];
+                } else {
+                    L.b_tip[nxt][rank] = k - 1;
+                    L.b_par[nxt][rank] = b_node[i];
+                    L.b_state[nxt][rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
+                    L.b_depth[nxt][rank] = b_depth[i] + 1;
+                }
+                L.nb_src[rank] = c | (L.c_new[c] << 30);
+                if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
+            }
+        }
+        __syncthreads();
+
+        // ---- phase C: child rows of the new beam + renormalise by the top entry (:278-282) ----
+        for (int item = lane; item < Bn * NL; item += kWave) {
+            const int s = item / NL, l = item - s * NL;
+            const int src = L.nb_src[s];
+            const int c = src & 0x3FFFFFFF;
+            const int i = c / N, k = c - i * N;
+            int v;
+            if (k == 0)
+                v = b_child[i * NL + l];
+            else if (src >> 30)
+                v = -1;
+            else
+                v = load_i32_l2(&rows[(int64_t)L.b_node[nxt][s] * NL + l]);
+            L.b_child[nxt][s * NL + l] = v;
+        }
+        const float top = *L.top;
+        for (int s = lane; s < Bn; s += kWave) {
+            L.b_lp[nxt][s] = L.b_lp[nxt][s] / top;
+            L.b_gp[nxt][s] = L.b_gp[nxt][s] / top;
+        }
+        if (!crf && t + 1 < T)
+            for (int j = lane; j < N; j += kWave) L.row[j] = post[(t + 1) * st_t + j * st_n];
+        B = Bn;
+        cur = nxt;
+        __syncthreads();
+    }
+
+    // ---- walk the best labelling leaf -> root (:285-300), writing it in sequence order ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines older than our own stores
+    if (lane == 0) {
+        int node = L.b_node[cur][0];
+        const int n = L.b_depth[cur][0];
+        uint8_t *lab = p.out.labels + r * p.out.out_stride;
+        uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
+        for (int j = n - 1; j >= 0 && node >= 0; --j) {
+            const int4 q = rec[node];
+            lab[j] = (uint8_t)(q.z + 1);
+            if (pth) pth[j] = (uint32_t)q.y;
+            node = q.x;
+        }
+        p.out.out_len[r] = (uint32_t)n;
+        p.out.status[r] = FCD_ST_OK;
+    }
+}
+
+}  // namespace
+
+size_t beam_generic_lds_bytes(int beam_size, int N) { return lds_words(beam_size, N) * 4 + 16; }
+
+hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
+                               const BeamArgs &a, const GenericArena &arena, const ResultDesc &out,
+                               hipStream_t stream) {
+    if (n_reads <= 0) return hipSuccess;
+    GenericParams p{in, a, arena, out, read_begin};
+    const size_t lds = beam_generic_lds_bytes(a.beam_size, in.N);
+    hipLaunchKernelGGL(beam_generic_kernel, dim3((unsigned)n_reads), dim3(64), lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace fcd

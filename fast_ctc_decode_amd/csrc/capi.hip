@@ -1,0 +1,525 @@
+// capi.hip -- the C ABI of libfcd_hip.so (include/fcd.h): argument checking, workspace and
+// chunking, stream/event plumbing, host staging for the *_host entry points.
+#include <math.h>
+#include <string.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "fcd_internal.h"
+
+using namespace fcd;
+
+namespace {
+
+#define FCD_HIP(h, expr)                                                          \
+    do {                                                                          \
+        hipError_t e__ = (expr);                                                  \
+        if (e__ != hipSuccess) {                                                  \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__);        \
+            return FCD_E_HIP;                                                     \
+        }                                                                         \
+    } while (0)
+
+int fail(fcd_handle *h, int code, const char *msg) {
+    if (h) h->err = msg;
+    return code;
+}
+
+int ensure(fcd_handle *h, void **buf, size_t *have, size_t need) {
+    if (*have >= need) return FCD_OK;
+    if (*buf) {
+        FCD_HIP(h, hipStreamSynchronize(h->stream));
+        FCD_HIP(h, hipFree(*buf));
+        *buf = nullptr;
+        *have = 0;
+    }
+    hipError_t e = hipMalloc(buf, need);
+    if (e != hipSuccess) {
+        *buf = nullptr;
+        h->err = std::string("hipMalloc of workspace failed: ") + hipGetErrorString(e);
+        return FCD_E_NOMEM;
+    }
+    *have = need;
+    return FCD_OK;
+}
+
+int check_batch(fcd_handle *h, const fcd_batch *in, bool crf) {
+    if (!h) return FCD_E_INVALID;
+    if (!in) return fail(h, FCD_E_INVALID, "null batch");
+    if (in->n_reads < 0 || in->T < 0 || in->N < 1) return fail(h, FCD_E_INVALID, "negative size");
+    if (in->n_reads > 0 && in->T > 0 && !in->post) return fail(h, FCD_E_INVALID, "null post");
+    if (in->N > 256) return fail(h, FCD_E_UNSUPPORTED, "alphabets above 256 labels are unsupported (u8 labels)");
+    if (in->T >= (1ll << 28)) return fail(h, FCD_E_UNSUPPORTED, "T must be < 2^28");
+    if (crf && in->S < 1) return fail(h, FCD_E_INVALID, "S must be >= 1");
+    return FCD_OK;
+}
+
+int check_result(fcd_handle *h, const fcd_batch *in, const fcd_result *out, bool need_status) {
+    if (!out) return fail(h, FCD_E_INVALID, "null result");
+    if (in->n_reads == 0) return FCD_OK;
+    if (!out->labels || !out->out_len) return fail(h, FCD_E_INVALID, "null labels/out_len");
+    if (need_status && !out->status) return fail(h, FCD_E_INVALID, "null status");
+    if (out->out_stride < in->T) return fail(h, FCD_E_INVALID, "out_stride must be >= T");
+    return FCD_OK;
+}
+
+BatchDesc to_desc(const fcd_batch *in, bool crf) {
+    BatchDesc d;
+    d.post = in->post;
+    d.lengths = in->lengths;
+    d.n_reads = in->n_reads;
+    d.T = in->T;
+    d.stride_read = in->stride_read;
+    d.stride_t = in->stride_t;
+    d.stride_s = crf ? in->stride_s : 0;
+    d.stride_n = in->stride_n;
+    d.S = crf ? (int)in->S : 1;
+    d.N = (int)in->N;
+    return d;
+}
+
+ResultDesc to_desc(const fcd_result *o) {
+    return ResultDesc{o->labels, o->path, o->qual, o->out_len, o->status, o->out_stride};
+}
+
+struct Timer {
+    fcd_handle *h;
+    explicit Timer(fcd_handle *hh) : h(hh) {
+        h->last_ms = -1.0;
+        hipEventRecord(h->ev0, h->stream);
+    }
+    void stop() { hipEventRecord(h->ev1, h->stream); }
+};
+
+int64_t workspace_budget(fcd_handle *h) {
+    if (h->ws_limit > 0) return h->ws_limit;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 8ll << 30;
+    return (int64_t)((free_b + h->arena_bytes) / 2);
+}
+
+// Shared driver of search::beam_search and search::crf_beam_search on device buffers.
+int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
+             const fcd_result *out) {
+    const bool crf = a.crf != 0;
+    int rc = check_batch(h, in, crf);
+    if (rc) return rc;
+    rc = check_result(h, in, out, true);
+    if (rc) return rc;
+    if (a.beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
+    if (in->N < 2) return fail(h, FCD_E_UNSUPPORTED, "alphabet needs at least one label besides the blank");
+    if (in->n_reads == 0) return FCD_OK;
+    FCD_HIP(h, hipSetDevice(h->device));
+
+    const BatchDesc d = to_desc(in, crf);
+    const ResultDesc o = to_desc(out);
+    const int N = d.N, NL = N - 1;
+    int64_t beam = a.beam_size;
+    BeamArgs args = a;
+
+    bool use_wave = false;
+    if (kernel == FCD_KERNEL_WAVE) {
+        if (!beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf))
+            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8, N <= 7, non-CRF");
+        use_wave = true;
+    } else if (kernel == FCD_KERNEL_AUTO) {
+        use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf);
+    }
+
+    // Worst-case tree size per read: every step every beam entry creates NL nodes
+    // (tree.rs:125 add_node is only called from the expansion loop, search.rs:200-239).
+    const int64_t T = std::max<int64_t>(d.T, 1);
+    int64_t cap_nodes;
+    size_t per_read;
+    if (use_wave) {
+        cap_nodes = T * std::min<int64_t>(beam, 8) * NL + 8;
+        const int row_words = NL <= 4 ? 4 : 8;
+        per_read = (size_t)cap_nodes * (sizeof(int2) + row_words * 4);
+    } else {
+        if (beam > (1 << 16)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 65536");
+        if (beam_generic_lds_bytes((int)beam, N) > 64 * 1024)
+            return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
+        cap_nodes = T * beam * NL + 8;
+        if (cap_nodes >= (1ll << 30)) return fail(h, FCD_E_UNSUPPORTED, "tree arena above 2^30 nodes per read");
+        per_read = (size_t)cap_nodes * (sizeof(int4) + (size_t)NL * 4);
+    }
+    args.beam_size = (int)beam;
+    const int64_t budget = workspace_budget(h);
+    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
+    chunk = std::min<int64_t>(chunk, d.n_reads);
+    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_read);
+    if (rc) return rc;
+
+    Timer tm(h);
+    for (int64_t begin = 0; begin < d.n_reads; begin += chunk) {
+        const int64_t n = std::min<int64_t>(chunk, d.n_reads - begin);
+        hipError_t e;
+        if (use_wave) {
+            WaveArena ar;
+            ar.cap_nodes = cap_nodes;
+            ar.row_words = NL <= 4 ? 4 : 8;
+            ar.rec = reinterpret_cast<int2 *>(h->arena);
+            ar.rows = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
+                                                  (size_t)chunk * cap_nodes * sizeof(int2));
+            e = launch_beam_wave(d, begin, n, args, ar, o, h->stream);
+        } else {
+            GenericArena ar;
+            ar.cap_nodes = cap_nodes;
+            ar.rec = reinterpret_cast<int4 *>(h->arena);
+            ar.rows = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
+                                                  (size_t)chunk * cap_nodes * sizeof(int4));
+            e = launch_beam_generic(d, begin, n, args, ar, o, h->stream);
+        }
+        FCD_HIP(h, e);
+    }
+    tm.stop();
+    return FCD_OK;
+}
+
+// ---- host staging -------------------------------------------------------------------------
+// Element span of a strided batch, so that an arbitrarily strided host view can be shipped with
+// one copy (non-negative strides only).
+int64_t span_elems(const fcd_batch *in, bool crf) {
+    if (in->n_reads == 0 || in->T == 0) return 0;
+    int64_t s = 1;
+    s += (in->n_reads - 1) * in->stride_read;
+    s += (in->T - 1) * in->stride_t;
+    if (crf) s += (in->S - 1) * in->stride_s;
+    s += (in->N - 1) * in->stride_n;
+    return s;
+}
+
+struct HostStage {
+    fcd_handle *h;
+    std::vector<std::pair<void *, size_t>> outs;  // (host dst, bytes) in staging order
+    char *base = nullptr;
+    size_t used = 0;
+    size_t cap = 0;
+    size_t reserve(size_t bytes) {
+        size_t off = (used + 255) & ~(size_t)255;
+        used = off + bytes;
+        return off;
+    }
+};
+
+}  // namespace
+
+// =============================================================================================
+extern "C" {
+
+int fcd_version(void) { return FCD_VERSION_MAJOR * 1000 + FCD_VERSION_MINOR; }
+
+int fcd_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int fcd_create(int device, fcd_handle **out) {
+    if (!out) return FCD_E_INVALID;
+    *out = nullptr;
+    int n = fcd_device_count();
+    if (n <= 0 || device < 0 || device >= n) return FCD_E_NODEVICE;
+    if (hipSetDevice(device) != hipSuccess) return FCD_E_HIP;
+    fcd_handle *h = new fcd_handle();
+    h->device = device;
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+        delete h;
+        return FCD_E_HIP;
+    }
+    h->stream = h->own_stream;
+    *out = h;
+    return FCD_OK;
+}
+
+int fcd_destroy(fcd_handle *h) {
+    if (!h) return FCD_OK;
+    hipSetDevice(h->device);
+    hipStreamSynchronize(h->stream);
+    if (h->arena) hipFree(h->arena);
+    if (h->stage) hipFree(h->stage);
+    if (h->ev0) hipEventDestroy(h->ev0);
+    if (h->ev1) hipEventDestroy(h->ev1);
+    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    delete h;
+    return FCD_OK;
+}
+
+int fcd_set_stream(fcd_handle *h, void *hip_stream) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    return FCD_OK;
+}
+
+int fcd_synchronize(fcd_handle *h) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    return FCD_OK;
+}
+
+const char *fcd_last_error(const fcd_handle *h) { return h ? h->err.c_str() : "null handle"; }
+
+const char *fcd_status_string(int status) {
+    switch (status) {  // src/lib.rs:46-53, verbatim
+        case FCD_ST_OK: return "";
+        case FCD_ST_RAN_OUT_OF_BEAM: return "Ran out of search space (beam_cut_threshold too high)";
+        case FCD_ST_INCOMPARABLE: return "Failed to compare values (NaNs in input?)";
+        case FCD_ST_INVALID_ENVELOPE: return "Invalid envelope values";
+        case FCD_ST_BAD_STATE: return "CRF state or init_state out of range (the reference would abort)";
+        case FCD_ST_INTERNAL: return "internal error: tree arena exhausted";
+        default: return "unknown status";
+    }
+}
+
+int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
+    if (!h || bytes < 0) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->ws_limit = bytes;
+    return FCD_OK;
+}
+
+double fcd_last_kernel_ms(fcd_handle *h) {
+    if (!h) return -1.0;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    float ms = -1.0f;
+    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    return (double)ms;
+}
+
+// ---- viterbi -------------------------------------------------------------------------------
+int fcd_viterbi_search_dev(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
+                           const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    int rc = check_batch(h, in, false);
+    if (rc) return rc;
+    rc = check_result(h, in, out, false);
+    if (rc) return rc;
+    if (in->n_reads == 0) return FCD_OK;
+    FCD_HIP(h, hipSetDevice(h->device));
+    Timer tm(h);
+    FCD_HIP(h, launch_viterbi(to_desc(in, false), collapse_repeats, to_desc(out), h->stream));
+    tm.stop();
+    return FCD_OK;
+}
+
+int fcd_beam_search_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
+                        float beam_cut_threshold, int collapse_repeats, int kernel,
+                        const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
+    BeamArgs a{};
+    a.beam_size = (int)std::min<int64_t>(beam_size, 1ll << 30);
+    a.thr = beam_cut_threshold;
+    a.collapse = collapse_repeats ? 1 : 0;
+    a.crf = 0;
+    return beam_dev(h, in, a, kernel, out);
+}
+
+int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                            int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                            const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
+    if (!init || n_init < 1) return fail(h, FCD_E_INVALID, "init_state missing");
+    BeamArgs a{};
+    a.beam_size = (int)std::min<int64_t>(beam_size, 1ll << 30);
+    a.thr = beam_cut_threshold;
+    a.collapse = 0;
+    a.crf = 1;
+    a.init = init;
+    a.n_init = n_init;
+    a.init_stride = init_stride;
+    return beam_dev(h, in, a, FCD_KERNEL_GENERIC, out);
+}
+
+int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                              int64_t init_stride, const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    int rc = check_batch(h, in, true);
+    if (rc) return rc;
+    rc = check_result(h, in, out, true);
+    if (rc) return rc;
+    if (!init || n_init < 1) return fail(h, FCD_E_INVALID, "init_state missing");
+    if (in->n_reads == 0) return FCD_OK;
+    FCD_HIP(h, hipSetDevice(h->device));
+    Timer tm(h);
+    FCD_HIP(h, launch_crf_greedy(to_desc(in, true), init, n_init, init_stride, to_desc(out), h->stream));
+    tm.stop();
+    return FCD_OK;
+}
+
+int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *, const fcd_batch *, const uint64_t *,
+                               int64_t, int64_t, float, int, int, const fcd_result *) {
+    return fail(h, FCD_E_UNSUPPORTED, "duplex search is not implemented yet");
+}
+
+int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *, const fcd_batch *,
+                                const uint64_t *, int64_t, int64_t, float, int, int,
+                                const fcd_result *) {
+    return fail(h, FCD_E_UNSUPPORTED, "duplex search is not implemented yet");
+}
+
+// ---- *_host: stage host buffers through device memory, run the *_dev path, copy back -------
+namespace {
+
+enum class Op { Viterbi, Beam, CrfBeam, CrfGreedy };
+
+struct HostCall {
+    Op op;
+    int collapse = 1;
+    int64_t beam_size = 5;
+    float thr = 0.0f;
+    int kernel = FCD_KERNEL_AUTO;
+    const float *init = nullptr;
+    int64_t n_init = 0, init_stride = 0;
+};
+
+int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c) {
+    if (!h) return FCD_E_INVALID;
+    const bool crf = c.op == Op::CrfBeam || c.op == Op::CrfGreedy;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        int rc = check_batch(h, in, crf);
+        if (rc) return rc;
+        rc = check_result(h, in, out, c.op != Op::Viterbi);
+        if (rc) return rc;
+        if (in->stride_read < 0 || in->stride_t < 0 || in->stride_n < 0 || (crf && in->stride_s < 0))
+            return fail(h, FCD_E_UNSUPPORTED, "negative strides: pass a contiguous copy");
+        if (crf && (!c.init || c.n_init < 1)) return fail(h, FCD_E_INVALID, "init_state missing");
+    }
+    if (in->n_reads == 0) return FCD_OK;
+    const int64_t B = in->n_reads;
+    const size_t n_in = (size_t)span_elems(in, crf);
+    const size_t n_out = (size_t)B * (size_t)out->out_stride;
+    const size_t n_init = crf ? (size_t)((B - 1) * c.init_stride + c.n_init) : 0;
+
+    size_t used = 0;
+    auto reserve = [&](size_t bytes) {
+        size_t off = (used + 255) & ~(size_t)255;
+        used = off + std::max<size_t>(bytes, 4);
+        return off;
+    };
+    const size_t o_in = reserve(n_in * 4);
+    const size_t o_len = reserve(in->lengths ? (size_t)B * 8 : 0);
+    const size_t o_init = reserve(n_init * 4);
+    const size_t o_lab = reserve(n_out);
+    const size_t o_path = reserve(out->path ? n_out * 4 : 0);
+    const size_t o_qual = reserve(out->qual ? n_out * 4 : 0);
+    const size_t o_olen = reserve((size_t)B * 4);
+    const size_t o_stat = reserve((size_t)B * 4);
+
+    int rc;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        FCD_HIP(h, hipSetDevice(h->device));
+        rc = ensure(h, &h->stage, &h->stage_bytes, used);
+        if (rc) return rc;
+    }
+    char *base = reinterpret_cast<char *>(h->stage);
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        if (n_in) FCD_HIP(h, hipMemcpyAsync(base + o_in, in->post, n_in * 4, hipMemcpyHostToDevice, h->stream));
+        if (in->lengths)
+            FCD_HIP(h, hipMemcpyAsync(base + o_len, in->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        if (crf) FCD_HIP(h, hipMemcpyAsync(base + o_init, c.init, n_init * 4, hipMemcpyHostToDevice, h->stream));
+    }
+    fcd_batch din = *in;
+    din.post = reinterpret_cast<const float *>(base + o_in);
+    din.lengths = in->lengths ? reinterpret_cast<const int64_t *>(base + o_len) : nullptr;
+    fcd_result dout;
+    dout.labels = reinterpret_cast<uint8_t *>(base + o_lab);
+    dout.path = out->path ? reinterpret_cast<uint32_t *>(base + o_path) : nullptr;
+    dout.qual = out->qual ? reinterpret_cast<float *>(base + o_qual) : nullptr;
+    dout.out_len = reinterpret_cast<uint32_t *>(base + o_olen);
+    dout.status = reinterpret_cast<int32_t *>(base + o_stat);
+    dout.out_stride = out->out_stride;
+    const float *dinit = reinterpret_cast<const float *>(base + o_init);
+
+    switch (c.op) {
+        case Op::Viterbi: rc = fcd_viterbi_search_dev(h, &din, c.collapse, &dout); break;
+        case Op::Beam: rc = fcd_beam_search_dev(h, &din, c.beam_size, c.thr, c.collapse, c.kernel, &dout); break;
+        case Op::CrfBeam:
+            rc = fcd_crf_beam_search_dev(h, &din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, &dout);
+            break;
+        case Op::CrfGreedy:
+            rc = fcd_crf_greedy_search_dev(h, &din, dinit, c.n_init, c.init_stride, &dout);
+            break;
+    }
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
+    if (out->path) FCD_HIP(h, hipMemcpyAsync(out->path, dout.path, n_out * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out->qual) FCD_HIP(h, hipMemcpyAsync(out->qual, dout.qual, n_out * 4, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out->status)
+        FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    return FCD_OK;
+}
+
+}  // namespace
+
+int fcd_viterbi_search_host(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
+                            const fcd_result *out) {
+    HostCall c{Op::Viterbi};
+    c.collapse = collapse_repeats;
+    return run_host(h, in, out, c);
+}
+
+int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
+                         float beam_cut_threshold, int collapse_repeats, int kernel,
+                         const fcd_result *out) {
+    HostCall c{Op::Beam};
+    c.collapse = collapse_repeats;
+    c.beam_size = beam_size;
+    c.thr = beam_cut_threshold;
+    c.kernel = kernel;
+    return run_host(h, in, out, c);
+}
+
+int fcd_crf_beam_search_host(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                             int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                             const fcd_result *out) {
+    HostCall c{Op::CrfBeam};
+    c.beam_size = beam_size;
+    c.thr = beam_cut_threshold;
+    c.init = init;
+    c.n_init = n_init;
+    c.init_stride = init_stride;
+    return run_host(h, in, out, c);
+}
+
+int fcd_crf_greedy_search_host(fcd_handle *h, const fcd_batch *in, const float *init,
+                               int64_t n_init, int64_t init_stride, const fcd_result *out) {
+    HostCall c{Op::CrfGreedy};
+    c.init = init;
+    c.n_init = n_init;
+    c.init_stride = init_stride;
+    return run_host(h, in, out, c);
+}
+
+// phred (src/search.rs:31-36), host side; log10f is libm's, as in the reference
+uint32_t fcd_phred(float prob, float qscale, float qbias) {
+    const float mx = 1e-4f;
+    const float om = 1.0f - prob;
+    const float p = (om < mx) ? mx : om;
+    const float q = -10.0f * log10f(p) * qscale + qbias;
+    const float rq = roundf(q);  // f32::round: half away from zero
+    uint32_t u;                  // Rust `as u32`: saturating, NaN -> 0
+    if (!(rq == rq) || rq <= 0.0f) u = 0;
+    else if (rq >= 4294967296.0f) u = 4294967295u;
+    else u = (uint32_t)rq;
+    return u + 33u;
+}
+
+}  // extern "C"

@@ -1,0 +1,98 @@
+// fcd_internal.h -- shared declarations of libfcd_hip.so (host side + kernel launchers).
+// gfx950 / CDNA4 only.  No CUDA compatibility paths by design.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <mutex>
+#include <string>
+
+#include "../../include/fcd.h"
+
+namespace fcd {
+
+// Everything a search kernel needs to know about the input batch (device pointers).
+struct BatchDesc {
+    const float *post;
+    const int64_t *lengths;  // nullable
+    int64_t n_reads;
+    int64_t T;
+    int64_t stride_read, stride_t, stride_s, stride_n;
+    int S;
+    int N;
+};
+
+// Device-side output arrays (see fcd_result in include/fcd.h).
+struct ResultDesc {
+    uint8_t *labels;
+    uint32_t *path;
+    float *qual;
+    uint32_t *out_len;
+    int32_t *status;
+    int64_t out_stride;
+};
+
+// Parameters of the 1D beam searches (search::beam_search / search::crf_beam_search).
+struct BeamArgs {
+    int beam_size;
+    float thr;
+    int collapse;
+    int crf;
+    const float *init;  // CRF only: [n_reads * init_stride]
+    int64_t n_init;
+    int64_t init_stride;
+};
+
+// Per-chunk tree arena of the LDS-resident ("generic") beam kernel: one slab per read.
+//   rec  : int4 {parent, time, label, depth} per node            (tree.rs LabelNode)
+//   rows : NL int32 per node, child index or -1                  (tree.rs children: Vec2D<i32>)
+struct GenericArena {
+    int4 *rec;
+    int32_t *rows;
+    int64_t cap_nodes;  // nodes per read
+};
+
+// Tree arena of the register-resident ("wave") beam kernel.
+//   rec  : int2 {parent, time<<3 | label} per node
+//   rows : int4 per node (NL <= 4) or 8 x int32 (NL <= 6..7); entry = child | EVER bit, or -1
+struct WaveArena {
+    int2 *rec;
+    int32_t *rows;
+    int64_t cap_nodes;
+    int row_words;  // 4 or 8
+};
+
+size_t beam_generic_lds_bytes(int beam_size, int N);
+hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
+                               const BeamArgs &a, const GenericArena &arena, const ResultDesc &out,
+                               hipStream_t stream);
+
+bool beam_wave_supported(int beam_size, int N, int crf);
+hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
+                            const BeamArgs &a, const WaveArena &arena, const ResultDesc &out,
+                            hipStream_t stream);
+
+hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &out,
+                          hipStream_t stream);
+
+hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_init,
+                             int64_t init_stride, const ResultDesc &out, hipStream_t stream);
+
+}  // namespace fcd
+
+struct fcd_handle {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double last_ms = -1.0;
+    int64_t ws_limit = 0;  // 0 = auto (half of the free device memory)
+    // grow-only device workspace (tree arenas, staging for *_host calls)
+    void *arena = nullptr;
+    size_t arena_bytes = 0;
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+    std::string err;
+    std::mutex mu;
+};

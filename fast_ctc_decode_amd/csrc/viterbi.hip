@@ -1,0 +1,229 @@
+// viterbi.hip -- greedy decoders: search::viterbi_search (/root/reference/src/search.rs:303-383)
+// and search::crf_greedy_search (:385-423), one read per wavefront.
+//
+// viterbi: the wave walks the read in tiles of 64 rows, one row per lane.  Per row: first-maximum
+// argmax with the reference's strict '>' fold (:303-318); emission test against the previous
+// row's label (lane-1 via a wave shuffle, lane 0 from the carry); wave-level stream compaction of
+// the emissions with ballot + prefix popcount, so labels / path are written coalesced.  The
+// optional quality output reproduces the reference's per-run f32 running sum IN ROW ORDER
+// (:348-376) -- a tree reduction would round differently -- by letting every run head absorb one
+// following row per iteration.
+#include "device_utils.h"
+#include "fcd_internal.h"
+
+namespace fcd {
+
+namespace {
+
+constexpr int kWavesPerBlock = 4;
+
+__global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc in, int collapse,
+                                                                    ResultDesc out) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (r >= in.n_reads) return;
+    int64_t T = in.T;
+    if (in.lengths) {
+        int64_t t = in.lengths[r];
+        T = t < 0 ? 0 : (t < T ? t : T);
+    }
+    const int N = in.N;
+    const float *post = in.post + r * in.stride_read;
+    uint8_t *lab = out.labels + r * out.out_stride;
+    uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
+    float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
+
+    int n_out = 0;        // emissions so far (wave-uniform)
+    int carry_label = -1; // label of the last row of the previous tile (None)
+    float run_total = 0.0f;  // open run carried across tiles (:337-339)
+    int run_count = 0;
+
+    for (int64_t base = 0; base < T; base += kWave) {
+        const int64_t row = base + lane;
+        const bool act = row < T;
+        int label = 0;
+        float prob = 0.0f;
+        if (act) {
+            const float *pr = post + row * in.stride_t;
+            prob = pr[0];
+            for (int j = 1; j < N; ++j) {  // find_max: strict '>' keeps the first maximum
+                const float v = pr[j * in.stride_n];
+                if (v > prob) {
+                    prob = v;
+                    label = j;
+                }
+            }
+        }
+        int prev = __shfl_up(label, 1);
+        if (lane == 0) prev = carry_label;
+        const bool emit = act && label != 0 && (!collapse || prev != label);  // :347
+        const uint64_t m_emit = __ballot(emit);
+        const int my_out = n_out + popc64(m_emit & lanemask_lt());
+        if (emit) {
+            lab[my_out] = (uint8_t)label;
+            if (pth) pth[my_out] = (uint32_t)row;
+        }
+
+        if (qual) {
+            // Each emission opens a run that owns every following non-blank row up to the next
+            // emission; its mean probability is what the reference feeds to phred().
+            const bool nonblank = act && label != 0;
+            const float contrib = nonblank ? prob : 0.0f;  // adding +0.0 is exact
+            const int cnt1 = nonblank ? 1 : 0;
+            // (a) the run carried in from the previous tile absorbs rows [0, first emission)
+            const int first_emit = m_emit ? __builtin_ctzll(m_emit) : kWave;
+            const int tile_rows = (int)((T - base) < kWave ? (T - base) : kWave);
+            const int lim = first_emit < tile_rows ? first_emit : tile_rows;
+            for (int j = 0; j < lim; ++j) {
+                run_total += __shfl(contrib, j);
+                run_count += __shfl(cnt1, j);
+            }
+            if (m_emit && run_count > 0) {
+                if (lane == 0) qual[n_out - 1] = run_total / (float)run_count;
+                run_total = 0.0f;
+                run_count = 0;
+            }
+            // (b) runs that start in this tile: every head absorbs one more row per iteration
+            float acc = contrib;  // the emission row itself (:362-365)
+            int cnt = cnt1;
+            bool alive = emit;
+            float sh_c = contrib;
+            int sh_n = cnt1;
+            bool sh_e = emit;
+            bool sh_a = act;
+            for (int d = 1; d < kWave; ++d) {
+                sh_c = __shfl_down(sh_c, 1);
+                sh_n = __shfl_down(sh_n, 1);
+                sh_e = __shfl_down((int)sh_e, 1) != 0;
+                sh_a = __shfl_down((int)sh_a, 1) != 0;
+                const bool in_tile = lane + d < kWave && sh_a;
+                if (alive && (!in_tile || sh_e)) alive = false;
+                if (alive) {
+                    acc += sh_c;
+                    cnt += sh_n;
+                }
+                if (__ballot(alive) == 0ull) break;
+            }
+            // a head whose run is closed by a later emission in this tile writes its mean now;
+            // the last head's run stays open and becomes the carry
+            const uint64_t later = m_emit & ~(lanemask_lt() | (1ull << lane));
+            if (emit && later) qual[my_out] = acc / (float)cnt;
+            if (m_emit) {
+                const int last = 63 - __builtin_clzll(m_emit);
+                run_total = __shfl(acc, last);
+                run_count = __shfl(cnt, last);
+            }
+        }
+
+        n_out += popc64(m_emit);
+        const int last_lane = (int)((T - base) < kWave ? (T - base - 1) : (kWave - 1));
+        carry_label = __shfl(label, last_lane);
+    }
+    if (qual && run_count > 0 && lane == 0) qual[n_out - 1] = run_total / (float)run_count;  // :370-376
+    if (lane == 0) {
+        out.out_len[r] = (uint32_t)n_out;
+        if (out.status) out.status[r] = FCD_ST_OK;
+    }
+}
+
+// crf_greedy_search (:385-423): the state walk is a serial dependency; one wave per read,
+// lanes 0..N-1 hold the current state's row and reduce it with a first-maximum argmax.
+__global__ __launch_bounds__(64) void crf_greedy_kernel(BatchDesc in, const float *init_all,
+                                                      int64_t n_init, int64_t init_stride,
+                                                      ResultDesc out) {
+    const int lane = threadIdx.x;
+    const int64_t r = blockIdx.x;
+    int64_t T = in.T;
+    if (in.lengths) {
+        int64_t t = in.lengths[r];
+        T = t < 0 ? 0 : (t < T ? t : T);
+    }
+    const int N = in.N, S = in.S, n_base = N - 1;
+    const float *post = in.post + r * in.stride_read;
+    uint8_t *lab = out.labels + r * out.out_stride;
+    uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
+    float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
+
+    // init_state.argmax() :399 (first maximum; NaN -> the reference panics)
+    const float *init = init_all + r * init_stride;
+    int state = 0;
+    bool bad = n_init <= 0;
+    if (!bad) {
+        float m = init[0];
+        bad = m != m;
+        for (int64_t j = 1; j < n_init && !bad; ++j) {
+            const float e = init[j];
+            if (e != e) bad = true;
+            if (e > m) {
+                m = e;
+                state = (int)j;
+            }
+        }
+    }
+    int n_out = 0;
+    for (int64_t t = 0; t < T && !bad; ++t) {
+        if (state < 0 || state >= S) {
+            bad = true;
+            break;
+        }
+        const float *pr = post + t * in.stride_t + (int64_t)state * in.stride_s;
+        // argmax over N columns, N may exceed 64: strided per-lane first-max, then wave reduce
+        float best = 0.0f;
+        int arg = 1 << 30;
+        bool nan = false;
+        for (int j = lane; j < N; j += kWave) {
+            const float v = pr[j * in.stride_n];
+            nan = nan || (v != v);
+            if (arg == (1 << 30) || v > best) {
+                best = v;
+                arg = j;
+            }
+        }
+        if (__ballot(nan) != 0ull) {
+            bad = true;
+            break;
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            const float ob = __shfl_xor(best, off);
+            const int oa = __shfl_xor(arg, off);
+            if (oa != (1 << 30) && (arg == (1 << 30) || ob > best || (ob == best && oa < arg))) {
+                best = ob;
+                arg = oa;
+            }
+        }
+        if (arg > 0) {  // :409-416
+            if (lane == 0) {
+                lab[n_out] = (uint8_t)arg;
+                if (pth) pth[n_out] = (uint32_t)t;
+                if (qual) qual[n_out] = best;
+            }
+            n_out++;
+            state = (int)(((int64_t)state * n_base) % S) + (arg - 1);
+        }
+    }
+    if (lane == 0) {
+        out.out_len[r] = bad ? 0u : (uint32_t)n_out;
+        if (out.status) out.status[r] = bad ? FCD_ST_BAD_STATE : FCD_ST_OK;
+    }
+}
+
+}  // namespace
+
+hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &out,
+                          hipStream_t stream) {
+    if (in.n_reads <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)((in.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, in,
+                       collapse, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_init,
+                             int64_t init_stride, const ResultDesc &out, hipStream_t stream) {
+    if (in.n_reads <= 0) return hipSuccess;
+    hipLaunchKernelGGL(crf_greedy_kernel, dim3((unsigned)in.n_reads), dim3(64), 0, stream, in, init,
+                       n_init, init_stride, out);
+    return hipGetLastError();
+}
+
+}  // namespace fcd

@@ -1,0 +1,180 @@
+/*
+ * fcd.h -- C ABI of the MI355X-native batched CTC decoder (libfcd_hip.so).
+ *
+ * This is the drop-in boundary for fast-ctc-decode's hot path.  The reference exports no C ABI
+ * of its own (only PyInit_fast_ctc_decode, /root/reference/src/lib.rs:617-628); its FFI seam is
+ * the set of Rust search functions the PyO3 wrappers call with the GIL released.  Each entry
+ * point below replaces one of those calls, batched over reads, and cites it:
+ *
+ *   fcd_viterbi_search_*      <- search::viterbi_search      src/search.rs:320-327 (call site src/lib.rs:199-208)
+ *   fcd_beam_search_*         <- search::beam_search         src/search.rs:159-165 (call site src/lib.rs:353-361)
+ *   fcd_crf_beam_search_*     <- search::crf_beam_search     src/search.rs:38-44   (call site src/lib.rs:274-282)
+ *   fcd_crf_greedy_search_*   <- search::crf_greedy_search   src/search.rs:385-392 (call site src/lib.rs:237-246)
+ *   fcd_beam_search_duplex_*  <- duplex::beam_search         src/duplex.rs:443-451 (call site src/lib.rs:474-484)
+ *   per-read status codes     <- enum SearchError            src/lib.rs:36-41
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no torch / numpy / HIP types in any signature
+ *     (a hipStream_t is passed as void*).
+ *   - `*_dev` functions take DEVICE pointers (inputs already resident in HBM, outputs written to
+ *     HBM) and only enqueue work on the handle's stream; `*_host` functions take HOST pointers,
+ *     stage through the handle's workspace and return after synchronising.
+ *   - strides are in ELEMENTS (the reference accepts arbitrarily strided ndarray views,
+ *     src/lib.rs:198,352).
+ *   - the device writes label INDICES into the caller's alphabet (1..N-1, 0 is the blank and is
+ *     never emitted); strings are joined on the host (src/search.rs:293,358).
+ *   - `path` values are the u32 row index at which the emitted label's tree node was created
+ *     (src/search.rs:214,231,359); the reference's usize is narrowed, T must be < 2^28.
+ *   - return value: FCD_OK or a negative FCD_E_* for API misuse / runtime failure;
+ *     per-read search outcomes go to status[read] (FCD_ST_*).
+ *   - one handle may be used by one host thread at a time (calls on a handle are serialised by
+ *     an internal mutex); use one handle per thread / per stream for concurrency.
+ */
+#ifndef FCD_H
+#define FCD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FCD_VERSION_MAJOR 0
+#define FCD_VERSION_MINOR 1
+
+/* return codes */
+enum {
+    FCD_OK = 0,
+    FCD_E_INVALID = -1,     /* bad argument (null pointer, negative size, unsupported shape) */
+    FCD_E_HIP = -2,         /* a HIP runtime call failed; see fcd_last_error() */
+    FCD_E_NOMEM = -3,       /* workspace allocation failed */
+    FCD_E_UNSUPPORTED = -4, /* shape outside what the kernels implement */
+    FCD_E_NODEVICE = -5     /* no usable gfx950 device */
+};
+
+/* per-read status, mirrors SearchError (src/lib.rs:36-41) */
+enum {
+    FCD_ST_OK = 0,
+    FCD_ST_RAN_OUT_OF_BEAM = 1,   /* "Ran out of search space (beam_cut_threshold too high)" */
+    FCD_ST_INCOMPARABLE = 2,      /* "Failed to compare values (NaNs in input?)" */
+    FCD_ST_INVALID_ENVELOPE = 3,  /* "Invalid envelope values" */
+    FCD_ST_BAD_STATE = 4,         /* CRF state index left [0,S): the reference panics (aborts) */
+    FCD_ST_INTERNAL = 5           /* tree arena exhausted -- a bug in workspace sizing */
+};
+
+/* duplex log-add flavour (SURVEY.md section 0 finding 3) */
+enum {
+    FCD_LOGADD_LOGSUMEXP = 0, /* reference built with --no-default-features */
+    FCD_LOGADD_MAX = 1        /* reference's default `fastexp` feature (exp() == 0.0) */
+};
+
+/* kernel selection for fcd_beam_search_* (0 = pick the fastest that supports the shape) */
+enum {
+    FCD_KERNEL_AUTO = 0,
+    FCD_KERNEL_GENERIC = 1,  /* LDS-resident beam, any beam_size / alphabet */
+    FCD_KERNEL_WAVE = 2      /* register-resident beam, beam_size <= 8, N <= 7 */
+};
+
+typedef struct fcd_handle fcd_handle;
+
+/* Shape/stride description of a batch of posterior matrices.
+ *   1D searches: element (read r, row t, column j)        at base[r*stride_read + t*stride_t + j*stride_n]
+ *   CRF searches: element (read r, row t, state s, col j) at base[r*stride_read + t*stride_t + s*stride_s + j*stride_n]
+ * lengths (nullable): per-read row count T_r <= T (ragged batches); device pointer for *_dev,
+ * host pointer for *_host. */
+typedef struct fcd_batch {
+    const float *post;
+    int64_t n_reads;
+    int64_t T;          /* rows allocated per read */
+    int64_t S;          /* CRF states; 1 for the plain searches */
+    int64_t N;          /* alphabet size including the blank */
+    int64_t stride_read;
+    int64_t stride_t;
+    int64_t stride_s;
+    int64_t stride_n;
+    const int64_t *lengths;
+} fcd_batch;
+
+/* Output of the 1D searches; every array has n_reads rows.
+ *   labels : [n_reads * out_stride] u8   alphabet index of each emitted label, in sequence order
+ *   path   : [n_reads * out_stride] u32  (nullable)
+ *   qual   : [n_reads * out_stride] f32  (nullable; viterbi/crf_greedy only) the probability the
+ *            reference feeds to phred() for each emitted label (src/search.rs:348-356,370-376)
+ *   out_len: [n_reads] u32   number of emitted labels
+ *   status : [n_reads] i32   FCD_ST_*  (nullable for viterbi)
+ * out_stride must be >= the longest possible output (T is always enough). */
+typedef struct fcd_result {
+    uint8_t *labels;
+    uint32_t *path;
+    float *qual;
+    uint32_t *out_len;
+    int32_t *status;
+    int64_t out_stride;
+} fcd_result;
+
+/* ---- library / handle ---- */
+int fcd_version(void);                                   /* major*1000 + minor */
+int fcd_device_count(void);                              /* number of visible HIP devices, 0 if none */
+int fcd_create(int device, fcd_handle **out);            /* binds to a device, creates its own stream */
+int fcd_destroy(fcd_handle *h);
+int fcd_set_stream(fcd_handle *h, void *hip_stream);     /* NULL restores the handle's own stream */
+int fcd_synchronize(fcd_handle *h);
+const char *fcd_last_error(const fcd_handle *h);         /* text of the last failure on this handle */
+const char *fcd_status_string(int status);               /* exact SearchError Display text, src/lib.rs:46-53 */
+/* cap (bytes) on the per-call tree-arena workspace; batches needing more are decoded in chunks */
+int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes);
+/* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP
+ * events on the stream the kernels were launched on; <0 if unavailable */
+double fcd_last_kernel_ms(fcd_handle *h);
+
+/* ---- search::viterbi_search (src/search.rs:320-383) ---- */
+int fcd_viterbi_search_dev(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
+                           const fcd_result *out);
+int fcd_viterbi_search_host(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
+                            const fcd_result *out);
+
+/* ---- search::beam_search (src/search.rs:159-301) ---- */
+int fcd_beam_search_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
+                        float beam_cut_threshold, int collapse_repeats, int kernel,
+                        const fcd_result *out);
+int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
+                         float beam_cut_threshold, int collapse_repeats, int kernel,
+                         const fcd_result *out);
+
+/* ---- search::crf_beam_search (src/search.rs:38-157) ----
+ * init: [n_reads * init_stride] f32, n_init entries used per read (src/search.rs:54-59). */
+int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                            int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                            const fcd_result *out);
+int fcd_crf_beam_search_host(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                             int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                             const fcd_result *out);
+
+/* ---- search::crf_greedy_search (src/search.rs:385-423) ---- */
+int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                              int64_t init_stride, const fcd_result *out);
+int fcd_crf_greedy_search_host(fcd_handle *h, const fcd_batch *in, const float *init,
+                               int64_t n_init, int64_t init_stride, const fcd_result *out);
+
+/* ---- duplex::beam_search (src/duplex.rs:443-650) ----
+ * in1/in2 describe the two reads of each pair (same n_reads and N); envelope is
+ * [n_reads * env_stride] pairs of u64 (lo,hi), row t of pair r at envelope[(r*env_stride + t)*2].
+ * Only labels/out_len/status of `out` are written (the reference returns the string only). */
+int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
+                               const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                               float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                               const fcd_result *out);
+int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
+                                const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                                const fcd_result *out);
+
+/* ---- host-side helpers shared with the language bindings ---- */
+/* phred quality character code point for a probability (src/search.rs:31-36) */
+uint32_t fcd_phred(float prob, float qscale, float qbias);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FCD_H */

@@ -1,0 +1,84 @@
+"""CPU-only: the C-ABI library builds (hipcc cross-compiles gfx950), loads, and exports every
+symbol include/fcd.h declares.  No compute calls."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from fast_ctc_decode_amd import _native, build
+    build.build()
+    return _native.load()
+
+
+def header_functions():
+    text = open(os.path.join(ROOT, "include", "fcd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fcd_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_exported(lib):
+    names = header_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libfcd_hip.so does not export %s" % n
+
+
+def test_binding_covers_header():
+    from fast_ctc_decode_amd import _native
+    assert sorted(_native.SYMBOLS) == header_functions()
+
+
+def test_version_and_strings(lib):
+    assert lib.fcd_version() == 1
+    # exact SearchError Display strings (src/lib.rs:46-53)
+    assert lib.fcd_status_string(1) == b"Ran out of search space (beam_cut_threshold too high)"
+    assert lib.fcd_status_string(2) == b"Failed to compare values (NaNs in input?)"
+    assert lib.fcd_status_string(3) == b"Invalid envelope values"
+
+
+def test_phred_host_helper(lib):
+    # K5 (src/search.rs:513-525) through the product's host helper
+    import numpy as np
+    f32 = np.float32
+    probs = [f32(0.0), f32(0.5), f32(1.0) - f32(1e-1), f32(1.0) - f32(1e-2), f32(1.0) - f32(1e-3),
+             f32(1.0) - f32(1e-4), f32(1.0) - f32(1e-5), f32(1.0) - f32(1e-6), f32(1.0)]
+    assert "".join(chr(lib.fcd_phred(float(p), 1.0, 0.0)) for p in probs) == "!$+5?IIII"
+
+
+def test_no_gpu_fails_loudly(lib):
+    """Without a device the product must raise, never fall back to a CPU path."""
+    import numpy as np
+    import fast_ctc_decode_amd as fcd
+    if lib.fcd_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        fcd.beam_search(np.full((10, 5), 0.2, np.float32), "NACGT")
+
+
+def test_validation_without_gpu():
+    """Argument validation (src/lib.rs:331-349) happens before any device work."""
+    import numpy as np
+    import fast_ctc_decode_amd as fcd
+    x = np.full((10, 5), 0.2, np.float32)
+    with pytest.raises(ValueError, match="alphabet size 4 does not match probability matrix inner dimension 5"):
+        fcd.beam_search(x, "NACG")
+    with pytest.raises(ValueError, match="beam_size cannot be 0"):
+        fcd.beam_search(x, "NACGT", 0)
+    with pytest.raises(ValueError, match="beam_cut_threshold must be at least 0.0"):
+        fcd.beam_search(x, "NACGT", 5, -0.1)
+    with pytest.raises(ValueError, match="beam_cut_threshold cannot be more than 0.2"):
+        fcd.beam_search(x, "NACGT", 5, 0.2)
+    with pytest.raises(ValueError, match="Empty alphabet given"):
+        fcd.viterbi_search(x, "")
+    with pytest.raises(ValueError, match="alphabet size does not match probability matrix dimensions"):
+        fcd.viterbi_search(x, "NACG")
+    with pytest.raises(TypeError):
+        fcd.beam_search(x.astype(np.float64), "NACGT")
+    with pytest.raises(TypeError):
+        fcd.beam_search(x)

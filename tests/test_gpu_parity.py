@@ -1,0 +1,180 @@
+"""Differential parity: HIP kernels (through the C ABI) vs the CPU oracle on seeded inputs.
+Bar: bit-exact (labels, path, status) -- this is integer/index output."""
+import numpy as np
+import pytest
+
+from kat_cases import reference_style_rows
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fcd():
+    import fast_ctc_decode_amd as m
+    return m
+
+
+def gen_batch(seed, B, T, N, peaky=False):
+    rng = np.random.default_rng(seed)
+    if peaky:
+        z = rng.normal(size=(B, T, N)).astype(np.float32) * 4.0
+        z[..., 0] += 2.0
+        e = np.exp(z - z.max(-1, keepdims=True))
+        return (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    return reference_style_rows(rng, B * T, N).reshape(B, T, N)
+
+
+def check_beam(fcd, x, beam, thr, collapse=True, lengths=None, kernel=0):
+    r = fcd.beam_search_batch_raw(x, beam, thr, collapse, lengths=lengths, kernel=kernel)
+    B = x.shape[0]
+    for i in range(B):
+        xi = x[i] if lengths is None else x[i, :lengths[i]]
+        st, labels, path, _ = oracle.beam_search_raw(np.ascontiguousarray(xi), beam, thr, collapse)
+        assert int(r.status[i]) == st, (i, int(r.status[i]), st)
+        if st == 0:
+            n = int(r.out_len[i])
+            assert n == len(labels), (i, n, len(labels))
+            np.testing.assert_array_equal(r.labels[i, :n], labels)
+            np.testing.assert_array_equal(r.path[i, :n], path)
+
+
+@pytest.mark.parametrize("N", [3, 5, 12])
+@pytest.mark.parametrize("beam", [1, 5, 32])
+def test_beam_generic_random(fcd, N, beam):
+    x = gen_batch(100 + N + beam, 6, 300, N)
+    thr = 0.1 if N <= 5 else 0.05
+    check_beam(fcd, x, beam, thr, kernel=fcd.KERNEL_GENERIC)
+
+
+@pytest.mark.parametrize("collapse", [True, False])
+def test_beam_generic_thr0(fcd, collapse):
+    x = gen_batch(7, 4, 200, 5)
+    check_beam(fcd, x, 5, 0.0, collapse, kernel=fcd.KERNEL_GENERIC)
+
+
+def test_beam_generic_peaky(fcd):
+    x = gen_batch(8, 8, 500, 5, peaky=True)
+    check_beam(fcd, x, 5, 0.001, kernel=fcd.KERNEL_GENERIC)
+    check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_GENERIC)  # many reads run out of beam: status parity
+
+
+def test_beam_ragged(fcd):
+    x = gen_batch(9, 5, 257, 5)
+    lengths = np.array([257, 1, 0, 100, 64], np.int64)
+    check_beam(fcd, x, 5, 0.1, lengths=lengths, kernel=fcd.KERNEL_GENERIC)
+
+
+def test_beam_nan_and_zero_rows(fcd):
+    x = gen_batch(10, 4, 50, 5)
+    x[0, 20] = np.nan           # NaN row -> IncomparableValues
+    x[1, 10:] = 0.0             # all-zero rows with thr 0.1 -> RanOutOfBeam
+    x[2, 5, 0] = np.nan         # NaN blank only
+    check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_GENERIC)
+    check_beam(fcd, x, 5, 0.0, kernel=fcd.KERNEL_GENERIC)
+
+
+def test_beam_strided_view(fcd):
+    big = gen_batch(11, 3, 120, 8)
+    x = big[:, ::2, 1:6]  # non-contiguous view, like a zero-copy ndarray view (src/lib.rs:352)
+    r = fcd.beam_search_batch_raw(x, 5, 0.1)
+    for i in range(3):
+        st, labels, path, _ = oracle.beam_search_raw(x[i], 5, 0.1)
+        n = int(r.out_len[i])
+        assert int(r.status[i]) == st
+        np.testing.assert_array_equal(r.labels[i, :n], labels)
+        np.testing.assert_array_equal(r.path[i, :n], path)
+
+
+def test_beam_full_size_reads(fcd):
+    """BASELINE config 2 shape (T=4000, N=5, beam 5, thr 0.1) on a handful of reads."""
+    x = gen_batch(1, 8, 4000, 5)
+    check_beam(fcd, x, 5, 0.1)
+
+
+def test_viterbi_random(fcd):
+    for N, collapse in ((5, True), (5, False), (3, True), (12, True)):
+        x = gen_batch(20 + N, 7, 1000, N)
+        x[0, 100:400, 1:] = 0.0  # a long blank stretch
+        x[1, 10:300, 2] = 5.0    # a long single-label run spanning tiles
+        lengths = np.array([1000, 1000, 1, 63, 64, 65, 999], np.int64)
+        r = fcd.viterbi_search_batch_raw(x, collapse, lengths=lengths, qual=True)
+        for i in range(x.shape[0]):
+            xi = np.ascontiguousarray(x[i, :lengths[i]])
+            labels, path, quals = oracle.viterbi_search_raw(xi, collapse)
+            n = int(r.out_len[i])
+            assert n == len(labels)
+            np.testing.assert_array_equal(r.labels[i, :n], labels)
+            np.testing.assert_array_equal(r.path[i, :n], path)
+            got = [oracle.lib.fcdo_phred(float(q), 1.0, 0.0) for q in r.qual[i, :n]]
+            assert [ord(c) for c in got] == list(quals)
+
+
+def test_viterbi_qual_bits(fcd):
+    """The per-run mean must be the reference's sequential f32 sum, bit for bit."""
+    x = gen_batch(31, 4, 777, 5)
+    r = fcd.viterbi_search_batch_raw(x, True, qual=True)
+    for i in range(4):
+        prob = x[i].max(1)
+        lab = x[i].argmax(1)
+        exp = []
+        tot, cnt, last = np.float32(0), 0, -1
+        for t in range(x.shape[1]):
+            if lab[t] != 0 and last != lab[t]:
+                if cnt:
+                    exp.append(tot / np.float32(cnt))
+                    tot, cnt = np.float32(0), 0
+            if lab[t] != 0:
+                tot = np.float32(tot + prob[t])
+                cnt += 1
+            last = lab[t]
+        if cnt:
+            exp.append(tot / np.float32(cnt))
+        n = int(r.out_len[i])
+        np.testing.assert_array_equal(r.qual[i, :n].view(np.uint32),
+                                      np.array(exp, np.float32).view(np.uint32))
+
+
+def gen_crf(seed, B, T, S=4, N=5):
+    rng = np.random.default_rng(seed)
+    x = rng.random((B, T, S, N), dtype=np.float32)
+    x /= x.sum(-1, keepdims=True)
+    init = np.zeros((B, S), np.float32)
+    init[np.arange(B), rng.integers(0, S, B)] = 1.0
+    return x.astype(np.float32), init
+
+
+@pytest.mark.parametrize("beam,thr", [(5, 0.0), (5, 0.1), (16, 0.05)])
+def test_crf_beam_random(fcd, beam, thr):
+    x, init = gen_crf(40 + beam, 5, 300)
+    got = fcd.crf_beam_search_batch(x, init, "NACGT", beam, thr)
+    for i in range(x.shape[0]):
+        want = oracle.crf_beam_search(x[i], init[i], "NACGT", beam, thr)
+        assert got[i] == want
+
+
+def test_crf_greedy_random(fcd):
+    x, init = gen_crf(50, 3, 400)
+    for i in range(3):
+        for q in (False, True):
+            assert fcd.crf_greedy_search(x[i], init[i], "NACGT", q) == \
+                oracle.crf_greedy_search(x[i], init[i], "NACGT", q)
+
+
+def test_torch_device_path(fcd):
+    """Zero-copy *_dev entry points on torch tensors: same answer as the host-staged path."""
+    torch = pytest.importorskip("torch")
+    x = gen_batch(60, 16, 500, 5)
+    xd = torch.from_numpy(x).cuda()
+    r = fcd.beam_search_batch_raw(xd, 5, 0.1)
+    torch.cuda.synchronize()
+    rh = fcd.beam_search_batch_raw(x, 5, 0.1)
+    rc = r.cpu()
+    np.testing.assert_array_equal(rc.out_len, rh.out_len)
+    for i in range(16):
+        n = int(rh.out_len[i])
+        np.testing.assert_array_equal(rc.labels[i, :n], rh.labels[i, :n])
+        np.testing.assert_array_equal(rc.path[i, :n].astype(np.uint32), rh.path[i, :n])
+    v = fcd.viterbi_search_batch_raw(xd).cpu()
+    vh = fcd.viterbi_search_batch_raw(x)
+    np.testing.assert_array_equal(v.out_len, vh.out_len)
