@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""bench.py -- the driver's benchmark contract for the MI355X-native CTC decoder.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path -- search::beam_search (beam_size 5, beam_cut_threshold 0.1,
+collapse_repeats) over one batch of 4096 synthetic reads of T=4000 x N=5 f32 posteriors per GPU
+(BASELINE.json configs[1]) -- with the posteriors already resident in HBM when the timed region
+starts.  Reads are independent, so N GPUs decode N independent shards (weak scaling, no collective
+inside the search); for N > 1 each step ends with ONE RCCL gather of the decoded
+(labels, path, lengths) to rank 0 over xGMI, inside the timed region.
+
+Rank 0 prints ONE JSON line.  `value` is whole-job reads/s = N * batch * K / max-over-ranks time.
+`roofline` prices the beam-search kernel against HBM bandwidth with ALGORITHMIC bytes
+(T*N*4 in + 5 bytes per emitted label out) over the kernel's own duration measured
+with HIP events on the launch stream.  `cpu_baseline` is the CPU oracle (a C restatement of the
+reference's Rust, NOT the Rust itself) timed on this box's host cores on a bounded sample, whose
+outputs are also compared with the GPU's.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+T, N, BEAM, THR = 4000, 5, 5, 0.1
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+
+
+def make_batch(seed, n_reads):
+    """reference-style rows (tests/test_decode.py:15-17), seeded."""
+    rng = np.random.default_rng(seed)
+    x = rng.random((n_reads * T, N), dtype=np.float32)
+    x /= np.linalg.norm(x, ord=2, axis=1, keepdims=True)
+    return x.reshape(n_reads, T, N).astype(np.float32)
+
+
+def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
+    """Times the oracle on a bounded sample of the same workload and checks the GPU's outputs
+    against it.  Returns the cpu_baseline object and the number of reads compared."""
+    from oracle import oracle
+
+    cores = os.cpu_count() or 1
+    # calibrate single-thread speed on a few reads, then size the sample for ~budget_s of wall
+    t0 = time.perf_counter()
+    oracle.beam_search_batch(x_host[:8], BEAM, THR, True, 1)
+    rate1 = 8.0 / max(time.perf_counter() - t0, 1e-6)
+    n = int(min(x_host.shape[0], max(32, rate1 * cores * budget_s)))
+    t0 = time.perf_counter()
+    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, cores)
+    dt = time.perf_counter() - t0
+    mism = 0
+    for i in range(n):
+        L = int(lens[i])
+        ok = status[i] == 0 and int(gpu_len[i]) == L \
+            and np.array_equal(gpu_labels[i, :L], labels[i, :L]) \
+            and np.array_equal(gpu_path[i, :L].astype(np.int64), path[i, :L])
+        mism += 0 if ok else 1
+    obj = {
+        "value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+        "sample": "first %d reads of rank 0's batch (T=%d N=%d beam=%d thr=%.1f), oracle C "
+                  "restatement of src/search.rs, %d pthreads, %.1f s" % (n, T, N, BEAM, THR, cores, dt),
+        "single_thread_reads_per_s": rate1,
+        "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n,
+    }
+    return obj
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4096, help="reads per GPU per step")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic (LDS), 2 wave (registers)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import fast_ctc_decode_amd as fcd
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    B = args.batch
+    x_host = make_batch(1 + rank, B)
+    x = torch.from_numpy(x_host).to(dev)  # resident in HBM before the timed region
+    torch.cuda.synchronize()
+
+    gather_bufs = None
+
+    def step():
+        r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel)
+        if distributed:
+            # ONE gather of fixed-stride results to rank 0 (RCCL over xGMI)
+            nonlocal gather_bufs
+            payload = (r.labels, r.path, r.out_len)
+            if gather_bufs is None and rank == 0:
+                gather_bufs = [[torch.empty_like(p) for _ in range(world)] for p in payload]
+            for j, p in enumerate(payload):
+                dist.gather(p, gather_bufs[j] if rank == 0 else None, dst=0)
+        return r
+
+    for _ in range(args.warmup):
+        r = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    handle = r._handle if args.warmup > 0 else step()._handle
+    torch.cuda.synchronize()
+    handle.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    # kernel duration: the C ABI brackets every launch of the timed region with a HIP event pair
+    # on the launch stream (torch's current stream); read them back after the final sync.
+    k_ms, k_calls = handle.timing_mean_ms()
+
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+
+    if rank == 0:
+        rc = r.cpu()
+        ok = int((rc.status == 0).sum())
+        mean_L = float(rc.out_len.astype(np.float64).mean())
+        bytes_per_read = T * N * 4 + 5.0 * mean_L  # posteriors in, u8 label + u32 time out
+        achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
+        cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds)
+        out = {
+            "metric": "reads/s (T=4000, N=5, beam=5)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "reads/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": "beam_search beam_size=5 beam_cut_threshold=0.1 collapse_repeats, "
+                            "batch=4096 reads T=4000 N=5 per GPU (BASELINE.json configs[1]), "
+                            "reference-style rows numpy default_rng(1+rank)",
+                "reads_per_gpu": B, "T": T, "N": N, "beam_size": BEAM, "beam_cut_threshold": THR,
+                "parallelism": "reads sharded x%d, one RCCL gather of results per step" % world
+                               if world > 1 else "single GPU",
+                "kernel": {0: "auto", 1: "generic-lds", 2: "wave-registers"}[args.kernel],
+                "reads_ok": ok, "mean_labels_per_read": mean_L,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "kernel": "beam search kernel, %.3f ms per launch (HIP events), %d reads x %.0f "
+                          "algorithmic B/read" % (k_ms, B, bytes_per_read),
+                "kernel_ms": k_ms, "launches_timed": k_calls,
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

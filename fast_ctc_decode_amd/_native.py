@@ -22,7 +22,7 @@ LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream",
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit",
-    "fcd_last_kernel_ms",
+    "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host",
     "fcd_crf_beam_search_dev", "fcd_crf_beam_search_host",
@@ -92,6 +92,9 @@ def load():
         lib.fcd_set_workspace_limit.argtypes = [P, i64]
         lib.fcd_last_kernel_ms.argtypes = [P]
         lib.fcd_last_kernel_ms.restype = C.c_double
+        lib.fcd_timing_reset.argtypes = [P]
+        lib.fcd_timing_mean_ms.argtypes = [P, C.POINTER(i64)]
+        lib.fcd_timing_mean_ms.restype = C.c_double
         for sfx in ("dev", "host"):
             getattr(lib, "fcd_viterbi_search_" + sfx).argtypes = [P, BP, i32, RP]
             getattr(lib, "fcd_beam_search_" + sfx).argtypes = [P, BP, i64, f32, i32, i32, RP]
@@ -131,6 +134,15 @@ class Handle:
 
     def last_kernel_ms(self):
         return float(self.lib.fcd_last_kernel_ms(self.ptr))
+
+    def timing_reset(self):
+        self.check(self.lib.fcd_timing_reset(self.ptr))
+
+    def timing_mean_ms(self):
+        """-> (mean kernel ms per search call since timing_reset, number of calls)"""
+        n = C.c_int64(0)
+        ms = float(self.lib.fcd_timing_mean_ms(self.ptr, C.byref(n)))
+        return ms, int(n.value)
 
     def set_workspace_limit(self, nbytes):
         self.check(self.lib.fcd_set_workspace_limit(self.ptr, int(nbytes)))

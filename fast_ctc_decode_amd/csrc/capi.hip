@@ -83,13 +83,25 @@ ResultDesc to_desc(const fcd_result *o) {
     return ResultDesc{o->labels, o->path, o->qual, o->out_len, o->status, o->out_stride};
 }
 
+// Brackets the kernel launches of one search call with HIP events on the launch stream.
 struct Timer {
     fcd_handle *h;
+    int slot;
     explicit Timer(fcd_handle *hh) : h(hh) {
-        h->last_ms = -1.0;
-        hipEventRecord(h->ev0, h->stream);
+        slot = (int)(h->n_timed % fcd_handle::kTimingRing);
+        if ((int)h->ev0.size() <= slot) {
+            hipEvent_t a = nullptr, b = nullptr;
+            (void)hipEventCreate(&a);
+            (void)hipEventCreate(&b);
+            h->ev0.push_back(a);
+            h->ev1.push_back(b);
+        }
+        (void)hipEventRecord(h->ev0[slot], h->stream);
     }
-    void stop() { hipEventRecord(h->ev1, h->stream); }
+    void stop() {
+        (void)hipEventRecord(h->ev1[slot], h->stream);
+        h->n_timed++;
+    }
 };
 
 int64_t workspace_budget(fcd_handle *h) {
@@ -190,19 +202,6 @@ int64_t span_elems(const fcd_batch *in, bool crf) {
     return s;
 }
 
-struct HostStage {
-    fcd_handle *h;
-    std::vector<std::pair<void *, size_t>> outs;  // (host dst, bytes) in staging order
-    char *base = nullptr;
-    size_t used = 0;
-    size_t cap = 0;
-    size_t reserve(size_t bytes) {
-        size_t off = (used + 255) & ~(size_t)255;
-        used = off + bytes;
-        return off;
-    }
-};
-
 }  // namespace
 
 // =============================================================================================
@@ -224,8 +223,7 @@ int fcd_create(int device, fcd_handle **out) {
     if (hipSetDevice(device) != hipSuccess) return FCD_E_HIP;
     fcd_handle *h = new fcd_handle();
     h->device = device;
-    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&h->ev0) != hipSuccess || hipEventCreate(&h->ev1) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         return FCD_E_HIP;
     }
@@ -236,13 +234,13 @@ int fcd_create(int device, fcd_handle **out) {
 
 int fcd_destroy(fcd_handle *h) {
     if (!h) return FCD_OK;
-    hipSetDevice(h->device);
-    hipStreamSynchronize(h->stream);
-    if (h->arena) hipFree(h->arena);
-    if (h->stage) hipFree(h->stage);
-    if (h->ev0) hipEventDestroy(h->ev0);
-    if (h->ev1) hipEventDestroy(h->ev1);
-    if (h->own_stream) hipStreamDestroy(h->own_stream);
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->stage) (void)hipFree(h->stage);
+    for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
+    for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
+    if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
     delete h;
     return FCD_OK;
 }
@@ -286,10 +284,35 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
 double fcd_last_kernel_ms(fcd_handle *h) {
     if (!h) return -1.0;
     std::lock_guard<std::mutex> g(h->mu);
-    if (hipEventSynchronize(h->ev1) != hipSuccess) return -1.0;
+    if (h->n_timed == 0) return -1.0;
+    const int slot = (int)((h->n_timed - 1) % fcd_handle::kTimingRing);
+    if (hipEventSynchronize(h->ev1[slot]) != hipSuccess) return -1.0;
     float ms = -1.0f;
-    if (hipEventElapsedTime(&ms, h->ev0, h->ev1) != hipSuccess) return -1.0;
+    if (hipEventElapsedTime(&ms, h->ev0[slot], h->ev1[slot]) != hipSuccess) return -1.0;
     return (double)ms;
+}
+
+int fcd_timing_reset(fcd_handle *h) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->n_timed = 0;
+    return FCD_OK;
+}
+
+double fcd_timing_mean_ms(fcd_handle *h, int64_t *n_calls) {
+    if (!h) return -1.0;
+    std::lock_guard<std::mutex> g(h->mu);
+    const int64_t n = std::min<int64_t>(h->n_timed, fcd_handle::kTimingRing);
+    if (n_calls) *n_calls = n;
+    if (n == 0) return -1.0;
+    double sum = 0.0;
+    for (int64_t i = 0; i < n; ++i) {
+        float ms = 0.0f;
+        if (hipEventSynchronize(h->ev1[i]) != hipSuccess) return -1.0;
+        if (hipEventElapsedTime(&ms, h->ev0[i], h->ev1[i]) != hipSuccess) return -1.0;
+        sum += ms;
+    }
+    return sum / (double)n;
 }
 
 // ---- viterbi -------------------------------------------------------------------------------

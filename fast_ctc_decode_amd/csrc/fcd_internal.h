@@ -7,6 +7,7 @@
 
 #include <mutex>
 #include <string>
+#include <vector>
 
 #include "../../include/fcd.h"
 
@@ -85,8 +86,10 @@ struct fcd_handle {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    double last_ms = -1.0;
+    // ring of (start, stop) event pairs, one per search call, recorded on the launch stream
+    static constexpr int kTimingRing = 256;
+    std::vector<hipEvent_t> ev0, ev1;
+    int64_t n_timed = 0;  // calls recorded since the last fcd_timing_reset
     int64_t ws_limit = 0;  // 0 = auto (half of the free device memory)
     // grow-only device workspace (tree arenas, staging for *_host calls)
     void *arena = nullptr;

@@ -127,6 +127,11 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes);
 /* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP
  * events on the stream the kernels were launched on; <0 if unavailable */
 double fcd_last_kernel_ms(fcd_handle *h);
+/* Every search call brackets its kernel launches with a HIP event pair on the launch stream
+ * (ring of 256).  fcd_timing_reset forgets them; fcd_timing_mean_ms synchronises on and averages
+ * the pairs recorded since the reset (n_calls, nullable, receives how many). */
+int fcd_timing_reset(fcd_handle *h);
+double fcd_timing_mean_ms(fcd_handle *h, int64_t *n_calls);
 
 /* ---- search::viterbi_search (src/search.rs:320-383) ---- */
 int fcd_viterbi_search_dev(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
