@@ -138,6 +138,10 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     } else if (kernel == FCD_KERNEL_AUTO) {
         use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf);
     }
+    if (use_wave && d.T >= (1ll << 26)) {  // depth is packed into 26 bits there
+        if (kernel == FCD_KERNEL_WAVE) return fail(h, FCD_E_UNSUPPORTED, "wave kernel: T must be < 2^26");
+        use_wave = false;
+    }
 
     // Worst-case tree size per read: every step every beam entry creates NL nodes
     // (tree.rs:125 add_node is only called from the expansion loop, search.rs:200-239).
@@ -145,7 +149,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     int64_t cap_nodes;
     size_t per_read;
     if (use_wave) {
-        cap_nodes = T * std::min<int64_t>(beam, 8) * NL + 8;
+        cap_nodes = (T * std::min<int64_t>(beam, 8) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
         const int row_words = NL <= 4 ? 4 : 8;
         per_read = (size_t)cap_nodes * (sizeof(int2) + row_words * 4);
     } else {

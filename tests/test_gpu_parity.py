@@ -47,31 +47,69 @@ def test_beam_generic_random(fcd, N, beam):
     check_beam(fcd, x, beam, thr, kernel=fcd.KERNEL_GENERIC)
 
 
+KERNELS = [1, 2]  # FCD_KERNEL_GENERIC (LDS-resident), FCD_KERNEL_WAVE (register-resident)
+
+
+@pytest.mark.parametrize("N", [3, 4, 5, 6, 7])
+@pytest.mark.parametrize("beam", [1, 2, 5, 8])
+def test_beam_wave_random(fcd, N, beam):
+    x = gen_batch(200 + N * 10 + beam, 6, 400, N)
+    check_beam(fcd, x, beam, 0.1 if N <= 5 else 0.05, kernel=fcd.KERNEL_WAVE)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
-def test_beam_generic_thr0(fcd, collapse):
+def test_beam_thr0(fcd, collapse, kernel):
     x = gen_batch(7, 4, 200, 5)
-    check_beam(fcd, x, 5, 0.0, collapse, kernel=fcd.KERNEL_GENERIC)
+    check_beam(fcd, x, 5, 0.0, collapse, kernel=kernel)
 
 
-def test_beam_generic_peaky(fcd):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_peaky(fcd, kernel):
     x = gen_batch(8, 8, 500, 5, peaky=True)
-    check_beam(fcd, x, 5, 0.001, kernel=fcd.KERNEL_GENERIC)
-    check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_GENERIC)  # many reads run out of beam: status parity
+    check_beam(fcd, x, 5, 0.001, kernel=kernel)
+    check_beam(fcd, x, 5, 0.1, kernel=kernel)  # many reads run out of beam: status parity
 
 
-def test_beam_ragged(fcd):
-    x = gen_batch(9, 5, 257, 5)
-    lengths = np.array([257, 1, 0, 100, 64], np.int64)
-    check_beam(fcd, x, 5, 0.1, lengths=lengths, kernel=fcd.KERNEL_GENERIC)
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_ragged(fcd, kernel):
+    x = gen_batch(9, 7, 257, 5)
+    lengths = np.array([257, 1, 0, 100, 64, 65, 128], np.int64)
+    check_beam(fcd, x, 5, 0.1, lengths=lengths, kernel=kernel)
 
 
-def test_beam_nan_and_zero_rows(fcd):
-    x = gen_batch(10, 4, 50, 5)
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_nan_and_zero_rows(fcd, kernel):
+    x = gen_batch(10, 5, 50, 5)
     x[0, 20] = np.nan           # NaN row -> IncomparableValues
     x[1, 10:] = 0.0             # all-zero rows with thr 0.1 -> RanOutOfBeam
     x[2, 5, 0] = np.nan         # NaN blank only
-    check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_GENERIC)
-    check_beam(fcd, x, 5, 0.0, kernel=fcd.KERNEL_GENERIC)
+    x[3, 7, 1:] = np.nan        # NaN labels only
+    x[4, :, :] = np.nan         # K16: everything NaN
+    check_beam(fcd, x, 5, 0.1, kernel=kernel)
+    check_beam(fcd, x, 5, 0.0, kernel=kernel)
+    check_beam(fcd, x, 1, 0.0, kernel=kernel)  # a lone NaN candidate is never compared
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_ties_and_zeros(fcd, kernel):
+    """Exact ties (equal probabilities, zeros) must resolve by ascending node index."""
+    rng = np.random.default_rng(77)
+    x = rng.integers(0, 3, size=(6, 300, 5)).astype(np.float32) * 0.25  # values in {0, .25, .5}
+    x[:, :, 0] = np.maximum(x[:, :, 0], 0.25)
+    check_beam(fcd, x, 5, 0.0, kernel=kernel)
+    check_beam(fcd, x, 5, 0.1, kernel=kernel)
+    check_beam(fcd, x, 3, 0.1, False, kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_denormals(fcd, kernel):
+    """f32 subnormals must not be flushed (the CPU reference keeps them)."""
+    x = gen_batch(12, 4, 200, 5) * np.float32(1e-38)
+    check_beam(fcd, x, 5, 0.0, kernel=kernel)
+    x2 = gen_batch(13, 4, 200, 5)
+    x2[:, ::3, :] *= np.float32(1e-30)
+    check_beam(fcd, x2, 5, 0.0, kernel=kernel)
 
 
 def test_beam_strided_view(fcd):
@@ -86,10 +124,24 @@ def test_beam_strided_view(fcd):
         np.testing.assert_array_equal(r.path[i, :n], path)
 
 
-def test_beam_full_size_reads(fcd):
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_full_size_reads(fcd, kernel):
     """BASELINE config 2 shape (T=4000, N=5, beam 5, thr 0.1) on a handful of reads."""
     x = gen_batch(1, 8, 4000, 5)
-    check_beam(fcd, x, 5, 0.1)
+    check_beam(fcd, x, 5, 0.1, kernel=kernel)
+
+
+def test_beam_many_reads_chunked(fcd):
+    """More reads than one workspace chunk holds: the C ABI decodes in chunks."""
+    from fast_ctc_decode_amd import _native as nat
+    x = gen_batch(14, 70, 300, 5)
+    h = nat.default_handle()
+    h.set_workspace_limit(8 << 20)
+    try:
+        check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_WAVE)
+        check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_GENERIC)
+    finally:
+        h.set_workspace_limit(0)
 
 
 def test_viterbi_random(fcd):
