@@ -107,18 +107,15 @@ def main():
     x = torch.from_numpy(x_host).to(dev)  # resident in HBM before the timed region
     torch.cuda.synchronize()
 
-    gather_bufs = None
+    from fast_ctc_decode_amd import dist as fdist
+    counts = [B] * world
+    scratch = {}
 
     def step():
         r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel)
         if distributed:
-            # ONE gather of fixed-stride results to rank 0 (RCCL over xGMI)
-            nonlocal gather_bufs
-            payload = (r.labels, r.path, r.out_len)
-            if gather_bufs is None and rank == 0:
-                gather_bufs = [[torch.empty_like(p) for _ in range(world)] for p in payload]
-            for j, p in enumerate(payload):
-                dist.gather(p, gather_bufs[j] if rank == 0 else None, dst=0)
+            # ONE gather of the packed fixed-stride results to rank 0 (RCCL over xGMI)
+            fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
         return r
 
     for _ in range(args.warmup):
