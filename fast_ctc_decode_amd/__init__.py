@@ -14,6 +14,9 @@ from .api import (  # noqa: F401
     beam_search_batch,
     beam_search_batch_raw,
     beam_search_duplex,
+    beam_search_duplex_batch,
+    beam_search_duplex_batch_raw,
+    set_duplex_logadd_mode,
     crf_beam_search,
     crf_beam_search_batch,
     crf_beam_search_batch_raw,
@@ -23,4 +26,4 @@ from .api import (  # noqa: F401
     viterbi_search_batch,
     viterbi_search_batch_raw,
 )
-from ._native import KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE  # noqa: F401
+from ._native import KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, LOGADD_LOGSUMEXP, LOGADD_MAX  # noqa: F401

@@ -219,23 +219,137 @@ def crf_greedy_search(network_output, init_state, alphabet, qstring=False, qscal
     return seq, [int(p) for p in out.path[0, :n]]
 
 
+_DEFAULT_LOGADD = [nat.LOGADD_LOGSUMEXP]
+
+
+def set_duplex_logadd_mode(mode):
+    """Select the duplex log-space addition: "logsumexp" (the reference built with
+    --no-default-features; BASELINE.json's north star) or "max" (the reference's default `fastexp`
+    feature, whose exp() is identically 0.0 -- what the PyPI wheels compute; SURVEY.md finding 3)."""
+    _DEFAULT_LOGADD[0] = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX,
+                          nat.LOGADD_LOGSUMEXP: nat.LOGADD_LOGSUMEXP,
+                          nat.LOGADD_MAX: nat.LOGADD_MAX}[mode]
+
+
+def _check_envelope(envelope, T1):
+    """src/lib.rs:445-456"""
+    if envelope is None:
+        return
+    if not isinstance(envelope, np.ndarray) or envelope.dtype != np.uint64 or envelope.ndim != 2:
+        raise TypeError("argument 'envelope': expected a 2-dimensional uint64 array")
+    if envelope.shape[0] != T1:
+        raise ValueError("the lengths of network_output_1 and envelope do not match")
+    if envelope.shape[1] != 2:
+        raise ValueError("the inner axis of envelope must have size 2")
+
+
+def _default_envelope(B, T1, T2):
+    """src/lib.rs:459-468: every row searches the whole of read 2."""
+    env = np.empty((B, max(T1, 1), 2), np.uint64)
+    env[:, :, 0] = 0
+    env[:, :, 1] = T2
+    return env
+
+
+def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes=None, beam_size=5,
+                                 beam_cut_threshold=0.0, collapse_repeats=True, lengths_1=None,
+                                 lengths_2=None, logadd_mode=None):
+    """(B,T1,N) and (B,T2,N) posteriors + (B,T1,2) uint64 envelopes -> BatchResult (labels only)."""
+    mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
+    if _is_torch_cuda(network_outputs_1):
+        import torch
+        x1, x2 = network_outputs_1, network_outputs_2
+        if x1.dtype != torch.float32 or x2.dtype != torch.float32:
+            raise TypeError("device posteriors must be float32")
+        B, T1, N = x1.shape
+        T2 = x2.shape[1]
+        dev = x1.device
+        if envelopes is None:
+            env = torch.from_numpy(_default_envelope(B, T1, T2).view(np.int64)).to(dev)
+        elif isinstance(envelopes, np.ndarray):
+            env = torch.from_numpy(np.ascontiguousarray(envelopes, np.uint64).view(np.int64)).to(dev)
+        else:
+            env = envelopes.contiguous()  # int64 tensor holding the u64 bit patterns
+        h = nat.default_handle(dev.index or 0)
+        s1, s2 = x1.stride(), x2.stride()
+        b1 = nat.Batch(x1.data_ptr(), B, T1, 1, N, s1[0], s1[1], 0, s1[2], None)
+        b2 = nat.Batch(x2.data_ptr(), B, T2, 1, N, s2[0], s2[1], 0, s2[2], None)
+        keep = [x1, x2, env]
+        if lengths_1 is not None:
+            l1 = torch.as_tensor(lengths_1, dtype=torch.int64, device=dev).contiguous()
+            b1.lengths = l1.data_ptr()
+            keep.append(l1)
+        if lengths_2 is not None:
+            l2 = torch.as_tensor(lengths_2, dtype=torch.int64, device=dev).contiguous()
+            b2.lengths = l2.data_ptr()
+            keep.append(l2)
+        w = max(int(T1), 1)
+        labels = torch.empty((B, w), dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        res = nat.Result(labels.data_ptr(), None, None, out_len.data_ptr(), status.data_ptr(), w)
+        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        h.check(h.lib.fcd_beam_search_duplex_dev(
+            h.ptr, C.byref(b1), C.byref(b2), C.c_void_p(env.data_ptr()), int(env.shape[1]),
+            int(beam_size), float(beam_cut_threshold), int(bool(collapse_repeats)), int(mode),
+            C.byref(res)))
+        r = BatchResult(labels, None, out_len, status)
+        r._handle, r._keep = h, keep
+        return r
+    x1 = _stack_host(network_outputs_1, 3)
+    x2 = _stack_host(network_outputs_2, 3)
+    B, T1, N = x1.shape
+    T2 = x2.shape[1]
+    if x2.shape[0] != B:
+        raise ValueError("both batches must hold the same number of reads")
+    env = _default_envelope(B, T1, T2) if envelopes is None else np.ascontiguousarray(envelopes, np.uint64)
+    if env.shape[0] != B or env.ndim != 3 or env.shape[2] != 2 or env.shape[1] < T1:
+        raise ValueError("envelopes must have shape (n_pairs, T1, 2)")
+    h = nat.default_handle()
+    out = _HostOut(B, T1, want_path=False)
+    l1, l2 = _np_lengths(lengths_1, B), _np_lengths(lengths_2, B)
+    b1, b2 = _host_batch(x1, False, l1), _host_batch(x2, False, l2)
+    h.check(h.lib.fcd_beam_search_duplex_host(
+        h.ptr, C.byref(b1), C.byref(b2), env.ctypes.data, int(env.shape[1]), int(beam_size),
+        float(beam_cut_threshold), int(bool(collapse_repeats)), int(mode), C.byref(out.res)))
+    r = BatchResult(out.labels, None, out.out_len, out.status)
+    r._handle = h
+    return r
+
+
 def beam_search_duplex(network_output_1, network_output_2, alphabet, envelope=None, beam_size=5,
-                       beam_cut_threshold=0.0, collapse_repeats=True):
-    """Mirrors src/lib.rs:401-488 -> duplex.rs:443-650."""
+                       beam_cut_threshold=0.0, collapse_repeats=True, *, logadd_mode=None):
+    """Mirrors src/lib.rs:401-488 -> duplex.rs:443-650.  Returns the consensus sequence (str).
+    `logadd_mode` (keyword-only, not a reference argument) overrides set_duplex_logadd_mode()."""
     x1 = _as_f32(network_output_1, 2, "network_output_1")
     x2 = _as_f32(network_output_2, 2, "network_output_2")
     alpha = _seq_to_vec(alphabet)
     if x1.shape[1] != x2.shape[1]:
         raise ValueError("inner axes of the network outputs do not match")
     _check_beam_args(len(alpha), x1.shape[1], beam_size, beam_cut_threshold)
-    if envelope is not None:
-        if not isinstance(envelope, np.ndarray) or envelope.dtype != np.uint64 or envelope.ndim != 2:
-            raise TypeError("argument 'envelope': expected a 2-dimensional uint64 array")
-        if envelope.shape[0] != x1.shape[0]:
-            raise ValueError("the lengths of network_output_1 and envelope do not match")
-        if envelope.shape[1] != 2:
-            raise ValueError("the inner axis of envelope must have size 2")
-    raise NotImplementedError("beam_search_duplex: the HIP duplex kernel is not built yet")
+    _check_envelope(envelope, x1.shape[0])
+    if x1.shape[0] == 0:
+        raise RuntimeError("network_output_1 is empty (the reference indexes envelope[(0,1)] and aborts)")
+    env = None if envelope is None else np.ascontiguousarray(envelope)[None]
+    r = beam_search_duplex_batch_raw(_dense(x1)[None], _dense(x2)[None], env, beam_size,
+                                     beam_cut_threshold, collapse_repeats, logadd_mode=logadd_mode)
+    _raise_status(int(r.status[0]))
+    n = int(r.out_len[0])
+    return "".join(alpha[l] for l in r.labels[0, :n])
+
+
+def beam_search_duplex_batch(network_outputs_1, network_outputs_2, alphabet, envelopes=None,
+                             beam_size=5, beam_cut_threshold=0.0, collapse_repeats=True,
+                             lengths_1=None, lengths_2=None, logadd_mode=None):
+    """Batched beam_search_duplex -> list[str]."""
+    alpha = _seq_to_vec(alphabet)
+    if network_outputs_1.shape[-1] != network_outputs_2.shape[-1]:
+        raise ValueError("inner axes of the network outputs do not match")
+    _check_beam_args(len(alpha), network_outputs_1.shape[-1], beam_size, beam_cut_threshold)
+    r = beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes, beam_size,
+                                     beam_cut_threshold, collapse_repeats, lengths_1, lengths_2,
+                                     logadd_mode).cpu()
+    return [s for s, _ in r.sequences(alpha)]
 
 
 def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, init_state_2,

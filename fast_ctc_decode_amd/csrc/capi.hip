@@ -242,6 +242,7 @@ int fcd_destroy(fcd_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->lnbuf) (void)hipFree(h->lnbuf);
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -385,15 +386,156 @@ int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *i
     return FCD_OK;
 }
 
-int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *, const fcd_batch *, const uint64_t *,
-                               int64_t, int64_t, float, int, int, const fcd_result *) {
-    return fail(h, FCD_E_UNSUPPORTED, "duplex search is not implemented yet");
+int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
+                               const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                               float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                               const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    int rc = check_batch(h, in1, false);
+    if (rc) return rc;
+    rc = check_batch(h, in2, false);
+    if (rc) return rc;
+    if (in1->n_reads != in2->n_reads) return fail(h, FCD_E_INVALID, "pair counts differ");
+    if (in1->N != in2->N) return fail(h, FCD_E_INVALID, "inner axes of the network outputs do not match");
+    if (in1->N < 2) return fail(h, FCD_E_UNSUPPORTED, "alphabet needs at least one label besides the blank");
+    if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
+    if (logadd_mode != FCD_LOGADD_LOGSUMEXP && logadd_mode != FCD_LOGADD_MAX)
+        return fail(h, FCD_E_INVALID, "unknown logadd_mode");
+    if (!out) return fail(h, FCD_E_INVALID, "null result");
+    const int64_t B = in1->n_reads;
+    if (B == 0) return FCD_OK;
+    if (!out->labels || !out->out_len || !out->status) return fail(h, FCD_E_INVALID, "null output array");
+    if (out->out_stride < in1->T) return fail(h, FCD_E_INVALID, "out_stride must be >= T1");
+    if (!envelope || env_stride < in1->T) return fail(h, FCD_E_INVALID, "envelope missing or shorter than read 1");
+    if (beam_size > (1 << 12)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 4096");
+    const int N = (int)in1->N, NL = N - 1;
+    if (duplex_lds_bytes((int)beam_size, N) > 64 * 1024)
+        return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
+    FCD_HIP(h, hipSetDevice(h->device));
+
+    // log-space copies + one int for the envelope width
+    const int64_t T1 = std::max<int64_t>(in1->T, 1), T2 = std::max<int64_t>(in2->T, 1);
+    const size_t n1 = (size_t)B * T1 * N, n2 = (size_t)B * T2 * N;
+    rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, (n1 + n2) * 4 + 256);
+    if (rc) return rc;
+    float *ln1 = reinterpret_cast<float *>(h->lnbuf);
+    float *ln2 = ln1 + n1;
+    int *d_width = reinterpret_cast<int *>(ln2 + n2);
+    Timer tm(h);
+    FCD_HIP(h, launch_ln_convert(in1->post, B, in1->T, N, in1->stride_read, in1->stride_t,
+                                 in1->stride_n, ln1, h->stream));
+    FCD_HIP(h, launch_ln_convert(in2->post, B, in2->T, N, in2->stride_read, in2->stride_t,
+                                 in2->stride_n, ln2, h->stream));
+    FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), h->stream));
+    FCD_HIP(h, launch_env_width(envelope, B, env_stride, in1->T, in2->T, in1->lengths,
+                                in2->lengths, d_width, h->stream));
+    int width = 0;
+    FCD_HIP(h, hipMemcpyAsync(&width, d_width, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipStreamSynchronize(h->stream));  // ring capacity is needed to size the arena
+    const int Wcap = std::max(width, 1) + 2;
+
+    const int64_t cap_nodes = (std::max<int64_t>(in1->T, 1) * beam_size * NL + 8 + 3) & ~3ll;
+    if (cap_nodes >= (1ll << 30)) return fail(h, FCD_E_UNSUPPORTED, "tree arena above 2^30 nodes per pair");
+    const size_t per_pair = (size_t)cap_nodes * (sizeof(int4) + 4 + (size_t)NL * 4 + (size_t)Wcap * 12) +
+                            (size_t)(in2->T + 1) * 4 + 64;
+    const int64_t budget = workspace_budget(h);
+    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_pair);
+    chunk = std::min<int64_t>(chunk, B);
+    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
+    if (rc) return rc;
+
+    DuplexArgs a;
+    a.ln1 = ln1; a.ln2 = ln2; a.T1cap = in1->T; a.T2cap = in2->T;
+    a.len1 = in1->lengths; a.len2 = in2->lengths; a.env = envelope; a.env_stride = env_stride;
+    a.N = N; a.beam_size = (int)beam_size;
+    // ln(threshold) with the kernels' definition of ln: correctly rounded f32 (duplex.rs:454)
+    a.thr_ln = (float)log((double)beam_cut_threshold);
+    a.collapse = collapse_repeats ? 1 : 0; a.mode = logadd_mode;
+    char *base = reinterpret_cast<char *>(h->arena);
+    a.meta = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
+    a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
+    a.rows = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * NL * 4;
+    a.vec = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * (size_t)Wcap * 12;
+    a.rootgap = reinterpret_cast<float *>(base);
+    a.cap_nodes = cap_nodes; a.Wcap = Wcap;
+    a.out = to_desc(out);
+    for (int64_t begin = 0; begin < B; begin += chunk) {
+        const int64_t n = std::min<int64_t>(chunk, B - begin);
+        FCD_HIP(h, launch_duplex(a, begin, n, h->stream));
+    }
+    tm.stop();
+    return FCD_OK;
 }
 
-int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *, const fcd_batch *,
-                                const uint64_t *, int64_t, int64_t, float, int, int,
-                                const fcd_result *) {
-    return fail(h, FCD_E_UNSUPPORTED, "duplex search is not implemented yet");
+int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
+                                const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                                const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        int rc = check_batch(h, in1, false);
+        if (rc) return rc;
+        rc = check_batch(h, in2, false);
+        if (rc) return rc;
+        if (in1->n_reads != in2->n_reads) return fail(h, FCD_E_INVALID, "pair counts differ");
+        if (!out || !envelope) return fail(h, FCD_E_INVALID, "null result/envelope");
+        if (in1->stride_read < 0 || in1->stride_t < 0 || in1->stride_n < 0 || in2->stride_read < 0 ||
+            in2->stride_t < 0 || in2->stride_n < 0)
+            return fail(h, FCD_E_UNSUPPORTED, "negative strides: pass a contiguous copy");
+    }
+    const int64_t B = in1->n_reads;
+    if (B == 0) return FCD_OK;
+    if (!out->labels || !out->out_len || !out->status) return fail(h, FCD_E_INVALID, "null output array");
+    const size_t e1 = (size_t)span_elems(in1, false), e2 = (size_t)span_elems(in2, false);
+    const size_t n_env = (size_t)B * (size_t)env_stride * 2;
+    const size_t n_out = (size_t)B * (size_t)out->out_stride;
+    size_t used = 0;
+    auto reserve = [&](size_t bytes) {
+        size_t off = (used + 255) & ~(size_t)255;
+        used = off + std::max<size_t>(bytes, 8);
+        return off;
+    };
+    const size_t o1 = reserve(e1 * 4), o2 = reserve(e2 * 4), oe = reserve(n_env * 8);
+    const size_t ol1 = reserve(in1->lengths ? (size_t)B * 8 : 0);
+    const size_t ol2 = reserve(in2->lengths ? (size_t)B * 8 : 0);
+    const size_t olab = reserve(n_out), oolen = reserve((size_t)B * 4), ostat = reserve((size_t)B * 4);
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        FCD_HIP(h, hipSetDevice(h->device));
+        int rc = ensure(h, &h->stage, &h->stage_bytes, used);
+        if (rc) return rc;
+        char *base = reinterpret_cast<char *>(h->stage);
+        if (e1) FCD_HIP(h, hipMemcpyAsync(base + o1, in1->post, e1 * 4, hipMemcpyHostToDevice, h->stream));
+        if (e2) FCD_HIP(h, hipMemcpyAsync(base + o2, in2->post, e2 * 4, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(base + oe, envelope, n_env * 8, hipMemcpyHostToDevice, h->stream));
+        if (in1->lengths)
+            FCD_HIP(h, hipMemcpyAsync(base + ol1, in1->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        if (in2->lengths)
+            FCD_HIP(h, hipMemcpyAsync(base + ol2, in2->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+    }
+    char *base = reinterpret_cast<char *>(h->stage);
+    fcd_batch d1 = *in1, d2 = *in2;
+    d1.post = reinterpret_cast<const float *>(base + o1);
+    d2.post = reinterpret_cast<const float *>(base + o2);
+    d1.lengths = in1->lengths ? reinterpret_cast<const int64_t *>(base + ol1) : nullptr;
+    d2.lengths = in2->lengths ? reinterpret_cast<const int64_t *>(base + ol2) : nullptr;
+    fcd_result dout{};
+    dout.labels = reinterpret_cast<uint8_t *>(base + olab);
+    dout.out_len = reinterpret_cast<uint32_t *>(base + oolen);
+    dout.status = reinterpret_cast<int32_t *>(base + ostat);
+    dout.out_stride = out->out_stride;
+    int rc = fcd_beam_search_duplex_dev(h, &d1, &d2, reinterpret_cast<const uint64_t *>(base + oe),
+                                        env_stride, beam_size, beam_cut_threshold, collapse_repeats,
+                                        logadd_mode, &dout);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    return FCD_OK;
 }
 
 // ---- *_host: stage host buffers through device memory, run the *_dev path, copy back -------

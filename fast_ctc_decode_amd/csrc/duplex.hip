@@ -1,0 +1,588 @@
+// duplex.hip -- 2D pair-consensus beam search, duplex::beam_search
+// (/root/reference/src/duplex.rs:443-650), one read PAIR per wavefront.
+//
+// The search over read 1 is the 1D prefix beam search of beam_generic.hip carried out in log
+// space (LogSpace, duplex.rs:7-80) without per-step renormalisation; every tree node additionally
+// owns a windowed CTC forward vector over read 2 ("SecondaryProbs", :152-210): (label, gap) log
+// probabilities of the node's labelling ending at each row of read 2 inside the envelope, and
+// their running maximum.  A candidate's score is prob_1 (+) max over the window of prob_2 (:146-148).
+//
+// Layout: the beam is a structure of arrays in LDS (as in beam_generic.hip).  Forward vectors
+// live in the per-pair HBM arena as rings of Wcap = (widest envelope + 2) entries of
+// {label, gap, label(+)gap}; entry for row t sits at slot t mod Wcap, so the reference's
+// discard_until (:181-191) is a pure offset update.  Storing label(+)gap makes update_max
+// (:193-204) a transcendental-free max-reduction done by all 64 lanes.
+// Per row of read 1:
+//   1. envelope check (:485-488);
+//   2. if the upper bound grew (:490-522): beam re-sorted by node (parents first) and every beam
+//      node's vector extended to the new bound -- sequential per node, as the recurrence is;
+//   3. expansion (:526-593): slot (i,k) evaluation as in the 1D kernel; every NEW node builds its
+//      whole window (:212-249), one node per lane, all new nodes of the step in parallel;
+//   4. merge / prob_2_max refresh / NaN check / exact rank on (probability desc, node asc) /
+//      truncate (:597-636).
+//
+// Log-space addition (:42-63): big + ln_1p(exp(small - big)).  The reference calls the platform
+// libm through Rust's f32::exp / ln_1p, whose last bit depends on the glibc version; this kernel
+// defines them as CORRECTLY ROUNDED f32 results (evaluated in f64 and rounded once), which is what
+// glibc >= 2.41 (CORE-MATH) returns.  mode FCD_LOGADD_MAX reproduces builds with the reference's
+// default `fastexp` feature, where exp() is identically 0 and the addition degenerates to max().
+#include "device_utils.h"
+#include "fcd_internal.h"
+
+namespace fcd {
+
+namespace {
+
+struct DuplexParams {
+    const float *ln1, *ln2;   // log-space posteriors, [pair][Tcap][N] contiguous
+    int64_t T1cap, T2cap;
+    const int64_t *len1, *len2;  // nullable per-pair row counts
+    const uint64_t *env;         // [pair][env_stride][2]
+    int64_t env_stride;
+    int N;
+    int beam_size;
+    float thr_ln;
+    int collapse;
+    int mode;
+    // arena (per pair slabs)
+    int4 *meta;      // {parent, label, offset, end}
+    float *nmax;     // running max per node
+    int32_t *rows;   // NL child ids per node
+    float *vec;      // Wcap * 3 floats per node
+    float *rootgap;  // T2cap + 1 per pair
+    int64_t cap_nodes;
+    int Wcap;
+    ResultDesc out;
+    int64_t pair_begin;
+};
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+__device__ __forceinline__ float ln_cr(float x) { return (float)log((double)x); }
+
+template <int MODE>
+__device__ __forceinline__ float ladd(float a, float b) {
+    // duplex.rs:42-63: operands ordered so that a NaN ends up in `big`
+    float big, small;
+    if (a <= b) {
+        big = b;
+        small = a;
+    } else {
+        big = a;
+        small = b;
+    }
+    if (small == kNegInf) return big;
+    if (MODE == FCD_LOGADD_MAX) return big + 0.0f;
+    const float e = (float)exp((double)(small - big));
+    return big + (float)log1p((double)e);
+}
+
+__device__ __forceinline__ float lmax(float self, float other) { return self < other ? other : self; }
+
+__device__ __forceinline__ float load_f32_l2(const float *p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ int4 load_meta_l2(const int4 *p) {
+    const int32_t *q = reinterpret_cast<const int32_t *>(p);
+    return make_int4(load_i32_l2(q), load_i32_l2(q + 1), load_i32_l2(q + 2), load_i32_l2(q + 3));
+}
+
+struct DLds {
+    int *b_node[2];
+    float *b_lp[2];
+    float *b_gp[2];
+    int *b_tip[2];
+    int *b_par[2];
+    int *b_child[2];
+    uint64_t *c_key;
+    float *c_lp, *c_gp, *c_p2;
+    int *c_id, *c_new;
+    int *nb_src;
+};
+
+__host__ __device__ inline size_t dlds_words(int BC, int N) {
+    const int NL = N - 1;
+    const size_t C = (size_t)BC * N;
+    return 2 * (size_t)BC * (5 + NL) + 2 * C + 5 * C + BC + 4;
+}
+
+__device__ inline DLds dcarve(int *smem, int BC, int N) {
+    DLds L;
+    const int NL = N - 1;
+    const size_t C = (size_t)BC * N;
+    L.c_key = reinterpret_cast<uint64_t *>(smem);
+    int *p = smem + 2 * C;
+    L.c_lp = reinterpret_cast<float *>(p); p += C;
+    L.c_gp = reinterpret_cast<float *>(p); p += C;
+    L.c_p2 = reinterpret_cast<float *>(p); p += C;
+    L.c_id = p; p += C;
+    L.c_new = p; p += C;
+    for (int b = 0; b < 2; ++b) {
+        L.b_node[b] = p; p += BC;
+        L.b_lp[b] = reinterpret_cast<float *>(p); p += BC;
+        L.b_gp[b] = reinterpret_cast<float *>(p); p += BC;
+        L.b_tip[b] = p; p += BC;
+        L.b_par[b] = p; p += BC;
+        L.b_child[b] = p; p += (size_t)BC * NL;
+    }
+    L.nb_src = p;
+    return L;
+}
+
+// Forward vector access: the reference's SecondaryProbs::get (:167-179) on a ring.
+struct VecRef {
+    const float *base;  // node's ring (Wcap*3 floats) or the root's gap array
+    int offset, end;    // rows [offset, end) are present
+    bool root;
+};
+
+__device__ __forceinline__ void vec_get(const VecRef &v, int at, int Wcap, float &gap, float &sum) {
+    if (at < v.offset || at >= v.end) {
+        gap = kNegInf;
+        sum = kNegInf;
+        return;
+    }
+    if (v.root) {  // root_probs (:389-409): label = zero, gap = cumulative blank product
+        gap = load_f32_l2(v.base + (at + 1));
+        sum = gap;
+        return;
+    }
+    const int slot = at % Wcap;
+    gap = load_f32_l2(v.base + 3 * slot + 1);
+    sum = load_f32_l2(v.base + 3 * slot + 2);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x;
+    const int64_t local = blockIdx.x;
+    const int64_t r = p.pair_begin + local;
+    const int N = p.N, NL = N - 1, BC = p.beam_size, Wcap = p.Wcap;
+    const bool collapse = p.collapse != 0;
+    const float thr = p.thr_ln;
+    DLds L = dcarve(smem, BC, N);
+
+    int64_t T1 = p.T1cap, T2 = p.T2cap;
+    if (p.len1) { int64_t t = p.len1[r]; T1 = t < 0 ? 0 : (t < T1 ? t : T1); }
+    if (p.len2) { int64_t t = p.len2[r]; T2 = t < 0 ? 0 : (t < T2 ? t : T2); }
+    const float *ln1 = p.ln1 + r * p.T1cap * N;
+    const float *ln2 = p.ln2 + r * p.T2cap * N;
+    const uint64_t *env = p.env + r * p.env_stride * 2;
+    int4 *meta = p.meta + local * p.cap_nodes;
+    float *nmax = p.nmax + local * p.cap_nodes;
+    int32_t *rows = p.rows + local * p.cap_nodes * NL;
+    float *vec = p.vec + local * p.cap_nodes * (int64_t)Wcap * 3;
+    float *rootgap = p.rootgap + local * (p.T2cap + 1);
+    uint8_t *lab_out = p.out.labels + r * p.out.out_stride;
+
+    auto fail = [&](int code) {
+        if (lane == 0) {
+            p.out.status[r] = code;
+            p.out.out_len[r] = 0;
+        }
+    };
+
+    // ---- root_probs (:389-409): needs envelope[(0,1)], so an empty read 1 panics in the reference
+    if (T1 <= 0) return fail(FCD_ST_BAD_STATE);
+    const uint64_t ub_u = env[1];
+    if (ub_u > (uint64_t)T2) return fail(FCD_ST_BAD_STATE);  // slice(s![..upper_bound]) panics
+    const int root_end = (int)ub_u;                            // root rows are [-1, ub)
+    if (lane == 0) {
+        float cur = 0.0f;
+        rootgap[0] = cur;
+        for (int t = 0; t < root_end; ++t) {
+            cur = cur + ln2[(int64_t)t * N];
+            rootgap[t + 1] = cur;
+        }
+        L.b_node[0][0] = -1;
+        L.b_lp[0][0] = kNegInf;  // label: zero
+        L.b_gp[0][0] = 0.0f;     // gap: one
+        L.b_tip[0][0] = -1;
+        L.b_par[0][0] = -2;
+    }
+    for (int j = lane; j < NL; j += kWave) L.b_child[0][j] = -1;
+    __syncthreads();
+
+    int cur = 0, B = 1, nn = 0;
+    int last_hi = 0;
+
+    auto node_vec = [&](int node, int off, int end) {
+        VecRef v;
+        if (node < 0) {
+            v.base = rootgap;
+            v.offset = -1;
+            v.end = root_end;
+            v.root = true;
+        } else {
+            v.base = vec + (int64_t)node * Wcap * 3;
+            v.offset = off;
+            v.end = end;
+            v.root = false;
+        }
+        return v;
+    };
+
+    for (int64_t t1 = 0; t1 < T1; ++t1) {
+        // ---- envelope (:485-488) ----
+        const uint64_t lo_u = env[2 * t1], hi_u = env[2 * t1 + 1];
+        const int hi = (int)(hi_u > (uint64_t)T2 ? (uint64_t)T2 : hi_u);
+        if (lo_u >= (uint64_t)hi || lo_u > (uint64_t)last_hi) return fail(FCD_ST_INVALID_ENVELOPE);
+        const int lo = (int)lo_u;
+
+        if (hi > last_hi) {
+            // ---- :493 beam.sort_by_key(node): parents before children ----
+            const int nx = cur ^ 1;
+            for (int e = lane; e < B; e += kWave) {
+                const int nd = L.b_node[cur][e];
+                int rk = 0;
+                for (int j = 0; j < B; ++j) rk += (L.b_node[cur][j] < nd) ? 1 : 0;
+                L.b_node[nx][rk] = nd;
+                L.b_lp[nx][rk] = L.b_lp[cur][e];
+                L.b_gp[nx][rk] = L.b_gp[cur][e];
+                L.b_tip[nx][rk] = L.b_tip[cur][e];
+                L.b_par[nx][rk] = L.b_par[cur][e];
+                for (int l = 0; l < NL; ++l) L.b_child[nx][rk * NL + l] = L.b_child[cur][e * NL + l];
+            }
+            cur = nx;
+            __syncthreads();
+            // ---- extend_secondary_probs (:338-387) for every beam node, in that order ----
+            for (int e = 0; e < B; ++e) {
+                const int node = L.b_node[cur][e];
+                if (node < 0) continue;
+                const int4 m = load_meta_l2(&meta[node]);
+                const int parent = m.x, lab = m.y;
+                int off = m.z, end = m.w;
+                float mx = load_f32_l2(&nmax[node]);
+                int p_off = 0, p_end = 0, p_lab = -1;
+                if (parent >= 0) {
+                    const int4 pm = load_meta_l2(&meta[parent]);
+                    p_lab = pm.y;
+                    p_off = pm.z;
+                    p_end = pm.w;
+                }
+                const VecRef pv = node_vec(parent, p_off, p_end);
+                const bool is_rep = parent >= 0 && p_lab == lab;  // :512, no collapse_repeats test
+                float *my = vec + (int64_t)node * Wcap * 3;
+                if (lo > off) {  // :351-359
+                    const int keep = lo - 1;
+                    if (keep > off) {  // discard_until
+                        if (keep < end) off = keep;
+                        else { off = keep; end = keep; }
+                    }
+                    if (end == off) { off = lo; end = lo; }
+                    // update_max(lo, hi): max of label(+)gap over rows [lo,hi) that are present
+                    const int b0 = lo > off ? lo : off;
+                    const int e0 = hi < end ? hi : end;
+                    float part = kNegInf;
+                    for (int t = b0 + lane; t < e0; t += kWave) {
+                        const float s = load_f32_l2(my + 3 * (t % Wcap) + 2);
+                        part = lmax(part, s);  // NaN entries never replace the running max
+                    }
+                    for (int o = 32; o > 0; o >>= 1) part = lmax(part, __shfl_xor(part, o));
+                    mx = part;
+                }
+                // continue the recurrence from the stored end (:361-386); wave-uniform work
+                float l_lab = kNegInf, l_gap = kNegInf, l_sum = kNegInf;
+                if (end > off) {
+                    const int s = (end - 1) % Wcap;
+                    l_lab = load_f32_l2(my + 3 * s);
+                    l_gap = load_f32_l2(my + 3 * s + 1);
+                    l_sum = load_f32_l2(my + 3 * s + 2);
+                }
+                (void)l_gap;
+                for (int idx = end; idx < hi; ++idx) {
+                    const float *row = ln2 + (int64_t)idx * N;
+                    float pg, ps;
+                    vec_get(pv, idx - 1, Wcap, pg, ps);
+                    const float g = l_sum + row[0];
+                    const float x = is_rep ? pg : ps;
+                    const float lb = row[lab + 1] + ladd<MODE>(l_lab, x);
+                    const float sm = ladd<MODE>(lb, g);
+                    if (lane == 0) {
+                        const int s = idx % Wcap;
+                        my[3 * s] = lb;
+                        my[3 * s + 1] = g;
+                        my[3 * s + 2] = sm;
+                    }
+                    mx = lmax(mx, sm);
+                    l_lab = lb;
+                    l_sum = sm;
+                }
+                if (hi > end) end = hi;
+                if (lane == 0) {
+                    meta[node] = make_int4(parent, lab, off, end);
+                    nmax[node] = mx;
+                }
+                __syncthreads();  // the next node may read this one's new rows (parents first)
+            }
+        }
+        last_hi = hi;
+
+        int *b_node = L.b_node[cur], *b_tip = L.b_tip[cur], *b_par = L.b_par[cur];
+        int *b_child = L.b_child[cur];
+        float *b_lp = L.b_lp[cur], *b_gp = L.b_gp[cur];
+        const int nslots = B * N;
+        const float *row1 = ln1 + t1 * N;
+        int n_valid = 0;
+        bool any_nan = false;
+
+        // ---- expansion (:526-593) ----
+        for (int base = 0; base < nslots; base += kWave) {
+            const int c = base + lane;
+            const bool act = c < nslots;
+            const int i = act ? c / N : 0;
+            const int k = act ? c - i * N : 0;
+            const int node = b_node[i];
+            const float lp = b_lp[i], gp = b_gp[i];
+            const int tip = b_tip[i];
+            bool valid = false, is_new = false, rep = false;
+            float clp = kNegInf, cgp = kNegInf, p2 = 0.0f;
+            int cid = -2;
+            if (act) {
+                if (k == 0) {
+                    const float pr0 = row1[0];
+                    const bool blank = pr0 > thr;  // :529
+                    if (blank) cgp = ladd<MODE>(lp, gp) + pr0;
+                    bool stay = collapse && tip >= 0;
+                    if (stay) {
+                        const float pt = row1[tip + 1];
+                        stay = !(pt < thr);
+                        if (stay) clp = lp + pt;  // :541-544
+                    }
+                    bool inc = false;
+                    if (node >= 0) {
+                        const int par = b_par[i];
+                        for (int j = 0; j < B; ++j) {
+                            if (b_node[j] == par) {
+                                const float pl = row1[tip + 1];
+                                if (!(pl < thr)) {
+                                    const bool rj = collapse && b_tip[j] == tip;
+                                    const float lpj = b_lp[j], gpj = b_gp[j];
+                                    const float contrib = rj ? gpj + pl : ladd<MODE>(lpj, gpj) + pl;
+                                    clp = ladd<MODE>(clp, contrib);  // :604 prob_1 += (commutative)
+                                    inc = true;
+                                }
+                                break;
+                            }
+                        }
+                    }
+                    valid = blank || stay || inc;
+                    cid = node;
+                } else {
+                    const int l = k - 1;
+                    const float pk = row1[k];
+                    const bool pass = !(pk < thr);  // :537
+                    rep = collapse && l == tip;
+                    const float contrib = rep ? gp + pk : ladd<MODE>(lp, gp) + pk;
+                    const int ch = b_child[i * NL + l];
+                    const bool exists = ch >= 0;
+                    valid = pass && (exists || !rep || gp > kNegInf);  // :546
+                    if (valid && exists) {
+                        for (int j = 0; j < B; ++j)
+                            if (b_node[j] == ch) {
+                                valid = false;
+                                break;
+                            }
+                    }
+                    is_new = valid && !exists;
+                    clp = contrib;
+                    cid = ch;
+                }
+            }
+            const uint64_t m_new = __ballot(is_new);
+            if (is_new) {
+                cid = nn + popc64(m_new & lanemask_lt());
+                if (cid < p.cap_nodes) {
+                    // build_secondary_probs (:212-249): whole window [lo, hi), one node per lane
+                    const int l = k - 1;
+                    int p_off = 0, p_end = 0;
+                    if (node >= 0) {
+                        const int4 pm = load_meta_l2(&meta[node]);
+                        p_off = pm.z;
+                        p_end = pm.w;
+                    }
+                    const VecRef pv = node_vec(node, p_off, p_end);
+                    float *my = vec + (int64_t)cid * Wcap * 3;
+                    float l_lab = kNegInf, l_sum = kNegInf, mx = kNegInf;
+                    int s = lo % Wcap;
+                    for (int idx = lo; idx < hi; ++idx) {
+                        const float *row = ln2 + (int64_t)idx * N;
+                        float pg, ps;
+                        vec_get(pv, idx - 1, Wcap, pg, ps);
+                        const float g = l_sum + row[0];
+                        const float x = rep ? pg : ps;
+                        const float lb = row[l + 1] + ladd<MODE>(l_lab, x);
+                        const float sm = ladd<MODE>(lb, g);
+                        my[3 * s] = lb;
+                        my[3 * s + 1] = g;
+                        my[3 * s + 2] = sm;
+                        mx = lmax(mx, sm);
+                        l_lab = lb;
+                        l_sum = sm;
+                        if (++s == Wcap) s = 0;
+                    }
+                    meta[cid] = make_int4(node, l, lo, hi);
+                    nmax[cid] = mx;
+                    for (int j = 0; j < NL; ++j) rows[(int64_t)cid * NL + j] = -1;
+                    if (node >= 0) rows[(int64_t)node * NL + l] = cid;
+                    b_child[i * NL + l] = cid;
+                    p2 = mx;
+                }
+            } else if (act && cid >= 0) {
+                p2 = load_f32_l2(&nmax[cid]);  // :613-618 prob_2_max = data.max_prob (may be stale)
+            }
+            nn += popc64(m_new);
+            const float prob = ladd<MODE>(clp, cgp) + p2;  // :146-148
+            if (act) {
+                L.c_lp[c] = clp;
+                L.c_gp[c] = cgp;
+                L.c_id[c] = cid;
+                L.c_new[c] = is_new ? 1 : 0;
+                L.c_key[c] = valid ? (prob == prob ? make_key(prob, cid) : 1ull) : 0ull;
+            }
+            n_valid += popc64(__ballot(valid));
+            any_nan = any_nan || (__ballot(valid && prob != prob) != 0ull);
+        }
+        if (nn > p.cap_nodes) return fail(FCD_ST_INTERNAL);
+        if (n_valid >= 2 && any_nan) return fail(FCD_ST_INCOMPARABLE);  // :619-631
+        if (n_valid == 0) return fail(FCD_ST_RAN_OUT_OF_BEAM);          // :633-636
+        __syncthreads();
+
+        // ---- rank and build the next beam (no renormalisation in log space) ----
+        const int nxt = cur ^ 1;
+        const int Bn = n_valid < BC ? n_valid : BC;
+        for (int base = 0; base < nslots; base += kWave) {
+            const int c = base + lane;
+            if (c >= nslots) continue;
+            const uint64_t key = L.c_key[c];
+            if (key == 0ull) continue;
+            int rank = 0;
+            for (int j = 0; j < nslots; ++j) rank += (L.c_key[j] > key) ? 1 : 0;
+            if (rank < BC) {
+                const int i = c / N, k = c - i * N;
+                L.b_node[nxt][rank] = L.c_id[c];
+                L.b_lp[nxt][rank] = L.c_lp[c];
+                L.b_gp[nxt][rank] = L.c_gp[c];
+                if (k == 0) {
+                    L.b_tip[nxt][rank] = b_tip[i];
+                    L.b_par[nxt][rank] = b_par[i];
+                } else {
+                    L.b_tip[nxt][rank] = k - 1;
+                    L.b_par[nxt][rank] = b_node[i];
+                }
+                L.nb_src[rank] = c | (L.c_new[c] << 30);
+            }
+        }
+        __syncthreads();
+        for (int item = lane; item < Bn * NL; item += kWave) {
+            const int s = item / NL, l = item - s * NL;
+            const int src = L.nb_src[s];
+            const int c = src & 0x3FFFFFFF;
+            const int i = c / N, k = c - i * N;
+            int v;
+            if (k == 0) v = b_child[i * NL + l];
+            else if (src >> 30) v = -1;
+            else v = load_i32_l2(&rows[(int64_t)L.b_node[nxt][s] * NL + l]);
+            L.b_child[nxt][s * NL + l] = v;
+        }
+        B = Bn;
+        cur = nxt;
+        __syncthreads();
+    }
+
+    // ---- labels leaf -> root (:638-649), written in sequence order ----
+    if (lane == 0) {
+        int node = L.b_node[cur][0];
+        int n = 0;
+        for (int q = node; q >= 0; q = load_i32_l2(reinterpret_cast<const int32_t *>(&meta[q]))) ++n;
+        for (int j = n - 1; j >= 0; --j) {
+            const int4 m = load_meta_l2(&meta[node]);
+            lab_out[j] = (uint8_t)(m.y + 1);
+            node = m.x;
+        }
+        p.out.out_len[r] = (uint32_t)n;
+        p.out.status[r] = FCD_ST_OK;
+    }
+}
+
+// ---- prepass: ln of the posteriors into contiguous log-space copies (:452-453) ----
+__global__ void ln_convert_kernel(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
+                                  int64_t s_t, int64_t s_n, float *out) {
+    const int64_t total = n_reads * T * N;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = idx % N, t = (idx / N) % T, r = idx / (N * T);
+        out[idx] = ln_cr(x[r * s_read + t * s_t + j * s_n]);
+    }
+}
+
+// widest clamped envelope row over the whole batch -> *out (int), for sizing the rings
+__global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t env_stride,
+                                 int64_t T1cap, int64_t T2cap, const int64_t *len1,
+                                 const int64_t *len2, int *out) {
+    int best = 0;
+    const int64_t total = n_pairs * T1cap;
+    for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = idx / T1cap, t = idx % T1cap;
+        int64_t T1 = T1cap, T2 = T2cap;
+        if (len1) { int64_t v = len1[r]; T1 = v < 0 ? 0 : (v < T1 ? v : T1); }
+        if (len2) { int64_t v = len2[r]; T2 = v < 0 ? 0 : (v < T2 ? v : T2); }
+        if (t >= T1) continue;
+        const uint64_t lo = env[(r * env_stride + t) * 2], hi_u = env[(r * env_stride + t) * 2 + 1];
+        const uint64_t hi = hi_u > (uint64_t)T2 ? (uint64_t)T2 : hi_u;
+        if (hi > lo) {
+            const uint64_t w = hi - lo;
+            best = max(best, (int)(w > 0x3FFFFFFFull ? 0x3FFFFFFFull : w));
+        }
+    }
+    atomicMax(out, best);
+}
+
+}  // namespace
+
+size_t duplex_lds_bytes(int beam_size, int N) { return dlds_words(beam_size, N) * 4 + 16; }
+
+hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
+                             int64_t s_t, int64_t s_n, float *out, hipStream_t stream) {
+    const int64_t total = n_reads * T * N;
+    if (total <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
+    hipLaunchKernelGGL(ln_convert_kernel, dim3(blocks), dim3(256), 0, stream, x, n_reads, T, N,
+                       s_read, s_t, s_n, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,
+                            int64_t T2cap, const int64_t *len1, const int64_t *len2, int *out,
+                            hipStream_t stream) {
+    const int64_t total = n_pairs * T1cap;
+    if (total <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(env_width_kernel, dim3(blocks), dim3(256), 0, stream, env, n_pairs,
+                       env_stride, T1cap, T2cap, len1, len2, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs,
+                         hipStream_t stream) {
+    if (n_pairs <= 0) return hipSuccess;
+    DuplexParams p;
+    p.ln1 = a.ln1; p.ln2 = a.ln2; p.T1cap = a.T1cap; p.T2cap = a.T2cap;
+    p.len1 = a.len1; p.len2 = a.len2; p.env = a.env; p.env_stride = a.env_stride;
+    p.N = a.N; p.beam_size = a.beam_size; p.thr_ln = a.thr_ln; p.collapse = a.collapse;
+    p.mode = a.mode; p.meta = a.meta; p.nmax = a.nmax; p.rows = a.rows; p.vec = a.vec;
+    p.rootgap = a.rootgap; p.cap_nodes = a.cap_nodes; p.Wcap = a.Wcap; p.out = a.out;
+    p.pair_begin = pair_begin;
+    const size_t lds = duplex_lds_bytes(a.beam_size, a.N);
+    if (a.mode == FCD_LOGADD_MAX)
+        hipLaunchKernelGGL(duplex_kernel<FCD_LOGADD_MAX>, dim3((unsigned)n_pairs), dim3(64), lds,
+                           stream, p);
+    else
+        hipLaunchKernelGGL(duplex_kernel<FCD_LOGADD_LOGSUMEXP>, dim3((unsigned)n_pairs), dim3(64),
+                           lds, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace fcd

@@ -80,6 +80,35 @@ hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &o
 hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_init,
                              int64_t init_stride, const ResultDesc &out, hipStream_t stream);
 
+// duplex::beam_search (src/duplex.rs:443-650) launch arguments; all pointers are device memory.
+struct DuplexArgs {
+    const float *ln1, *ln2;  // log-space posteriors [pair][Tcap][N]
+    int64_t T1cap, T2cap;
+    const int64_t *len1, *len2;
+    const uint64_t *env;
+    int64_t env_stride;
+    int N, beam_size;
+    float thr_ln;
+    int collapse, mode;
+    int4 *meta;
+    float *nmax;
+    int32_t *rows;
+    float *vec;
+    float *rootgap;
+    int64_t cap_nodes;
+    int Wcap;
+    ResultDesc out;
+};
+
+size_t duplex_lds_bytes(int beam_size, int N);
+hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
+                             int64_t s_t, int64_t s_n, float *out, hipStream_t stream);
+hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,
+                            int64_t T2cap, const int64_t *len1, const int64_t *len2, int *out,
+                            hipStream_t stream);
+hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs,
+                         hipStream_t stream);
+
 }  // namespace fcd
 
 struct fcd_handle {
@@ -96,6 +125,8 @@ struct fcd_handle {
     size_t arena_bytes = 0;
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
+    size_t lnbuf_bytes = 0;
     std::string err;
     std::mutex mu;
 };

@@ -469,6 +469,24 @@ static const float NEG_INF = -INFINITY;
  * whose exp() returns 0.0 for every input on little-endian targets (src/fastexp.rs:33-58:
  * the f32 view of the i64 union reads the low 32 bits of `i << 52`), so
  * big + ln_1p(0.0) == big. */
+/*
+ * libm flavour.  Rust's f32::ln / exp / ln_1p call the platform libm (logf / expf / log1pf), whose
+ * last-bit behaviour differs between glibc versions (2.35's logf is < 0.82 ULP, log1pf < 1 ULP;
+ * glibc >= 2.41 ships correctly rounded CORE-MATH versions).  FCDO_MATH_CR selects correctly
+ * rounded f32 results (evaluated in x87 long double, double-rounding risk ~2^-40): a
+ * platform-independent definition the HIP kernels reproduce (they evaluate in f64).  Without the
+ * flag the host libm is used, exactly as the reference would on this machine.
+ */
+static inline float ln_m(float x, int mode) {
+    return (mode & FCDO_MATH_CR) ? (float)logl((long double)x) : logf(x);
+}
+static inline float exp_m(float x, int mode) {
+    return (mode & FCDO_MATH_CR) ? (float)expl((long double)x) : expf(x);
+}
+static inline float log1p_m(float x, int mode) {
+    return (mode & FCDO_MATH_CR) ? (float)log1pl((long double)x) : log1pf(x);
+}
+
 float fcdo_logspace_add(float a, float b, int mode) {
     float big, small;
     if (a <= b) {
@@ -479,8 +497,8 @@ float fcdo_logspace_add(float a, float b, int mode) {
         small = b;
     }
     if (small == NEG_INF) return big;
-    if (mode == FCDO_LOGADD_MAX) return big + 0.0f; /* big + ln_1p(+-0.0) */
-    return big + log1pf(expf(small - big));
+    if ((mode & 3) == FCDO_LOGADD_MAX) return big + 0.0f; /* big + ln_1p(+-0.0) */
+    return big + log1p_m(exp_m(small - big, mode), mode);
 }
 #define LADD(a, b) fcdo_logspace_add((a), (b), mode)
 static inline float lmax(float self, float other) { return (self < other) ? other : self; } /* :33-39 */
@@ -656,12 +674,12 @@ static void secvec_push(secvec *d, secprobs s) {
 }
 
 static float *to_logspace(const float *x, int64_t T, int64_t S, int64_t N, int64_t s0, int64_t s1,
-                          int64_t s2) { /* LogSpace::new = ln :24-26, :452-453 */
+                          int64_t s2, int mode) { /* LogSpace::new = ln :24-26, :452-453 */
     float *o = (float *)malloc(sizeof(float) * (size_t)(T * S * N > 0 ? T * S * N : 1));
     for (int64_t t = 0; t < T; ++t)
         for (int64_t s = 0; s < S; ++s)
             for (int64_t j = 0; j < N; ++j)
-                o[(t * S + s) * N + j] = logf(x[t * s0 + s * s1 + j * s2]);
+                o[(t * S + s) * N + j] = ln_m(x[t * s0 + s * s1 + j * s2], mode);
     return o;
 }
 
@@ -674,7 +692,7 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
                        int64_t beam_size, float thr_real, int collapse_repeats, int mode,
                        int32_t *labels, int64_t *n_out) {
     const int64_t N = n1->N, n_base = N - 1, n_state = n1->S;
-    const float thr = logf(thr_real); /* :454 */
+    const float thr = ln_m(thr_real, mode); /* :454 */
     int status = FCDO_OK;
     if (n1->T <= 0) return FCDO_PANIC; /* envelope[(0,1)] out of bounds :477 */
 
@@ -877,8 +895,8 @@ int fcdo_beam_search_duplex(const float *x1, int64_t T1, int64_t rs1, int64_t cs
                             int64_t N, const uint64_t *envelope, int64_t e0, int64_t e1,
                             int64_t beam_size, float thr, int collapse_repeats,
                             int logadd_mode, int32_t *labels, int64_t *n_out) {
-    float *l1 = to_logspace(x1, T1, 1, N, rs1, 0, cs1);
-    float *l2 = to_logspace(x2, T2, 1, N, rs2, 0, cs2);
+    float *l1 = to_logspace(x1, T1, 1, N, rs1, 0, cs1, logadd_mode);
+    float *l2 = to_logspace(x2, T2, 1, N, rs2, 0, cs2, logadd_mode);
     lognet n1 = {l1, T1, 1, N}, n2 = {l2, T2, 1, N};
     int st = duplex_core(&n1, &n2, 0, 0, 0, envelope, e0, e1, beam_size, thr, collapse_repeats,
                          logadd_mode, labels, n_out);
@@ -899,8 +917,8 @@ int fcdo_crf_beam_search_duplex(const float *x1, int64_t T1, const int64_t *st1,
     float m;
     if (argmax_strided(init1, n_init1, i1s, &a1, &m) != FCDO_OK) return FCDO_PANIC; /* :679 */
     if (argmax_strided(init2, n_init2, i2s, &a2, &m) != FCDO_OK) return FCDO_PANIC; /* :691 */
-    float *l1 = to_logspace(x1, T1, S, N, st1[0], st1[1], st1[2]);
-    float *l2 = to_logspace(x2, T2, S, N, st2[0], st2[1], st2[2]);
+    float *l1 = to_logspace(x1, T1, S, N, st1[0], st1[1], st1[2], logadd_mode);
+    float *l2 = to_logspace(x2, T2, S, N, st2[0], st2[1], st2[2], logadd_mode);
     lognet n1 = {l1, T1, S, N}, n2 = {l2, T2, S, N};
     int st = duplex_core(&n1, &n2, 1, a1, a2, envelope, e0, e1, beam_size, thr, 0, logadd_mode,
                          labels, n_out);

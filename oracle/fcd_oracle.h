@@ -45,7 +45,8 @@ enum {
 /* duplex log-add modes (SURVEY.md section 0 finding 3) */
 enum {
     FCDO_LOGADD_LOGSUMEXP = 0,   /* cargo --no-default-features: libm expf/log1pf */
-    FCDO_LOGADD_MAX = 1          /* default-feature wheels: fastexp() == 0.0 => max() */
+    FCDO_LOGADD_MAX = 1,         /* default-feature wheels: fastexp() == 0.0 => max() */
+    FCDO_MATH_CR = 4             /* OR-able: correctly rounded ln/exp/ln_1p instead of the host libm */
 };
 
 /* src/search.rs:31-36 */

@@ -15,7 +15,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libfcd_oracle.so")
 
 OK, RAN_OUT_OF_BEAM, INCOMPARABLE, INVALID_ENVELOPE, PANIC = 0, 1, 2, 3, 100
-LOGSUMEXP, MAXMODE = 0, 1
+LOGSUMEXP, MAXMODE, MATH_CR = 0, 1, 4
 
 # src/lib.rs:46-53
 _MESSAGES = {

@@ -1,0 +1,133 @@
+"""duplex::beam_search (src/duplex.rs:443-650) on the GPU vs the CPU oracle.
+
+The kernels define ln / exp / ln_1p as correctly rounded f32, so the exact
+target is the oracle with FCDO_MATH_CR: strings must be IDENTICAL.  Against the oracle on the host
+libm (what the reference computes on this machine's glibc) strings may differ in the rare case a
+last-bit difference flips a near-tie; that agreement is checked with an explicit tolerance."""
+import numpy as np
+import pytest
+
+import kat_cases
+from kat_cases import reference_style_rows
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+LSE, MAX, CR = oracle.LOGSUMEXP, oracle.MAXMODE, oracle.MATH_CR
+
+
+@pytest.fixture(scope="module")
+def fcd():
+    import fast_ctc_decode_amd as m
+    return m
+
+
+class _Mode:
+    def __init__(self, fcd, mode):
+        self.fcd, self.mode = fcd, mode
+
+    def beam_search_duplex(self, *a, **k):
+        return self.fcd.beam_search_duplex(*a, logadd_mode=self.mode, **k)
+
+
+@pytest.mark.parametrize("mode", [0, 1], ids=["logsumexp", "max"])
+@pytest.mark.parametrize("case", kat_cases.DUPLEX_CASES, ids=lambda f: f.__name__)
+def test_kat_duplex(fcd, case, mode):
+    case(_Mode(fcd, mode))
+
+
+def band(T1, T2, w):
+    i = np.arange(T1)
+    return np.stack([np.maximum(0, i - w), np.minimum(T2, i + w)], 1).astype(np.uint64)
+
+
+def pairs(seed, B, T1, T2, N=5):
+    rng = np.random.default_rng(seed)
+    x1 = reference_style_rows(rng, B * T1, N).reshape(B, T1, N)
+    x2 = reference_style_rows(rng, B * T2, N).reshape(B, T2, N)
+    return x1, x2
+
+
+def oracle_strings(x1, x2, alpha, envs, beam, thr, collapse, mode):
+    out = []
+    for i in range(x1.shape[0]):
+        e = None if envs is None else envs[i]
+        try:
+            out.append(oracle.beam_search_duplex(x1[i], x2[i], alpha, e, beam, thr, collapse, mode))
+        except RuntimeError as err:
+            out.append(str(err))
+    return out
+
+
+def gpu_strings(fcd, x1, x2, alpha, envs, beam, thr, collapse, mode):
+    r = fcd.beam_search_duplex_batch_raw(x1, x2, envs, beam, thr, collapse, logadd_mode=mode).cpu()
+    out = []
+    for i in range(x1.shape[0]):
+        if int(r.status[i]) != 0:
+            out.append(fcd.api.nat.status_string(int(r.status[i])))
+        else:
+            out.append("".join(alpha[l] for l in r.labels[i, :int(r.out_len[i])]))
+    return out
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+@pytest.mark.parametrize("collapse", [True, False])
+def test_duplex_banded_exact(fcd, mode, collapse):
+    x1, x2 = pairs(300 + mode, 6, 160, 150)
+    envs = np.stack([band(160, 150, 24)] * 6)
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, collapse, mode)
+    want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, collapse, mode | CR)
+    assert got == want
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_default_envelope_exact(fcd, mode):
+    x1, x2 = pairs(310 + mode, 4, 60, 70)
+    got = gpu_strings(fcd, x1, x2, "NACGT", None, 5, 0.0, True, mode)
+    want = oracle_strings(x1, x2, "NACGT", None, 5, 0.0, True, mode | CR)
+    assert got == want
+
+
+@pytest.mark.parametrize("beam,N", [(1, 5), (3, 3), (8, 5), (16, 4)])
+def test_duplex_shapes_exact(fcd, beam, N):
+    alpha = "NACGTXY"[:N]
+    x1, x2 = pairs(320 + beam, 4, 90, 100, N)
+    envs = np.stack([band(90, 100, 16)] * 4)
+    thr = 0.05
+    got = gpu_strings(fcd, x1, x2, alpha, envs, beam, thr, True, LSE)
+    want = oracle_strings(x1, x2, alpha, envs, beam, thr, True, LSE | CR)
+    assert got == want
+
+
+def test_duplex_envelope_errors_and_edges(fcd):
+    x1, x2 = pairs(330, 5, 40, 40)
+    envs = np.stack([band(40, 40, 8)] * 5)
+    envs[1, 10, 0] = 30           # lower bound jumps past the previous upper bound -> InvalidEnvelope
+    envs[2, 5] = (7, 7)           # empty row -> InvalidEnvelope
+    envs[3, :, 1] = 1000          # upper bounds beyond read 2 are clamped ... but row 0 must be <= T2
+    envs[3, 0, 1] = 8
+    x1[4, 20:] = 0.0              # nothing passes the threshold -> RanOutOfBeam
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+    want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, LSE | CR)
+    assert got == want
+    assert got[1] == got[2] == "Invalid envelope values"
+
+
+def test_duplex_vs_host_libm_tolerance(fcd):
+    """Tolerance statement: vs the oracle on the HOST libm (glibc logf/expf/log1pf, not correctly
+    rounded) at least 90 % of random pairs must give the identical string."""
+    x1, x2 = pairs(340, 20, 200, 200)
+    envs = np.stack([band(200, 200, 32)] * 20)
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+    want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+    same = sum(g == w for g, w in zip(got, want))
+    assert same >= 18, (same, 20)
+
+
+def test_duplex_config5_shape_sample(fcd):
+    """BASELINE config 5 shape (T1 = T2 = 2000, band +-64) on a few pairs, exact vs the CR oracle."""
+    x1, x2 = pairs(4, 3, 2000, 2000)
+    envs = np.stack([band(2000, 2000, 64)] * 3)
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+    want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, LSE | CR)
+    assert got == want
