@@ -1,29 +1,37 @@
 // beam_wave.hip -- register-resident CTC prefix beam search for search::beam_search
-// (/root/reference/src/search.rs:159-301): beam_size <= 8, 3 <= N <= 7.  One read per wavefront.
+// (/root/reference/src/search.rs:159-301).
 //
-// Lane map (wave64): lane = 8*i + k.  i = beam slot (beam kept in rank order, as the reference's
-// sorted Vec), k = 0 is the slot's own node, k = 1..NL the child reached by label k-1, lane 8*i+7
-// is a scratch target for cross-lane pushes.  Every lane of group i carries a copy of slot i's
-// (node, label_prob, gap_prob, tip label, depth); lane (i,k>=1) also carries node i's child entry
-// for label k-1.  The whole search state therefore lives in VGPRs; LDS is used only as the
-// cross-lane network (ds_permute / ds_bpermute) and for the 64 sort keys of the prune step.
+// Two instantiation families of one kernel template <N, GW, RPW>:
+//   RPW = 2, GW = 6 : TWO reads per wavefront (one per 32-lane half), beam_size <= 5, N <= 5
+//                     -- the BASELINE headline shape (beam 5, N = 5);
+//   RPW = 1, GW = 8 : one read per wavefront, beam_size <= 8, N <= 7.
+//
+// Lane map inside a half: q = GW*i + k.  i = beam slot (rank order, like the reference's sorted
+// Vec), k = 0 the slot's own node, k = 1..NL the child reached by label k-1, k = GW-1 a scratch
+// target for cross-lane pushes.  Every lane of group i carries slot i's (node, label_prob,
+// gap_prob, tip label, depth); lane (i, k>=1) also carries node i's child entry for label k-1.
+// The search state lives in VGPRs; LDS is only the cross-lane network (ds_permute/ds_bpermute)
+// and a 64-entry sort-key table per wave.
 //
 // Per timestep:
-//   * the posterior row comes from a 64-row register tile (lane r holds row tile*64+r, loaded one
-//     tile ahead; v_readlane broadcasts row t to SGPRs) -- no LDS, no per-step memory latency;
-//   * child lanes evaluate the extension (:200-239); an extension whose target is already in the
-//     beam is pushed to that slot's lane 0 (ds_permute), which adds it to its own blank/stay
-//     terms -- the reference's sort-by-node + fold (:245-260), order-independent because at most
-//     two non-zero f32 addends ever meet;
+//   * posterior row: a register FIFO holds the next TR*RPR rows of each half's read, element
+//     (row g, column c) of the front register sitting in lane g*N+c, so the three values a lane
+//     needs (blank, its own label, the tip's label) are three ds_bpermutes -- no per-step memory
+//     access; one coalesced load per RPR steps refills the FIFO ~40 rows ahead;
+//   * child lanes evaluate the extension (:200-239).  A child entry carries IN-BEAM/slot bits, so
+//     "is my target already a beam entry, and where?" costs no search: the extension is pushed to
+//     that slot's lane 0 (ds_permute), which adds it to its own blank/stay terms -- the
+//     reference's sort-by-node + fold (:245-260), order-independent because at most two non-zero
+//     f32 addends ever meet;
 //   * new tree nodes get ids in the reference's creation order via ballot + prefix popcount;
-//   * pruning ranks the <= 40 candidates exactly on a 64-bit key (probability desc, node asc);
-//   * the survivors are gathered into rank order with ds_bpermute and divided by the top
+//   * pruning ranks the candidates exactly on a 64-bit key (probability desc, node asc);
+//   * survivors are gathered into rank order with ds_bpermute and divided by the top
 //     probability (:278-282, IEEE f32 division).
 //
-// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = child entries.
-// A child entry is -1 (none) or id | EVER, EVER marking children that have themselves been in the
-// beam: only those can own children, so only their row is ever re-read when they re-enter the
-// beam (3.9 % of steps on BASELINE's generator) -- everything else stays in registers.
+// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = child entries
+// (id | EVER, or -1).  EVER marks children that have themselves been in the beam: only those can
+// own children, so only their row is re-read when they re-enter the beam (3.9 % of steps on
+// BASELINE's generator) -- everything else stays in registers.
 #include "device_utils.h"
 #include "fcd_internal.h"
 
@@ -32,7 +40,10 @@ namespace fcd {
 namespace {
 
 constexpr int kEver = 1 << 30;
-constexpr int kIdMask = kEver - 1;
+constexpr int kInBeam = 1 << 29;
+constexpr int kSlotShift = 26;
+constexpr int kIdMask = (1 << 26) - 1;
+constexpr int kStored = kEver | kIdMask;  // what goes to HBM
 
 struct WaveParams {
     BatchDesc in;
@@ -51,51 +62,58 @@ __device__ __forceinline__ float bpermf(int src_lane, float v) {
 __device__ __forceinline__ int perm(int dst_lane, int v) {
     return __builtin_amdgcn_ds_permute(dst_lane << 2, v);
 }
-__device__ __forceinline__ float readlane_f(float v, int lane) {
-    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-
-template <int N>
-__device__ __forceinline__ void load_tile(float (&dst)[N], const float *post, int64_t row, int64_t T,
-                                          int64_t st_t, int64_t st_n) {
-    const bool ok = row < T;
-    const float *p = post + (ok ? row : 0) * st_t;
-#pragma unroll
-    for (int c = 0; c < N; ++c) dst[c] = ok ? p[c * st_n] : 0.0f;
-}
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kFifo = 8;  // registers in the row FIFO
 
-template <int N>
+template <int N, int GW, int RPW>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr int NL = N - 1;
-    constexpr int RW = NL <= 4 ? 4 : 8;  // child-row width in the arena
+    constexpr int HALF = 64 / RPW;
+    constexpr int BCAP = HALF / GW;     // beam slots per read
+    constexpr int RPR = HALF / N;       // rows per FIFO register
+    constexpr int RW = NL <= 4 ? 4 : 8; // child-row width in the arena
+    static_assert(N <= GW - 1, "a scratch lane per group is required");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
-    const int64_t local = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    if (local >= p.in.n_reads) return;  // n_reads here = reads in this launch
-    const int64_t r = p.read_begin + local;
-    uint64_t *keys = s_keys[wave];
-
-    const int i = lane >> 3, k = lane & 7;
-    const bool is_self = k == 0;
-    const bool is_child = k >= 1 && k <= NL;
+    const int q = lane & (HALF - 1);
+    const int hbase = lane - q;
+    const int i = q / GW, k = q - i * GW;
+    const bool idle = i >= BCAP;             // e.g. lanes 30,31 of a half when GW = 6
+    const bool is_self = !idle && k == 0;
+    const bool is_child = !idle && k >= 1 && k <= NL;
     const int l = k - 1;
+    const int grp0 = hbase + i * GW;         // lane 0 of my group
+    const int dummy = idle ? lane : grp0 + GW - 1;
     const int beam_size = p.a.beam_size;
     const bool collapse = p.a.collapse != 0;
     const float thr = p.a.thr;
+    uint64_t *keys = s_keys[wave];
 
-    int64_t T = p.in.T;
-    if (p.in.lengths) {
-        int64_t t = p.in.lengths[r];
-        T = t < 0 ? 0 : (t < T ? t : T);
+    const int64_t local = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW + (lane / HALF);
+    const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
+    const int64_t r = p.read_begin + (has_read ? local : 0);
+
+    int T = 0;
+    if (has_read) {
+        int64_t t64 = p.in.T;
+        if (p.in.lengths) {
+            const int64_t tl = p.in.lengths[r];
+            t64 = tl < 0 ? 0 : (tl < t64 ? tl : t64);
+        }
+        T = (int)t64;
     }
+    int Tmax = T;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
+    Tmax = __builtin_amdgcn_readfirstlane(Tmax);
+
     const float *post = p.in.post + r * p.in.stride_read;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n;
-    int2 *rec = p.arena.rec + local * p.arena.cap_nodes;
-    int32_t *rows = p.arena.rows + local * p.arena.cap_nodes * RW;
+    int2 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
+    int32_t *rows = p.arena.rows + (has_read ? local : 0) * p.arena.cap_nodes * RW;
     const int cap = (int)p.arena.cap_nodes;
 
     // ---- beam state (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
@@ -106,29 +124,36 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     int child = -1;
     int B = 1;
     int nn = 0;
+    bool alive = has_read;
 
-    float cur[N], nxt[N];
-    load_tile<N>(cur, post, lane, T, st_t, st_n);
-    load_tile<N>(nxt, post, 64 + lane, T, st_t, st_n);
+    // ---- row FIFO: register j holds rows [blk*RPR, blk*RPR+RPR) of block (front + j) ----
+    const int fg = q / N, fc = q - fg * N;  // this lane's (row-in-block, column) as a FIFO element
+    const bool f_lane = q < RPR * N;
+    auto load_block = [&](int blk) -> float {
+        const int row = blk * RPR + fg;
+        return (f_lane && row < T) ? post[(int64_t)row * st_t + fc * st_n] : 0.0f;
+    };
+    float win[kFifo];
+#pragma unroll
+    for (int j = 0; j < kFifo; ++j) win[j] = load_block(j);
+    int g = 0;    // row within the front block (wave-uniform)
+    int blk = 0;  // index of the front block (wave-uniform)
 
-    for (int64_t t = 0; t < T; ++t) {
-        const int rr = (int)(t & 63);
-        if (rr == 0 && t > 0) {
+    for (int t = 0; t < Tmax; ++t) {
+        const bool act = alive && t < T;
+        // ---- the three row values this lane needs ----
+        const int rbase = hbase + g * N;
+        const float pr0 = bpermf(rbase, win[0]);
+        const float pk = bpermf(rbase + (is_child ? k : 0), win[0]);
+        const float ptip = bpermf(rbase + tip + 1, win[0]);
+        if (++g == RPR) {
+            g = 0;
 #pragma unroll
-            for (int c = 0; c < N; ++c) cur[c] = nxt[c];
-            load_tile<N>(nxt, post, t + 64 + lane, T, st_t, st_n);
+            for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
+            win[kFifo - 1] = load_block(blk + kFifo);
+            ++blk;
         }
-        float pr[N];
-#pragma unroll
-        for (int c = 0; c < N; ++c) pr[c] = readlane_f(cur[c], rr);
-        const float pr0 = pr[0];
-        float pk = pr0, ptip = 0.0f;
-#pragma unroll
-        for (int c = 1; c <= NL; ++c) {
-            pk = (k == c) ? pr[c] : pk;
-            ptip = (tip + 1 == c) ? pr[c] : ptip;
-        }
-        const bool grp = i < B;
+        const bool grp = act && i < B;
 
         // ---- child lanes: extension by label l (:200-239) ----
         const bool pass = !(pk < thr);  // :201 skips only when pr_b < thr
@@ -136,17 +161,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const float contrib = rep ? gp * pk : (lp + gp) * pk;
         const bool exists = child >= 0;
         const int cid = child & kIdMask;
+        const bool inbeam = exists && (child & kInBeam);
+        const int mslot = (child >> kSlotShift) & 7;
         const bool cvalid = grp && is_child && pass && (exists || !rep || gp > 0.0f);  // :212-218
-
-        // is the extension's target already in the beam?  (beam node ids -> SGPRs)
-        int mslot = -1;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int bn = __builtin_amdgcn_readlane(node, j * 8);
-            if (j < B) mslot = (cid == bn) ? j : mslot;
-        }
-        const bool merged = cvalid && exists && mslot >= 0;
-        const int dst = merged ? mslot * 8 : (lane | 7);
+        const bool merged = cvalid && inbeam;  // the target's own lane 0 absorbs this extension
+        const int dst = merged ? hbase + mslot * GW : dummy;
         const float inc = __int_as_float(perm(dst, __float_as_int(merged ? contrib : 0.0f)));
         const int incv = perm(dst, merged ? 1 : 0);
 
@@ -168,69 +187,91 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // ---- tree.rs:125-145 add_node: ids in (beam order, label order) == lane order ----
         const bool is_new = cvalid && !exists;
         const uint64_t m_new = __ballot(is_new);
-        const int newid = nn + popc64(m_new & lanemask_lt());
-        nn += popc64(m_new);
-        if (nn > cap) {
-            if (lane == 0) {
-                p.out.status[r] = FCD_ST_INTERNAL;
-                p.out.out_len[r] = 0;
-            }
-            return;
+        const uint32_t w_new = RPW == 1 ? 0u : (hbase ? (uint32_t)(m_new >> 32) : (uint32_t)m_new);
+        int n_new, pre_new;
+        if (RPW == 1) {
+            n_new = popc64(m_new);
+            pre_new = popc64(m_new & lanemask_lt());
+        } else {
+            n_new = __builtin_popcount(w_new);
+            pre_new = __builtin_popcount(w_new & ((1u << q) - 1u));
         }
-        if (is_new) {
-            rec[newid] = make_int2(node, (int)(t << 3) | l);
+        const int newid = nn + pre_new;
+        nn += n_new;
+        const bool f_cap = act && nn > cap;
+        if (is_new && !f_cap) {
+            rec[newid] = make_int2(node, (t << 3) | l);
             if (node >= 0) rows[(int64_t)node * RW + l] = newid;
             child = newid;
         }
         const int id = is_self ? node : (is_new ? newid : cid);
 
         // ---- search.rs:261-277 ----
-        const int n_valid = popc64(__ballot(valid));
-        const bool any_nan = __ballot(valid && prob != prob) != 0ull;
-        if ((n_valid >= 2 && any_nan) || n_valid == 0) {
-            if (lane == 0) {
-                p.out.status[r] = n_valid == 0 ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE;
+        const uint64_t m_valid = __ballot(valid);
+        const uint64_t m_nan = __ballot(valid && prob != prob);
+        int n_valid;
+        bool any_nan;
+        if (RPW == 1) {
+            n_valid = popc64(m_valid);
+            any_nan = m_nan != 0ull;
+        } else {
+            n_valid = __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
+            any_nan = (hbase ? (uint32_t)(m_nan >> 32) : (uint32_t)m_nan) != 0u;
+        }
+        const bool f_nan = act && n_valid >= 2 && any_nan;
+        const bool f_empty = act && n_valid == 0;
+        if (f_nan || f_empty || f_cap) {
+            if (q == 0) {
+                p.out.status[r] = f_cap ? FCD_ST_INTERNAL
+                                        : (f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
                 p.out.out_len[r] = 0;
             }
-            return;
+            alive = false;
         }
+        const bool go = act && alive;  // this half completes the step
 
         // ---- prune: exact rank on (probability desc, node asc) ----
-        const uint64_t key = valid ? (prob == prob ? make_key(prob, id) : 1ull) : 0ull;
+        const uint64_t key = (valid && go) ? (prob == prob ? make_key(prob, id) : 1ull) : 0ull;
         keys[lane] = key;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rank = 0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            if (j < B) {
+        for (int j = 0; j < BCAP; ++j) {
 #pragma unroll
-                for (int c = 0; c <= NL; ++c) rank += (keys[j * 8 + c] > key) ? 1 : 0;
-            }
+            for (int c = 0; c <= NL; ++c) rank += (keys[hbase + j * GW + c] > key) ? 1 : 0;
         }
         __builtin_amdgcn_wave_barrier();
 
-        // ---- gather the survivors into rank order ----
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
-        const bool sel = valid && rank < beam_size;
-        // a child entering the beam for the first time: mark it EVER in its parent's row (the
-        // register copy here, the HBM copy below) and give it an empty row of its own
-        const bool first_entry = sel && is_child && !(exists && (child & kEver));
-        if (first_entry) {
-            child = id | kEver;
-            if (node >= 0) rows[(int64_t)node * RW + l] = child;
-            int32_t *row = rows + (int64_t)id * RW;
-            if (RW == 4) {
-                *reinterpret_cast<int4 *>(row) = make_int4(-1, -1, -1, -1);
-            } else {
-                *reinterpret_cast<int4 *>(row) = make_int4(-1, -1, -1, -1);
-                *reinterpret_cast<int4 *>(row + 4) = make_int4(-1, -1, -1, -1);
+        const bool sel = valid && go && rank < beam_size;
+
+        // ---- keep the IN-BEAM/slot bits of every child entry current ----
+        // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
+        const int selrank = sel ? rank : -1;
+        const int fate = bperm(hbase + mslot * GW, selrank);
+        const bool first_entry = sel && is_child && !(child & kEver);  // child >= 0 here
+        if (go && is_child) {
+            if (inbeam) {
+                child = (child & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
+            } else if (sel) {
+                // a child entering the beam: mark it EVER (here and in its parent's HBM row) and,
+                // on its first entry, give it an empty row of its own
+                if (first_entry) {
+                    if (node >= 0) rows[(int64_t)node * RW + l] = id | kEver;
+                    int32_t *row = rows + (int64_t)id * RW;
+                    *reinterpret_cast<int4 *>(row) = make_int4(-1, -1, -1, -1);
+                    if (RW == 8) *reinterpret_cast<int4 *>(row + 4) = make_int4(-1, -1, -1, -1);
+                }
+                child = id | kEver | kInBeam | (rank << kSlotShift);
             }
         }
+
+        // ---- gather the survivors into rank order ----
         const int kind = is_self ? 0 : (first_entry ? 1 : 2);  // 2: re-entering, row is in HBM
-        const int src0 = perm(sel ? rank * 8 : (lane | 7), lane);
-        const int src = bperm(lane & ~7, src0);  // every lane of new group s knows its source lane
+        const int src0 = perm(sel ? hbase + rank * GW : dummy, lane);
+        const int src = bperm(grp0, src0);  // every lane of new group s knows its source lane
         const int tipc = is_self ? tip : l;
         const int depc = is_self ? depth : depth + 1;
         const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
@@ -240,36 +281,58 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int n_meta = bperm(src, meta);
         int n_child = bperm(src + k, child);  // meaningful when the source is a self lane
         const int n_kind = n_meta & 3;
-        const bool ngrp = i < Bn;
+        const bool ngrp = go && i < Bn;
         if (n_kind == 1 || !is_child) n_child = -1;
-        if (__ballot(ngrp && n_kind == 2 && is_child) != 0ull) {
-            if (ngrp && n_kind == 2 && is_child) n_child = load_i32_l2(&rows[(int64_t)n_node * RW + l]);
+        const bool reload = ngrp && n_kind == 2 && is_child;
+        if (__ballot(reload) != 0ull) {
+            // a node that was in the beam before comes back: its row is in HBM, and which of its
+            // children are beam entries right now has to be looked up (rare path)
+            int e = -1;
+            if (reload) e = load_i32_l2(&rows[(int64_t)n_node * RW + l]);
+#pragma unroll
+            for (int j = 0; j < BCAP; ++j) {
+                const int nj = bperm(hbase + j * GW, n_node);
+                if (reload && e >= 0 && j < Bn && (e & kIdMask) == nj)
+                    e = (e & kStored) | kInBeam | (j << kSlotShift);
+            }
+            if (reload) n_child = e;
         }
-        const float top = readlane_f(n_lp + n_gp, 0);  // beam[0].probability() :278
-        node = n_node;
-        lp = n_lp / top;
-        gp = n_gp / top;
-        tip = ((n_meta >> 2) & 7) - 1;
-        depth = n_meta >> 5;
-        child = n_child;
-        B = Bn;
+        const float top = bpermf(hbase, n_lp + n_gp);  // beam[0].probability() :278
+        if (go) {
+            node = n_node;
+            lp = n_lp / top;
+            gp = n_gp / top;
+            tip = ((n_meta >> 2) & 7) - 1;
+            depth = n_meta >> 5;
+            child = n_child;
+            B = Bn;
+        }
     }
 
     // ---- walk the best labelling leaf -> root (:285-300) ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    if (lane == 0) {
+    if (q == 0 && alive) {
         uint8_t *lab = p.out.labels + r * p.out.out_stride;
         uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
         int cur_node = node;
         for (int j = depth - 1; j >= 0 && cur_node >= 0; --j) {
-            const int2 q = rec[cur_node];
-            lab[j] = (uint8_t)((q.y & 7) + 1);
-            if (pth) pth[j] = (uint32_t)(q.y >> 3);
-            cur_node = q.x;
+            const int2 e = rec[cur_node];
+            lab[j] = (uint8_t)((e.y & 7) + 1);
+            if (pth) pth[j] = (uint32_t)(e.y >> 3);
+            cur_node = e.x;
         }
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
     }
+}
+
+template <int N, int GW, int RPW>
+hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
+    const int64_t waves = (n_reads + RPW - 1) / RPW;
+    const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+                       stream, p);
+    return hipGetLastError();
 }
 
 }  // namespace
@@ -284,17 +347,22 @@ hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_r
     if (n_reads <= 0) return hipSuccess;
     WaveParams p{in, a, arena, out, read_begin};
     p.in.n_reads = n_reads;  // reads in this launch
-    const unsigned blocks = (unsigned)((n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
-    const dim3 grid(blocks), block(64 * kWavesPerBlock);
-    switch (in.N) {
-        case 3: hipLaunchKernelGGL(beam_wave_kernel<3>, grid, block, 0, stream, p); break;
-        case 4: hipLaunchKernelGGL(beam_wave_kernel<4>, grid, block, 0, stream, p); break;
-        case 5: hipLaunchKernelGGL(beam_wave_kernel<5>, grid, block, 0, stream, p); break;
-        case 6: hipLaunchKernelGGL(beam_wave_kernel<6>, grid, block, 0, stream, p); break;
-        case 7: hipLaunchKernelGGL(beam_wave_kernel<7>, grid, block, 0, stream, p); break;
-        default: return hipErrorInvalidValue;
+    const bool two = a.beam_size <= 5 && in.N <= 5 && !a.force_one_read_per_wave;
+    if (two) {
+        switch (in.N) {
+            case 3: return launch_t<3, 6, 2>(p, n_reads, stream);
+            case 4: return launch_t<4, 6, 2>(p, n_reads, stream);
+            case 5: return launch_t<5, 6, 2>(p, n_reads, stream);
+        }
     }
-    return hipGetLastError();
+    switch (in.N) {
+        case 3: return launch_t<3, 8, 1>(p, n_reads, stream);
+        case 4: return launch_t<4, 8, 1>(p, n_reads, stream);
+        case 5: return launch_t<5, 8, 1>(p, n_reads, stream);
+        case 6: return launch_t<6, 8, 1>(p, n_reads, stream);
+        case 7: return launch_t<7, 8, 1>(p, n_reads, stream);
+    }
+    return hipErrorInvalidValue;
 }
 
 }  // namespace fcd

@@ -131,17 +131,19 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     BeamArgs args = a;
 
     bool use_wave = false;
-    if (kernel == FCD_KERNEL_WAVE) {
+    if (kernel == FCD_KERNEL_WAVE || kernel == FCD_KERNEL_WAVE1) {
         if (!beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf))
             return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8, N <= 7, non-CRF");
         use_wave = true;
     } else if (kernel == FCD_KERNEL_AUTO) {
         use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf);
     }
-    if (use_wave && d.T >= (1ll << 26)) {  // depth is packed into 26 bits there
-        if (kernel == FCD_KERNEL_WAVE) return fail(h, FCD_E_UNSUPPORTED, "wave kernel: T must be < 2^26");
+    // the wave kernel packs node ids and depths into 26 bits
+    if (use_wave && (d.T >= (1ll << 26) || d.T * std::min<int64_t>(beam, 8) * NL + 16 >= (1ll << 26))) {
+        if (kernel != FCD_KERNEL_AUTO) return fail(h, FCD_E_UNSUPPORTED, "wave kernel: T too large");
         use_wave = false;
     }
+    args.force_one_read_per_wave = kernel == FCD_KERNEL_WAVE1 ? 1 : 0;
 
     // Worst-case tree size per read: every step every beam entry creates NL nodes
     // (tree.rs:125 add_node is only called from the expansion loop, search.rs:200-239).

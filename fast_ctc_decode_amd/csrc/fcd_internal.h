@@ -43,6 +43,7 @@ struct BeamArgs {
     const float *init;  // CRF only: [n_reads * init_stride]
     int64_t n_init;
     int64_t init_stride;
+    int force_one_read_per_wave;  // wave kernel: skip the two-reads-per-wavefront variant
 };
 
 // Per-chunk tree arena of the LDS-resident ("generic") beam kernel: one slab per read.

@@ -47,14 +47,15 @@ def test_beam_generic_random(fcd, N, beam):
     check_beam(fcd, x, beam, thr, kernel=fcd.KERNEL_GENERIC)
 
 
-KERNELS = [1, 2]  # FCD_KERNEL_GENERIC (LDS-resident), FCD_KERNEL_WAVE (register-resident)
+KERNELS = [1, 2, 3]  # generic (LDS), wave (two reads per wavefront where possible), wave1
 
 
+@pytest.mark.parametrize("kernel", [2, 3])
 @pytest.mark.parametrize("N", [3, 4, 5, 6, 7])
 @pytest.mark.parametrize("beam", [1, 2, 5, 8])
-def test_beam_wave_random(fcd, N, beam):
-    x = gen_batch(200 + N * 10 + beam, 6, 400, N)
-    check_beam(fcd, x, beam, 0.1 if N <= 5 else 0.05, kernel=fcd.KERNEL_WAVE)
+def test_beam_wave_random(fcd, N, beam, kernel):
+    x = gen_batch(200 + N * 10 + beam, 7, 400, N)
+    check_beam(fcd, x, beam, 0.1 if N <= 5 else 0.05, kernel=kernel)
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
@@ -139,6 +140,7 @@ def test_beam_many_reads_chunked(fcd):
     h.set_workspace_limit(8 << 20)
     try:
         check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_WAVE)
+        check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_WAVE1)
         check_beam(fcd, x, 5, 0.1, kernel=fcd.KERNEL_GENERIC)
     finally:
         h.set_workspace_limit(0)
