@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
         // ---- tree.rs:125-145 add_node: ids in (beam order, label order) == lane order ----
         const bool is_new = cvalid && !exists;
-        const uint64_t m_new = __ballot(is_new);
+        const uint64_t m_new = ballot(is_new);
         const uint32_t w_new = RPW == 1 ? 0u : (hbase ? (uint32_t)(m_new >> 32) : (uint32_t)m_new);
         int n_new, pre_new;
         if (RPW == 1) {
@@ -207,8 +207,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int id = is_self ? node : (is_new ? newid : cid);
 
         // ---- search.rs:261-277 ----
-        const uint64_t m_valid = __ballot(valid);
-        const uint64_t m_nan = __ballot(valid && prob != prob);
+        const uint64_t m_valid = ballot(valid);
+        const uint64_t m_nan = ballot(valid && prob != prob);
         int n_valid;
         bool any_nan;
         if (RPW == 1) {
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const bool ngrp = go && i < Bn;
         if (n_kind == 1 || !is_child) n_child = -1;
         const bool reload = ngrp && n_kind == 2 && is_child;
-        if (__ballot(reload) != 0ull) {
+        if (ballot(reload) != 0ull) {
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up (rare path)
             int e = -1;

@@ -14,6 +14,9 @@ __device__ __forceinline__ uint64_t lanemask_lt() {
 
 __device__ __forceinline__ int popc64(uint64_t m) { return __builtin_popcountll(m); }
 
+// wave-wide vote straight from an i1 (no 0/1 materialisation + compare as __ballot(int) does)
+__device__ __forceinline__ uint64_t ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
+
 // Sort key for the prune step: descending probability, ties -> ascending node index
 // (src/search.rs:245 stable sort by node followed by :262-269 sort by probability; see
 // SURVEY.md 8a A4).  Larger key == earlier in the beam.  prob must not be NaN.

@@ -17,6 +17,96 @@ namespace {
 
 constexpr int kWavesPerBlock = 4;
 
+// Running state of one read's scan, carried across 64-row sub-tiles.
+struct ScanState {
+    int n_out = 0;          // emissions so far (wave-uniform)
+    int carry_label = -1;   // label of the last row of the previous sub-tile (None)
+    float run_total = 0.0f; // open quality run carried across sub-tiles (:337-339)
+    int run_count = 0;
+};
+
+// One sub-tile: lane holds (label, prob) of row base+lane; emits, compacts, accumulates quality.
+__device__ __forceinline__ void scan_subtile(ScanState &st, int label, float prob, bool act,
+                                             int64_t base, int64_t T, int collapse, uint8_t *lab,
+                                             uint32_t *pth, float *qual) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = base + lane;
+    int prev = __shfl_up(label, 1);
+    if (lane == 0) prev = st.carry_label;
+    const bool emit = act && label != 0 && (!collapse || prev != label);  // :347
+    const uint64_t m_emit = ballot(emit);
+    const int my_out = st.n_out + popc64(m_emit & lanemask_lt());
+    if (emit) {
+        lab[my_out] = (uint8_t)label;
+        if (pth) pth[my_out] = (uint32_t)row;
+    }
+    if (qual) {
+        // Each emission opens a run that owns every following non-blank row up to the next
+        // emission; its mean probability is what the reference feeds to phred().
+        const bool nonblank = act && label != 0;
+        const float contrib = nonblank ? prob : 0.0f;  // adding +0.0 is exact
+        const int cnt1 = nonblank ? 1 : 0;
+        // (a) the run carried in from the previous sub-tile absorbs rows [0, first emission)
+        const int first_emit = m_emit ? __builtin_ctzll(m_emit) : kWave;
+        const int tile_rows = (int)((T - base) < kWave ? (T - base) : kWave);
+        const int lim = first_emit < tile_rows ? first_emit : tile_rows;
+        for (int j = 0; j < lim; ++j) {
+            st.run_total += __shfl(contrib, j);
+            st.run_count += __shfl(cnt1, j);
+        }
+        if (m_emit && st.run_count > 0) {
+            if (lane == 0) qual[st.n_out - 1] = st.run_total / (float)st.run_count;
+            st.run_total = 0.0f;
+            st.run_count = 0;
+        }
+        // (b) runs that start in this sub-tile: every head absorbs one more row per iteration
+        float acc = contrib;  // the emission row itself (:362-365)
+        int cnt = cnt1;
+        bool alive = emit;
+        float sh_c = contrib;
+        int sh_n = cnt1;
+        bool sh_e = emit;
+        bool sh_a = act;
+        for (int d = 1; d < kWave; ++d) {
+            sh_c = __shfl_down(sh_c, 1);
+            sh_n = __shfl_down(sh_n, 1);
+            sh_e = __shfl_down((int)sh_e, 1) != 0;
+            sh_a = __shfl_down((int)sh_a, 1) != 0;
+            const bool in_tile = lane + d < kWave && sh_a;
+            if (alive && (!in_tile || sh_e)) alive = false;
+            if (alive) {
+                acc += sh_c;
+                cnt += sh_n;
+            }
+            if (ballot(alive) == 0ull) break;
+        }
+        // a head whose run is closed by a later emission in this sub-tile writes its mean now;
+        // the last head's run stays open and becomes the carry
+        const uint64_t later = m_emit & ~(lanemask_lt() | (1ull << lane));
+        if (emit && later) qual[my_out] = acc / (float)cnt;
+        if (m_emit) {
+            const int last = 63 - __builtin_clzll(m_emit);
+            st.run_total = __shfl(acc, last);
+            st.run_count = __shfl(cnt, last);
+        }
+    }
+    st.n_out += popc64(m_emit);
+    const int last_lane = (int)((T - base) < kWave ? (T - base - 1) : (kWave - 1));
+    st.carry_label = __shfl(label, last_lane);
+}
+
+__device__ __forceinline__ void scan_finish(ScanState &st, int64_t r, float *qual,
+                                            const ResultDesc &out) {
+    const int lane = threadIdx.x & 63;
+    if (qual && st.run_count > 0 && lane == 0)
+        qual[st.n_out - 1] = st.run_total / (float)st.run_count;  // :370-376
+    if (lane == 0) {
+        out.out_len[r] = (uint32_t)st.n_out;
+        if (out.status) out.status[r] = FCD_ST_OK;
+    }
+}
+
+// Generic path: any N, any strides; one row per lane, strided 4-byte loads.
 __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc in, int collapse,
                                                                     ResultDesc out) {
     const int lane = threadIdx.x & 63;
@@ -32,12 +122,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc 
     uint8_t *lab = out.labels + r * out.out_stride;
     uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
     float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
-
-    int n_out = 0;        // emissions so far (wave-uniform)
-    int carry_label = -1; // label of the last row of the previous tile (None)
-    float run_total = 0.0f;  // open run carried across tiles (:337-339)
-    int run_count = 0;
-
+    ScanState st;
     for (int64_t base = 0; base < T; base += kWave) {
         const int64_t row = base + lane;
         const bool act = row < T;
@@ -54,76 +139,93 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc 
                 }
             }
         }
-        int prev = __shfl_up(label, 1);
-        if (lane == 0) prev = carry_label;
-        const bool emit = act && label != 0 && (!collapse || prev != label);  // :347
-        const uint64_t m_emit = __ballot(emit);
-        const int my_out = n_out + popc64(m_emit & lanemask_lt());
-        if (emit) {
-            lab[my_out] = (uint8_t)label;
-            if (pth) pth[my_out] = (uint32_t)row;
-        }
+        scan_subtile(st, label, prob, act, base, T, collapse, lab, pth, qual);
+    }
+    scan_finish(st, r, qual, out);
+}
 
-        if (qual) {
-            // Each emission opens a run that owns every following non-blank row up to the next
-            // emission; its mean probability is what the reference feeds to phred().
-            const bool nonblank = act && label != 0;
-            const float contrib = nonblank ? prob : 0.0f;  // adding +0.0 is exact
-            const int cnt1 = nonblank ? 1 : 0;
-            // (a) the run carried in from the previous tile absorbs rows [0, first emission)
-            const int first_emit = m_emit ? __builtin_ctzll(m_emit) : kWave;
-            const int tile_rows = (int)((T - base) < kWave ? (T - base) : kWave);
-            const int lim = first_emit < tile_rows ? first_emit : tile_rows;
-            for (int j = 0; j < lim; ++j) {
-                run_total += __shfl(contrib, j);
-                run_count += __shfl(cnt1, j);
+// Streaming path for C-contiguous reads (stride_n == 1, stride_t == N, 16-byte aligned reads):
+// the wave pulls a 256-row tile with N fully coalesced 16-byte loads per lane (1 KiB per wave
+// instruction), parks it in LDS and reads it back one row per lane (row stride N dwords: conflict
+// free for odd N), so HBM sees only wide contiguous requests.  The next tile's loads are issued
+// before the current tile is scanned.
+constexpr int kTileRows = 256;
+
+template <int N>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(BatchDesc in,
+                                                                           int collapse,
+                                                                           ResultDesc out) {
+    __shared__ __attribute__((aligned(16))) float s_tile[kWavesPerBlock][kTileRows * N];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (r >= in.n_reads) return;
+    int64_t T = in.T;
+    if (in.lengths) {
+        int64_t t = in.lengths[r];
+        T = t < 0 ? 0 : (t < T ? t : T);
+    }
+    const float *post = in.post + r * in.stride_read;
+    uint8_t *lab = out.labels + r * out.out_stride;
+    uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
+    float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
+    float *tile = s_tile[wave];
+    const int64_t total = T * N;  // floats in this read
+
+    auto fetch = [&](int64_t tile_row0, float4 (&v)[N]) {
+        const int64_t f0 = tile_row0 * N;
+#pragma unroll
+        for (int m = 0; m < N; ++m) {
+            const int64_t f = f0 + (int64_t)(lane + 64 * m) * 4;
+            if (f + 3 < total) {
+                v[m] = *reinterpret_cast<const float4 *>(post + f);
+            } else {
+                v[m].x = f < total ? post[f] : 0.0f;
+                v[m].y = f + 1 < total ? post[f + 1] : 0.0f;
+                v[m].z = f + 2 < total ? post[f + 2] : 0.0f;
+                v[m].w = 0.0f;
             }
-            if (m_emit && run_count > 0) {
-                if (lane == 0) qual[n_out - 1] = run_total / (float)run_count;
-                run_total = 0.0f;
-                run_count = 0;
-            }
-            // (b) runs that start in this tile: every head absorbs one more row per iteration
-            float acc = contrib;  // the emission row itself (:362-365)
-            int cnt = cnt1;
-            bool alive = emit;
-            float sh_c = contrib;
-            int sh_n = cnt1;
-            bool sh_e = emit;
-            bool sh_a = act;
-            for (int d = 1; d < kWave; ++d) {
-                sh_c = __shfl_down(sh_c, 1);
-                sh_n = __shfl_down(sh_n, 1);
-                sh_e = __shfl_down((int)sh_e, 1) != 0;
-                sh_a = __shfl_down((int)sh_a, 1) != 0;
-                const bool in_tile = lane + d < kWave && sh_a;
-                if (alive && (!in_tile || sh_e)) alive = false;
-                if (alive) {
-                    acc += sh_c;
-                    cnt += sh_n;
+        }
+    };
+
+    ScanState st;
+    float4 cur[N], nxt[N];
+    if (T > 0) fetch(0, cur);
+    for (int64_t base = 0; base < T; base += kTileRows) {
+        if (base + kTileRows < T) fetch(base + kTileRows, nxt);
+#pragma unroll
+        for (int m = 0; m < N; ++m)
+            *reinterpret_cast<float4 *>(tile + (lane + 64 * m) * 4) = cur[m];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < kTileRows / 64; ++u) {
+            const int64_t sub = base + 64 * u;
+            if (sub >= T) break;
+            const bool act = sub + lane < T;
+            const float *pr = tile + (64 * u + lane) * N;
+            float prob = pr[0];
+            int label = 0;
+#pragma unroll
+            for (int j = 1; j < N; ++j) {  // find_max: strict '>' keeps the first maximum
+                const float v = pr[j];
+                if (v > prob) {
+                    prob = v;
+                    label = j;
                 }
-                if (__ballot(alive) == 0ull) break;
             }
-            // a head whose run is closed by a later emission in this tile writes its mean now;
-            // the last head's run stays open and becomes the carry
-            const uint64_t later = m_emit & ~(lanemask_lt() | (1ull << lane));
-            if (emit && later) qual[my_out] = acc / (float)cnt;
-            if (m_emit) {
-                const int last = 63 - __builtin_clzll(m_emit);
-                run_total = __shfl(acc, last);
-                run_count = __shfl(cnt, last);
+            if (!act) {
+                label = 0;
+                prob = 0.0f;
             }
+            scan_subtile(st, label, prob, act, sub, T, collapse, lab, pth, qual);
         }
-
-        n_out += popc64(m_emit);
-        const int last_lane = (int)((T - base) < kWave ? (T - base - 1) : (kWave - 1));
-        carry_label = __shfl(label, last_lane);
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < N; ++m) cur[m] = nxt[m];
     }
-    if (qual && run_count > 0 && lane == 0) qual[n_out - 1] = run_total / (float)run_count;  // :370-376
-    if (lane == 0) {
-        out.out_len[r] = (uint32_t)n_out;
-        if (out.status) out.status[r] = FCD_ST_OK;
-    }
+    scan_finish(st, r, qual, out);
 }
 
 // crf_greedy_search (:385-423): the state walk is a serial dependency; one wave per read,
@@ -213,8 +315,22 @@ hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &o
                           hipStream_t stream) {
     if (in.n_reads <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((in.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL(viterbi_kernel, dim3(blocks), dim3(64 * kWavesPerBlock), 0, stream, in,
-                       collapse, out);
+    const dim3 grid(blocks), block(64 * kWavesPerBlock);
+    const bool stream_ok = in.stride_n == 1 && in.stride_t == in.N && (in.stride_read % 4) == 0 &&
+                           (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
+    if (stream_ok) {
+        switch (in.N) {
+#define FCD_VSTREAM(NN)                                                                         \
+    case NN:                                                                                    \
+        hipLaunchKernelGGL(viterbi_stream_kernel<NN>, grid, block, 0, stream, in, collapse, out); \
+        return hipGetLastError();
+            FCD_VSTREAM(2) FCD_VSTREAM(3) FCD_VSTREAM(4) FCD_VSTREAM(5) FCD_VSTREAM(6) FCD_VSTREAM(7)
+            FCD_VSTREAM(8)
+#undef FCD_VSTREAM
+            default: break;
+        }
+    }
+    hipLaunchKernelGGL(viterbi_kernel, grid, block, 0, stream, in, collapse, out);
     return hipGetLastError();
 }
 
