@@ -72,6 +72,51 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
     return obj
 
 
+def pmc_traffic(kernel_prefix):
+    """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_summary.json,
+    produced by tools/profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the
+    same kernel at the same shape, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    if not files:
+        return None, None
+    with open(files[-1]) as f:
+        summ = json.load(f)
+    for name, e in summ.get("kernels", {}).items():
+        if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+            return e["hbm_bytes_per_launch"], "%s: %s; %s; %s" % (
+                os.path.basename(files[-1]), name, e.get("workload", ""), e.get("fetch_correction_note", ""))
+    return None, None
+
+
+def viterbi_roofline(fcd, torch, dev, n_reads=16384, reps=5):
+    """The HBM-bound kernel of the path: viterbi_search on n_reads x T x N,
+    timed with the C ABI's HIP events."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(7)
+    x = torch.rand((n_reads, T, N), generator=g, device=dev, dtype=torch.float32)
+    x /= torch.linalg.vector_norm(x, ord=2, dim=-1, keepdim=True)
+    r = fcd.viterbi_search_batch_raw(x)
+    torch.cuda.synchronize()
+    h = r._handle
+    h.timing_reset()
+    for _ in range(reps):
+        r = fcd.viterbi_search_batch_raw(x)
+    torch.cuda.synchronize()
+    ms, calls = h.timing_mean_ms()
+    mean_L = float(r.out_len.float().mean())
+    bytes_per_read = T * N * 4 + 5.0 * mean_L
+    achieved = n_reads * bytes_per_read / (ms * 1e-3) / 1e9
+    traffic, note = pmc_traffic("viterbi_stream_kernel")
+    return {
+        "kernel": "viterbi_stream_kernel<5> (search::viterbi_search)", "bound": "hbm",
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "traffic": traffic, "traffic_source": note,
+        "reads": n_reads, "kernel_ms": ms, "launches_timed": calls,
+        "reads_per_s": n_reads / (ms * 1e-3), "algorithmic_bytes_per_read": bytes_per_read,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,7 +124,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="reads per GPU per step")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 generic (LDS), 2 wave (registers)")
+    ap.add_argument("--kernel", type=int, default=0,
+                    help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront)")
+    ap.add_argument("--no-viterbi", action="store_true", help="skip the secondary viterbi roofline leg")
     args = ap.parse_args()
 
     import torch
@@ -152,6 +199,12 @@ def main():
         bytes_per_read = T * N * 4 + 5.0 * mean_L  # posteriors in, u8 label + u32 time out
         achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
         cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds)
+        traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2>" if args.kernel in (0, 2)
+                                            else "beam_wave_kernel<5, 8, 1>" if args.kernel == 3
+                                            else "beam_generic_kernel")
+        if args.batch != 4096:
+            traffic, traffic_note = None, None
+        vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
         out = {
             "metric": "reads/s (T=4000, N=5, beam=5)",
             "value": world * B * args.steps / elapsed,
@@ -172,7 +225,8 @@ def main():
                 "reads_per_gpu": B, "T": T, "N": N, "beam_size": BEAM, "beam_cut_threshold": THR,
                 "parallelism": "reads sharded x%d, one RCCL gather of results per step" % world
                                if world > 1 else "single GPU",
-                "kernel": {0: "auto", 1: "generic-lds", 2: "wave-registers"}[args.kernel],
+                "kernel": {0: "auto (wave, two reads per wavefront)", 1: "generic-lds",
+                           2: "wave-registers-2reads", 3: "wave-registers-1read"}[args.kernel],
                 "reads_ok": ok, "mean_labels_per_read": mean_L,
             },
             "roofline": {
@@ -181,12 +235,14 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_note,
                 "kernel": "beam search kernel, %.3f ms per launch (HIP events), %d reads x %.0f "
                           "algorithmic B/read" % (k_ms, B, bytes_per_read),
                 "kernel_ms": k_ms, "launches_timed": k_calls,
             },
             "cpu_baseline": cpu,
+            "viterbi_roofline": vit,
         }
         print(json.dumps(out), flush=True)
     if distributed:

@@ -1,0 +1,42 @@
+"""Workload for rocprofv3 runs: a few launches of each hot kernel at the BASELINE shapes."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+
+import fast_ctc_decode_amd as fcd
+
+
+def gen(B, T, N, seed):
+    g = torch.Generator(device="cuda")
+    g.manual_seed(seed)
+    x = torch.rand((B, T, N), generator=g, device="cuda", dtype=torch.float32)
+    return x / torch.linalg.vector_norm(x, ord=2, dim=-1, keepdim=True)
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "all"
+    reps = 3
+    if which in ("all", "beam"):
+        x = gen(4096, 4000, 5, 1)
+        for _ in range(reps):
+            r = fcd.beam_search_batch_raw(x, 5, 0.1, True)
+        torch.cuda.synchronize()
+        print("beam ok", int((r.status == 0).sum()), "mean L", float(r.out_len.float().mean()))
+    if which in ("all", "viterbi"):
+        x = gen(16384, 4000, 5, 2)
+        for _ in range(reps):
+            r = fcd.viterbi_search_batch_raw(x)
+        torch.cuda.synchronize()
+        print("viterbi mean L", float(r.out_len.float().mean()))
+    if which in ("all", "beam32"):
+        x = gen(2048, 4000, 5, 3)
+        for _ in range(2):
+            r = fcd.beam_search_batch_raw(x, 32, 0.1, True)
+        torch.cuda.synchronize()
+        print("beam32 ok", int((r.status == 0).sum()))
+
+
+if __name__ == "__main__":
+    main()
