@@ -52,8 +52,12 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
     oracle.beam_search_batch(x_host[:8], BEAM, THR, True, 1)
     rate1 = 8.0 / max(time.perf_counter() - t0, 1e-6)
     n = int(min(x_host.shape[0], max(32, rate1 * cores * budget_s)))
+    # enough passes over those n reads to fill ~budget_s of wall time on all cores
+    passes = int(max(1, min(64, rate1 * cores * budget_s / n)))
+    out = oracle.batch_outputs(n, T)  # pre-touched: page faults stay out of the timed call
     t0 = time.perf_counter()
-    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, cores)
+    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, cores,
+                                                          n_passes=passes, out=out)
     dt = time.perf_counter() - t0
     mism = 0
     for i in range(n):
@@ -63,9 +67,9 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
             and np.array_equal(gpu_path[i, :L].astype(np.int64), path[i, :L])
         mism += 0 if ok else 1
     obj = {
-        "value": n / dt, "unit": "reads/s", "cores": cores, "kind": "port",
-        "sample": "first %d reads of rank 0's batch (T=%d N=%d beam=%d thr=%.1f), oracle C "
-                  "restatement of src/search.rs, %d pthreads, %.1f s" % (n, T, N, BEAM, THR, cores, dt),
+        "value": n * passes / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+        "sample": "first %d reads of rank 0's batch x %d passes (T=%d N=%d beam=%d thr=%.1f), oracle C "
+                  "restatement of src/search.rs, %d pthreads, %.1f s" % (n, passes, T, N, BEAM, THR, cores, dt),
         "single_thread_reads_per_s": rate1,
         "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n,
     }
@@ -123,7 +127,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4096, help="reads per GPU per step")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--kernel", type=int, default=0,
                     help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront)")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the secondary viterbi roofline leg")

@@ -60,5 +60,35 @@ def build(force=False, verbose=False):
     return LIB
 
 
+PYMOD_SRC = os.path.join(CSRC, "pymodule.cpp")
+
+
+def pymodule_path():
+    import sysconfig
+    return os.path.join(HERE, "fast_ctc_decode" + sysconfig.get_config_var("EXT_SUFFIX"))
+
+
+def build_pymodule(force=False, verbose=False):
+    """The compiled Python module `fast_ctc_decode` (csrc/pymodule.cpp, pybind11): the C++ host side
+    above the C ABI, mirroring the reference's PyO3 layer.  Links libfcd_hip.so via $ORIGIN."""
+    import sysconfig
+
+    import pybind11
+
+    out = pymodule_path()
+    build(force=False, verbose=verbose)
+    deps = [PYMOD_SRC, os.path.join(HERE, "..", "include", "fcd.h"), LIB]
+    if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
+        return out
+    cmd = ["g++", "-O2", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden", "-ffp-contract=off",
+           "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"], PYMOD_SRC, "-o", out,
+           "-L", HERE, "-lfcd_hip", "-Wl,-rpath,$ORIGIN"]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
     print(build(force="--force" in sys.argv, verbose=True))
+    print(build_pymodule(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,376 @@
+// pymodule.cpp -- the compiled Python module `fast_ctc_decode`, host side above the C ABI.
+//
+// This is the C++ counterpart of the reference's PyO3 layer (/root/reference/src/lib.rs:142-628;
+// no Rust toolchain exists in the build image): same module name, function names, argument names,
+// order and defaults, the same validation order and messages, ValueError for argument errors,
+// RuntimeError carrying the SearchError text for search failures, TypeError for wrong array
+// types, GIL released around the search.  Every search runs on the GPU through include/fcd.h;
+// there is no CPU path in here.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+
+#include <charconv>
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/fcd.h"
+
+namespace py = pybind11;
+
+namespace {
+
+fcd_handle *thread_handle() {
+    // one handle per host thread: the reference's functions are re-entrant (lib.rs:199 releases
+    // the GIL), so concurrent callers must not share a stream / workspace
+    thread_local fcd_handle *h = nullptr;
+    if (!h) {
+        int rc = fcd_create(0, &h);
+        if (rc != FCD_OK || !h)
+            throw std::runtime_error("fast_ctc_decode: no usable gfx950 device (fcd_create failed with " +
+                                     std::to_string(rc) + "); this module has no CPU fallback");
+    }
+    return h;
+}
+
+void check_rc(fcd_handle *h, int rc) {
+    if (rc != FCD_OK)
+        throw std::runtime_error(std::string("libfcd_hip error ") + std::to_string(rc) + ": " +
+                                 fcd_last_error(h));
+}
+
+// lib.rs:143-146: PySequence -> tuple -> str() of every element
+std::vector<std::string> seq_to_vec(const py::object &alphabet) {
+    py::tuple t;
+    try {
+        t = py::tuple(alphabet);
+    } catch (py::error_already_set &) {
+        throw py::type_error("argument 'alphabet': expected a sequence");
+    }
+    std::vector<std::string> out;
+    out.reserve(t.size());
+    for (auto item : t) out.push_back(py::str(item).cast<std::string>());
+    return out;
+}
+
+// PyO3 extracts &PyArrayN<f32>: wrong type / dtype / rank is a TypeError, never a cast
+py::array as_f32(const py::object &o, int ndim, const char *name) {
+    if (!py::isinstance<py::array>(o))
+        throw py::type_error(std::string("argument '") + name + "': expected numpy.ndarray");
+    py::array a = py::reinterpret_borrow<py::array>(o);
+    if (!a.dtype().is(py::dtype::of<float>()) || a.ndim() != ndim)
+        throw py::type_error(std::string("argument '") + name + "': expected a " +
+                             std::to_string(ndim) + "-dimensional float32 array");
+    for (int d = 0; d < ndim; ++d)
+        if (a.strides(d) < 0) return py::array::ensure(a, py::array::c_style);  // staging copies one span
+    return a;
+}
+
+std::string f32_display(float v) {  // Rust `format!("{}", f32)`: shortest round-trip, never scientific
+    char buf[64];
+    auto r = std::to_chars(buf, buf + sizeof(buf), v, std::chars_format::fixed);
+    return std::string(buf, r.ptr);
+}
+
+// lib.rs:331-349, in this order
+void check_beam_args(size_t n_alpha, py::ssize_t inner, py::ssize_t beam_size, float thr) {
+    const float max_beam_cut = 1.0f / (float)n_alpha;
+    if ((py::ssize_t)n_alpha != inner)
+        throw py::value_error("alphabet size " + std::to_string(n_alpha) +
+                              " does not match probability matrix inner dimension " +
+                              std::to_string(inner));
+    if (beam_size == 0) throw py::value_error("beam_size cannot be 0");
+    if (thr < -0.0f) throw py::value_error("beam_cut_threshold must be at least 0.0");
+    if (thr >= max_beam_cut)
+        throw py::value_error("beam_cut_threshold cannot be more than " + f32_display(max_beam_cut));
+}
+
+void check_greedy_alphabet(size_t n_alpha, py::ssize_t inner) {  // lib.rs:190-195
+    if (n_alpha == 0) throw py::value_error("Empty alphabet given");
+    if ((py::ssize_t)n_alpha != inner)
+        throw py::value_error("alphabet size does not match probability matrix dimensions");
+}
+
+size_t to_usize(const py::object &o, const char *name) {  // PyO3 usize extraction
+    if (py::isinstance<py::bool_>(o) || !py::isinstance<py::int_>(o))
+        throw py::type_error(std::string("argument '") + name + "': expected an integer");
+    if (o.cast<py::int_>() < py::int_(0)) throw py::value_error("can't convert negative int to unsigned");
+    return o.cast<size_t>();
+}
+
+void raise_status(int st) {  // lib.rs:363 map_err -> PyRuntimeError(format!("{}", e))
+    if (st != FCD_ST_OK) throw std::runtime_error(fcd_status_string(st));
+}
+
+void append_utf8(std::string &s, uint32_t cp) {
+    if (cp < 0x80) s.push_back((char)cp);
+    else if (cp < 0x800) { s.push_back((char)(0xC0 | (cp >> 6))); s.push_back((char)(0x80 | (cp & 0x3F))); }
+    else if (cp < 0x10000) {
+        s.push_back((char)(0xE0 | (cp >> 12))); s.push_back((char)(0x80 | ((cp >> 6) & 0x3F)));
+        s.push_back((char)(0x80 | (cp & 0x3F)));
+    } else {
+        s.push_back((char)(0xF0 | (cp >> 18))); s.push_back((char)(0x80 | ((cp >> 12) & 0x3F)));
+        s.push_back((char)(0x80 | ((cp >> 6) & 0x3F))); s.push_back((char)(0x80 | (cp & 0x3F)));
+    }
+}
+
+std::string reverse_chars(const std::string &s) {  // Rust `.chars().rev().collect()`
+    std::string out;
+    out.reserve(s.size());
+    size_t end = s.size();
+    while (end > 0) {
+        size_t start = end - 1;
+        while (start > 0 && ((unsigned char)s[start] & 0xC0) == 0x80) --start;
+        out.append(s, start, end - start);
+        end = start;
+    }
+    return out;
+}
+
+struct Out {
+    std::vector<uint8_t> labels;
+    std::vector<uint32_t> path;
+    std::vector<float> qual;
+    uint32_t len = 0;
+    int32_t status = 0;
+    fcd_result res{};
+    Out(py::ssize_t T, bool want_path, bool want_qual) {
+        const size_t w = T > 0 ? (size_t)T : 1;
+        labels.resize(w);
+        if (want_path) path.resize(w);
+        if (want_qual) qual.resize(w);
+        res.labels = labels.data();
+        res.path = want_path ? path.data() : nullptr;
+        res.qual = want_qual ? qual.data() : nullptr;
+        res.out_len = &len;
+        res.status = &status;
+        res.out_stride = (int64_t)w;
+    }
+};
+
+fcd_batch batch2(const py::array &a) {  // (T, N) view as a one-read batch, element strides
+    fcd_batch b{};
+    b.post = static_cast<const float *>(a.data());
+    b.n_reads = 1;
+    b.T = a.shape(0);
+    b.S = 1;
+    b.N = a.shape(1);
+    b.stride_read = 0;
+    b.stride_t = a.strides(0) / 4;
+    b.stride_n = a.strides(1) / 4;
+    return b;
+}
+
+fcd_batch batch3(const py::array &a) {  // (T, S, N)
+    fcd_batch b{};
+    b.post = static_cast<const float *>(a.data());
+    b.n_reads = 1;
+    b.T = a.shape(0);
+    b.S = a.shape(1);
+    b.N = a.shape(2);
+    b.stride_t = a.strides(0) / 4;
+    b.stride_s = a.strides(1) / 4;
+    b.stride_n = a.strides(2) / 4;
+    return b;
+}
+
+py::list path_list(const Out &o) {
+    py::list l;
+    for (uint32_t i = 0; i < o.len; ++i) l.append(py::int_((size_t)o.path[i]));
+    return l;
+}
+
+// ---- viterbi_search: lib.rs:170-212 ----
+py::tuple viterbi_search(const py::object &network_output, const py::object &alphabet, bool qstring,
+                         float qscale, float qbias, bool collapse_repeats) {
+    py::array x = as_f32(network_output, 2, "network_output");
+    auto alpha = seq_to_vec(alphabet);
+    check_greedy_alphabet(alpha.size(), x.shape(1));
+    if (x.shape(0) == 0)
+        throw std::runtime_error("network_output is empty (the reference asserts and aborts here)");
+    Out o(x.shape(0), true, qstring);
+    fcd_batch b = batch2(x);
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_viterbi_search_host(h, &b, collapse_repeats ? 1 : 0, &o.res);
+    }
+    check_rc(h, rc);
+    std::string seq;
+    for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
+    if (qstring)
+        for (uint32_t i = 0; i < o.len; ++i) append_utf8(seq, fcd_phred(o.qual[i], qscale, qbias));
+    return py::make_tuple(py::str(seq), path_list(o));
+}
+
+// ---- beam_search: lib.rs:318-365 ----
+py::tuple beam_search(const py::object &network_output, const py::object &alphabet,
+                      const py::object &beam_size_o, float beam_cut_threshold, bool collapse_repeats) {
+    py::array x = as_f32(network_output, 2, "network_output");
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    check_beam_args(alpha.size(), x.shape(1), (py::ssize_t)beam_size, beam_cut_threshold);
+    Out o(x.shape(0), true, false);
+    fcd_batch b = batch2(x);
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_beam_search_host(h, &b, (int64_t)beam_size, beam_cut_threshold,
+                                  collapse_repeats ? 1 : 0, FCD_KERNEL_AUTO, &o.res);
+    }
+    check_rc(h, rc);
+    raise_status(o.status);
+    std::string seq;
+    for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
+    return py::make_tuple(py::str(seq), path_list(o));
+}
+
+// ---- crf_beam_search: lib.rs:252-286 (validates only the alphabet) ----
+py::tuple crf_beam_search(const py::object &network_output, const py::object &init_state,
+                          const py::object &alphabet, const py::object &beam_size_o,
+                          float beam_cut_threshold) {
+    py::array x = as_f32(network_output, 3, "network_output");
+    py::array init = py::array::ensure(as_f32(init_state, 1, "init_state"), py::array::c_style);
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    check_greedy_alphabet(alpha.size(), x.shape(2));
+    if (x.size() == 0 || init.size() == 0)
+        throw std::runtime_error("network_output/init_state is empty (the reference asserts and aborts here)");
+    if (beam_size == 0) raise_status(FCD_ST_RAN_OUT_OF_BEAM);  // truncate(0) empties the beam (search.rs:133-137)
+    Out o(x.shape(0), true, false);
+    fcd_batch b = batch3(x);
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_crf_beam_search_host(h, &b, static_cast<const float *>(init.data()), init.shape(0),
+                                      init.shape(0), (int64_t)beam_size, beam_cut_threshold, &o.res);
+    }
+    check_rc(h, rc);
+    raise_status(o.status);
+    // search.rs:146-156: labels appended leaf -> root, then the CHARACTERS are reversed
+    std::string rev;
+    for (uint32_t i = o.len; i > 0; --i) rev += alpha[o.labels[i - 1]];
+    return py::make_tuple(py::str(reverse_chars(rev)), path_list(o));
+}
+
+// ---- crf_greedy_search: lib.rs:214-250 ----
+py::tuple crf_greedy_search(const py::object &network_output, const py::object &init_state,
+                            const py::object &alphabet, bool qstring, float qscale, float qbias) {
+    py::array x = as_f32(network_output, 3, "network_output");
+    py::array init = py::array::ensure(as_f32(init_state, 1, "init_state"), py::array::c_style);
+    auto alpha = seq_to_vec(alphabet);
+    check_greedy_alphabet(alpha.size(), x.shape(2));
+    if (x.size() == 0 || init.size() == 0)
+        throw std::runtime_error("network_output/init_state is empty (the reference asserts and aborts here)");
+    Out o(x.shape(0), true, true);
+    fcd_batch b = batch3(x);
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_crf_greedy_search_host(h, &b, static_cast<const float *>(init.data()), init.shape(0),
+                                        init.shape(0), &o.res);
+    }
+    check_rc(h, rc);
+    raise_status(o.status);
+    std::string seq;
+    for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
+    if (qstring)
+        for (uint32_t i = 0; i < o.len; ++i) append_utf8(seq, fcd_phred(o.qual[i], qscale, qbias));
+    return py::make_tuple(py::str(seq), path_list(o));
+}
+
+int g_logadd_mode = FCD_LOGADD_LOGSUMEXP;
+
+// ---- beam_search_duplex: lib.rs:401-488 ----
+py::str beam_search_duplex(const py::object &network_output_1, const py::object &network_output_2,
+                           const py::object &alphabet, const py::object &envelope,
+                           const py::object &beam_size_o, float beam_cut_threshold,
+                           bool collapse_repeats) {
+    py::array x1 = as_f32(network_output_1, 2, "network_output_1");
+    py::array x2 = as_f32(network_output_2, 2, "network_output_2");
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    if (x1.shape(1) != x2.shape(1)) throw py::value_error("inner axes of the network outputs do not match");
+    check_beam_args(alpha.size(), x1.shape(1), (py::ssize_t)beam_size, beam_cut_threshold);
+    const py::ssize_t T1 = x1.shape(0), T2 = x2.shape(0);
+    std::vector<uint64_t> env_default;
+    py::array env_arr;
+    const uint64_t *env = nullptr;
+    if (!envelope.is_none()) {  // lib.rs:445-456
+        if (!py::isinstance<py::array>(envelope))
+            throw py::type_error("argument 'envelope': expected numpy.ndarray");
+        py::array e = py::reinterpret_borrow<py::array>(envelope);
+        if (!e.dtype().is(py::dtype::of<uint64_t>()) || e.ndim() != 2)
+            throw py::type_error("argument 'envelope': expected a 2-dimensional uint64 array");
+        if (e.shape(0) != T1) throw py::value_error("the lengths of network_output_1 and envelope do not match");
+        if (e.shape(1) != 2) throw py::value_error("the inner axis of envelope must have size 2");
+        env_arr = py::array::ensure(e, py::array::c_style);
+        env = static_cast<const uint64_t *>(env_arr.data());
+    } else {  // lib.rs:459-468: every row searches the whole of read 2
+        env_default.resize((size_t)(T1 > 0 ? T1 : 1) * 2);
+        for (py::ssize_t t = 0; t < T1; ++t) {
+            env_default[2 * t] = 0;
+            env_default[2 * t + 1] = (uint64_t)T2;
+        }
+        env = env_default.data();
+    }
+    if (T1 == 0)
+        throw std::runtime_error("network_output_1 is empty (the reference indexes envelope[(0,1)] and aborts)");
+    Out o(T1, false, false);
+    fcd_batch b1 = batch2(x1), b2 = batch2(x2);
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_beam_search_duplex_host(h, &b1, &b2, env, T1, (int64_t)beam_size, beam_cut_threshold,
+                                         collapse_repeats ? 1 : 0, g_logadd_mode, &o.res);
+    }
+    check_rc(h, rc);
+    raise_status(o.status);
+    std::string seq;
+    for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
+    return py::str(seq);
+}
+
+py::str crf_beam_search_duplex(const py::args &, const py::kwargs &) {
+    // src/lib.rs:490-578 -> duplex.rs:652-834: outside BASELINE.json's north star
+    throw std::runtime_error("crf_beam_search_duplex is not available in the MI355X build");
+}
+
+}  // namespace
+
+PYBIND11_MODULE(fast_ctc_decode, m) {
+    m.doc() = "Methods for labelling RNN results using CTC decoding (MI355X / HIP build of fast_ctc_decode).";
+    using namespace pybind11::literals;
+    m.def("viterbi_search", &viterbi_search, "network_output"_a, "alphabet"_a, "qstring"_a = false,
+          "qscale"_a = 1.0f, "qbias"_a = 0.0f, "collapse_repeats"_a = true,
+          "viterbi_search(network_output, alphabet, qstring=False, qscale=1.0, qbias=0.0, collapse_repeats=True)");
+    m.def("beam_search", &beam_search, "network_output"_a, "alphabet"_a, "beam_size"_a = 5,
+          "beam_cut_threshold"_a = 0.0f, "collapse_repeats"_a = true,
+          "beam_search(network_output, alphabet, beam_size=5, beam_cut_threshold=0.0, collapse_repeats=True)");
+    m.def("crf_beam_search", &crf_beam_search, "network_output"_a, "init_state"_a, "alphabet"_a,
+          "beam_size"_a = 5, "beam_cut_threshold"_a = 0.0f,
+          "crf_beam_search(network_output, init_state, alphabet, beam_size, beam_cut_threshold)");
+    m.def("crf_greedy_search", &crf_greedy_search, "network_output"_a, "init_state"_a, "alphabet"_a,
+          "qstring"_a = false, "qscale"_a = 1.0f, "qbias"_a = 0.0f,
+          "crf_greedy_search(network_output, init_state, alphabet)");
+    m.def("beam_search_duplex", &beam_search_duplex, "network_output_1"_a, "network_output_2"_a,
+          "alphabet"_a, "envelope"_a = py::none(), "beam_size"_a = 5, "beam_cut_threshold"_a = 0.0f,
+          "collapse_repeats"_a = true,
+          "beam_search_duplex(network_output_1, network_output_2, alphabet, envelope=None, beam_size=5, "
+          "beam_cut_threshold=0.0, collapse_repeats=True)");
+    m.def("crf_beam_search_duplex", &crf_beam_search_duplex);
+    // not part of the reference surface: selects what the reference fixes at build time
+    // (`fastexp` feature on = "max", off = "logsumexp"; SURVEY.md finding 3)
+    m.def("_set_duplex_logadd_mode", [](const std::string &mode) {
+        if (mode == "logsumexp") g_logadd_mode = FCD_LOGADD_LOGSUMEXP;
+        else if (mode == "max") g_logadd_mode = FCD_LOGADD_MAX;
+        else throw py::value_error("mode must be 'logsumexp' or 'max'");
+    });
+    m.attr("__version__") = "0.3.7";  // src/lib.rs:626 (CARGO_PKG_VERSION of the mirrored reference)
+}

@@ -32,10 +32,19 @@ struct fcdo_tree {
     int32_t *root_children;
 };
 
-fcdo_tree *fcdo_tree_new(int64_t n_labels) {
+static fcdo_tree *tree_new_cap(int64_t n_labels, int64_t cap);
+
+fcdo_tree *fcdo_tree_new(int64_t n_labels) { return tree_new_cap(n_labels, 1024); }
+
+static void tree_reset(fcdo_tree *t) {
+    t->len = 0;
+    for (int64_t i = 0; i < t->n_labels; ++i) t->root_children[i] = -1;
+}
+
+static fcdo_tree *tree_new_cap(int64_t n_labels, int64_t cap) {
     fcdo_tree *t = (fcdo_tree *)calloc(1, sizeof(*t));
     t->n_labels = n_labels;
-    t->cap = 1024;
+    t->cap = cap > 16 ? cap : 16;
     t->parent = (int32_t *)malloc(sizeof(int32_t) * t->cap);
     t->label = (int32_t *)malloc(sizeof(int32_t) * t->cap);
     t->data = (int64_t *)malloc(sizeof(int64_t) * t->cap);
@@ -295,14 +304,44 @@ static int64_t tree_walk_1d(const fcdo_tree *tree, int32_t node, int32_t *labels
     return n;
 }
 
+/* Reusable per-thread scratch of the batch driver (avoids allocator traffic in the timed loop). */
+typedef struct {
+    fcdo_tree *tree;
+    sp1vec beam, next;
+    sp1 *tmp;
+    int64_t tmpcap;
+} beam_ws;
+
+static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                          int64_t beam_size, float thr, int collapse_repeats, int32_t *labels,
+                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out);
+
 int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                      int64_t beam_size, float thr, int collapse_repeats,
                      int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out) {
+    beam_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.tree = fcdo_tree_new(N - 1);
+    int st = beam_search_ws(&ws, x, T, N, rs, cs, beam_size, thr, collapse_repeats, labels, path,
+                            n_out, n_nodes_out);
+    free(ws.beam.v);
+    free(ws.next.v);
+    free(ws.tmp);
+    fcdo_tree_free(ws.tree);
+    return st;
+}
+
+static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                          int64_t beam_size, float thr, int collapse_repeats, int32_t *labels,
+                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out) {
     int64_t alphabet_size = N - 1; /* :167 */
-    fcdo_tree *tree = fcdo_tree_new(alphabet_size);
-    sp1vec beam = {0}, next = {0};
-    sp1 *tmp = NULL;
-    int64_t tmpcap = 0;
+    fcdo_tree *tree = ws->tree;
+    tree_reset(tree);
+    sp1vec beam = ws->beam, next = ws->next;
+    beam.len = 0;
+    next.len = 0;
+    sp1 *tmp = ws->tmp;
+    int64_t tmpcap = ws->tmpcap;
     int status = FCDO_OK;
     sp1 root = {-1, 0, 0.0f, 1.0f}; /* :170-175 */
     sp1_push(&beam, root);
@@ -348,10 +387,10 @@ int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t c
 
     if (status == FCDO_OK) *n_out = tree_walk_1d(tree, beam.v[0].node, labels, path);
     if (n_nodes_out) *n_nodes_out = tree->len;
-    free(beam.v);
-    free(next.v);
-    free(tmp);
-    fcdo_tree_free(tree);
+    ws->beam = beam;
+    ws->next = next;
+    ws->tmp = tmp;
+    ws->tmpcap = tmpcap;
     return status;
 }
 
@@ -932,6 +971,7 @@ int fcdo_crf_beam_search_duplex(const float *x1, int64_t T1, const int64_t *st1,
  * ---------------------------------------------------------------------------------------- */
 typedef struct {
     const float *x;
+    int64_t n_tasks; /* n_reads * passes: task k decodes read k % n_reads; only pass 0 is stored */
     int64_t n_reads, T, N, beam_size;
     float thr;
     int collapse, kind; /* kind 0 = beam, 1 = viterbi */
@@ -943,21 +983,38 @@ typedef struct {
 
 static void *batch_worker(void *arg) {
     batch_job *j = (batch_job *)arg;
+    beam_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    /* worst-case tree up front: T * beam * labels nodes (search.rs:200-239) */
+    ws.tree = tree_new_cap(j->N - 1, j->kind == 0 ? j->T * j->beam_size * (j->N - 1) + 16 : 16);
+    int32_t *sl = (int32_t *)malloc(sizeof(int32_t) * (j->T > 0 ? j->T : 1));
+    int64_t *sp = (int64_t *)malloc(sizeof(int64_t) * (j->T > 0 ? j->T : 1));
     for (;;) {
-        int64_t r = __sync_fetch_and_add(j->next, 1);
-        if (r >= j->n_reads) break;
+        int64_t k = __sync_fetch_and_add(j->next, 1);
+        if (k >= j->n_tasks) break;
+        const int64_t r = k % j->n_reads;
+        const int store = k < j->n_reads;
         const float *x = j->x + r * j->T * j->N;
+        int32_t *ol = store ? j->labels + r * j->T : sl;
+        int64_t *op = store ? j->path + r * j->T : sp;
         int64_t n = 0;
         int st;
         if (j->kind == 0)
-            st = fcdo_beam_search(x, j->T, j->N, j->N, 1, j->beam_size, j->thr, j->collapse,
-                                  j->labels + r * j->T, j->path + r * j->T, &n, NULL);
+            st = beam_search_ws(&ws, x, j->T, j->N, j->N, 1, j->beam_size, j->thr, j->collapse, ol,
+                                op, &n, NULL);
         else
-            st = fcdo_viterbi_search(x, j->T, j->N, j->N, 1, j->collapse, 1.0f, 0.0f,
-                                     j->labels + r * j->T, j->path + r * j->T, NULL, &n);
-        j->lens[r] = (st == FCDO_OK) ? n : 0;
-        if (j->status) j->status[r] = st;
+            st = fcdo_viterbi_search(x, j->T, j->N, j->N, 1, j->collapse, 1.0f, 0.0f, ol, op, NULL, &n);
+        if (store) {
+            j->lens[r] = (st == FCDO_OK) ? n : 0;
+            if (j->status) j->status[r] = st;
+        }
     }
+    free(sl);
+    free(sp);
+    free(ws.beam.v);
+    free(ws.next.v);
+    free(ws.tmp);
+    fcdo_tree_free(ws.tree);
     return NULL;
 }
 
@@ -978,13 +1035,15 @@ static int run_batch(batch_job *job, int n_threads) {
 int fcdo_beam_search_batch(const float *x, int64_t n_reads, int64_t T, int64_t N,
                            int64_t beam_size, float thr, int collapse,
                            int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
-                           int n_threads) {
-    batch_job job = {x, n_reads, T, N, beam_size, thr, collapse, 0, labels, path, lens, status, NULL};
+                           int n_threads, int64_t n_passes) {
+    if (n_passes < 1) n_passes = 1;
+    batch_job job = {x, n_reads * n_passes, n_reads, T, N, beam_size, thr, collapse, 0,
+                     labels, path, lens, status, NULL};
     return run_batch(&job, n_threads);
 }
 
 int fcdo_viterbi_batch(const float *x, int64_t n_reads, int64_t T, int64_t N, int collapse,
                        int32_t *labels, int64_t *path, int64_t *lens, int n_threads) {
-    batch_job job = {x, n_reads, T, N, 0, 0.0f, collapse, 1, labels, path, lens, NULL, NULL};
+    batch_job job = {x, n_reads, n_reads, T, N, 0, 0.0f, collapse, 1, labels, path, lens, NULL, NULL};
     return run_batch(&job, n_threads);
 }

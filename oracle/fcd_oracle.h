@@ -111,11 +111,12 @@ int fcdo_crf_beam_search_duplex(const float *x1, int64_t T1, const int64_t *st1 
  * Batch driver used by bench.py's cpu_baseline leg and the differential tests:
  * decodes n_reads C-contiguous (T,N) reads with beam_search, n_threads pthreads
  * (one read per task).  labels/path are (n_reads, T) row-major, lens/status (n_reads,).
+ * n_passes > 1 decodes the batch that many times (timing only; the first pass is stored).
  */
 int fcdo_beam_search_batch(const float *x, int64_t n_reads, int64_t T, int64_t N,
                            int64_t beam_size, float thr, int collapse,
                            int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
-                           int n_threads);
+                           int n_threads, int64_t n_passes);
 
 int fcdo_viterbi_batch(const float *x, int64_t n_reads, int64_t T, int64_t N, int collapse,
                        int32_t *labels, int64_t *path, int64_t *lens, int n_threads);

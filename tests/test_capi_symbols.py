@@ -82,3 +82,32 @@ def test_validation_without_gpu():
         fcd.beam_search(x.astype(np.float64), "NACGT")
     with pytest.raises(TypeError):
         fcd.beam_search(x)
+
+
+def test_compiled_module_surface_and_validation():
+    """The compiled drop-in module (csrc/pymodule.cpp): reference names, defaults, messages."""
+    import numpy as np
+    import fast_ctc_decode as m
+    assert m.__version__ == "0.3.7"
+    for name in ("beam_search", "beam_search_duplex", "viterbi_search", "crf_greedy_search",
+                 "crf_beam_search", "crf_beam_search_duplex"):  # src/lib.rs:619-624
+        assert callable(getattr(m, name))
+    x = np.full((10, 5), 0.2, np.float32)
+    with pytest.raises(ValueError, match="alphabet size 6 does not match probability matrix inner dimension 5"):
+        m.beam_search(x, "NACGTX")
+    with pytest.raises(ValueError, match="beam_size cannot be 0"):
+        m.beam_search(network_output=x, alphabet="NACGT", beam_size=0)
+    with pytest.raises(ValueError, match="beam_cut_threshold cannot be more than 0.33333334"):
+        m.beam_search(x[:, :3], "NAB", 5, 0.5)
+    with pytest.raises(ValueError, match="inner axes of the network outputs do not match"):
+        m.beam_search_duplex(x, x[:, :4], "NACGT")
+    with pytest.raises(ValueError, match="the lengths of network_output_1 and envelope do not match"):
+        m.beam_search_duplex(x, x, "NACGT", np.zeros((3, 2), np.uint64))
+    with pytest.raises(ValueError, match="the inner axis of envelope must have size 2"):
+        m.beam_search_duplex(x, x, "NACGT", np.zeros((10, 3), np.uint64))
+    with pytest.raises(ValueError, match="Empty alphabet given"):
+        m.viterbi_search(x, [])
+    with pytest.raises(TypeError):
+        m.viterbi_search(x.astype(np.float64), "NACGT")
+    with pytest.raises(TypeError):
+        m.crf_beam_search(x, x[0], "NACGT")  # rank 2 instead of 3
