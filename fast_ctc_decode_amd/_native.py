@@ -20,12 +20,12 @@ LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
 # every symbol include/fcd.h declares (tests/test_capi_symbols.py checks the .so against this
 # list AND against the header text)
 SYMBOLS = [
-    "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream",
+    "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host",
-    "fcd_crf_beam_search_dev", "fcd_crf_beam_search_host",
+    "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k", "fcd_crf_beam_search_host",
     "fcd_crf_greedy_search_dev", "fcd_crf_greedy_search_host",
     "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
     "fcd_phred",
@@ -84,6 +84,7 @@ def load():
         lib.fcd_create.argtypes = [i32, C.POINTER(P)]
         lib.fcd_destroy.argtypes = [P]
         lib.fcd_set_stream.argtypes = [P, P]
+        lib.fcd_reset_stream.argtypes = [P]
         lib.fcd_synchronize.argtypes = [P]
         lib.fcd_last_error.argtypes = [P]
         lib.fcd_last_error.restype = C.c_char_p
@@ -102,6 +103,7 @@ def load():
             getattr(lib, "fcd_crf_greedy_search_" + sfx).argtypes = [P, BP, P, i64, i64, RP]
             getattr(lib, "fcd_beam_search_duplex_" + sfx).argtypes = [
                 P, BP, BP, P, i64, i64, f32, i32, i32, RP]
+        lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
         lib.fcd_phred.argtypes = [f32, f32, f32]
         lib.fcd_phred.restype = C.c_uint32
         _lib = lib
@@ -127,7 +129,11 @@ class Handle:
             raise NativeError("libfcd_hip error %d: %s" % (rc, msg.decode() if msg else ""))
 
     def set_stream(self, stream_ptr):
+        """Launch on this hipStream_t handle; 0/None is the HIP null stream (torch's default)."""
         self.check(self.lib.fcd_set_stream(self.ptr, C.c_void_p(stream_ptr or None)))
+
+    def reset_stream(self):
+        self.check(self.lib.fcd_reset_stream(self.ptr))
 
     def synchronize(self):
         self.check(self.lib.fcd_synchronize(self.ptr))

@@ -498,15 +498,16 @@ def viterbi_search_batch(network_outputs, alphabet, qstring=False, qscale=1.0, q
 
 
 def crf_beam_search_batch_raw(network_outputs, init_states, beam_size=5, beam_cut_threshold=0.0,
-                              lengths=None):
-    """(B,T,S,N) posteriors + (B,n_init) initial state scores -> BatchResult."""
+                              lengths=None, kernel=nat.KERNEL_AUTO):
+    """(B,T,S,N) posteriors + (B,n_init) initial state scores -> BatchResult.
+    `kernel` is honoured for device tensors only (host arrays use the automatic choice)."""
     if _is_torch_cuda(network_outputs):
         import torch
         init = torch.as_tensor(init_states, dtype=torch.float32,
                                device=network_outputs.device).contiguous()
-        r = _torch_call("fcd_crf_beam_search_dev", network_outputs, True, lengths,
+        r = _torch_call("fcd_crf_beam_search_dev_k", network_outputs, True, lengths,
                         (C.c_void_p(init.data_ptr()), int(init.shape[1]), int(init.shape[1]),
-                         int(beam_size), float(beam_cut_threshold)))
+                         int(beam_size), float(beam_cut_threshold), int(kernel)))
         r._keep = r._keep + (init,)
         return r
     x = _stack_host(network_outputs, 4)

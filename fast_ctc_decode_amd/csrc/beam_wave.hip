@@ -66,12 +66,18 @@ __device__ __forceinline__ int perm(int dst_lane, int v) {
 constexpr int kWavesPerBlock = 4;
 constexpr int kFifo = 8;  // registers in the row FIFO
 
-template <int N, int GW, int RPW>
+// S == 0: search::beam_search.  S > 0: search::crf_beam_search (:38-157) with S transition states:
+// the row is probs[t, state, :] of the entry's state, there is no repeat-stay, and an extension
+// moves to state (state * n_base) % n_state + label (:97).
+template <int N, int GW, int RPW, int S>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
+    constexpr bool CRF = S > 0;
     constexpr int NL = N - 1;
     constexpr int HALF = 64 / RPW;
     constexpr int BCAP = HALF / GW;     // beam slots per read
-    constexpr int RPR = HALF / N;       // rows per FIFO register
+    constexpr int E = (CRF ? S : 1) * N; // posterior values per timestep
+    constexpr int RPR = HALF / E;       // rows per FIFO register
+    static_assert(RPR >= 1, "one timestep must fit the lanes of a half");
     constexpr int RW = NL <= 4 ? 4 : 8; // child-row width in the arena
     static_assert(N <= GW - 1, "a scratch lane per group is required");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const int grp0 = hbase + i * GW;         // lane 0 of my group
     const int dummy = idle ? lane : grp0 + GW - 1;
     const int beam_size = p.a.beam_size;
-    const bool collapse = p.a.collapse != 0;
+    const bool collapse = !CRF && p.a.collapse != 0;
     const float thr = p.a.thr;
     uint64_t *keys = s_keys[wave];
 
@@ -111,7 +117,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
 
     const float *post = p.in.post + r * p.in.stride_read;
-    const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n;
+    const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
     int2 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
     int32_t *rows = p.arena.rows + (has_read ? local : 0) * p.arena.cap_nodes * RW;
     const int cap = (int)p.arena.cap_nodes;
@@ -125,13 +131,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     int B = 1;
     int nn = 0;
     bool alive = has_read;
+    int state = 0;
+    if (CRF && has_read) {
+        // search.rs:54-59: state = argmax(init), label_prob = max(init), gap_prob = init[0];
+        // ndarray-stats: first maximum wins, NaN -> Err -> unwrap() panics
+        const float *init = p.a.init + r * p.a.init_stride;
+        float m = init[0];
+        bool bad = m != m;
+        for (int64_t j = 1; j < p.a.n_init; ++j) {
+            const float e = init[j];
+            bad = bad || (e != e);
+            if (e > m) {
+                m = e;
+                state = (int)j;
+            }
+        }
+        lp = m;
+        gp = init[0];
+        if ((bad || state >= S) && T > 0) {
+            if (q == 0) {
+                p.out.status[r] = FCD_ST_BAD_STATE;
+                p.out.out_len[r] = 0;
+            }
+            alive = false;
+            state = 0;
+        }
+    }
 
     // ---- row FIFO: register j holds rows [blk*RPR, blk*RPR+RPR) of block (front + j) ----
-    const int fg = q / N, fc = q - fg * N;  // this lane's (row-in-block, column) as a FIFO element
-    const bool f_lane = q < RPR * N;
+    // this lane's (row-in-block, state, column) as a FIFO element
+    const int fg = q / E, fe = q - fg * E, fs = fe / N, fc = fe - fs * N;
+    const bool f_lane = q < RPR * E;
     auto load_block = [&](int blk) -> float {
         const int row = blk * RPR + fg;
-        return (f_lane && row < T) ? post[(int64_t)row * st_t + fc * st_n] : 0.0f;
+        return (f_lane && row < T) ? post[(int64_t)row * st_t + fs * st_s + fc * st_n] : 0.0f;
     };
     float win[kFifo];
 #pragma unroll
@@ -142,10 +175,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     for (int t = 0; t < Tmax; ++t) {
         const bool act = alive && t < T;
         // ---- the three row values this lane needs ----
-        const int rbase = hbase + g * N;
+        const int rbase = hbase + g * E + (CRF ? state * N : 0);
         const float pr0 = bpermf(rbase, win[0]);
         const float pk = bpermf(rbase + (is_child ? k : 0), win[0]);
-        const float ptip = bpermf(rbase + tip + 1, win[0]);
+        const float ptip = CRF ? 0.0f : bpermf(rbase + tip + 1, win[0]);
         if (++g == RPR) {
             g = 0;
 #pragma unroll
@@ -274,11 +307,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int src = bperm(grp0, src0);  // every lane of new group s knows its source lane
         const int tipc = is_self ? tip : l;
         const int depc = is_self ? depth : depth + 1;
+        const int statec = (CRF && !is_self) ? (state * NL) % S + l : state;  // :97
         const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
         const int n_node = bperm(src, id);
         const float n_lp = bpermf(src, clp);
         const float n_gp = bpermf(src, cgp);
         const int n_meta = bperm(src, meta);
+        const int n_state = CRF ? bperm(src, statec) : 0;
         int n_child = bperm(src + k, child);  // meaningful when the source is a self lane
         const int n_kind = n_meta & 3;
         const bool ngrp = go && i < Bn;
@@ -306,6 +341,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             depth = n_meta >> 5;
             child = n_child;
             B = Bn;
+            if (CRF) state = n_state;  // always < S for the instantiated (N, S) = (5, 4): (s*4) % 4 + l = l
         }
     }
 
@@ -326,19 +362,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     }
 }
 
-template <int N, int GW, int RPW>
+template <int N, int GW, int RPW, int S = 0>
 hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
     const int64_t waves = (n_reads + RPW - 1) / RPW;
     const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+    hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                        stream, p);
     return hipGetLastError();
 }
 
 }  // namespace
 
-bool beam_wave_supported(int beam_size, int N, int crf) {
-    return !crf && beam_size >= 1 && beam_size <= 8 && N >= 3 && N <= 7;
+bool beam_wave_supported(int beam_size, int N, int crf, int S) {
+    if (beam_size < 1 || beam_size > 8) return false;
+    if (crf) return N == 5 && S == 4;  // the CRF instantiations: 4 states x 5 symbols
+    return N >= 3 && N <= 7;
 }
 
 hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
@@ -348,6 +386,10 @@ hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_r
     WaveParams p{in, a, arena, out, read_begin};
     p.in.n_reads = n_reads;  // reads in this launch
     const bool two = a.beam_size <= 5 && in.N <= 5 && !a.force_one_read_per_wave;
+    if (a.crf) {
+        if (in.N != 5 || in.S != 4) return hipErrorInvalidValue;
+        return two ? launch_t<5, 6, 2, 4>(p, n_reads, stream) : launch_t<5, 8, 1, 4>(p, n_reads, stream);
+    }
     if (two) {
         switch (in.N) {
             case 3: return launch_t<3, 6, 2>(p, n_reads, stream);

@@ -132,11 +132,11 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
 
     bool use_wave = false;
     if (kernel == FCD_KERNEL_WAVE || kernel == FCD_KERNEL_WAVE1) {
-        if (!beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf))
-            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8, N <= 7, non-CRF");
+        if (!beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S))
+            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8 and N <= 7 (CRF: N = 5, S = 4)");
         use_wave = true;
     } else if (kernel == FCD_KERNEL_AUTO) {
-        use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf);
+        use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S);
     }
     // the wave kernel packs node ids and depths into 26 bits
     if (use_wave && (d.T >= (1ll << 26) || d.T * std::min<int64_t>(beam, 8) * NL + 16 >= (1ll << 26))) {
@@ -255,7 +255,14 @@ int fcd_destroy(fcd_handle *h) {
 int fcd_set_stream(fcd_handle *h, void *hip_stream) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::mutex> g(h->mu);
-    h->stream = hip_stream ? reinterpret_cast<hipStream_t>(hip_stream) : h->own_stream;
+    h->stream = reinterpret_cast<hipStream_t>(hip_stream);  // nullptr is the HIP null stream
+    return FCD_OK;
+}
+
+int fcd_reset_stream(fcd_handle *h) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    h->stream = h->own_stream;
     return FCD_OK;
 }
 
@@ -356,6 +363,13 @@ int fcd_beam_search_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
 int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                             int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                             const fcd_result *out) {
+    return fcd_crf_beam_search_dev_k(h, in, init, n_init, init_stride, beam_size, beam_cut_threshold,
+                                     FCD_KERNEL_AUTO, out);
+}
+
+int fcd_crf_beam_search_dev_k(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                              int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                              int kernel, const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::mutex> g(h->mu);
     if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
@@ -368,7 +382,7 @@ int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *ini
     a.init = init;
     a.n_init = n_init;
     a.init_stride = init_stride;
-    return beam_dev(h, in, a, FCD_KERNEL_GENERIC, out);
+    return beam_dev(h, in, a, kernel, out);
 }
 
 int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,

@@ -70,7 +70,7 @@ hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t 
                                const BeamArgs &a, const GenericArena &arena, const ResultDesc &out,
                                hipStream_t stream);
 
-bool beam_wave_supported(int beam_size, int N, int crf);
+bool beam_wave_supported(int beam_size, int N, int crf, int S);
 hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
                             const BeamArgs &a, const WaveArena &arena, const ResultDesc &out,
                             hipStream_t stream);

@@ -120,7 +120,8 @@ int fcd_version(void);                                   /* major*1000 + minor *
 int fcd_device_count(void);                              /* number of visible HIP devices, 0 if none */
 int fcd_create(int device, fcd_handle **out);            /* binds to a device, creates its own stream */
 int fcd_destroy(fcd_handle *h);
-int fcd_set_stream(fcd_handle *h, void *hip_stream);     /* NULL restores the handle's own stream */
+int fcd_set_stream(fcd_handle *h, void *hip_stream);     /* launch on this hipStream_t; NULL = the HIP null (legacy default) stream */
+int fcd_reset_stream(fcd_handle *h);                     /* back to the handle's own non-blocking stream */
 int fcd_synchronize(fcd_handle *h);
 const char *fcd_last_error(const fcd_handle *h);         /* text of the last failure on this handle */
 const char *fcd_status_string(int status);               /* exact SearchError Display text, src/lib.rs:46-53 */
@@ -154,6 +155,10 @@ int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
 int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                             int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                             const fcd_result *out);
+/* same as fcd_crf_beam_search_dev with an explicit FCD_KERNEL_* choice (tests / benchmarks) */
+int fcd_crf_beam_search_dev_k(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                              int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                              int kernel, const fcd_result *out);
 int fcd_crf_beam_search_host(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                              int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                              const fcd_result *out);

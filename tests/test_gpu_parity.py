@@ -207,6 +207,31 @@ def test_crf_beam_random(fcd, beam, thr):
         assert got[i] == want
 
 
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("beam,thr", [(1, 0.0), (5, 0.0), (5, 0.1), (8, 0.05)])
+def test_crf_beam_kernels(fcd, kernel, beam, thr):
+    """crf_beam_search on every kernel family (S = 4 states x 5 symbols is the wave kernels' shape)."""
+    torch = pytest.importorskip("torch")
+    x, init = gen_crf(70 + beam, 9, 500)
+    init[3] = [0.1, 0.7, 0.7, 0.05]      # a tie: the first maximum is the start state
+    lengths = np.array([500, 499, 1, 0, 64, 65, 500, 31, 500], np.int64)
+    r = fcd.crf_beam_search_batch_raw(torch.from_numpy(x).cuda(), init, beam, thr, lengths=lengths,
+                                      kernel=kernel).cpu()
+    for i in range(x.shape[0]):
+        n = int(r.out_len[i])
+        if lengths[i] == 0:
+            assert n == 0 and int(r.status[i]) == 0
+            continue
+        try:
+            want = oracle.crf_beam_search(np.ascontiguousarray(x[i, :lengths[i]]), init[i], "NACGT", beam, thr)
+        except RuntimeError as e:
+            assert fcd.api.nat.status_string(int(r.status[i])) == str(e)
+            continue
+        assert int(r.status[i]) == 0
+        seq = "".join("NACGT"[l] for l in r.labels[i, :n])
+        assert (seq, r.path[i, :n].tolist()) == want
+
+
 def test_crf_greedy_random(fcd):
     x, init = gen_crf(50, 3, 400)
     for i in range(3):
