@@ -426,7 +426,7 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
     if (!envelope || env_stride < in1->T) return fail(h, FCD_E_INVALID, "envelope missing or shorter than read 1");
     if (beam_size > (1 << 12)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 4096");
     const int N = (int)in1->N, NL = N - 1;
-    if (duplex_lds_bytes((int)beam_size, N) > 64 * 1024)
+    if (duplex_lds_bytes((int)beam_size, N, 0) > 64 * 1024)
         return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
     FCD_HIP(h, hipSetDevice(h->device));
 
@@ -453,7 +453,7 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
 
     const int64_t cap_nodes = (std::max<int64_t>(in1->T, 1) * beam_size * NL + 8 + 3) & ~3ll;
     if (cap_nodes >= (1ll << 30)) return fail(h, FCD_E_UNSUPPORTED, "tree arena above 2^30 nodes per pair");
-    const size_t per_pair = (size_t)cap_nodes * (sizeof(int4) + 4 + (size_t)NL * 4 + (size_t)Wcap * 12) +
+    const size_t per_pair = (size_t)cap_nodes * (sizeof(int4) + 8 + (size_t)NL * 4 + (size_t)Wcap * 12) +
                             (size_t)(in2->T + 1) * 4 + 64;
     const int64_t budget = workspace_budget(h);
     int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_pair);
@@ -471,10 +471,13 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
     char *base = reinterpret_cast<char *>(h->arena);
     a.meta = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
     a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
+    a.rlo = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * 4;
     a.rows = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * NL * 4;
     a.vec = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * (size_t)Wcap * 12;
     a.rootgap = reinterpret_cast<float *>(base);
     a.cap_nodes = cap_nodes; a.Wcap = Wcap;
+    // tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
+    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2) <= 48 * 1024 ? 1 : 0;
     a.out = to_desc(out);
     for (int64_t begin = 0; begin < B; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, B - begin);

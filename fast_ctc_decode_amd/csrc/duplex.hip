@@ -47,11 +47,13 @@ struct DuplexParams {
     // arena (per pair slabs)
     int4 *meta;      // {parent, label, offset, end}
     float *nmax;     // running max per node
+    int32_t *rlo;    // first row the running max covers (lower bound of the last update_max)
     int32_t *rows;   // NL child ids per node
     float *vec;      // Wcap * 3 floats per node
     float *rootgap;  // T2cap + 1 per pair
     int64_t cap_nodes;
     int Wcap;
+    int staged;      // 1: the step's read-2 window and the beam's forward windows are tiled in LDS
     ResultDesc out;
     int64_t pair_begin;
 };
@@ -98,15 +100,19 @@ struct DLds {
     float *c_lp, *c_gp, *c_p2;
     int *c_id, *c_new;
     int *nb_src;
+    int *s_off, *s_end;  // BC each: window bounds of the beam entries' vectors
+    float *w2;           // Wmax*N: log posteriors of read 2, rows [lo, hi)
+    float *pw;           // BC*Wmax*2: (gap, label(+)gap) of every beam entry at rows [lo-1, hi-1)
 };
 
-__host__ __device__ inline size_t dlds_words(int BC, int N) {
+__host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax) {
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
-    return 2 * (size_t)BC * (5 + NL) + 2 * C + 5 * C + BC + 4;
+    return 2 * (size_t)BC * (5 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 +
+           (size_t)Wmax * N + (size_t)BC * Wmax * 2;
 }
 
-__device__ inline DLds dcarve(int *smem, int BC, int N) {
+__device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax) {
     DLds L;
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
@@ -125,7 +131,11 @@ __device__ inline DLds dcarve(int *smem, int BC, int N) {
         L.b_par[b] = p; p += BC;
         L.b_child[b] = p; p += (size_t)BC * NL;
     }
-    L.nb_src = p;
+    L.nb_src = p; p += BC;
+    L.s_off = p; p += BC;
+    L.s_end = p; p += BC;
+    L.w2 = reinterpret_cast<float *>(p); p += (size_t)Wmax * N;
+    L.pw = reinterpret_cast<float *>(p);
     return L;
 }
 
@@ -161,7 +171,9 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
     const int N = p.N, NL = N - 1, BC = p.beam_size, Wcap = p.Wcap;
     const bool collapse = p.collapse != 0;
     const float thr = p.thr_ln;
-    DLds L = dcarve(smem, BC, N);
+    const bool staged = p.staged != 0;
+    const int Wmax = staged ? Wcap - 2 : 0;
+    DLds L = dcarve(smem, BC, N, Wmax);
 
     int64_t T1 = p.T1cap, T2 = p.T2cap;
     if (p.len1) { int64_t t = p.len1[r]; T1 = t < 0 ? 0 : (t < T1 ? t : T1); }
@@ -171,6 +183,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
     const uint64_t *env = p.env + r * p.env_stride * 2;
     int4 *meta = p.meta + local * p.cap_nodes;
     float *nmax = p.nmax + local * p.cap_nodes;
+    int32_t *rlo = p.rlo + local * p.cap_nodes;
     int32_t *rows = p.rows + local * p.cap_nodes * NL;
     float *vec = p.vec + local * p.cap_nodes * (int64_t)Wcap * 3;
     float *rootgap = p.rootgap + local * (p.T2cap + 1);
@@ -246,8 +259,84 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             }
             cur = nx;
             __syncthreads();
-            // ---- extend_secondary_probs (:338-387) for every beam node, in that order ----
-            for (int e = 0; e < B; ++e) {
+            // ---- extend_secondary_probs (:338-387) for every beam node ----
+            // Fast path (the sliding-band case): the bound grew by exactly one row and every beam
+            // node's vector already ends at the old bound, so each node appends ONE row that only
+            // reads rows its parent already holds -- all nodes proceed in parallel, one per lane.
+            // update_max (:193-204) is evaluated incrementally: the maximum over [lo, end) equals
+            // the stored maximum over [rlo, end) unless one of the rows leaving the range attains it.
+            bool fast_ok = hi == last_hi + 1 && B <= kWave;
+            {
+                const int e = lane;
+                const bool mine = e < B && L.b_node[cur][e] >= 0;
+                int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0,
+                    p_lab = -1;
+                float mx = kNegInf;
+                bool bad = false;
+                if (fast_ok && mine) {
+                    node = L.b_node[cur][e];
+                    const int4 m = load_meta_l2(&meta[node]);
+                    parent = m.x; lab = m.y; off = m.z; end = m.w;
+                    mx = load_f32_l2(&nmax[node]);
+                    rl = load_i32_l2(&rlo[node]);
+                    bad = end != last_hi;
+                    if (!bad && lo > off) {
+                        const int keep = lo - 1;
+                        const int off_old = off;
+                        if (keep > off) {
+                            if (keep < end) off = keep;
+                            else { off = keep; end = keep; }
+                        }
+                        if (end == off) { off = lo; end = lo; }
+                        bad = end != last_hi;
+                        if (!bad && lo < rl) bad = true;  // the range grows downwards: rescan (slow path)
+                        if (!bad && lo > rl) {
+                            if (lo - rl > 4) bad = true;  // a long stale range: rescan on the slow path
+                            const float *my = vec + (int64_t)node * Wcap * 3;
+                            for (int t = rl; t < lo && !bad; ++t) {
+                                if (t < off_old || t >= end) continue;
+                                const float sv = load_f32_l2(my + 3 * (t % Wcap) + 2);
+                                if (sv == sv && !(sv < mx)) bad = true;  // the leaving row holds the max
+                            }
+                            rl = lo;
+                        }
+                    }
+                    if (!bad && parent >= 0) {
+                        const int4 pm = load_meta_l2(&meta[parent]);
+                        p_lab = pm.y; p_off = pm.z; p_end = pm.w;
+                    }
+                }
+                fast_ok = fast_ok && ballot(bad) == 0ull;
+                if (fast_ok && mine) {
+                    const VecRef pv = node_vec(parent, p_off, p_end);
+                    const bool is_rep = parent >= 0 && p_lab == lab;  // :512
+                    float *my = vec + (int64_t)node * Wcap * 3;
+                    float l_lab = kNegInf, l_sum = kNegInf;
+                    if (end > off) {
+                        const int sl = (end - 1) % Wcap;
+                        l_lab = load_f32_l2(my + 3 * sl);
+                        l_sum = load_f32_l2(my + 3 * sl + 2);
+                    }
+                    const int idx = end;  // == last_hi == hi - 1
+                    const float *row = ln2 + (int64_t)idx * N;
+                    float pg, ps;
+                    vec_get(pv, idx - 1, Wcap, pg, ps);
+                    const float g = l_sum + row[0];
+                    const float xx = is_rep ? pg : ps;
+                    const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
+                    const float sm = ladd<MODE>(lb, g);
+                    const int sl = idx % Wcap;
+                    my[3 * sl] = lb;
+                    my[3 * sl + 1] = g;
+                    my[3 * sl + 2] = sm;
+                    mx = lmax(mx, sm);
+                    meta[node] = make_int4(parent, lab, off, hi);
+                    nmax[node] = mx;
+                    rlo[node] = rl;
+                }
+            }
+            __syncthreads();
+            for (int e = 0; e < B && !fast_ok; ++e) {
                 const int node = L.b_node[cur][e];
                 if (node < 0) continue;
                 const int4 m = load_meta_l2(&meta[node]);
@@ -281,6 +370,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                     }
                     for (int o = 32; o > 0; o >>= 1) part = lmax(part, __shfl_xor(part, o));
                     mx = part;
+                    if (lane == 0) rlo[node] = lo;
                 }
                 // continue the recurrence from the stored end (:361-386); wave-uniform work
                 float l_lab = kNegInf, l_gap = kNegInf, l_sum = kNegInf;
@@ -318,6 +408,35 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             }
         }
         last_hi = hi;
+
+        const int W = hi - lo;
+        if (staged) {
+            // ---- LDS tile of the DP envelope for this row of read 1 ----
+            for (int e = lane; e < B; e += kWave) {
+                const int nd = L.b_node[cur][e];
+                int off = -1, end = root_end;
+                if (nd >= 0) {
+                    const int4 m = load_meta_l2(&meta[nd]);
+                    off = m.z;
+                    end = m.w;
+                }
+                L.s_off[e] = off;
+                L.s_end[e] = end;
+            }
+            for (int xw = lane; xw < W * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * N + xw];
+            __syncthreads();
+            for (int e = 0; e < B; ++e) {
+                const int nd = L.b_node[cur][e];
+                const VecRef pv = node_vec(nd, L.s_off[e], L.s_end[e]);
+                for (int j = lane; j < W; j += kWave) {
+                    float pg, ps;
+                    vec_get(pv, lo - 1 + j, Wcap, pg, ps);
+                    L.pw[((size_t)e * Wmax + j) * 2] = pg;
+                    L.pw[((size_t)e * Wmax + j) * 2 + 1] = ps;
+                }
+            }
+            __syncthreads();
+        }
 
         int *b_node = L.b_node[cur], *b_tip = L.b_tip[cur], *b_par = L.b_par[cur];
         int *b_child = L.b_child[cur];
@@ -407,12 +526,22 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                     float l_lab = kNegInf, l_sum = kNegInf, mx = kNegInf;
                     int s = lo % Wcap;
                     for (int idx = lo; idx < hi; ++idx) {
-                        const float *row = ln2 + (int64_t)idx * N;
-                        float pg, ps;
-                        vec_get(pv, idx - 1, Wcap, pg, ps);
-                        const float g = l_sum + row[0];
+                        float pg, ps, r0, rl1;
+                        if (staged) {
+                            const int j = idx - lo;
+                            r0 = L.w2[j * N];
+                            rl1 = L.w2[j * N + l + 1];
+                            pg = L.pw[((size_t)i * Wmax + j) * 2];
+                            ps = L.pw[((size_t)i * Wmax + j) * 2 + 1];
+                        } else {
+                            const float *row = ln2 + (int64_t)idx * N;
+                            r0 = row[0];
+                            rl1 = row[l + 1];
+                            vec_get(pv, idx - 1, Wcap, pg, ps);
+                        }
+                        const float g = l_sum + r0;
                         const float x = rep ? pg : ps;
-                        const float lb = row[l + 1] + ladd<MODE>(l_lab, x);
+                        const float lb = rl1 + ladd<MODE>(l_lab, x);
                         const float sm = ladd<MODE>(lb, g);
                         my[3 * s] = lb;
                         my[3 * s + 1] = g;
@@ -424,6 +553,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                     }
                     meta[cid] = make_int4(node, l, lo, hi);
                     nmax[cid] = mx;
+                    rlo[cid] = lo;
                     for (int j = 0; j < NL; ++j) rows[(int64_t)cid * NL + j] = -1;
                     if (node >= 0) rows[(int64_t)node * NL + l] = cid;
                     b_child[i * NL + l] = cid;
@@ -542,7 +672,7 @@ __global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t e
 
 }  // namespace
 
-size_t duplex_lds_bytes(int beam_size, int N) { return dlds_words(beam_size, N) * 4 + 16; }
+size_t duplex_lds_bytes(int beam_size, int N, int Wmax) { return dlds_words(beam_size, N, Wmax) * 4 + 16; }
 
 hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
                              int64_t s_t, int64_t s_n, float *out, hipStream_t stream) {
@@ -574,8 +704,9 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     p.N = a.N; p.beam_size = a.beam_size; p.thr_ln = a.thr_ln; p.collapse = a.collapse;
     p.mode = a.mode; p.meta = a.meta; p.nmax = a.nmax; p.rows = a.rows; p.vec = a.vec;
     p.rootgap = a.rootgap; p.cap_nodes = a.cap_nodes; p.Wcap = a.Wcap; p.out = a.out;
+    p.rlo = a.rlo; p.staged = a.staged;
     p.pair_begin = pair_begin;
-    const size_t lds = duplex_lds_bytes(a.beam_size, a.N);
+    const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0);
     if (a.mode == FCD_LOGADD_MAX)
         hipLaunchKernelGGL(duplex_kernel<FCD_LOGADD_MAX>, dim3((unsigned)n_pairs), dim3(64), lds,
                            stream, p);

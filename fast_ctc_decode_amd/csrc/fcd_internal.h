@@ -93,15 +93,17 @@ struct DuplexArgs {
     int collapse, mode;
     int4 *meta;
     float *nmax;
+    int32_t *rlo;
     int32_t *rows;
     float *vec;
     float *rootgap;
     int64_t cap_nodes;
     int Wcap;
+    int staged;
     ResultDesc out;
 };
 
-size_t duplex_lds_bytes(int beam_size, int N);
+size_t duplex_lds_bytes(int beam_size, int N, int Wmax);
 hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
                              int64_t s_t, int64_t s_n, float *out, hipStream_t stream);
 hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,

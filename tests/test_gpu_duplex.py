@@ -131,3 +131,36 @@ def test_duplex_config5_shape_sample(fcd):
     got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
     want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, LSE | CR)
     assert got == want
+
+
+def test_duplex_wobbly_envelope_exact(fcd):
+    """Envelopes whose bounds do not slide monotonically (lower bound moving back, upper bound
+    jumping by several rows, plateaus) exercise both the incremental and the rescanning paths of
+    extend_secondary_probs / update_max."""
+    rng = np.random.default_rng(350)
+    T1 = T2 = 140
+    x1, x2 = pairs(350, 6, T1, T2)
+    envs = []
+    for p in range(6):
+        lo = np.zeros(T1, np.int64)
+        hi = np.zeros(T1, np.int64)
+        cur_lo, cur_hi = 0, 10 + int(rng.integers(0, 10))
+        for t in range(T1):
+            cur_hi = min(T2, cur_hi + int(rng.choice([0, 1, 1, 1, 2, 5])))
+            cur_lo = max(0, min(cur_hi - 1, cur_lo + int(rng.choice([-3, 0, 1, 1, 1, 2]))))
+            lo[t], hi[t] = cur_lo, cur_hi
+        envs.append(np.stack([lo, hi], 1).astype(np.uint64))
+    envs = np.stack(envs)
+    for mode in (LSE, MAX):
+        got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, mode)
+        want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, mode | CR)
+        assert got == want
+
+
+def test_duplex_wide_band_unstaged_path(fcd):
+    """A band too wide for the LDS tile (beam 16, +-300 rows) takes the HBM-only path."""
+    x1, x2 = pairs(360, 2, 400, 400)
+    envs = np.stack([band(400, 400, 300)] * 2)
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 16, 0.1, True, MAX)
+    want = oracle_strings(x1, x2, "NACGT", envs, 16, 0.1, True, MAX | CR)
+    assert got == want
