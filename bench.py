@@ -42,21 +42,39 @@ def make_batch(seed, n_reads):
 
 
 def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
-    """Times the oracle on a bounded sample of the same workload and checks the GPU's outputs
-    against it.  Returns the cpu_baseline object and the number of reads compared."""
+    """Times the oracle (C restatement of src/search.rs -- NOT the Rust) on this box's host cores
+    on a bounded sample of the same workload and checks the GPU's outputs against it.
+
+    os.cpu_count() over-reports what a container may actually use, so the thread count is found
+    empirically: short probes at 1, 2, 4, ... threads until throughput stops improving; the timed
+    run uses the best count and ~budget_s seconds of wall time."""
     from oracle import oracle
 
-    cores = os.cpu_count() or 1
-    # calibrate single-thread speed on a few reads, then size the sample for ~budget_s of wall
-    t0 = time.perf_counter()
-    oracle.beam_search_batch(x_host[:8], BEAM, THR, True, 1)
-    rate1 = 8.0 / max(time.perf_counter() - t0, 1e-6)
-    n = int(min(x_host.shape[0], max(32, rate1 * cores * budget_s)))
-    # enough passes over those n reads to fill ~budget_s of wall time on all cores
-    passes = int(max(1, min(64, rate1 * cores * budget_s / n)))
+    n_avail = x_host.shape[0]
+    max_threads = os.cpu_count() or 1
+
+    def run(n, threads, passes=1, out=None):
+        out = out or oracle.batch_outputs(n, T)
+        t0 = time.perf_counter()
+        res = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, threads, n_passes=passes, out=out)
+        return n * passes / (time.perf_counter() - t0), res
+
+    rate1, _ = run(32, 1)
+    best_rate, best_threads = rate1, 1
+    threads = 2
+    while threads <= max_threads:
+        n = min(n_avail, max(64, 4 * threads))
+        rate, _ = run(n, threads)
+        if rate > best_rate * 1.10:
+            best_rate, best_threads = rate, threads
+            threads *= 2
+        else:
+            break
+    n = int(min(n_avail, max(64, best_rate * budget_s)))
+    passes = int(max(1, min(256, best_rate * budget_s / n)))
     out = oracle.batch_outputs(n, T)  # pre-touched: page faults stay out of the timed call
     t0 = time.perf_counter()
-    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, cores,
+    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, best_threads,
                                                           n_passes=passes, out=out)
     dt = time.perf_counter() - t0
     mism = 0
@@ -66,14 +84,14 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
             and np.array_equal(gpu_labels[i, :L], labels[i, :L]) \
             and np.array_equal(gpu_path[i, :L].astype(np.int64), path[i, :L])
         mism += 0 if ok else 1
-    obj = {
-        "value": n * passes / dt, "unit": "reads/s", "cores": cores, "kind": "port",
+    return {
+        "value": n * passes / dt, "unit": "reads/s", "cores": best_threads, "kind": "port",
         "sample": "first %d reads of rank 0's batch x %d passes (T=%d N=%d beam=%d thr=%.1f), oracle C "
-                  "restatement of src/search.rs, %d pthreads, %.1f s" % (n, passes, T, N, BEAM, THR, cores, dt),
+                  "restatement of src/search.rs, %d pthreads (best of a 1,2,4,.. probe; os.cpu_count()=%d), "
+                  "%.1f s" % (n, passes, T, N, BEAM, THR, best_threads, max_threads, dt),
         "single_thread_reads_per_s": rate1,
         "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n,
     }
-    return obj
 
 
 def pmc_traffic(kernel_prefix):
