@@ -1,0 +1,133 @@
+"""BASELINE-size checks (4096 reads x 4000 x 5) through size-independent properties, plus oracle
+spot checks: three independently written kernels must agree on every read; permuting the batch
+permutes the answers; `lengths` equals physical truncation; viterbi equals a vectorised numpy
+restatement on every read."""
+import numpy as np
+import pytest
+
+from kat_cases import reference_style_rows
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+B, T, N = 4096, 4000, 5
+
+
+@pytest.fixture(scope="module")
+def fcd():
+    import fast_ctc_decode_amd as m
+    return m
+
+
+@pytest.fixture(scope="module")
+def batch():
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(1)
+    x = rng.random((B * T, N), dtype=np.float32)
+    x /= np.linalg.norm(x, ord=2, axis=1, keepdims=True)
+    x = x.reshape(B, T, N)
+    return x, torch.from_numpy(x).cuda()
+
+
+def digest(r):
+    """Order-sensitive checksum per read of (labels, path, len, status)."""
+    r = r.cpu()
+    w = np.arange(1, r.labels.shape[1] + 1, dtype=np.uint64)
+    mask = np.arange(r.labels.shape[1])[None, :] < r.out_len[:, None]
+    lab = (r.labels.astype(np.uint64) * mask * w).sum(1)
+    pth = (r.path.astype(np.uint64) * mask * (w * np.uint64(2654435761))).sum(1)
+    return lab ^ (pth << np.uint64(1)) ^ (r.out_len.astype(np.uint64) << np.uint64(40)) ^ \
+        (r.status.astype(np.uint64) << np.uint64(60))
+
+
+def test_three_kernels_agree_on_every_read(fcd, batch):
+    _, xd = batch
+    d = [digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k)) for k in (1, 2, 3)]
+    assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2])
+
+
+def test_oracle_spot_check(fcd, batch):
+    x, xd = batch
+    r = fcd.beam_search_batch_raw(xd, 5, 0.1, True).cpu()
+    assert int((r.status == 0).sum()) == B
+    for i in list(range(0, B, 257)) + [B - 1]:
+        st, labels, path, _ = oracle.beam_search_raw(x[i], 5, 0.1, True)
+        n = int(r.out_len[i])
+        assert st == 0 and n == len(labels)
+        np.testing.assert_array_equal(r.labels[i, :n], labels)
+        np.testing.assert_array_equal(r.path[i, :n], path)
+
+
+def test_batch_permutation_equivariance(fcd, batch):
+    torch = pytest.importorskip("torch")
+    _, xd = batch
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(5))
+    base = digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True))
+    shuf = digest(fcd.beam_search_batch_raw(xd[perm.cuda()].contiguous(), 5, 0.1, True))
+    assert np.array_equal(shuf, base[perm.numpy()])
+
+
+def test_lengths_equal_truncation_and_determinism(fcd, batch):
+    _, xd = batch
+    sub = xd[:512]
+    lengths = np.random.default_rng(6).integers(0, T + 1, 512)
+    lengths[:4] = (0, 1, T, T - 1)
+    a = fcd.beam_search_batch_raw(sub, 5, 0.1, True, lengths=lengths).cpu()
+    b = fcd.beam_search_batch_raw(sub, 5, 0.1, True, lengths=lengths).cpu()
+    assert np.array_equal(digest(a), digest(b))  # run-to-run determinism
+    for i in (0, 1, 2, 3, 100, 511):
+        L = int(lengths[i])
+        if L == 0:
+            assert int(a.out_len[i]) == 0 and int(a.status[i]) == 0
+            continue
+        t = fcd.beam_search_batch_raw(sub[i:i + 1, :L].contiguous(), 5, 0.1, True).cpu()
+        n = int(t.out_len[0])
+        assert n == int(a.out_len[i])
+        np.testing.assert_array_equal(t.labels[0, :n], a.labels[i, :n])
+        np.testing.assert_array_equal(t.path[0, :n], a.path[i, :n])
+
+
+def numpy_viterbi(x):
+    """Vectorised restatement of search.rs:341-368 for one (T,N) matrix without NaNs."""
+    lab = x.argmax(1)  # numpy argmax returns the first maximum, like the strict '>' fold
+    prev = np.concatenate([[-1], lab[:-1]])
+    emit = (lab != 0) & (lab != prev)
+    return lab[emit], np.nonzero(emit)[0]
+
+
+def test_viterbi_every_read(fcd, batch):
+    x, xd = batch
+    r = fcd.viterbi_search_batch_raw(xd).cpu()
+    for i in range(0, B, 16):
+        labels, path = numpy_viterbi(x[i])
+        n = int(r.out_len[i])
+        assert n == len(labels)
+        np.testing.assert_array_equal(r.labels[i, :n], labels)
+        np.testing.assert_array_equal(r.path[i, :n], path)
+    # every read: emission count and a checksum against the vectorised restatement
+    lab = x.argmax(2)
+    prev = np.concatenate([np.full((B, 1), -1), lab[:, :-1]], 1)
+    emit = (lab != 0) & (lab != prev)
+    np.testing.assert_array_equal(r.out_len, emit.sum(1))
+    want = (np.where(emit, lab, 0) * (np.arange(T)[None, :] + 1)).sum(1)
+    mask = np.arange(T)[None, :] < r.out_len[:, None]
+    got = (r.labels.astype(np.int64) * mask * (r.path.astype(np.int64) + 1)).sum(1)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_crf_full_size_kernels_agree(fcd):
+    torch = pytest.importorskip("torch")
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = torch.rand((1024, 4000, 4, 5), generator=g, device="cuda")
+    x = x / x.sum(-1, keepdim=True)
+    init = torch.zeros((1024, 4), device="cuda")
+    init[torch.arange(1024), torch.arange(1024) % 4] = 1.0
+    d = [digest(fcd.crf_beam_search_batch_raw(x, init, 5, 0.0, kernel=k)) for k in (1, 2, 3)]
+    assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2])
+    xc, ic = x[:3].cpu().numpy(), init[:3].cpu().numpy()
+    r = fcd.crf_beam_search_batch_raw(x[:3].contiguous(), init[:3].contiguous(), 5, 0.0).cpu()
+    for i in range(3):
+        want = oracle.crf_beam_search(xc[i], ic[i], "NACGT", 5, 0.0)
+        n = int(r.out_len[i])
+        assert ("".join("NACGT"[l] for l in r.labels[i, :n]), r.path[i, :n].tolist()) == want
