@@ -28,8 +28,11 @@
 //   * survivors are gathered into rank order with ds_bpermute and divided by the top
 //     probability (:278-282, IEEE f32 division).
 //
-// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = child entries
-// (id | EVER, or -1).  EVER marks children that have themselves been in the beam: only those can
+// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label, jump, -}; rows[node] = child
+// entries (id | EVER, or -1).  `jump` is the nearest proper ancestor whose depth is a multiple of
+// 64: the final leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling
+// into 64-node segments and then walks all segments in parallel, one lane each, instead of chasing
+// ~2000 dependent pointers with a single lane.  EVER marks children that have themselves been in the beam: only those can
 // own children, so only their row is re-read when they re-enter the beam (3.9 % of steps on
 // BASELINE's generator) -- everything else stays in registers.
 #include "device_utils.h"
@@ -65,6 +68,7 @@ __device__ __forceinline__ int perm(int dst_lane, int v) {
 
 constexpr int kWavesPerBlock = 4;
 constexpr int kFifo = 8;  // registers in the row FIFO
+constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 
 // S == 0: search::beam_search.  S > 0: search::crf_beam_search (:38-157) with S transition states:
 // the row is probs[t, state, :] of the entry's state, there is no repeat-stay, and an extension
@@ -81,6 +85,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     constexpr int RW = NL <= 4 ? 4 : 8; // child-row width in the arena
     static_assert(N <= GW - 1, "a scratch lane per group is required");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
+    __shared__ int s_heads[kWavesPerBlock][64];
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -118,7 +123,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
     const float *post = p.in.post + r * p.in.stride_read;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
-    int2 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
+    int4 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
     int32_t *rows = p.arena.rows + (has_read ? local : 0) * p.arena.cap_nodes * RW;
     const int cap = (int)p.arena.cap_nodes;
 
@@ -127,6 +132,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     float lp = 0.0f, gp = 1.0f;
     int tip = -1;
     int depth = 0;
+    int jump = -1;  // nearest proper ancestor of `node` at a depth that is a multiple of kSeg
     int child = -1;
     int B = 1;
     int nn = 0;
@@ -233,7 +239,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         nn += n_new;
         const bool f_cap = act && nn > cap;
         if (is_new && !f_cap) {
-            rec[newid] = make_int2(node, (t << 3) | l);
+            rec[newid] = make_int4(node, (t << 3) | l, (depth % kSeg == 0) ? node : jump, 0);
             if (node >= 0) rows[(int64_t)node * RW + l] = newid;
             child = newid;
         }
@@ -308,12 +314,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int tipc = is_self ? tip : l;
         const int depc = is_self ? depth : depth + 1;
         const int statec = (CRF && !is_self) ? (state * NL) % S + l : state;  // :97
+        const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
         const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
         const int n_node = bperm(src, id);
         const float n_lp = bpermf(src, clp);
         const float n_gp = bpermf(src, cgp);
         const int n_meta = bperm(src, meta);
         const int n_state = CRF ? bperm(src, statec) : 0;
+        const int n_jump = bperm(src, jumpc);
         int n_child = bperm(src + k, child);  // meaningful when the source is a self lane
         const int n_kind = n_meta & 3;
         const bool ngrp = go && i < Bn;
@@ -339,26 +347,58 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             gp = n_gp / top;
             tip = ((n_meta >> 2) & 7) - 1;
             depth = n_meta >> 5;
+            jump = n_jump;
             child = n_child;
             B = Bn;
             if (CRF) state = n_state;  // always < S for the instantiated (N, S) = (5, 4): (s*4) % 4 + l = l
         }
     }
 
-    // ---- walk the best labelling leaf -> root (:285-300) ----
+    // ---- walk the best labelling leaf -> root (:285-300), segment-parallel ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint8_t *lab = p.out.labels + r * p.out.out_stride;
+    uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
     if (q == 0 && alive) {
-        uint8_t *lab = p.out.labels + r * p.out.out_stride;
-        uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
-        int cur_node = node;
-        for (int j = depth - 1; j >= 0 && cur_node >= 0; --j) {
-            const int2 e = rec[cur_node];
-            lab[j] = (uint8_t)((e.y & 7) + 1);
-            if (pth) pth[j] = (uint32_t)(e.y >> 3);
-            cur_node = e.x;
-        }
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
+    }
+    int *heads = s_heads[wave];
+    // beam[0] lives in group 0: every lane of the half takes ITS leaf and depth
+    int h0 = bperm(hbase, node);               // current chunk's first segment head
+    int d0 = bperm(hbase, alive ? depth : 0);  // its depth; 0 == nothing left
+    while (ballot(d0 > 0) != 0ull) {
+        // phase 1: one lane hops along the jump pointers, collecting up to HALF segment heads
+        int cnt = 0, nh = h0, nd = d0;
+        if (q == 0) {
+            while (cnt < HALF && nd > 0) {
+                heads[hbase + cnt] = nh;
+                nh = rec[nh].z;
+                nd = ((nd - 1) / kSeg) * kSeg;
+                ++cnt;
+            }
+        }
+        cnt = bperm(hbase, cnt);
+        nh = bperm(hbase, nh);
+        nd = bperm(hbase, nd);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // phase 2: lane q walks segment q: depths (d_q, d_{q+1}]
+        if (q < cnt) {
+            const int d1 = ((d0 - 1) / kSeg) * kSeg;
+            const int ds = q == 0 ? d0 : d1 - (q - 1) * kSeg;
+            const int de = q == 0 ? d1 : ds - kSeg;
+            int h = heads[hbase + q];
+            for (int dd = ds; dd > de && h >= 0; --dd) {
+                const int4 e = rec[h];
+                lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
+                if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
+                h = e.x;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        h0 = nh;
+        d0 = nd;
     }
 }
 

@@ -126,6 +126,16 @@ def test_beam_strided_view(fcd):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
+def test_beam_traceback_segment_boundaries(fcd, kernel):
+    """Many final depths around multiples of 64 (the wave kernels walk the labelling in 64-node
+    segments along jump pointers; beam entries whose depths straddle a segment boundary at the
+    end of the read were a bug once)."""
+    x = gen_batch(15, 200, 340, 5)
+    lengths = (140 + np.arange(200)).astype(np.int64)
+    check_beam(fcd, x, 5, 0.1, lengths=lengths, kernel=kernel)
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
 def test_beam_full_size_reads(fcd, kernel):
     """BASELINE config 2 shape (T=4000, N=5, beam 5, thr 0.1) on a handful of reads."""
     x = gen_batch(1, 8, 4000, 5)
