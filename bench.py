@@ -149,6 +149,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0,
                     help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront)")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the secondary viterbi roofline leg")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise RCCL and run the gather even with one rank (path check on a 1-GPU box)")
     args = ap.parse_args()
 
     import torch
@@ -166,9 +168,12 @@ def main():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    distributed = world > 1
+    distributed = world > 1 or args.force_dist
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank))
+        os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=dev)
 
     B = args.batch

@@ -31,14 +31,19 @@ def packed_nbytes(n_reads, width):
     return n_reads * width + 4 * n_reads * width + 4 * n_reads + 4 * n_reads
 
 
-def pack_result(r, pad_reads):
-    """BatchResult (torch tensors, any device) -> one uint8 tensor of packed_nbytes(pad_reads, W)."""
+def pack_result(r, pad_reads, out=None):
+    """BatchResult (torch tensors, any device) -> one uint8 tensor of packed_nbytes(pad_reads, W).
+    `out` (optional) is a reusable buffer of that size."""
     import torch
 
     labels = r.labels
     B, W = labels.shape
     dev = labels.device
-    buf = torch.zeros(packed_nbytes(pad_reads, W), dtype=torch.uint8, device=dev)
+    nbytes = packed_nbytes(pad_reads, W)
+    if out is not None and out.numel() == nbytes and out.device == dev:
+        buf = out
+    else:
+        buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     o = 0
     buf[o:o + B * W] = labels.reshape(-1)
     o = pad_reads * W
@@ -94,7 +99,9 @@ def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
     r = _to_torch(r)
     pad = max(counts)
     W = r.labels.shape[1]
-    send = pack_result(r, pad)
+    send = pack_result(r, pad, out=None if scratch is None else scratch.get("send"))
+    if scratch is not None:
+        scratch["send"] = send
     recv = None
     if rank == dst:
         key = (pad, W, send.device)
