@@ -49,6 +49,8 @@ struct Lds {
     int *c_id;
     int *c_new;
     int *nb_src;   // BC
+    int *b_pslot;  // BC: beam slot of the entry's parent, or -1
+    int *m_flag;   // C: 1 when slot (i,k)'s child is itself a beam entry (its own slot absorbs the extension)
     float *row;    // N (non-CRF staging of the current posterior row)
     float *top;    // 1
 };
@@ -61,6 +63,8 @@ __host__ __device__ inline size_t lds_words(int BC, int N) {
     w += 2 * C;  // keys (u64)
     w += 4 * C;  // lp, gp, id, new
     w += BC;     // nb_src
+    w += BC;     // b_pslot
+    w += C;      // m_flag
     w += N;      // row
     w += 2;      // top + pad
     return w;
@@ -88,6 +92,8 @@ __device__ inline Lds carve(int *smem, int BC, int N) {
         L.b_child[b] = p; p += (size_t)BC * NL;
     }
     L.nb_src = p; p += BC;
+    L.b_pslot = p; p += BC;
+    L.m_flag = p; p += C;
     L.row = reinterpret_cast<float *>(p); p += N;
     L.top = reinterpret_cast<float *>(p);
     return L;
@@ -169,6 +175,25 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         int n_valid = 0;
         bool any_nan = false, bad_state = false;
 
+        // ---- phase P: where is each entry's parent in the beam?  O(B^2/64) once per step instead
+        // of a beam search per slot: entry e with parent slot j marks slot (j, tip_e + 1) as merged
+        for (int c = lane; c < nslots; c += kWave) L.m_flag[c] = 0;
+        __syncthreads();
+        for (int e = lane; e < B; e += kWave) {
+            int ps = -1;
+            if (b_node[e] >= 0) {
+                const int par = b_par[e];
+                for (int j = 0; j < B; ++j)
+                    if (b_node[j] == par) {
+                        ps = j;
+                        break;
+                    }
+                if (ps >= 0) L.m_flag[ps * N + b_tip[e] + 1] = 1;
+            }
+            L.b_pslot[e] = ps;
+        }
+        __syncthreads();
+
         // ---- phase A: evaluate every (entry, k) slot; number the new nodes ----
         for (int base = 0; base < nslots; base += kWave) {
             const int c = base + lane;
@@ -199,25 +224,19 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                     }
                     // extension arriving from this node's parent, if the parent is in the beam
                     bool inc = false;
-                    if (node >= 0) {
-                        const int par = b_par[i];
-                        for (int j = 0; j < B; ++j) {
-                            if (b_node[j] == par) {
-                                const int stj = b_state[j];
-                                if (crf && (stj < 0 || stj >= S)) {
-                                    bad_state = true;
-                                    break;
-                                }
-                                const float pl = crf ? frame[stj * st_s + (tip + 1) * st_n]
-                                                     : L.row[tip + 1];
-                                if (!(pl < thr)) {  // :201 skip only if pr_b < thr
-                                    const bool rep = !crf && collapse && b_tip[j] == tip;
-                                    const float lpj = b_lp[j], gpj = b_gp[j];
-                                    const float contrib = rep ? gpj * pl : (lpj + gpj) * pl;
-                                    clp = clp + contrib;
-                                    inc = true;
-                                }
-                                break;
+                    const int j = L.b_pslot[i];
+                    if (j >= 0) {
+                        const int stj = b_state[j];
+                        if (crf && (stj < 0 || stj >= S)) {
+                            bad_state = true;
+                        } else {
+                            const float pl = crf ? frame[stj * st_s + (tip + 1) * st_n] : L.row[tip + 1];
+                            if (!(pl < thr)) {  // :201 skip only if pr_b < thr
+                                const bool rep = !crf && collapse && b_tip[j] == tip;
+                                const float lpj = b_lp[j], gpj = b_gp[j];
+                                const float contrib = rep ? gpj * pl : (lpj + gpj) * pl;
+                                clp = clp + contrib;
+                                inc = true;
                             }
                         }
                     }
@@ -233,14 +252,8 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                     const int ch = b_child[i * NL + l];
                     const bool exists = ch >= 0;
                     valid = pass && (exists || !rep || gp > 0.0f);  // :212-218
-                    if (valid && exists) {
-                        // child already in the beam: its own slot absorbs this extension
-                        for (int j = 0; j < B; ++j)
-                            if (b_node[j] == ch) {
-                                valid = false;
-                                break;
-                            }
-                    }
+                    // child already in the beam: its own slot absorbs this extension
+                    if (valid && exists && L.m_flag[c]) valid = false;
                     is_new = valid && !exists;
                     clp = contrib;
                     cid = ch;
@@ -282,13 +295,26 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         // ---- phase B: exact rank of every slot; the top beam_size build the next beam ----
         const int nxt = cur ^ 1;
         const int Bn = n_valid < BC ? n_valid : BC;
-        for (int base = 0; base < nslots; base += kWave) {
-            const int c = base + lane;
-            if (c >= nslots) continue;
-            const uint64_t key = L.c_key[c];
-            if (key == 0ull) continue;
-            int rank = 0;
-            for (int j = 0; j < nslots; ++j) rank += (L.c_key[j] > key) ? 1 : 0;
+        // every lane owns slots lane, lane+64, ...: rank up to four of them in one sweep over the keys
+        for (int base0 = 0; base0 < nslots; base0 += 4 * kWave) {
+            uint64_t myk[4];
+            int myr[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = base0 + u * kWave + lane;
+                myk[u] = c < nslots ? L.c_key[c] : 0ull;
+            }
+            for (int j = 0; j < nslots; ++j) {
+                const uint64_t kj = L.c_key[j];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) myr[u] += (kj > myk[u]) ? 1 : 0;
+            }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int c = base0 + u * kWave + lane;
+            const uint64_t key = myk[u];
+            const int rank = myr[u];
+            if (c >= nslots || key == 0ull) continue;
             if (rank < BC) {
                 const int i = c / N, k = c - i * N;
                 L.b_node[nxt][rank] = L.c_id[c];
@@ -308,6 +334,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                 L.nb_src[rank] = c | (L.c_new[c] << 30);
                 if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
             }
+          }
         }
         __syncthreads();
 
