@@ -101,6 +101,7 @@ struct DLds {
     int *c_id, *c_new;
     int *nb_src;
     int *s_off, *s_end;  // BC each: window bounds of the beam entries' vectors
+    int *bt;             // 64: lane that owns the m-th new node of the current pass
     float *w2;           // Wmax*N: log posteriors of read 2, rows [lo, hi)
     float *pw;           // BC*Wmax*2: (gap, label(+)gap) of every beam entry at rows [lo-1, hi-1)
 };
@@ -108,7 +109,7 @@ struct DLds {
 __host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax) {
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
-    return 2 * (size_t)BC * (5 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 +
+    return 2 * (size_t)BC * (5 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 + 64 +
            (size_t)Wmax * N + (size_t)BC * Wmax * 2;
 }
 
@@ -134,6 +135,7 @@ __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax) {
     L.nb_src = p; p += BC;
     L.s_off = p; p += BC;
     L.s_end = p; p += BC;
+    L.bt = p; p += 64;
     L.w2 = reinterpret_cast<float *>(p); p += (size_t)Wmax * N;
     L.pw = reinterpret_cast<float *>(p);
     return L;
@@ -509,7 +511,9 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                     cid = ch;
                 }
             }
-            const uint64_t m_new = __ballot(is_new);
+            const uint64_t m_new = ballot(is_new);
+            if (MODE == FCD_LOGADD_MAX) {
+            // max-product mode has no transcendental in the recurrence: one lane per new node
             if (is_new) {
                 cid = nn + popc64(m_new & lanemask_lt());
                 if (cid < p.cap_nodes) {
@@ -561,6 +565,109 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 }
             } else if (act && cid >= 0) {
                 p2 = load_f32_l2(&nmax[cid]);  // :613-618 prob_2_max = data.max_prob (may be stale)
+            }
+            } else {
+            // ---- new nodes: ids in creation order, then build_secondary_probs (:212-249) ----
+            // The recurrence of one node is two interleaved serial chains:
+            //   label_t = p_t[label] (x) (label_{t-1} (+) X_{t-1})            (needs only the label chain)
+            //   sum_t   = label_t (+) (sum_{t-1} (x) p_t[blank])   [gap_t = sum_{t-1} (x) p_t[blank]]
+            // so every new node gets a PAIR of lanes: the even lane runs the label chain, the odd
+            // lane runs the sum chain one row behind it -- same operations in the same order as the
+            // reference (exact), but one log-add per iteration instead of two.
+            const int pre = popc64(m_new & lanemask_lt());
+            const int n_new = popc64(m_new);
+            if (is_new) {
+                cid = nn + pre;
+                L.bt[pre] = lane;
+            }
+            const bool can = is_new && cid < p.cap_nodes;
+            int par_off = 0, par_end = 0;
+            if (can && node >= 0 && !staged) {
+                const int4 pm = load_meta_l2(&meta[node]);
+                par_off = pm.z;
+                par_end = pm.w;
+            }
+            __syncthreads();
+            for (int rd = 0; rd * 32 < n_new; ++rd) {
+                const int m = rd * 32 + (lane >> 1);
+                const bool have = m < n_new;
+                const int owner = have ? L.bt[m] : lane;
+                const bool isA = (lane & 1) == 0;
+                // the owner's parameters
+                const int q_cid = __shfl(cid, owner);
+                const int q_i = __shfl(i, owner);
+                const int q_l = __shfl(k - 1, owner);
+                const int q_flags = __shfl((can ? 1 : 0) | (rep ? 2 : 0), owner);
+                const int q_node = __shfl(node, owner);
+                const int q_poff = __shfl(par_off, owner);
+                const int q_pend = __shfl(par_end, owner);
+                const bool work = have && (q_flags & 1);
+                const bool q_rep = (q_flags & 2) != 0;
+                const VecRef pv = node_vec(q_node, q_poff, q_pend);
+                float *my = vec + (int64_t)(work ? q_cid : 0) * Wcap * 3;
+                float lb = kNegInf;   // A: label_{t-1};  B: label_{t'} received from A
+                float sm = kNegInf;   // B: sum_{t'-1}
+                float mx = kNegInf;
+                for (int sidx = 0; sidx <= W; ++sidx) {
+                    // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
+                    const int j = isA ? sidx : sidx - 1;
+                    const bool on = work && j >= 0 && j < W;
+                    float a = kNegInf, bb = kNegInf, add_after = 0.0f, r0 = 0.0f;
+                    if (on) {
+                        if (isA) {
+                            float pg, ps, rl1;
+                            if (staged) {
+                                rl1 = L.w2[j * N + q_l + 1];
+                                pg = L.pw[((size_t)q_i * Wmax + j) * 2];
+                                ps = L.pw[((size_t)q_i * Wmax + j) * 2 + 1];
+                            } else {
+                                rl1 = ln2[(int64_t)(lo + j) * N + q_l + 1];
+                                vec_get(pv, lo + j - 1, Wcap, pg, ps);
+                            }
+                            a = lb;
+                            bb = q_rep ? pg : ps;
+                            add_after = rl1;
+                        } else {
+                            r0 = staged ? L.w2[j * N] : ln2[(int64_t)(lo + j) * N];
+                            a = lb;          // label_{t'} from the even lane
+                            bb = sm + r0;    // gap_{t'}
+                        }
+                    }
+                    const float v = ladd<MODE>(a, bb);
+                    float lb_out = lb;
+                    if (on) {
+                        const int slot = (lo + j) % Wcap;
+                        if (isA) {
+                            lb_out = add_after + v;  // label_t
+                            my[3 * slot] = lb_out;
+                        } else {
+                            my[3 * slot + 1] = bb;   // gap_{t'}
+                            my[3 * slot + 2] = v;    // sum_{t'}
+                            sm = v;
+                            mx = lmax(mx, v);
+                        }
+                    }
+                    // hand label_t to the odd lane for the next iteration; the even lane keeps it
+                    const float from_even = __shfl(lb_out, lane & ~1);
+                    lb = isA ? lb_out : from_even;
+                }
+                if (work && !isA) {
+                    meta[q_cid] = make_int4(q_node, q_l, lo, hi);
+                    nmax[q_cid] = mx;
+                    rlo[q_cid] = lo;
+                    for (int jj = 0; jj < NL; ++jj) rows[(int64_t)q_cid * NL + jj] = -1;
+                    if (q_node >= 0) rows[(int64_t)q_node * NL + q_l] = q_cid;
+                }
+                // the owner slot needs the new node's running maximum as its prob_2_max
+                const int pair_b = 2 * (pre & 31) + 1;
+                const float got = __shfl(mx, pair_b);
+                if (can && (pre >> 5) == rd) p2 = got;
+            }
+            if (can) b_child[i * NL + (k - 1)] = cid;
+            if (!is_new && act && cid >= 0) {
+                p2 = load_f32_l2(&nmax[cid]);  // :613-618 prob_2_max = data.max_prob (may be stale)
+            }
+            __syncthreads();
             }
             nn += popc64(m_new);
             const float prob = ladd<MODE>(clp, cgp) + p2;  // :146-148
