@@ -557,6 +557,16 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
     return FCD_OK;
 }
 
+int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
+                           float *out_ln, int64_t n, int logadd_mode) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n < 0 || (n > 0 && (!a || !b || !out_add || !out_ln))) return fail(h, FCD_E_INVALID, "null array");
+    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_HIP(h, launch_logspace_probe(a, b, out_add, out_ln, n, logadd_mode, h->stream));
+    return FCD_OK;
+}
+
 // ---- *_host: stage host buffers through device memory, run the *_dev path, copy back -------
 namespace {
 

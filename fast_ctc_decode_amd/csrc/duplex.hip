@@ -754,6 +754,17 @@ __global__ void ln_convert_kernel(const float *x, int64_t n_reads, int64_t T, in
     }
 }
 
+// test hook: out[i] = LogSpace::add(a[i], b[i]) and ln(a[i]) exactly as the duplex kernels compute them
+__global__ void logspace_probe_kernel(const float *a, const float *b, float *out_add, float *out_ln,
+                                      int64_t n, int mode) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        out_add[i] = mode == FCD_LOGADD_MAX ? ladd<FCD_LOGADD_MAX>(a[i], b[i])
+                                            : ladd<FCD_LOGADD_LOGSUMEXP>(a[i], b[i]);
+        out_ln[i] = ln_cr(a[i]);
+    }
+}
+
 // widest clamped envelope row over the whole batch -> *out (int), for sizing the rings
 __global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t env_stride,
                                  int64_t T1cap, int64_t T2cap, const int64_t *len1,
@@ -799,6 +810,15 @@ hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_st
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(env_width_kernel, dim3(blocks), dim3(256), 0, stream, env, n_pairs,
                        env_stride, T1cap, T2cap, len1, len2, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
+                                 int64_t n, int mode, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(logspace_probe_kernel, dim3(blocks), dim3(256), 0, stream, a, b, out_add, out_ln,
+                       n, mode);
     return hipGetLastError();
 }
 

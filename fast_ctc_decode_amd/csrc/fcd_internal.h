@@ -111,6 +111,8 @@ hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_st
                             hipStream_t stream);
 hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs,
                          hipStream_t stream);
+hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
+                                 int64_t n, int mode, hipStream_t stream);
 
 }  // namespace fcd
 

@@ -182,6 +182,12 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
                                 float beam_cut_threshold, int collapse_repeats, int logadd_mode,
                                 const fcd_result *out);
 
+/* Test hook (device pointers, n elements): out_add[i] = LogSpace::add(a[i], b[i]) (src/duplex.rs:42-63)
+ * and out_ln[i] = LogSpace::new(a[i]) = ln(a[i]) (:24-26), computed by the very device functions the
+ * duplex kernel uses, so the log-space arithmetic can be checked bit for bit against the oracle. */
+int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
+                           float *out_ln, int64_t n, int logadd_mode);
+
 /* ---- host-side helpers shared with the language bindings ---- */
 /* phred quality character code point for a probability (src/search.rs:31-36) */
 uint32_t fcd_phred(float prob, float qscale, float qbias);

@@ -164,3 +164,48 @@ def test_duplex_wide_band_unstaged_path(fcd):
     got = gpu_strings(fcd, x1, x2, "NACGT", envs, 16, 0.1, True, MAX)
     want = oracle_strings(x1, x2, "NACGT", envs, 16, 0.1, True, MAX | CR)
     assert got == want
+
+
+def test_logspace_arithmetic_bits(fcd):
+    """LogSpace::new / LogSpace::add of the duplex kernels vs the oracle's correctly rounded
+    versions, bit for bit, on a million operand pairs incl. the edge cases (-inf, equal, NaN,
+    far apart, denormal probabilities)."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
+    from fast_ctc_decode_amd import _native as nat
+    rng = np.random.default_rng(370)
+    n = 1 << 20
+    pa = rng.random(n, dtype=np.float32) ** 8           # probabilities, many tiny
+    pb = rng.random(n, dtype=np.float32) ** 3
+    pa[:8] = [0.0, 1.0, 1e-45, 1e-38, 0.5, 0.25, 3.0, np.nan]
+    a = np.log(pa.astype(np.float64)).astype(np.float32)
+    b = np.log(pb.astype(np.float64)).astype(np.float32)
+    b[8:4096] = a[8:4096] - rng.random(4088, dtype=np.float32) * 120.0   # wide range of small-big
+    b[4096:4200] = a[4096:4200]                                           # equal operands
+    a[4200:4210] = -np.inf
+    b[4205:4215] = -np.inf
+    ad, bd = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    pad = torch.from_numpy(pa).cuda()
+    out_add, out_ln = torch.empty_like(ad), torch.empty_like(ad)
+    h = nat.default_handle()
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    for mode, omode in ((0, LSE | CR), (1, MAX | CR)):
+        h.check(h.lib.fcd_logspace_probe_dev(h.ptr, ad.data_ptr(), bd.data_ptr(), out_add.data_ptr(),
+                                             out_ln.data_ptr(), n, mode))
+        torch.cuda.synchronize()
+        got = out_add.cpu().numpy()
+        add = oracle.lib.fcdo_logspace_add
+        idx = np.concatenate([np.arange(0, 8192), rng.integers(0, n, 40000)])
+        want = np.array([add(float(a[i]), float(b[i]), omode) for i in idx], np.float32)
+        g = got[idx]
+        same = (g.view(np.uint32) == want.view(np.uint32)) | (np.isnan(g) & np.isnan(want))
+        assert same.all(), (mode, int((~same).sum()), idx[~same][:5], g[~same][:5], want[~same][:5])
+    # ln of the posteriors: probe ln(pa) against the correctly rounded reference
+    h.check(h.lib.fcd_logspace_probe_dev(h.ptr, pad.data_ptr(), bd.data_ptr(), out_add.data_ptr(),
+                                         out_ln.data_ptr(), n, 0))
+    torch.cuda.synchronize()
+    got_ln = out_ln.cpu().numpy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        want_ln = np.log(pa.astype(np.longdouble)).astype(np.float32)
+    same = (got_ln.view(np.uint32) == want_ln.view(np.uint32)) | (np.isnan(got_ln) & np.isnan(want_ln))
+    assert same.all(), (int((~same).sum()), got_ln[~same][:5], want_ln[~same][:5])
