@@ -267,3 +267,57 @@ def test_torch_device_path(fcd):
     v = fcd.viterbi_search_batch_raw(xd).cpu()
     vh = fcd.viterbi_search_batch_raw(x)
     np.testing.assert_array_equal(v.out_len, vh.out_len)
+
+
+def test_concurrent_python_threads(fcd):
+    """The reference releases the GIL and is re-entrant (src/lib.rs:199,353): many Python threads
+    may decode at once.  Each thread gets its own fcd_handle (stream + workspace)."""
+    import threading
+    import fast_ctc_decode as compiled
+    x = gen_batch(80, 24, 600, 5)
+    want = [oracle.beam_search(x[i], "NACGT", 5, 0.1) for i in range(24)]
+    got = [None] * 24
+    errors = []
+
+    def work(tid):
+        try:
+            for i in range(tid, 24, 6):
+                m = compiled if (i % 2) else fcd  # both host layers, interleaved
+                got[i] = m.beam_search(x[i], "NACGT", 5, 0.1)
+                assert m.viterbi_search(x[i], "NACGT") == oracle.viterbi_search(x[i], "NACGT")
+        except Exception as e:  # pragma: no cover
+            errors.append(e)
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(6)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    assert not errors, errors
+    assert got == want
+
+
+def test_c_abi_misuse_is_reported(fcd):
+    """API misuse returns negative FCD_E_* codes with a message, never crashes."""
+    import ctypes as C
+    from fast_ctc_decode_amd import _native as nat
+    h = nat.default_handle()
+    x = gen_batch(81, 2, 50, 5)
+    out = fcd.api._HostOut(2, 50)
+    b = fcd.api._host_batch(x, False)
+    lib = h.lib
+    assert lib.fcd_beam_search_host(h.ptr, C.byref(b), 0, 0.1, 1, 0, C.byref(out.res)) == nat.E_INVALID
+    assert b"beam_size" in lib.fcd_last_error(h.ptr)
+    assert lib.fcd_beam_search_host(h.ptr, None, 5, 0.1, 1, 0, C.byref(out.res)) == nat.E_INVALID
+    small = fcd.api._HostOut(2, 10)  # out_stride < T
+    assert lib.fcd_beam_search_host(h.ptr, C.byref(b), 5, 0.1, 1, 0, C.byref(small.res)) == nat.E_INVALID
+    # a shape the register kernel does not implement must be refused when it is forced
+    x12 = gen_batch(82, 2, 50, 12)
+    b12 = fcd.api._host_batch(x12, False)
+    assert lib.fcd_beam_search_host(h.ptr, C.byref(b12), 5, 0.0, 1, nat.KERNEL_WAVE, C.byref(out.res)) == nat.E_UNSUPPORTED
+    assert lib.fcd_beam_search_host(h.ptr, C.byref(b12), 5, 0.0, 1, nat.KERNEL_AUTO, C.byref(out.res)) == nat.OK
+    # huge beam sizes fall outside the LDS budget: refused, not mis-computed
+    assert lib.fcd_beam_search_host(h.ptr, C.byref(b), 100000, 0.0, 1, 0, C.byref(out.res)) == nat.E_UNSUPPORTED
+    # and the handle is still usable afterwards
+    assert lib.fcd_beam_search_host(h.ptr, C.byref(b), 5, 0.1, 1, 0, C.byref(out.res)) == nat.OK
+    st, labels, path, _ = oracle.beam_search_raw(x[0], 5, 0.1)
+    n = int(out.out_len[0])
+    np.testing.assert_array_equal(out.labels[0, :n], labels)
