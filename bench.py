@@ -149,6 +149,10 @@ def main():
     ap.add_argument("--kernel", type=int, default=0,
                     help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront)")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the secondary viterbi roofline leg")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="issue successive steps round-robin on this many HIP streams (each with its own "
+                         "handle and tree arena) so that independent batches overlap on the GPU; 1 = strictly "
+                         "one batch after the other (the default, and what `value` is quoted on)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather even with one rank (path check on a 1-GPU box)")
     args = ap.parse_args()
@@ -182,14 +186,22 @@ def main():
     torch.cuda.synchronize()
 
     from fast_ctc_decode_amd import dist as fdist
+    from fast_ctc_decode_amd import _native as nat
     counts = [B] * world
     scratch = {}
+    n_streams = max(1, args.streams)
+    handles = [nat.default_handle(local_rank)] + [nat.Handle(local_rank) for _ in range(n_streams - 1)]
+    streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    step_no = [0]
 
     def step():
-        r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel)
-        if distributed:
-            # ONE gather of the packed fixed-stride results to rank 0 (RCCL over xGMI)
-            fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
+        s = step_no[0] % n_streams
+        step_no[0] += 1
+        with torch.cuda.stream(streams[s]):
+            r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel, handle=handles[s])
+            if distributed:
+                # ONE gather of the packed fixed-stride results to rank 0 (RCCL over xGMI)
+                fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
         return r
 
     for _ in range(args.warmup):
@@ -198,9 +210,11 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
-    handle = r._handle if args.warmup > 0 else step()._handle
+    if args.warmup == 0:
+        step()
     torch.cuda.synchronize()
-    handle.timing_reset()
+    for hh in handles:
+        hh.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = step()
@@ -212,7 +226,9 @@ def main():
 
     # kernel duration: the C ABI brackets every launch of the timed region with a HIP event pair
     # on the launch stream (torch's current stream); read them back after the final sync.
-    k_ms, k_calls = handle.timing_mean_ms()
+    tm = [hh.timing_mean_ms() for hh in handles]
+    k_calls = sum(n for _, n in tm)
+    k_ms = sum(ms * n for ms, n in tm) / max(k_calls, 1)
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if distributed:
@@ -254,7 +270,7 @@ def main():
                                if world > 1 else "single GPU",
                 "kernel": {0: "auto (wave, two reads per wavefront)", 1: "generic-lds",
                            2: "wave-registers-2reads", 3: "wave-registers-1read"}[args.kernel],
-                "reads_ok": ok, "mean_labels_per_read": mean_L,
+                "reads_ok": ok, "mean_labels_per_read": mean_L, "streams": n_streams,
             },
             "roofline": {
                 "bound": "hbm",

@@ -397,13 +397,13 @@ class BatchResult:
 
 
 def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path=True,
-                need_status=True):
+                need_status=True, handle=None):
     import torch
 
     if x.dtype != torch.float32:
         raise TypeError("device posteriors must be float32")
     dev = x.device.index or 0
-    h = nat.default_handle(dev)
+    h = handle if handle is not None else nat.default_handle(dev)
     if crf:
         B, T, S, N = x.shape
         st = x.stride()
@@ -444,12 +444,14 @@ def _stack_host(x, ndim):
 
 
 def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
-                          collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO):
-    """Decode a (B,T,N) batch with search::beam_search semantics; returns a BatchResult."""
+                          collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, handle=None):
+    """Decode a (B,T,N) batch with search::beam_search semantics; returns a BatchResult.
+    `handle` (device tensors only): an explicit fast_ctc_decode_amd._native.Handle -- one per
+    concurrent torch stream, since a handle owns the tree-arena workspace its kernels use."""
     if _is_torch_cuda(network_outputs):
         return _torch_call("fcd_beam_search_dev", network_outputs, False, lengths,
                            (int(beam_size), float(beam_cut_threshold),
-                            int(bool(collapse_repeats)), int(kernel)))
+                            int(bool(collapse_repeats)), int(kernel)), handle=handle)
     x = _stack_host(network_outputs, 3)
     B, T, N = x.shape
     h = nat.default_handle()
