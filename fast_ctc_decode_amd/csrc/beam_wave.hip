@@ -175,8 +175,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     float win[kFifo];
 #pragma unroll
     for (int j = 0; j < kFifo; ++j) win[j] = load_block(j);
+    // the block in flight joins the FIFO one rotation after its load was launched
+    float incoming = load_block(kFifo);
     int g = 0;    // row within the front block (wave-uniform)
     int blk = 0;  // index of the front block (wave-uniform)
+    // Drain the prologue loads HERE, with a wait the compiler's scoreboard sees: otherwise the loop
+    // header inherits "win[0] may still be in flight" and gets an s_waitcnt vmcnt(0) on EVERY step,
+    // which on gfx9-family counters also waits for the previous step's tree stores to be acked.
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
 
     for (int t = 0; t < Tmax; ++t) {
         const bool act = alive && t < T;
@@ -189,8 +195,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             g = 0;
 #pragma unroll
             for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
-            win[kFifo - 1] = load_block(blk + kFifo);
+            // wait for the block launched one rotation ago BEFORE launching the next one (vmcnt
+            // counts in order: a wait placed after the new load would wait for it as well)
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            win[kFifo - 1] = incoming;
             ++blk;
+            incoming = load_block(blk + kFifo);
         }
         const bool grp = act && i < B;
 
