@@ -34,15 +34,21 @@ struct GenericParams {
 };
 
 // LDS carve-up (all 4-byte words unless noted).  BC = beam_size, NL = N-1, C = BC*N.
+// NB: no runtime-indexed pointer arrays in here -- `ptr[cur]` with a runtime `cur` would push the
+// whole struct into scratch memory (every access a vector-memory round trip).  The two beam buffers
+// are addressed arithmetically instead: buffer b starts at beam0 + b * beam_stride.
 struct Lds {
-    int *b_node[2];
-    float *b_lp[2];
-    float *b_gp[2];
-    int *b_tip[2];
-    int *b_par[2];
-    int *b_state[2];
-    int *b_depth[2];
-    int *b_child[2];  // BC*NL
+    int *beam0;       // [2][beam_stride] words: node, lp, gp, tip, par, state, depth (BC each), child (BC*NL)
+    int beam_stride;
+    int BC;
+    __device__ __forceinline__ int *b_node(int b) const { return beam0 + b * beam_stride; }
+    __device__ __forceinline__ float *b_lp(int b) const { return reinterpret_cast<float *>(b_node(b) + BC); }
+    __device__ __forceinline__ float *b_gp(int b) const { return reinterpret_cast<float *>(b_node(b) + 2 * BC); }
+    __device__ __forceinline__ int *b_tip(int b) const { return b_node(b) + 3 * BC; }
+    __device__ __forceinline__ int *b_par(int b) const { return b_node(b) + 4 * BC; }
+    __device__ __forceinline__ int *b_state(int b) const { return b_node(b) + 5 * BC; }
+    __device__ __forceinline__ int *b_depth(int b) const { return b_node(b) + 6 * BC; }
+    __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 7 * BC; }  // BC*NL
     uint64_t *c_key;  // C, 8-byte aligned
     float *c_lp;
     float *c_gp;
@@ -81,16 +87,10 @@ __device__ inline Lds carve(int *smem, int BC, int N) {
     L.c_gp = reinterpret_cast<float *>(p); p += C;
     L.c_id = p; p += C;
     L.c_new = p; p += C;
-    for (int b = 0; b < 2; ++b) {
-        L.b_node[b] = p; p += BC;
-        L.b_lp[b] = reinterpret_cast<float *>(p); p += BC;
-        L.b_gp[b] = reinterpret_cast<float *>(p); p += BC;
-        L.b_tip[b] = p; p += BC;
-        L.b_par[b] = p; p += BC;
-        L.b_state[b] = p; p += BC;
-        L.b_depth[b] = p; p += BC;
-        L.b_child[b] = p; p += (size_t)BC * NL;
-    }
+    L.BC = BC;
+    L.beam_stride = BC * (7 + NL);
+    L.beam0 = p;
+    p += 2 * (size_t)L.beam_stride;
     L.nb_src = p; p += BC;
     L.b_pslot = p; p += BC;
     L.m_flag = p; p += C;
@@ -150,15 +150,15 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             lp0 = m;
             gp0 = init[0];
         }
-        L.b_node[0][0] = -1;
-        L.b_lp[0][0] = lp0;
-        L.b_gp[0][0] = gp0;
-        L.b_tip[0][0] = -1;
-        L.b_par[0][0] = -2;
-        L.b_state[0][0] = bad ? -1 : st0;
-        L.b_depth[0][0] = 0;
+        L.b_node(0)[0] = -1;
+        L.b_lp(0)[0] = lp0;
+        L.b_gp(0)[0] = gp0;
+        L.b_tip(0)[0] = -1;
+        L.b_par(0)[0] = -2;
+        L.b_state(0)[0] = bad ? -1 : st0;
+        L.b_depth(0)[0] = 0;
     }
-    for (int j = lane; j < NL; j += kWave) L.b_child[0][j] = -1;
+    for (int j = lane; j < NL; j += kWave) L.b_child(0)[j] = -1;
     if (!crf && T > 0)
         for (int j = lane; j < N; j += kWave) L.row[j] = post[j * st_n];
     __syncthreads();
@@ -166,9 +166,9 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
     int nn = 0;  // nodes in this read's tree (wave-uniform)
 
     for (int64_t t = 0; t < T; ++t) {
-        int *b_node = L.b_node[cur], *b_tip = L.b_tip[cur], *b_par = L.b_par[cur];
-        int *b_state = L.b_state[cur], *b_depth = L.b_depth[cur], *b_child = L.b_child[cur];
-        float *b_lp = L.b_lp[cur], *b_gp = L.b_gp[cur];
+        int *b_node = L.b_node(cur), *b_tip = L.b_tip(cur), *b_par = L.b_par(cur);
+        int *b_state = L.b_state(cur), *b_depth = L.b_depth(cur), *b_child = L.b_child(cur);
+        float *b_lp = L.b_lp(cur), *b_gp = L.b_gp(cur);
         const int nslots = B * N;
         const float *frame = post + t * st_t;
 
@@ -317,19 +317,19 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             if (c >= nslots || key == 0ull) continue;
             if (rank < BC) {
                 const int i = c / N, k = c - i * N;
-                L.b_node[nxt][rank] = L.c_id[c];
-                L.b_lp[nxt][rank] = L.c_lp[c];
-                L.b_gp[nxt][rank] = L.c_gp[c];
+                L.b_node(nxt)[rank] = L.c_id[c];
+                L.b_lp(nxt)[rank] = L.c_lp[c];
+                L.b_gp(nxt)[rank] = L.c_gp[c];
                 if (k == 0) {
-                    L.b_tip[nxt][rank] = b_tip[i];
-                    L.b_par[nxt][rank] = b_par[i];
-                    L.b_state[nxt][rank] = b_state[i];
-                    L.b_depth[nxt][rank] = b_depth[i];
+                    L.b_tip(nxt)[rank] = b_tip[i];
+                    L.b_par(nxt)[rank] = b_par[i];
+                    L.b_state(nxt)[rank] = b_state[i];
+                    L.b_depth(nxt)[rank] = b_depth[i];
                 } else {
-                    L.b_tip[nxt][rank] = k - 1;
-                    L.b_par[nxt][rank] = b_node[i];
-                    L.b_state[nxt][rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
-                    L.b_depth[nxt][rank] = b_depth[i] + 1;
+                    L.b_tip(nxt)[rank] = k - 1;
+                    L.b_par(nxt)[rank] = b_node[i];
+                    L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
+                    L.b_depth(nxt)[rank] = b_depth[i] + 1;
                 }
                 L.nb_src[rank] = c | (L.c_new[c] << 30);
                 if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
@@ -350,13 +350,13 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             else if (src >> 30)
                 v = -1;
             else
-                v = load_i32_l2(&rows[(int64_t)L.b_node[nxt][s] * NL + l]);
-            L.b_child[nxt][s * NL + l] = v;
+                v = load_i32_l2(&rows[(int64_t)L.b_node(nxt)[s] * NL + l]);
+            L.b_child(nxt)[s * NL + l] = v;
         }
         const float top = *L.top;
         for (int s = lane; s < Bn; s += kWave) {
-            L.b_lp[nxt][s] = L.b_lp[nxt][s] / top;
-            L.b_gp[nxt][s] = L.b_gp[nxt][s] / top;
+            L.b_lp(nxt)[s] = L.b_lp(nxt)[s] / top;
+            L.b_gp(nxt)[s] = L.b_gp(nxt)[s] / top;
         }
         if (!crf && t + 1 < T)
             for (int j = lane; j < N; j += kWave) L.row[j] = post[(t + 1) * st_t + j * st_n];
@@ -368,8 +368,8 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
     // ---- walk the best labelling leaf -> root (:285-300), writing it in sequence order ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // drop L1 lines older than our own stores
     if (lane == 0) {
-        int node = L.b_node[cur][0];
-        const int n = L.b_depth[cur][0];
+        int node = L.b_node(cur)[0];
+        const int n = L.b_depth(cur)[0];
         uint8_t *lab = p.out.labels + r * p.out.out_stride;
         uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
         for (int j = n - 1; j >= 0 && node >= 0; --j) {

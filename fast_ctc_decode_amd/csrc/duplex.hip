@@ -89,13 +89,17 @@ __device__ __forceinline__ int4 load_meta_l2(const int4 *p) {
     return make_int4(load_i32_l2(q), load_i32_l2(q + 1), load_i32_l2(q + 2), load_i32_l2(q + 3));
 }
 
+// (no runtime-indexed pointer arrays: they would force the struct into scratch memory)
 struct DLds {
-    int *b_node[2];
-    float *b_lp[2];
-    float *b_gp[2];
-    int *b_tip[2];
-    int *b_par[2];
-    int *b_child[2];
+    int *beam0;  // [2][beam_stride] words: node, lp, gp, tip, par (BC each), child (BC*NL)
+    int beam_stride;
+    int BC;
+    __device__ __forceinline__ int *b_node(int b) const { return beam0 + b * beam_stride; }
+    __device__ __forceinline__ float *b_lp(int b) const { return reinterpret_cast<float *>(b_node(b) + BC); }
+    __device__ __forceinline__ float *b_gp(int b) const { return reinterpret_cast<float *>(b_node(b) + 2 * BC); }
+    __device__ __forceinline__ int *b_tip(int b) const { return b_node(b) + 3 * BC; }
+    __device__ __forceinline__ int *b_par(int b) const { return b_node(b) + 4 * BC; }
+    __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 5 * BC; }
     uint64_t *c_key;
     float *c_lp, *c_gp, *c_p2;
     int *c_id, *c_new;
@@ -124,14 +128,10 @@ __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax) {
     L.c_p2 = reinterpret_cast<float *>(p); p += C;
     L.c_id = p; p += C;
     L.c_new = p; p += C;
-    for (int b = 0; b < 2; ++b) {
-        L.b_node[b] = p; p += BC;
-        L.b_lp[b] = reinterpret_cast<float *>(p); p += BC;
-        L.b_gp[b] = reinterpret_cast<float *>(p); p += BC;
-        L.b_tip[b] = p; p += BC;
-        L.b_par[b] = p; p += BC;
-        L.b_child[b] = p; p += (size_t)BC * NL;
-    }
+    L.BC = BC;
+    L.beam_stride = BC * (5 + NL);
+    L.beam0 = p;
+    p += 2 * (size_t)L.beam_stride;
     L.nb_src = p; p += BC;
     L.s_off = p; p += BC;
     L.s_end = p; p += BC;
@@ -210,13 +210,13 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             cur = cur + ln2[(int64_t)t * N];
             rootgap[t + 1] = cur;
         }
-        L.b_node[0][0] = -1;
-        L.b_lp[0][0] = kNegInf;  // label: zero
-        L.b_gp[0][0] = 0.0f;     // gap: one
-        L.b_tip[0][0] = -1;
-        L.b_par[0][0] = -2;
+        L.b_node(0)[0] = -1;
+        L.b_lp(0)[0] = kNegInf;  // label: zero
+        L.b_gp(0)[0] = 0.0f;     // gap: one
+        L.b_tip(0)[0] = -1;
+        L.b_par(0)[0] = -2;
     }
-    for (int j = lane; j < NL; j += kWave) L.b_child[0][j] = -1;
+    for (int j = lane; j < NL; j += kWave) L.b_child(0)[j] = -1;
     __syncthreads();
 
     int cur = 0, B = 1, nn = 0;
@@ -249,15 +249,15 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             // ---- :493 beam.sort_by_key(node): parents before children ----
             const int nx = cur ^ 1;
             for (int e = lane; e < B; e += kWave) {
-                const int nd = L.b_node[cur][e];
+                const int nd = L.b_node(cur)[e];
                 int rk = 0;
-                for (int j = 0; j < B; ++j) rk += (L.b_node[cur][j] < nd) ? 1 : 0;
-                L.b_node[nx][rk] = nd;
-                L.b_lp[nx][rk] = L.b_lp[cur][e];
-                L.b_gp[nx][rk] = L.b_gp[cur][e];
-                L.b_tip[nx][rk] = L.b_tip[cur][e];
-                L.b_par[nx][rk] = L.b_par[cur][e];
-                for (int l = 0; l < NL; ++l) L.b_child[nx][rk * NL + l] = L.b_child[cur][e * NL + l];
+                for (int j = 0; j < B; ++j) rk += (L.b_node(cur)[j] < nd) ? 1 : 0;
+                L.b_node(nx)[rk] = nd;
+                L.b_lp(nx)[rk] = L.b_lp(cur)[e];
+                L.b_gp(nx)[rk] = L.b_gp(cur)[e];
+                L.b_tip(nx)[rk] = L.b_tip(cur)[e];
+                L.b_par(nx)[rk] = L.b_par(cur)[e];
+                for (int l = 0; l < NL; ++l) L.b_child(nx)[rk * NL + l] = L.b_child(cur)[e * NL + l];
             }
             cur = nx;
             __syncthreads();
@@ -270,13 +270,13 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             bool fast_ok = hi == last_hi + 1 && B <= kWave;
             {
                 const int e = lane;
-                const bool mine = e < B && L.b_node[cur][e] >= 0;
+                const bool mine = e < B && L.b_node(cur)[e] >= 0;
                 int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0,
                     p_lab = -1;
                 float mx = kNegInf;
                 bool bad = false;
                 if (fast_ok && mine) {
-                    node = L.b_node[cur][e];
+                    node = L.b_node(cur)[e];
                     const int4 m = load_meta_l2(&meta[node]);
                     parent = m.x; lab = m.y; off = m.z; end = m.w;
                     mx = load_f32_l2(&nmax[node]);
@@ -339,7 +339,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             }
             __syncthreads();
             for (int e = 0; e < B && !fast_ok; ++e) {
-                const int node = L.b_node[cur][e];
+                const int node = L.b_node(cur)[e];
                 if (node < 0) continue;
                 const int4 m = load_meta_l2(&meta[node]);
                 const int parent = m.x, lab = m.y;
@@ -415,7 +415,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
         if (staged) {
             // ---- LDS tile of the DP envelope for this row of read 1 ----
             for (int e = lane; e < B; e += kWave) {
-                const int nd = L.b_node[cur][e];
+                const int nd = L.b_node(cur)[e];
                 int off = -1, end = root_end;
                 if (nd >= 0) {
                     const int4 m = load_meta_l2(&meta[nd]);
@@ -428,7 +428,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             for (int xw = lane; xw < W * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * N + xw];
             __syncthreads();
             for (int e = 0; e < B; ++e) {
-                const int nd = L.b_node[cur][e];
+                const int nd = L.b_node(cur)[e];
                 const VecRef pv = node_vec(nd, L.s_off[e], L.s_end[e]);
                 for (int j = lane; j < W; j += kWave) {
                     float pg, ps;
@@ -440,9 +440,9 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             __syncthreads();
         }
 
-        int *b_node = L.b_node[cur], *b_tip = L.b_tip[cur], *b_par = L.b_par[cur];
-        int *b_child = L.b_child[cur];
-        float *b_lp = L.b_lp[cur], *b_gp = L.b_gp[cur];
+        int *b_node = L.b_node(cur), *b_tip = L.b_tip(cur), *b_par = L.b_par(cur);
+        int *b_child = L.b_child(cur);
+        float *b_lp = L.b_lp(cur), *b_gp = L.b_gp(cur);
         const int nslots = B * N;
         const float *row1 = ln1 + t1 * N;
         int n_valid = 0;
@@ -698,15 +698,15 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             for (int j = 0; j < nslots; ++j) rank += (L.c_key[j] > key) ? 1 : 0;
             if (rank < BC) {
                 const int i = c / N, k = c - i * N;
-                L.b_node[nxt][rank] = L.c_id[c];
-                L.b_lp[nxt][rank] = L.c_lp[c];
-                L.b_gp[nxt][rank] = L.c_gp[c];
+                L.b_node(nxt)[rank] = L.c_id[c];
+                L.b_lp(nxt)[rank] = L.c_lp[c];
+                L.b_gp(nxt)[rank] = L.c_gp[c];
                 if (k == 0) {
-                    L.b_tip[nxt][rank] = b_tip[i];
-                    L.b_par[nxt][rank] = b_par[i];
+                    L.b_tip(nxt)[rank] = b_tip[i];
+                    L.b_par(nxt)[rank] = b_par[i];
                 } else {
-                    L.b_tip[nxt][rank] = k - 1;
-                    L.b_par[nxt][rank] = b_node[i];
+                    L.b_tip(nxt)[rank] = k - 1;
+                    L.b_par(nxt)[rank] = b_node[i];
                 }
                 L.nb_src[rank] = c | (L.c_new[c] << 30);
             }
@@ -720,8 +720,8 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             int v;
             if (k == 0) v = b_child[i * NL + l];
             else if (src >> 30) v = -1;
-            else v = load_i32_l2(&rows[(int64_t)L.b_node[nxt][s] * NL + l]);
-            L.b_child[nxt][s * NL + l] = v;
+            else v = load_i32_l2(&rows[(int64_t)L.b_node(nxt)[s] * NL + l]);
+            L.b_child(nxt)[s * NL + l] = v;
         }
         B = Bn;
         cur = nxt;
@@ -730,7 +730,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
 
     // ---- labels leaf -> root (:638-649), written in sequence order ----
     if (lane == 0) {
-        int node = L.b_node[cur][0];
+        int node = L.b_node(cur)[0];
         int n = 0;
         for (int q = node; q >= 0; q = load_i32_l2(reinterpret_cast<const int32_t *>(&meta[q]))) ++n;
         for (int j = n - 1; j >= 0; --j) {
