@@ -443,15 +443,51 @@ def _stack_host(x, ndim):
     return _dense(a)
 
 
+def _ragged(network_outputs, lengths, ndim):
+    """A list/tuple of per-read arrays of different lengths -> (padded batch, lengths).
+    Reads are padded with zeros to the longest one; the kernels never look past lengths[i]."""
+    if isinstance(network_outputs, (list, tuple)) and len(network_outputs) > 0 and lengths is None \
+            and all(isinstance(v, np.ndarray) for v in network_outputs):
+        Ts = [v.shape[0] for v in network_outputs]
+        if len(set(Ts)) > 1:
+            tail = network_outputs[0].shape[1:]
+            if any(v.dtype != np.float32 or v.ndim != ndim - 1 or v.shape[1:] != tail for v in network_outputs):
+                raise TypeError("expected float32 arrays of rank %d with equal inner shapes" % (ndim - 1))
+            out = np.zeros((len(Ts), max(Ts)) + tail, np.float32)
+            for i, v in enumerate(network_outputs):
+                out[i, :Ts[i]] = v
+            return out, np.asarray(Ts, np.int64)
+    return network_outputs, lengths
+
+
+def _device_tensor(x):
+    """torch ROCm tensors pass through; any other device array speaking DLPack (e.g. CuPy) is
+    wrapped zero-copy.  Host objects return None."""
+    if _is_torch_cuda(x):
+        return x
+    if hasattr(x, "__dlpack__") and not isinstance(x, np.ndarray) and hasattr(x, "__dlpack_device__"):
+        try:
+            dev_type = int(x.__dlpack_device__()[0])
+        except Exception:
+            return None
+        if dev_type in (2, 10):  # kDLCUDA, kDLROCM
+            import torch
+            return torch.from_dlpack(x)
+    return None
+
+
 def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
                           collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, handle=None):
     """Decode a (B,T,N) batch with search::beam_search semantics; returns a BatchResult.
     `handle` (device tensors only): an explicit fast_ctc_decode_amd._native.Handle -- one per
     concurrent torch stream, since a handle owns the tree-arena workspace its kernels use."""
-    if _is_torch_cuda(network_outputs):
+    dev_x = _device_tensor(network_outputs)
+    if dev_x is not None:
+        network_outputs = dev_x
         return _torch_call("fcd_beam_search_dev", network_outputs, False, lengths,
                            (int(beam_size), float(beam_cut_threshold),
                             int(bool(collapse_repeats)), int(kernel)), handle=handle)
+    network_outputs, lengths = _ragged(network_outputs, lengths, 3)
     x = _stack_host(network_outputs, 3)
     B, T, N = x.shape
     h = nat.default_handle()
@@ -467,16 +503,19 @@ def beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold
                       collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO):
     """Batched beam_search: element i equals beam_search(network_outputs[i][:lengths[i]], ...)."""
     alpha = _seq_to_vec(alphabet)
-    _check_beam_args(len(alpha), network_outputs.shape[-1], beam_size, beam_cut_threshold)
+    inner = network_outputs[0].shape[-1] if isinstance(network_outputs, (list, tuple)) else network_outputs.shape[-1]
+    _check_beam_args(len(alpha), inner, beam_size, beam_cut_threshold)
     r = beam_search_batch_raw(network_outputs, beam_size, beam_cut_threshold, collapse_repeats,
                               lengths, kernel)
     return r.sequences(alpha)
 
 
 def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=None, qual=False):
-    if _is_torch_cuda(network_outputs):
-        return _torch_call("fcd_viterbi_search_dev", network_outputs, False, lengths,
+    dev_x = _device_tensor(network_outputs)
+    if dev_x is not None:
+        return _torch_call("fcd_viterbi_search_dev", dev_x, False, lengths,
                            (int(bool(collapse_repeats)),), want_qual=qual)
+    network_outputs, lengths = _ragged(network_outputs, lengths, 3)
     x = _stack_host(network_outputs, 3)
     B, T, N = x.shape
     h = nat.default_handle()
@@ -491,7 +530,8 @@ def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=Non
 def viterbi_search_batch(network_outputs, alphabet, qstring=False, qscale=1.0, qbias=0.0,
                          collapse_repeats=True, lengths=None):
     alpha = _seq_to_vec(alphabet)
-    _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
+    inner = network_outputs[0].shape[-1] if isinstance(network_outputs, (list, tuple)) else network_outputs.shape[-1]
+    _check_greedy_alphabet(len(alpha), inner)
     r = viterbi_search_batch_raw(network_outputs, collapse_repeats, lengths, qual=qstring).cpu()
     res = r.sequences(alpha)
     if qstring:

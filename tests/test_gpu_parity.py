@@ -321,3 +321,37 @@ def test_c_abi_misuse_is_reported(fcd):
     st, labels, path, _ = oracle.beam_search_raw(x[0], 5, 0.1)
     n = int(out.out_len[0])
     np.testing.assert_array_equal(out.labels[0, :n], labels)
+
+
+def test_ragged_list_batch_equals_single_calls(fcd):
+    """A Python list of reads of different lengths decodes like one call per read."""
+    rng = np.random.default_rng(90)
+    reads = [reference_style_rows(rng, int(t), 5) for t in (120, 1, 333, 64, 200)]
+    got = fcd.beam_search_batch(reads, "NACGT", 5, 0.1)
+    assert got == [oracle.beam_search(x, "NACGT", 5, 0.1) for x in reads]
+    gv = fcd.viterbi_search_batch(reads, "NACGT", qstring=True)
+    assert gv == [oracle.viterbi_search(x, "NACGT", True) for x in reads]
+
+
+def test_dlpack_device_input(fcd):
+    """Any device array speaking DLPack is accepted zero-copy (here: a torch tensor behind a
+    minimal DLPack-only wrapper)."""
+    torch = pytest.importorskip("torch")
+
+    class DL:
+        def __init__(self, t):
+            self.t = t
+
+        def __dlpack__(self, stream=None):
+            return self.t.__dlpack__()
+
+        def __dlpack_device__(self):
+            return self.t.__dlpack_device__()
+
+    x = gen_batch(91, 5, 300, 5)
+    r = fcd.beam_search_batch_raw(DL(torch.from_numpy(x).cuda()), 5, 0.1).cpu()
+    for i in range(5):
+        st, labels, path, _ = oracle.beam_search_raw(x[i], 5, 0.1)
+        n = int(r.out_len[i])
+        np.testing.assert_array_equal(r.labels[i, :n], labels)
+        np.testing.assert_array_equal(r.path[i, :n], path)
