@@ -21,6 +21,7 @@ from .api import (  # noqa: F401
     crf_beam_search_batch,
     crf_beam_search_batch_raw,
     crf_beam_search_duplex,
+    crf_beam_search_duplex_batch_raw,
     crf_greedy_search,
     viterbi_search,
     viterbi_search_batch,

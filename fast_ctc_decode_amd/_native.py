@@ -28,6 +28,7 @@ SYMBOLS = [
     "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k", "fcd_crf_beam_search_host",
     "fcd_crf_greedy_search_dev", "fcd_crf_greedy_search_host",
     "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
+    "fcd_crf_beam_search_duplex_dev", "fcd_crf_beam_search_duplex_host",
     "fcd_logspace_probe_dev", "fcd_phred",
 ]
 
@@ -103,6 +104,9 @@ def load():
             getattr(lib, "fcd_crf_greedy_search_" + sfx).argtypes = [P, BP, P, i64, i64, RP]
             getattr(lib, "fcd_beam_search_duplex_" + sfx).argtypes = [
                 P, BP, BP, P, i64, i64, f32, i32, i32, RP]
+        for sfx in ("dev", "host"):
+            getattr(lib, "fcd_crf_beam_search_duplex_" + sfx).argtypes = [
+                P, BP, P, i64, i64, BP, P, i64, i64, P, i64, i64, f32, i32, RP]
         lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
         lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
         lib.fcd_phred.argtypes = [f32, f32, f32]

@@ -352,10 +352,67 @@ def beam_search_duplex_batch(network_outputs_1, network_outputs_2, alphabet, env
     return [s for s, _ in r.sequences(alpha)]
 
 
+def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_outputs_2,
+                                     init_states_2, envelopes=None, beam_size=5,
+                                     beam_cut_threshold=0.0, lengths_1=None, lengths_2=None,
+                                     logadd_mode=None):
+    """(B,T1,S,N) / (B,T2,S,N) host posteriors, (B,n_init) initial state scores, (B,T1,2) uint64
+    envelopes -> BatchResult (labels only)."""
+    mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
+    x1 = _stack_host(network_outputs_1, 4)
+    x2 = _stack_host(network_outputs_2, 4)
+    i1 = np.ascontiguousarray(np.asarray(init_states_1, np.float32))
+    i2 = np.ascontiguousarray(np.asarray(init_states_2, np.float32))
+    B, T1, S, N = x1.shape
+    T2 = x2.shape[1]
+    if x2.shape[0] != B or i1.shape[0] != B or i2.shape[0] != B or i1.ndim != 2 or i2.ndim != 2:
+        raise ValueError("all inputs must hold the same number of pairs")
+    env = _default_envelope(B, T1, T2) if envelopes is None else np.ascontiguousarray(envelopes, np.uint64)
+    if env.shape[0] != B or env.ndim != 3 or env.shape[2] != 2 or env.shape[1] < T1:
+        raise ValueError("envelopes must have shape (n_pairs, T1, 2)")
+    h = nat.default_handle()
+    out = _HostOut(B, T1, want_path=False)
+    l1, l2 = _np_lengths(lengths_1, B), _np_lengths(lengths_2, B)
+    b1, b2 = _host_batch(x1, True, l1), _host_batch(x2, True, l2)
+    h.check(h.lib.fcd_crf_beam_search_duplex_host(
+        h.ptr, C.byref(b1), i1.ctypes.data, int(i1.shape[1]), int(i1.shape[1]), C.byref(b2),
+        i2.ctypes.data, int(i2.shape[1]), int(i2.shape[1]), env.ctypes.data, int(env.shape[1]),
+        int(beam_size), float(beam_cut_threshold), int(mode), C.byref(out.res)))
+    r = BatchResult(out.labels, None, out.out_len, out.status)
+    r._handle = h
+    return r
+
+
 def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, init_state_2,
-                           alphabet, envelope=None, beam_size=5, beam_cut_threshold=0.0):
-    """Mirrors src/lib.rs:490-578 -> duplex.rs:652-834 (outside BASELINE.json's north star)."""
-    raise NotImplementedError("crf_beam_search_duplex is out of scope for this build (SURVEY.md 8f.3)")
+                           alphabet, envelope=None, beam_size=5, beam_cut_threshold=0.0, *,
+                           logadd_mode=None):
+    """Mirrors src/lib.rs:490-578 -> duplex.rs:652-834.  Returns the consensus sequence (str)."""
+    x1 = _as_f32(network_output_1, 3, "network_output_1")
+    i1 = _as_f32(init_state_1, 1, "init_state_1")
+    x2 = _as_f32(network_output_2, 3, "network_output_2")
+    i2 = _as_f32(init_state_2, 1, "init_state_2")
+    alpha = _seq_to_vec(alphabet)
+    if x1.shape[2] != x2.shape[2]:
+        raise ValueError("inner axes of the network outputs do not match")
+    # src/lib.rs:509-530 (the message quotes shape()[1], as the reference does)
+    n_alpha = len(alpha)
+    if n_alpha != x1.shape[2]:
+        raise ValueError("alphabet size %d does not match probability matrix inner dimension %d"
+                         % (n_alpha, x1.shape[1]))
+    _check_beam_args(n_alpha, x1.shape[2], beam_size, beam_cut_threshold)
+    _check_envelope(envelope, x1.shape[0])
+    if x1.shape[1] != x2.shape[1]:
+        raise RuntimeError("state axes of the network outputs do not match (the reference asserts and aborts)")
+    if x1.shape[0] == 0 or i1.size == 0 or i2.size == 0:
+        raise RuntimeError("empty network_output_1 / init_state (the reference aborts here)")
+    env = None if envelope is None else np.ascontiguousarray(envelope)[None]
+    r = crf_beam_search_duplex_batch_raw(_dense(x1)[None], np.ascontiguousarray(i1)[None],
+                                         _dense(x2)[None], np.ascontiguousarray(i2)[None], env,
+                                         beam_size, beam_cut_threshold, logadd_mode=logadd_mode)
+    _raise_status(int(r.status[0]))
+    n = int(r.out_len[0])
+    # src/duplex.rs:825-833: labels appended leaf -> root, then the CHARACTERS reversed
+    return "".join(alpha[l] for l in r.labels[0, :n][::-1])[::-1]
 
 
 # ---------------------------------------------------------------------------------------------

@@ -402,16 +402,28 @@ int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *i
     return FCD_OK;
 }
 
-int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
-                               const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
-                               float beam_cut_threshold, int collapse_repeats, int logadd_mode,
-                               const fcd_result *out) {
+namespace {
+struct CrfInit {
+    const float *init1 = nullptr, *init2 = nullptr;
+    int64_t n1 = 0, s1 = 0, n2 = 0, s2 = 0;
+};
+
+// Shared driver of duplex::beam_search (crf == nullptr) and duplex::crf_beam_search.
+int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const CrfInit *crf,
+               const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+               float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+               const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::mutex> g(h->mu);
-    int rc = check_batch(h, in1, false);
+    const bool is_crf = crf != nullptr;
+    int rc = check_batch(h, in1, is_crf);
     if (rc) return rc;
-    rc = check_batch(h, in2, false);
+    rc = check_batch(h, in2, is_crf);
     if (rc) return rc;
+    if (is_crf && in1->S != in2->S) return fail(h, FCD_E_INVALID, "state counts of the two network outputs differ");
+    if (is_crf && (!crf->init1 || !crf->init2 || crf->n1 < 1 || crf->n2 < 1))
+        return fail(h, FCD_E_INVALID, "init_state missing");
+    const int S = is_crf ? (int)in1->S : 1;
     if (in1->n_reads != in2->n_reads) return fail(h, FCD_E_INVALID, "pair counts differ");
     if (in1->N != in2->N) return fail(h, FCD_E_INVALID, "inner axes of the network outputs do not match");
     if (in1->N < 2) return fail(h, FCD_E_UNSUPPORTED, "alphabet needs at least one label besides the blank");
@@ -426,23 +438,23 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
     if (!envelope || env_stride < in1->T) return fail(h, FCD_E_INVALID, "envelope missing or shorter than read 1");
     if (beam_size > (1 << 12)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 4096");
     const int N = (int)in1->N, NL = N - 1;
-    if (duplex_lds_bytes((int)beam_size, N, 0) > 64 * 1024)
+    if (duplex_lds_bytes((int)beam_size, N, 0, S) > 64 * 1024)
         return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
     FCD_HIP(h, hipSetDevice(h->device));
 
     // log-space copies + one int for the envelope width
     const int64_t T1 = std::max<int64_t>(in1->T, 1), T2 = std::max<int64_t>(in2->T, 1);
-    const size_t n1 = (size_t)B * T1 * N, n2 = (size_t)B * T2 * N;
+    const size_t n1 = (size_t)B * T1 * S * N, n2 = (size_t)B * T2 * S * N;
     rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, (n1 + n2) * 4 + 256);
     if (rc) return rc;
     float *ln1 = reinterpret_cast<float *>(h->lnbuf);
     float *ln2 = ln1 + n1;
     int *d_width = reinterpret_cast<int *>(ln2 + n2);
     Timer tm(h);
-    FCD_HIP(h, launch_ln_convert(in1->post, B, in1->T, N, in1->stride_read, in1->stride_t,
-                                 in1->stride_n, ln1, h->stream));
-    FCD_HIP(h, launch_ln_convert(in2->post, B, in2->T, N, in2->stride_read, in2->stride_t,
-                                 in2->stride_n, ln2, h->stream));
+    FCD_HIP(h, launch_ln_convert(in1->post, B, in1->T, S, N, in1->stride_read, in1->stride_t,
+                                 is_crf ? in1->stride_s : 0, in1->stride_n, ln1, h->stream));
+    FCD_HIP(h, launch_ln_convert(in2->post, B, in2->T, S, N, in2->stride_read, in2->stride_t,
+                                 is_crf ? in2->stride_s : 0, in2->stride_n, ln2, h->stream));
     FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), h->stream));
     FCD_HIP(h, launch_env_width(envelope, B, env_stride, in1->T, in2->T, in1->lengths,
                                 in2->lengths, d_width, h->stream));
@@ -468,6 +480,10 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
     // ln(threshold) with the kernels' definition of ln: correctly rounded f32 (duplex.rs:454)
     a.thr_ln = (float)log((double)beam_cut_threshold);
     a.collapse = collapse_repeats ? 1 : 0; a.mode = logadd_mode;
+    a.S = S; a.crf = is_crf ? 1 : 0;
+    a.init1 = is_crf ? crf->init1 : nullptr; a.init2 = is_crf ? crf->init2 : nullptr;
+    a.n_init1 = is_crf ? crf->n1 : 0; a.n_init2 = is_crf ? crf->n2 : 0;
+    a.init1_stride = is_crf ? crf->s1 : 0; a.init2_stride = is_crf ? crf->s2 : 0;
     char *base = reinterpret_cast<char *>(h->arena);
     a.meta = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
     a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
@@ -477,7 +493,7 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
     a.rootgap = reinterpret_cast<float *>(base);
     a.cap_nodes = cap_nodes; a.Wcap = Wcap;
     // tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
-    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2) <= 48 * 1024 ? 1 : 0;
+    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S) <= 48 * 1024 ? 1 : 0;
     a.out = to_desc(out);
     for (int64_t begin = 0; begin < B; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, B - begin);
@@ -486,30 +502,58 @@ int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_ba
     tm.stop();
     return FCD_OK;
 }
+}  // namespace
 
-int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
-                                const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
-                                float beam_cut_threshold, int collapse_repeats, int logadd_mode,
-                                const fcd_result *out) {
+int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
+                               const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                               float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                               const fcd_result *out) {
+    return duplex_dev(h, in1, in2, nullptr, envelope, env_stride, beam_size, beam_cut_threshold,
+                      collapse_repeats, logadd_mode, out);
+}
+
+int fcd_crf_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const float *init1,
+                                   int64_t n_init1, int64_t init1_stride, const fcd_batch *in2,
+                                   const float *init2, int64_t n_init2, int64_t init2_stride,
+                                   const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                   float beam_cut_threshold, int logadd_mode, const fcd_result *out) {
+    CrfInit c;
+    c.init1 = init1; c.n1 = n_init1; c.s1 = init1_stride;
+    c.init2 = init2; c.n2 = n_init2; c.s2 = init2_stride;
+    return duplex_dev(h, in1, in2, &c, envelope, env_stride, beam_size, beam_cut_threshold, 0,
+                      logadd_mode, out);
+}
+
+namespace {
+// host staging shared by fcd_beam_search_duplex_host / fcd_crf_beam_search_duplex_host
+int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const CrfInit *crf,
+                const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
+    const bool is_crf = crf != nullptr;
     {
         std::lock_guard<std::mutex> g(h->mu);
-        int rc = check_batch(h, in1, false);
+        int rc = check_batch(h, in1, is_crf);
         if (rc) return rc;
-        rc = check_batch(h, in2, false);
+        rc = check_batch(h, in2, is_crf);
         if (rc) return rc;
         if (in1->n_reads != in2->n_reads) return fail(h, FCD_E_INVALID, "pair counts differ");
         if (!out || !envelope) return fail(h, FCD_E_INVALID, "null result/envelope");
         if (in1->stride_read < 0 || in1->stride_t < 0 || in1->stride_n < 0 || in2->stride_read < 0 ||
-            in2->stride_t < 0 || in2->stride_n < 0)
+            in2->stride_t < 0 || in2->stride_n < 0 || (is_crf && (in1->stride_s < 0 || in2->stride_s < 0)))
             return fail(h, FCD_E_UNSUPPORTED, "negative strides: pass a contiguous copy");
+        if (is_crf && (!crf->init1 || !crf->init2 || crf->n1 < 1 || crf->n2 < 1))
+            return fail(h, FCD_E_INVALID, "init_state missing");
     }
     const int64_t B = in1->n_reads;
     if (B == 0) return FCD_OK;
     if (!out->labels || !out->out_len || !out->status) return fail(h, FCD_E_INVALID, "null output array");
-    const size_t e1 = (size_t)span_elems(in1, false), e2 = (size_t)span_elems(in2, false);
+    const size_t e1 = (size_t)span_elems(in1, is_crf), e2 = (size_t)span_elems(in2, is_crf);
     const size_t n_env = (size_t)B * (size_t)env_stride * 2;
     const size_t n_out = (size_t)B * (size_t)out->out_stride;
+    const size_t ni1 = is_crf ? (size_t)((B - 1) * crf->s1 + crf->n1) : 0;
+    const size_t ni2 = is_crf ? (size_t)((B - 1) * crf->s2 + crf->n2) : 0;
     size_t used = 0;
     auto reserve = [&](size_t bytes) {
         size_t off = (used + 255) & ~(size_t)255;
@@ -519,6 +563,7 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
     const size_t o1 = reserve(e1 * 4), o2 = reserve(e2 * 4), oe = reserve(n_env * 8);
     const size_t ol1 = reserve(in1->lengths ? (size_t)B * 8 : 0);
     const size_t ol2 = reserve(in2->lengths ? (size_t)B * 8 : 0);
+    const size_t oi1 = reserve(ni1 * 4), oi2 = reserve(ni2 * 4);
     const size_t olab = reserve(n_out), oolen = reserve((size_t)B * 4), ostat = reserve((size_t)B * 4);
     {
         std::lock_guard<std::mutex> g(h->mu);
@@ -533,6 +578,10 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
             FCD_HIP(h, hipMemcpyAsync(base + ol1, in1->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
         if (in2->lengths)
             FCD_HIP(h, hipMemcpyAsync(base + ol2, in2->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        if (is_crf) {
+            FCD_HIP(h, hipMemcpyAsync(base + oi1, crf->init1, ni1 * 4, hipMemcpyHostToDevice, h->stream));
+            FCD_HIP(h, hipMemcpyAsync(base + oi2, crf->init2, ni2 * 4, hipMemcpyHostToDevice, h->stream));
+        }
     }
     char *base = reinterpret_cast<char *>(h->stage);
     fcd_batch d1 = *in1, d2 = *in2;
@@ -545,9 +594,14 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
     dout.out_len = reinterpret_cast<uint32_t *>(base + oolen);
     dout.status = reinterpret_cast<int32_t *>(base + ostat);
     dout.out_stride = out->out_stride;
-    int rc = fcd_beam_search_duplex_dev(h, &d1, &d2, reinterpret_cast<const uint64_t *>(base + oe),
-                                        env_stride, beam_size, beam_cut_threshold, collapse_repeats,
-                                        logadd_mode, &dout);
+    CrfInit dc;
+    if (is_crf) {
+        dc = *crf;
+        dc.init1 = reinterpret_cast<const float *>(base + oi1);
+        dc.init2 = reinterpret_cast<const float *>(base + oi2);
+    }
+    int rc = duplex_dev(h, &d1, &d2, is_crf ? &dc : nullptr, reinterpret_cast<const uint64_t *>(base + oe),
+                        env_stride, beam_size, beam_cut_threshold, collapse_repeats, logadd_mode, &dout);
     if (rc) return rc;
     std::lock_guard<std::mutex> g(h->mu);
     FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
@@ -555,6 +609,27 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
     FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
+}
+}  // namespace
+
+int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
+                                const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                float beam_cut_threshold, int collapse_repeats, int logadd_mode,
+                                const fcd_result *out) {
+    return duplex_host(h, in1, in2, nullptr, envelope, env_stride, beam_size, beam_cut_threshold,
+                       collapse_repeats, logadd_mode, out);
+}
+
+int fcd_crf_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const float *init1,
+                                    int64_t n_init1, int64_t init1_stride, const fcd_batch *in2,
+                                    const float *init2, int64_t n_init2, int64_t init2_stride,
+                                    const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                    float beam_cut_threshold, int logadd_mode, const fcd_result *out) {
+    CrfInit c;
+    c.init1 = init1; c.n1 = n_init1; c.s1 = init1_stride;
+    c.init2 = init2; c.n2 = n_init2; c.s2 = init2_stride;
+    return duplex_host(h, in1, in2, &c, envelope, env_stride, beam_size, beam_cut_threshold, 0,
+                       logadd_mode, out);
 }
 
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,

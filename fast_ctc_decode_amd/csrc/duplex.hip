@@ -44,6 +44,10 @@ struct DuplexParams {
     float thr_ln;
     int collapse;
     int mode;
+    int S;                       // transition states (1 for the plain search)
+    int crf;                     // 1: duplex::crf_beam_search (:652-834)
+    const float *init1, *init2;  // CRF: [pair * init_stride] initial state scores
+    int64_t n_init1, n_init2, init1_stride, init2_stride;
     // arena (per pair slabs)
     int4 *meta;      // {parent, label, offset, end}
     float *nmax;     // running max per node
@@ -99,25 +103,26 @@ struct DLds {
     __device__ __forceinline__ float *b_gp(int b) const { return reinterpret_cast<float *>(b_node(b) + 2 * BC); }
     __device__ __forceinline__ int *b_tip(int b) const { return b_node(b) + 3 * BC; }
     __device__ __forceinline__ int *b_par(int b) const { return b_node(b) + 4 * BC; }
-    __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 5 * BC; }
+    __device__ __forceinline__ int *b_state(int b) const { return b_node(b) + 5 * BC; }
+    __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 6 * BC; }
     uint64_t *c_key;
     float *c_lp, *c_gp, *c_p2;
     int *c_id, *c_new;
     int *nb_src;
     int *s_off, *s_end;  // BC each: window bounds of the beam entries' vectors
     int *bt;             // 64: lane that owns the m-th new node of the current pass
-    float *w2;           // Wmax*N: log posteriors of read 2, rows [lo, hi)
+    float *w2;           // Wmax*S*N: log posteriors of read 2, rows [lo, hi), all states
     float *pw;           // BC*Wmax*2: (gap, label(+)gap) of every beam entry at rows [lo-1, hi-1)
 };
 
-__host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax) {
+__host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax, int S) {
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
-    return 2 * (size_t)BC * (5 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 + 64 +
-           (size_t)Wmax * N + (size_t)BC * Wmax * 2;
+    return 2 * (size_t)BC * (6 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 + 64 +
+           (size_t)Wmax * S * N + (size_t)BC * Wmax * 2;
 }
 
-__device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax) {
+__device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S) {
     DLds L;
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
@@ -129,14 +134,14 @@ __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax) {
     L.c_id = p; p += C;
     L.c_new = p; p += C;
     L.BC = BC;
-    L.beam_stride = BC * (5 + NL);
+    L.beam_stride = BC * (6 + NL);
     L.beam0 = p;
     p += 2 * (size_t)L.beam_stride;
     L.nb_src = p; p += BC;
     L.s_off = p; p += BC;
     L.s_end = p; p += BC;
     L.bt = p; p += 64;
-    L.w2 = reinterpret_cast<float *>(p); p += (size_t)Wmax * N;
+    L.w2 = reinterpret_cast<float *>(p); p += (size_t)Wmax * S * N;
     L.pw = reinterpret_cast<float *>(p);
     return L;
 }
@@ -170,18 +175,19 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
     const int lane = threadIdx.x;
     const int64_t local = blockIdx.x;
     const int64_t r = p.pair_begin + local;
-    const int N = p.N, NL = N - 1, BC = p.beam_size, Wcap = p.Wcap;
-    const bool collapse = p.collapse != 0;
+    const int N = p.N, NL = N - 1, BC = p.beam_size, Wcap = p.Wcap, S = p.S;
+    const bool crf = p.crf != 0;
+    const bool collapse = !crf && p.collapse != 0;
     const float thr = p.thr_ln;
     const bool staged = p.staged != 0;
     const int Wmax = staged ? Wcap - 2 : 0;
-    DLds L = dcarve(smem, BC, N, Wmax);
+    DLds L = dcarve(smem, BC, N, Wmax, S);
 
     int64_t T1 = p.T1cap, T2 = p.T2cap;
     if (p.len1) { int64_t t = p.len1[r]; T1 = t < 0 ? 0 : (t < T1 ? t : T1); }
     if (p.len2) { int64_t t = p.len2[r]; T2 = t < 0 ? 0 : (t < T2 ? t : T2); }
-    const float *ln1 = p.ln1 + r * p.T1cap * N;
-    const float *ln2 = p.ln2 + r * p.T2cap * N;
+    const float *ln1 = p.ln1 + r * p.T1cap * S * N;
+    const float *ln2 = p.ln2 + r * p.T2cap * S * N;
     const uint64_t *env = p.env + r * p.env_stride * 2;
     int4 *meta = p.meta + local * p.cap_nodes;
     float *nmax = p.nmax + local * p.cap_nodes;
@@ -203,13 +209,37 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
     const uint64_t ub_u = env[1];
     if (ub_u > (uint64_t)T2) return fail(FCD_ST_BAD_STATE);  // slice(s![..upper_bound]) panics
     const int root_end = (int)ub_u;                            // root rows are [-1, ub)
+    // CRF start states: init_state.argmax() (:679,:691; first maximum, NaN panics in the reference)
+    int st1 = 0, st2 = 0;
+    if (crf) {
+        bool bad = false;
+        for (int which = 0; which < 2; ++which) {
+            const float *init = which ? p.init2 + r * p.init2_stride : p.init1 + r * p.init1_stride;
+            const int64_t n_init = which ? p.n_init2 : p.n_init1;
+            int arg = 0;
+            float m = init[0];
+            bad = bad || (m != m);
+            for (int64_t j = 1; j < n_init; ++j) {
+                const float e = init[j];
+                bad = bad || (e != e);
+                if (e > m) { m = e; arg = (int)j; }
+            }
+            bad = bad || arg >= S;
+            if (which) st2 = arg; else st1 = arg;
+        }
+        if (bad) return fail(FCD_ST_BAD_STATE);
+    }
     if (lane == 0) {
+        // root_probs (:389-409) / crf_root_probs (:411-441): cumulative blank product
         float cur = 0.0f;
         rootgap[0] = cur;
+        int st = st2;
         for (int t = 0; t < root_end; ++t) {
-            cur = cur + ln2[(int64_t)t * N];
+            cur = cur + ln2[((int64_t)t * S + st) * N];
             rootgap[t + 1] = cur;
+            if (crf) st = (int)(((int64_t)st * NL) % S);  // :437
         }
+        L.b_state(0)[0] = st1;
         L.b_node(0)[0] = -1;
         L.b_lp(0)[0] = kNegInf;  // label: zero
         L.b_gp(0)[0] = 0.0f;     // gap: one
@@ -257,6 +287,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 L.b_gp(nx)[rk] = L.b_gp(cur)[e];
                 L.b_tip(nx)[rk] = L.b_tip(cur)[e];
                 L.b_par(nx)[rk] = L.b_par(cur)[e];
+                L.b_state(nx)[rk] = L.b_state(cur)[e];
                 for (int l = 0; l < NL; ++l) L.b_child(nx)[rk * NL + l] = L.b_child(cur)[e * NL + l];
             }
             cur = nx;
@@ -311,7 +342,8 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 fast_ok = fast_ok && ballot(bad) == 0ull;
                 if (fast_ok && mine) {
                     const VecRef pv = node_vec(parent, p_off, p_end);
-                    const bool is_rep = parent >= 0 && p_lab == lab;  // :512
+                    const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512 (crf: :320-334, no repeat case)
+                    const int tst = L.b_state(cur)[e];                        // crf: the entry's own state (:725-728)
                     float *my = vec + (int64_t)node * Wcap * 3;
                     float l_lab = kNegInf, l_sum = kNegInf;
                     if (end > off) {
@@ -320,7 +352,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                         l_sum = load_f32_l2(my + 3 * sl + 2);
                     }
                     const int idx = end;  // == last_hi == hi - 1
-                    const float *row = ln2 + (int64_t)idx * N;
+                    const float *row = ln2 + ((int64_t)idx * S + tst) * N;
                     float pg, ps;
                     vec_get(pv, idx - 1, Wcap, pg, ps);
                     const float g = l_sum + row[0];
@@ -353,7 +385,8 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                     p_end = pm.w;
                 }
                 const VecRef pv = node_vec(parent, p_off, p_end);
-                const bool is_rep = parent >= 0 && p_lab == lab;  // :512, no collapse_repeats test
+                const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512, no collapse_repeats test
+                const int tst = L.b_state(cur)[e];
                 float *my = vec + (int64_t)node * Wcap * 3;
                 if (lo > off) {  // :351-359
                     const int keep = lo - 1;
@@ -384,7 +417,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 }
                 (void)l_gap;
                 for (int idx = end; idx < hi; ++idx) {
-                    const float *row = ln2 + (int64_t)idx * N;
+                    const float *row = ln2 + ((int64_t)idx * S + tst) * N;
                     float pg, ps;
                     vec_get(pv, idx - 1, Wcap, pg, ps);
                     const float g = l_sum + row[0];
@@ -425,7 +458,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 L.s_off[e] = off;
                 L.s_end[e] = end;
             }
-            for (int xw = lane; xw < W * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * N + xw];
+            for (int xw = lane; xw < W * S * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * S * N + xw];
             __syncthreads();
             for (int e = 0; e < B; ++e) {
                 const int nd = L.b_node(cur)[e];
@@ -442,9 +475,10 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
 
         int *b_node = L.b_node(cur), *b_tip = L.b_tip(cur), *b_par = L.b_par(cur);
         int *b_child = L.b_child(cur);
+        int *b_state = L.b_state(cur);
         float *b_lp = L.b_lp(cur), *b_gp = L.b_gp(cur);
         const int nslots = B * N;
-        const float *row1 = ln1 + t1 * N;
+        const float *frame1 = ln1 + t1 * S * N;
         int n_valid = 0;
         bool any_nan = false;
 
@@ -457,6 +491,8 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             const int node = b_node[i];
             const float lp = b_lp[i], gp = b_gp[i];
             const int tip = b_tip[i];
+            const int state = b_state[i];
+            const float *row1 = frame1 + state * N;  // crf: probs[state, :] (:749)
             bool valid = false, is_new = false, rep = false;
             float clp = kNegInf, cgp = kNegInf, p2 = 0.0f;
             int cid = -2;
@@ -476,7 +512,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                         const int par = b_par[i];
                         for (int j = 0; j < B; ++j) {
                             if (b_node[j] == par) {
-                                const float pl = row1[tip + 1];
+                                const float pl = frame1[b_state[j] * N + tip + 1];  // the PARENT's row
                                 if (!(pl < thr)) {
                                     const bool rj = collapse && b_tip[j] == tip;
                                     const float lpj = b_lp[j], gpj = b_gp[j];
@@ -533,12 +569,12 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                         float pg, ps, r0, rl1;
                         if (staged) {
                             const int j = idx - lo;
-                            r0 = L.w2[j * N];
-                            rl1 = L.w2[j * N + l + 1];
+                            r0 = L.w2[(j * S + state) * N];
+                            rl1 = L.w2[(j * S + state) * N + l + 1];
                             pg = L.pw[((size_t)i * Wmax + j) * 2];
                             ps = L.pw[((size_t)i * Wmax + j) * 2 + 1];
                         } else {
-                            const float *row = ln2 + (int64_t)idx * N;
+                            const float *row = ln2 + ((int64_t)idx * S + state) * N;  // crf: tip.state (:772)
                             r0 = row[0];
                             rl1 = row[l + 1];
                             vec_get(pv, idx - 1, Wcap, pg, ps);
@@ -598,6 +634,7 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 const int q_i = __shfl(i, owner);
                 const int q_l = __shfl(k - 1, owner);
                 const int q_flags = __shfl((can ? 1 : 0) | (rep ? 2 : 0), owner);
+                const int q_state = __shfl(state, owner);
                 const int q_node = __shfl(node, owner);
                 const int q_poff = __shfl(par_off, owner);
                 const int q_pend = __shfl(par_end, owner);
@@ -617,18 +654,18 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                         if (isA) {
                             float pg, ps, rl1;
                             if (staged) {
-                                rl1 = L.w2[j * N + q_l + 1];
+                                rl1 = L.w2[(j * S + q_state) * N + q_l + 1];
                                 pg = L.pw[((size_t)q_i * Wmax + j) * 2];
                                 ps = L.pw[((size_t)q_i * Wmax + j) * 2 + 1];
                             } else {
-                                rl1 = ln2[(int64_t)(lo + j) * N + q_l + 1];
+                                rl1 = ln2[((int64_t)(lo + j) * S + q_state) * N + q_l + 1];
                                 vec_get(pv, lo + j - 1, Wcap, pg, ps);
                             }
                             a = lb;
                             bb = q_rep ? pg : ps;
                             add_after = rl1;
                         } else {
-                            r0 = staged ? L.w2[j * N] : ln2[(int64_t)(lo + j) * N];
+                            r0 = staged ? L.w2[(j * S + q_state) * N] : ln2[((int64_t)(lo + j) * S + q_state) * N];
                             a = lb;          // label_{t'} from the even lane
                             bb = sm + r0;    // gap_{t'}
                         }
@@ -704,9 +741,11 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
                 if (k == 0) {
                     L.b_tip(nxt)[rank] = b_tip[i];
                     L.b_par(nxt)[rank] = b_par[i];
+                    L.b_state(nxt)[rank] = b_state[i];
                 } else {
                     L.b_tip(nxt)[rank] = k - 1;
                     L.b_par(nxt)[rank] = b_node[i];
+                    L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;  // :782
                 }
                 L.nb_src[rank] = c | (L.c_new[c] << 30);
             }
@@ -722,6 +761,11 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
             else if (src >> 30) v = -1;
             else v = load_i32_l2(&rows[(int64_t)L.b_node(nxt)[s] * NL + l]);
             L.b_child(nxt)[s * NL + l] = v;
+        }
+        if (crf) {  // a state outside [0, S) is an ndarray index panic in the reference (:749)
+            bool bs = false;
+            for (int s2 = lane; s2 < Bn; s2 += kWave) bs = bs || L.b_state(nxt)[s2] >= S;
+            if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
         }
         B = Bn;
         cur = nxt;
@@ -744,13 +788,14 @@ __global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
 }
 
 // ---- prepass: ln of the posteriors into contiguous log-space copies (:452-453) ----
-__global__ void ln_convert_kernel(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
-                                  int64_t s_t, int64_t s_n, float *out) {
-    const int64_t total = n_reads * T * N;
+__global__ void ln_convert_kernel(const float *x, int64_t n_reads, int64_t T, int S, int N,
+                                  int64_t s_read, int64_t s_t, int64_t s_s, int64_t s_n, float *out) {
+    const int64_t total = n_reads * T * S * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t j = idx % N, t = (idx / N) % T, r = idx / (N * T);
-        out[idx] = ln_cr(x[r * s_read + t * s_t + j * s_n]);
+        const int64_t j = idx % N, st = (idx / N) % S, t = (idx / ((int64_t)N * S)) % T,
+                      r = idx / ((int64_t)N * S * T);
+        out[idx] = ln_cr(x[r * s_read + t * s_t + st * s_s + j * s_n]);
     }
 }
 
@@ -790,15 +835,17 @@ __global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t e
 
 }  // namespace
 
-size_t duplex_lds_bytes(int beam_size, int N, int Wmax) { return dlds_words(beam_size, N, Wmax) * 4 + 16; }
+size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S) {
+    return dlds_words(beam_size, N, Wmax, S) * 4 + 16;
+}
 
-hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
-                             int64_t s_t, int64_t s_n, float *out, hipStream_t stream) {
-    const int64_t total = n_reads * T * N;
+hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
+                             int64_t s_t, int64_t s_s, int64_t s_n, float *out, hipStream_t stream) {
+    const int64_t total = n_reads * T * S * N;
     if (total <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(ln_convert_kernel, dim3(blocks), dim3(256), 0, stream, x, n_reads, T, N,
-                       s_read, s_t, s_n, out);
+    hipLaunchKernelGGL(ln_convert_kernel, dim3(blocks), dim3(256), 0, stream, x, n_reads, T, S, N,
+                       s_read, s_t, s_s, s_n, out);
     return hipGetLastError();
 }
 
@@ -832,8 +879,10 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     p.mode = a.mode; p.meta = a.meta; p.nmax = a.nmax; p.rows = a.rows; p.vec = a.vec;
     p.rootgap = a.rootgap; p.cap_nodes = a.cap_nodes; p.Wcap = a.Wcap; p.out = a.out;
     p.rlo = a.rlo; p.staged = a.staged;
+    p.S = a.S; p.crf = a.crf; p.init1 = a.init1; p.init2 = a.init2; p.n_init1 = a.n_init1;
+    p.n_init2 = a.n_init2; p.init1_stride = a.init1_stride; p.init2_stride = a.init2_stride;
     p.pair_begin = pair_begin;
-    const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0);
+    const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S);
     if (a.mode == FCD_LOGADD_MAX)
         hipLaunchKernelGGL(duplex_kernel<FCD_LOGADD_MAX>, dim3((unsigned)n_pairs), dim3(64), lds,
                            stream, p);

@@ -91,6 +91,9 @@ struct DuplexArgs {
     int N, beam_size;
     float thr_ln;
     int collapse, mode;
+    int S, crf;                  // CRF: S transition states, init scores per pair
+    const float *init1, *init2;
+    int64_t n_init1, n_init2, init1_stride, init2_stride;
     int4 *meta;
     float *nmax;
     int32_t *rlo;
@@ -103,9 +106,9 @@ struct DuplexArgs {
     ResultDesc out;
 };
 
-size_t duplex_lds_bytes(int beam_size, int N, int Wmax);
-hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int N, int64_t s_read,
-                             int64_t s_t, int64_t s_n, float *out, hipStream_t stream);
+size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S);
+hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
+                             int64_t s_t, int64_t s_s, int64_t s_n, float *out, hipStream_t stream);
 hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,
                             int64_t T2cap, const int64_t *len1, const int64_t *len2, int *out,
                             hipStream_t stream);

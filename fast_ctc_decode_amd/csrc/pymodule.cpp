@@ -337,9 +337,65 @@ py::str beam_search_duplex(const py::object &network_output_1, const py::object 
     return py::str(seq);
 }
 
-py::str crf_beam_search_duplex(const py::args &, const py::kwargs &) {
-    // src/lib.rs:490-578 -> duplex.rs:652-834: outside BASELINE.json's north star
-    throw std::runtime_error("crf_beam_search_duplex is not available in the MI355X build");
+// ---- crf_beam_search_duplex: lib.rs:490-578 ----
+py::str crf_beam_search_duplex(const py::object &network_output_1, const py::object &init_state_1,
+                               const py::object &network_output_2, const py::object &init_state_2,
+                               const py::object &alphabet, const py::object &envelope,
+                               const py::object &beam_size_o, float beam_cut_threshold) {
+    py::array x1 = as_f32(network_output_1, 3, "network_output_1");
+    py::array i1 = py::array::ensure(as_f32(init_state_1, 1, "init_state_1"), py::array::c_style);
+    py::array x2 = as_f32(network_output_2, 3, "network_output_2");
+    py::array i2 = py::array::ensure(as_f32(init_state_2, 1, "init_state_2"), py::array::c_style);
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    if (x1.shape(2) != x2.shape(2)) throw py::value_error("inner axes of the network outputs do not match");
+    if ((py::ssize_t)alpha.size() != x1.shape(2))  // the reference's message quotes shape()[1] (lib.rs:512-516)
+        throw py::value_error("alphabet size " + std::to_string(alpha.size()) +
+                              " does not match probability matrix inner dimension " +
+                              std::to_string(x1.shape(1)));
+    check_beam_args(alpha.size(), x1.shape(2), (py::ssize_t)beam_size, beam_cut_threshold);
+    const py::ssize_t T1 = x1.shape(0), T2 = x2.shape(0);
+    std::vector<uint64_t> env_default;
+    py::array env_arr;
+    const uint64_t *env = nullptr;
+    if (!envelope.is_none()) {
+        if (!py::isinstance<py::array>(envelope))
+            throw py::type_error("argument 'envelope': expected numpy.ndarray");
+        py::array e = py::reinterpret_borrow<py::array>(envelope);
+        if (!e.dtype().is(py::dtype::of<uint64_t>()) || e.ndim() != 2)
+            throw py::type_error("argument 'envelope': expected a 2-dimensional uint64 array");
+        if (e.shape(0) != T1) throw py::value_error("the lengths of network_output_1 and envelope do not match");
+        if (e.shape(1) != 2) throw py::value_error("the inner axis of envelope must have size 2");
+        env_arr = py::array::ensure(e, py::array::c_style);
+        env = static_cast<const uint64_t *>(env_arr.data());
+    } else {
+        env_default.resize((size_t)(T1 > 0 ? T1 : 1) * 2);
+        for (py::ssize_t t = 0; t < T1; ++t) {
+            env_default[2 * t] = 0;
+            env_default[2 * t + 1] = (uint64_t)T2;
+        }
+        env = env_default.data();
+    }
+    if (x1.shape(1) != x2.shape(1))
+        throw std::runtime_error("state axes of the network outputs do not match (the reference asserts and aborts)");
+    if (T1 == 0 || i1.size() == 0 || i2.size() == 0)
+        throw std::runtime_error("empty network_output_1 / init_state (the reference aborts here)");
+    Out o(T1, false, false);
+    fcd_batch b1 = batch3(x1), b2 = batch3(x2);
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_crf_beam_search_duplex_host(h, &b1, static_cast<const float *>(i1.data()), i1.shape(0),
+                                             i1.shape(0), &b2, static_cast<const float *>(i2.data()),
+                                             i2.shape(0), i2.shape(0), env, T1, (int64_t)beam_size,
+                                             beam_cut_threshold, g_logadd_mode, &o.res);
+    }
+    check_rc(h, rc);
+    raise_status(o.status);
+    std::string rev;  // duplex.rs:825-833: appended leaf -> root, characters reversed
+    for (uint32_t i = o.len; i > 0; --i) rev += alpha[o.labels[i - 1]];
+    return py::str(reverse_chars(rev));
 }
 
 }  // namespace
@@ -364,7 +420,11 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
           "collapse_repeats"_a = true,
           "beam_search_duplex(network_output_1, network_output_2, alphabet, envelope=None, beam_size=5, "
           "beam_cut_threshold=0.0, collapse_repeats=True)");
-    m.def("crf_beam_search_duplex", &crf_beam_search_duplex);
+    m.def("crf_beam_search_duplex", &crf_beam_search_duplex, "network_output_1"_a, "init_state_1"_a,
+          "network_output_2"_a, "init_state_2"_a, "alphabet"_a, "envelope"_a = py::none(),
+          "beam_size"_a = 5, "beam_cut_threshold"_a = 0.0f,
+          "crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, init_state_2, alphabet, "
+          "envelope=None, beam_size=5, beam_cut_threshold=0.0)");
     // not part of the reference surface: selects what the reference fixes at build time
     // (`fastexp` feature on = "max", off = "logsumexp"; SURVEY.md finding 3)
     m.def("_set_duplex_logadd_mode", [](const std::string &mode) {

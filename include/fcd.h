@@ -11,6 +11,7 @@
  *   fcd_crf_beam_search_*     <- search::crf_beam_search     src/search.rs:38-44   (call site src/lib.rs:274-282)
  *   fcd_crf_greedy_search_*   <- search::crf_greedy_search   src/search.rs:385-392 (call site src/lib.rs:237-246)
  *   fcd_beam_search_duplex_*  <- duplex::beam_search         src/duplex.rs:443-451 (call site src/lib.rs:474-484)
+ *   fcd_crf_beam_search_duplex_* <- duplex::crf_beam_search  src/duplex.rs:652-661 (call site src/lib.rs:563-575)
  *   per-read status codes     <- enum SearchError            src/lib.rs:36-41
  *
  * Conventions
@@ -181,6 +182,20 @@ int fcd_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_b
                                 const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
                                 float beam_cut_threshold, int collapse_repeats, int logadd_mode,
                                 const fcd_result *out);
+
+/* ---- duplex::crf_beam_search (src/duplex.rs:652-834) ----
+ * in1/in2 are (T,S,N) batches with the same S and N; init1/init2: [n_reads * initX_stride] f32 with
+ * n_initX entries used per pair (the start state is their argmax, src/duplex.rs:679,691). */
+int fcd_crf_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const float *init1,
+                                   int64_t n_init1, int64_t init1_stride, const fcd_batch *in2,
+                                   const float *init2, int64_t n_init2, int64_t init2_stride,
+                                   const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                   float beam_cut_threshold, int logadd_mode, const fcd_result *out);
+int fcd_crf_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const float *init1,
+                                    int64_t n_init1, int64_t init1_stride, const fcd_batch *in2,
+                                    const float *init2, int64_t n_init2, int64_t init2_stride,
+                                    const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
+                                    float beam_cut_threshold, int logadd_mode, const fcd_result *out);
 
 /* Test hook (device pointers, n elements): out_add[i] = LogSpace::add(a[i], b[i]) (src/duplex.rs:42-63)
  * and out_ln[i] = LogSpace::new(a[i]) = ln(a[i]) (:24-26), computed by the very device functions the

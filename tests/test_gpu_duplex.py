@@ -209,3 +209,50 @@ def test_logspace_arithmetic_bits(fcd):
         want_ln = np.log(pa.astype(np.longdouble)).astype(np.float32)
     same = (got_ln.view(np.uint32) == want_ln.view(np.uint32)) | (np.isnan(got_ln) & np.isnan(want_ln))
     assert same.all(), (int((~same).sum()), got_ln[~same][:5], want_ln[~same][:5])
+
+
+def crf_pairs(seed, T1, T2, S=4, N=5):
+    rng = np.random.default_rng(seed)
+    x1 = rng.random((T1, S, N), dtype=np.float32)
+    x2 = rng.random((T2, S, N), dtype=np.float32)
+    x1 /= x1.sum(-1, keepdims=True)
+    x2 /= x2.sum(-1, keepdims=True)
+    i1 = np.zeros(S, np.float32)
+    i2 = np.zeros(S, np.float32)
+    i1[rng.integers(0, S)] = 1.0
+    i2[rng.integers(0, S)] = 1.0
+    return x1.astype(np.float32), i1, x2.astype(np.float32), i2
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+@pytest.mark.parametrize("beam,thr,w", [(5, 0.0, 12), (5, 0.1, 20), (3, 0.05, None), (8, 0.0, 16)])
+def test_crf_duplex_exact(fcd, mode, beam, thr, w):
+    """duplex::crf_beam_search (src/duplex.rs:652-834) vs the correctly rounded oracle, both host layers."""
+    import fast_ctc_decode as compiled
+    for seed in (400, 401, 402):
+        x1, i1, x2, i2 = crf_pairs(seed + beam, 70, 64)
+        env = None if w is None else band(70, 64, w)
+        want = oracle.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, beam, thr, mode | CR)
+        got = fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, beam, thr, logadd_mode=mode)
+        assert got == want
+        compiled._set_duplex_logadd_mode("max" if mode == MAX else "logsumexp")
+        try:
+            assert compiled.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, beam, thr) == want
+        finally:
+            compiled._set_duplex_logadd_mode("logsumexp")
+
+
+def test_crf_duplex_multichar_and_errors(fcd):
+    x1, i1, x2, i2 = crf_pairs(410, 40, 40)
+    alpha = ["N", "Aa", "Cc", "Gg", "Tt"]
+    want = oracle.crf_beam_search_duplex(x1, i1, x2, i2, alpha, None, 5, 0.0, LSE | CR)
+    assert fcd.crf_beam_search_duplex(x1, i1, x2, i2, alpha) == want  # character-reversal quirk included
+    bad = band(40, 40, 6)
+    bad[7, 0] = 35
+    with pytest.raises(RuntimeError, match="Invalid envelope values"):
+        fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", bad)
+    with pytest.raises(ValueError, match="beam_size cannot be 0"):
+        fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", None, 0)
+    x1[:] = np.nan
+    with pytest.raises(RuntimeError, match="Failed to compare values"):
+        fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT")
