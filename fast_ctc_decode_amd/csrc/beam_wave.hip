@@ -28,9 +28,10 @@
 //   * survivors are gathered into rank order with ds_bpermute and divided by the top
 //     probability (:278-282, IEEE f32 division).
 //
-// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label, jump, -}; rows[node] = child
-// entries (id | EVER, or -1).  `jump` is the nearest proper ancestor whose depth is a multiple of
-// 64: the final leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling
+// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = child entries
+// (id | EVER, or -1); jmp[node] (written only for nodes whose depth is a multiple of 64) = the
+// nearest proper ancestor whose depth is a multiple of 64.  Every beam entry carries its own jump
+// pointer in a register, so the final leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling
 // into 64-node segments and then walks all segments in parallel, one lane each, instead of chasing
 // ~2000 dependent pointers with a single lane.  EVER marks children that have themselves been in the beam: only those can
 // own children, so only their row is re-read when they re-enter the beam (3.9 % of steps on
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
     const float *post = p.in.post + r * p.in.stride_read;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
-    int4 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
+    int2 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
+    int32_t *jmp = p.arena.jmp + (has_read ? local : 0) * p.arena.cap_nodes;
     int32_t *rows = p.arena.rows + (has_read ? local : 0) * p.arena.cap_nodes * RW;
     const int cap = (int)p.arena.cap_nodes;
 
@@ -249,7 +251,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         nn += n_new;
         const bool f_cap = act && nn > cap;
         if (is_new && !f_cap) {
-            rec[newid] = make_int4(node, (t << 3) | l, (depth % kSeg == 0) ? node : jump, 0);
+            rec[newid] = make_int2(node, (t << 3) | l);
+            // a segment head (depth % 64 == 0) records where the next head up the tree is
+            if ((depth + 1) % kSeg == 0) jmp[newid] = (depth % kSeg == 0) ? node : jump;
             if (node >= 0) rows[(int64_t)node * RW + l] = newid;
             child = newid;
         }
@@ -376,13 +380,16 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // beam[0] lives in group 0: every lane of the half takes ITS leaf and depth
     int h0 = bperm(hbase, node);               // current chunk's first segment head
     int d0 = bperm(hbase, alive ? depth : 0);  // its depth; 0 == nothing left
+    int j0 = bperm(hbase, jump);               // the leaf's own jump pointer (from its beam entry)
     while (ballot(d0 > 0) != 0ull) {
         // phase 1: one lane hops along the jump pointers, collecting up to HALF segment heads
         int cnt = 0, nh = h0, nd = d0;
         if (q == 0) {
             while (cnt < HALF && nd > 0) {
                 heads[hbase + cnt] = nh;
-                nh = rec[nh].z;
+                // the leaf may sit at any depth and brings its jump pointer along; every later head
+                // sits at a multiple of 64 and has it stored
+                nh = (nd % kSeg != 0) ? j0 : jmp[nh];
                 nd = ((nd - 1) / kSeg) * kSeg;
                 ++cnt;
             }
@@ -400,7 +407,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             const int de = q == 0 ? d1 : ds - kSeg;
             int h = heads[hbase + q];
             for (int dd = ds; dd > de && h >= 0; --dd) {
-                const int4 e = rec[h];
+                const int2 e = rec[h];
                 lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
                 if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
                 h = e.x;

@@ -153,7 +153,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     if (use_wave) {
         cap_nodes = (T * std::min<int64_t>(beam, 8) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
         const int row_words = NL <= 4 ? 4 : 8;
-        per_read = (size_t)cap_nodes * (sizeof(int4) + row_words * 4);
+        per_read = (size_t)cap_nodes * (sizeof(int2) + 4 + row_words * 4);
     } else {
         if (beam > (1 << 16)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 65536");
         if (beam_generic_lds_bytes((int)beam, N) > 64 * 1024)
@@ -177,9 +177,11 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
             WaveArena ar;
             ar.cap_nodes = cap_nodes;
             ar.row_words = NL <= 4 ? 4 : 8;
-            ar.rec = reinterpret_cast<int4 *>(h->arena);
+            ar.rec = reinterpret_cast<int2 *>(h->arena);
+            ar.jmp = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
+                                                 (size_t)chunk * cap_nodes * sizeof(int2));
             ar.rows = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
-                                                  (size_t)chunk * cap_nodes * sizeof(int4));
+                                                  (size_t)chunk * cap_nodes * (sizeof(int2) + 4));
             e = launch_beam_wave(d, begin, n, args, ar, o, h->stream);
         } else {
             GenericArena ar;

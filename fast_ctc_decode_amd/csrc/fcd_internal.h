@@ -56,10 +56,12 @@ struct GenericArena {
 };
 
 // Tree arena of the register-resident ("wave") beam kernel.
-//   rec  : int4 {parent, time<<3 | label, jump, -} per node (jump: ancestor at depth % 64 == 0)
+//   rec  : int2 {parent, time<<3 | label} per node
+//   jmp  : i32 per node, written for nodes at depth % 64 == 0: next such ancestor (traceback)
 //   rows : int4 per node (NL <= 4) or 8 x int32 (NL <= 6..7); entry = child | EVER bit, or -1
 struct WaveArena {
-    int4 *rec;
+    int2 *rec;
+    int32_t *jmp;
     int32_t *rows;
     int64_t cap_nodes;
     int row_words;  // 4 or 8
