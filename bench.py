@@ -242,8 +242,8 @@ def main():
         bytes_per_read = T * N * 4 + 5.0 * mean_L  # posteriors in, u8 label + u32 time out
         achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
         cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds)
-        traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2>" if args.kernel in (0, 2)
-                                            else "beam_wave_kernel<5, 8, 1>" if args.kernel == 3
+        traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2, 0>" if args.kernel in (0, 2)
+                                            else "beam_wave_kernel<5, 8, 1, 0>" if args.kernel == 3
                                             else "beam_generic_kernel")
         if args.batch != 4096:
             traffic, traffic_note = None, None
