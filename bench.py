@@ -41,6 +41,18 @@ def make_batch(seed, n_reads):
     return x.reshape(n_reads, T, N).astype(np.float32)
 
 
+def make_batch_peaky(seed, n_reads):
+    """SURVEY.md 8d's second, clearly labelled set: peaky softmax rows (logits ~ 4*N(0,1)), the shape
+    real basecaller posteriors have -- most symbols fall under beam_cut_threshold.  NOT the metric's
+    input; `--data peaky` exists to show how much of the reference-style figure is its worst-case density."""
+    rng = np.random.default_rng(seed)
+    z = 4.0 * rng.standard_normal((n_reads * T, N), dtype=np.float32)
+    z -= z.max(axis=1, keepdims=True)
+    np.exp(z, out=z)
+    z /= z.sum(axis=1, keepdims=True)
+    return z.reshape(n_reads, T, N).astype(np.float32)
+
+
 def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
     """Times the oracle (C restatement of src/search.rs -- NOT the Rust) on this box's host cores
     on a bounded sample of the same workload and checks the GPU's outputs against it.
@@ -153,6 +165,9 @@ def main():
                     help="issue successive steps round-robin on this many HIP streams (each with its own "
                          "handle and tree arena) so that independent batches overlap on the GPU; 1 = strictly "
                          "one batch after the other (the default, and what `value` is quoted on)")
+    ap.add_argument("--data", choices=("reference", "peaky"), default="reference",
+                    help="reference = the metric's generator (tests/test_decode.py:15-17 style rows); "
+                         "peaky = softmax rows, a labelled secondary set")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather even with one rank (path check on a 1-GPU box)")
     args = ap.parse_args()
@@ -181,7 +196,7 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev)
 
     B = args.batch
-    x_host = make_batch(1 + rank, B)
+    x_host = (make_batch if args.data == "reference" else make_batch_peaky)(1 + rank, B)
     x = torch.from_numpy(x_host).to(dev)  # resident in HBM before the timed region
     torch.cuda.synchronize()
 
@@ -245,8 +260,11 @@ def main():
         traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2, 0>" if args.kernel in (0, 2)
                                             else "beam_wave_kernel<5, 8, 1, 0>" if args.kernel == 3
                                             else "beam_generic_kernel")
-        if args.batch != 4096:
+        if args.batch != 4096 or args.data != "reference":
             traffic, traffic_note = None, None
+        props = torch.cuda.get_device_properties(dev)
+        simds = props.multi_processor_count * 4
+        rpw = 2 if args.kernel in (0, 2) else 1
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
         out = {
             "metric": "reads/s (T=4000, N=5, beam=5)",
@@ -264,7 +282,8 @@ def main():
             "config": {
                 "workload": "beam_search beam_size=5 beam_cut_threshold=0.1 collapse_repeats, "
                             "batch=4096 reads T=4000 N=5 per GPU (BASELINE.json configs[1]), "
-                            "reference-style rows numpy default_rng(1+rank)",
+                            + ("reference-style rows numpy default_rng(1+rank)" if args.data == "reference"
+                               else "SECONDARY SET: peaky softmax rows (logits 4*N(0,1)), default_rng(1+rank)"),
                 "reads_per_gpu": B, "T": T, "N": N, "beam_size": BEAM, "beam_cut_threshold": THR,
                 "parallelism": "reads sharded x%d, one RCCL gather of results per step" % world
                                if world > 1 else "single GPU",
@@ -283,6 +302,16 @@ def main():
                 "kernel": "beam search kernel, %.3f ms per launch (HIP events), %d reads x %.0f "
                           "algorithmic B/read" % (k_ms, B, bytes_per_read),
                 "kernel_ms": k_ms, "launches_timed": k_calls,
+                # SURVEY.md 8d's honest secondary bound: a read advances one timestep per step latency,
+                # so reads/s <= resident reads / (T x step latency); the search is a serial chain of T
+                # dependent steps per read and is bound by instruction issue, not by HBM.
+                "secondary_bound": {
+                    "kind": "reads/s <= resident_reads / (T * step_latency)",
+                    "resident_reads": B,
+                    "wavefronts_per_simd": B / rpw / simds,
+                    "step_latency_us": k_ms * 1e3 / T,
+                    "reads_per_s_at_this_latency": B / (k_ms * 1e-3),
+                },
             },
             "cpu_baseline": cpu,
             "viterbi_roofline": vit,

@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libfcd_hip.so")
+LIB_PATH = os.environ.get("FCD_LIB_PATH") or os.path.join(_HERE, "libfcd_hip.so")  # env: developer override
 
 OK = 0
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5

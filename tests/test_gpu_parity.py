@@ -355,3 +355,47 @@ def test_dlpack_device_input(fcd):
         n = int(r.out_len[i])
         np.testing.assert_array_equal(r.labels[i, :n], labels)
         np.testing.assert_array_equal(r.path[i, :n], path)
+
+
+def _fuzz_case(seed):
+    """One random (shape, parameters, input style) draw; quantised styles create exact f32 ties."""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(2, 9))
+    beam = int(rng.choice([1, 2, 3, 4, 5, 6, 8, 11, 16]))
+    T = int(rng.integers(1, 180))
+    B = int(rng.integers(1, 6))
+    thr = float(rng.choice([0.0, 0.0, 0.01, 0.1, 0.2]))
+    collapse = bool(rng.integers(0, 2))
+    style = int(rng.integers(0, 4))
+    if style == 0:
+        x = reference_style_rows(rng, B * T, N).reshape(B, T, N)
+    elif style == 1:  # peaky softmax
+        z = rng.normal(size=(B, T, N)).astype(np.float32) * 3.0
+        e = np.exp(z - z.max(-1, keepdims=True))
+        x = (e / e.sum(-1, keepdims=True)).astype(np.float32)
+    elif style == 2:  # coarse grid: many exactly equal probabilities (ties in the prune)
+        x = (rng.integers(0, 4, size=(B, T, N)) / 4.0).astype(np.float32)
+    else:  # powers of two incl. zeros: exact products, ties and dead candidates
+        x = np.ldexp(1.0, -rng.integers(0, 5, size=(B, T, N))).astype(np.float32)
+        x[rng.random((B, T, N)) < 0.15] = 0.0
+    lengths = None
+    if rng.integers(0, 3) == 0:
+        lengths = rng.integers(0, T + 1, size=B).astype(np.int64)
+    return x, beam, thr, collapse, lengths
+
+
+@pytest.mark.parametrize("chunk", range(8))
+def test_beam_fuzz(fcd, chunk):
+    """Randomised differential test: every kernel family that supports the drawn shape must agree
+    with the oracle bit for bit (labels, path, status), including inputs built to tie."""
+    for seed in range(1000 + chunk * 12, 1000 + (chunk + 1) * 12):
+        x, beam, thr, collapse, lengths = _fuzz_case(seed)
+        for kernel in (0, 1, 2, 3):
+            try:
+                check_beam(fcd, x, beam, thr, collapse, lengths=lengths, kernel=kernel)
+            except RuntimeError as e:
+                # an explicitly requested wave kernel refuses shapes it is not built for
+                assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
+            except AssertionError as e:
+                raise AssertionError("fuzz seed %d kernel %d beam %d thr %g collapse %s shape %s: %s"
+                                     % (seed, kernel, beam, thr, collapse, x.shape, e))
