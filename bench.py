@@ -168,6 +168,9 @@ def main():
     ap.add_argument("--data", choices=("reference", "peaky"), default="reference",
                     help="reference = the metric's generator (tests/test_decode.py:15-17 style rows); "
                          "peaky = softmax rows, a labelled secondary set")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: run each step's result gather on the compute stream instead of overlapping it "
+                         "with the next step's search on a second HIP stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather even with one rank (path check on a 1-GPU box)")
     args = ap.parse_args()
@@ -208,14 +211,24 @@ def main():
     handles = [nat.default_handle(local_rank)] + [nat.Handle(local_rank) for _ in range(n_streams - 1)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
     step_no = [0]
+    # The gather of step i (RCCL over xGMI, ~20 KB of results per read into rank 0) runs on its own
+    # HIP stream and overlaps the search of step i+1; it only reads step i's result tensors, which
+    # every call allocates afresh.  All gathers have completed before the closing synchronize.
+    comm_stream = torch.cuda.Stream(dev) if distributed and not args.no_overlap else None
 
     def step():
         s = step_no[0] % n_streams
         step_no[0] += 1
         with torch.cuda.stream(streams[s]):
             r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel, handle=handles[s])
-            if distributed:
+            if distributed and comm_stream is None:
                 # ONE gather of the packed fixed-stride results to rank 0 (RCCL over xGMI)
+                fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
+        if comm_stream is not None:
+            comm_stream.wait_stream(streams[s])
+            with torch.cuda.stream(comm_stream):
+                for tns in (r.labels, r.path, r.out_len, r.status):
+                    tns.record_stream(comm_stream)
                 fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
         return r
 
@@ -285,7 +298,8 @@ def main():
                             + ("reference-style rows numpy default_rng(1+rank)" if args.data == "reference"
                                else "SECONDARY SET: peaky softmax rows (logits 4*N(0,1)), default_rng(1+rank)"),
                 "reads_per_gpu": B, "T": T, "N": N, "beam_size": BEAM, "beam_cut_threshold": THR,
-                "parallelism": "reads sharded x%d, one RCCL gather of results per step" % world
+                "parallelism": ("reads sharded x%d, one RCCL gather of results per step%s"
+                                % (world, "" if args.no_overlap else " (on a second stream, overlapping the next step)"))
                                if world > 1 else "single GPU",
                 "kernel": {0: "auto (wave, two reads per wavefront)", 1: "generic-lds",
                            2: "wave-registers-2reads", 3: "wave-registers-1read"}[args.kernel],
