@@ -256,3 +256,38 @@ def test_crf_duplex_multichar_and_errors(fcd):
     x1[:] = np.nan
     with pytest.raises(RuntimeError, match="Failed to compare values"):
         fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT")
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_fuzz(fcd, mode):
+    """Random shapes, beams, thresholds and random VALID envelopes (monotone, overlapping rows) as
+    well as a few invalid ones: strings and error texts must equal the correctly-rounded oracle's."""
+    for seed in range(5000, 5016):
+        rng = np.random.default_rng(seed)
+        N = int(rng.integers(3, 7))
+        B = int(rng.integers(1, 4))
+        T1, T2 = int(rng.integers(2, 60)), int(rng.integers(2, 60))
+        beam = int(rng.choice([1, 2, 5, 9]))
+        thr = float(rng.choice([0.0, 0.05, 0.15]))
+        collapse = bool(rng.integers(0, 2))
+        x1, x2 = pairs(seed, B, T1, T2, N)
+        envs = None
+        kind = int(rng.integers(0, 4))
+        if kind >= 1:
+            envs = np.zeros((B, T1, 2), np.uint64)
+            for b in range(B):
+                lo = np.sort(rng.integers(0, T2, size=T1))
+                lo[0] = 0
+                w = rng.integers(1, T2 + 1, size=T1)
+                hi = np.minimum(T2, lo + w)
+                hi = np.maximum.accumulate(hi)
+                for i in range(1, T1):           # rows must overlap or touch: lo(i) <= hi(i-1)
+                    lo[i] = min(lo[i], hi[i - 1])
+                if kind == 3 and T1 > 2:         # sometimes break the envelope
+                    lo[T1 // 2] = min(T2, hi[T1 // 2 - 1] + 1)
+                    hi[T1 // 2] = min(T2, max(hi[T1 // 2], lo[T1 // 2]))
+                envs[b, :, 0], envs[b, :, 1] = lo, hi
+        alpha = "N" + "ACGTUV"[:N - 1]
+        want = oracle_strings(x1, x2, alpha, envs, beam, thr, collapse, mode | CR)
+        got = gpu_strings(fcd, x1, x2, alpha, envs, beam, thr, collapse, mode)
+        assert got == want, (seed, N, B, T1, T2, beam, thr, collapse, kind)

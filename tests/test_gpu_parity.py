@@ -399,3 +399,82 @@ def test_beam_fuzz(fcd, chunk):
             except AssertionError as e:
                 raise AssertionError("fuzz seed %d kernel %d beam %d thr %g collapse %s shape %s: %s"
                                      % (seed, kernel, beam, thr, collapse, x.shape, e))
+
+
+@pytest.mark.parametrize("chunk", range(4))
+def test_crf_fuzz(fcd, chunk):
+    """Random (S, N, beam, thr, T, init, ragged) draws of crf_beam_search on every kernel family."""
+    torch = pytest.importorskip("torch")
+    for seed in range(3000 + chunk * 10, 3000 + (chunk + 1) * 10):
+        rng = np.random.default_rng(seed)
+        wave_shape = bool(rng.integers(0, 2))
+        S, N = (4, 5) if wave_shape else (int(rng.integers(1, 7)), int(rng.integers(2, 7)))
+        beam = int(rng.choice([1, 2, 5, 8, 12]))
+        thr = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
+        B, T = int(rng.integers(1, 5)), int(rng.integers(1, 150))
+        style = int(rng.integers(0, 3))
+        if style == 0:
+            x = rng.random((B, T, S, N), dtype=np.float32)
+            x /= x.sum(-1, keepdims=True)
+        elif style == 1:
+            x = (rng.integers(0, 4, size=(B, T, S, N)) / 4.0).astype(np.float32)  # exact ties
+        else:
+            x = np.ldexp(1.0, -rng.integers(0, 6, size=(B, T, S, N))).astype(np.float32)
+            x[rng.random((B, T, S, N)) < 0.1] = 0.0
+        init = rng.random((B, S)).astype(np.float32)
+        if rng.integers(0, 2):
+            init = np.round(init * 2) / 2  # tied maxima: the first one is the start state
+        init = init.astype(np.float32)
+        lengths = rng.integers(0, T + 1, size=B).astype(np.int64) if rng.integers(0, 3) == 0 else None
+        alpha = "N" + "ACGTUV"[:N - 1]
+        for kernel in (0, 1, 2, 3):
+            try:
+                r = fcd.crf_beam_search_batch_raw(torch.from_numpy(x).cuda(), init, beam, thr,
+                                                  lengths=lengths, kernel=kernel).cpu()
+            except RuntimeError as e:
+                assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
+                continue
+            for i in range(B):
+                Ti = T if lengths is None else int(lengths[i])
+                n = int(r.out_len[i])
+                ctx = (seed, kernel, i, S, N, beam, thr, Ti)
+                if Ti == 0:
+                    assert n == 0 and int(r.status[i]) == 0, ctx
+                    continue
+                try:
+                    want = oracle.crf_beam_search(np.ascontiguousarray(x[i, :Ti]), init[i], alpha, beam, thr)
+                except RuntimeError as e:
+                    if "panic" in str(e):
+                        # an out-of-range transition state: the reference aborts the process
+                        # (src/search.rs:72 ndarray bounds check); the library reports BAD_STATE
+                        assert int(r.status[i]) == fcd.api.nat.ST_BAD_STATE, ctx
+                    else:
+                        assert fcd.api.nat.status_string(int(r.status[i])) == str(e), ctx
+                    continue
+                assert int(r.status[i]) == 0, ctx
+                seq = "".join(alpha[l] for l in r.labels[i, :n])
+                assert (seq, r.path[i, :n].tolist()) == want, ctx
+
+
+def test_viterbi_fuzz(fcd):
+    """Random shapes with quantised rows: argmax ties (first maximum wins), run means, ragged lengths."""
+    for seed in range(4000, 4030):
+        rng = np.random.default_rng(seed)
+        N = int(rng.integers(2, 10))
+        B, T = int(rng.integers(1, 6)), int(rng.integers(1, 700))
+        collapse = bool(rng.integers(0, 2))
+        if rng.integers(0, 2):
+            x = (rng.integers(0, 3, size=(B, T, N)) / 2.0).astype(np.float32)
+        else:
+            x = reference_style_rows(rng, B * T, N).reshape(B, T, N)
+        lengths = rng.integers(0, T + 1, size=B).astype(np.int64) if rng.integers(0, 2) else None
+        r = fcd.viterbi_search_batch_raw(x, collapse, lengths=lengths, qual=True)
+        for i in range(B):
+            Ti = T if lengths is None else int(lengths[i])
+            labels, path, quals = oracle.viterbi_search_raw(np.ascontiguousarray(x[i, :Ti]), collapse)
+            n = int(r.out_len[i])
+            assert n == len(labels), (seed, i)
+            np.testing.assert_array_equal(r.labels[i, :n], labels)
+            np.testing.assert_array_equal(r.path[i, :n], path)
+            got = [oracle.lib.fcdo_phred(float(q), 1.0, 0.0) for q in r.qual[i, :n]]
+            assert [ord(c) for c in got] == list(quals), (seed, i)
