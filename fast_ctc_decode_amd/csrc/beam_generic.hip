@@ -59,7 +59,17 @@ struct Lds {
     int *m_flag;   // C: 1 when slot (i,k)'s child is itself a beam entry (its own slot absorbs the extension)
     float *row;    // N (non-CRF staging of the current posterior row)
     float *top;    // 1
+    int *hist;          // kBuckets: candidates per probability bucket (prune pre-selection)
+    uint64_t *l_key;    // list_cap(BC): keys of the candidates that can still reach the beam
+    int *l_c;           // list_cap(BC): their slot index
 };
+
+// Prune pre-selection (phase B): candidates are bucketed by how far their probability lies below the
+// step's maximum, in units of 2^kBucketShift steps of the orderable f32 bit pattern (1/32 binade);
+// everything 8 binades or more below the maximum shares the last bucket.
+constexpr int kBuckets = 256;
+constexpr int kBucketShift = 18;
+__host__ __device__ inline int list_cap(int BC) { return BC + 64; }
 
 __host__ __device__ inline size_t lds_words(int BC, int N) {
     int NL = N - 1;
@@ -73,6 +83,8 @@ __host__ __device__ inline size_t lds_words(int BC, int N) {
     w += C;      // m_flag
     w += N;      // row
     w += 2;      // top + pad
+    w += kBuckets + 3;              // hist, 16-byte aligned
+    w += 3 * (size_t)list_cap(BC);  // l_key (u64) + l_c
     return w;
 }
 
@@ -95,8 +107,21 @@ __device__ inline Lds carve(int *smem, int BC, int N) {
     L.b_pslot = p; p += BC;
     L.m_flag = p; p += C;
     L.row = reinterpret_cast<float *>(p); p += N;
-    L.top = reinterpret_cast<float *>(p);
+    L.top = reinterpret_cast<float *>(p); p += 2;
+    while ((p - smem) & 3) ++p;  // smem is 16-byte aligned: hist is cleared / scanned as int4
+    L.hist = p; p += kBuckets;   // ... which leaves the u64 list 8-byte aligned
+    L.l_key = reinterpret_cast<uint64_t *>(p); p += 2 * (size_t)list_cap(BC);
+    L.l_c = p;
     return L;
+}
+
+// One workgroup == one wavefront, and a wave's LDS instructions execute in issue order: ordering LDS
+// traffic between phases only needs the COMPILER to keep it in order.  __syncthreads() would also
+// drain vmcnt -- every outstanding tree store and posterior load -- several times per timestep.
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 __device__ __forceinline__ void fail(const GenericParams &p, int64_t r, int code) {
@@ -161,7 +186,11 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
     for (int j = lane; j < NL; j += kWave) L.b_child(0)[j] = -1;
     if (!crf && T > 0)
         for (int j = lane; j < N; j += kWave) L.row[j] = post[j * st_n];
-    __syncthreads();
+    // row t+1 travels in a register while step t runs, so its HBM latency is never waited for
+    // (alphabets above 64 labels fall back to loading it when it is needed)
+    const bool row_in_reg = !crf && N <= kWave;
+    float next_row = (row_in_reg && lane < N && T > 1) ? post[st_t + lane * st_n] : 0.0f;
+    wave_sync();
 
     int nn = 0;  // nodes in this read's tree (wave-uniform)
 
@@ -178,7 +207,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         // ---- phase P: where is each entry's parent in the beam?  O(B^2/64) once per step instead
         // of a beam search per slot: entry e with parent slot j marks slot (j, tip_e + 1) as merged
         for (int c = lane; c < nslots; c += kWave) L.m_flag[c] = 0;
-        __syncthreads();
+        wave_sync();
         for (int e = lane; e < B; e += kWave) {
             int ps = -1;
             if (b_node[e] >= 0) {
@@ -192,7 +221,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             }
             L.b_pslot[e] = ps;
         }
-        __syncthreads();
+        wave_sync();
 
         // ---- phase A: evaluate every (entry, k) slot; number the new nodes ----
         for (int base = 0; base < nslots; base += kWave) {
@@ -290,11 +319,104 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         // search.rs:261-277: any NaN among >= 2 candidates -> IncomparableValues, then empty -> RanOutOfBeam
         if (n_valid >= 2 && any_nan) return fail(p, r, FCD_ST_INCOMPARABLE);
         if (n_valid == 0) return fail(p, r, FCD_ST_RAN_OUT_OF_BEAM);
-        __syncthreads();
+        wave_sync();
 
-        // ---- phase B: exact rank of every slot; the top beam_size build the next beam ----
+        // ---- phase B: the top beam_size candidates, in exact key order, build the next beam ----
+        // Ranking all C = B*N candidates against each other costs O(C^2/64) per step.  Instead a
+        // histogram over "distance below the maximum probability" finds the bucket holding the
+        // beam_size-th largest candidate; only the candidates in that bucket or above (Lc of them,
+        // usually beam_size + 1 or 2) are compacted into a list and ranked exactly on the 64-bit key.
+        // Equal probabilities share a bucket, so ties still resolve by node index.  If the list would
+        // not fit (heavily tied or extremely spread probabilities) the step falls back to all-pairs.
         const int nxt = cur ^ 1;
         const int Bn = n_valid < BC ? n_valid : BC;
+        const int cap = list_cap(BC);
+        int bstar = kBuckets - 1;  // accept every valid candidate (n_valid <= BC)
+        int Lc = n_valid;
+        uint32_t mx = 0;
+        if (n_valid > BC) {
+            for (int c = lane; c < nslots; c += kWave) {
+                const uint32_t hi = (uint32_t)(L.c_key[c] >> 32);
+                mx = hi > mx ? hi : mx;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)mx, o);
+                mx = other > mx ? other : mx;
+            }
+            *reinterpret_cast<int4 *>(L.hist + 4 * lane) = make_int4(0, 0, 0, 0);
+            wave_sync();
+            for (int c = lane; c < nslots; c += kWave) {
+                const uint64_t key = L.c_key[c];
+                if (key != 0ull) {
+                    const uint32_t d = (mx - (uint32_t)(key >> 32)) >> kBucketShift;
+                    atomicAdd(&L.hist[d < (uint32_t)(kBuckets - 1) ? d : (uint32_t)(kBuckets - 1)], 1);
+                }
+            }
+            wave_sync();
+            const int4 h = *reinterpret_cast<const int4 *>(L.hist + 4 * lane);
+            const int s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
+            int incl = s3;
+#pragma unroll
+            for (int o = 1; o < kWave; o <<= 1) {
+                const int v = __shfl_up(incl, o);
+                if (lane >= o) incl += v;
+            }
+            const int excl = incl - s3;
+            // exactly one lane owns the bucket where the running count reaches BC (the total is n_valid > BC)
+            const bool cross = excl < BC && incl >= BC;
+            const int kk = (excl + s0 >= BC) ? 0 : (excl + s1 >= BC) ? 1 : (excl + s2 >= BC) ? 2 : 3;
+            const int cum = excl + (kk == 0 ? s0 : kk == 1 ? s1 : kk == 2 ? s2 : s3);
+            const int owner = __builtin_ctzll(__ballot(cross));
+            bstar = __shfl(4 * lane + kk, owner);
+            Lc = __shfl(cum, owner);
+        }
+        if (Lc <= cap) {
+            // compaction in slot order, then exact rank inside the list
+            int base = 0;
+            for (int base0 = 0; base0 < nslots; base0 += kWave) {
+                const int c = base0 + lane;
+                const uint64_t key = c < nslots ? L.c_key[c] : 0ull;
+                bool in = key != 0ull;
+                if (in && n_valid > BC) {
+                    const uint32_t d = (mx - (uint32_t)(key >> 32)) >> kBucketShift;
+                    in = (int)(d < (uint32_t)(kBuckets - 1) ? d : (uint32_t)(kBuckets - 1)) <= bstar;
+                }
+                const uint64_t m_in = __ballot(in);
+                if (in) {
+                    const int pos = base + popc64(m_in & lanemask_lt());
+                    L.l_key[pos] = key;
+                    L.l_c[pos] = c;
+                }
+                base += popc64(m_in);
+            }
+            wave_sync();
+            for (int e = lane; e < Lc; e += kWave) {
+                const uint64_t key = L.l_key[e];
+                int rank = 0;
+                for (int j = 0; j < Lc; ++j) rank += (L.l_key[j] > key) ? 1 : 0;
+                if (rank < BC) {
+                    const int c = L.l_c[e];
+                    const int i = c / N, k = c - i * N;
+                    L.b_node(nxt)[rank] = L.c_id[c];
+                    L.b_lp(nxt)[rank] = L.c_lp[c];
+                    L.b_gp(nxt)[rank] = L.c_gp[c];
+                    if (k == 0) {
+                        L.b_tip(nxt)[rank] = b_tip[i];
+                        L.b_par(nxt)[rank] = b_par[i];
+                        L.b_state(nxt)[rank] = b_state[i];
+                        L.b_depth(nxt)[rank] = b_depth[i];
+                    } else {
+                        L.b_tip(nxt)[rank] = k - 1;
+                        L.b_par(nxt)[rank] = b_node[i];
+                        L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
+                        L.b_depth(nxt)[rank] = b_depth[i] + 1;
+                    }
+                    L.nb_src[rank] = c | (L.c_new[c] << 30);
+                    if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
+                }
+            }
+        } else {
         // every lane owns slots lane, lane+64, ...: rank up to four of them in one sweep over the keys
         for (int base0 = 0; base0 < nslots; base0 += 4 * kWave) {
             uint64_t myk[4];
@@ -336,7 +458,8 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             }
           }
         }
-        __syncthreads();
+        }
+        wave_sync();
 
         // ---- phase C: child rows of the new beam + renormalise by the top entry (:278-282) ----
         for (int item = lane; item < Bn * NL; item += kWave) {
@@ -358,11 +481,15 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             L.b_lp(nxt)[s] = L.b_lp(nxt)[s] / top;
             L.b_gp(nxt)[s] = L.b_gp(nxt)[s] / top;
         }
-        if (!crf && t + 1 < T)
+        if (row_in_reg) {
+            if (lane < N) L.row[lane] = next_row;
+            next_row = (lane < N && t + 2 < T) ? post[(t + 2) * st_t + lane * st_n] : 0.0f;
+        } else if (!crf && t + 1 < T) {
             for (int j = lane; j < N; j += kWave) L.row[j] = post[(t + 1) * st_t + j * st_n];
+        }
         B = Bn;
         cur = nxt;
-        __syncthreads();
+        wave_sync();
     }
 
     // ---- walk the best labelling leaf -> root (:285-300), writing it in sequence order ----
