@@ -230,7 +230,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const float sgp = blank ? gpn : 0.0f;
         const bool svalid = grp && is_self && (blank || stay || has_inc);
 
-        const bool valid = is_self ? svalid : (cvalid && !merged);
+        const bool valid = svalid || (cvalid && !merged);  // svalid / cvalid already carry is_self / is_child
         const float clp = is_self ? slp : contrib;
         const float cgp = is_self ? sgp : 0.0f;
         const float prob = clp + cgp;
@@ -261,30 +261,30 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
         // ---- search.rs:261-277 ----
         const uint64_t m_valid = ballot(valid);
-        const uint64_t m_nan = ballot(valid && prob != prob);
-        int n_valid;
-        bool any_nan;
-        if (RPW == 1) {
-            n_valid = popc64(m_valid);
-            any_nan = m_nan != 0ull;
-        } else {
-            n_valid = __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
-            any_nan = (hbase ? (uint32_t)(m_nan >> 32) : (uint32_t)m_nan) != 0u;
-        }
-        const bool f_nan = act && n_valid >= 2 && any_nan;
-        const bool f_empty = act && n_valid == 0;
-        if (f_nan || f_empty || f_cap) {
-            if (q == 0) {
-                p.out.status[r] = f_cap ? FCD_ST_INTERNAL
-                                        : (f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
-                p.out.out_len[r] = 0;
+        const int n_valid = RPW == 1 ? popc64(m_valid)
+                                     : __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
+        // Everything that ends a read is rare: one wave-wide test, the bookkeeping behind it.
+        const bool is_nan = valid && prob != prob;
+        if (ballot(act && (n_valid == 0 || f_cap || is_nan)) != 0ull) {
+            const uint64_t m_nan = ballot(is_nan);
+            const bool any_nan = RPW == 1 ? m_nan != 0ull
+                                          : (hbase ? (uint32_t)(m_nan >> 32) : (uint32_t)m_nan) != 0u;
+            const bool f_nan = act && n_valid >= 2 && any_nan;  // a lone NaN is never compared (:262)
+            const bool f_empty = act && n_valid == 0;
+            if (f_nan || f_empty || f_cap) {
+                if (q == 0) {
+                    p.out.status[r] = f_cap ? FCD_ST_INTERNAL
+                                            : (f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
+                    p.out.out_len[r] = 0;
+                }
+                alive = false;
             }
-            alive = false;
         }
         const bool go = act && alive;  // this half completes the step
 
         // ---- prune: exact rank on (probability desc, node asc) ----
-        const uint64_t key = (valid && go) ? (prob == prob ? make_key(prob, id) : 1ull) : 0ull;
+        // (a NaN that gets this far is the lone candidate of its read: any non-zero key ranks it first)
+        const uint64_t key = (valid && go) ? make_key(prob, id) : 0ull;
         keys[lane] = key;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -305,20 +305,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int selrank = sel ? rank : -1;
         const int fate = bperm(hbase + mslot * GW, selrank);
         const bool first_entry = sel && is_child && !(child & kEver);  // child >= 0 here
-        if (go && is_child) {
-            if (inbeam) {
-                child = (child & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
-            } else if (sel) {
-                // a child entering the beam: mark it EVER (here and in its parent's HBM row) and,
-                // on its first entry, give it an empty row of its own
-                if (first_entry) {
-                    if (node >= 0) rows[(int64_t)node * RW + l] = id | kEver;
-                    int32_t *row = rows + (int64_t)id * RW;
-                    *reinterpret_cast<int4 *>(row) = make_int4(-1, -1, -1, -1);
-                    if (RW == 8) *reinterpret_cast<int4 *>(row + 4) = make_int4(-1, -1, -1, -1);
-                }
-                child = id | kEver | kInBeam | (rank << kSlotShift);
+        {
+            // a child entry whose node is a beam entry follows it to its new slot (or learns it left);
+            // a child entering the beam is marked EVER (here and in its parent's HBM row) and, on its
+            // first entry, gets an empty row of its own
+            const int followed = (child & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
+            const int entered = id | kEver | kInBeam | (rank << kSlotShift);
+            const bool upd = go && is_child;
+            if (first_entry) {
+                if (node >= 0) rows[(int64_t)node * RW + l] = id | kEver;
+                int32_t *row = rows + (int64_t)id * RW;
+                *reinterpret_cast<int4 *>(row) = make_int4(-1, -1, -1, -1);
+                if (RW == 8) *reinterpret_cast<int4 *>(row + 4) = make_int4(-1, -1, -1, -1);
             }
+            child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child);
         }
 
         // ---- gather the survivors into rank order ----
