@@ -1,0 +1,64 @@
+"""Long randomised differential run (GPU vs oracle), beyond what the test suite samples:
+    python tools/soak.py [n_seeds] [first_seed] [beam|crf|viterbi|duplex]
+Reuses the fuzz generators of tests/test_gpu_parity.py; prints one line per failing seed."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np
+
+import fast_ctc_decode_amd as fcd
+import test_gpu_parity as tp
+
+
+def other(which, n, first):
+    import test_gpu_duplex as td
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + n):
+        try:
+            if which == "crf":
+                tp.crf_fuzz_seed(fcd, seed)
+            elif which == "viterbi":
+                tp.viterbi_fuzz_seed(fcd, seed)
+            else:
+                td.duplex_fuzz_seed(fcd, seed, td.LSE)
+                td.duplex_fuzz_seed(fcd, seed, td.MAX)
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH %s seed %d: %s" % (which, seed, str(e)[:300]), flush=True)
+    print("soak %s: %d seeds, %d failures, %.1f s" % (which, n, bad, time.time() - t0), flush=True)
+    return 1 if bad else 0
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 500
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 100000
+    which = sys.argv[3] if len(sys.argv) > 3 else "beam"
+    if which != "beam":
+        return other(which, n, first)
+    bad = 0
+    t0 = time.time()
+    for seed in range(first, first + n):
+        x, beam, thr, collapse, lengths = tp._fuzz_case(seed)
+        for kernel in (0, 1, 2, 3):
+            try:
+                tp.check_beam(fcd, x, beam, thr, collapse, lengths=lengths, kernel=kernel)
+            except RuntimeError as e:
+                if not (kernel in (2, 3) and "wave kernel" in str(e)):
+                    bad += 1
+                    print("seed %d kernel %d: %s" % (seed, kernel, e), flush=True)
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH seed %d kernel %d beam %d thr %g collapse %s shape %s: %s"
+                      % (seed, kernel, beam, thr, collapse, x.shape, str(e)[:200]), flush=True)
+    print("soak: %d seeds x 4 kernels, %d failures, %.1f s" % (n, bad, time.time() - t0), flush=True)
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
