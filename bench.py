@@ -269,7 +269,8 @@ def main():
         mean_L = float(rc.out_len.astype(np.float64).mean())
         bytes_per_read = T * N * 4 + 5.0 * mean_L  # posteriors in, u8 label + u32 time out
         achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
-        cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds)
+        # the CPU leg (and its output cross-check) runs on rank 0 at N = 1 only, as the contract asks
+        cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds) if world == 1 else None
         traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2, 0>" if args.kernel in (0, 2)
                                             else "beam_wave_kernel<5, 8, 1, 0>" if args.kernel == 3
                                             else "beam_generic_kernel")
