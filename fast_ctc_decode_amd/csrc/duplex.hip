@@ -28,6 +28,7 @@
 // default `fastexp` feature, where exp() is identically 0 and the addition degenerates to max().
 #include "device_utils.h"
 #include "fcd_internal.h"
+#include "logadd_fast.h"
 
 namespace fcd {
 
@@ -79,8 +80,23 @@ __device__ __forceinline__ float ladd(float a, float b) {
     }
     if (small == kNegInf) return big;
     if (MODE == FCD_LOGADD_MAX) return big + 0.0f;
-    const float e = (float)exp((double)(small - big));
-    return big + (float)log1p((double)e);
+    // big + ln_1p(exp(small - big)), exp and ln_1p each correctly rounded to f32.  Fast binary64
+    // evaluations (logadd_fast.h, verified exhaustively on the host) with Ziv's rounding test; the
+    // general-purpose library routines only run for the ~1e-6 of arguments that test rejects and
+    // for exponentials with subnormal results.
+    const float x = small - big;                      // <= 0, or NaN
+    if (x < kExpZeroBelow) return big + 0.0f;         // exp -> +0, ln_1p(+0) = +0
+    // x < -86: e = exp(x) <= 4.5e-38 and ln_1p(e) = e; adding it to a `big` of magnitude >= 2^-90
+    // (half a unit in the last place >= 2^-115) cannot change `big`
+    if (x < kExpFastMin && __builtin_fabsf(big) >= 8.0779356694631609e-28f) return big;
+    const double ye = exp_fast((double)x);
+    float e = (float)ye;
+    if (!(x >= kExpFastMin) || round_to_f32_unsafe(ye)) e = (float)exp((double)x);
+    if (e < kLog1pIdentityBelow) return big + e;      // ln_1p(e) rounds to e below 2^-24
+    const double yl = log1p_fast((double)e);
+    float l = (float)yl;
+    if (round_to_f32_unsafe(yl)) l = (float)log1p((double)e);
+    return big + l;
 }
 
 __device__ __forceinline__ float lmax(float self, float other) { return self < other ? other : self; }
@@ -170,7 +186,7 @@ __device__ __forceinline__ void vec_get(const VecRef &v, int at, int Wcap, float
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void duplex_kernel(DuplexParams p) {
+__global__ __launch_bounds__(64, 3) void duplex_kernel(DuplexParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x;
     const int64_t local = blockIdx.x;

@@ -539,6 +539,10 @@ float fcdo_logspace_add(float a, float b, int mode) {
     if ((mode & 3) == FCDO_LOGADD_MAX) return big + 0.0f; /* big + ln_1p(+-0.0) */
     return big + log1p_m(exp_m(small - big, mode), mode);
 }
+void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int mode) {
+    for (int64_t i = 0; i < n; ++i) out[i] = fcdo_logspace_add(a[i], b[i], mode);
+}
+
 #define LADD(a, b) fcdo_logspace_add((a), (b), mode)
 static inline float lmax(float self, float other) { return (self < other) ? other : self; } /* :33-39 */
 

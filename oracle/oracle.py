@@ -70,6 +70,8 @@ def _load():
     lib.fcdo_secondary_update_max.restype = f32
     lib.fcdo_logspace_add.argtypes = [f32, f32, i32]
     lib.fcdo_logspace_add.restype = f32
+    lib.fcdo_logspace_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i32]
+    lib.fcdo_logspace_add_batch.restype = None
     return lib
 
 
