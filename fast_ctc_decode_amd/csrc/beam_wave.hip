@@ -29,7 +29,7 @@
 //     probability (:278-282, IEEE f32 division).
 //
 // Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = child entries
-// (id | EVER, or -1); jmp[node] (written only for nodes whose depth is a multiple of 64) = the
+// (id | EVER, or -1), written when the node leaves the beam; jmp[node] (written only for nodes whose depth is a multiple of 64) = the
 // nearest proper ancestor whose depth is a multiple of 64.  Every beam entry carries its own jump
 // pointer in a register, so the final leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling
 // into 64-node segments and then walks all segments in parallel, one lane each, instead of chasing
@@ -254,7 +254,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             rec[newid] = make_int2(node, (t << 3) | l);
             // a segment head (depth % 64 == 0) records where the next head up the tree is
             if ((depth + 1) % kSeg == 0) jmp[newid] = (depth % kSeg == 0) ? node : jump;
-            if (node >= 0) rows[(int64_t)node * RW + l] = newid;
             child = newid;
         }
         const int id = is_self ? node : (is_new ? newid : cid);
@@ -304,21 +303,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
         const int selrank = sel ? rank : -1;
         const int fate = bperm(hbase + mslot * GW, selrank);
+        const int own = bperm(grp0, selrank);  // ... and this group's own candidate?
         const bool first_entry = sel && is_child && !(child & kEver);  // child >= 0 here
         {
             // a child entry whose node is a beam entry follows it to its new slot (or learns it left);
-            // a child entering the beam is marked EVER (here and in its parent's HBM row) and, on its
-            // first entry, gets an empty row of its own
+            // a child entering the beam is marked EVER: from now on it may own children
             const int followed = (child & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
             const int entered = id | kEver | kInBeam | (rank << kSlotShift);
             const bool upd = go && is_child;
-            if (first_entry) {
-                if (node >= 0) rows[(int64_t)node * RW + l] = id | kEver;
-                int32_t *row = rows + (int64_t)id * RW;
-                *reinterpret_cast<int4 *>(row) = make_int4(-1, -1, -1, -1);
-                if (RW == 8) *reinterpret_cast<int4 *>(row + 4) = make_int4(-1, -1, -1, -1);
-            }
             child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child);
+            // A node's child row only has to exist in HBM while the node is OUT of the beam (it is
+            // read back if the node re-enters, below): write it once, when the node is evicted --
+            // four lanes, 16 contiguous bytes -- instead of a scattered 4-byte store per created node.
+            if (upd && grp && own < 0 && node >= 0)
+                rows[(int64_t)node * RW + l] = child < 0 ? -1 : (child & kStored);
         }
 
         // ---- gather the survivors into rank order ----
