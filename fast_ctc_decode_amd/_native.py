@@ -29,6 +29,7 @@ SYMBOLS = [
     "fcd_crf_greedy_search_dev", "fcd_crf_greedy_search_host",
     "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
     "fcd_crf_beam_search_duplex_dev", "fcd_crf_beam_search_duplex_host",
+    "fcd_duplex_envelope_dev", "fcd_duplex_envelope_host",
     "fcd_logspace_probe_dev", "fcd_phred",
 ]
 
@@ -108,6 +109,9 @@ def load():
             getattr(lib, "fcd_crf_beam_search_duplex_" + sfx).argtypes = [
                 P, BP, P, i64, i64, BP, P, i64, i64, P, i64, i64, f32, i32, RP]
         lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
+        for sfx in ("dev", "host"):
+            getattr(lib, "fcd_duplex_envelope_" + sfx).argtypes = [
+                P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]
         lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
         lib.fcd_phred.argtypes = [f32, f32, f32]
         lib.fcd_phred.restype = C.c_uint32

@@ -243,11 +243,16 @@ def _check_envelope(envelope, T1):
         raise ValueError("the inner axis of envelope must have size 2")
 
 
-def _default_envelope(B, T1, T2):
-    """src/lib.rs:459-468: every row searches the whole of read 2."""
+def _default_envelope(B, T1, T2, lengths_2=None):
+    """src/lib.rs:459-468: every row searches the whole of read 2 -- of THAT pair's read 2 when the
+    batch is ragged (an upper bound past the pair's own T2 is an out-of-range slice in the reference)."""
     env = np.empty((B, max(T1, 1), 2), np.uint64)
     env[:, :, 0] = 0
-    env[:, :, 1] = T2
+    if lengths_2 is None:
+        env[:, :, 1] = T2
+    else:
+        l2 = np.asarray(lengths_2.cpu() if hasattr(lengths_2, "cpu") else lengths_2, np.int64)
+        env[:, :, 1] = np.clip(l2, 0, T2).astype(np.uint64)[:, None]
     return env
 
 
@@ -265,7 +270,7 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
         T2 = x2.shape[1]
         dev = x1.device
         if envelopes is None:
-            env = torch.from_numpy(_default_envelope(B, T1, T2).view(np.int64)).to(dev)
+            env = torch.from_numpy(_default_envelope(B, T1, T2, lengths_2).view(np.int64)).to(dev)
         elif isinstance(envelopes, np.ndarray):
             env = torch.from_numpy(np.ascontiguousarray(envelopes, np.uint64).view(np.int64)).to(dev)
         else:
@@ -302,7 +307,7 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
     T2 = x2.shape[1]
     if x2.shape[0] != B:
         raise ValueError("both batches must hold the same number of reads")
-    env = _default_envelope(B, T1, T2) if envelopes is None else np.ascontiguousarray(envelopes, np.uint64)
+    env = _default_envelope(B, T1, T2, lengths_2) if envelopes is None else np.ascontiguousarray(envelopes, np.uint64)
     if env.shape[0] != B or env.ndim != 3 or env.shape[2] != 2 or env.shape[1] < T1:
         raise ValueError("envelopes must have shape (n_pairs, T1, 2)")
     h = nat.default_handle()
@@ -352,6 +357,73 @@ def beam_search_duplex_batch(network_outputs_1, network_outputs_2, alphabet, env
     return [s for s, _ in r.sequences(alpha)]
 
 
+def estimate_envelope_batch(network_outputs_1, network_outputs_2, band=64, lengths_1=None, lengths_2=None):
+    """Alignment-band estimator for the duplex searches: (B,T1,N) and (B,T2,N) posteriors ->
+    (B,T1,2) envelopes usable as `envelopes=` of beam_search_duplex_batch*.
+
+    NOT a reference function (the reference defaults to the full matrix and only anticipates a
+    better default, /root/reference/src/lib.rs:376-378): both reads are decoded greedily
+    (viterbi_search), the label sequences are aligned globally on the GPU, matched labels anchor
+    read-1 time to read-2 time, and row i becomes [centre(i) - band, centre(i) + band + 1) with the
+    rows forced to start at 0, end at T2 and touch (specification: tests/envelope_model.py).
+    Device tensors in -> int64 torch tensor holding the u64 bit patterns; numpy in -> uint64 array."""
+    if _is_torch_cuda(network_outputs_1):
+        import torch
+        x1, x2 = network_outputs_1, network_outputs_2
+        B, T1 = int(x1.shape[0]), int(x1.shape[1])
+        T2 = int(x2.shape[1])
+        dev = x1.device
+        r1 = viterbi_search_batch_raw(x1, True, lengths_1)
+        r2 = viterbi_search_batch_raw(x2, True, lengths_2)
+        env = torch.zeros((B, max(T1, 1), 2), dtype=torch.int64, device=dev)
+        keep = [r1, r2]
+        l1 = l2 = None
+        if lengths_1 is not None:
+            l1 = torch.as_tensor(lengths_1, dtype=torch.int64, device=dev).contiguous()
+        if lengths_2 is not None:
+            l2 = torch.as_tensor(lengths_2, dtype=torch.int64, device=dev).contiguous()
+        h = r1._handle
+        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        h.check(h.lib.fcd_duplex_envelope_dev(
+            h.ptr, B, r1.labels.data_ptr(), r1.path.data_ptr(), r1.out_len.data_ptr(), int(r1.labels.shape[1]),
+            None if l1 is None else l1.data_ptr(), T1,
+            r2.labels.data_ptr(), r2.path.data_ptr(), r2.out_len.data_ptr(), int(r2.labels.shape[1]),
+            None if l2 is None else l2.data_ptr(), T2, int(band), env.data_ptr(), int(env.shape[1])))
+        env._keep = (keep, l1, l2)
+        return env
+    x1 = _stack_host(network_outputs_1, 3)
+    x2 = _stack_host(network_outputs_2, 3)
+    B, T1, _ = x1.shape
+    T2 = x2.shape[1]
+    if x2.shape[0] != B:
+        raise ValueError("both batches must hold the same number of reads")
+    r1 = viterbi_search_batch_raw(x1, True, lengths_1)
+    r2 = viterbi_search_batch_raw(x2, True, lengths_2)
+    env = np.zeros((B, max(T1, 1), 2), np.uint64)
+    l1, l2 = _np_lengths(lengths_1, B), _np_lengths(lengths_2, B)
+    h = nat.default_handle()
+    lab1, lab2 = np.ascontiguousarray(r1.labels), np.ascontiguousarray(r2.labels)
+    p1, p2 = np.ascontiguousarray(r1.path).view(np.uint32), np.ascontiguousarray(r2.path).view(np.uint32)
+    n1, n2 = np.ascontiguousarray(r1.out_len).view(np.uint32), np.ascontiguousarray(r2.out_len).view(np.uint32)
+    h.check(h.lib.fcd_duplex_envelope_host(
+        h.ptr, B, lab1.ctypes.data, p1.ctypes.data, n1.ctypes.data, int(lab1.shape[1]),
+        None if l1 is None else l1.ctypes.data, T1,
+        lab2.ctypes.data, p2.ctypes.data, n2.ctypes.data, int(lab2.shape[1]),
+        None if l2 is None else l2.ctypes.data, T2, int(band), env.ctypes.data, int(env.shape[1])))
+    return env[:, :T1]
+
+
+def estimate_envelope(network_output_1, network_output_2, band=64):
+    """Single pair: (T1,N), (T2,N) posteriors -> (T1,2) uint64 envelope for beam_search_duplex(envelope=...)."""
+    x1 = np.asarray(network_output_1)
+    x2 = np.asarray(network_output_2)
+    if x1.ndim != 2 or x2.ndim != 2:
+        raise ValueError("expected two (T, N) matrices")
+    if x1.shape[0] == 0:
+        return np.zeros((0, 2), np.uint64)
+    return estimate_envelope_batch(_dense(x1)[None], _dense(x2)[None], band)[0]
+
+
 def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_outputs_2,
                                      init_states_2, envelopes=None, beam_size=5,
                                      beam_cut_threshold=0.0, lengths_1=None, lengths_2=None,
@@ -367,7 +439,7 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
     T2 = x2.shape[1]
     if x2.shape[0] != B or i1.shape[0] != B or i2.shape[0] != B or i1.ndim != 2 or i2.ndim != 2:
         raise ValueError("all inputs must hold the same number of pairs")
-    env = _default_envelope(B, T1, T2) if envelopes is None else np.ascontiguousarray(envelopes, np.uint64)
+    env = _default_envelope(B, T1, T2, lengths_2) if envelopes is None else np.ascontiguousarray(envelopes, np.uint64)
     if env.shape[0] != B or env.ndim != 3 or env.shape[2] != 2 or env.shape[1] < T1:
         raise ValueError("envelopes must have shape (n_pairs, T1, 2)")
     h = nat.default_handle()

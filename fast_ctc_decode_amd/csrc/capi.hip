@@ -634,6 +634,101 @@ int fcd_crf_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const f
                        logadd_mode, out);
 }
 
+// ---- alignment-band estimator (envelope.hip) ----
+int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
+                            const uint8_t *labels1, const uint32_t *path1, const uint32_t *len1,
+                            int64_t stride1, const int64_t *T1, int64_t T1cap,
+                            const uint8_t *labels2, const uint32_t *path2, const uint32_t *len2,
+                            int64_t stride2, const int64_t *T2, int64_t T2cap,
+                            int64_t band, uint64_t *envelope, int64_t env_stride) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n_pairs < 0 || T1cap < 0 || T2cap < 0 || band < 0) return fail(h, FCD_E_INVALID, "negative size");
+    if (n_pairs == 0 || T1cap == 0) return FCD_OK;
+    if (!labels1 || !path1 || !len1 || !labels2 || !path2 || !len2 || !envelope)
+        return fail(h, FCD_E_INVALID, "null array");
+    if (stride1 < T1cap || stride2 < T2cap) return fail(h, FCD_E_INVALID, "label strides shorter than the reads");
+    if (env_stride < T1cap) return fail(h, FCD_E_INVALID, "envelope shorter than read 1");
+    if (T1cap + T2cap > 65535) return fail(h, FCD_E_UNSUPPORTED, "envelope estimator: T1 + T2 above 65535");
+    if (envelope_lds_bytes(T2cap) > 64 * 1024)
+        return fail(h, FCD_E_UNSUPPORTED, "envelope estimator: read 2 too long for the LDS-resident rows");
+    band = std::min<int64_t>(band, 1 << 20);
+    FCD_HIP(h, hipSetDevice(h->device));
+    const int nchunk = (int)((T2cap + 63) / 64);
+    const int64_t dirs_stride = std::max<int64_t>(T1cap * std::max(nchunk, 1) * 2, 2);
+    const size_t anchor_bytes = ((size_t)(T1cap + 1) * 4 + 15) & ~(size_t)15;
+    const size_t per_pair = (size_t)dirs_stride * 8 + anchor_bytes;
+    int64_t chunk = std::max<int64_t>(1, workspace_budget(h) / (int64_t)per_pair);
+    chunk = std::min<int64_t>(chunk, n_pairs);
+    int rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
+    if (rc) return rc;
+    EnvelopeArgs a;
+    a.labels1 = labels1; a.labels2 = labels2; a.path1 = path1; a.path2 = path2;
+    a.len1 = len1; a.len2 = len2; a.stride1 = stride1; a.stride2 = stride2;
+    a.T1 = T1; a.T2 = T2; a.T1cap = T1cap; a.T2cap = T2cap; a.band = band;
+    a.env = envelope; a.env_stride = env_stride;
+    a.dirs = reinterpret_cast<uint64_t *>(h->arena);
+    a.dirs_stride = dirs_stride;
+    a.nchunk = std::max(nchunk, 1);
+    a.anchor = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) + (size_t)chunk * dirs_stride * 8);
+    // anchor slabs are (T1cap + 1) ints apart inside their region
+    Timer tm(h);
+    for (int64_t b0 = 0; b0 < n_pairs; b0 += chunk)
+        FCD_HIP(h, launch_envelope(a, b0, std::min<int64_t>(chunk, n_pairs - b0), h->stream));
+    tm.stop();
+    return FCD_OK;
+}
+
+int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
+                             const uint8_t *labels1, const uint32_t *path1, const uint32_t *len1,
+                             int64_t stride1, const int64_t *T1, int64_t T1cap,
+                             const uint8_t *labels2, const uint32_t *path2, const uint32_t *len2,
+                             int64_t stride2, const int64_t *T2, int64_t T2cap,
+                             int64_t band, uint64_t *envelope, int64_t env_stride) {
+    if (!h) return FCD_E_INVALID;
+    if (n_pairs < 0 || T1cap < 0 || T2cap < 0) return fail(h, FCD_E_INVALID, "negative size");
+    if (n_pairs == 0 || T1cap == 0) return FCD_OK;
+    if (!labels1 || !path1 || !len1 || !labels2 || !path2 || !len2 || !envelope)
+        return fail(h, FCD_E_INVALID, "null array");
+    if (stride1 < T1cap || stride2 < T2cap || env_stride < T1cap) return fail(h, FCD_E_INVALID, "strides shorter than the reads");
+    FCD_HIP(h, hipSetDevice(h->device));
+    // one device slab: labels, paths, lengths, row counts of both reads, then the envelope
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    const size_t o_l1 = 0, o_l2 = o_l1 + al((size_t)n_pairs * stride1);
+    const size_t o_p1 = o_l2 + al((size_t)n_pairs * stride2), o_p2 = o_p1 + al((size_t)n_pairs * stride1 * 4);
+    const size_t o_n1 = o_p2 + al((size_t)n_pairs * stride2 * 4), o_n2 = o_n1 + al((size_t)n_pairs * 4);
+    const size_t o_t1 = o_n2 + al((size_t)n_pairs * 4), o_t2 = o_t1 + al((size_t)n_pairs * 8);
+    const size_t o_env = o_t2 + al((size_t)n_pairs * 8);
+    const size_t total = o_env + (size_t)n_pairs * env_stride * 16;
+    char *d = nullptr;
+    {
+        std::lock_guard<std::mutex> g(h->mu);
+        int rc = ensure(h, &h->stage, &h->stage_bytes, total);
+        if (rc) return rc;
+        d = reinterpret_cast<char *>(h->stage);
+        FCD_HIP(h, hipMemcpyAsync(d + o_l1, labels1, (size_t)n_pairs * stride1, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(d + o_l2, labels2, (size_t)n_pairs * stride2, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(d + o_p1, path1, (size_t)n_pairs * stride1 * 4, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(d + o_p2, path2, (size_t)n_pairs * stride2 * 4, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(d + o_n1, len1, (size_t)n_pairs * 4, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(d + o_n2, len2, (size_t)n_pairs * 4, hipMemcpyHostToDevice, h->stream));
+        if (T1) FCD_HIP(h, hipMemcpyAsync(d + o_t1, T1, (size_t)n_pairs * 8, hipMemcpyHostToDevice, h->stream));
+        if (T2) FCD_HIP(h, hipMemcpyAsync(d + o_t2, T2, (size_t)n_pairs * 8, hipMemcpyHostToDevice, h->stream));
+        FCD_HIP(h, hipMemsetAsync(d + o_env, 0, (size_t)n_pairs * env_stride * 16, h->stream));
+    }
+    int rc = fcd_duplex_envelope_dev(
+        h, n_pairs, reinterpret_cast<uint8_t *>(d + o_l1), reinterpret_cast<uint32_t *>(d + o_p1),
+        reinterpret_cast<uint32_t *>(d + o_n1), stride1, T1 ? reinterpret_cast<int64_t *>(d + o_t1) : nullptr, T1cap,
+        reinterpret_cast<uint8_t *>(d + o_l2), reinterpret_cast<uint32_t *>(d + o_p2),
+        reinterpret_cast<uint32_t *>(d + o_n2), stride2, T2 ? reinterpret_cast<int64_t *>(d + o_t2) : nullptr, T2cap,
+        band, reinterpret_cast<uint64_t *>(d + o_env), env_stride);
+    if (rc) return rc;
+    std::lock_guard<std::mutex> g(h->mu);
+    FCD_HIP(h, hipMemcpyAsync(envelope, d + o_env, (size_t)n_pairs * env_stride * 16, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    return FCD_OK;
+}
+
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
                            float *out_ln, int64_t n, int logadd_mode) {
     if (!h) return FCD_E_INVALID;

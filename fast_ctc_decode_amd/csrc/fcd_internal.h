@@ -116,6 +116,25 @@ hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_st
                             hipStream_t stream);
 hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs,
                          hipStream_t stream);
+// alignment-band estimator (envelope.hip); all pointers are device memory
+struct EnvelopeArgs {
+    const uint8_t *labels1, *labels2;  // [pair][stride] label indices of the two reads
+    const uint32_t *path1, *path2;     // [pair][stride] emission times of those labels
+    const uint32_t *len1, *len2;       // labels per read
+    int64_t stride1, stride2;
+    const int64_t *T1, *T2;            // nullable per-pair row counts
+    int64_t T1cap, T2cap;
+    int64_t band;
+    uint64_t *env;                     // [pair][env_stride][2]
+    int64_t env_stride;
+    uint64_t *dirs;                    // workspace: [pair][dirs_stride] decision ballots
+    int64_t dirs_stride;
+    int nchunk;                        // 64-column chunks per DP row
+    int32_t *anchor;                   // workspace: [pair][T1cap + 1]
+};
+size_t envelope_lds_bytes(int64_t T2cap);
+hipError_t launch_envelope(const EnvelopeArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream);
+
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
                                  int64_t n, int mode, hipStream_t stream);
 

@@ -197,6 +197,29 @@ int fcd_crf_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const f
                                     const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
                                     float beam_cut_threshold, int logadd_mode, const fcd_result *out);
 
+/* ---- alignment-band estimator for the duplex searches ----
+ * NOT a reference function: duplex::beam_search takes the envelope as an argument, the PyO3 wrapper
+ * defaults to the full matrix and its docstring only anticipates a better default
+ * (/root/reference/src/lib.rs:376-378,459-468).  Input: per pair, the label sequences of the two
+ * reads with their emission times (e.g. the labels / path / out_len arrays of fcd_viterbi_search_*).
+ * The label sequences are aligned globally (unit-cost edit distance); matched labels anchor read-1
+ * time to read-2 time; envelope row i = [centre(i) - band, centre(i) + band + 1) clipped to
+ * [0, T2], with lo(0) = 0, hi(T1 - 1) = T2 and consecutive rows touching (src/duplex.rs:485-488).
+ * T1 / T2: nullable per-pair row counts (else T1cap / T2cap).  Limits: T1cap + T2cap <= 65535 and
+ * T2cap <= ~13000 (the DP rows live in LDS as u16; FCD_E_UNSUPPORTED beyond).  Executable specification: tests/envelope_model.py. */
+int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
+                            const uint8_t *labels1, const uint32_t *path1, const uint32_t *len1,
+                            int64_t stride1, const int64_t *T1, int64_t T1cap,
+                            const uint8_t *labels2, const uint32_t *path2, const uint32_t *len2,
+                            int64_t stride2, const int64_t *T2, int64_t T2cap,
+                            int64_t band, uint64_t *envelope, int64_t env_stride);
+int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
+                             const uint8_t *labels1, const uint32_t *path1, const uint32_t *len1,
+                             int64_t stride1, const int64_t *T1, int64_t T1cap,
+                             const uint8_t *labels2, const uint32_t *path2, const uint32_t *len2,
+                             int64_t stride2, const int64_t *T2, int64_t T2cap,
+                             int64_t band, uint64_t *envelope, int64_t env_stride);
+
 /* Test hook (device pointers, n elements): out_add[i] = LogSpace::add(a[i], b[i]) (src/duplex.rs:42-63)
  * and out_ln[i] = LogSpace::new(a[i]) = ln(a[i]) (:24-26), computed by the very device functions the
  * duplex kernel uses, so the log-space arithmetic can be checked bit for bit against the oracle. */
