@@ -649,23 +649,34 @@ int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
         return fail(h, FCD_E_INVALID, "null array");
     if (stride1 < T1cap || stride2 < T2cap) return fail(h, FCD_E_INVALID, "label strides shorter than the reads");
     if (env_stride < T1cap) return fail(h, FCD_E_INVALID, "envelope shorter than read 1");
-    if (T1cap + T2cap > 65535) return fail(h, FCD_E_UNSUPPORTED, "envelope estimator: T1 + T2 above 65535");
-    if (envelope_lds_bytes(T2cap) > 64 * 1024)
-        return fail(h, FCD_E_UNSUPPORTED, "envelope estimator: read 2 too long for the LDS-resident rows");
     band = std::min<int64_t>(band, 1 << 20);
     FCD_HIP(h, hipSetDevice(h->device));
-    const int nchunk = (int)((T2cap + 63) / 64);
-    const int64_t dirs_stride = std::max<int64_t>(T1cap * std::max(nchunk, 1) * 2, 2);
+    // the DP is sized by the longest labellings actually present, not by the time axes
+    int rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, 256);
+    if (rc) return rc;
+    uint32_t *d_max = reinterpret_cast<uint32_t *>(h->lnbuf);
+    uint32_t h_max[2] = {0, 0};
+    FCD_HIP(h, hipMemsetAsync(d_max, 0, 8, h->stream));
+    FCD_HIP(h, launch_max_u32(len1, len2, n_pairs, d_max, h->stream));
+    FCD_HIP(h, hipMemcpyAsync(h_max, d_max, 8, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    const int64_t L1cap = std::max<int64_t>(1, std::min<int64_t>(h_max[0], T1cap));
+    const int64_t L2cap = std::max<int64_t>(1, std::min<int64_t>(h_max[1], T2cap));
+    if (L1cap + L2cap > 65535) return fail(h, FCD_E_UNSUPPORTED, "envelope estimator: more than 65535 labels in a pair");
+    if (envelope_lds_bytes(L2cap) > 64 * 1024)
+        return fail(h, FCD_E_UNSUPPORTED, "envelope estimator: read 2 holds too many labels for the LDS-resident rows");
+    const int nchunk = (int)((L2cap + 63) / 64);
+    const int64_t dirs_stride = std::max<int64_t>(L1cap * std::max(nchunk, 1) * 2, 2);
     const size_t anchor_bytes = ((size_t)(T1cap + 1) * 4 + 15) & ~(size_t)15;
     const size_t per_pair = (size_t)dirs_stride * 8 + anchor_bytes;
     int64_t chunk = std::max<int64_t>(1, workspace_budget(h) / (int64_t)per_pair);
     chunk = std::min<int64_t>(chunk, n_pairs);
-    int rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
+    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
     if (rc) return rc;
     EnvelopeArgs a;
     a.labels1 = labels1; a.labels2 = labels2; a.path1 = path1; a.path2 = path2;
     a.len1 = len1; a.len2 = len2; a.stride1 = stride1; a.stride2 = stride2;
-    a.T1 = T1; a.T2 = T2; a.T1cap = T1cap; a.T2cap = T2cap; a.band = band;
+    a.T1 = T1; a.T2 = T2; a.T1cap = T1cap; a.T2cap = T2cap; a.L2cap = L2cap; a.band = band;
     a.env = envelope; a.env_stride = env_stride;
     a.dirs = reinterpret_cast<uint64_t *>(h->arena);
     a.dirs_stride = dirs_stride;

@@ -15,6 +15,8 @@
 //      lo(0) = 0, hi(T1 - 1) = T2 and lo(i) <= hi(i - 1) (src/duplex.rs:485-488).
 #include <limits.h>
 
+#include <algorithm>
+
 #include "device_utils.h"
 #include "fcd_internal.h"
 
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(64) void envelope_kernel(EnvParams p) {
     int L1 = (int)a.len1[r], L2 = (int)a.len2[r];
     L1 = L1 < 0 ? 0 : (L1 < T1 ? L1 : (int)T1);
     L2 = L2 < 0 ? 0 : (L2 < T2 ? L2 : (int)T2);
+    L2 = L2 < a.L2cap ? L2 : (int)a.L2cap;
     const uint8_t *lab1 = a.labels1 + r * a.stride1;
     const uint8_t *lab2 = a.labels2 + r * a.stride2;
     const uint32_t *pth1 = a.path1 + r * a.stride1;
@@ -80,8 +83,9 @@ __global__ __launch_bounds__(64) void envelope_kernel(EnvParams p) {
     uint64_t *env = a.env + r * a.env_stride * 2;
     const int nchunk = a.nchunk;
 
-    // LDS: two u16 DP rows of L2cap + 1 entries, then the labels of read 2
-    const int rowlen = (int)a.T2cap + 1;
+    // LDS: two u16 DP rows of L2cap + 1 entries (L2cap = the batch's longest read-2 labelling), then
+    // the labels of read 2
+    const int rowlen = (int)a.L2cap + 1;
     uint16_t *prev = reinterpret_cast<uint16_t *>(smem);
     uint16_t *cur = prev + rowlen;
     uint8_t *s2 = reinterpret_cast<uint8_t *>(cur + rowlen);
@@ -215,12 +219,32 @@ __global__ __launch_bounds__(64) void envelope_kernel(EnvParams p) {
 
 }  // namespace
 
-size_t envelope_lds_bytes(int64_t T2cap) { return (size_t)(2 * (T2cap + 1) * 2 + T2cap + 16); }
+size_t envelope_lds_bytes(int64_t L2cap) { return (size_t)(2 * (L2cap + 1) * 2 + L2cap + 16); }
+
+namespace {
+__global__ void max_u32_kernel(const uint32_t *a, const uint32_t *b, int64_t n, uint32_t *out2) {
+    uint32_t ma = 0, mb = 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        ma = max(ma, a[i]);
+        mb = max(mb, b[i]);
+    }
+    atomicMax(&out2[0], ma);
+    atomicMax(&out2[1], mb);
+}
+}  // namespace
+
+// out2[0] = max(a), out2[1] = max(b); out2 must be zeroed by the caller
+hipError_t launch_max_u32(const uint32_t *a, const uint32_t *b, int64_t n, uint32_t *out2, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 256);
+    hipLaunchKernelGGL(max_u32_kernel, dim3(blocks), dim3(256), 0, stream, a, b, n, out2);
+    return hipGetLastError();
+}
 
 hipError_t launch_envelope(const EnvelopeArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream) {
     if (n_pairs <= 0) return hipSuccess;
     EnvParams p{a, pair_begin};
-    hipLaunchKernelGGL(envelope_kernel, dim3((unsigned)n_pairs), dim3(64), envelope_lds_bytes(a.T2cap), stream, p);
+    hipLaunchKernelGGL(envelope_kernel, dim3((unsigned)n_pairs), dim3(64), envelope_lds_bytes(a.L2cap), stream, p);
     return hipGetLastError();
 }
 

@@ -124,6 +124,7 @@ struct EnvelopeArgs {
     int64_t stride1, stride2;
     const int64_t *T1, *T2;            // nullable per-pair row counts
     int64_t T1cap, T2cap;
+    int64_t L2cap;                     // most labels any read 2 of the batch holds (sizes the LDS rows)
     int64_t band;
     uint64_t *env;                     // [pair][env_stride][2]
     int64_t env_stride;
@@ -132,7 +133,8 @@ struct EnvelopeArgs {
     int nchunk;                        // 64-column chunks per DP row
     int32_t *anchor;                   // workspace: [pair][T1cap + 1]
 };
-size_t envelope_lds_bytes(int64_t T2cap);
+size_t envelope_lds_bytes(int64_t L2cap);
+hipError_t launch_max_u32(const uint32_t *a, const uint32_t *b, int64_t n, uint32_t *out2, hipStream_t stream);
 hipError_t launch_envelope(const EnvelopeArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream);
 
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,

@@ -205,8 +205,8 @@ int fcd_crf_beam_search_duplex_host(fcd_handle *h, const fcd_batch *in1, const f
  * The label sequences are aligned globally (unit-cost edit distance); matched labels anchor read-1
  * time to read-2 time; envelope row i = [centre(i) - band, centre(i) + band + 1) clipped to
  * [0, T2], with lo(0) = 0, hi(T1 - 1) = T2 and consecutive rows touching (src/duplex.rs:485-488).
- * T1 / T2: nullable per-pair row counts (else T1cap / T2cap).  Limits: T1cap + T2cap <= 65535 and
- * T2cap <= ~13000 (the DP rows live in LDS as u16; FCD_E_UNSUPPORTED beyond).  Executable specification: tests/envelope_model.py. */
+ * T1 / T2: nullable per-pair row counts (else T1cap / T2cap).  Limits: at most 65535 labels per pair and
+ * ~13000 labels in read 2 (the DP rows live in LDS as u16; FCD_E_UNSUPPORTED beyond).  Executable specification: tests/envelope_model.py. */
 int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
                             const uint8_t *labels1, const uint32_t *path1, const uint32_t *len1,
                             int64_t stride1, const int64_t *T1, int64_t T1cap,

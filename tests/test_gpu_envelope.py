@@ -127,7 +127,13 @@ def test_envelope_limits_and_edges(fcd):
     assert fcd.estimate_envelope(np.zeros((0, 5), np.float32), x).shape == (0, 2)
     e = fcd.estimate_envelope(x, x, 0)        # identical reads, zero band: the diagonal itself
     check_valid(e, 10, 10)
+    # limits follow the number of LABELS, not the time axis: 40000 blank rows are fine ...
     big = np.zeros((1, 40000, 5), np.float32)
     big[..., 0] = 1.0
+    check_valid(fcd.estimate_envelope_batch(big, big[:, :30000], 8)[0], 40000, 30000)
+    # ... 20000 labels in read 2 are not
+    alt = np.zeros((1, 40000, 5), np.float32)
+    alt[0, 0::2, 1] = 1.0
+    alt[0, 1::2, 2] = 1.0
     with pytest.raises(RuntimeError, match="envelope estimator"):
-        fcd.estimate_envelope_batch(big, big, 8)
+        fcd.estimate_envelope_batch(alt, alt, 8)
