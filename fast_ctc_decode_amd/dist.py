@@ -8,7 +8,8 @@ into one contiguous byte buffer and moved to the destination rank with a single
 (tests/test_dist_gloo.py runs this exact code path with world_size 2).
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a gather to rank 0 uses each peer's direct
-link once, so it is per-link bound; at BASELINE config 2 the payload is ~82 MB per rank.
+link once, so it is per-link bound; at BASELINE config 2 the payload is ~49 MB per rank (labels u8 +
+path u16 at fixed stride T = 4000).
 """
 import numpy as np
 
@@ -26,9 +27,14 @@ def shard_bounds(n_reads, world):
     return out
 
 
+def _path_bytes(width):
+    # path entries are time indices < width: two bytes are enough for reads shorter than 65536 steps
+    return 2 if width <= 65535 else 4
+
+
 def packed_nbytes(n_reads, width):
-    # labels u8 [B,W] | path u32 [B,W] | out_len u32 [B] | status i32 [B]
-    return n_reads * width + 4 * n_reads * width + 4 * n_reads + 4 * n_reads
+    # labels u8 [B,W] | path u16/u32 [B,W] | out_len u32 [B] | status i32 [B]
+    return n_reads * width + _path_bytes(width) * n_reads * width + 4 * n_reads + 4 * n_reads
 
 
 def pack_result(r, pad_reads, out=None):
@@ -47,8 +53,10 @@ def pack_result(r, pad_reads, out=None):
     o = 0
     buf[o:o + B * W] = labels.reshape(-1)
     o = pad_reads * W
-    buf[o:o + 4 * B * W] = r.path.contiguous().view(torch.uint8).reshape(-1)
-    o += 4 * pad_reads * W
+    pb = _path_bytes(W)
+    path = r.path.contiguous() if pb == 4 else r.path.to(torch.int16)  # low 16 bits, exact below 65536
+    buf[o:o + pb * B * W] = path.view(torch.uint8).reshape(-1)
+    o += pb * pad_reads * W
     buf[o:o + 4 * B] = r.out_len.contiguous().view(torch.uint8).reshape(-1)
     o += 4 * pad_reads
     buf[o:o + 4 * B] = r.status.contiguous().view(torch.uint8).reshape(-1)
@@ -65,8 +73,12 @@ def unpack_results(bufs, counts, width, pad_reads):
         o = 0
         labels.append(buf[o:o + B * W].reshape(B, W))
         o = pad_reads * W
-        path.append(buf[o:o + 4 * B * W].view(torch.int32).reshape(B, W))
-        o += 4 * pad_reads * W
+        pb = _path_bytes(W)
+        if pb == 4:
+            path.append(buf[o:o + 4 * B * W].view(torch.int32).reshape(B, W))
+        else:
+            path.append(buf[o:o + 2 * B * W].view(torch.int16).reshape(B, W).to(torch.int32) & 0xFFFF)
+        o += pb * pad_reads * W
         out_len.append(buf[o:o + 4 * B].view(torch.int32))
         o += 4 * pad_reads
         status.append(buf[o:o + 4 * B].view(torch.int32))

@@ -79,3 +79,25 @@ def test_shard_bounds():
     assert shard_bounds(10, 4) == [(0, 3), (3, 6), (6, 8), (8, 10)]
     assert shard_bounds(2, 4) == [(0, 1), (1, 2), (2, 2), (2, 2)]
     assert shard_bounds(65536, 8)[-1] == (57344, 65536)
+
+
+def test_pack_unpack_roundtrip_wide_paths():
+    """The gather payload stores path entries in two bytes below 65536 steps: values above 32767
+    must survive, and reads of 65536+ steps fall back to four bytes."""
+    import torch
+
+    from fast_ctc_decode_amd import dist as fdist
+    from fast_ctc_decode_amd.api import BatchResult
+
+    for W in (50000, 70000):
+        g = torch.Generator().manual_seed(W)
+        B = 2
+        labels = torch.randint(1, 5, (B, W), dtype=torch.uint8, generator=g)
+        path = torch.randint(0, W, (B, W), dtype=torch.int32, generator=g)
+        path[0, :3] = torch.tensor([0, 32768, W - 1], dtype=torch.int32)
+        r = BatchResult(labels, path, torch.tensor([W, 3], dtype=torch.int32), torch.zeros(B, dtype=torch.int32))
+        buf = fdist.pack_result(r, pad_reads=3)
+        assert buf.numel() == fdist.packed_nbytes(3, W)
+        back = fdist.unpack_results([buf], [B], W, 3)
+        assert torch.equal(back.labels, labels) and torch.equal(back.path, path)
+        assert torch.equal(back.out_len, r.out_len) and torch.equal(back.status, r.status)
