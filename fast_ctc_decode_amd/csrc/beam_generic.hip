@@ -53,9 +53,10 @@ struct Lds {
     float *c_lp;
     float *c_gp;
     int *c_id;
-    int *c_new;
+    uint64_t *c_newmask;  // ceil(C/64) ballots: slot c created its node in this step
     int *nb_src;   // BC
     int *b_pslot;  // BC: beam slot of the entry's parent, or -1
+    // m_flag, hist and l_key are never live at the same time and share one region:
     int *m_flag;   // C: 1 when slot (i,k)'s child is itself a beam entry (its own slot absorbs the extension)
     float *row;    // N (non-CRF staging of the current posterior row)
     float *top;    // 1
@@ -71,20 +72,27 @@ constexpr int kBuckets = 256;
 constexpr int kBucketShift = 18;
 __host__ __device__ inline int list_cap(int BC) { return BC + 64; }
 
+__host__ __device__ inline size_t shared_region_words(int BC, int N) {
+    size_t w = (size_t)BC * N;                                   // m_flag
+    if (w < (size_t)kBuckets) w = kBuckets;                      // hist
+    if (w < 2 * (size_t)list_cap(BC)) w = 2 * (size_t)list_cap(BC);  // l_key
+    return (w + 3) & ~(size_t)3;
+}
+
 __host__ __device__ inline size_t lds_words(int BC, int N) {
     int NL = N - 1;
     size_t C = (size_t)BC * N;
     size_t w = 0;
     w += 2 * (size_t)BC * (7 + NL);
     w += 2 * C;  // keys (u64)
-    w += 4 * C;  // lp, gp, id, new
+    w += 3 * C;  // lp, gp, id
+    w += 2 * ((C + 63) / 64) + 2;  // newmask (u64)
     w += BC;     // nb_src
     w += BC;     // b_pslot
-    w += C;      // m_flag
     w += N;      // row
     w += 2;      // top + pad
-    w += kBuckets + 3;              // hist, 16-byte aligned
-    w += 3 * (size_t)list_cap(BC);  // l_key (u64) + l_c
+    w += shared_region_words(BC, N) + 3;  // m_flag / hist / l_key, 16-byte aligned
+    w += (size_t)list_cap(BC);            // l_c
     return w;
 }
 
@@ -98,19 +106,21 @@ __device__ inline Lds carve(int *smem, int BC, int N) {
     L.c_lp = reinterpret_cast<float *>(p); p += C;
     L.c_gp = reinterpret_cast<float *>(p); p += C;
     L.c_id = p; p += C;
-    L.c_new = p; p += C;
+    if ((p - smem) & 1) ++p;
+    L.c_newmask = reinterpret_cast<uint64_t *>(p); p += 2 * ((C + 63) / 64);
     L.BC = BC;
     L.beam_stride = BC * (7 + NL);
     L.beam0 = p;
     p += 2 * (size_t)L.beam_stride;
     L.nb_src = p; p += BC;
     L.b_pslot = p; p += BC;
-    L.m_flag = p; p += C;
     L.row = reinterpret_cast<float *>(p); p += N;
     L.top = reinterpret_cast<float *>(p); p += 2;
     while ((p - smem) & 3) ++p;  // smem is 16-byte aligned: hist is cleared / scanned as int4
-    L.hist = p; p += kBuckets;   // ... which leaves the u64 list 8-byte aligned
-    L.l_key = reinterpret_cast<uint64_t *>(p); p += 2 * (size_t)list_cap(BC);
+    L.m_flag = p;
+    L.hist = p;
+    L.l_key = reinterpret_cast<uint64_t *>(p);
+    p += shared_region_words(BC, N);
     L.l_c = p;
     return L;
 }
@@ -301,12 +311,12 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                 }
             }
             nn += popc64(m_new);
+            if (lane == 0) L.c_newmask[base >> 6] = m_new;
             const float prob = clp + cgp;
             if (act) {
                 L.c_lp[c] = clp;
                 L.c_gp[c] = cgp;
                 L.c_id[c] = cid;
-                L.c_new[c] = is_new ? 1 : 0;
                 // a NaN key is only ever ranked when it is the lone candidate (never compared, :262)
                 L.c_key[c] = valid ? (prob == prob ? make_key(prob, cid) : 1ull) : 0ull;
             }
@@ -372,7 +382,8 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             Lc = __shfl(cum, owner);
         }
         if (Lc <= cap) {
-            // compaction in slot order, then exact rank inside the list
+            // compaction in slot order (the list overwrites the histogram), then exact rank inside the list
+            wave_sync();
             int base = 0;
             for (int base0 = 0; base0 < nslots; base0 += kWave) {
                 const int c = base0 + lane;
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                         L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
                         L.b_depth(nxt)[rank] = b_depth[i] + 1;
                     }
-                    L.nb_src[rank] = c | (L.c_new[c] << 30);
+                    L.nb_src[rank] = c | ((int)((L.c_newmask[c >> 6] >> (c & 63)) & 1ull) << 30);
                     if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
                 }
             }
@@ -453,7 +464,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                     L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
                     L.b_depth(nxt)[rank] = b_depth[i] + 1;
                 }
-                L.nb_src[rank] = c | (L.c_new[c] << 30);
+                L.nb_src[rank] = c | ((int)((L.c_newmask[c >> 6] >> (c & 63)) & 1ull) << 30);
                 if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
             }
           }
