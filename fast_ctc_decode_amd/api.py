@@ -506,22 +506,47 @@ class BatchResult:
             return a if a is None or isinstance(a, np.ndarray) else a.cpu().numpy()
         return BatchResult(c(self.labels), c(self.path), c(self.out_len), c(self.status), c(self.qual))
 
-    def sequences(self, alphabet, raise_on_error=True):
-        """-> list of (str, list[int]) exactly as the single-read functions would return."""
+    def sequences(self, alphabet, raise_on_error=True, paths="list"):
+        """-> list of (str, path) per read, exactly what the single-read functions return.
+
+        paths="list" (default) gives list[int] like the reference; building millions of Python ints
+        dominates large batches (4096 reads x ~2000 labels: ~150 ms against a 5 ms kernel), so
+        paths="array" returns int32 numpy views into the result instead, and paths=None skips them."""
+        if paths not in ("list", "array", None):
+            raise ValueError("paths must be 'list', 'array' or None")
         r = self.cpu()
         alpha = _seq_to_vec(alphabet)
-        table = np.array(alpha, dtype=object)
+        ok = np.ones(len(r.out_len), bool) if r.status is None else (np.asarray(r.status) == nat.ST_OK)
+        if raise_on_error and not ok.all():
+            i = int(np.flatnonzero(~ok)[0])
+            raise RuntimeError("read %d: %s" % (i, nat.status_string(int(r.status[i]))))
+        lens = np.asarray(r.out_len).astype(np.int64)
+        labels = np.asarray(r.labels)
+        single = all(len(a) == 1 and ord(a) < 128 for a in alpha)
+        if single:
+            # one vectorised table lookup for the whole batch, then a slice + decode per read
+            lut = np.zeros(256, np.uint8)
+            lut[:len(alpha)] = np.frombuffer("".join(alpha).encode("ascii"), np.uint8)
+            chars = lut[labels]
+        else:
+            table = np.array(alpha, dtype=object)
         out = []
-        for i in range(len(r.out_len)):
-            st = int(r.status[i]) if r.status is not None else 0
-            if st != nat.ST_OK:
-                if raise_on_error:
-                    raise RuntimeError("read %d: %s" % (i, nat.status_string(st)))
+        for i in range(len(lens)):
+            if not ok[i]:
                 out.append(None)
                 continue
-            n = int(r.out_len[i])
-            seq = "".join(table[r.labels[i, :n]]) if n else ""
-            out.append((seq, r.path[i, :n].astype(np.int64).tolist() if r.path is not None else None))
+            n = int(lens[i])
+            if single:
+                seq = chars[i, :n].tobytes().decode("ascii")
+            else:
+                seq = "".join(table[labels[i, :n]]) if n else ""
+            if r.path is None or paths is None:
+                pth = None
+            elif paths == "array":
+                pth = r.path[i, :n]
+            else:
+                pth = r.path[i, :n].tolist()
+            out.append((seq, pth))
         return out
 
 
@@ -629,14 +654,15 @@ def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
 
 
 def beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold=0.0,
-                      collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO):
-    """Batched beam_search: element i equals beam_search(network_outputs[i][:lengths[i]], ...)."""
+                      collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, paths="list"):
+    """Batched beam_search: element i equals beam_search(network_outputs[i][:lengths[i]], ...).
+    paths="array" returns the paths as numpy arrays instead of list[int] (see BatchResult.sequences)."""
     alpha = _seq_to_vec(alphabet)
     inner = network_outputs[0].shape[-1] if isinstance(network_outputs, (list, tuple)) else network_outputs.shape[-1]
     _check_beam_args(len(alpha), inner, beam_size, beam_cut_threshold)
     r = beam_search_batch_raw(network_outputs, beam_size, beam_cut_threshold, collapse_repeats,
                               lengths, kernel)
-    return r.sequences(alpha)
+    return r.sequences(alpha, paths=paths)
 
 
 def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=None, qual=False):
@@ -657,12 +683,12 @@ def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=Non
 
 
 def viterbi_search_batch(network_outputs, alphabet, qstring=False, qscale=1.0, qbias=0.0,
-                         collapse_repeats=True, lengths=None):
+                         collapse_repeats=True, lengths=None, paths="list"):
     alpha = _seq_to_vec(alphabet)
     inner = network_outputs[0].shape[-1] if isinstance(network_outputs, (list, tuple)) else network_outputs.shape[-1]
     _check_greedy_alphabet(len(alpha), inner)
     r = viterbi_search_batch_raw(network_outputs, collapse_repeats, lengths, qual=qstring).cpu()
-    res = r.sequences(alpha)
+    res = r.sequences(alpha, paths=paths if paths is not None else "array")
     if qstring:
         res = [(s + _qual_chars(r.qual[i, :len(p)], qscale, qbias), p) for i, (s, p) in enumerate(res)]
     return res

@@ -492,3 +492,18 @@ def viterbi_fuzz_seed(fcd, seed):
 def test_viterbi_fuzz(fcd):
     for seed in range(4000, 4030):
         viterbi_fuzz_seed(fcd, seed)
+
+
+def test_batch_sequences_path_flavours(fcd):
+    """BatchResult.sequences: the vectorised string build and the three path flavours agree with the
+    single-read calls; multi-character alphabets take the generic route."""
+    x = gen_batch(55, 5, 120, 5)
+    want = [fcd.beam_search(x[i], "NACGT", 5, 0.1) for i in range(5)]
+    assert fcd.beam_search_batch(x, "NACGT", 5, 0.1) == want
+    arr = fcd.beam_search_batch(x, "NACGT", 5, 0.1, paths="array")
+    assert [(s, p.tolist()) for s, p in arr] == want
+    none = fcd.beam_search_batch(x, "NACGT", 5, 0.1, paths=None)
+    assert [s for s, _ in none] == [s for s, _ in want] and all(p is None for _, p in none)
+    multi = ["N", "Ade", "Cyt", "Gua", "Thy"]
+    wm = [fcd.beam_search(x[i], multi, 5, 0.1) for i in range(5)]
+    assert fcd.beam_search_batch(x, multi, 5, 0.1) == wm
