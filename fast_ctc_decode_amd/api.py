@@ -264,8 +264,12 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
     if _is_torch_cuda(network_outputs_1):
         import torch
         x1, x2 = network_outputs_1, network_outputs_2
+        if x1.dtype in (torch.float16, torch.bfloat16):
+            x1 = x1.float()
+        if x2.dtype in (torch.float16, torch.bfloat16):
+            x2 = x2.float()
         if x1.dtype != torch.float32 or x2.dtype != torch.float32:
-            raise TypeError("device posteriors must be float32")
+            raise TypeError("device posteriors must be float32 (float16 / bfloat16 are upcast)")
         B, T1, N = x1.shape
         T2 = x2.shape[1]
         dev = x1.device
@@ -554,8 +558,12 @@ def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path
                 need_status=True, handle=None):
     import torch
 
+    if x.dtype in (torch.float16, torch.bfloat16):
+        # half-precision posteriors (what basecaller networks emit): upcast on the device -- exact, so
+        # the result is the reference's on the upcast matrix; the kernels themselves compute in f32
+        x = x.float()
     if x.dtype != torch.float32:
-        raise TypeError("device posteriors must be float32")
+        raise TypeError("device posteriors must be float32 (float16 / bfloat16 are upcast)")
     dev = x.device.index or 0
     h = handle if handle is not None else nat.default_handle(dev)
     if crf:

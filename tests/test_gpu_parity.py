@@ -507,3 +507,23 @@ def test_batch_sequences_path_flavours(fcd):
     multi = ["N", "Ade", "Cyt", "Gua", "Thy"]
     wm = [fcd.beam_search(x[i], multi, 5, 0.1) for i in range(5)]
     assert fcd.beam_search_batch(x, multi, 5, 0.1) == wm
+
+
+def test_half_precision_device_tensors(fcd):
+    """float16 / bfloat16 device posteriors are upcast exactly: same result as the f32 call on the
+    upcast matrix (which is what the reference would be given)."""
+    torch = pytest.importorskip("torch")
+    x = torch.from_numpy(gen_batch(66, 4, 300, 5)).cuda()
+    for dt in (torch.float16, torch.bfloat16):
+        xh = x.to(dt)
+        up = xh.float()
+        a = fcd.beam_search_batch_raw(xh, 5, 0.1).cpu()
+        b = fcd.beam_search_batch_raw(up, 5, 0.1).cpu()
+        np.testing.assert_array_equal(a.out_len, b.out_len)
+        for i in range(4):
+            n = int(a.out_len[i])
+            np.testing.assert_array_equal(a.labels[i, :n], b.labels[i, :n])
+            np.testing.assert_array_equal(a.path[i, :n], b.path[i, :n])
+        va, vb = fcd.viterbi_search_batch_raw(xh).cpu(), fcd.viterbi_search_batch_raw(up).cpu()
+        np.testing.assert_array_equal(va.out_len, vb.out_len)
+        check_beam(fcd, up.cpu().numpy(), 5, 0.1)
