@@ -432,9 +432,57 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
                                      init_states_2, envelopes=None, beam_size=5,
                                      beam_cut_threshold=0.0, lengths_1=None, lengths_2=None,
                                      logadd_mode=None):
-    """(B,T1,S,N) / (B,T2,S,N) host posteriors, (B,n_init) initial state scores, (B,T1,2) uint64
-    envelopes -> BatchResult (labels only)."""
+    """(B,T1,S,N) / (B,T2,S,N) posteriors (numpy, or torch ROCm tensors: zero-copy), (B,n_init)
+    initial state scores, (B,T1,2) uint64 envelopes -> BatchResult (labels only)."""
     mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
+    if _is_torch_cuda(network_outputs_1):
+        import torch
+        x1, x2 = network_outputs_1, network_outputs_2
+        if x1.dtype in (torch.float16, torch.bfloat16):
+            x1 = x1.float()
+        if x2.dtype in (torch.float16, torch.bfloat16):
+            x2 = x2.float()
+        if x1.dtype != torch.float32 or x2.dtype != torch.float32:
+            raise TypeError("device posteriors must be float32 (float16 / bfloat16 are upcast)")
+        B, T1, S, N = x1.shape
+        T2 = x2.shape[1]
+        dev = x1.device
+        i1 = torch.as_tensor(init_states_1, dtype=torch.float32, device=dev).contiguous()
+        i2 = torch.as_tensor(init_states_2, dtype=torch.float32, device=dev).contiguous()
+        if x2.shape[0] != B or i1.shape[0] != B or i2.shape[0] != B or i1.ndim != 2 or i2.ndim != 2:
+            raise ValueError("all inputs must hold the same number of pairs")
+        if envelopes is None:
+            env = torch.from_numpy(_default_envelope(B, T1, T2, lengths_2).view(np.int64)).to(dev)
+        elif isinstance(envelopes, np.ndarray):
+            env = torch.from_numpy(np.ascontiguousarray(envelopes, np.uint64).view(np.int64)).to(dev)
+        else:
+            env = envelopes.contiguous()
+        h = nat.default_handle(dev.index or 0)
+        s1, s2 = x1.stride(), x2.stride()
+        b1 = nat.Batch(x1.data_ptr(), B, T1, S, N, s1[0], s1[1], s1[2], s1[3], None)
+        b2 = nat.Batch(x2.data_ptr(), B, T2, S, N, s2[0], s2[1], s2[2], s2[3], None)
+        keep = [x1, x2, env, i1, i2]
+        if lengths_1 is not None:
+            l1 = torch.as_tensor(lengths_1, dtype=torch.int64, device=dev).contiguous()
+            b1.lengths = l1.data_ptr()
+            keep.append(l1)
+        if lengths_2 is not None:
+            l2 = torch.as_tensor(lengths_2, dtype=torch.int64, device=dev).contiguous()
+            b2.lengths = l2.data_ptr()
+            keep.append(l2)
+        w = max(int(T1), 1)
+        labels = torch.empty((B, w), dtype=torch.uint8, device=dev)
+        out_len = torch.zeros(B, dtype=torch.int32, device=dev)
+        status = torch.zeros(B, dtype=torch.int32, device=dev)
+        res = nat.Result(labels.data_ptr(), None, None, out_len.data_ptr(), status.data_ptr(), w)
+        h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+        h.check(h.lib.fcd_crf_beam_search_duplex_dev(
+            h.ptr, C.byref(b1), C.c_void_p(i1.data_ptr()), int(i1.shape[1]), int(i1.shape[1]), C.byref(b2),
+            C.c_void_p(i2.data_ptr()), int(i2.shape[1]), int(i2.shape[1]), C.c_void_p(env.data_ptr()),
+            int(env.shape[1]), int(beam_size), float(beam_cut_threshold), int(mode), C.byref(res)))
+        r = BatchResult(labels, None, out_len, status)
+        r._handle, r._keep = h, keep
+        return r
     x1 = _stack_host(network_outputs_1, 4)
     x2 = _stack_host(network_outputs_2, 4)
     i1 = np.ascontiguousarray(np.asarray(init_states_1, np.float32))

@@ -307,3 +307,23 @@ def duplex_fuzz_seed(fcd, seed, mode):
 def test_duplex_fuzz(fcd, mode):
     for seed in range(5000, 5016):
         duplex_fuzz_seed(fcd, seed, mode)
+
+
+def test_crf_duplex_device_tensors(fcd):
+    """The zero-copy (torch ROCm tensor) entry of the CRF duplex search equals the host entry."""
+    torch = pytest.importorskip("torch")
+    ps = [crf_pairs(600 + i, 50, 48) for i in range(3)]
+    X1 = np.stack([p[0] for p in ps]); I1 = np.stack([p[1] for p in ps])
+    X2 = np.stack([p[2] for p in ps]); I2 = np.stack([p[3] for p in ps])
+    env = np.broadcast_to(band(50, 48, 10), (3, 50, 2)).copy()
+    host = fcd.crf_beam_search_duplex_batch_raw(X1, I1, X2, I2, env, 5, 0.0)
+    dev = fcd.crf_beam_search_duplex_batch_raw(torch.from_numpy(X1).cuda(), I1, torch.from_numpy(X2).cuda(), I2,
+                                               env, 5, 0.0).cpu()
+    for i in range(3):
+        assert int(dev.status[i]) == int(host.status[i]) == 0
+        n = int(host.out_len[i])
+        assert int(dev.out_len[i]) == n
+        np.testing.assert_array_equal(dev.labels[i, :n], host.labels[i, :n])
+        want = oracle.crf_beam_search_duplex(ps[i][0], ps[i][1], ps[i][2], ps[i][3], "NACGT", env[i], 5, 0.0,
+                                             LSE | CR)
+        assert "".join("NACGT"[l] for l in host.labels[i, :n]) == want
