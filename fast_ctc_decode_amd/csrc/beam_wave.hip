@@ -1,10 +1,11 @@
 // beam_wave.hip -- register-resident CTC prefix beam search for search::beam_search
 // (/root/reference/src/search.rs:159-301).
 //
-// Two instantiation families of one kernel template <N, GW, RPW>:
+// Three instantiation families of one kernel template <N, GW, RPW>:
 //   RPW = 2, GW = 6 : TWO reads per wavefront (one per 32-lane half), beam_size <= 5, N <= 5
 //                     -- the BASELINE headline shape (beam 5, N = 5);
-//   RPW = 1, GW = 8 : one read per wavefront, beam_size <= 8, N <= 7.
+//   RPW = 1, GW = 8 : one read per wavefront, beam_size <= 8, N <= 7;
+//   RPW = 1, GW = 5 : one read per wavefront, beam_size 9..12, N <= 5 (twelve groups of five lanes).
 //
 // Lane map inside a half: q = GW*i + k.  i = beam slot (rank order, like the reference's sorted
 // Vec), k = 0 the slot's own node, k = 1..NL the child reached by label k-1, k = GW-1 a scratch
@@ -43,10 +44,12 @@ namespace fcd {
 
 namespace {
 
+// child entry: node id in bits 0..24, beam slot in bits 25..28, IN-BEAM bit 29, EVER bit 30
 constexpr int kEver = 1 << 30;
 constexpr int kInBeam = 1 << 29;
-constexpr int kSlotShift = 26;
-constexpr int kIdMask = (1 << 26) - 1;
+constexpr int kSlotShift = 25;
+constexpr int kSlotMask = 15;
+constexpr int kIdMask = (1 << 25) - 1;
 constexpr int kStored = kEver | kIdMask;  // what goes to HBM
 
 struct WaveParams {
@@ -84,7 +87,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     constexpr int RPR = HALF / E;       // rows per FIFO register
     static_assert(RPR >= 1, "one timestep must fit the lanes of a half");
     constexpr int RW = NL <= 4 ? 4 : 8; // child-row width in the arena
-    static_assert(N <= GW - 1, "a scratch lane per group is required");
+    // ds_permute pushes that have nothing to say need a harmless target: the group's spare lane when it
+    // has one (N < GW), otherwise one of the lanes past the last group
+    static_assert(N <= GW, "a group holds the node's own slot and one lane per label");
+    constexpr bool HAS_SCRATCH = N <= GW - 1;
+    constexpr int NIDLE = HALF - BCAP * GW;
+    static_assert(HAS_SCRATCH || NIDLE >= 1, "no lane left to absorb idle pushes");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
 
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const bool is_child = !idle && k >= 1 && k <= NL;
     const int l = k - 1;
     const int grp0 = hbase + i * GW;         // lane 0 of my group
-    const int dummy = idle ? lane : grp0 + GW - 1;
+    const int dummy = HAS_SCRATCH ? (idle ? lane : grp0 + GW - 1) : hbase + BCAP * GW + (q % (NIDLE > 0 ? NIDLE : 1));
     const int beam_size = p.a.beam_size;
     const bool collapse = !CRF && p.a.collapse != 0;
     const float thr = p.a.thr;
@@ -213,7 +221,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const bool exists = child >= 0;
         const int cid = child & kIdMask;
         const bool inbeam = exists && (child & kInBeam);
-        const int mslot = (child >> kSlotShift) & 7;
+        const int mslot = (child >> kSlotShift) & kSlotMask;
         const bool cvalid = grp && is_child && pass && (exists || !rep || gp > 0.0f);  // :212-218
         const bool merged = cvalid && inbeam;  // the target's own lane 0 absorbs this extension
         const int dst = merged ? hbase + mslot * GW : dummy;
@@ -429,8 +437,9 @@ hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
 }  // namespace
 
 bool beam_wave_supported(int beam_size, int N, int crf, int S) {
-    if (beam_size < 1 || beam_size > 8) return false;
+    if (beam_size < 1 || beam_size > 12) return false;
     if (crf) return N == 5 && S == 4;  // the CRF instantiations: 4 states x 5 symbols
+    if (beam_size > 8) return N >= 3 && N <= 5;
     return N >= 3 && N <= 7;
 }
 
@@ -441,9 +450,19 @@ hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_r
     WaveParams p{in, a, arena, out, read_begin};
     p.in.n_reads = n_reads;  // reads in this launch
     const bool two = a.beam_size <= 5 && in.N <= 5 && !a.force_one_read_per_wave;
+    const bool wide = a.beam_size > 8;  // 9..12 beam slots: groups of five lanes
     if (a.crf) {
         if (in.N != 5 || in.S != 4) return hipErrorInvalidValue;
+        if (wide) return launch_t<5, 5, 1, 4>(p, n_reads, stream);
         return two ? launch_t<5, 6, 2, 4>(p, n_reads, stream) : launch_t<5, 8, 1, 4>(p, n_reads, stream);
+    }
+    if (wide) {
+        switch (in.N) {
+            case 3: return launch_t<3, 5, 1>(p, n_reads, stream);
+            case 4: return launch_t<4, 5, 1>(p, n_reads, stream);
+            case 5: return launch_t<5, 5, 1>(p, n_reads, stream);
+        }
+        return hipErrorInvalidValue;
     }
     if (two) {
         switch (in.N) {

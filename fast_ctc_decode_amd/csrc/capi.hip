@@ -133,13 +133,13 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     bool use_wave = false;
     if (kernel == FCD_KERNEL_WAVE || kernel == FCD_KERNEL_WAVE1) {
         if (!beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S))
-            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8 and N <= 7 (CRF: N = 5, S = 4)");
+            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8 and N <= 7, or beam_size <= 12 and N <= 5 (CRF: N = 5, S = 4)");
         use_wave = true;
     } else if (kernel == FCD_KERNEL_AUTO) {
         use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S);
     }
-    // the wave kernel packs node ids and depths into 26 bits
-    if (use_wave && (d.T >= (1ll << 26) || d.T * std::min<int64_t>(beam, 8) * NL + 16 >= (1ll << 26))) {
+    // the wave kernel packs node ids into 25 bits and depths into 26
+    if (use_wave && (d.T >= (1ll << 26) || d.T * std::min<int64_t>(beam, 12) * NL + 16 >= (1ll << 25))) {
         if (kernel != FCD_KERNEL_AUTO) return fail(h, FCD_E_UNSUPPORTED, "wave kernel: T too large");
         use_wave = false;
     }
@@ -151,7 +151,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     int64_t cap_nodes;
     size_t per_read;
     if (use_wave) {
-        cap_nodes = (T * std::min<int64_t>(beam, 8) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
+        cap_nodes = (T * std::min<int64_t>(beam, 12) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
         const int row_words = NL <= 4 ? 4 : 8;
         per_read = (size_t)cap_nodes * (sizeof(int2) + 4 + row_words * 4);
     } else {

@@ -58,6 +58,18 @@ def test_beam_wave_random(fcd, N, beam, kernel):
     check_beam(fcd, x, beam, 0.1 if N <= 5 else 0.05, kernel=kernel)
 
 
+@pytest.mark.parametrize("kernel", [0, 2, 3])
+@pytest.mark.parametrize("N", [3, 4, 5])
+@pytest.mark.parametrize("beam", [9, 10, 12])
+def test_beam_wave_wide(fcd, N, beam, kernel):
+    """beam 9..12: the twelve-groups-of-five-lanes instantiation of the wave kernel."""
+    x = gen_batch(900 + N * 10 + beam, 6, 500, N)
+    check_beam(fcd, x, beam, 0.1, kernel=kernel)
+    check_beam(fcd, x[:2], beam, 0.0, collapse=False, kernel=kernel)
+    lengths = np.array([500, 1, 0, 65, 64, 499], np.int64)
+    check_beam(fcd, x, beam, 0.05, lengths=lengths, kernel=kernel)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
 def test_beam_thr0(fcd, collapse, kernel):
@@ -218,7 +230,7 @@ def test_crf_beam_random(fcd, beam, thr):
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
-@pytest.mark.parametrize("beam,thr", [(1, 0.0), (5, 0.0), (5, 0.1), (8, 0.05)])
+@pytest.mark.parametrize("beam,thr", [(1, 0.0), (5, 0.0), (5, 0.1), (8, 0.05), (12, 0.0), (10, 0.1)])
 def test_crf_beam_kernels(fcd, kernel, beam, thr):
     """crf_beam_search on every kernel family (S = 4 states x 5 symbols is the wave kernels' shape)."""
     torch = pytest.importorskip("torch")
