@@ -74,8 +74,8 @@ enum {
 enum {
     FCD_KERNEL_AUTO = 0,
     FCD_KERNEL_GENERIC = 1,  /* LDS-resident beam, any beam_size / alphabet */
-    FCD_KERNEL_WAVE = 2,     /* register-resident beam, beam_size <= 8, N <= 7; packs two reads per
-                                wavefront when beam_size <= 5 and N <= 5 */
+    FCD_KERNEL_WAVE = 2,     /* register-resident beam: beam_size <= 8 with N <= 7, or beam_size <= 12
+                                with N <= 5; packs two reads per wavefront when beam_size <= 5, N <= 5 */
     FCD_KERNEL_WAVE1 = 3     /* the same kernel, always one read per wavefront */
 };
 
