@@ -8,8 +8,9 @@
 //   RPW = 1, GW = 5 : one read per wavefront, beam_size 9..12, N <= 5 (twelve groups of five lanes).
 //
 // Lane map inside a half: q = GW*i + k.  i = beam slot (rank order, like the reference's sorted
-// Vec), k = 0 the slot's own node, k = 1..NL the child reached by label k-1, k = GW-1 a scratch
-// target for cross-lane pushes.  Every lane of group i carries slot i's (node, label_prob,
+// Vec), k = 0 the slot's own node, k = 1..NL the child reached by label k-1, and -- when the group
+// has a lane to spare -- k = GW-1 a scratch target for cross-lane pushes (GW = 5, N = 5 uses the
+// four lanes past the last group instead).  Every lane of group i carries slot i's (node, label_prob,
 // gap_prob, tip label, depth); lane (i, k>=1) also carries node i's child entry for label k-1.
 // The search state lives in VGPRs; LDS is only the cross-lane network (ds_permute/ds_bpermute)
 // and a 64-entry sort-key table per wave.
@@ -29,14 +30,15 @@
 //   * survivors are gathered into rank order with ds_bpermute and divided by the top
 //     probability (:278-282, IEEE f32 division).
 //
-// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = child entries
-// (id | EVER, or -1), written when the node leaves the beam; jmp[node] (written only for nodes whose depth is a multiple of 64) = the
-// nearest proper ancestor whose depth is a multiple of 64.  Every beam entry carries its own jump
-// pointer in a register, so the final leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling
-// into 64-node segments and then walks all segments in parallel, one lane each, instead of chasing
-// ~2000 dependent pointers with a single lane.  EVER marks children that have themselves been in the beam: only those can
-// own children, so only their row is re-read when they re-enter the beam (3.9 % of steps on
-// BASELINE's generator) -- everything else stays in registers.
+// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = the node's child
+// entries (id | EVER, or -1), written once, when the node is evicted from the beam; jmp[node]
+// (written only for nodes whose depth is a multiple of 64) = the nearest proper ancestor whose depth
+// is a multiple of 64.  Every beam entry carries its own jump pointer in a register, so the final
+// leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling into 64-node
+// segments and then walks all segments in parallel, one lane each, instead of chasing ~2000
+// dependent pointers with a single lane.  EVER marks children that have themselves been in the
+// beam: only those can own children, so only their row is re-read when they re-enter the beam
+// (3.9 % of steps on BASELINE's generator) -- everything else stays in registers.
 #include "device_utils.h"
 #include "fcd_internal.h"
 
