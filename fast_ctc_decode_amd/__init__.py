@@ -23,6 +23,8 @@ from .api import (  # noqa: F401
     crf_beam_search_duplex,
     crf_beam_search_duplex_batch_raw,
     crf_greedy_search,
+    crf_greedy_search_batch,
+    crf_greedy_search_batch_raw,
     estimate_envelope,
     estimate_envelope_batch,
     viterbi_search,

@@ -219,6 +219,41 @@ def crf_greedy_search(network_output, init_state, alphabet, qstring=False, qscal
     return seq, [int(p) for p in out.path[0, :n]]
 
 
+def crf_greedy_search_batch_raw(network_outputs, init_states, lengths=None, qual=False):
+    """(B,T,S,N) posteriors (numpy or torch ROCm tensor) + (B,n_init) initial state scores ->
+    BatchResult of search::crf_greedy_search (src/search.rs:385-423) per read."""
+    if _is_torch_cuda(network_outputs):
+        import torch
+        init = torch.as_tensor(init_states, dtype=torch.float32, device=network_outputs.device).contiguous()
+        r = _torch_call("fcd_crf_greedy_search_dev", network_outputs, True, lengths,
+                        (C.c_void_p(init.data_ptr()), int(init.shape[1]), int(init.shape[1])), want_qual=qual)
+        r._keep = r._keep + (init,)
+        return r
+    x = _stack_host(network_outputs, 4)
+    init = np.ascontiguousarray(np.asarray(init_states, np.float32))
+    B, T, S, N = x.shape
+    if init.ndim != 2 or init.shape[0] != B:
+        raise ValueError("init_states must have shape (n_reads, n_init)")
+    h = nat.default_handle()
+    out = _HostOut(B, T, want_qual=qual)
+    b = _host_batch(x, True, _np_lengths(lengths, B))
+    h.check(h.lib.fcd_crf_greedy_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[1],
+                                             init.shape[1], C.byref(out.res)))
+    return BatchResult(out.labels, out.path, out.out_len, out.status, out.qual)
+
+
+def crf_greedy_search_batch(network_outputs, init_states, alphabet, qstring=False, qscale=1.0, qbias=0.0,
+                            lengths=None, paths="list"):
+    """Batched crf_greedy_search: element i equals crf_greedy_search(network_outputs[i], init_states[i], ...)."""
+    alpha = _seq_to_vec(alphabet)
+    _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
+    r = crf_greedy_search_batch_raw(network_outputs, init_states, lengths, qual=qstring).cpu()
+    res = r.sequences(alpha, paths=paths if paths is not None else "array")
+    if qstring:
+        res = [(s + _qual_chars(r.qual[i, :len(p)], qscale, qbias), p) for i, (s, p) in enumerate(res)]
+    return res
+
+
 _DEFAULT_LOGADD = [nat.LOGADD_LOGSUMEXP]
 
 

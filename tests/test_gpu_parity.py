@@ -539,3 +539,15 @@ def test_half_precision_device_tensors(fcd):
         va, vb = fcd.viterbi_search_batch_raw(xh).cpu(), fcd.viterbi_search_batch_raw(up).cpu()
         np.testing.assert_array_equal(va.out_len, vb.out_len)
         check_beam(fcd, up.cpu().numpy(), 5, 0.1)
+
+
+def test_crf_greedy_batch(fcd):
+    """The batched crf_greedy_search (host arrays and device tensors) equals the single-read calls."""
+    torch = pytest.importorskip("torch")
+    x, init = gen_crf(51, 5, 300)
+    want = [fcd.crf_greedy_search(x[i], init[i], "NACGT") for i in range(5)]
+    assert want == [oracle.crf_greedy_search(x[i], init[i], "NACGT", False) for i in range(5)]
+    assert fcd.crf_greedy_search_batch(x, init, "NACGT") == want
+    assert fcd.crf_greedy_search_batch(torch.from_numpy(x).cuda(), init, "NACGT") == want
+    wq = [fcd.crf_greedy_search(x[i], init[i], "NACGT", True) for i in range(5)]
+    assert fcd.crf_greedy_search_batch(x, init, "NACGT", qstring=True) == wq
