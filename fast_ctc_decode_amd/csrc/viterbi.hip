@@ -309,6 +309,203 @@ __global__ __launch_bounds__(64) void crf_greedy_kernel(BatchDesc in, const floa
     }
 }
 
+
+// crf_greedy_search for small state counts (S <= 8), streamed at HBM rate.
+//
+// The state walk looks serial -- row t is read at the state row t-1 left behind -- but over S states
+// row t is just a function f_t : state -> state (with one extra absorbing value for "out of range",
+// where the reference aborts).  So: every lane takes one row of a 64-row tile, evaluates the
+// first-maximum argmax for ALL S states of its row, packs f_t into 4-bit entries of a 64-bit word,
+// and an inclusive wave scan of function COMPOSITION (six shuffle steps) yields the state every row is
+// entered with.  The visited state then selects each row's label / probability / NaN flag, and the
+// emissions are compacted with ballot + prefix popcount like viterbi_search's.  Tiles arrive through
+// LDS with 16-byte coalesced loads; the next tile is in flight while the current one is scanned.
+template <int S>
+__device__ __forceinline__ uint64_t fn_compose(uint64_t first, uint64_t then) {
+    // (then o first)[s] = then[first[s]], entries 0..S (S = the absorbing "out of range")
+    uint64_t out = 0;
+#pragma unroll
+    for (int s = 0; s <= S; ++s) {
+        const int mid = (int)((first >> (4 * s)) & 15ull);
+        out |= ((then >> (4 * mid)) & 15ull) << (4 * s);
+    }
+    return out;
+}
+
+template <int S>
+__device__ __forceinline__ uint64_t fn_identity() {
+    uint64_t id = 0;
+#pragma unroll
+    for (int s = 0; s <= S; ++s) id |= (uint64_t)s << (4 * s);
+    return id;
+}
+
+__device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
+    const int lo = __shfl_up((int)(uint32_t)v, o), hi = __shfl_up((int)(uint32_t)(v >> 32), o);
+    return ((uint64_t)(uint32_t)hi << 32) | (uint32_t)lo;
+}
+
+constexpr int kCrfTileRows = 64;
+
+template <int S>
+__global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
+    BatchDesc in, const float *init_all, int64_t n_init, int64_t init_stride, ResultDesc out) {
+    extern __shared__ __attribute__((aligned(16))) float s_dyn[];
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (r >= in.n_reads) return;
+    int64_t T = in.T;
+    if (in.lengths) {
+        int64_t t = in.lengths[r];
+        T = t < 0 ? 0 : (t < T ? t : T);
+    }
+    const int N = in.N, n_base = N - 1;
+    const int E = S * N;                      // floats per row
+    const int tile_f = kCrfTileRows * E;      // floats per tile
+    const int nload = (tile_f / 4 + 63) / 64; // float4 loads per lane and tile
+    float *tile = s_dyn + (size_t)wave * tile_f;
+    const float *post = in.post + r * in.stride_read;
+    const int64_t total = T * E;
+    uint8_t *lab = out.labels + r * out.out_stride;
+    uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
+    float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
+
+    // init_state.argmax() :399 (first maximum; NaN -> the reference panics)
+    const float *init = init_all + r * init_stride;
+    int state = 0;
+    bool bad = n_init <= 0;
+    if (!bad) {
+        float m = init[0];
+        bad = m != m;
+        for (int64_t j = 1; j < n_init && !bad; ++j) {
+            const float e = init[j];
+            if (e != e) bad = true;
+            if (e > m) {
+                m = e;
+                state = (int)j;
+            }
+        }
+    }
+    if (state >= S) state = S;  // out of range: the first row would abort
+
+    constexpr int kMaxLoads = 8;  // S * N <= 32 floats per row (the launcher checks)
+    float4 cur[kMaxLoads], nxt[kMaxLoads];
+    auto fetch = [&](int64_t row0, float4 (&v)[kMaxLoads]) {
+        const int64_t f0 = row0 * E;
+#pragma unroll
+        for (int m = 0; m < kMaxLoads; ++m) {
+            if (m >= nload) break;
+            const int64_t fl = (int64_t)(lane + 64 * m) * 4;  // float offset inside the tile
+            const int64_t f = f0 + fl;
+            if (fl + 3 < tile_f && f + 3 < total) {
+                v[m] = *reinterpret_cast<const float4 *>(post + f);
+            } else {
+                v[m].x = (fl < tile_f && f < total) ? post[f] : 0.0f;
+                v[m].y = (fl + 1 < tile_f && f + 1 < total) ? post[f + 1] : 0.0f;
+                v[m].z = (fl + 2 < tile_f && f + 2 < total) ? post[f + 2] : 0.0f;
+                v[m].w = (fl + 3 < tile_f && f + 3 < total) ? post[f + 3] : 0.0f;
+            }
+        }
+    };
+
+    int n_out = 0;
+    if (T > 0) fetch(0, cur);
+    for (int64_t base = 0; base < T; base += kCrfTileRows) {
+        if (base + kCrfTileRows < T) fetch(base + kCrfTileRows, nxt);
+#pragma unroll
+        for (int m = 0; m < kMaxLoads; ++m) {
+            if (m >= nload) break;
+            const int fl = (lane + 64 * m) * 4;
+            if (fl + 3 < tile_f) {
+                *reinterpret_cast<float4 *>(tile + fl) = cur[m];
+            } else {
+                if (fl < tile_f) tile[fl] = cur[m].x;
+                if (fl + 1 < tile_f) tile[fl + 1] = cur[m].y;
+                if (fl + 2 < tile_f) tile[fl + 2] = cur[m].z;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        const int64_t row = base + lane;
+        const bool act = row < T;
+        // this row, for every state: first-maximum argmax (:405), its probability, NaN anywhere in the row
+        const float *pr = tile + lane * E;
+        float prob_s[S];
+        uint32_t labels_packed = 0, nan_mask = 0;
+        uint64_t f = 0;
+#pragma unroll
+        for (int s = 0; s < S; ++s) {
+            float best = pr[s * N];
+            int arg = 0;
+            bool nan = best != best;
+            for (int j = 1; j < N; ++j) {
+                const float v = pr[s * N + j];
+                nan = nan || (v != v);
+                if (v > best) {
+                    best = v;
+                    arg = j;
+                }
+            }
+            prob_s[s] = best;
+            labels_packed |= (uint32_t)arg << (4 * s);
+            nan_mask |= nan ? (1u << s) : 0u;
+            int next = arg > 0 ? (s * n_base) % S + (arg - 1) : s;  // :415
+            if (next >= S) next = S;
+            f |= (uint64_t)next << (4 * s);
+        }
+        f |= (uint64_t)S << (4 * S);          // out of range stays out of range
+        if (!act) f = fn_identity<S>();        // rows past the end change nothing
+
+        // inclusive scan of composition: F_k = f_k o ... o f_0
+        uint64_t F = f;
+#pragma unroll
+        for (int o = 1; o < kWave; o <<= 1) {
+            const uint64_t g = shfl_up_u64(F, o);
+            if (lane >= o) F = fn_compose<S>(g, F);
+        }
+        // the state this row is entered with
+        uint64_t Fprev = shfl_up_u64(F, 1);
+        if (lane == 0) Fprev = fn_identity<S>();
+        const int st = (int)((Fprev >> (4 * state)) & 15ull);
+        // the state the tile leaves behind (wave-uniform)
+        const uint64_t Flast = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(F >> 32), 63) << 32) |
+                               (uint32_t)__shfl((int)(uint32_t)F, 63);
+        const int state_out = (int)((Flast >> (4 * state)) & 15ull);
+
+        // a row entered out of range, or a NaN in the visited state's row: the reference aborts
+        const bool row_bad = act && (st >= S || ((nan_mask >> (st < S ? st : 0)) & 1u));
+        if (ballot(row_bad) != 0ull) bad = true;
+        int label = 0;
+        float prob = 0.0f;
+#pragma unroll
+        for (int s = 0; s < S; ++s)
+            if (st == s) {
+                label = (int)((labels_packed >> (4 * s)) & 15u);
+                prob = prob_s[s];
+            }
+        const bool emit = act && !row_bad && label > 0;
+        const uint64_t m_emit = ballot(emit);
+        const int my_out = n_out + popc64(m_emit & lanemask_lt());
+        if (emit) {
+            lab[my_out] = (uint8_t)label;
+            if (pth) pth[my_out] = (uint32_t)row;
+            if (qual) qual[my_out] = prob;
+        }
+        n_out += popc64(m_emit);
+        state = state_out;
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < kMaxLoads; ++m) cur[m] = nxt[m];
+    }
+    if (lane == 0) {
+        out.out_len[r] = bad ? 0u : (uint32_t)n_out;
+        if (out.status) out.status[r] = bad ? FCD_ST_BAD_STATE : FCD_ST_OK;
+    }
+}
+
 }  // namespace
 
 hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &out,
@@ -337,6 +534,26 @@ hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &o
 hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_init,
                              int64_t init_stride, const ResultDesc &out, hipStream_t stream) {
     if (in.n_reads <= 0) return hipSuccess;
+    // small state counts, C-contiguous rows: the streaming kernel (function-composition scan)
+    const int64_t E = (int64_t)in.S * in.N;
+    const bool stream_ok = in.S >= 1 && in.S <= 8 && in.N >= 1 && in.N <= 15 && E <= 32 && in.stride_n == 1 &&
+                           in.stride_s == in.N && in.stride_t == E && (in.stride_read % 4) == 0 &&
+                           (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
+    if (stream_ok) {
+        const unsigned blocks = (unsigned)((in.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+        const size_t lds = (size_t)kWavesPerBlock * kCrfTileRows * E * sizeof(float);
+        switch (in.S) {
+#define FCD_GSTREAM(SS)                                                                                   \
+    case SS:                                                                                              \
+        hipLaunchKernelGGL(crf_greedy_stream_kernel<SS>, dim3(blocks), dim3(64 * kWavesPerBlock), lds, stream, \
+                           in, init, n_init, init_stride, out);                                           \
+        return hipGetLastError();
+            FCD_GSTREAM(1) FCD_GSTREAM(2) FCD_GSTREAM(3) FCD_GSTREAM(4) FCD_GSTREAM(5) FCD_GSTREAM(6)
+            FCD_GSTREAM(7) FCD_GSTREAM(8)
+#undef FCD_GSTREAM
+            default: break;
+        }
+    }
     hipLaunchKernelGGL(crf_greedy_kernel, dim3((unsigned)in.n_reads), dim3(64), 0, stream, in, init,
                        n_init, init_stride, out);
     return hipGetLastError();

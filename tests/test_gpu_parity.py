@@ -551,3 +551,49 @@ def test_crf_greedy_batch(fcd):
     assert fcd.crf_greedy_search_batch(torch.from_numpy(x).cuda(), init, "NACGT") == want
     wq = [fcd.crf_greedy_search(x[i], init[i], "NACGT", True) for i in range(5)]
     assert fcd.crf_greedy_search_batch(x, init, "NACGT", qstring=True) == wq
+
+
+def crf_greedy_fuzz_seed(fcd, seed):
+    """One random draw of crf_greedy_search: small state counts take the streaming kernel (function
+    composition scan), larger ones the serial walk; ties, NaNs, out-of-range transitions, ragged lengths."""
+    rng = np.random.default_rng(seed)
+    S = int(rng.choice([1, 2, 3, 4, 4, 5, 8, 9, 12]))
+    N = int(rng.integers(2, 8))
+    if S * N > 32 and rng.integers(0, 2):
+        N = max(2, 32 // S)
+    B, T = int(rng.integers(1, 5)), int(rng.integers(1, 400))
+    style = int(rng.integers(0, 3))
+    if style == 0:
+        x = rng.random((B, T, S, N), dtype=np.float32)
+    elif style == 1:
+        x = (rng.integers(0, 3, size=(B, T, S, N)) / 2.0).astype(np.float32)   # ties: first maximum wins
+    else:
+        x = rng.random((B, T, S, N), dtype=np.float32)
+        x[..., 0] += 0.7                                                       # mostly blanks
+    if rng.integers(0, 6) == 0:
+        x[rng.integers(0, B), rng.integers(0, T), rng.integers(0, S), rng.integers(0, N)] = np.nan
+    init = rng.random((B, int(rng.choice([S, S, S + 2])))).astype(np.float32)
+    lengths = rng.integers(0, T + 1, size=B).astype(np.int64) if rng.integers(0, 3) == 0 else None
+    alpha = "N" + "ACGTUVW"[:N - 1]
+    r = fcd.crf_greedy_search_batch_raw(x, init, lengths, qual=True)
+    for i in range(B):
+        Ti = T if lengths is None else int(lengths[i])
+        ctx = (seed, i, S, N, Ti)
+        if Ti == 0:
+            assert int(r.out_len[i]) == 0, ctx
+            continue
+        try:
+            seq, path = oracle.crf_greedy_search(np.ascontiguousarray(x[i, :Ti]), init[i], alpha, False)
+        except RuntimeError:
+            assert int(r.status[i]) == fcd.api.nat.ST_BAD_STATE, ctx
+            continue
+        assert int(r.status[i]) == 0, ctx
+        n = int(r.out_len[i])
+        assert "".join(alpha[l] for l in r.labels[i, :n]) == seq and r.path[i, :n].tolist() == path, ctx
+        qs = oracle.crf_greedy_search(np.ascontiguousarray(x[i, :Ti]), init[i], alpha, True)[0][n:]
+        assert "".join(oracle.phred(float(q)) for q in r.qual[i, :n]) == qs, ctx
+
+
+def test_crf_greedy_fuzz(fcd):
+    for seed in range(7000, 7060):
+        crf_greedy_fuzz_seed(fcd, seed)
