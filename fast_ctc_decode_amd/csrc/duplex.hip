@@ -778,7 +778,9 @@ __global__ __launch_bounds__(64, 3) void duplex_kernel(DuplexParams p) {
             else v = load_i32_l2(&rows[(int64_t)L.b_node(nxt)[s] * NL + l]);
             L.b_child(nxt)[s * NL + l] = v;
         }
-        if (crf) {  // a state outside [0, S) is an ndarray index panic in the reference (:749)
+        // a state outside [0, S) is an ndarray index panic in the reference when the entry is next
+        // expanded (:749) -- which never happens for the entries the last row leaves behind
+        if (crf && t1 + 1 < T1) {
             bool bs = false;
             for (int s2 = lane; s2 < Bn; s2 += kWave) bs = bs || L.b_state(nxt)[s2] >= S;
             if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);

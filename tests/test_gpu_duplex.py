@@ -327,3 +327,53 @@ def test_crf_duplex_device_tensors(fcd):
         want = oracle.crf_beam_search_duplex(ps[i][0], ps[i][1], ps[i][2], ps[i][3], "NACGT", env[i], 5, 0.0,
                                              LSE | CR)
         assert "".join("NACGT"[l] for l in host.labels[i, :n]) == want
+
+
+def crf_duplex_fuzz_seed(fcd, seed, mode):
+    """Random CRF pairs (state counts, alphabets, beams, thresholds, envelopes, init scores with ties):
+    consensus strings and error texts must equal the correctly rounded oracle's."""
+    rng = np.random.default_rng(seed)
+    S = int(rng.choice([1, 2, 4, 4, 5]))
+    N = int(rng.integers(3, 6))
+    T1, T2 = int(rng.integers(2, 45)), int(rng.integers(2, 45))
+    beam = int(rng.choice([1, 3, 5, 8]))
+    thr = float(rng.choice([0.0, 0.0, 0.05, 0.15]))
+    x1 = rng.random((T1, S, N), dtype=np.float32)
+    x2 = rng.random((T2, S, N), dtype=np.float32)
+    if rng.integers(0, 3) == 0:
+        x1 = (rng.integers(1, 4, size=x1.shape) / 4.0).astype(np.float32)   # ties
+        x2 = (rng.integers(1, 4, size=x2.shape) / 4.0).astype(np.float32)
+    x1 /= x1.sum(-1, keepdims=True)
+    x2 /= x2.sum(-1, keepdims=True)
+    i1 = np.round(rng.random(S) * 2).astype(np.float32) / 2
+    i2 = np.round(rng.random(S) * 2).astype(np.float32) / 2
+    env = None
+    if rng.integers(0, 2):
+        w = int(rng.integers(3, 20))
+        i = np.arange(T1)
+        c = (i * T2) // T1
+        env = np.stack([np.maximum(0, c - w), np.minimum(T2, c + w + 1)], 1).astype(np.uint64)
+        env[0, 0] = 0
+        env[-1, 1] = T2
+        env[1:, 0] = np.minimum(env[1:, 0], env[:-1, 1])
+    alpha = "N" + "ACGTUV"[:N - 1]
+    omode = mode | CR
+    try:
+        want = oracle.crf_beam_search_duplex(x1, i1, x2, i2, alpha, env, beam, thr, omode)
+    except RuntimeError as e:
+        want = str(e)
+    try:
+        got = fcd.crf_beam_search_duplex(x1.astype(np.float32), i1, x2.astype(np.float32), i2, alpha, env, beam, thr,
+                                         logadd_mode=(0 if mode == LSE else 1))
+    except RuntimeError as e:
+        got = str(e)
+    if "panic" in want:
+        assert "abort" in got, (seed, S, N, T1, T2, beam, thr, got, want)
+    else:
+        assert got == want, (seed, S, N, T1, T2, beam, thr)
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_crf_duplex_fuzz(fcd, mode):
+    for seed in range(8000, 8012):
+        crf_duplex_fuzz_seed(fcd, seed, mode)

@@ -1,5 +1,5 @@
 """Long randomised differential run (GPU vs oracle), beyond what the test suite samples:
-    python tools/soak.py [n_seeds] [first_seed] [beam|crf|crf_greedy|viterbi|duplex|envelope]
+    python tools/soak.py [n_seeds] [first_seed] [beam|crf|crf_greedy|crf_duplex|viterbi|duplex|envelope]
 Reuses the fuzz generators of tests/test_gpu_parity.py; prints one line per failing seed."""
 import os
 import sys
@@ -25,6 +25,9 @@ def other(which, n, first):
                 tp.crf_fuzz_seed(fcd, seed)
             elif which == "viterbi":
                 tp.viterbi_fuzz_seed(fcd, seed)
+            elif which == "crf_duplex":
+                td.crf_duplex_fuzz_seed(fcd, seed, td.LSE)
+                td.crf_duplex_fuzz_seed(fcd, seed, td.MAX)
             elif which == "crf_greedy":
                 tp.crf_greedy_fuzz_seed(fcd, seed)
             elif which == "envelope":
