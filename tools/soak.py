@@ -1,5 +1,5 @@
 """Long randomised differential run (GPU vs oracle), beyond what the test suite samples:
-    python tools/soak.py [n_seeds] [first_seed] [beam|crf|crf_greedy|crf_duplex|viterbi|duplex|envelope]
+    python tools/soak.py [n_seeds] [first_seed] [beam|beam_long|crf|crf_greedy|crf_duplex|viterbi|duplex|envelope]
 Reuses the fuzz generators of tests/test_gpu_parity.py; prints one line per failing seed."""
 import os
 import sys
@@ -25,6 +25,20 @@ def other(which, n, first):
                 tp.crf_fuzz_seed(fcd, seed)
             elif which == "viterbi":
                 tp.viterbi_fuzz_seed(fcd, seed)
+            elif which == "beam_long":
+                # long reads: FIFO refills, row reloads, jump-pointer traceback across many segments
+                rng = np.random.default_rng(seed)
+                N = int(rng.integers(3, 8))
+                T = int(rng.integers(200, 3000))
+                beam = int(rng.choice([1, 2, 5, 5, 8, 10, 12, 20]))
+                x = tp.gen_batch(seed, int(rng.integers(1, 4)), T, N, peaky=bool(rng.integers(0, 2)))
+                thr = float(rng.choice([0.0, 0.001, 0.1]))
+                lengths = rng.integers(1, T + 1, size=x.shape[0]).astype(np.int64) if rng.integers(0, 2) else None
+                for kernel in (0, 1, 2, 3):
+                    try:
+                        tp.check_beam(fcd, x, beam, thr, True, lengths=lengths, kernel=kernel)
+                    except RuntimeError as e:
+                        assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
             elif which == "crf_duplex":
                 td.crf_duplex_fuzz_seed(fcd, seed, td.LSE)
                 td.crf_duplex_fuzz_seed(fcd, seed, td.MAX)
