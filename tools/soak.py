@@ -1,5 +1,5 @@
 """Long randomised differential run (GPU vs oracle), beyond what the test suite samples:
-    python tools/soak.py [n_seeds] [first_seed] [beam|beam_long|crf|crf_greedy|crf_duplex|viterbi|duplex|envelope]
+    python tools/soak.py [n_seeds] [first_seed] [beam|beam_long|duplex_long|crf|crf_greedy|crf_duplex|viterbi|duplex|envelope]
 Reuses the fuzz generators of tests/test_gpu_parity.py; prints one line per failing seed."""
 import os
 import sys
@@ -39,6 +39,22 @@ def other(which, n, first):
                         tp.check_beam(fcd, x, beam, thr, True, lengths=lengths, kernel=kernel)
                     except RuntimeError as e:
                         assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
+            elif which == "duplex_long":
+                rng = np.random.default_rng(seed)
+                T1, T2 = int(rng.integers(100, 500)), int(rng.integers(100, 500))
+                w = int(rng.integers(4, 70))
+                x1, x2 = td.pairs(seed, 2, T1, T2, 5)
+                i = np.arange(T1)
+                c = (i * T2) // T1
+                env = np.stack([np.maximum(0, c - w), np.minimum(T2, c + w + 1)], 1).astype(np.uint64)
+                env[0, 0], env[-1, 1] = 0, T2
+                env[1:, 0] = np.minimum(env[1:, 0], env[:-1, 1])
+                envs = np.broadcast_to(env, (2, T1, 2)).copy()
+                for mode in (td.LSE, td.MAX):
+                    beam, thr = int(rng.choice([3, 5, 8])), float(rng.choice([0.0, 0.1]))
+                    want = td.oracle_strings(x1, x2, "NACGT", envs, beam, thr, True, mode | td.CR)
+                    got = td.gpu_strings(fcd, x1, x2, "NACGT", envs, beam, thr, True, mode)
+                    assert got == want, (seed, T1, T2, w, beam, thr, mode)
             elif which == "crf_duplex":
                 td.crf_duplex_fuzz_seed(fcd, seed, td.LSE)
                 td.crf_duplex_fuzz_seed(fcd, seed, td.MAX)
