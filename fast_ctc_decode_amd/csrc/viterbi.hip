@@ -320,25 +320,42 @@ __global__ __launch_bounds__(64) void crf_greedy_kernel(BatchDesc in, const floa
 // entered with.  The visited state then selects each row's label / probability / NaN flag, and the
 // emissions are compacted with ballot + prefix popcount like viterbi_search's.  Tiles arrive through
 // LDS with 16-byte coalesced loads; the next tile is in flight while the current one is scanned.
+// A state -> state function over S + 1 <= 16 values, as 4-bit entries of a 64-bit word; for S <= 7
+// the entries are whole BYTES instead (8 of them), because then composing two functions is exactly
+// what v_perm_b32 does -- pick bytes of one operand pair by the selector bytes of another: two
+// instructions per composition instead of ~30 shift/mask operations.
 template <int S>
-__device__ __forceinline__ uint64_t fn_compose(uint64_t first, uint64_t then) {
-    // (then o first)[s] = then[first[s]], entries 0..S (S = the absorbing "out of range")
-    uint64_t out = 0;
+struct FnTable {
+    static constexpr bool kBytes = S <= 7;
+    static constexpr int kBits = kBytes ? 8 : 4;
+    __device__ static __forceinline__ uint64_t compose(uint64_t first, uint64_t then) {
+        // (then o first)[s] = then[first[s]]
+        if (kBytes) {
+            const uint32_t tl = (uint32_t)then, th = (uint32_t)(then >> 32);
+            const uint32_t lo = __builtin_amdgcn_perm(th, tl, (uint32_t)first);
+            const uint32_t hi = __builtin_amdgcn_perm(th, tl, (uint32_t)(first >> 32));
+            return ((uint64_t)hi << 32) | lo;
+        }
+        uint64_t out = 0;
 #pragma unroll
-    for (int s = 0; s <= S; ++s) {
-        const int mid = (int)((first >> (4 * s)) & 15ull);
-        out |= ((then >> (4 * mid)) & 15ull) << (4 * s);
+        for (int s = 0; s <= S; ++s) {
+            const int mid = (int)((first >> (4 * s)) & 15ull);
+            out |= ((then >> (4 * mid)) & 15ull) << (4 * s);
+        }
+        return out;
     }
-    return out;
-}
-
-template <int S>
-__device__ __forceinline__ uint64_t fn_identity() {
-    uint64_t id = 0;
+    __device__ static __forceinline__ uint64_t identity() {
+        if (kBytes) return 0x0706050403020100ull;
+        uint64_t id = 0;
 #pragma unroll
-    for (int s = 0; s <= S; ++s) id |= (uint64_t)s << (4 * s);
-    return id;
-}
+        for (int s = 0; s <= S; ++s) id |= (uint64_t)s << (4 * s);
+        return id;
+    }
+    __device__ static __forceinline__ uint64_t entry(int s, int value) { return (uint64_t)value << (kBits * s); }
+    __device__ static __forceinline__ int at(uint64_t f, int s) {
+        return (int)((f >> (kBits * s)) & (kBytes ? 255ull : 15ull));
+    }
+};
 
 __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
     const int lo = __shfl_up((int)(uint32_t)v, o), hi = __shfl_up((int)(uint32_t)(v >> 32), o);
@@ -454,26 +471,32 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
             nan_mask |= nan ? (1u << s) : 0u;
             int next = arg > 0 ? (s * n_base) % S + (arg - 1) : s;  // :415
             if (next >= S) next = S;
-            f |= (uint64_t)next << (4 * s);
+            f |= FnTable<S>::entry(s, next);
         }
-        f |= (uint64_t)S << (4 * S);          // out of range stays out of range
-        if (!act) f = fn_identity<S>();        // rows past the end change nothing
+        // out of range stays out of range (byte tables: the unused upper entries map to themselves)
+        if (FnTable<S>::kBytes) {
+#pragma unroll
+            for (int s2 = S; s2 < 8; ++s2) f |= FnTable<S>::entry(s2, s2 == S ? S : s2);
+        } else {
+            f |= FnTable<S>::entry(S, S);
+        }
+        if (!act) f = FnTable<S>::identity();  // rows past the end change nothing
 
         // inclusive scan of composition: F_k = f_k o ... o f_0
         uint64_t F = f;
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) {
             const uint64_t g = shfl_up_u64(F, o);
-            if (lane >= o) F = fn_compose<S>(g, F);
+            if (lane >= o) F = FnTable<S>::compose(g, F);
         }
         // the state this row is entered with
         uint64_t Fprev = shfl_up_u64(F, 1);
-        if (lane == 0) Fprev = fn_identity<S>();
-        const int st = (int)((Fprev >> (4 * state)) & 15ull);
+        if (lane == 0) Fprev = FnTable<S>::identity();
+        const int st = FnTable<S>::at(Fprev, state);
         // the state the tile leaves behind (wave-uniform)
         const uint64_t Flast = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(F >> 32), 63) << 32) |
                                (uint32_t)__shfl((int)(uint32_t)F, 63);
-        const int state_out = (int)((Flast >> (4 * state)) & 15ull);
+        const int state_out = FnTable<S>::at(Flast, state);
 
         // a row entered out of range, or a NaN in the visited state's row: the reference aborts
         const bool row_bad = act && (st >= S || ((nan_mask >> (st < S ? st : 0)) & 1u));
