@@ -31,4 +31,6 @@ from .api import (  # noqa: F401
     viterbi_search_batch,
     viterbi_search_batch_raw,
 )
-from ._native import KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE1, LOGADD_LOGSUMEXP, LOGADD_MAX  # noqa: F401
+from ._native import (  # noqa: F401
+    KERNEL_AUTO, KERNEL_GENERIC, KERNEL_LANE, KERNEL_WAVE, KERNEL_WAVE1, LOGADD_LOGSUMEXP, LOGADD_MAX,
+)

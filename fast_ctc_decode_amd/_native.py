@@ -14,7 +14,7 @@ LIB_PATH = os.environ.get("FCD_LIB_PATH") or os.path.join(_HERE, "libfcd_hip.so"
 OK = 0
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
 ST_OK, ST_RAN_OUT_OF_BEAM, ST_INCOMPARABLE, ST_INVALID_ENVELOPE, ST_BAD_STATE, ST_INTERNAL = range(6)
-KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE1 = 0, 1, 2, 3
+KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE1, KERNEL_LANE = 0, 1, 2, 3, 4
 LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
 
 # every symbol include/fcd.h declares (tests/test_capi_symbols.py checks the .so against this

@@ -1,0 +1,499 @@
+// beam_lane.hip -- CTC prefix beam search (search::beam_search, /root/reference/src/search.rs:159-301)
+// for WIDE beams: one beam ENTRY per lane, beam_size <= 64, N <= 8, one read per wavefront.
+//
+// beam_wave.hip gives every candidate slot its own lane, which stops at 12 beam entries x 5 lanes;
+// beam_generic.hip keeps the beam in LDS and spends ~2500 instructions per step at beam 32.  Here lane i
+// holds beam entry i (rank order) with its whole state in registers -- node, label/gap probability,
+// tip, depth, jump pointer and the node's child entries -- and evaluates the entry's own candidate
+// and its N-1 extensions itself, so the expansion needs no cross-lane traffic at all:
+//   * the posterior row is wave-uniform: v_readlane out of a register FIFO filled by coalesced loads;
+//   * an extension whose target is already a beam entry (IN-BEAM/slot bits in the child entry, as in
+//     beam_wave.hip) is dropped into that entry's slot of a 64-entry LDS table -- a node has one
+//     parent, so at most one write per slot -- and picked up by the target lane (:245-260: at most
+//     two non-zero f32 addends meet, so the fold order is immaterial);
+//   * new nodes are numbered in the reference's creation order (beam order x label order) with a
+//     wave prefix sum of the per-lane counts;
+//   * prune: a 256-bucket histogram over "distance below the step's maximum probability" finds the
+//     bucket of the beam_size-th largest candidate; the candidates in that bucket or above are
+//     compacted into a list and ranked exactly on the 64-bit key (probability desc, node asc); ranks
+//     travel back to the owning lanes through a byte table; heavily tied steps fall back to all-pairs;
+//   * survivors publish their record in rank order (LDS), lane r picks up record r, the child entries
+//     follow through a second table, a re-entering node re-reads its row from HBM.
+// Tree arena and the segment-parallel leaf -> root walk are beam_wave.hip's.
+#include "device_utils.h"
+#include "fcd_internal.h"
+
+namespace fcd {
+
+namespace {
+
+// child entry: node id in bits 0..22, beam slot in bits 23..28, IN-BEAM bit 29, EVER bit 30
+constexpr int kEver = 1 << 30;
+constexpr int kInBeam = 1 << 29;
+constexpr int kSlotShift = 23;
+constexpr int kSlotMask = 63;
+constexpr int kIdMask = (1 << 23) - 1;
+constexpr int kStored = kEver | kIdMask;
+
+constexpr int kSeg = 64;        // nodes per traceback segment
+constexpr int kFifo = 4;        // registers in the row FIFO
+constexpr int kBuckets = 256;   // prune pre-selection histogram
+constexpr int kBucketShift = 18;
+constexpr int kListCap = 128;
+
+struct LaneParams {
+    BatchDesc in;
+    BeamArgs a;
+    WaveArena arena;
+    ResultDesc out;
+    int64_t read_begin;
+};
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_or_zero(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// inclusive prefix sum over the 64 lanes (the classic GCN DPP scan; see envelope.hip)
+__device__ __forceinline__ int wave_prefix_add(int x) {
+    int t = x + dpp_or_zero<0x111, 0xf, 0xf>(x);
+    t += dpp_or_zero<0x112, 0xf, 0xf>(x);
+    t += dpp_or_zero<0x113, 0xf, 0xf>(x);
+    t += dpp_or_zero<0x114, 0xf, 0xe>(t);
+    t += dpp_or_zero<0x118, 0xf, 0xc>(t);
+    t += dpp_or_zero<0x142, 0xa, 0xf>(t);
+    t += dpp_or_zero<0x143, 0xc, 0xf>(t);
+    return t;
+}
+
+__device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rdlanef(float v, int l) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
+}
+
+template <int N>
+__global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
+    constexpr int NL = N - 1;
+    constexpr int RPR = 64 / N;          // rows per FIFO register
+    constexpr int RW = NL <= 4 ? 4 : 8;  // child-row width in the arena
+    static_assert(N >= 2 && N <= 8, "candidate ids are lane * 8 + k");
+
+    __shared__ uint64_t s_inc[64];                        // {flag, contribution} pushed to a beam slot
+    __shared__ __attribute__((aligned(16))) int4 s_u[64 * N / 2 > 160 ? 64 * N / 2 : 160];  // hist+list | all keys
+    __shared__ __attribute__((aligned(8))) int8_t s_rank[64 * 8];  // rank of candidate (lane, k), -1 = out
+    __shared__ __attribute__((aligned(16))) int4 s_rec[64 * 2];     // survivor records by rank
+    __shared__ int s_fate[64];                           // new slot of old slot i's own candidate, or -1
+    __shared__ __attribute__((aligned(16))) int s_child[64 * RW];   // child entries of old slot i
+    __shared__ int s_heads[64];
+
+    int *hist = reinterpret_cast<int *>(s_u);                        // 256 ints      (1 KB)
+    uint64_t *l_key = reinterpret_cast<uint64_t *>(s_u + 64);        // 128 u64      (1 KB)
+    int *l_src = reinterpret_cast<int *>(s_u + 128);                 // 128 ints     (0.5 KB)
+    uint64_t *c_key = reinterpret_cast<uint64_t *>(s_u);             // 64 * N u64, fallback only
+
+    const int lane = threadIdx.x;
+    const int64_t local = blockIdx.x;
+    const int64_t r = p.read_begin + local;
+    const int beam_size = p.a.beam_size;
+    const bool collapse = p.a.collapse != 0;
+    const float thr = p.a.thr;
+
+    int64_t t64 = p.in.T;
+    if (p.in.lengths) {
+        const int64_t tl = p.in.lengths[r];
+        t64 = tl < 0 ? 0 : (tl < t64 ? tl : t64);
+    }
+    const int T = (int)t64;
+    const float *post = p.in.post + r * p.in.stride_read;
+    const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n;
+    int2 *rec = p.arena.rec + local * p.arena.cap_nodes;
+    int32_t *jmp = p.arena.jmp + local * p.arena.cap_nodes;
+    int32_t *rows = p.arena.rows + local * p.arena.cap_nodes * RW;
+    const int cap = (int)p.arena.cap_nodes;
+
+    // ---- beam state: lane i = beam entry i (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
+    int node = -1;
+    float lp = 0.0f, gp = 1.0f;
+    int tip = -1;
+    int depth = 0;
+    int jump = -1;
+    int child[NL];
+#pragma unroll
+    for (int l = 0; l < NL; ++l) child[l] = -1;
+    int B = 1;
+    int nn = 0;
+
+    // ---- row FIFO: register j holds rows [blk*RPR, blk*RPR + RPR) of block (front + j) ----
+    const int fg = lane / N, fc = lane - fg * N;
+    const bool f_lane = lane < RPR * N;
+    auto load_block = [&](int blk) -> float {
+        const int row = blk * RPR + fg;
+        return (f_lane && row < T) ? post[(int64_t)row * st_t + fc * st_n] : 0.0f;
+    };
+    float win[kFifo];
+#pragma unroll
+    for (int j = 0; j < kFifo; ++j) win[j] = load_block(j);
+    float incoming = load_block(kFifo);
+    int g = 0, blk = 0;
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see beam_wave.hip
+
+    bool failed = false;
+    for (int t = 0; t < T; ++t) {
+        // ---- the posterior row, wave-uniform ----
+        float pr[N];
+#pragma unroll
+        for (int c = 0; c < N; ++c) pr[c] = rdlanef(win[0], g * N + c);
+        if (++g == RPR) {
+            g = 0;
+#pragma unroll
+            for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            win[kFifo - 1] = incoming;
+            ++blk;
+            incoming = load_block(blk + kFifo);
+        }
+        const bool ent = lane < B;
+
+        // ---- extensions by label l (:200-239); targets that are beam entries get the push ----
+        s_inc[lane] = 0ull;
+        wave_sync();
+        float contrib[NL];
+        bool cvalid[NL], merged[NL];
+        int ccand[NL];  // candidate id of extension l (existing child or the new node)
+        int n_new = 0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float pk = pr[l + 1];
+            const bool pass = !(pk < thr);  // :201 skips only when pr_b < thr
+            const bool rep = collapse && l == tip;
+            contrib[l] = rep ? gp * pk : (lp + gp) * pk;
+            const int ch = child[l];
+            const bool exists = ch >= 0;
+            cvalid[l] = ent && pass && (exists || !rep || gp > 0.0f);  // :212-218
+            merged[l] = cvalid[l] && exists && (ch & kInBeam);
+            if (merged[l])
+                s_inc[(ch >> kSlotShift) & kSlotMask] = (1ull << 32) | (uint32_t)__float_as_int(contrib[l]);
+            n_new += (cvalid[l] && !exists) ? 1 : 0;
+        }
+        wave_sync();
+
+        // ---- the entry's own node: blank (:191-198) + repeat-stay (:206-211) + incoming extension ----
+        const uint64_t iv = s_inc[lane];
+        const bool has_inc = ent && (iv >> 32) != 0ull;
+        const float inc = __int_as_float((int)(uint32_t)iv);
+        float ptip = 0.0f;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) ptip = (tip == l) ? pr[l + 1] : ptip;
+        const float pr0 = pr[0];
+        const bool blank = pr0 > thr;
+        const float gpn = (lp + gp) * pr0;
+        const bool stay = collapse && tip >= 0 && !(ptip < thr);
+        const float lpn = lp * ptip;
+        const float slp = (stay ? lpn : 0.0f) + (has_inc ? inc : 0.0f);
+        const float sgp = blank ? gpn : 0.0f;
+        const bool svalid = ent && (blank || stay || has_inc);
+
+        // ---- tree.rs:125-145 add_node: ids in (beam order, label order) ----
+        const int incl = wave_prefix_add(n_new);
+        int next_id = nn + incl - n_new;
+        nn += rdlane(incl, 63);
+        const bool f_cap = nn > cap;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const bool is_new = cvalid[l] && child[l] < 0;
+            if (is_new && !f_cap) {
+                const int id = next_id++;
+                rec[id] = make_int2(node, (t << 3) | l);
+                if ((depth + 1) % kSeg == 0) jmp[id] = (depth % kSeg == 0) ? node : jump;
+                child[l] = id;
+            }
+            ccand[l] = child[l] & kIdMask;
+        }
+
+        // ---- search.rs:261-277 ----
+        uint64_t key[N];
+        float clp[N], cgp[N];
+        clp[0] = slp;
+        cgp[0] = sgp;
+        bool cand_valid[N];
+        cand_valid[0] = svalid;
+        int n_valid = popc64(ballot(svalid));
+        bool any_nan = ballot(svalid && (slp + sgp) != (slp + sgp)) != 0ull;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            clp[l + 1] = contrib[l];
+            cgp[l + 1] = 0.0f;
+            cand_valid[l + 1] = cvalid[l] && !merged[l];
+            n_valid += popc64(ballot(cand_valid[l + 1]));
+            any_nan = any_nan || ballot(cand_valid[l + 1] && contrib[l] != contrib[l]) != 0ull;
+        }
+        if ((n_valid >= 2 && any_nan) || n_valid == 0 || f_cap) {
+            if (lane == 0) {
+                p.out.status[r] = f_cap ? FCD_ST_INTERNAL
+                                        : (n_valid == 0 ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
+                p.out.out_len[r] = 0;
+            }
+            failed = true;
+            break;
+        }
+        // (a NaN that gets this far is the lone candidate of the read: any non-zero key ranks it first)
+        key[0] = svalid ? make_key(slp + sgp, node) : 0ull;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) key[l + 1] = cand_valid[l + 1] ? make_key(contrib[l], ccand[l]) : 0ull;
+
+        // ---- prune: the top beam_size candidates in exact key order ----
+        const int Bn = n_valid < beam_size ? n_valid : beam_size;
+        int rank[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) rank[k] = -1;
+        int bstar = kBuckets - 1;
+        int Lc = n_valid;
+        uint32_t mx = 0;
+        if (n_valid > beam_size) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const uint32_t hi = (uint32_t)(key[k] >> 32);
+                mx = hi > mx ? hi : mx;
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const uint32_t other = (uint32_t)__shfl_xor((int)mx, o);
+                mx = other > mx ? other : mx;
+            }
+            *reinterpret_cast<int4 *>(hist + 4 * lane) = make_int4(0, 0, 0, 0);
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                if (key[k] != 0ull) {
+                    const uint32_t d = (mx - (uint32_t)(key[k] >> 32)) >> kBucketShift;
+                    atomicAdd(&hist[d < (uint32_t)(kBuckets - 1) ? d : (uint32_t)(kBuckets - 1)], 1);
+                }
+            wave_sync();
+            const int4 h = *reinterpret_cast<const int4 *>(hist + 4 * lane);
+            const int s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
+            const int hin = wave_prefix_add(s3);
+            const int hex = hin - s3;
+            const bool cross = hex < beam_size && hin >= beam_size;  // exactly one lane (total > beam_size)
+            const int kk = (hex + s0 >= beam_size) ? 0 : (hex + s1 >= beam_size) ? 1 : (hex + s2 >= beam_size) ? 2 : 3;
+            const int cum = hex + (kk == 0 ? s0 : kk == 1 ? s1 : kk == 2 ? s2 : s3);
+            const int owner = __builtin_ctzll(ballot(cross));
+            bstar = rdlane(4 * lane + kk, owner);
+            Lc = rdlane(cum, owner);
+            wave_sync();  // the list overwrites nothing of the histogram, but keep the phases apart
+        }
+        if (Lc <= kListCap) {
+            int base = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                bool in = key[k] != 0ull;
+                if (in && n_valid > beam_size) {
+                    const uint32_t d = (mx - (uint32_t)(key[k] >> 32)) >> kBucketShift;
+                    in = (int)(d < (uint32_t)(kBuckets - 1) ? d : (uint32_t)(kBuckets - 1)) <= bstar;
+                }
+                const uint64_t m_in = ballot(in);
+                if (in) {
+                    const int pos = base + popc64(m_in & lanemask_lt());
+                    l_key[pos] = key[k];
+                    l_src[pos] = lane * 8 + k;
+                }
+                base += popc64(m_in);
+            }
+            *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
+            wave_sync();
+            for (int e = lane; e < Lc; e += kWave) {
+                const uint64_t ke = l_key[e];
+                int rk = 0;
+                for (int j = 0; j < Lc; ++j) rk += (l_key[j] > ke) ? 1 : 0;
+                if (rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+            }
+            wave_sync();
+            const uint64_t mine = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
+#pragma unroll
+            for (int k = 0; k < N; ++k) rank[k] = (int)(int8_t)(uint8_t)(mine >> (8 * k));
+        } else {
+            // heavily tied (or extremely spread) probabilities: rank every candidate against all of them
+#pragma unroll
+            for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
+            wave_sync();
+            int rk[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) rk[k] = 0;
+            for (int j = 0; j < kWave * N; ++j) {
+                const uint64_t kj = c_key[j];
+#pragma unroll
+                for (int k = 0; k < N; ++k) rk[k] += (kj > key[k]) ? 1 : 0;
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) rank[k] = (key[k] != 0ull && rk[k] < beam_size) ? rk[k] : -1;
+            wave_sync();
+        }
+
+        // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
+        s_fate[lane] = rank[0];
+#pragma unroll
+        for (int k = 0; k < N; ++k) {
+            if (rank[k] >= 0) {
+                const bool self = k == 0;
+                const int l = k - 1;
+                const int kind = self ? 0 : ((child[self ? 0 : l] & kEver) ? 2 : 1);  // 2: re-entering, row is in HBM
+                const int tipc = self ? tip : l;
+                const int depc = self ? depth : depth + 1;
+                const int jumpc = self ? jump : ((depth % kSeg == 0) ? node : jump);
+                const int idc = self ? node : ccand[self ? 0 : l];
+                const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
+                s_rec[2 * rank[k]] = make_int4(__float_as_int(clp[k]), __float_as_int(cgp[k]), idc, meta);
+                s_rec[2 * rank[k] + 1] = make_int4(jumpc, lane, k, 0);
+            }
+        }
+        wave_sync();
+
+        // ---- child entries: follow a beam entry to its new slot, mark entering children, evict rows ----
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            int ch = child[l];
+            if (ent && ch >= 0) {
+                if (ch & kInBeam) {
+                    const int fate = s_fate[(ch >> kSlotShift) & kSlotMask];
+                    ch = (ch & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
+                } else if (rank[l + 1] >= 0) {
+                    ch = (ch & kIdMask) | kEver | kInBeam | (rank[l + 1] << kSlotShift);
+                }
+            }
+            child[l] = ch;
+        }
+        if (ent && rank[0] < 0 && node >= 0) {
+            // this node leaves the beam: its child row has to exist in HBM from now on
+            int32_t *row = rows + (int64_t)node * RW;
+            int v[RW];
+#pragma unroll
+            for (int l = 0; l < RW; ++l) v[l] = (l < NL && child[l < NL ? l : 0] >= 0) ? (child[l < NL ? l : 0] & kStored) : -1;
+            *reinterpret_cast<int4 *>(row) = make_int4(v[0], v[1], v[2], v[3]);
+            if (RW == 8) *reinterpret_cast<int4 *>(row + 4) = make_int4(v[4 % RW], v[5 % RW], v[6 % RW], v[7 % RW]);
+        }
+#pragma unroll
+        for (int l = 0; l < RW; ++l) s_child[lane * RW + l] = l < NL ? child[l < NL ? l : 0] : -1;
+        wave_sync();
+
+        // ---- the new beam: lane r takes record r ----
+        const int me = lane < Bn ? lane : 0;
+        const int4 ra = s_rec[2 * me], rb = s_rec[2 * me + 1];
+        const int2 r0 = *reinterpret_cast<const int2 *>(&s_rec[0]);
+        const int n_node = ra.z;
+        const int n_meta = ra.w;
+        const int n_kind = n_meta & 3;
+        const int src = rb.y;
+        int n_child[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) n_child[l] = n_kind == 0 ? s_child[src * RW + l] : -1;
+        const bool reload = lane < Bn && n_kind == 2;
+        if (ballot(reload) != 0ull) {
+            // a node that was in the beam before comes back: its row is in HBM, and which of its
+            // children are beam entries right now has to be looked up
+            int e[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) e[l] = reload ? load_i32_l2(&rows[(int64_t)n_node * RW + l]) : -1;
+            for (int j = 0; j < Bn; ++j) {
+                const int nj = rdlane(n_node, j);
+#pragma unroll
+                for (int l = 0; l < NL; ++l)
+                    if (e[l] >= 0 && (e[l] & kIdMask) == nj) e[l] = (e[l] & kStored) | kInBeam | (j << kSlotShift);
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                if (reload) n_child[l] = e[l];
+        }
+        const float top = __int_as_float(r0.x) + __int_as_float(r0.y);  // beam[0].probability() :278
+        if (lane < Bn) {
+            node = n_node;
+            lp = __int_as_float(ra.x) / top;
+            gp = __int_as_float(ra.y) / top;
+            tip = ((n_meta >> 2) & 7) - 1;
+            depth = n_meta >> 5;
+            jump = rb.x;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) child[l] = n_child[l];
+        }
+        B = Bn;
+        wave_sync();
+    }
+    if (failed) return;
+
+    // ---- walk the best labelling leaf -> root (:285-300), segment-parallel (see beam_wave.hip) ----
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    uint8_t *lab = p.out.labels + r * p.out.out_stride;
+    uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
+    if (lane == 0) {
+        p.out.out_len[r] = (uint32_t)depth;
+        p.out.status[r] = FCD_ST_OK;
+    }
+    int h0 = rdlane(node, 0);
+    int d0 = rdlane(depth, 0);
+    const int j0 = rdlane(jump, 0);
+    while (d0 > 0) {
+        int cnt = 0, nh = h0, nd = d0;
+        if (lane == 0) {
+            while (cnt < kWave && nd > 0) {
+                s_heads[cnt] = nh;
+                nh = (nd % kSeg != 0) ? j0 : jmp[nh];
+                nd = ((nd - 1) / kSeg) * kSeg;
+                ++cnt;
+            }
+        }
+        cnt = rdlane(cnt, 0);
+        nh = rdlane(nh, 0);
+        nd = rdlane(nd, 0);
+        wave_sync();
+        if (lane < cnt) {
+            const int d1 = ((d0 - 1) / kSeg) * kSeg;
+            const int ds = lane == 0 ? d0 : d1 - (lane - 1) * kSeg;
+            const int de = lane == 0 ? d1 : ds - kSeg;
+            int h = s_heads[lane];
+            for (int dd = ds; dd > de && h >= 0; --dd) {
+                const int2 e = rec[h];
+                lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
+                if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
+                h = e.x;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        h0 = nh;
+        d0 = nd;
+    }
+}
+
+template <int N>
+hipError_t launch_n(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
+    hipLaunchKernelGGL((beam_lane_kernel<N>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool beam_lane_supported(int beam_size, int N, int crf) {
+    return !crf && beam_size >= 1 && beam_size <= 64 && N >= 2 && N <= 8;
+}
+
+hipError_t launch_beam_lane(const BatchDesc &in, int64_t read_begin, int64_t n_reads, const BeamArgs &a,
+                            const WaveArena &arena, const ResultDesc &out, hipStream_t stream) {
+    if (n_reads <= 0) return hipSuccess;
+    LaneParams p{in, a, arena, out, read_begin};
+    p.in.n_reads = n_reads;
+    switch (in.N) {
+        case 2: return launch_n<2>(p, n_reads, stream);
+        case 3: return launch_n<3>(p, n_reads, stream);
+        case 4: return launch_n<4>(p, n_reads, stream);
+        case 5: return launch_n<5>(p, n_reads, stream);
+        case 6: return launch_n<6>(p, n_reads, stream);
+        case 7: return launch_n<7>(p, n_reads, stream);
+        case 8: return launch_n<8>(p, n_reads, stream);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace fcd

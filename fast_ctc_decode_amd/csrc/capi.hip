@@ -144,14 +144,23 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         use_wave = false;
     }
     args.force_one_read_per_wave = kernel == FCD_KERNEL_WAVE1 ? 1 : 0;
+    // wide beams: one beam entry per lane (node ids in 23 bits)
+    bool use_lane = false;
+    if (kernel == FCD_KERNEL_LANE || (kernel == FCD_KERNEL_AUTO && !use_wave)) {
+        const bool ok = beam_lane_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf) &&
+                        d.T < (1ll << 26) && d.T * beam * NL + 16 < (1ll << 23);
+        if (kernel == FCD_KERNEL_LANE && !ok)
+            return fail(h, FCD_E_UNSUPPORTED, "lane kernel: needs beam_size <= 64, N <= 8, no CRF, T * beam_size * (N-1) < 2^23");
+        use_lane = ok;
+    }
 
     // Worst-case tree size per read: every step every beam entry creates NL nodes
     // (tree.rs:125 add_node is only called from the expansion loop, search.rs:200-239).
     const int64_t T = std::max<int64_t>(d.T, 1);
     int64_t cap_nodes;
     size_t per_read;
-    if (use_wave) {
-        cap_nodes = (T * std::min<int64_t>(beam, 12) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
+    if (use_wave || use_lane) {
+        cap_nodes = (T * std::min<int64_t>(beam, use_lane ? 64 : 12) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
         const int row_words = NL <= 4 ? 4 : 8;
         per_read = (size_t)cap_nodes * (sizeof(int2) + 4 + row_words * 4);
     } else {
@@ -173,7 +182,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     for (int64_t begin = 0; begin < d.n_reads; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, d.n_reads - begin);
         hipError_t e;
-        if (use_wave) {
+        if (use_wave || use_lane) {
             WaveArena ar;
             ar.cap_nodes = cap_nodes;
             ar.row_words = NL <= 4 ? 4 : 8;
@@ -182,7 +191,8 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
                                                  (size_t)chunk * cap_nodes * sizeof(int2));
             ar.rows = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
                                                   (size_t)chunk * cap_nodes * (sizeof(int2) + 4));
-            e = launch_beam_wave(d, begin, n, args, ar, o, h->stream);
+            e = use_lane ? launch_beam_lane(d, begin, n, args, ar, o, h->stream)
+                         : launch_beam_wave(d, begin, n, args, ar, o, h->stream);
         } else {
             GenericArena ar;
             ar.cap_nodes = cap_nodes;

@@ -76,7 +76,8 @@ enum {
     FCD_KERNEL_GENERIC = 1,  /* LDS-resident beam, any beam_size / alphabet */
     FCD_KERNEL_WAVE = 2,     /* register-resident beam: beam_size <= 8 with N <= 7, or beam_size <= 12
                                 with N <= 5; packs two reads per wavefront when beam_size <= 5, N <= 5 */
-    FCD_KERNEL_WAVE1 = 3     /* the same kernel, always one read per wavefront */
+    FCD_KERNEL_WAVE1 = 3,    /* the same kernel, always one read per wavefront */
+    FCD_KERNEL_LANE = 4      /* one beam entry per lane: beam_size <= 64, N <= 8, plain (non-CRF) search */
 };
 
 typedef struct fcd_handle fcd_handle;

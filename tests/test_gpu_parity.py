@@ -70,6 +70,22 @@ def test_beam_wave_wide(fcd, N, beam, kernel):
     check_beam(fcd, x, beam, 0.05, lengths=lengths, kernel=kernel)
 
 
+@pytest.mark.parametrize("N", [2, 3, 5, 8])
+@pytest.mark.parametrize("beam", [1, 5, 13, 32, 64])
+def test_beam_lane_random(fcd, N, beam):
+    """One beam entry per lane (beam_size <= 64, N <= 8): seeded batches, thr 0 / 0.1, collapse on/off,
+    ragged lengths, exact ties."""
+    x = gen_batch(1300 + N * 10 + beam, 5, 400, N)
+    thr = 0.1 if N <= 5 else 0.05
+    check_beam(fcd, x, beam, thr, kernel=fcd.KERNEL_LANE)
+    check_beam(fcd, x[:2], beam, 0.0, collapse=False, kernel=fcd.KERNEL_LANE)
+    lengths = np.array([400, 1, 0, 65, 399], np.int64)
+    check_beam(fcd, x, beam, thr / 2, lengths=lengths, kernel=fcd.KERNEL_LANE)
+    rng = np.random.default_rng(beam * 100 + N)
+    q = (rng.integers(0, 4, size=(3, 150, N)) / 4.0).astype(np.float32)   # exact ties: the all-pairs fallback
+    check_beam(fcd, q, beam, 0.0, kernel=fcd.KERNEL_LANE)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
 def test_beam_thr0(fcd, collapse, kernel):
@@ -402,12 +418,12 @@ def test_beam_fuzz(fcd, chunk):
     with the oracle bit for bit (labels, path, status), including inputs built to tie."""
     for seed in range(1000 + chunk * 12, 1000 + (chunk + 1) * 12):
         x, beam, thr, collapse, lengths = _fuzz_case(seed)
-        for kernel in (0, 1, 2, 3):
+        for kernel in (0, 1, 2, 3, 4):
             try:
                 check_beam(fcd, x, beam, thr, collapse, lengths=lengths, kernel=kernel)
             except RuntimeError as e:
-                # an explicitly requested wave kernel refuses shapes it is not built for
-                assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
+                # an explicitly requested register kernel refuses shapes it is not built for
+                assert kernel in (2, 3, 4) and " kernel: " in str(e), (seed, kernel, str(e))
             except AssertionError as e:
                 raise AssertionError("fuzz seed %d kernel %d beam %d thr %g collapse %s shape %s: %s"
                                      % (seed, kernel, beam, thr, collapse, x.shape, e))

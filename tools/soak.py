@@ -34,11 +34,11 @@ def other(which, n, first):
                 x = tp.gen_batch(seed, int(rng.integers(1, 4)), T, N, peaky=bool(rng.integers(0, 2)))
                 thr = float(rng.choice([0.0, 0.001, 0.1]))
                 lengths = rng.integers(1, T + 1, size=x.shape[0]).astype(np.int64) if rng.integers(0, 2) else None
-                for kernel in (0, 1, 2, 3):
+                for kernel in (0, 1, 2, 3, 4):
                     try:
                         tp.check_beam(fcd, x, beam, thr, True, lengths=lengths, kernel=kernel)
                     except RuntimeError as e:
-                        assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
+                        assert kernel in (2, 3, 4) and " kernel: " in str(e), (seed, kernel, str(e))
             elif which == "duplex_long":
                 rng = np.random.default_rng(seed)
                 T1, T2 = int(rng.integers(100, 500)), int(rng.integers(100, 500))
@@ -83,18 +83,18 @@ def main():
     t0 = time.time()
     for seed in range(first, first + n):
         x, beam, thr, collapse, lengths = tp._fuzz_case(seed)
-        for kernel in (0, 1, 2, 3):
+        for kernel in (0, 1, 2, 3, 4):
             try:
                 tp.check_beam(fcd, x, beam, thr, collapse, lengths=lengths, kernel=kernel)
             except RuntimeError as e:
-                if not (kernel in (2, 3) and "wave kernel" in str(e)):
+                if not (kernel in (2, 3, 4) and " kernel: " in str(e)):
                     bad += 1
                     print("seed %d kernel %d: %s" % (seed, kernel, e), flush=True)
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH seed %d kernel %d beam %d thr %g collapse %s shape %s: %s"
                       % (seed, kernel, beam, thr, collapse, x.shape, str(e)[:200]), flush=True)
-    print("soak: %d seeds x 4 kernels, %d failures, %.1f s" % (n, bad, time.time() - t0), flush=True)
+    print("soak: %d seeds x 5 kernel selections, %d failures, %.1f s" % (n, bad, time.time() - t0), flush=True)
     return 1 if bad else 0
 
 
