@@ -308,8 +308,15 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             wave_sync();
             for (int e = lane; e < Lc; e += kWave) {
                 const uint64_t ke = l_key[e];
-                int rk = 0;
-                for (int j = 0; j < Lc; ++j) rk += (l_key[j] > ke) ? 1 : 0;
+                int rk = 0, rk2 = 0;
+                int j = 0;
+                for (; j + 2 <= Lc; j += 2) {  // two keys per 16-byte LDS read
+                    const ulonglong2 kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
+                    rk += (kk2.x > ke) ? 1 : 0;
+                    rk2 += (kk2.y > ke) ? 1 : 0;
+                }
+                if (j < Lc) rk += (l_key[j] > ke) ? 1 : 0;
+                rk += rk2;
                 if (rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
             }
             wave_sync();
@@ -395,18 +402,23 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         if (ballot(reload) != 0ull) {
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up
-            int e[NL];
+            int e[NL], eid[NL], eslot[NL];
 #pragma unroll
-            for (int l = 0; l < NL; ++l) e[l] = reload ? load_i32_l2(&rows[(int64_t)n_node * RW + l]) : -1;
+            for (int l = 0; l < NL; ++l) {
+                e[l] = reload ? load_i32_l2(&rows[(int64_t)n_node * RW + l]) : -1;
+                // only a child that has been a beam entry (EVER) can be one now
+                eid[l] = (e[l] >= 0 && (e[l] & kEver)) ? (e[l] & kIdMask) : -2;
+                eslot[l] = -1;
+            }
             for (int j = 0; j < Bn; ++j) {
                 const int nj = rdlane(n_node, j);
 #pragma unroll
-                for (int l = 0; l < NL; ++l)
-                    if (e[l] >= 0 && (e[l] & kIdMask) == nj) e[l] = (e[l] & kStored) | kInBeam | (j << kSlotShift);
+                for (int l = 0; l < NL; ++l) eslot[l] = (eid[l] == nj) ? j : eslot[l];
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l)
-                if (reload) n_child[l] = e[l];
+                if (reload)
+                    n_child[l] = eslot[l] >= 0 ? ((e[l] & kStored) | kInBeam | (eslot[l] << kSlotShift)) : e[l];
         }
         const float top = __int_as_float(r0.x) + __int_as_float(r0.y);  // beam[0].probability() :278
         if (lane < Bn) {
