@@ -410,10 +410,18 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
                 eid[l] = (e[l] >= 0 && (e[l] & kEver)) ? (e[l] & kIdMask) : -2;
                 eslot[l] = -1;
             }
-            for (int j = 0; j < Bn; ++j) {
-                const int nj = rdlane(n_node, j);
+            // few lanes reload in a step: take them one at a time and let the whole wave look for each
+            // of their children among the new beam's nodes (one compare + ballot per child)
+            for (uint64_t m_rel = ballot(reload); m_rel != 0ull; m_rel &= m_rel - 1ull) {
+                const int L = __builtin_ctzll(m_rel);
 #pragma unroll
-                for (int l = 0; l < NL; ++l) eslot[l] = (eid[l] == nj) ? j : eslot[l];
+                for (int l = 0; l < NL; ++l) {
+                    const int id = rdlane(eid[l], L);
+                    if (id >= 0) {
+                        const uint64_t m_hit = ballot(lane < Bn && n_node == id);
+                        if (m_hit != 0ull && lane == L) eslot[l] = __builtin_ctzll(m_hit);
+                    }
+                }
             }
 #pragma unroll
             for (int l = 0; l < NL; ++l)
