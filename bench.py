@@ -112,14 +112,13 @@ def pmc_traffic(kernel_prefix):
     same kernel at the same shape, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
-    if not files:
-        return None, None
-    with open(files[-1]) as f:
-        summ = json.load(f)
-    for name, e in summ.get("kernels", {}).items():
-        if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
-            return e["hbm_bytes_per_launch"], "%s: %s; %s; %s" % (
-                os.path.basename(files[-1]), name, e.get("workload", ""), e.get("fetch_correction_note", ""))
+    for path in reversed(files):  # newest summary that holds this kernel
+        with open(path) as f:
+            summ = json.load(f)
+        for name, e in summ.get("kernels", {}).items():
+            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+                return e["hbm_bytes_per_launch"], "%s: %s; %s; %s" % (
+                    os.path.basename(path), name, e.get("workload", ""), e.get("fetch_correction_note", ""))
     return None, None
 
 
