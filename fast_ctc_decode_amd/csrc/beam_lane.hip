@@ -218,17 +218,12 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 
         // ---- search.rs:261-277 ----
         uint64_t key[N];
-        float clp[N], cgp[N];
-        clp[0] = slp;
-        cgp[0] = sgp;
         bool cand_valid[N];
         cand_valid[0] = svalid;
         int n_valid = popc64(ballot(svalid));
         bool any_nan = ballot(svalid && (slp + sgp) != (slp + sgp)) != 0ull;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
-            clp[l + 1] = contrib[l];
-            cgp[l + 1] = 0.0f;
             cand_valid[l + 1] = cvalid[l] && !merged[l];
             n_valid += popc64(ballot(cand_valid[l + 1]));
             any_nan = any_nan || ballot(cand_valid[l + 1] && contrib[l] != contrib[l]) != 0ull;
@@ -343,19 +338,19 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 
         // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
         s_fate[lane] = rank[0];
+        if (rank[0] >= 0) {  // the entry's own node stays in the beam
+            const int meta = 0 | ((tip + 1) << 2) | (depth << 5);
+            s_rec[2 * rank[0]] = make_int4(__float_as_int(slp), __float_as_int(sgp), node, meta);
+            s_rec[2 * rank[0] + 1] = make_int4(jump, lane, 0, 0);
+        }
 #pragma unroll
-        for (int k = 0; k < N; ++k) {
-            if (rank[k] >= 0) {
-                const bool self = k == 0;
-                const int l = k - 1;
-                const int kind = self ? 0 : ((child[self ? 0 : l] & kEver) ? 2 : 1);  // 2: re-entering, row is in HBM
-                const int tipc = self ? tip : l;
-                const int depc = self ? depth : depth + 1;
-                const int jumpc = self ? jump : ((depth % kSeg == 0) ? node : jump);
-                const int idc = self ? node : ccand[self ? 0 : l];
-                const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
-                s_rec[2 * rank[k]] = make_int4(__float_as_int(clp[k]), __float_as_int(cgp[k]), idc, meta);
-                s_rec[2 * rank[k] + 1] = make_int4(jumpc, lane, k, 0);
+        for (int l = 0; l < NL; ++l) {
+            const int rk = rank[l + 1];
+            if (rk >= 0) {  // the child by label l enters the beam
+                const int kind = (child[l] & kEver) ? 2 : 1;  // 2: it has been there before, its row is in HBM
+                const int meta = kind | ((l + 1) << 2) | ((depth + 1) << 5);
+                s_rec[2 * rk] = make_int4(__float_as_int(contrib[l]), 0, ccand[l], meta);
+                s_rec[2 * rk + 1] = make_int4((depth % kSeg == 0) ? node : jump, lane, l + 1, 0);
             }
         }
         wave_sync();
@@ -374,17 +369,22 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             }
             child[l] = ch;
         }
+        // word l of this entry's child row as it is stored: the entry without its beam-position bits, or -1
+        int row_word[RW];
+#pragma unroll
+        for (int l = 0; l < RW; ++l) row_word[l] = -1;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) row_word[l] = child[l] >= 0 ? (child[l] & kStored) : -1;
         if (ent && rank[0] < 0 && node >= 0) {
             // this node leaves the beam: its child row has to exist in HBM from now on
-            int32_t *row = rows + (int64_t)node * RW;
-            int v[RW];
-#pragma unroll
-            for (int l = 0; l < RW; ++l) v[l] = (l < NL && child[l < NL ? l : 0] >= 0) ? (child[l < NL ? l : 0] & kStored) : -1;
-            *reinterpret_cast<int4 *>(row) = make_int4(v[0], v[1], v[2], v[3]);
-            if (RW == 8) *reinterpret_cast<int4 *>(row + 4) = make_int4(v[4 % RW], v[5 % RW], v[6 % RW], v[7 % RW]);
+            int4 *row = reinterpret_cast<int4 *>(rows + (int64_t)node * RW);
+            row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
+            if (RW == 8) row[1] = make_int4(row_word[RW - 4], row_word[RW - 3], row_word[RW - 2], row_word[RW - 1]);
         }
 #pragma unroll
-        for (int l = 0; l < RW; ++l) s_child[lane * RW + l] = l < NL ? child[l < NL ? l : 0] : -1;
+        for (int l = 0; l < RW; ++l) s_child[lane * RW + l] = -1;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) s_child[lane * RW + l] = child[l];
         wave_sync();
 
         // ---- the new beam: lane r takes record r ----
