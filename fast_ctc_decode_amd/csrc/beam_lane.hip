@@ -1,5 +1,6 @@
 // beam_lane.hip -- CTC prefix beam search (search::beam_search, /root/reference/src/search.rs:159-301)
-// for WIDE beams: one beam ENTRY per lane, beam_size <= 64, N <= 8, one read per wavefront.
+// for WIDE beams: one beam ENTRY per lane, N <= 8; one read per wavefront with beam_size <= 64, or TWO
+// reads per wavefront (one per 32-lane half) with beam_size <= 32.
 //
 // beam_wave.hip gives every candidate slot its own lane, which stops at 12 beam entries x 5 lanes;
 // beam_generic.hip keeps the beam in LDS and spends ~2500 instructions per step at beam 32.  Here lane i
@@ -60,16 +61,23 @@ __device__ __forceinline__ int dpp_or_zero(int x) {
     return __builtin_amdgcn_update_dpp(0, x, CTRL, ROW_MASK, BANK_MASK, false);
 }
 
-// inclusive prefix sum over the 64 lanes (the classic GCN DPP scan; see envelope.hip)
-__device__ __forceinline__ int wave_prefix_add(int x) {
+// inclusive prefix sum over the 64 lanes (the classic GCN DPP scan; see envelope.hip) -- or, without the
+// last step, over each 32-lane half separately
+template <int RPW>
+__device__ __forceinline__ int half_prefix_add(int x) {
     int t = x + dpp_or_zero<0x111, 0xf, 0xf>(x);
     t += dpp_or_zero<0x112, 0xf, 0xf>(x);
     t += dpp_or_zero<0x113, 0xf, 0xf>(x);
     t += dpp_or_zero<0x114, 0xf, 0xe>(t);
     t += dpp_or_zero<0x118, 0xf, 0xc>(t);
     t += dpp_or_zero<0x142, 0xa, 0xf>(t);
-    t += dpp_or_zero<0x143, 0xc, 0xf>(t);
+    if (RPW == 1) t += dpp_or_zero<0x143, 0xc, 0xf>(t);
     return t;
+}
+
+__device__ __forceinline__ int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ float bpermf(int src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
 
 __device__ __forceinline__ int rdlane(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
@@ -77,47 +85,68 @@ __device__ __forceinline__ float rdlanef(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-template <int N>
+template <int N, int RPW>
 __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     constexpr int NL = N - 1;
-    constexpr int RPR = 64 / N;          // rows per FIFO register
-    constexpr int RW = NL <= 4 ? 4 : 8;  // child-row width in the arena
+    constexpr int HALF = 64 / RPW;          // lanes (= beam slots) per read
+    constexpr int RPR = HALF / N;           // rows per FIFO register
+    constexpr int RW = NL <= 4 ? 4 : 8;     // child-row width in the arena
+    constexpr int KB = kBuckets / RPW;      // histogram buckets per read (four per lane)
+    constexpr int LCAP = kListCap / RPW;    // list capacity per read
     static_assert(N >= 2 && N <= 8, "candidate ids are lane * 8 + k");
 
     __shared__ uint64_t s_inc[64];                        // {flag, contribution} pushed to a beam slot
     __shared__ __attribute__((aligned(16))) int4 s_u[64 * N / 2 > 160 ? 64 * N / 2 : 160];  // hist+list | all keys
     __shared__ __attribute__((aligned(8))) int8_t s_rank[64 * 8];  // rank of candidate (lane, k), -1 = out
-    __shared__ __attribute__((aligned(16))) int4 s_rec[64 * 2];     // survivor records by rank
+    __shared__ __attribute__((aligned(16))) int4 s_rec[64 * 2];     // survivor records by (half, rank)
     __shared__ int s_fate[64];                           // new slot of old slot i's own candidate, or -1
     __shared__ __attribute__((aligned(16))) int s_child[64 * RW];   // child entries of old slot i
     __shared__ int s_heads[64];
 
     int *hist = reinterpret_cast<int *>(s_u);                        // 256 ints      (1 KB)
-    uint64_t *l_key = reinterpret_cast<uint64_t *>(s_u + 64);        // 128 u64      (1 KB)
-    int *l_src = reinterpret_cast<int *>(s_u + 128);                 // 128 ints     (0.5 KB)
+    uint64_t *l_key_all = reinterpret_cast<uint64_t *>(s_u + 64);    // 128 u64      (1 KB)
+    int *l_src_all = reinterpret_cast<int *>(s_u + 128);             // 128 ints     (0.5 KB)
     uint64_t *c_key = reinterpret_cast<uint64_t *>(s_u);             // 64 * N u64, fallback only
 
     const int lane = threadIdx.x;
-    const int64_t local = blockIdx.x;
-    const int64_t r = p.read_begin + local;
+    const int q = lane & (HALF - 1);
+    const int hbase = lane - q;
+    const int hh = lane / HALF;
+    uint64_t *l_key = l_key_all + hh * LCAP;
+    int *l_src = l_src_all + hh * LCAP;
+    const int64_t local = (int64_t)blockIdx.x * RPW + hh;
+    const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
+    const int64_t r = p.read_begin + (has_read ? local : 0);
     const int beam_size = p.a.beam_size;
     const bool collapse = p.a.collapse != 0;
     const float thr = p.a.thr;
 
-    int64_t t64 = p.in.T;
-    if (p.in.lengths) {
-        const int64_t tl = p.in.lengths[r];
-        t64 = tl < 0 ? 0 : (tl < t64 ? tl : t64);
+    int T = 0;
+    if (has_read) {
+        int64_t t64 = p.in.T;
+        if (p.in.lengths) {
+            const int64_t tl = p.in.lengths[r];
+            t64 = tl < 0 ? 0 : (tl < t64 ? tl : t64);
+        }
+        T = (int)t64;
     }
-    const int T = (int)t64;
+    int Tmax = T;
+    if (RPW == 2) Tmax = max(Tmax, __shfl_xor(Tmax, 32));
+    Tmax = __builtin_amdgcn_readfirstlane(Tmax);
     const float *post = p.in.post + r * p.in.stride_read;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n;
-    int2 *rec = p.arena.rec + local * p.arena.cap_nodes;
-    int32_t *jmp = p.arena.jmp + local * p.arena.cap_nodes;
-    int32_t *rows = p.arena.rows + local * p.arena.cap_nodes * RW;
+    const int64_t slab = has_read ? local : 0;
+    int2 *rec = p.arena.rec + slab * p.arena.cap_nodes;
+    int32_t *jmp = p.arena.jmp + slab * p.arena.cap_nodes;
+    int32_t *rows = p.arena.rows + slab * p.arena.cap_nodes * RW;
     const int cap = (int)p.arena.cap_nodes;
 
-    // ---- beam state: lane i = beam entry i (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
+    // votes and counts over this lane's half
+    auto hmask = [&](uint64_t m) -> uint64_t { return RPW == 1 ? m : (hh ? (m >> 32) : (m & 0xFFFFFFFFull)); };
+    auto hcount = [&](bool pred) -> int { return popc64(hmask(ballot(pred))); };
+    const uint64_t below = (1ull << q) - 1ull;  // lanes of my half before me
+
+    // ---- beam state: lane q of a half = beam entry q (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
     int node = -1;
     float lp = 0.0f, gp = 1.0f;
     int tip = -1;
@@ -128,10 +157,11 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     for (int l = 0; l < NL; ++l) child[l] = -1;
     int B = 1;
     int nn = 0;
+    bool alive = has_read;
 
     // ---- row FIFO: register j holds rows [blk*RPR, blk*RPR + RPR) of block (front + j) ----
-    const int fg = lane / N, fc = lane - fg * N;
-    const bool f_lane = lane < RPR * N;
+    const int fg = q / N, fc = q - fg * N;
+    const bool f_lane = q < RPR * N;
     auto load_block = [&](int blk) -> float {
         const int row = blk * RPR + fg;
         return (f_lane && row < T) ? post[(int64_t)row * st_t + fc * st_n] : 0.0f;
@@ -143,12 +173,13 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     int g = 0, blk = 0;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see beam_wave.hip
 
-    bool failed = false;
-    for (int t = 0; t < T; ++t) {
-        // ---- the posterior row, wave-uniform ----
+    for (int t = 0; t < Tmax; ++t) {
+        const bool act = alive && t < T;
+        // ---- the posterior row: uniform over the read's lanes ----
         float pr[N];
 #pragma unroll
-        for (int c = 0; c < N; ++c) pr[c] = rdlanef(win[0], g * N + c);
+        for (int c = 0; c < N; ++c)
+            pr[c] = RPW == 1 ? rdlanef(win[0], g * N + c) : bpermf(hbase + g * N + c, win[0]);
         if (++g == RPR) {
             g = 0;
 #pragma unroll
@@ -158,7 +189,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             ++blk;
             incoming = load_block(blk + kFifo);
         }
-        const bool ent = lane < B;
+        const bool ent = act && q < B;
 
         // ---- extensions by label l (:200-239); targets that are beam entries get the push ----
         s_inc[lane] = 0ull;
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             cvalid[l] = ent && pass && (exists || !rep || gp > 0.0f);  // :212-218
             merged[l] = cvalid[l] && exists && (ch & kInBeam);
             if (merged[l])
-                s_inc[(ch >> kSlotShift) & kSlotMask] = (1ull << 32) | (uint32_t)__float_as_int(contrib[l]);
+                s_inc[hbase + ((ch >> kSlotShift) & kSlotMask)] = (1ull << 32) | (uint32_t)__float_as_int(contrib[l]);
             n_new += (cvalid[l] && !exists) ? 1 : 0;
         }
         wave_sync();
@@ -200,10 +231,10 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         const bool svalid = ent && (blank || stay || has_inc);
 
         // ---- tree.rs:125-145 add_node: ids in (beam order, label order) ----
-        const int incl = wave_prefix_add(n_new);
+        const int incl = half_prefix_add<RPW>(n_new);
         int next_id = nn + incl - n_new;
-        nn += rdlane(incl, 63);
-        const bool f_cap = nn > cap;
+        nn += RPW == 1 ? rdlane(incl, 63) : bperm(hbase + HALF - 1, incl);
+        const bool f_cap = act && nn > cap;
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const bool is_new = cvalid[l] && child[l] < 0;
@@ -220,44 +251,47 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         uint64_t key[N];
         bool cand_valid[N];
         cand_valid[0] = svalid;
-        int n_valid = popc64(ballot(svalid));
-        bool any_nan = ballot(svalid && (slp + sgp) != (slp + sgp)) != 0ull;
+        int n_valid = hcount(svalid);
+        bool lane_nan = svalid && (slp + sgp) != (slp + sgp);
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             cand_valid[l + 1] = cvalid[l] && !merged[l];
-            n_valid += popc64(ballot(cand_valid[l + 1]));
-            any_nan = any_nan || ballot(cand_valid[l + 1] && contrib[l] != contrib[l]) != 0ull;
+            n_valid += hcount(cand_valid[l + 1]);
+            lane_nan = lane_nan || (cand_valid[l + 1] && contrib[l] != contrib[l]);
         }
-        if ((n_valid >= 2 && any_nan) || n_valid == 0 || f_cap) {
-            if (lane == 0) {
-                p.out.status[r] = f_cap ? FCD_ST_INTERNAL
-                                        : (n_valid == 0 ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
+        const bool any_nan = hcount(lane_nan) != 0;
+        const bool f_nan = act && n_valid >= 2 && any_nan;
+        const bool f_empty = act && n_valid == 0;
+        if (f_nan || f_empty || f_cap) {
+            if (q == 0) {
+                p.out.status[r] = f_cap ? FCD_ST_INTERNAL : (f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
                 p.out.out_len[r] = 0;
             }
-            failed = true;
-            break;
+            alive = false;
         }
+        const bool go = act && alive;  // this read completes the step
         // (a NaN that gets this far is the lone candidate of the read: any non-zero key ranks it first)
-        key[0] = svalid ? make_key(slp + sgp, node) : 0ull;
+        key[0] = (svalid && go) ? make_key(slp + sgp, node) : 0ull;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) key[l + 1] = cand_valid[l + 1] ? make_key(contrib[l], ccand[l]) : 0ull;
+        for (int l = 0; l < NL; ++l) key[l + 1] = (cand_valid[l + 1] && go) ? make_key(contrib[l], ccand[l]) : 0ull;
 
         // ---- prune: the top beam_size candidates in exact key order ----
-        const int Bn = n_valid < beam_size ? n_valid : beam_size;
+        const int Bn = go ? (n_valid < beam_size ? n_valid : beam_size) : 0;
         int rank[N];
 #pragma unroll
         for (int k = 0; k < N; ++k) rank[k] = -1;
-        int bstar = kBuckets - 1;
-        int Lc = n_valid;
+        const bool need_sel = go && n_valid > beam_size;
+        int bstar = KB - 1;
+        int Lc = go ? n_valid : 0;
         uint32_t mx = 0;
-        if (n_valid > beam_size) {
+        if (ballot(need_sel) != 0ull) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 const uint32_t hi = (uint32_t)(key[k] >> 32);
                 mx = hi > mx ? hi : mx;
             }
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
+            for (int o = HALF / 2; o > 0; o >>= 1) {
                 const uint32_t other = (uint32_t)__shfl_xor((int)mx, o);
                 mx = other > mx ? other : mx;
             }
@@ -265,69 +299,79 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             wave_sync();
 #pragma unroll
             for (int k = 0; k < N; ++k)
-                if (key[k] != 0ull) {
+                if (need_sel && key[k] != 0ull) {
                     const uint32_t d = (mx - (uint32_t)(key[k] >> 32)) >> kBucketShift;
-                    atomicAdd(&hist[d < (uint32_t)(kBuckets - 1) ? d : (uint32_t)(kBuckets - 1)], 1);
+                    atomicAdd(&hist[4 * hbase + (d < (uint32_t)(KB - 1) ? d : (uint32_t)(KB - 1))], 1);
                 }
             wave_sync();
             const int4 h = *reinterpret_cast<const int4 *>(hist + 4 * lane);
             const int s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
-            const int hin = wave_prefix_add(s3);
+            const int hin = half_prefix_add<RPW>(s3);
             const int hex = hin - s3;
-            const bool cross = hex < beam_size && hin >= beam_size;  // exactly one lane (total > beam_size)
+            // exactly one lane of a selecting half owns the bucket where the running count reaches beam_size
+            const bool cross = need_sel && hex < beam_size && hin >= beam_size;
             const int kk = (hex + s0 >= beam_size) ? 0 : (hex + s1 >= beam_size) ? 1 : (hex + s2 >= beam_size) ? 2 : 3;
             const int cum = hex + (kk == 0 ? s0 : kk == 1 ? s1 : kk == 2 ? s2 : s3);
-            const int owner = __builtin_ctzll(ballot(cross));
-            bstar = rdlane(4 * lane + kk, owner);
-            Lc = rdlane(cum, owner);
-            wave_sync();  // the list overwrites nothing of the histogram, but keep the phases apart
+            const uint64_t m_cross = hmask(ballot(cross));
+            const int owner = hbase + (m_cross ? __builtin_ctzll(m_cross) : 0);
+            const int b_sel = bperm(owner, 4 * q + kk);
+            const int l_sel = bperm(owner, cum);
+            if (need_sel) {
+                bstar = b_sel;
+                Lc = l_sel;
+            }
+            wave_sync();
         }
-        if (Lc <= kListCap) {
+        if (ballot(Lc > LCAP) == 0ull) {
             int base = 0;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 bool in = key[k] != 0ull;
-                if (in && n_valid > beam_size) {
+                if (in && need_sel) {
                     const uint32_t d = (mx - (uint32_t)(key[k] >> 32)) >> kBucketShift;
-                    in = (int)(d < (uint32_t)(kBuckets - 1) ? d : (uint32_t)(kBuckets - 1)) <= bstar;
+                    in = (int)(d < (uint32_t)(KB - 1) ? d : (uint32_t)(KB - 1)) <= bstar;
                 }
-                const uint64_t m_in = ballot(in);
+                const uint64_t m_in = hmask(ballot(in));
                 if (in) {
-                    const int pos = base + popc64(m_in & lanemask_lt());
+                    const int pos = base + popc64(m_in & below);
                     l_key[pos] = key[k];
                     l_src[pos] = lane * 8 + k;
                 }
                 base += popc64(m_in);
             }
+            // the ranking loop runs to a wave-uniform, even bound: pad this read's list with zero keys
+            int lmax = Lc;
+            if (RPW == 2) lmax = max(lmax, __shfl_xor(lmax, 32));
+            lmax = (__builtin_amdgcn_readfirstlane(lmax) + 1) & ~1;
+            for (int z = Lc + q; z < lmax; z += HALF) l_key[z] = 0ull;
             *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
             wave_sync();
-            for (int e = lane; e < Lc; e += kWave) {
-                const uint64_t ke = l_key[e];
+            for (int e0 = 0; e0 < lmax; e0 += HALF) {
+                const int e = e0 + q;
+                const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
                 int rk = 0, rk2 = 0;
-                int j = 0;
-                for (; j + 2 <= Lc; j += 2) {  // two keys per 16-byte LDS read
+                for (int j = 0; j < lmax; j += 2) {  // two keys per 16-byte LDS read
                     const ulonglong2 kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
                     rk += (kk2.x > ke) ? 1 : 0;
                     rk2 += (kk2.y > ke) ? 1 : 0;
                 }
-                if (j < Lc) rk += (l_key[j] > ke) ? 1 : 0;
                 rk += rk2;
-                if (rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                if (e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
             }
             wave_sync();
             const uint64_t mine = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
 #pragma unroll
             for (int k = 0; k < N; ++k) rank[k] = (int)(int8_t)(uint8_t)(mine >> (8 * k));
         } else {
-            // heavily tied (or extremely spread) probabilities: rank every candidate against all of them
+            // heavily tied (or extremely spread) probabilities: rank every candidate against all of its read's
 #pragma unroll
             for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
             wave_sync();
             int rk[N];
 #pragma unroll
             for (int k = 0; k < N; ++k) rk[k] = 0;
-            for (int j = 0; j < kWave * N; ++j) {
-                const uint64_t kj = c_key[j];
+            for (int j = 0; j < HALF * N; ++j) {
+                const uint64_t kj = c_key[hbase * N + j];
 #pragma unroll
                 for (int k = 0; k < N; ++k) rk[k] += (kj > key[k]) ? 1 : 0;
             }
@@ -340,8 +384,8 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         s_fate[lane] = rank[0];
         if (rank[0] >= 0) {  // the entry's own node stays in the beam
             const int meta = 0 | ((tip + 1) << 2) | (depth << 5);
-            s_rec[2 * rank[0]] = make_int4(__float_as_int(slp), __float_as_int(sgp), node, meta);
-            s_rec[2 * rank[0] + 1] = make_int4(jump, lane, 0, 0);
+            s_rec[2 * (hbase + rank[0])] = make_int4(__float_as_int(slp), __float_as_int(sgp), node, meta);
+            s_rec[2 * (hbase + rank[0]) + 1] = make_int4(jump, lane, 0, 0);
         }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -349,8 +393,8 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             if (rk >= 0) {  // the child by label l enters the beam
                 const int kind = (child[l] & kEver) ? 2 : 1;  // 2: it has been there before, its row is in HBM
                 const int meta = kind | ((l + 1) << 2) | ((depth + 1) << 5);
-                s_rec[2 * rk] = make_int4(__float_as_int(contrib[l]), 0, ccand[l], meta);
-                s_rec[2 * rk + 1] = make_int4((depth % kSeg == 0) ? node : jump, lane, l + 1, 0);
+                s_rec[2 * (hbase + rk)] = make_int4(__float_as_int(contrib[l]), 0, ccand[l], meta);
+                s_rec[2 * (hbase + rk) + 1] = make_int4((depth % kSeg == 0) ? node : jump, lane, l + 1, 0);
             }
         }
         wave_sync();
@@ -359,9 +403,9 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             int ch = child[l];
-            if (ent && ch >= 0) {
+            if (ent && go && ch >= 0) {
                 if (ch & kInBeam) {
-                    const int fate = s_fate[(ch >> kSlotShift) & kSlotMask];
+                    const int fate = s_fate[hbase + ((ch >> kSlotShift) & kSlotMask)];
                     ch = (ch & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
                 } else if (rank[l + 1] >= 0) {
                     ch = (ch & kIdMask) | kEver | kInBeam | (rank[l + 1] << kSlotShift);
@@ -375,7 +419,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         for (int l = 0; l < RW; ++l) row_word[l] = -1;
 #pragma unroll
         for (int l = 0; l < NL; ++l) row_word[l] = child[l] >= 0 ? (child[l] & kStored) : -1;
-        if (ent && rank[0] < 0 && node >= 0) {
+        if (ent && go && rank[0] < 0 && node >= 0) {
             // this node leaves the beam: its child row has to exist in HBM from now on
             int4 *row = reinterpret_cast<int4 *>(rows + (int64_t)node * RW);
             row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
@@ -387,18 +431,18 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         for (int l = 0; l < NL; ++l) s_child[lane * RW + l] = child[l];
         wave_sync();
 
-        // ---- the new beam: lane r takes record r ----
-        const int me = lane < Bn ? lane : 0;
+        // ---- the new beam: lane r of the half takes record r ----
+        const int me = hbase + (q < Bn ? q : 0);
         const int4 ra = s_rec[2 * me], rb = s_rec[2 * me + 1];
-        const int2 r0 = *reinterpret_cast<const int2 *>(&s_rec[0]);
+        const int2 r0 = *reinterpret_cast<const int2 *>(&s_rec[2 * hbase]);
         const int n_node = ra.z;
         const int n_meta = ra.w;
         const int n_kind = n_meta & 3;
-        const int src = rb.y;
+        const int src = rb.y & 63;
         int n_child[NL];
 #pragma unroll
         for (int l = 0; l < NL; ++l) n_child[l] = n_kind == 0 ? s_child[src * RW + l] : -1;
-        const bool reload = lane < Bn && n_kind == 2;
+        const bool reload = q < Bn && n_kind == 2;
         if (ballot(reload) != 0ull) {
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up
@@ -410,15 +454,17 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
                 eid[l] = (e[l] >= 0 && (e[l] & kEver)) ? (e[l] & kIdMask) : -2;
                 eslot[l] = -1;
             }
-            // few lanes reload in a step: take them one at a time and let the whole wave look for each
+            // few lanes reload in a step: take them one at a time and let their read's lanes look for each
             // of their children among the new beam's nodes (one compare + ballot per child)
             for (uint64_t m_rel = ballot(reload); m_rel != 0ull; m_rel &= m_rel - 1ull) {
                 const int L = __builtin_ctzll(m_rel);
+                const int Lb = L & ~(HALF - 1);
 #pragma unroll
                 for (int l = 0; l < NL; ++l) {
                     const int id = rdlane(eid[l], L);
                     if (id >= 0) {
-                        const uint64_t m_hit = ballot(lane < Bn && n_node == id);
+                        uint64_t m_hit = ballot(q < Bn && n_node == id);
+                        if (RPW == 2) m_hit = Lb ? (m_hit >> 32) : (m_hit & 0xFFFFFFFFull);
                         if (m_hit != 0ull && lane == L) eslot[l] = __builtin_ctzll(m_hit);
                     }
                 }
@@ -429,7 +475,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
                     n_child[l] = eslot[l] >= 0 ? ((e[l] & kStored) | kInBeam | (eslot[l] << kSlotShift)) : e[l];
         }
         const float top = __int_as_float(r0.x) + __int_as_float(r0.y);  // beam[0].probability() :278
-        if (lane < Bn) {
+        if (q < Bn) {
             node = n_node;
             lp = __int_as_float(ra.x) / top;
             gp = __int_as_float(ra.y) / top;
@@ -439,41 +485,40 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 #pragma unroll
             for (int l = 0; l < NL; ++l) child[l] = n_child[l];
         }
-        B = Bn;
+        if (go) B = Bn;
         wave_sync();
     }
-    if (failed) return;
 
     // ---- walk the best labelling leaf -> root (:285-300), segment-parallel (see beam_wave.hip) ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     uint8_t *lab = p.out.labels + r * p.out.out_stride;
     uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
-    if (lane == 0) {
+    if (q == 0 && alive) {
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
     }
-    int h0 = rdlane(node, 0);
-    int d0 = rdlane(depth, 0);
-    const int j0 = rdlane(jump, 0);
-    while (d0 > 0) {
+    int h0 = bperm(hbase, node);
+    int d0 = bperm(hbase, alive ? depth : 0);
+    const int j0 = bperm(hbase, jump);
+    while (ballot(d0 > 0) != 0ull) {
         int cnt = 0, nh = h0, nd = d0;
-        if (lane == 0) {
-            while (cnt < kWave && nd > 0) {
-                s_heads[cnt] = nh;
+        if (q == 0) {
+            while (cnt < HALF && nd > 0) {
+                s_heads[hbase + cnt] = nh;
                 nh = (nd % kSeg != 0) ? j0 : jmp[nh];
                 nd = ((nd - 1) / kSeg) * kSeg;
                 ++cnt;
             }
         }
-        cnt = rdlane(cnt, 0);
-        nh = rdlane(nh, 0);
-        nd = rdlane(nd, 0);
+        cnt = bperm(hbase, cnt);
+        nh = bperm(hbase, nh);
+        nd = bperm(hbase, nd);
         wave_sync();
-        if (lane < cnt) {
+        if (q < cnt) {
             const int d1 = ((d0 - 1) / kSeg) * kSeg;
-            const int ds = lane == 0 ? d0 : d1 - (lane - 1) * kSeg;
-            const int de = lane == 0 ? d1 : ds - kSeg;
-            int h = s_heads[lane];
+            const int ds = q == 0 ? d0 : d1 - (q - 1) * kSeg;
+            const int de = q == 0 ? d1 : ds - kSeg;
+            int h = s_heads[hbase + q];
             for (int dd = ds; dd > de && h >= 0; --dd) {
                 const int2 e = rec[h];
                 lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
@@ -489,7 +534,11 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 
 template <int N>
 hipError_t launch_n(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
-    hipLaunchKernelGGL((beam_lane_kernel<N>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
+    if (p.a.beam_size <= 32) {  // two reads per wavefront
+        hipLaunchKernelGGL((beam_lane_kernel<N, 2>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
+    } else {
+        hipLaunchKernelGGL((beam_lane_kernel<N, 1>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
+    }
     return hipGetLastError();
 }
 
