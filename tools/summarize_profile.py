@@ -17,7 +17,7 @@ WORK = {
     "beam_wave_kernel<5, 6, 2, 4>": "4096 reads T=4000 S=4 N=5 CRF beam 5 thr 0 (config 4)",
     "viterbi_stream_kernel<5>": "16384 reads T=4000 N=5",
     "beam_generic_kernel": "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)",
-    "beam_lane_kernel<5>": "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)",
+    "beam_lane_kernel<5, 2>": "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)",
     "duplex_kernel<0>": "1024 pairs T=2000 band +-64 beam 5 thr 0.1 logsumexp (config 5)",
     "duplex_kernel<1>": "1024 pairs T=2000 band +-64 beam 5 thr 0.1 max mode (config 5)",
 }
