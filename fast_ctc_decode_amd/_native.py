@@ -9,7 +9,7 @@ import os
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FCD_LIB_PATH") or os.path.join(_HERE, "libfcd_hip.so")  # env: developer override
+LIB_PATH = os.path.join(_HERE, "libfcd_hip.so")
 
 OK = 0
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
@@ -79,44 +79,49 @@ def load():
             lib = C.CDLL(LIB_PATH)
         except OSError as e:  # no silent fallback
             raise NativeError("cannot load %s: %s" % (LIB_PATH, e))
-        P, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
-        BP, RP = C.POINTER(Batch), C.POINTER(Result)
-        lib.fcd_version.restype = i32
-        lib.fcd_device_count.restype = i32
-        lib.fcd_create.argtypes = [i32, C.POINTER(P)]
-        lib.fcd_destroy.argtypes = [P]
-        lib.fcd_set_stream.argtypes = [P, P]
-        lib.fcd_reset_stream.argtypes = [P]
-        lib.fcd_synchronize.argtypes = [P]
-        lib.fcd_last_error.argtypes = [P]
-        lib.fcd_last_error.restype = C.c_char_p
-        lib.fcd_status_string.argtypes = [i32]
-        lib.fcd_status_string.restype = C.c_char_p
-        lib.fcd_set_workspace_limit.argtypes = [P, i64]
-        lib.fcd_last_kernel_ms.argtypes = [P]
-        lib.fcd_last_kernel_ms.restype = C.c_double
-        lib.fcd_timing_reset.argtypes = [P]
-        lib.fcd_timing_mean_ms.argtypes = [P, C.POINTER(i64)]
-        lib.fcd_timing_mean_ms.restype = C.c_double
-        for sfx in ("dev", "host"):
-            getattr(lib, "fcd_viterbi_search_" + sfx).argtypes = [P, BP, i32, RP]
-            getattr(lib, "fcd_beam_search_" + sfx).argtypes = [P, BP, i64, f32, i32, i32, RP]
-            getattr(lib, "fcd_crf_beam_search_" + sfx).argtypes = [P, BP, P, i64, i64, i64, f32, RP]
-            getattr(lib, "fcd_crf_greedy_search_" + sfx).argtypes = [P, BP, P, i64, i64, RP]
-            getattr(lib, "fcd_beam_search_duplex_" + sfx).argtypes = [
-                P, BP, BP, P, i64, i64, f32, i32, i32, RP]
-        for sfx in ("dev", "host"):
-            getattr(lib, "fcd_crf_beam_search_duplex_" + sfx).argtypes = [
-                P, BP, P, i64, i64, BP, P, i64, i64, P, i64, i64, f32, i32, RP]
-        lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
-        for sfx in ("dev", "host"):
-            getattr(lib, "fcd_duplex_envelope_" + sfx).argtypes = [
-                P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]
-        lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
-        lib.fcd_phred.argtypes = [f32, f32, f32]
-        lib.fcd_phred.restype = C.c_uint32
-        _lib = lib
-        return lib
+        _lib = bind(lib)
+        return _lib
+
+
+def bind(lib):
+    """Declare the argument / result types of every C-ABI entry point on a loaded library."""
+    P, i64, i32, f32 = C.c_void_p, C.c_int64, C.c_int, C.c_float
+    BP, RP = C.POINTER(Batch), C.POINTER(Result)
+    lib.fcd_version.restype = i32
+    lib.fcd_device_count.restype = i32
+    lib.fcd_create.argtypes = [i32, C.POINTER(P)]
+    lib.fcd_destroy.argtypes = [P]
+    lib.fcd_set_stream.argtypes = [P, P]
+    lib.fcd_reset_stream.argtypes = [P]
+    lib.fcd_synchronize.argtypes = [P]
+    lib.fcd_last_error.argtypes = [P]
+    lib.fcd_last_error.restype = C.c_char_p
+    lib.fcd_status_string.argtypes = [i32]
+    lib.fcd_status_string.restype = C.c_char_p
+    lib.fcd_set_workspace_limit.argtypes = [P, i64]
+    lib.fcd_last_kernel_ms.argtypes = [P]
+    lib.fcd_last_kernel_ms.restype = C.c_double
+    lib.fcd_timing_reset.argtypes = [P]
+    lib.fcd_timing_mean_ms.argtypes = [P, C.POINTER(i64)]
+    lib.fcd_timing_mean_ms.restype = C.c_double
+    for sfx in ("dev", "host"):
+        getattr(lib, "fcd_viterbi_search_" + sfx).argtypes = [P, BP, i32, RP]
+        getattr(lib, "fcd_beam_search_" + sfx).argtypes = [P, BP, i64, f32, i32, i32, RP]
+        getattr(lib, "fcd_crf_beam_search_" + sfx).argtypes = [P, BP, P, i64, i64, i64, f32, RP]
+        getattr(lib, "fcd_crf_greedy_search_" + sfx).argtypes = [P, BP, P, i64, i64, RP]
+        getattr(lib, "fcd_beam_search_duplex_" + sfx).argtypes = [
+            P, BP, BP, P, i64, i64, f32, i32, i32, RP]
+    for sfx in ("dev", "host"):
+        getattr(lib, "fcd_crf_beam_search_duplex_" + sfx).argtypes = [
+            P, BP, P, i64, i64, BP, P, i64, i64, P, i64, i64, f32, i32, RP]
+    lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
+    for sfx in ("dev", "host"):
+        getattr(lib, "fcd_duplex_envelope_" + sfx).argtypes = [
+            P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]
+    lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
+    lib.fcd_phred.argtypes = [f32, f32, f32]
+    lib.fcd_phred.restype = C.c_uint32
+    return lib
 
 
 class Handle:

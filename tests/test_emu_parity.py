@@ -1,0 +1,79 @@
+"""CPU-side logic check of the HIP kernels: the product's csrc/*.hip, compiled unchanged against
+tests/hipemu's lockstep wave64 emulation, must reproduce the oracle on the same seeded inputs the -m gpu
+parity tests use (a selection sized for the CPU suite; FCD_TEST_EMU=1 python -m pytest tests -m gpu runs
+them all).  This is NOT the parity gate -- that is tests -m gpu on the MI355X -- it catches logic errors
+in cross-lane protocols, node numbering, arena handling and pruning before a GPU is needed."""
+import numpy as np
+import pytest
+
+import test_gpu_duplex as D
+import test_gpu_envelope as E
+import test_gpu_parity as P
+from emu_util import emulated_kernels
+
+
+@pytest.fixture(scope="module")
+def fcd():
+    import fast_ctc_decode_amd as m
+    with emulated_kernels():
+        yield m
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_beam_kernels(fcd, kernel):
+    P.test_beam_thr0(fcd, True, kernel)
+    P.test_beam_ragged(fcd, kernel)
+    P.test_beam_nan_and_zero_rows(fcd, kernel)
+    P.test_beam_ties_and_zeros(fcd, kernel)
+    P.test_beam_traceback_segment_boundaries(fcd, kernel)
+
+
+@pytest.mark.parametrize("N,beam,kernel", [(5, 5, 2), (3, 2, 2), (7, 8, 3), (5, 12, 0), (4, 9, 2)])
+def test_beam_wave_shapes(fcd, N, beam, kernel):
+    if beam > 8:
+        P.test_beam_wave_wide(fcd, N, beam, kernel)
+    else:
+        P.test_beam_wave_random(fcd, N, beam, kernel)
+
+
+@pytest.mark.parametrize("N,beam", [(5, 32), (5, 64), (8, 13), (2, 5)])
+def test_beam_lane_shapes(fcd, N, beam):
+    P.test_beam_lane_random(fcd, N, beam)
+
+
+@pytest.mark.parametrize("N,beam", [(5, 32), (12, 5)])
+def test_beam_generic_shapes(fcd, N, beam):
+    P.test_beam_generic_random(fcd, N, beam)
+
+
+def test_full_length_read_every_kernel(fcd):
+    """T = 4000 (BASELINE row count): wave (two reads per wavefront), generic, lane at beam 32 and 64."""
+    x = P.gen_batch(4242, 2, 4000, 5)
+    P.check_beam(fcd, x, 5, 0.1, kernel=0)
+    P.check_beam(fcd, x[:1], 5, 0.1, kernel=1)
+    P.check_beam(fcd, x, 32, 0.1, kernel=4)
+    P.check_beam(fcd, x[:1], 64, 0.1, kernel=4)
+
+
+def test_viterbi_and_crf(fcd):
+    P.test_viterbi_random(fcd)
+    P.test_viterbi_qual_bits(fcd)
+    P.test_crf_beam_random(fcd, 5, 0.1)
+    P.test_crf_greedy_random(fcd)
+
+
+def test_duplex(fcd):
+    D.test_duplex_banded_exact(fcd, D.LSE, True)
+    D.test_duplex_banded_exact(fcd, D.MAX, False)
+    D.test_duplex_envelope_errors_and_edges(fcd)
+    D.test_duplex_shapes_exact(fcd, 3, 3)
+    from oracle import oracle
+    x1, i1, x2, i2 = D.crf_pairs(405, 70, 64)   # duplex::crf_beam_search, banded
+    env = D.band(70, 64, 20)
+    for mode in (D.LSE, D.MAX):
+        want = oracle.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, mode | D.CR)
+        assert fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, logadd_mode=mode) == want
+
+
+def test_envelope(fcd):
+    E.test_envelope_equals_model(fcd, 3)
