@@ -26,6 +26,7 @@ SYMBOLS = [
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host",
     "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k", "fcd_crf_beam_search_host",
+    "fcd_crf_beam_search_host_k",
     "fcd_crf_greedy_search_dev", "fcd_crf_greedy_search_host",
     "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
     "fcd_crf_beam_search_duplex_dev", "fcd_crf_beam_search_duplex_host",
@@ -46,6 +47,7 @@ class Result(C.Structure):
     _fields_ = [
         ("labels", C.c_void_p), ("path", C.c_void_p), ("qual", C.c_void_p),
         ("out_len", C.c_void_p), ("status", C.c_void_p), ("out_stride", C.c_int64),
+        ("ambiguous", C.c_void_p),
     ]
 
 
@@ -115,6 +117,7 @@ def bind(lib):
         getattr(lib, "fcd_crf_beam_search_duplex_" + sfx).argtypes = [
             P, BP, P, i64, i64, BP, P, i64, i64, P, i64, i64, f32, i32, RP]
     lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
+    lib.fcd_crf_beam_search_host_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
     for sfx in ("dev", "host"):
         getattr(lib, "fcd_duplex_envelope_" + sfx).argtypes = [
             P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]

@@ -84,8 +84,9 @@ def _dense(a):
 # low-level batched calls (host numpy buffers)
 # ---------------------------------------------------------------------------------------------
 class _HostOut:
-    def __init__(self, B, T, want_path=True, want_qual=False):
+    def __init__(self, B, T, want_path=True, want_qual=False, want_amb=False):
         w = max(int(T), 1)
+        self.ambiguous = np.zeros(B, np.uint32) if want_amb else None
         self.labels = np.zeros((B, w), np.uint8)
         self.path = np.zeros((B, w), np.uint32) if want_path else None
         self.qual = np.zeros((B, w), np.float32) if want_qual else None
@@ -94,7 +95,7 @@ class _HostOut:
         self.res = nat.Result(
             self.labels.ctypes.data, self.path.ctypes.data if want_path else None,
             self.qual.ctypes.data if want_qual else None, self.out_len.ctypes.data,
-            self.status.ctypes.data, w)
+            self.status.ctypes.data, w, self.ambiguous.ctypes.data if want_amb else None)
 
 
 def _host_batch(x, crf, lengths=None):
@@ -585,13 +586,17 @@ class BatchResult:
     """Raw outcome of a batched search: label indices, paths, lengths and per-read status.
     Arrays are numpy for host inputs, torch tensors (same device) for device inputs."""
 
-    def __init__(self, labels, path, out_len, status, qual=None):
+    def __init__(self, labels, path, out_len, status, qual=None, ambiguous=None):
         self.labels, self.path, self.out_len, self.status, self.qual = labels, path, out_len, status, qual
+        # beam searches with count_ambiguous=True: per read, the number of steps whose tie order the
+        # reference's sort_unstable_by does not pin (include/fcd.h, fcd_result.ambiguous)
+        self.ambiguous = ambiguous
 
     def cpu(self):
         def c(a):
             return a if a is None or isinstance(a, np.ndarray) else a.cpu().numpy()
-        return BatchResult(c(self.labels), c(self.path), c(self.out_len), c(self.status), c(self.qual))
+        return BatchResult(c(self.labels), c(self.path), c(self.out_len), c(self.status), c(self.qual),
+                           c(self.ambiguous))
 
     def sequences(self, alphabet, raise_on_error=True, paths="list"):
         """-> list of (str, path) per read, exactly what the single-read functions return.
@@ -638,7 +643,7 @@ class BatchResult:
 
 
 def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path=True,
-                need_status=True, handle=None):
+                need_status=True, handle=None, want_amb=False):
     import torch
 
     if x.dtype in (torch.float16, torch.bfloat16):
@@ -666,13 +671,14 @@ def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path
     qual = torch.empty((B, w), dtype=torch.float32, device=x.device) if want_qual else None
     out_len = torch.zeros(B, dtype=torch.int32, device=x.device)
     status = torch.zeros(B, dtype=torch.int32, device=x.device)
+    amb = torch.zeros(B, dtype=torch.int32, device=x.device) if want_amb else None
     res = nat.Result(labels.data_ptr(), path.data_ptr() if want_path else None,
                      qual.data_ptr() if want_qual else None, out_len.data_ptr(),
-                     status.data_ptr(), w)
+                     status.data_ptr(), w, amb.data_ptr() if want_amb else None)
     h.set_stream(torch.cuda.current_stream(x.device).cuda_stream)
     fn = getattr(h.lib, fn_name)
     h.check(fn(h.ptr, C.byref(b), *extra_args, C.byref(res)))
-    r = BatchResult(labels, path, out_len, status, qual)
+    r = BatchResult(labels, path, out_len, status, qual, amb)
     r._handle = h
     r._keep = (x, lengths)
     return r
@@ -722,26 +728,29 @@ def _device_tensor(x):
 
 
 def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
-                          collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, handle=None):
+                          collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, handle=None,
+                          count_ambiguous=False):
     """Decode a (B,T,N) batch with search::beam_search semantics; returns a BatchResult.
     `handle` (device tensors only): an explicit fast_ctc_decode_amd._native.Handle -- one per
-    concurrent torch stream, since a handle owns the tree-arena workspace its kernels use."""
+    concurrent torch stream, since a handle owns the tree-arena workspace its kernels use.
+    `count_ambiguous`: also fill BatchResult.ambiguous (instrumented kernels; include/fcd.h)."""
     dev_x = _device_tensor(network_outputs)
     if dev_x is not None:
         network_outputs = dev_x
         return _torch_call("fcd_beam_search_dev", network_outputs, False, lengths,
                            (int(beam_size), float(beam_cut_threshold),
-                            int(bool(collapse_repeats)), int(kernel)), handle=handle)
+                            int(bool(collapse_repeats)), int(kernel)), handle=handle,
+                           want_amb=count_ambiguous)
     network_outputs, lengths = _ragged(network_outputs, lengths, 3)
     x = _stack_host(network_outputs, 3)
     B, T, N = x.shape
     h = nat.default_handle()
-    out = _HostOut(B, T)
+    out = _HostOut(B, T, want_amb=count_ambiguous)
     l = _np_lengths(lengths, B)
     b = _host_batch(x, False, l)
     h.check(h.lib.fcd_beam_search_host(h.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
                                        int(bool(collapse_repeats)), int(kernel), C.byref(out.res)))
-    return BatchResult(out.labels, out.path, out.out_len, out.status)
+    return BatchResult(out.labels, out.path, out.out_len, out.status, ambiguous=out.ambiguous)
 
 
 def beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold=0.0,
@@ -786,16 +795,16 @@ def viterbi_search_batch(network_outputs, alphabet, qstring=False, qscale=1.0, q
 
 
 def crf_beam_search_batch_raw(network_outputs, init_states, beam_size=5, beam_cut_threshold=0.0,
-                              lengths=None, kernel=nat.KERNEL_AUTO):
-    """(B,T,S,N) posteriors + (B,n_init) initial state scores -> BatchResult.
-    `kernel` is honoured for device tensors only (host arrays use the automatic choice)."""
+                              lengths=None, kernel=nat.KERNEL_AUTO, count_ambiguous=False):
+    """(B,T,S,N) posteriors + (B,n_init) initial state scores -> BatchResult."""
     if _is_torch_cuda(network_outputs):
         import torch
         init = torch.as_tensor(init_states, dtype=torch.float32,
                                device=network_outputs.device).contiguous()
         r = _torch_call("fcd_crf_beam_search_dev_k", network_outputs, True, lengths,
                         (C.c_void_p(init.data_ptr()), int(init.shape[1]), int(init.shape[1]),
-                         int(beam_size), float(beam_cut_threshold), int(kernel)))
+                         int(beam_size), float(beam_cut_threshold), int(kernel)),
+                        want_amb=count_ambiguous)
         r._keep = r._keep + (init,)
         return r
     x = _stack_host(network_outputs, 4)
@@ -804,13 +813,13 @@ def crf_beam_search_batch_raw(network_outputs, init_states, beam_size=5, beam_cu
     if init.shape[0] != B or init.ndim != 2:
         raise ValueError("init_states must have shape (n_reads, n_init)")
     h = nat.default_handle()
-    out = _HostOut(B, T)
+    out = _HostOut(B, T, want_amb=count_ambiguous)
     l = _np_lengths(lengths, B)
     b = _host_batch(x, True, l)
-    h.check(h.lib.fcd_crf_beam_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[1],
-                                           init.shape[1], int(beam_size), float(beam_cut_threshold),
-                                           C.byref(out.res)))
-    return BatchResult(out.labels, out.path, out.out_len, out.status)
+    h.check(h.lib.fcd_crf_beam_search_host_k(h.ptr, C.byref(b), init.ctypes.data, init.shape[1],
+                                             init.shape[1], int(beam_size), float(beam_cut_threshold),
+                                             int(kernel), C.byref(out.res)))
+    return BatchResult(out.labels, out.path, out.out_len, out.status, ambiguous=out.ambiguous)
 
 
 def crf_beam_search_batch(network_outputs, init_states, alphabet, beam_size=5,

@@ -85,7 +85,8 @@ __device__ __forceinline__ float rdlanef(float v, int l) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l));
 }
 
-template <int N, int RPW>
+// AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous, see beam_wave.hip).
+template <int N, int RPW, bool AMB>
 __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     constexpr int NL = N - 1;
     constexpr int HALF = 64 / RPW;          // lanes (= beam slots) per read
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     int B = 1;
     int nn = 0;
     bool alive = has_read;
+    int n_amb = 0;
 
     // ---- row FIFO: register j holds rows [blk*RPR, blk*RPR + RPR) of block (front + j) ----
     const int fg = q / N, fc = q - fg * N;
@@ -284,6 +286,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         int bstar = KB - 1;
         int Lc = go ? n_valid : 0;
         uint32_t mx = 0;
+        bool tie = false;  // AMB: a kept candidate of this lane shares its probability with another candidate
         if (ballot(need_sel) != 0ull) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
@@ -349,14 +352,19 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             for (int e0 = 0; e0 < lmax; e0 += HALF) {
                 const int e = e0 + q;
                 const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
-                int rk = 0, rk2 = 0;
+                int rk = 0, rk2 = 0, n_eq = 0;
                 for (int j = 0; j < lmax; j += 2) {  // two keys per 16-byte LDS read
                     const ulonglong2 kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
                     rk += (kk2.x > ke) ? 1 : 0;
                     rk2 += (kk2.y > ke) ? 1 : 0;
+                    if (AMB) {  // equal probabilities share a bucket: every candidate tied with a kept one is listed
+                        n_eq += (kk2.x != 0ull && (uint32_t)(kk2.x >> 32) == (uint32_t)(ke >> 32)) ? 1 : 0;
+                        n_eq += (kk2.y != 0ull && (uint32_t)(kk2.y >> 32) == (uint32_t)(ke >> 32)) ? 1 : 0;
+                    }
                 }
                 rk += rk2;
                 if (e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                if (AMB) tie = tie || (e < Lc && rk < beam_size && n_valid > 20 && n_eq >= 2);
             }
             wave_sync();
             const uint64_t mine = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
@@ -367,18 +375,26 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 #pragma unroll
             for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
             wave_sync();
-            int rk[N];
+            int rk[N], n_eq[N];
 #pragma unroll
-            for (int k = 0; k < N; ++k) rk[k] = 0;
+            for (int k = 0; k < N; ++k) rk[k] = n_eq[k] = 0;
             for (int j = 0; j < HALF * N; ++j) {
                 const uint64_t kj = c_key[hbase * N + j];
 #pragma unroll
-                for (int k = 0; k < N; ++k) rk[k] += (kj > key[k]) ? 1 : 0;
+                for (int k = 0; k < N; ++k) {
+                    rk[k] += (kj > key[k]) ? 1 : 0;
+                    if (AMB) n_eq[k] += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key[k] >> 32)) ? 1 : 0;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < N; ++k) rank[k] = (key[k] != 0ull && rk[k] < beam_size) ? rk[k] : -1;
+            for (int k = 0; k < N; ++k) {
+                rank[k] = (key[k] != 0ull && rk[k] < beam_size) ? rk[k] : -1;
+                if (AMB) tie = tie || (rank[k] >= 0 && go && n_valid > 20 && n_eq[k] >= 2);
+            }
             wave_sync();
         }
+
+        if (AMB) n_amb += hcount(tie) != 0 ? 1 : 0;
 
         // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
         s_fate[lane] = rank[0];
@@ -497,6 +513,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
     }
+    if (AMB && q == 0 && has_read) p.out.ambiguous[r] = (uint32_t)n_amb;
     int h0 = bperm(hbase, node);
     int d0 = bperm(hbase, alive ? depth : 0);
     const int j0 = bperm(hbase, jump);
@@ -532,14 +549,19 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     }
 }
 
-template <int N>
-hipError_t launch_n(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
+template <int N, bool AMB>
+hipError_t launch_na(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
     if (p.a.beam_size <= 32) {  // two reads per wavefront
-        hipLaunchKernelGGL((beam_lane_kernel<N, 2>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((beam_lane_kernel<N, 1>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
     }
     return hipGetLastError();
+}
+
+template <int N>
+hipError_t launch_n(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
+    return p.out.ambiguous ? launch_na<N, true>(p, n_reads, stream) : launch_na<N, false>(p, n_reads, stream);
 }
 
 }  // namespace

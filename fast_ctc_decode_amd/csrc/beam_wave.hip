@@ -79,7 +79,13 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // S == 0: search::beam_search.  S > 0: search::crf_beam_search (:38-157) with S transition states:
 // the row is probs[t, state, :] of the entry's state, there is no repeat-stay, and an extension
 // moves to state (state * n_base) % n_state + label (:97).
-template <int N, int GW, int RPW, int S>
+//
+// AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous): the number of
+// steps with more than 20 candidates in which a KEPT candidate shares its exact probability with another
+// candidate -- the only steps where the reference's sort_unstable_by (pdqsort above 20 elements) could
+// produce a different beam (set or order) from the stable rule used here.  A separate instantiation: the
+// timed kernel pays nothing.
+template <int N, int GW, int RPW, int S, bool AMB>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S > 0;
     constexpr int NL = N - 1;
@@ -97,6 +103,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     static_assert(HAS_SCRATCH || NIDLE >= 1, "no lane left to absorb idle pushes");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
+    int n_amb = 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -299,15 +306,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rank = 0;
+        int n_eq = 0;  // AMB: candidates of exactly this probability, itself included
 #pragma unroll
         for (int j = 0; j < BCAP; ++j) {
 #pragma unroll
-            for (int c = 0; c <= NL; ++c) rank += (keys[hbase + j * GW + c] > key) ? 1 : 0;
+            for (int c = 0; c <= NL; ++c) {
+                const uint64_t kj = keys[hbase + j * GW + c];
+                rank += (kj > key) ? 1 : 0;
+                if (AMB) n_eq += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
+            }
         }
         __builtin_amdgcn_wave_barrier();
 
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
         const bool sel = valid && go && rank < beam_size;
+        if (AMB) {
+            // a kept candidate that shares its probability with any other candidate of a > 20-candidate step
+            const bool tie = sel && n_valid > 20 && n_eq >= 2;
+            const uint64_t m_tie = ballot(tie);
+            n_amb += (RPW == 1 ? m_tie : (hbase ? (m_tie >> 32) : (m_tie & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
+        }
 
         // ---- keep the IN-BEAM/slot bits of every child entry current ----
         // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
@@ -384,6 +402,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
     }
+    if (AMB && q == 0 && has_read) p.out.ambiguous[r] = (uint32_t)n_amb;
     int *heads = s_heads[wave];
     // beam[0] lives in group 0: every lane of the half takes ITS leaf and depth
     int h0 = bperm(hbase, node);               // current chunk's first segment head
@@ -431,8 +450,12 @@ template <int N, int GW, int RPW, int S = 0>
 hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
     const int64_t waves = (n_reads + RPW - 1) / RPW;
     const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
-    hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
-                       stream, p);
+    if (p.out.ambiguous)
+        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+                           stream, p);
+    else
+        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+                           stream, p);
     return hipGetLastError();
 }
 

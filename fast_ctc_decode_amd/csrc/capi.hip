@@ -80,7 +80,7 @@ BatchDesc to_desc(const fcd_batch *in, bool crf) {
 }
 
 ResultDesc to_desc(const fcd_result *o) {
-    return ResultDesc{o->labels, o->path, o->qual, o->out_len, o->status, o->out_stride};
+    return ResultDesc{o->labels, o->path, o->qual, o->out_len, o->status, o->out_stride, o->ambiguous};
 }
 
 // Brackets the kernel launches of one search call with HIP events on the launch stream.
@@ -808,6 +808,8 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     const size_t o_qual = reserve(out->qual ? n_out * 4 : 0);
     const size_t o_olen = reserve((size_t)B * 4);
     const size_t o_stat = reserve((size_t)B * 4);
+    const bool want_amb = out->ambiguous && (c.op == Op::Beam || c.op == Op::CrfBeam);
+    const size_t o_amb = reserve(want_amb ? (size_t)B * 4 : 0);
 
     int rc;
     {
@@ -834,13 +836,15 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     dout.out_len = reinterpret_cast<uint32_t *>(base + o_olen);
     dout.status = reinterpret_cast<int32_t *>(base + o_stat);
     dout.out_stride = out->out_stride;
+    dout.ambiguous = want_amb ? reinterpret_cast<uint32_t *>(base + o_amb) : nullptr;
     const float *dinit = reinterpret_cast<const float *>(base + o_init);
 
     switch (c.op) {
         case Op::Viterbi: rc = fcd_viterbi_search_dev(h, &din, c.collapse, &dout); break;
         case Op::Beam: rc = fcd_beam_search_dev(h, &din, c.beam_size, c.thr, c.collapse, c.kernel, &dout); break;
         case Op::CrfBeam:
-            rc = fcd_crf_beam_search_dev(h, &din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, &dout);
+            rc = fcd_crf_beam_search_dev_k(h, &din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel,
+                                           &dout);
             break;
         case Op::CrfGreedy:
             rc = fcd_crf_greedy_search_dev(h, &din, dinit, c.n_init, c.init_stride, &dout);
@@ -854,6 +858,8 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     if (out->status)
         FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (want_amb)
+        FCD_HIP(h, hipMemcpyAsync(out->ambiguous, dout.ambiguous, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
 }
@@ -881,9 +887,17 @@ int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
 int fcd_crf_beam_search_host(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                              int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                              const fcd_result *out) {
+    return fcd_crf_beam_search_host_k(h, in, init, n_init, init_stride, beam_size, beam_cut_threshold,
+                                      FCD_KERNEL_AUTO, out);
+}
+
+int fcd_crf_beam_search_host_k(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                               int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                               int kernel, const fcd_result *out) {
     HostCall c{Op::CrfBeam};
     c.beam_size = beam_size;
     c.thr = beam_cut_threshold;
+    c.kernel = kernel;
     c.init = init;
     c.n_init = n_init;
     c.init_stride = init_stride;

@@ -32,6 +32,7 @@ struct ResultDesc {
     uint32_t *out_len;
     int32_t *status;
     int64_t out_stride;
+    uint32_t *ambiguous;  // nullable: per-read count of unpinned tie steps (beam searches only)
 };
 
 // Parameters of the 1D beam searches (search::beam_search / search::crf_beam_search).

@@ -107,6 +107,15 @@ typedef struct fcd_batch {
  *            reference feeds to phred() for each emitted label (src/search.rs:348-356,370-376)
  *   out_len: [n_reads] u32   number of emitted labels
  *   status : [n_reads] i32   FCD_ST_*  (nullable for viterbi)
+ *   ambiguous: [n_reads] u32 (nullable; fcd_beam_search_* and fcd_crf_beam_search_* only; device pointer
+ *            for *_dev, host pointer for *_host).  A tie instrument, not a reference output: the number
+ *            of time steps at which the merged candidate list held more than 20 entries AND a candidate
+ *            that survived the truncation had exactly the probability of another candidate.  The
+ *            reference sorts candidates with sort_unstable_by (src/search.rs:122,262), which is a
+ *            stable insertion sort up to 20 elements and pdqsort (implementation-defined tie order)
+ *            above; the kernels break ties by ascending node index.  A read whose count is 0 has the
+ *            same beam (set and order) at every step under ANY tie order.
+ *            Passing the array selects instrumented kernel instantiations (slower by a few percent).
  * out_stride must be >= the longest possible output (T is always enough). */
 typedef struct fcd_result {
     uint8_t *labels;
@@ -115,6 +124,7 @@ typedef struct fcd_result {
     uint32_t *out_len;
     int32_t *status;
     int64_t out_stride;
+    uint32_t *ambiguous;
 } fcd_result;
 
 /* ---- library / handle ---- */
@@ -164,6 +174,9 @@ int fcd_crf_beam_search_dev_k(fcd_handle *h, const fcd_batch *in, const float *i
 int fcd_crf_beam_search_host(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                              int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                              const fcd_result *out);
+int fcd_crf_beam_search_host_k(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                               int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
+                               int kernel, const fcd_result *out);
 
 /* ---- search::crf_greedy_search (src/search.rs:385-423) ---- */
 int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,

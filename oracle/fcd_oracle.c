@@ -251,7 +251,16 @@ DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
 /*
  * Shared tail of every 1D step: :245-282 (== :105-142).  Returns FCDO_* status.
  */
-static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *tmpcap) {
+/*
+ * n_amb (nullable) counts the steps whose outcome the restatement cannot pin to the reference: the
+ * merged list holds more than 20 candidates (so Rust 1.78's sort_unstable_by is a true pdqsort whose
+ * tie order is implementation-defined) AND a candidate that survives the truncation has
+ * exactly the probability of another candidate (kept or dropped).  Ties among dropped candidates never
+ * matter.  With no such step in a read, the kept list -- set AND order -- of every > 20-candidate step is
+ * the same under any tie order, every <= 20-candidate step is Rust's stable insertion sort, which the
+ * stable sort here reproduces, so node numbering, beam and output follow the reference step for step.
+ */
+static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *tmpcap, int64_t *n_amb) {
     sp1_sort_node(beam->v, beam->len, tmp, tmpcap); /* :245 stable */
     /* :246-260 fold equal nodes into the first occurrence, then retain */
     int64_t w = 0;
@@ -273,6 +282,12 @@ static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *
         }
     }
     sp1_sort_prob(beam->v, beam->len, tmp, tmpcap);
+    if (n_amb && beam->len > 20) {
+        int tie = 0; /* sorted: equal probabilities are adjacent */
+        for (int64_t i = 0; i < beam_size && i + 1 < beam->len; ++i)
+            tie |= sp1_prob(&beam->v[i]) == sp1_prob(&beam->v[i + 1]);
+        if (tie) ++*n_amb;
+    }
     if (beam->len > beam_size) beam->len = beam_size; /* :273 */
     if (beam->len == 0) return FCDO_RAN_OUT_OF_BEAM;  /* :274-277 */
     float top = sp1_prob(&beam->v[0]);                /* :278-282 */
@@ -314,16 +329,25 @@ typedef struct {
 
 static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                           int64_t beam_size, float thr, int collapse_repeats, int32_t *labels,
-                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out);
+                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out, int64_t *n_amb);
 
 int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                      int64_t beam_size, float thr, int collapse_repeats,
                      int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out) {
+    return fcdo_beam_search_ex(x, T, N, rs, cs, beam_size, thr, collapse_repeats, labels, path, n_out,
+                               n_nodes_out, NULL);
+}
+
+int fcdo_beam_search_ex(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                        int64_t beam_size, float thr, int collapse_repeats,
+                        int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out,
+                        int64_t *n_ambiguous_out) {
     beam_ws ws;
     memset(&ws, 0, sizeof(ws));
     ws.tree = fcdo_tree_new(N - 1);
+    if (n_ambiguous_out) *n_ambiguous_out = 0;
     int st = beam_search_ws(&ws, x, T, N, rs, cs, beam_size, thr, collapse_repeats, labels, path,
-                            n_out, n_nodes_out);
+                            n_out, n_nodes_out, n_ambiguous_out);
     free(ws.beam.v);
     free(ws.next.v);
     free(ws.tmp);
@@ -333,7 +357,7 @@ int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t c
 
 static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                           int64_t beam_size, float thr, int collapse_repeats, int32_t *labels,
-                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out) {
+                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out, int64_t *n_amb) {
     int64_t alphabet_size = N - 1; /* :167 */
     fcdo_tree *tree = ws->tree;
     tree_reset(tree);
@@ -381,7 +405,7 @@ static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int
         sp1vec t = beam; /* :242 swap */
         beam = next;
         next = t;
-        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap);
+        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap, n_amb);
         if (status != FCDO_OK) break;
     }
 
@@ -419,6 +443,16 @@ int fcdo_crf_beam_search(const float *x, int64_t T, int64_t S, int64_t N,
                          const float *init, int64_t n_init, int64_t is0,
                          int64_t beam_size, float thr,
                          int32_t *labels, int64_t *path, int64_t *n_out) {
+    return fcdo_crf_beam_search_ex(x, T, S, N, s0, s1, s2, init, n_init, is0, beam_size, thr, labels, path,
+                                   n_out, NULL);
+}
+
+int fcdo_crf_beam_search_ex(const float *x, int64_t T, int64_t S, int64_t N,
+                            int64_t s0, int64_t s1, int64_t s2,
+                            const float *init, int64_t n_init, int64_t is0,
+                            int64_t beam_size, float thr,
+                            int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_ambiguous_out) {
+    if (n_ambiguous_out) *n_ambiguous_out = 0;
     if (T <= 0 || S <= 0 || N <= 0) return FCDO_PANIC; /* :46 */
     int64_t n_state = S, n_base = N - 1;               /* :50-51 */
     int64_t st0;
@@ -459,7 +493,7 @@ int fcdo_crf_beam_search(const float *x, int64_t T, int64_t S, int64_t N,
         sp1vec t = beam;
         beam = next;
         next = t;
-        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap); /* :104-142 */
+        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap, n_ambiguous_out); /* :104-142 */
     }
     if (status == FCDO_OK) *n_out = tree_walk_1d(tree, beam.v[0].node, labels, path);
     free(beam.v);
@@ -982,6 +1016,7 @@ typedef struct {
     int32_t *labels;
     int64_t *path, *lens;
     int32_t *status;
+    int64_t *ambiguous; /* nullable: per-read count of unpinned tie steps (sp1_merge_prune) */
     volatile int64_t *next;
 } batch_job;
 
@@ -1001,16 +1036,17 @@ static void *batch_worker(void *arg) {
         const float *x = j->x + r * j->T * j->N;
         int32_t *ol = store ? j->labels + r * j->T : sl;
         int64_t *op = store ? j->path + r * j->T : sp;
-        int64_t n = 0;
+        int64_t n = 0, amb = 0;
         int st;
         if (j->kind == 0)
             st = beam_search_ws(&ws, x, j->T, j->N, j->N, 1, j->beam_size, j->thr, j->collapse, ol,
-                                op, &n, NULL);
+                                op, &n, NULL, (store && j->ambiguous) ? &amb : NULL);
         else
             st = fcdo_viterbi_search(x, j->T, j->N, j->N, 1, j->collapse, 1.0f, 0.0f, ol, op, NULL, &n);
         if (store) {
             j->lens[r] = (st == FCDO_OK) ? n : 0;
             if (j->status) j->status[r] = st;
+            if (j->ambiguous) j->ambiguous[r] = amb;
         }
     }
     free(sl);
@@ -1040,14 +1076,22 @@ int fcdo_beam_search_batch(const float *x, int64_t n_reads, int64_t T, int64_t N
                            int64_t beam_size, float thr, int collapse,
                            int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
                            int n_threads, int64_t n_passes) {
+    return fcdo_beam_search_batch_ex(x, n_reads, T, N, beam_size, thr, collapse, labels, path, lens, status,
+                                     NULL, n_threads, n_passes);
+}
+
+int fcdo_beam_search_batch_ex(const float *x, int64_t n_reads, int64_t T, int64_t N,
+                              int64_t beam_size, float thr, int collapse,
+                              int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
+                              int64_t *ambiguous, int n_threads, int64_t n_passes) {
     if (n_passes < 1) n_passes = 1;
     batch_job job = {x, n_reads * n_passes, n_reads, T, N, beam_size, thr, collapse, 0,
-                     labels, path, lens, status, NULL};
+                     labels, path, lens, status, ambiguous, NULL};
     return run_batch(&job, n_threads);
 }
 
 int fcdo_viterbi_batch(const float *x, int64_t n_reads, int64_t T, int64_t N, int collapse,
                        int32_t *labels, int64_t *path, int64_t *lens, int n_threads) {
-    batch_job job = {x, n_reads, n_reads, T, N, 0, 0.0f, collapse, 1, labels, path, lens, NULL, NULL};
+    batch_job job = {x, n_reads, n_reads, T, N, 0, 0.0f, collapse, 1, labels, path, lens, NULL, NULL, NULL};
     return run_batch(&job, n_threads);
 }

@@ -71,6 +71,19 @@ int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t c
                      int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out);
 
 /*
+ * The same search plus the tie instrument of SURVEY.md 8a A4: n_ambiguous_out (nullable) receives the
+ * number of time steps at which the merged candidate list held MORE than 20 entries (Rust 1.78's
+ * sort_unstable_by is a stable insertion sort up to 20 elements, pdqsort above) AND a candidate that
+ * survived the truncation had exactly the probability of another candidate.  On a read where the
+ * count is 0 the stable tie rule used here and ANY tie order of pdqsort give the same beam -- set and
+ * order -- at every step, hence the same node numbering and the same output.
+ */
+int fcdo_beam_search_ex(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                        int64_t beam_size, float beam_cut_threshold, int collapse_repeats,
+                        int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out,
+                        int64_t *n_ambiguous_out);
+
+/*
  * src/search.rs:38-157.  x is (T,S,N) with strides (s0,s1,s2); init is (>=S,) stride is0,
  * n_init its length.
  */
@@ -79,6 +92,12 @@ int fcdo_crf_beam_search(const float *x, int64_t T, int64_t S, int64_t N,
                          const float *init, int64_t n_init, int64_t is0,
                          int64_t beam_size, float beam_cut_threshold,
                          int32_t *labels, int64_t *path, int64_t *n_out);
+
+int fcdo_crf_beam_search_ex(const float *x, int64_t T, int64_t S, int64_t N,
+                            int64_t s0, int64_t s1, int64_t s2,
+                            const float *init, int64_t n_init, int64_t is0,
+                            int64_t beam_size, float beam_cut_threshold,
+                            int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_ambiguous_out);
 
 /* src/search.rs:385-423.  quals[] (nullable) one phred char per label. */
 int fcdo_crf_greedy_search(const float *x, int64_t T, int64_t S, int64_t N,
@@ -117,6 +136,12 @@ int fcdo_beam_search_batch(const float *x, int64_t n_reads, int64_t T, int64_t N
                            int64_t beam_size, float thr, int collapse,
                            int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
                            int n_threads, int64_t n_passes);
+
+/* as above; ambiguous (nullable, n_reads entries) receives fcdo_beam_search_ex's tie count per read */
+int fcdo_beam_search_batch_ex(const float *x, int64_t n_reads, int64_t T, int64_t N,
+                              int64_t beam_size, float thr, int collapse,
+                              int32_t *labels, int64_t *path, int64_t *lens, int32_t *status,
+                              int64_t *ambiguous, int n_threads, int64_t n_passes);
 
 int fcdo_viterbi_batch(const float *x, int64_t n_reads, int64_t T, int64_t N, int collapse,
                        int32_t *labels, int64_t *path, int64_t *lens, int n_threads);

@@ -42,6 +42,9 @@ def _load():
     P = C.c_void_p
     lib.fcdo_viterbi_search.argtypes = [P, i64, i64, i64, i64, i32, f32, f32, P, P, P, P]
     lib.fcdo_beam_search.argtypes = [P, i64, i64, i64, i64, i64, f32, i32, P, P, P, P]
+    lib.fcdo_beam_search_ex.argtypes = [P, i64, i64, i64, i64, i64, f32, i32, P, P, P, P, P]
+    lib.fcdo_crf_beam_search_ex.argtypes = [P, i64, i64, i64, i64, i64, i64, P, i64, i64, i64, f32, P, P, P, P]
+    lib.fcdo_beam_search_batch_ex.argtypes = [P, i64, i64, i64, i64, f32, i32, P, P, P, P, P, i32, i64]
     lib.fcdo_crf_beam_search.argtypes = [P, i64, i64, i64, i64, i64, i64, P, i64, i64, i64, f32, P, P, P]
     lib.fcdo_crf_greedy_search.argtypes = [P, i64, i64, i64, i64, i64, i64, P, i64, i64, f32, f32, P, P, P, P]
     lib.fcdo_beam_search_duplex.argtypes = [P, i64, i64, i64, P, i64, i64, i64, i64, P, i64, i64, i64, f32, i32, i32, P, P]
@@ -151,6 +154,35 @@ def beam_search_raw(network_output, beam_size, beam_cut_threshold, collapse_repe
                               int(collapse_repeats), _ptr(labels), _ptr(path), C.byref(n),
                               C.byref(nn))
     return st, labels[: n.value], path[: n.value], nn.value
+
+
+def beam_search_ambiguous(network_output, beam_size, beam_cut_threshold, collapse_repeats=True):
+    """-> (status, labels, path, n_ambiguous): fcdo_beam_search_ex, the search plus the number of steps
+    with > 20 candidates and an exact tie at ranks 0/1 or across the truncation boundary."""
+    x = network_output
+    T, N = x.shape
+    rs, cs = _estrides(x)
+    labels = np.empty(max(T, 1), np.int32)
+    path = np.empty(max(T, 1), np.int64)
+    n, nn, na = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    st = lib.fcdo_beam_search_ex(_ptr(x), T, N, rs, cs, beam_size, beam_cut_threshold,
+                                 int(collapse_repeats), _ptr(labels), _ptr(path), C.byref(n),
+                                 C.byref(nn), C.byref(na))
+    return st, labels[: n.value], path[: n.value], na.value
+
+
+def crf_beam_search_ambiguous(network_output, init_state, beam_size, beam_cut_threshold):
+    """-> (status, labels, path, n_ambiguous) of fcdo_crf_beam_search_ex (labels in sequence order)"""
+    x, init = network_output, init_state
+    T, S, N = x.shape
+    s0, s1, s2 = _estrides(x)
+    labels = np.empty(max(T, 1), np.int32)
+    path = np.empty(max(T, 1), np.int64)
+    n, na = C.c_int64(0), C.c_int64(0)
+    st = lib.fcdo_crf_beam_search_ex(_ptr(x), T, S, N, s0, s1, s2, _ptr(init), init.shape[0],
+                                     _estrides(init)[0], beam_size, beam_cut_threshold,
+                                     _ptr(labels), _ptr(path), C.byref(n), C.byref(na))
+    return st, labels[: n.value], path[: n.value], na.value
 
 
 def _check_beam_args(n_alpha, inner, beam_size, thr):
@@ -297,16 +329,18 @@ def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, ini
     return "".join(alphabet[l] for l in labels[: n.value][::-1])[::-1]
 
 
-def beam_search_batch(x, beam_size, thr, collapse=True, n_threads=1, n_passes=1, out=None):
+def beam_search_batch(x, beam_size, thr, collapse=True, n_threads=1, n_passes=1, out=None, ambiguous=None):
     """x: (B,T,N) C-contiguous f32 -> (labels (B,T) i32, path (B,T) i64, lens (B,), status (B,)).
-    `out` may carry pre-touched output arrays (so that page faults stay out of a timed call)."""
+    `out` may carry pre-touched output arrays (so that page faults stay out of a timed call).
+    `ambiguous`: optional int64 (B,) array that receives the per-read tie count of beam_search_ambiguous."""
     x = np.ascontiguousarray(x, np.float32)
     B, T, N = x.shape
     if out is None:
         out = batch_outputs(B, T)
     labels, path, lens, status = out
-    lib.fcdo_beam_search_batch(_ptr(x), B, T, N, beam_size, thr, int(collapse), _ptr(labels),
-                               _ptr(path), _ptr(lens), _ptr(status), n_threads, n_passes)
+    lib.fcdo_beam_search_batch_ex(_ptr(x), B, T, N, beam_size, thr, int(collapse), _ptr(labels),
+                                  _ptr(path), _ptr(lens), _ptr(status),
+                                  None if ambiguous is None else _ptr(ambiguous), n_threads, n_passes)
     return labels, path, lens, status
 
 

@@ -55,6 +55,10 @@ def test_full_length_read_every_kernel(fcd):
     P.check_beam(fcd, x[:1], 64, 0.1, kernel=4)
 
 
+def test_ambiguity_counter(fcd):
+    P.test_ambiguity_counter(fcd)
+
+
 def test_viterbi_and_crf(fcd):
     P.test_viterbi_random(fcd)
     P.test_viterbi_qual_bits(fcd)

@@ -40,10 +40,68 @@ def digest(r):
         (r.status.astype(np.uint64) << np.uint64(60))
 
 
-def test_three_kernels_agree_on_every_read(fcd, batch):
+def test_four_kernels_agree_on_every_read(fcd, batch):
+    """generic (LDS), wave (two reads per wavefront), wave (one read), lane: four independently written
+    kernels give the same (labels, path, len, status) on all 4096 BASELINE config-2 reads."""
     _, xd = batch
-    d = [digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k)) for k in (1, 2, 3)]
-    assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2])
+    d = [digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k)) for k in (1, 2, 3, 4)]
+    for k in (1, 2, 3):
+        assert np.array_equal(d[0], d[k]), k
+
+
+def test_config2_has_no_unpinned_ties(fcd, batch):
+    """above 20 candidates the reference's sort_unstable_by is pdqsort, whose tie order is
+    not pinned.  The tie instrument (fcd_result.ambiguous) must read 0 on every read of BASELINE config 2
+    -- on the GPU for all 4096, and the oracle's own counter must agree on a sample -- so that "identical
+    to the reference" does not depend on the tie rule there; the instrumented kernels must also return
+    the timed kernels' results."""
+    x, xd = batch
+    base = digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True))
+    for k in (0, 1, 4):
+        r = fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k, count_ambiguous=True).cpu()
+        assert int(np.asarray(r.ambiguous).sum()) == 0, k
+        assert np.array_equal(digest(r), base), k
+    amb = np.zeros(64, np.int64)
+    oracle.beam_search_batch(x[:64], 5, 0.1, True, n_threads=8, ambiguous=amb)
+    assert int(amb.sum()) == 0
+
+
+@pytest.mark.parametrize("beam,n_oracle", [(32, 16), (64, 16)])
+def test_config3_lane_kernel_full_length_vs_oracle(fcd, batch, beam, n_oracle):
+    """BASELINE config 3 rows (T = 4000, N = 5) on the kernel AUTO picks for wide beams -- one beam entry
+    per lane, two reads per wavefront at beam 32, one at beam 64: 23-bit node ids, ~172 k nodes per read,
+    eviction / reload of child rows over the whole read.  Bit-exact (labels, path, status) against the
+    oracle on n_oracle reads, no unpinned ties on them."""
+    x, xd = batch
+    sub = xd[:n_oracle + 1]  # an odd count: the last wavefront of the two-reads-per-wave variant is half full
+    r = fcd.beam_search_batch_raw(sub, beam, 0.1, True, count_ambiguous=True).cpu()
+    r_lane = fcd.beam_search_batch_raw(sub, beam, 0.1, True, kernel=fcd.KERNEL_LANE).cpu()
+    assert np.array_equal(digest(r), digest(r_lane))  # AUTO == the lane kernel here
+    for i in range(n_oracle):
+        st, labels, path, n_amb = oracle.beam_search_ambiguous(x[i], beam, 0.1, True)
+        n = int(r.out_len[i])
+        assert int(r.status[i]) == st == 0 and n == len(labels), i
+        np.testing.assert_array_equal(r.labels[i, :n], labels)
+        np.testing.assert_array_equal(r.path[i, :n], path)
+        assert n_amb == 0 and int(r.ambiguous[i]) == 0, i
+
+
+def test_config3_lane_and_generic_agree_on_8192_reads(fcd):
+    """BASELINE config 3's per-GPU shard (8192 reads x 4000 x 5, beam 32): the lane kernel (two reads per
+    wavefront) and the LDS kernel agree on every read, and the tie instrument reads 0 on all of them."""
+    torch = pytest.importorskip("torch")
+    rng = np.random.default_rng(2)
+    x = rng.random((8192 * T, N), dtype=np.float32)
+    x /= np.linalg.norm(x, ord=2, axis=1, keepdims=True)
+    xd = torch.from_numpy(x.reshape(8192, T, N)).cuda()
+    lane = fcd.beam_search_batch_raw(xd, 32, 0.1, True, kernel=fcd.KERNEL_LANE, count_ambiguous=True)
+    d_lane = digest(lane)
+    assert int(lane.cpu().ambiguous.astype(np.int64).sum()) == 0
+    del lane
+    d_plain = digest(fcd.beam_search_batch_raw(xd, 32, 0.1, True))
+    assert np.array_equal(d_lane, d_plain)
+    gen = fcd.beam_search_batch_raw(xd[:2048], 32, 0.1, True, kernel=fcd.KERNEL_GENERIC)
+    assert np.array_equal(digest(gen), d_lane[:2048])
 
 
 def test_oracle_spot_check(fcd, batch):
@@ -125,6 +183,9 @@ def test_crf_full_size_kernels_agree(fcd):
     init[torch.arange(1024), torch.arange(1024) % 4] = 1.0
     d = [digest(fcd.crf_beam_search_batch_raw(x, init, 5, 0.0, kernel=k)) for k in (1, 2, 3)]
     assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2])
+    # BASELINE config 4 shape: no unpinned ties, instrumented == timed kernels
+    ra = fcd.crf_beam_search_batch_raw(x, init, 5, 0.0, count_ambiguous=True).cpu()
+    assert int(np.asarray(ra.ambiguous).sum()) == 0 and np.array_equal(digest(ra), d[0])
     xc, ic = x[:3].cpu().numpy(), init[:3].cpu().numpy()
     r = fcd.crf_beam_search_batch_raw(x[:3].contiguous(), init[:3].contiguous(), 5, 0.0).cpu()
     for i in range(3):

@@ -86,6 +86,42 @@ def test_beam_lane_random(fcd, N, beam):
     check_beam(fcd, q, beam, 0.0, kernel=fcd.KERNEL_LANE)
 
 
+def check_ambiguous(fcd, x, beam, thr, kernels, collapse=True):
+    """fcd_result.ambiguous == the oracle's count of unpinned-tie steps, and the
+    instrumented kernels return exactly what the oracle (and hence the timed kernels) return."""
+    want = [oracle.beam_search_ambiguous(x[i], beam, thr, collapse) for i in range(len(x))]
+    for k in kernels:
+        r = fcd.beam_search_batch_raw(x, beam, thr, collapse, kernel=k, count_ambiguous=True)
+        for i, (st, labels, path, n_amb) in enumerate(want):
+            n = int(r.out_len[i])
+            assert int(r.status[i]) == st, (k, i)
+            if st == 0:
+                np.testing.assert_array_equal(r.labels[i, :n], labels)
+                np.testing.assert_array_equal(r.path[i, :n], path)
+            assert int(r.ambiguous[i]) == n_amb, (k, i, int(r.ambiguous[i]), n_amb)
+    return sum(w[3] for w in want)
+
+
+def test_ambiguity_counter(fcd):
+    """The tie instrument on every kernel family: quantised posteriors (exact ties at almost every step
+    above 20 candidates) must give the oracle's non-zero counts; reference-style rows must give 0."""
+    rng = np.random.default_rng(77)
+    q = (rng.integers(0, 4, size=(5, 150, 5)) / 4.0).astype(np.float32)
+    assert check_ambiguous(fcd, q, 5, 0.0, (0, 1, 2, 3, 4)) > 0
+    assert check_ambiguous(fcd, q, 12, 0.0, (0, 1, 2, 4)) > 0
+    assert check_ambiguous(fcd, q, 32, 0.0, (0, 1, 4), collapse=False) > 0
+    q8 = (rng.integers(0, 3, size=(3, 100, 8)) / 4.0).astype(np.float32)
+    assert check_ambiguous(fcd, q8, 8, 0.0, (1, 4)) > 0
+    assert check_ambiguous(fcd, q8, 64, 0.0, (1, 4)) > 0
+    q4 = (rng.integers(0, 4, size=(3, 100, 4)) / 4.0).astype(np.float32)   # 5 x 4 = 20 candidates: never > 20
+    assert check_ambiguous(fcd, q4, 5, 0.0, (1, 2, 3, 4)) == 0
+    x = gen_batch(78, 4, 300, 5)
+    assert check_ambiguous(fcd, x, 5, 0.1, (0, 1, 2, 3, 4)) == 0
+    assert check_ambiguous(fcd, x, 32, 0.1, (0, 1, 4)) == 0
+    x[1, 100] = np.nan   # a read that fails mid-way reports the count up to the failing step
+    check_ambiguous(fcd, x, 5, 0.1, (1, 2, 3, 4))
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
 def test_beam_thr0(fcd, collapse, kernel):
