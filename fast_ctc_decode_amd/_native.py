@@ -32,6 +32,7 @@ SYMBOLS = [
     "fcd_crf_beam_search_duplex_dev", "fcd_crf_beam_search_duplex_host",
     "fcd_duplex_envelope_dev", "fcd_duplex_envelope_host",
     "fcd_logspace_probe_dev", "fcd_phred",
+    "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
 ]
 
 
@@ -122,6 +123,11 @@ def bind(lib):
         getattr(lib, "fcd_duplex_envelope_" + sfx).argtypes = [
             P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]
     lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
+    lib.fcd_packed_result_bytes.argtypes = [i64, i64, i32]
+    lib.fcd_packed_result_bytes.restype = i64
+    lib.fcd_result_offsets_dev.argtypes = [P, P, i64, i64, P]
+    lib.fcd_pack_results_dev.argtypes = [P, RP, i64, i32, P, P]
+    lib.fcd_unpack_results_dev.argtypes = [P, P, i64, P, RP]
     lib.fcd_phred.argtypes = [f32, f32, f32]
     lib.fcd_phred.restype = C.c_uint32
     return lib

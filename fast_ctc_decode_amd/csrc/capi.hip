@@ -760,6 +760,54 @@ int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float 
     return FCD_OK;
 }
 
+// ---- compact wire format of a shard's results (pack.hip) ----
+int64_t fcd_packed_result_bytes(int64_t n_reads, int64_t total_labels, int path_bytes) {
+    if (n_reads < 0 || total_labels < 0 || (path_bytes != 2 && path_bytes != 4)) return -1;
+    const int64_t b = 16 + 8 * n_reads + ((total_labels + 3) & ~3ll) + total_labels * path_bytes;
+    return (b + 15) & ~15ll;
+}
+
+int fcd_result_offsets_dev(fcd_handle *h, const uint32_t *out_len, int64_t n_reads, int64_t out_stride,
+                           uint64_t *offsets) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (n_reads < 0 || !offsets || (n_reads > 0 && !out_len) || out_stride < 0) return fail(h, FCD_E_INVALID, "bad argument");
+    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_HIP(h, launch_result_offsets(out_len, n_reads, out_stride, offsets, h->stream));
+    return FCD_OK;
+}
+
+int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, int path_bytes,
+                         const uint64_t *offsets, uint8_t *buf) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!res || n_reads < 0 || !offsets || !buf || (path_bytes != 2 && path_bytes != 4))
+        return fail(h, FCD_E_INVALID, "bad argument");
+    if (n_reads > 0 && (!res->labels || !res->path || !res->out_len)) return fail(h, FCD_E_INVALID, "null labels/path/out_len");
+    FCD_HIP(h, hipSetDevice(h->device));
+    if (n_reads == 0) {
+        FCD_HIP(h, hipMemsetAsync(buf, 0, 16, h->stream));
+        return FCD_OK;
+    }
+    FCD_HIP(h, launch_pack(to_desc(res), n_reads, path_bytes, offsets, buf, h->stream));
+    return FCD_OK;
+}
+
+int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, uint64_t *offsets,
+                           const fcd_result *out) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (!buf || n_reads < 0 || !offsets || !out) return fail(h, FCD_E_INVALID, "bad argument");
+    if (n_reads == 0) return FCD_OK;
+    if (!out->labels || !out->out_len) return fail(h, FCD_E_INVALID, "null labels/out_len");
+    FCD_HIP(h, hipSetDevice(h->device));
+    // the buffer's own out_len array (offset 16) gives the read offsets
+    FCD_HIP(h, launch_result_offsets(reinterpret_cast<const uint32_t *>(buf + 16), n_reads, out->out_stride, offsets,
+                                     h->stream));
+    FCD_HIP(h, launch_unpack(buf, n_reads, offsets, to_desc(out), h->stream));
+    return FCD_OK;
+}
+
 // ---- *_host: stage host buffers through device memory, run the *_dev path, copy back -------
 namespace {
 

@@ -144,6 +144,13 @@ size_t envelope_lds_bytes(int64_t L2cap);
 hipError_t launch_max_u32(const uint32_t *a, const uint32_t *b, int64_t n, uint32_t *out2, hipStream_t stream);
 hipError_t launch_envelope(const EnvelopeArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream);
 
+// compact wire format of decoded results (pack.hip)
+hipError_t launch_result_offsets(const uint32_t *len, int64_t n, int64_t stride, uint64_t *offsets, hipStream_t stream);
+hipError_t launch_pack(const ResultDesc &res, int64_t n, int path_bytes, const uint64_t *offsets, uint8_t *buf,
+                       hipStream_t stream);
+hipError_t launch_unpack(const uint8_t *buf, int64_t n, const uint64_t *offsets, const ResultDesc &out,
+                         hipStream_t stream);
+
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
                                  int64_t n, int mode, hipStream_t stream);
 

@@ -1,0 +1,166 @@
+// pack.hip -- compact wire format of a shard's decoded results for the ONE gather of the multi-GPU path
+// (fast_ctc_decode_amd/dist.py).  The searches write fixed-stride rows (out_stride >= T
+// entries per read) of which ~48 % are used at BASELINE config 2; shipping only the used prefix of every
+// row halves the bytes on the xGMI link:
+//
+//   [ 0, 8)              u64  total = sum(out_len)
+//   [ 8,16)              u32  n_reads, u32 path_bytes (2 or 4)
+//   [16, 16+4n)          u32  out_len[n]
+//   [16+4n, 16+8n)       i32  status[n]
+//   [16+8n, +align4(total))   u8   labels of read 0, read 1, ... back to back
+//   [.., + total*path_bytes)  u16/u32 path entries, same order
+//
+// fcd_result_offsets_dev: exclusive prefix sum of out_len (one workgroup, DPP-free shuffle scan).
+// fcd_pack_results_dev / fcd_unpack_results_dev: one wavefront per read, coalesced 4-byte source loads.
+#include "device_utils.h"
+#include "fcd_internal.h"
+
+namespace fcd {
+
+namespace {
+
+constexpr int kScanThreads = 1024;
+
+// offsets[i] = sum of len[0..i), offsets[n] = total; len[i] is clamped to `stride`
+__global__ __launch_bounds__(kScanThreads) void result_offsets_kernel(const uint32_t *len, int64_t n, int64_t stride,
+                                                                      uint64_t *offsets) {
+    __shared__ uint64_t s_part[kScanThreads / 64];
+    __shared__ uint64_t s_carry;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += kScanThreads) {
+        const int64_t i = base + tid;
+        uint64_t v = 0;
+        if (i < n) {
+            const uint64_t l = len[i];
+            v = l < (uint64_t)stride ? l : (uint64_t)stride;
+        }
+        // inclusive scan inside the wavefront (two 32-bit halves per shuffle)
+        uint64_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o);
+            if (lane >= o) incl += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        uint64_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_part[w];
+        if (i < n) offsets[i] = before + incl - v;
+        __syncthreads();
+        if (tid == kScanThreads - 1) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) offsets[n] = s_carry;
+}
+
+struct PackParams {
+    const uint8_t *labels;
+    const uint32_t *path;
+    const uint32_t *out_len;
+    const int32_t *status;
+    int64_t stride;
+    int64_t n;
+    int path_bytes;
+    const uint64_t *offsets;
+    uint8_t *buf;
+};
+
+__device__ __forceinline__ size_t header_bytes(int64_t n) { return 16 + 8 * (size_t)n; }
+
+__global__ __launch_bounds__(256) void pack_kernel(PackParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.n) return;
+    const uint64_t total = p.offsets[p.n];
+    uint32_t *hdr = reinterpret_cast<uint32_t *>(p.buf);
+    if (r == 0 && lane == 0) {
+        hdr[0] = (uint32_t)total;
+        hdr[1] = (uint32_t)(total >> 32);
+        hdr[2] = (uint32_t)p.n;
+        hdr[3] = (uint32_t)p.path_bytes;
+    }
+    const uint64_t off = p.offsets[r];
+    const int64_t len = (int64_t)(p.offsets[r + 1] - off);
+    if (lane == 0) {
+        hdr[4 + r] = (uint32_t)len;
+        reinterpret_cast<int32_t *>(hdr + 4 + p.n)[r] = p.status ? p.status[r] : 0;
+    }
+    uint8_t *lab_out = p.buf + header_bytes(p.n) + off;
+    const uint8_t *lab_in = p.labels + r * p.stride;
+    for (int64_t j = lane; j < len; j += 64) lab_out[j] = lab_in[j];
+    uint8_t *path_region = p.buf + header_bytes(p.n) + ((total + 3) & ~(uint64_t)3);
+    const uint32_t *pth_in = p.path + r * p.stride;
+    if (p.path_bytes == 2) {
+        uint16_t *o = reinterpret_cast<uint16_t *>(path_region) + off;
+        for (int64_t j = lane; j < len; j += 64) o[j] = (uint16_t)pth_in[j];
+    } else {
+        uint32_t *o = reinterpret_cast<uint32_t *>(path_region) + off;
+        for (int64_t j = lane; j < len; j += 64) o[j] = pth_in[j];
+    }
+}
+
+struct UnpackParams {
+    const uint8_t *buf;
+    int64_t n;
+    const uint64_t *offsets;  // prefix sums of the buffer's out_len
+    uint8_t *labels;
+    uint32_t *path;
+    uint32_t *out_len;
+    int32_t *status;
+    int64_t stride;
+};
+
+__global__ __launch_bounds__(256) void unpack_kernel(UnpackParams p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= p.n) return;
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.buf);
+    const uint64_t total = (uint64_t)hdr[0] | ((uint64_t)hdr[1] << 32);
+    const int64_t n_in = hdr[2];
+    const int path_bytes = (int)hdr[3];
+    const uint64_t off = p.offsets[r];
+    const int64_t len = (int64_t)(p.offsets[r + 1] - off);
+    if (lane == 0) {
+        p.out_len[r] = (uint32_t)len;
+        if (p.status) p.status[r] = reinterpret_cast<const int32_t *>(hdr + 4 + n_in)[r];
+    }
+    const uint8_t *lab_in = p.buf + header_bytes(n_in) + off;
+    uint8_t *lab_out = p.labels + r * p.stride;
+    for (int64_t j = lane; j < len; j += 64) lab_out[j] = lab_in[j];
+    if (!p.path) return;
+    const uint8_t *path_region = p.buf + header_bytes(n_in) + ((total + 3) & ~(uint64_t)3);
+    uint32_t *pth_out = p.path + r * p.stride;
+    if (path_bytes == 2) {
+        const uint16_t *in = reinterpret_cast<const uint16_t *>(path_region) + off;
+        for (int64_t j = lane; j < len; j += 64) pth_out[j] = in[j];
+    } else {
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(path_region) + off;
+        for (int64_t j = lane; j < len; j += 64) pth_out[j] = in[j];
+    }
+}
+
+}  // namespace
+
+hipError_t launch_result_offsets(const uint32_t *len, int64_t n, int64_t stride, uint64_t *offsets, hipStream_t stream) {
+    hipLaunchKernelGGL(result_offsets_kernel, dim3(1), dim3(kScanThreads), 0, stream, len, n, stride, offsets);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack(const ResultDesc &res, int64_t n, int path_bytes, const uint64_t *offsets, uint8_t *buf,
+                       hipStream_t stream) {
+    PackParams p{res.labels, res.path, res.out_len, res.status, res.out_stride, n, path_bytes, offsets, buf};
+    hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_unpack(const uint8_t *buf, int64_t n, const uint64_t *offsets, const ResultDesc &out,
+                         hipStream_t stream) {
+    UnpackParams p{buf, n, offsets, out.labels, out.path, out.out_len, out.status, out.out_stride};
+    hipLaunchKernelGGL(unpack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace fcd

@@ -2,18 +2,25 @@
 
 Reads are independent units (the reference decodes one read per call, src/lib.rs:318-365), so a
 batch is partitioned into contiguous per-rank shards and every rank decodes its shard with no
-collective inside the search.  The decoded (labels, path, out_len, status) of a shard are packed
-into one contiguous byte buffer and moved to the destination rank with a single
-`torch.distributed.gather` -- RCCL over xGMI with the "nccl" backend on MI355X nodes, gloo on CPU
-(tests/test_dist_gloo.py runs this exact code path with world_size 2).
+collective inside the search.  A shard's decoded (labels, path, out_len, status) are packed into one
+contiguous byte buffer holding only the USED prefix of every fixed-stride row (csrc/pack.hip; ~48 % of a
+row at BASELINE config 2) and moved to the destination rank with a single `torch.distributed.gather`
+-- RCCL over xGMI with the "nccl" backend on MI355X nodes, gloo on CPU (tests/test_dist_gloo.py runs
+this code path with world_size 2).  A gather needs equally sized buffers, so the ranks first agree on
+the largest payload with an 8-byte all_reduce(MAX); that is the only other collective.
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): a gather to rank 0 uses each peer's direct
-link once, so it is per-link bound; at BASELINE config 2 the payload is ~49 MB per rank (labels u8 +
-path u16 at fixed stride T = 4000).
+link once, so it is per-link bound; at BASELINE config 2 the payload is ~24 MB per rank (4096 reads x
+~1940 labels x (u8 label + u16 time)) instead of 49 MB for fixed-stride rows.
 """
+import ctypes as C
+
 import numpy as np
 
+from . import _native as nat
 from .api import BatchResult
+
+_HEADER = 16
 
 
 def shard_bounds(n_reads, world):
@@ -32,57 +39,126 @@ def _path_bytes(width):
     return 2 if width <= 65535 else 4
 
 
-def packed_nbytes(n_reads, width):
-    # labels u8 [B,W] | path u16/u32 [B,W] | out_len u32 [B] | status i32 [B]
-    return n_reads * width + _path_bytes(width) * n_reads * width + 4 * n_reads + 4 * n_reads
+def packed_nbytes(n_reads, total_labels, width):
+    """Bytes of the wire buffer (csrc/pack.hip): header | out_len u32[n] | status i32[n] | labels u8[total]
+    (padded to 4) | path u16/u32[total], rounded up to 16."""
+    pb = _path_bytes(width)
+    b = _HEADER + 8 * n_reads + ((total_labels + 3) & ~3) + total_labels * pb
+    return (b + 15) & ~15
 
 
-def pack_result(r, pad_reads, out=None):
-    """BatchResult (torch tensors, any device) -> one uint8 tensor of packed_nbytes(pad_reads, W).
-    `out` (optional) is a reusable buffer of that size."""
+def _is_device(t):
+    return hasattr(t, "is_cuda") and t.is_cuda
+
+
+def _handle_for(t):
     import torch
 
-    labels = r.labels
-    B, W = labels.shape
-    dev = labels.device
-    nbytes = packed_nbytes(pad_reads, W)
+    h = nat.default_handle(t.device.index or 0)
+    h.set_stream(torch.cuda.current_stream(t.device).cuda_stream)
+    return h
+
+
+def _result_struct(r, width):
+    return nat.Result(r.labels.data_ptr(), r.path.data_ptr() if r.path is not None else None, None,
+                      r.out_len.data_ptr(), r.status.data_ptr() if r.status is not None else None, width)
+
+
+def result_total(r):
+    """-> (offsets, total): prefix sums of out_len (torch int64, n+1 entries, same device) and their last
+    element as a Python int (one small device -> host read)."""
+    import torch
+
+    B, W = r.labels.shape
+    if _is_device(r.labels):
+        h = _handle_for(r.labels)
+        offs = torch.empty(B + 1, dtype=torch.int64, device=r.labels.device)
+        h.check(h.lib.fcd_result_offsets_dev(h.ptr, r.out_len.data_ptr(), B, W, offs.data_ptr()))
+    else:
+        lens = torch.clamp(r.out_len.to(torch.int64), max=W)
+        offs = torch.zeros(B + 1, dtype=torch.int64)
+        offs[1:] = torch.cumsum(lens, 0)
+    return offs, int(offs[-1].item())
+
+
+def pack_result(r, offsets, nbytes, out=None):
+    """BatchResult (torch tensors, any device) -> one uint8 tensor of `nbytes` (>= packed_nbytes of this
+    shard) in the wire format.  `out` (optional) is a reusable buffer."""
+    import torch
+
+    B, W = r.labels.shape
+    dev = r.labels.device
+    pb = _path_bytes(W)
     if out is not None and out.numel() == nbytes and out.device == dev:
         buf = out
     else:
-        buf = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    o = 0
-    buf[o:o + B * W] = labels.reshape(-1)
-    o = pad_reads * W
-    pb = _path_bytes(W)
-    path = r.path.contiguous() if pb == 4 else r.path.to(torch.int16)  # low 16 bits, exact below 65536
-    buf[o:o + pb * B * W] = path.view(torch.uint8).reshape(-1)
-    o += pb * pad_reads * W
-    buf[o:o + 4 * B] = r.out_len.contiguous().view(torch.uint8).reshape(-1)
-    o += 4 * pad_reads
-    buf[o:o + 4 * B] = r.status.contiguous().view(torch.uint8).reshape(-1)
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    if _is_device(r.labels):
+        h = _handle_for(r.labels)
+        res = _result_struct(r, W)
+        h.check(h.lib.fcd_pack_results_dev(h.ptr, C.byref(res), B, pb, offsets.data_ptr(), buf.data_ptr()))
+        return buf
+    # host tensors (gloo): the same layout with numpy
+    o = offsets.numpy()
+    total = int(o[-1])
+    b = buf.numpy()
+    b[:8] = np.frombuffer(np.uint64(total).tobytes(), np.uint8)
+    b[8:12] = np.frombuffer(np.uint32(B).tobytes(), np.uint8)
+    b[12:16] = np.frombuffer(np.uint32(pb).tobytes(), np.uint8)
+    lens = (o[1:] - o[:-1]).astype(np.uint32)
+    b[16:16 + 4 * B] = lens.view(np.uint8)
+    b[16 + 4 * B:16 + 8 * B] = r.status.numpy().astype(np.int32).view(np.uint8)
+    mask = np.arange(W)[None, :] < lens[:, None]
+    lab0 = _HEADER + 8 * B
+    b[lab0:lab0 + total] = r.labels.numpy()[mask]
+    p0 = lab0 + ((total + 3) & ~3)
+    pth = r.path.numpy()[mask]
+    b[p0:p0 + total * pb] = pth.astype(np.uint16 if pb == 2 else np.uint32).view(np.uint8)
     return buf
 
 
-def unpack_results(bufs, counts, width, pad_reads):
-    """Inverse of pack_result for the gathered per-rank buffers -> one BatchResult (same device)."""
+def unpack_results(bufs, counts, width):
+    """Inverse of pack_result for the gathered per-rank buffers -> one BatchResult (same device) with
+    fixed-stride rows of `width` entries, in global read order."""
     import torch
 
-    labels, path, out_len, status = [], [], [], []
-    W = width
+    n_total = int(sum(counts))
+    dev = bufs[0].device
+    labels = torch.zeros((n_total, width), dtype=torch.uint8, device=dev)
+    path = torch.zeros((n_total, width), dtype=torch.int32, device=dev)
+    out_len = torch.zeros(n_total, dtype=torch.int32, device=dev)
+    status = torch.zeros(n_total, dtype=torch.int32, device=dev)
+    row = 0
     for buf, B in zip(bufs, counts):
-        o = 0
-        labels.append(buf[o:o + B * W].reshape(B, W))
-        o = pad_reads * W
-        pb = _path_bytes(W)
-        if pb == 4:
-            path.append(buf[o:o + 4 * B * W].view(torch.int32).reshape(B, W))
+        if B == 0:
+            continue
+        view = BatchResult(labels[row:row + B], path[row:row + B], out_len[row:row + B], status[row:row + B])
+        if _is_device(buf):
+            h = _handle_for(buf)
+            offs = torch.empty(B + 1, dtype=torch.int64, device=dev)
+            res = _result_struct(view, width)
+            h.check(h.lib.fcd_unpack_results_dev(h.ptr, buf.data_ptr(), B, offs.data_ptr(), C.byref(res)))
+            view._keep = offs
         else:
-            path.append(buf[o:o + 2 * B * W].view(torch.int16).reshape(B, W).to(torch.int32) & 0xFFFF)
-        o += pb * pad_reads * W
-        out_len.append(buf[o:o + 4 * B].view(torch.int32))
-        o += 4 * pad_reads
-        status.append(buf[o:o + 4 * B].view(torch.int32))
-    return BatchResult(torch.cat(labels), torch.cat(path), torch.cat(out_len), torch.cat(status))
+            b = buf.numpy()
+            total = int(b[:8].view(np.uint64)[0])
+            n_in = int(b[8:12].view(np.uint32)[0])
+            pb = int(b[12:16].view(np.uint32)[0])
+            assert n_in == B, (n_in, B)
+            lens = b[16:16 + 4 * B].view(np.uint32).copy()
+            out_len[row:row + B] = torch.from_numpy(lens.astype(np.int32))
+            status[row:row + B] = torch.from_numpy(b[16 + 4 * B:16 + 8 * B].view(np.int32).copy())
+            mask = np.arange(width)[None, :] < lens[:, None]
+            lab0 = _HEADER + 8 * B
+            lab = np.zeros((B, width), np.uint8)
+            lab[mask] = b[lab0:lab0 + total]
+            p0 = lab0 + ((total + 3) & ~3)
+            pth = np.zeros((B, width), np.int32)
+            pth[mask] = b[p0:p0 + total * pb].view(np.uint16 if pb == 2 else np.uint32).astype(np.int32)
+            labels[row:row + B] = torch.from_numpy(lab)
+            path[row:row + B] = torch.from_numpy(pth)
+        row += B
+    return BatchResult(labels, path, out_len, status)
 
 
 def _to_torch(r):
@@ -91,17 +167,18 @@ def _to_torch(r):
     def t(a, dtype):
         if isinstance(a, np.ndarray):
             a = torch.from_numpy(np.ascontiguousarray(a).view(dtype))
-        return a
+        return a.contiguous()
     return BatchResult(t(r.labels, np.uint8), t(r.path, np.int32), t(r.out_len, np.int32),
                        t(r.status, np.int32))
 
 
 def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
-    """ONE collective: gather every rank's packed shard result on `dst`.
+    """Gather every rank's packed shard result on `dst`: an 8-byte all_reduce(MAX) of the payload size,
+    then ONE gather of the compact buffers.
 
     r       this rank's BatchResult (numpy or torch)
     counts  reads per rank (len == world size), e.g. from shard_bounds
-    scratch optional dict reused across calls to avoid re-allocating the receive buffers
+    scratch optional dict reused across calls to avoid re-allocating the buffers
     Returns the concatenated BatchResult on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
@@ -109,24 +186,34 @@ def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
     r = _to_torch(r)
-    pad = max(counts)
     W = r.labels.shape[1]
-    send = pack_result(r, pad, out=None if scratch is None else scratch.get("send"))
-    if scratch is not None:
+    offsets, total = result_total(r)
+    size = torch.tensor([packed_nbytes(max(counts), total, W)], dtype=torch.int64, device=r.labels.device)
+    if world > 1:
+        dist.all_reduce(size, op=dist.ReduceOp.MAX, group=group)
+    nbytes = int(size.item())
+    # buffers are reused while the agreed size does not grow past what was allocated
+    send = None
+    if scratch is not None and scratch.get("send") is not None and scratch["send"].numel() >= nbytes \
+            and scratch["send"].device == r.labels.device:
+        send = scratch["send"][:nbytes]
+    send = pack_result(r, offsets, nbytes, out=send)
+    if scratch is not None and (scratch.get("send") is None or scratch["send"].numel() < nbytes):
         scratch["send"] = send
     recv = None
     if rank == dst:
-        key = (pad, W, send.device)
-        if scratch is not None and scratch.get("key") == key:
-            recv = scratch["bufs"]
+        have = None if scratch is None else scratch.get("bufs")
+        if have is not None and have[0].numel() >= nbytes and have[0].device == send.device and len(have) == world:
+            recv = [b[:nbytes] for b in have]
         else:
-            recv = [torch.empty_like(send) for _ in range(world)]
+            full = [torch.empty(nbytes, dtype=torch.uint8, device=send.device) for _ in range(world)]
             if scratch is not None:
-                scratch["key"], scratch["bufs"] = key, recv
+                scratch["bufs"] = full
+            recv = full
     dist.gather(send, recv, dst=dst, group=group)
     if rank != dst:
         return None
-    return unpack_results(recv, counts, W, pad)
+    return unpack_results(recv, counts, W)
 
 
 def decode_sharded(x_local, decode_fn, counts, dst=0, group=None, scratch=None):

@@ -240,6 +240,22 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
                            float *out_ln, int64_t n, int logadd_mode);
 
+/* ---- compact wire format of a shard's results, for the ONE gather of the multi-GPU path ----
+ * The searches write fixed-stride rows; only out_len[r] entries of row r are meaningful (~48 % at BASELINE
+ * config 2).  These three calls turn a result into one contiguous buffer holding just the used prefixes
+ * (layout in csrc/pack.hip) and back.  All pointers are device memory; work is enqueued on the handle's stream.
+ *   1. fcd_result_offsets_dev: offsets[i] = sum of out_len[0..i) (clamped to out_stride), offsets[n_reads] =
+ *      total labels.  Read offsets[n_reads] back to size the buffer: fcd_packed_result_bytes().
+ *   2. fcd_pack_results_dev: labels/path(u32 -> path_bytes = 2 or 4 wide)/out_len/status -> buf.
+ *   3. fcd_unpack_results_dev: buf -> fixed-stride arrays of `out` (offsets: workspace of n_reads+1 u64). */
+int64_t fcd_packed_result_bytes(int64_t n_reads, int64_t total_labels, int path_bytes);
+int fcd_result_offsets_dev(fcd_handle *h, const uint32_t *out_len, int64_t n_reads, int64_t out_stride,
+                           uint64_t *offsets);
+int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, int path_bytes,
+                         const uint64_t *offsets, uint8_t *buf);
+int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, uint64_t *offsets,
+                           const fcd_result *out);
+
 /* ---- host-side helpers shared with the language bindings ---- */
 /* phred quality character code point for a probability (src/search.rs:31-36) */
 uint32_t fcd_phred(float prob, float qscale, float qbias);

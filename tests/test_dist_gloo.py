@@ -81,6 +81,24 @@ def test_shard_bounds():
     assert shard_bounds(65536, 8)[-1] == (57344, 65536)
 
 
+def _random_result(B, W, seed, torch):
+    from fast_ctc_decode_amd.api import BatchResult
+    g = torch.Generator().manual_seed(seed)
+    labels = torch.randint(1, 5, (B, W), dtype=torch.uint8, generator=g)
+    path = torch.randint(0, W, (B, W), dtype=torch.int32, generator=g)
+    out_len = torch.randint(0, W + 1, (B,), dtype=torch.int32, generator=g)
+    status = torch.randint(0, 3, (B,), dtype=torch.int32, generator=g)
+    out_len[status != 0] = 0
+    return BatchResult(labels, path, out_len, status)
+
+
+def _assert_same_used(a, b, W):
+    import torch
+    assert torch.equal(a.out_len, b.out_len) and torch.equal(a.status, b.status)
+    mask = torch.arange(W)[None, :] < a.out_len[:, None]
+    assert torch.equal(a.labels[mask], b.labels[mask]) and torch.equal(a.path[mask], b.path[mask])
+
+
 def test_pack_unpack_roundtrip_wide_paths():
     """The gather payload stores path entries in two bytes below 65536 steps: values above 32767
     must survive, and reads of 65536+ steps fall back to four bytes."""
@@ -96,8 +114,63 @@ def test_pack_unpack_roundtrip_wide_paths():
         path = torch.randint(0, W, (B, W), dtype=torch.int32, generator=g)
         path[0, :3] = torch.tensor([0, 32768, W - 1], dtype=torch.int32)
         r = BatchResult(labels, path, torch.tensor([W, 3], dtype=torch.int32), torch.zeros(B, dtype=torch.int32))
-        buf = fdist.pack_result(r, pad_reads=3)
-        assert buf.numel() == fdist.packed_nbytes(3, W)
-        back = fdist.unpack_results([buf], [B], W, 3)
-        assert torch.equal(back.labels, labels) and torch.equal(back.path, path)
-        assert torch.equal(back.out_len, r.out_len) and torch.equal(back.status, r.status)
+        offs, total = fdist.result_total(r)
+        assert total == W + 3
+        nbytes = fdist.packed_nbytes(3, total, W)
+        buf = fdist.pack_result(r, offs, nbytes)
+        assert buf.numel() == nbytes
+        back = fdist.unpack_results([buf], [B], W)
+        _assert_same_used(r, back, W)
+
+
+@pytest.mark.parametrize("B,W", [(3, 5), (1, 1), (7, 33), (4, 2), (5, 130)])
+def test_pack_unpack_odd_shapes(B, W):
+    """section offsets that are not 2- / 4-byte aligned (odd B, odd W) must round-trip."""
+    import torch
+
+    from fast_ctc_decode_amd import dist as fdist
+
+    for seed in range(3):
+        r = _random_result(B, W, 100 * B + W + seed, torch)
+        offs, total = fdist.result_total(r)
+        buf = fdist.pack_result(r, offs, fdist.packed_nbytes(B + 2, total, W) + 16 * seed)
+        back = fdist.unpack_results([buf], [B], W)
+        _assert_same_used(r, back, W)
+
+
+def test_device_pack_kernels_match_the_host_layout():
+    """csrc/pack.hip (through the lockstep emulation, tests/hipemu) writes byte for byte the buffer the
+    numpy packer writes, and its unpack kernel inverts it -- the -m gpu twin runs on the MI355X."""
+    import ctypes as C
+
+    import torch
+
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    from fast_ctc_decode_amd import dist as fdist
+
+    with emulated_kernels():
+        h = nat.default_handle()
+        for B, W in ((3, 5), (9, 70), (130, 40), (2100, 3)):
+            r = _random_result(B, W, B + W, torch)
+            offs_host, total = fdist.result_total(r)
+            nbytes = fdist.packed_nbytes(B, total, W)
+            want = fdist.pack_result(r, offs_host, nbytes).numpy()
+            offs = np.zeros(B + 1, np.uint64)
+            h.check(h.lib.fcd_result_offsets_dev(h.ptr, r.out_len.data_ptr(), B, W, offs.ctypes.data))
+            assert np.array_equal(offs.astype(np.int64), offs_host.numpy())
+            assert h.lib.fcd_packed_result_bytes(B, total, 2) == nbytes
+            got = np.zeros(nbytes, np.uint8)
+            res = nat.Result(r.labels.data_ptr(), r.path.data_ptr(), None, r.out_len.data_ptr(), r.status.data_ptr(), W)
+            h.check(h.lib.fcd_pack_results_dev(h.ptr, C.byref(res), B, 2, offs.ctypes.data, got.ctypes.data))
+            used = 16 + 8 * B + ((total + 3) & ~3) + 2 * total   # padding bytes are unspecified
+            lab_end = 16 + 8 * B + total
+            assert np.array_equal(got[:lab_end], want[:lab_end])
+            assert np.array_equal(got[16 + 8 * B + ((total + 3) & ~3):used], want[16 + 8 * B + ((total + 3) & ~3):used])
+            back = fdist._to_torch(type(r)(np.zeros((B, W), np.uint8), np.zeros((B, W), np.int32),
+                                           np.zeros(B, np.int32), np.zeros(B, np.int32)))
+            res2 = nat.Result(back.labels.data_ptr(), back.path.data_ptr(), None, back.out_len.data_ptr(),
+                              back.status.data_ptr(), W)
+            work = np.zeros(B + 1, np.uint64)
+            h.check(h.lib.fcd_unpack_results_dev(h.ptr, got.ctypes.data, B, work.ctypes.data, C.byref(res2)))
+            _assert_same_used(r, back, W)
