@@ -86,7 +86,11 @@ __device__ __forceinline__ float rdlanef(float v, int l) {
 }
 
 // AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous, see beam_wave.hip).
-template <int N, int RPW, bool AMB>
+// CRF: search::crf_beam_search (:38-157) with a run-time state count S (a power of two >= 4, N = 5, as in
+// beam_wave.hip's gather mode): every entry reads the row of ITS state, probs[t, state, :] -- N values per
+// lane, requested for step t+1 as soon as the entry's next state is known; no repeat-stay; an extension
+// moves to state (state * 4) & (S - 1) + label (:97), which cannot leave the table.
+template <int N, int RPW, bool AMB, bool CRF>
 __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     constexpr int NL = N - 1;
     constexpr int HALF = 64 / RPW;          // lanes (= beam slots) per read
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
     const int64_t r = p.read_begin + (has_read ? local : 0);
     const int beam_size = p.a.beam_size;
-    const bool collapse = p.a.collapse != 0;
+    const bool collapse = !CRF && p.a.collapse != 0;
     const float thr = p.a.thr;
 
     int T = 0;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     if (RPW == 2) Tmax = max(Tmax, __shfl_xor(Tmax, 32));
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
     const float *post = p.in.post + r * p.in.stride_read;
-    const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n;
+    const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
     const int64_t slab = has_read ? local : 0;
     int2 *rec = p.arena.rec + slab * p.arena.cap_nodes;
     int32_t *jmp = p.arena.jmp + slab * p.arena.cap_nodes;
@@ -160,6 +164,33 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     int nn = 0;
     bool alive = has_read;
     int n_amb = 0;
+    int state = 0;
+    const int s_mask = CRF ? (int)p.in.S - 1 : 0;
+    if (CRF && has_read) {
+        // search.rs:54-59: state = argmax(init), label_prob = max(init), gap_prob = init[0];
+        // ndarray-stats: first maximum wins, NaN -> Err -> unwrap() panics
+        const float *init = p.a.init + r * p.a.init_stride;
+        float m = init[0];
+        bool bad = m != m;
+        for (int64_t j = 1; j < p.a.n_init; ++j) {
+            const float e = init[j];
+            bad = bad || (e != e);
+            if (e > m) {
+                m = e;
+                state = (int)j;
+            }
+        }
+        lp = m;
+        gp = init[0];
+        if ((bad || state > s_mask) && T > 0) {
+            if (q == 0) {
+                p.out.status[r] = FCD_ST_BAD_STATE;
+                p.out.out_len[r] = 0;
+            }
+            alive = false;
+            state = 0;
+        }
+    }
 
     // ---- row FIFO: register j holds rows [blk*RPR, blk*RPR + RPR) of block (front + j) ----
     const int fg = q / N, fc = q - fg * N;
@@ -170,9 +201,14 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     };
     float win[kFifo];
 #pragma unroll
-    for (int j = 0; j < kFifo; ++j) win[j] = load_block(j);
-    float incoming = load_block(kFifo);
+    for (int j = 0; j < kFifo; ++j) win[j] = CRF ? 0.0f : load_block(j);
+    float incoming = CRF ? 0.0f : load_block(kFifo);
     int g = 0, blk = 0;
+    // CRF: the row of this entry's state, requested one step ahead
+    float rowv[N];
+#pragma unroll
+    for (int c = 0; c < N; ++c)
+        rowv[c] = (CRF && T > 0) ? post[(int64_t)state * st_s + c * st_n] : 0.0f;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see beam_wave.hip
 
     for (int t = 0; t < Tmax; ++t) {
@@ -181,8 +217,8 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         float pr[N];
 #pragma unroll
         for (int c = 0; c < N; ++c)
-            pr[c] = RPW == 1 ? rdlanef(win[0], g * N + c) : bpermf(hbase + g * N + c, win[0]);
-        if (++g == RPR) {
+            pr[c] = CRF ? rowv[c] : (RPW == 1 ? rdlanef(win[0], g * N + c) : bpermf(hbase + g * N + c, win[0]));
+        if (!CRF && ++g == RPR) {
             g = 0;
 #pragma unroll
             for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
@@ -401,7 +437,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         if (rank[0] >= 0) {  // the entry's own node stays in the beam
             const int meta = 0 | ((tip + 1) << 2) | (depth << 5);
             s_rec[2 * (hbase + rank[0])] = make_int4(__float_as_int(slp), __float_as_int(sgp), node, meta);
-            s_rec[2 * (hbase + rank[0]) + 1] = make_int4(jump, lane, 0, 0);
+            s_rec[2 * (hbase + rank[0]) + 1] = make_int4(jump, lane, 0, state);
         }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -410,7 +446,8 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
                 const int kind = (child[l] & kEver) ? 2 : 1;  // 2: it has been there before, its row is in HBM
                 const int meta = kind | ((l + 1) << 2) | ((depth + 1) << 5);
                 s_rec[2 * (hbase + rk)] = make_int4(__float_as_int(contrib[l]), 0, ccand[l], meta);
-                s_rec[2 * (hbase + rk) + 1] = make_int4((depth % kSeg == 0) ? node : jump, lane, l + 1, 0);
+                s_rec[2 * (hbase + rk) + 1] =
+                    make_int4((depth % kSeg == 0) ? node : jump, lane, l + 1, CRF ? ((state * NL) & s_mask) + l : 0);  // :97
             }
         }
         wave_sync();
@@ -490,6 +527,12 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
                 if (reload)
                     n_child[l] = eslot[l] >= 0 ? ((e[l] & kStored) | kInBeam | (eslot[l] << kSlotShift)) : e[l];
         }
+        if (CRF) {
+            if (q < Bn) state = rb.w;
+#pragma unroll
+            for (int c = 0; c < N; ++c)   // in flight during the divisions below
+                rowv[c] = t + 1 < T ? post[(int64_t)(t + 1) * st_t + (int64_t)state * st_s + c * st_n] : 0.0f;
+        }
         const float top = __int_as_float(r0.x) + __int_as_float(r0.y);  // beam[0].probability() :278
         if (q < Bn) {
             node = n_node;
@@ -549,25 +592,27 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     }
 }
 
-template <int N, bool AMB>
+template <int N, bool AMB, bool CRF>
 hipError_t launch_na(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
     if (p.a.beam_size <= 32) {  // two reads per wavefront
-        hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB, CRF>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB, CRF>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
     }
     return hipGetLastError();
 }
 
 template <int N>
 hipError_t launch_n(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
-    return p.out.ambiguous ? launch_na<N, true>(p, n_reads, stream) : launch_na<N, false>(p, n_reads, stream);
+    return p.out.ambiguous ? launch_na<N, true, false>(p, n_reads, stream) : launch_na<N, false, false>(p, n_reads, stream);
 }
 
 }  // namespace
 
-bool beam_lane_supported(int beam_size, int N, int crf) {
-    return !crf && beam_size >= 1 && beam_size <= 64 && N >= 2 && N <= 8;
+bool beam_lane_supported(int beam_size, int N, int crf, int S) {
+    if (beam_size < 1 || beam_size > 64) return false;
+    if (crf) return N == 5 && S >= 4 && (S & (S - 1)) == 0;  // 5 symbols x 2^k states
+    return N >= 2 && N <= 8;
 }
 
 hipError_t launch_beam_lane(const BatchDesc &in, int64_t read_begin, int64_t n_reads, const BeamArgs &a,
@@ -575,6 +620,10 @@ hipError_t launch_beam_lane(const BatchDesc &in, int64_t read_begin, int64_t n_r
     if (n_reads <= 0) return hipSuccess;
     LaneParams p{in, a, arena, out, read_begin};
     p.in.n_reads = n_reads;
+    if (a.crf) {
+        if (!beam_lane_supported(a.beam_size, in.N, 1, in.S)) return hipErrorInvalidValue;
+        return out.ambiguous ? launch_na<5, true, true>(p, n_reads, stream) : launch_na<5, false, true>(p, n_reads, stream);
+    }
     switch (in.N) {
         case 2: return launch_n<2>(p, n_reads, stream);
         case 3: return launch_n<3>(p, n_reads, stream);

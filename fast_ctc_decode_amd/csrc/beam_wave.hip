@@ -73,12 +73,19 @@ __device__ __forceinline__ int perm(int dst_lane, int v) {
 }
 
 constexpr int kWavesPerBlock = 4;
+constexpr int kCrfGather = -1;
 constexpr int kFifo = 8;  // registers in the row FIFO
 constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 
 // S == 0: search::beam_search.  S > 0: search::crf_beam_search (:38-157) with S transition states:
 // the row is probs[t, state, :] of the entry's state, there is no repeat-stay, and an extension
 // moves to state (state * n_base) % n_state + label (:97).
+// S == kCrfGather: crf_beam_search with a RUN-TIME state count (a power of two >= 4, N = 5: real
+// basecaller heads have 4^k states, far too many rows for the register FIFO).  Only the rows of visited
+// states are read: every lane fetches the one value it needs, probs[t+1, state', its column], as soon as
+// its slot's next state is known -- before the renormalising divisions of step t -- and uses it at the top
+// of step t+1 (4 B per lane, five 20-byte rows per read and step).  (state * 4) & (S - 1) + label < S
+// always holds for such S, so no transition can leave the table.
 //
 // AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous): the number of
 // steps with more than 20 candidates in which a KEPT candidate shares its exact probability with another
@@ -87,11 +94,12 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // timed kernel pays nothing.
 template <int N, int GW, int RPW, int S, bool AMB>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
-    constexpr bool CRF = S > 0;
+    constexpr bool CRF = S != 0;
+    constexpr bool GATHER = S == kCrfGather;
     constexpr int NL = N - 1;
     constexpr int HALF = 64 / RPW;
     constexpr int BCAP = HALF / GW;     // beam slots per read
-    constexpr int E = (CRF ? S : 1) * N; // posterior values per timestep
+    constexpr int E = (S > 0 ? S : 1) * N; // posterior values per timestep (register FIFO)
     constexpr int RPR = HALF / E;       // rows per FIFO register
     static_assert(RPR >= 1, "one timestep must fit the lanes of a half");
     constexpr int RW = NL <= 4 ? 4 : 8; // child-row width in the arena
@@ -173,7 +181,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         }
         lp = m;
         gp = init[0];
-        if ((bad || state >= S) && T > 0) {
+        if ((bad || state >= (GATHER ? p.in.S : S)) && T > 0) {
             if (q == 0) {
                 p.out.status[r] = FCD_ST_BAD_STATE;
                 p.out.out_len[r] = 0;
@@ -193,11 +201,19 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     };
     float win[kFifo];
 #pragma unroll
-    for (int j = 0; j < kFifo; ++j) win[j] = load_block(j);
+    for (int j = 0; j < kFifo; ++j) win[j] = GATHER ? 0.0f : load_block(j);
     // the block in flight joins the FIFO one rotation after its load was launched
-    float incoming = load_block(kFifo);
+    float incoming = GATHER ? 0.0f : load_block(kFifo);
     int g = 0;    // row within the front block (wave-uniform)
     int blk = 0;  // index of the front block (wave-uniform)
+    // GATHER: the one value of row tt this lane needs -- column 0 (blank) on a slot's own lane, the
+    // label's column on a child lane -- in the row of the slot's current state
+    const int s_mask = GATHER ? (int)p.in.S - 1 : 0;
+    const int kcol = is_child ? k : 0;
+    auto gather_row = [&](int tt) -> float {
+        return tt < T ? post[(int64_t)tt * st_t + (int64_t)state * st_s + kcol * st_n] : 0.0f;
+    };
+    float rowv = GATHER ? gather_row(0) : 0.0f;
     // Drain the prologue loads HERE, with a wait the compiler's scoreboard sees: otherwise the loop
     // header inherits "win[0] may still be in flight" and gets an s_waitcnt vmcnt(0) on EVERY step,
     // which on gfx9-family counters also waits for the previous step's tree stores to be acked.
@@ -206,11 +222,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     for (int t = 0; t < Tmax; ++t) {
         const bool act = alive && t < T;
         // ---- the three row values this lane needs ----
-        const int rbase = hbase + g * E + (CRF ? state * N : 0);
-        const float pr0 = bpermf(rbase, win[0]);
-        const float pk = bpermf(rbase + (is_child ? k : 0), win[0]);
+        const int rbase = hbase + g * E + (S > 0 ? state * N : 0);
+        const float pr0 = GATHER ? rowv : bpermf(rbase, win[0]);
+        const float pk = GATHER ? rowv : bpermf(rbase + (is_child ? k : 0), win[0]);
         const float ptip = CRF ? 0.0f : bpermf(rbase + tip + 1, win[0]);
-        if (++g == RPR) {
+        if (!GATHER && ++g == RPR) {
             g = 0;
 #pragma unroll
             for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
@@ -353,7 +369,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int src = bperm(grp0, src0);  // every lane of new group s knows its source lane
         const int tipc = is_self ? tip : l;
         const int depc = is_self ? depth : depth + 1;
-        const int statec = (CRF && !is_self) ? (state * NL) % S + l : state;  // :97
+        const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
+                                             : state;  // :97
         const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
         const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
         const int n_node = bperm(src, id);
@@ -380,6 +397,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             }
             if (reload) n_child = e;
         }
+        if (CRF && go) state = n_state;  // < S: (s*4) % 4 + l = l for (N, S) = (5, 4); masked when GATHER
+        if (GATHER) rowv = gather_row(t + 1);  // in flight during the divisions below
         const float top = bpermf(hbase, n_lp + n_gp);  // beam[0].probability() :278
         if (go) {
             node = n_node;
@@ -390,7 +409,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             jump = n_jump;
             child = n_child;
             B = Bn;
-            if (CRF) state = n_state;  // always < S for the instantiated (N, S) = (5, 4): (s*4) % 4 + l = l
         }
     }
 
@@ -463,7 +481,8 @@ hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
 
 bool beam_wave_supported(int beam_size, int N, int crf, int S) {
     if (beam_size < 1 || beam_size > 12) return false;
-    if (crf) return N == 5 && S == 4;  // the CRF instantiations: 4 states x 5 symbols
+    // the CRF instantiations: 5 symbols x 4 states (register FIFO) or x 8, 16, ... 2^k states (row gather)
+    if (crf) return N == 5 && S >= 4 && (S & (S - 1)) == 0;
     if (beam_size > 8) return N >= 3 && N <= 5;
     return N >= 3 && N <= 7;
 }
@@ -477,9 +496,13 @@ hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_r
     const bool two = a.beam_size <= 5 && in.N <= 5 && !a.force_one_read_per_wave;
     const bool wide = a.beam_size > 8;  // 9..12 beam slots: groups of five lanes
     if (a.crf) {
-        if (in.N != 5 || in.S != 4) return hipErrorInvalidValue;
-        if (wide) return launch_t<5, 5, 1, 4>(p, n_reads, stream);
-        return two ? launch_t<5, 6, 2, 4>(p, n_reads, stream) : launch_t<5, 8, 1, 4>(p, n_reads, stream);
+        if (!beam_wave_supported(a.beam_size, in.N, 1, in.S)) return hipErrorInvalidValue;
+        if (in.S == 4) {
+            if (wide) return launch_t<5, 5, 1, 4>(p, n_reads, stream);
+            return two ? launch_t<5, 6, 2, 4>(p, n_reads, stream) : launch_t<5, 8, 1, 4>(p, n_reads, stream);
+        }
+        if (wide) return launch_t<5, 5, 1, kCrfGather>(p, n_reads, stream);
+        return two ? launch_t<5, 6, 2, kCrfGather>(p, n_reads, stream) : launch_t<5, 8, 1, kCrfGather>(p, n_reads, stream);
     }
     if (wide) {
         switch (in.N) {

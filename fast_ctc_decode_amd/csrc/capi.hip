@@ -133,7 +133,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     bool use_wave = false;
     if (kernel == FCD_KERNEL_WAVE || kernel == FCD_KERNEL_WAVE1) {
         if (!beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S))
-            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8 and N <= 7, or beam_size <= 12 and N <= 5 (CRF: N = 5, S = 4)");
+            return fail(h, FCD_E_UNSUPPORTED, "wave kernel: needs beam_size <= 8 and N <= 7, or beam_size <= 12 and N <= 5 (CRF: N = 5, S a power of two >= 4)");
         use_wave = true;
     } else if (kernel == FCD_KERNEL_AUTO) {
         use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S);
@@ -147,10 +147,10 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     // wide beams: one beam entry per lane (node ids in 23 bits)
     bool use_lane = false;
     if (kernel == FCD_KERNEL_LANE || (kernel == FCD_KERNEL_AUTO && !use_wave)) {
-        const bool ok = beam_lane_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf) &&
+        const bool ok = beam_lane_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S) &&
                         d.T < (1ll << 26) && d.T * beam * NL + 16 < (1ll << 23);
         if (kernel == FCD_KERNEL_LANE && !ok)
-            return fail(h, FCD_E_UNSUPPORTED, "lane kernel: needs beam_size <= 64, N <= 8, no CRF, T * beam_size * (N-1) < 2^23");
+            return fail(h, FCD_E_UNSUPPORTED, "lane kernel: needs beam_size <= 64, N <= 8 (CRF: N = 5, S a power of two >= 4), T * beam_size * (N-1) < 2^23");
         use_lane = ok;
     }
 

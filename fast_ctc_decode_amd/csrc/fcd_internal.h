@@ -78,8 +78,8 @@ hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_r
                             const BeamArgs &a, const WaveArena &arena, const ResultDesc &out,
                             hipStream_t stream);
 
-// one beam entry per lane: beam_size <= 64, N <= 8, plain (non-CRF) search; uses the wave arena layout
-bool beam_lane_supported(int beam_size, int N, int crf);
+// one beam entry per lane: beam_size <= 64, N <= 8 (CRF: N = 5, S a power of two >= 4); uses the wave arena layout
+bool beam_lane_supported(int beam_size, int N, int crf, int S);
 hipError_t launch_beam_lane(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
                             const BeamArgs &a, const WaveArena &arena, const ResultDesc &out,
                             hipStream_t stream);

@@ -59,6 +59,18 @@ def test_ambiguity_counter(fcd):
     P.test_ambiguity_counter(fcd)
 
 
+@pytest.mark.parametrize("S,beam,thr", [(16, 5, 0.1), (1024, 12, 0.05), (64, 32, 0.1), (8, 64, 0.0)])
+def test_crf_many_states(fcd, S, beam, thr):
+    P.test_crf_beam_many_states(fcd, S, beam, thr)
+
+
+def test_crf_kernels_and_fuzz(fcd):
+    P.test_crf_beam_kernels(fcd, 2, 5, 0.1)
+    P.test_crf_bad_state_parity(fcd)
+    for seed in range(3000, 3012):
+        P.crf_fuzz_seed(fcd, seed)
+
+
 def test_viterbi_and_crf(fcd):
     P.test_viterbi_random(fcd)
     P.test_viterbi_qual_bits(fcd)

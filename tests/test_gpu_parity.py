@@ -263,6 +263,18 @@ def test_viterbi_qual_bits(fcd):
                                       np.array(exp, np.float32).view(np.uint32))
 
 
+def to_dev(x):
+    """A device tensor when a GPU is present (zero-copy *_dev entry points), the numpy array otherwise
+    (host-staged *_host entry points: what FCD_TEST_EMU / tests/test_emu_parity.py run)."""
+    try:
+        import torch
+        if torch.cuda.is_available():
+            return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    except ImportError:
+        pass
+    return x
+
+
 def gen_crf(seed, B, T, S=4, N=5):
     rng = np.random.default_rng(seed)
     x = rng.random((B, T, S, N), dtype=np.float32)
@@ -285,12 +297,10 @@ def test_crf_beam_random(fcd, beam, thr):
 @pytest.mark.parametrize("beam,thr", [(1, 0.0), (5, 0.0), (5, 0.1), (8, 0.05), (12, 0.0), (10, 0.1)])
 def test_crf_beam_kernels(fcd, kernel, beam, thr):
     """crf_beam_search on every kernel family (S = 4 states x 5 symbols is the wave kernels' shape)."""
-    torch = pytest.importorskip("torch")
     x, init = gen_crf(70 + beam, 9, 500)
     init[3] = [0.1, 0.7, 0.7, 0.05]      # a tie: the first maximum is the start state
     lengths = np.array([500, 499, 1, 0, 64, 65, 500, 31, 500], np.int64)
-    r = fcd.crf_beam_search_batch_raw(torch.from_numpy(x).cuda(), init, beam, thr, lengths=lengths,
-                                      kernel=kernel).cpu()
+    r = fcd.crf_beam_search_batch_raw(to_dev(x), init, beam, thr, lengths=lengths, kernel=kernel).cpu()
     for i in range(x.shape[0]):
         n = int(r.out_len[i])
         if lengths[i] == 0:
@@ -304,6 +314,64 @@ def test_crf_beam_kernels(fcd, kernel, beam, thr):
         assert int(r.status[i]) == 0
         seq = "".join("NACGT"[l] for l in r.labels[i, :n])
         assert (seq, r.path[i, :n].tolist()) == want
+
+
+@pytest.mark.parametrize("S", [8, 16, 64, 256, 1024])
+@pytest.mark.parametrize("beam,thr", [(1, 0.0), (5, 0.0), (5, 0.1), (12, 0.05), (16, 0.05), (32, 0.1), (64, 0.0)])
+def test_crf_beam_many_states(fcd, S, beam, thr):
+    """crf_beam_search with S = 4^k-style state counts (real basecaller heads), 5 symbols.  The
+    register kernels gather only the rows of visited states (wave: beam <= 12, lane: beam <= 64); every
+    kernel that accepts the shape must reproduce the oracle bit for bit, ragged lengths included, and the
+    tie instrument must agree."""
+    B, T = 6, 260
+    x, init = gen_crf(7000 + S + beam, B, T, S=S)
+    init[2] = 0.25                        # all tied: the first state starts
+    lengths = np.array([T, T - 1, 1, 0, 64, 65], np.int64)
+    want = []
+    for i in range(B):
+        L = int(lengths[i])
+        want.append(None if L == 0 else
+                    oracle.crf_beam_search_ambiguous(np.ascontiguousarray(x[i, :L]), init[i], beam, thr))
+    kernels = [0, 1] + ([2, 3] if beam <= 12 else []) + [4]
+    xd = to_dev(x)
+    for kernel in kernels:
+        r = fcd.crf_beam_search_batch_raw(xd, init, beam, thr, lengths=lengths, kernel=kernel,
+                                          count_ambiguous=True).cpu()
+        for i in range(B):
+            n = int(r.out_len[i])
+            if want[i] is None:
+                assert n == 0 and int(r.status[i]) == 0
+                continue
+            st, labels, path, n_amb = want[i]
+            assert int(r.status[i]) == st, (kernel, i)
+            if st == 0:
+                np.testing.assert_array_equal(r.labels[i, :n], labels)
+                np.testing.assert_array_equal(r.path[i, :n], path)
+            assert int(r.ambiguous[i]) == n_amb, (kernel, i)
+
+
+def test_crf_bad_state_parity(fcd):
+    """A state count that lets (state * n_base) % n_state + label leave the table (the reference aborts on
+    the ndarray bounds check, src/search.rs:72): only the LDS kernel accepts such shapes and reports
+    BAD_STATE where the oracle reports the panic; init_state entries beyond S start out of range."""
+    rng = np.random.default_rng(71)
+    for S, n_init in ((5, 5), (6, 6), (16, 20), (64, 64)):
+        B, T = 4, 60
+        x = rng.random((B, T, S, 5), dtype=np.float32)
+        x /= x.sum(-1, keepdims=True)
+        init = rng.random((B, n_init)).astype(np.float32)
+        if n_init > S:
+            init[1, S + 1] = 2.0          # argmax beyond the table: out of range before the first row
+        r = fcd.crf_beam_search_batch_raw(to_dev(x), init, 5, 0.0).cpu()
+        for i in range(B):
+            try:
+                want = oracle.crf_beam_search(x[i], init[i], "NACGT", 5, 0.0)
+            except RuntimeError as e:
+                assert "panic" in str(e) and int(r.status[i]) == fcd.api.nat.ST_BAD_STATE, (S, i)
+                continue
+            n = int(r.out_len[i])
+            assert int(r.status[i]) == 0
+            assert ("".join("NACGT"[l] for l in r.labels[i, :n]), r.path[i, :n].tolist()) == want
 
 
 def test_crf_greedy_random(fcd):
@@ -467,12 +535,16 @@ def test_beam_fuzz(fcd, chunk):
 
 def crf_fuzz_seed(fcd, seed):
     """One random (S, N, beam, thr, T, init, ragged) draw of crf_beam_search on every kernel family."""
-    import torch
     if True:
         rng = np.random.default_rng(seed)
-        wave_shape = bool(rng.integers(0, 2))
-        S, N = (4, 5) if wave_shape else (int(rng.integers(1, 7)), int(rng.integers(2, 7)))
-        beam = int(rng.choice([1, 2, 5, 8, 12]))
+        shape = int(rng.integers(0, 3))
+        if shape == 0:
+            S, N = 4, 5                                            # the wave kernels' register-FIFO shape
+        elif shape == 1:
+            S, N = int(rng.choice([8, 16, 64, 256, 1024])), 5     # gathered rows (wave / lane kernels)
+        else:
+            S, N = int(rng.integers(1, 7)), int(rng.integers(2, 7))
+        beam = int(rng.choice([1, 2, 5, 8, 12, 20, 40]))
         thr = float(rng.choice([0.0, 0.0, 0.05, 0.2]))
         B, T = int(rng.integers(1, 5)), int(rng.integers(1, 150))
         style = int(rng.integers(0, 3))
@@ -490,12 +562,11 @@ def crf_fuzz_seed(fcd, seed):
         init = init.astype(np.float32)
         lengths = rng.integers(0, T + 1, size=B).astype(np.int64) if rng.integers(0, 3) == 0 else None
         alpha = "N" + "ACGTUV"[:N - 1]
-        for kernel in (0, 1, 2, 3):
+        for kernel in (0, 1, 2, 3, 4):
             try:
-                r = fcd.crf_beam_search_batch_raw(torch.from_numpy(x).cuda(), init, beam, thr,
-                                                  lengths=lengths, kernel=kernel).cpu()
+                r = fcd.crf_beam_search_batch_raw(to_dev(x), init, beam, thr, lengths=lengths, kernel=kernel).cpu()
             except RuntimeError as e:
-                assert kernel in (2, 3) and "wave kernel" in str(e), (seed, kernel, str(e))
+                assert kernel in (2, 3, 4) and " kernel: " in str(e), (seed, kernel, str(e))
                 continue
             for i in range(B):
                 Ti = T if lengths is None else int(lengths[i])
@@ -521,7 +592,6 @@ def crf_fuzz_seed(fcd, seed):
 
 @pytest.mark.parametrize("chunk", range(4))
 def test_crf_fuzz(fcd, chunk):
-    pytest.importorskip("torch")
     for seed in range(3000 + chunk * 10, 3000 + (chunk + 1) * 10):
         crf_fuzz_seed(fcd, seed)
 
