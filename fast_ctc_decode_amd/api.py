@@ -86,7 +86,7 @@ def _dense(a):
 class _HostOut:
     def __init__(self, B, T, want_path=True, want_qual=False, want_amb=False):
         w = max(int(T), 1)
-        self.ambiguous = np.zeros(B, np.uint32) if want_amb else None
+        self.ambiguous = np.zeros((B, 2), np.uint32) if want_amb else None
         self.labels = np.zeros((B, w), np.uint8)
         self.path = np.zeros((B, w), np.uint32) if want_path else None
         self.qual = np.zeros((B, w), np.float32) if want_qual else None
@@ -588,8 +588,9 @@ class BatchResult:
 
     def __init__(self, labels, path, out_len, status, qual=None, ambiguous=None):
         self.labels, self.path, self.out_len, self.status, self.qual = labels, path, out_len, status, qual
-        # beam searches with count_ambiguous=True: per read, the number of steps whose tie order the
-        # reference's sort_unstable_by does not pin (include/fcd.h, fcd_result.ambiguous)
+        # beam searches with count_ambiguous=True: (n_reads, 2) tie counters per read -- [:, 0] steps with
+        # > 20 candidates and an exact tie involving a kept one, [:, 1] steps with an exact tie at ranks
+        # 0 / 1 or across the truncation boundary (include/fcd.h, fcd_result.ambiguous)
         self.ambiguous = ambiguous
 
     def cpu(self):
@@ -671,7 +672,7 @@ def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path
     qual = torch.empty((B, w), dtype=torch.float32, device=x.device) if want_qual else None
     out_len = torch.zeros(B, dtype=torch.int32, device=x.device)
     status = torch.zeros(B, dtype=torch.int32, device=x.device)
-    amb = torch.zeros(B, dtype=torch.int32, device=x.device) if want_amb else None
+    amb = torch.zeros((B, 2), dtype=torch.int32, device=x.device) if want_amb else None
     res = nat.Result(labels.data_ptr(), path.data_ptr() if want_path else None,
                      qual.data_ptr() if want_qual else None, out_len.data_ptr(),
                      status.data_ptr(), w, amb.data_ptr() if want_amb else None)

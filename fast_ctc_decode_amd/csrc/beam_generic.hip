@@ -134,11 +134,14 @@ __device__ __forceinline__ void wave_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ __forceinline__ void fail(const GenericParams &p, int64_t r, int code, int n_amb) {
+__device__ __forceinline__ void fail(const GenericParams &p, int64_t r, int code, int n_amb, int n_crit) {
     if (threadIdx.x == 0) {
         p.out.status[r] = code;
         p.out.out_len[r] = 0;
-        if (p.out.ambiguous) p.out.ambiguous[r] = (uint32_t)n_amb;
+        if (p.out.ambiguous) {
+            p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+            p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+        }
     }
 }
 
@@ -204,10 +207,9 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
     wave_sync();
 
     int nn = 0;  // nodes in this read's tree (wave-uniform)
-    // tie instrument (fcd_result.ambiguous): steps with > 20 candidates in which a kept
-    // candidate shares its exact probability with another candidate
+    // tie instrument (fcd_result.ambiguous; two counters, semantics in include/fcd.h)
     const bool count_amb = p.out.ambiguous != nullptr;
-    int n_amb = 0;
+    int n_amb = 0, n_crit = 0;
 
     for (int64_t t = 0; t < T; ++t) {
         int *b_node = L.b_node(cur), *b_tip = L.b_tip(cur), *b_par = L.b_par(cur);
@@ -329,11 +331,11 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             any_nan = any_nan || (__ballot(valid && prob != prob) != 0ull);
         }
         bad_state = __ballot(bad_state) != 0ull;
-        if (bad_state) return fail(p, r, FCD_ST_BAD_STATE, n_amb);
-        if (nn > p.arena.cap_nodes) return fail(p, r, FCD_ST_INTERNAL, n_amb);
+        if (bad_state) return fail(p, r, FCD_ST_BAD_STATE, n_amb, n_crit);
+        if (nn > p.arena.cap_nodes) return fail(p, r, FCD_ST_INTERNAL, n_amb, n_crit);
         // search.rs:261-277: any NaN among >= 2 candidates -> IncomparableValues, then empty -> RanOutOfBeam
-        if (n_valid >= 2 && any_nan) return fail(p, r, FCD_ST_INCOMPARABLE, n_amb);
-        if (n_valid == 0) return fail(p, r, FCD_ST_RAN_OUT_OF_BEAM, n_amb);
+        if (n_valid >= 2 && any_nan) return fail(p, r, FCD_ST_INCOMPARABLE, n_amb, n_crit);
+        if (n_valid == 0) return fail(p, r, FCD_ST_RAN_OUT_OF_BEAM, n_amb, n_crit);
         wave_sync();
 
         // ---- phase B: the top beam_size candidates, in exact key order, build the next beam ----
@@ -349,7 +351,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         int bstar = kBuckets - 1;  // accept every valid candidate (n_valid <= BC)
         int Lc = n_valid;
         uint32_t mx = 0;
-        bool tie = false;
+        bool tie = false, crit = false;
         if (n_valid > BC) {
             for (int c = lane; c < nslots; c += kWave) {
                 const uint32_t hi = (uint32_t)(L.c_key[c] >> 32);
@@ -412,11 +414,17 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                 const uint64_t key = L.l_key[e];
                 int rank = 0;
                 for (int j = 0; j < Lc; ++j) rank += (L.l_key[j] > key) ? 1 : 0;
-                if (count_amb && rank < BC && n_valid > 20) {
-                    // equal probabilities share a bucket: every candidate tied with a kept one is in the list
-                    int n_eq = 0;
-                    for (int j = 0; j < Lc; ++j) n_eq += ((uint32_t)(L.l_key[j] >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
-                    tie = tie || n_eq >= 2;
+                if (count_amb) {
+                    // equal probabilities share a bucket: every candidate tied with a kept one is in the list,
+                    // and so is every candidate of greater probability
+                    int n_eq = 0, n_gt = 0;
+                    for (int j = 0; j < Lc; ++j) {
+                        const uint32_t hj = (uint32_t)(L.l_key[j] >> 32), he = (uint32_t)(key >> 32);
+                        n_eq += hj == he ? 1 : 0;
+                        n_gt += hj > he ? 1 : 0;
+                    }
+                    tie = tie || (rank < BC && n_valid > 20 && n_eq >= 2);
+                    crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < BC && n_gt + n_eq > BC)));
                 }
                 if (rank < BC) {
                     const int c = L.l_c[e];
@@ -460,13 +468,15 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             const uint64_t key = myk[u];
             const int rank = myr[u];
             if (c >= nslots || key == 0ull) continue;
-            if (count_amb && rank < BC && n_valid > 20) {
-                int n_eq = 0;
+            if (count_amb) {
+                int n_eq = 0, n_gt = 0;
                 for (int j = 0; j < nslots; ++j) {
                     const uint64_t kj = L.c_key[j];
                     n_eq += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
+                    n_gt += ((uint32_t)(kj >> 32) > (uint32_t)(key >> 32)) ? 1 : 0;
                 }
-                tie = tie || n_eq >= 2;
+                tie = tie || (rank < BC && n_valid > 20 && n_eq >= 2);
+                crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < BC && n_gt + n_eq > BC)));
             }
             if (rank < BC) {
                 const int i = c / N, k = c - i * N;
@@ -491,7 +501,10 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         }
         }
         wave_sync();
-        if (count_amb) n_amb += __ballot(tie) != 0ull ? 1 : 0;
+        if (count_amb) {
+            n_amb += __ballot(tie) != 0ull ? 1 : 0;
+            n_crit += __ballot(crit) != 0ull ? 1 : 0;
+        }
 
         // ---- phase C: child rows of the new beam + renormalise by the top entry (:278-282) ----
         for (int item = lane; item < Bn * NL; item += kWave) {
@@ -539,7 +552,10 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         }
         p.out.out_len[r] = (uint32_t)n;
         p.out.status[r] = FCD_ST_OK;
-        if (count_amb) p.out.ambiguous[r] = (uint32_t)n_amb;
+        if (count_amb) {
+            p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+            p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+        }
     }
 }
 

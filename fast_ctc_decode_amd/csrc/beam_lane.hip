@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     int B = 1;
     int nn = 0;
     bool alive = has_read;
-    int n_amb = 0;
+    int n_amb = 0, n_crit = 0;
     int state = 0;
     const int s_mask = CRF ? (int)p.in.S - 1 : 0;
     if (CRF && has_read) {
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         int bstar = KB - 1;
         int Lc = go ? n_valid : 0;
         uint32_t mx = 0;
-        bool tie = false;  // AMB: a kept candidate of this lane shares its probability with another candidate
+        bool tie = false, crit = false;  // AMB: the two tie conditions of include/fcd.h (fcd_result.ambiguous)
         if (ballot(need_sel) != 0ull) {
 #pragma unroll
             for (int k = 0; k < N; ++k) {
@@ -388,7 +388,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             for (int e0 = 0; e0 < lmax; e0 += HALF) {
                 const int e = e0 + q;
                 const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
-                int rk = 0, rk2 = 0, n_eq = 0;
+                int rk = 0, rk2 = 0, n_eq = 0, n_gt = 0;
                 for (int j = 0; j < lmax; j += 2) {  // two keys per 16-byte LDS read
                     const ulonglong2 kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
                     rk += (kk2.x > ke) ? 1 : 0;
@@ -396,11 +396,16 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
                     if (AMB) {  // equal probabilities share a bucket: every candidate tied with a kept one is listed
                         n_eq += (kk2.x != 0ull && (uint32_t)(kk2.x >> 32) == (uint32_t)(ke >> 32)) ? 1 : 0;
                         n_eq += (kk2.y != 0ull && (uint32_t)(kk2.y >> 32) == (uint32_t)(ke >> 32)) ? 1 : 0;
+                        n_gt += ((uint32_t)(kk2.x >> 32) > (uint32_t)(ke >> 32)) ? 1 : 0;
+                        n_gt += ((uint32_t)(kk2.y >> 32) > (uint32_t)(ke >> 32)) ? 1 : 0;
                     }
                 }
                 rk += rk2;
                 if (e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
-                if (AMB) tie = tie || (e < Lc && rk < beam_size && n_valid > 20 && n_eq >= 2);
+                if (AMB && e < Lc) {
+                    tie = tie || (rk < beam_size && n_valid > 20 && n_eq >= 2);
+                    crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < beam_size && n_gt + n_eq > beam_size)));
+                }
             }
             wave_sync();
             const uint64_t mine = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
@@ -411,26 +416,35 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 #pragma unroll
             for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
             wave_sync();
-            int rk[N], n_eq[N];
+            int rk[N], n_eq[N], n_gt[N];
 #pragma unroll
-            for (int k = 0; k < N; ++k) rk[k] = n_eq[k] = 0;
+            for (int k = 0; k < N; ++k) rk[k] = n_eq[k] = n_gt[k] = 0;
             for (int j = 0; j < HALF * N; ++j) {
                 const uint64_t kj = c_key[hbase * N + j];
 #pragma unroll
                 for (int k = 0; k < N; ++k) {
                     rk[k] += (kj > key[k]) ? 1 : 0;
-                    if (AMB) n_eq[k] += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key[k] >> 32)) ? 1 : 0;
+                    if (AMB) {
+                        n_eq[k] += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key[k] >> 32)) ? 1 : 0;
+                        n_gt[k] += ((uint32_t)(kj >> 32) > (uint32_t)(key[k] >> 32)) ? 1 : 0;
+                    }
                 }
             }
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 rank[k] = (key[k] != 0ull && rk[k] < beam_size) ? rk[k] : -1;
-                if (AMB) tie = tie || (rank[k] >= 0 && go && n_valid > 20 && n_eq[k] >= 2);
+                if (AMB && key[k] != 0ull) {
+                    tie = tie || (rank[k] >= 0 && n_valid > 20 && n_eq[k] >= 2);
+                    crit = crit || (n_eq[k] >= 2 && (n_gt[k] == 0 || (n_gt[k] < beam_size && n_gt[k] + n_eq[k] > beam_size)));
+                }
             }
             wave_sync();
         }
 
-        if (AMB) n_amb += hcount(tie) != 0 ? 1 : 0;
+        if (AMB) {
+            n_amb += hcount(tie) != 0 ? 1 : 0;
+            n_crit += hcount(crit) != 0 ? 1 : 0;
+        }
 
         // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
         s_fate[lane] = rank[0];
@@ -556,7 +570,10 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
     }
-    if (AMB && q == 0 && has_read) p.out.ambiguous[r] = (uint32_t)n_amb;
+    if (AMB && q == 0 && has_read) {
+        p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+        p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+    }
     int h0 = bperm(hbase, node);
     int d0 = bperm(hbase, alive ? depth : 0);
     const int j0 = bperm(hbase, jump);

@@ -87,11 +87,8 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // of step t+1 (4 B per lane, five 20-byte rows per read and step).  (state * 4) & (S - 1) + label < S
 // always holds for such S, so no transition can leave the table.
 //
-// AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous): the number of
-// steps with more than 20 candidates in which a KEPT candidate shares its exact probability with another
-// candidate -- the only steps where the reference's sort_unstable_by (pdqsort above 20 elements) could
-// produce a different beam (set or order) from the stable rule used here.  A separate instantiation: the
-// timed kernel pays nothing.
+// AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous, two counters per
+// read; semantics in include/fcd.h).  A separate instantiation: the timed kernel pays nothing.
 template <int N, int GW, int RPW, int S, bool AMB>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
@@ -111,7 +108,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     static_assert(HAS_SCRATCH || NIDLE >= 1, "no lane left to absorb idle pushes");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
-    int n_amb = 0;
+    int n_amb = 0, n_crit = 0;
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -322,14 +319,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         int rank = 0;
-        int n_eq = 0;  // AMB: candidates of exactly this probability, itself included
+        int n_eq = 0, n_gt = 0;  // AMB: candidates of exactly this probability (itself included) / of a greater one
 #pragma unroll
         for (int j = 0; j < BCAP; ++j) {
 #pragma unroll
             for (int c = 0; c <= NL; ++c) {
                 const uint64_t kj = keys[hbase + j * GW + c];
                 rank += (kj > key) ? 1 : 0;
-                if (AMB) n_eq += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
+                if (AMB) {
+                    n_eq += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
+                    n_gt += ((uint32_t)(kj >> 32) > (uint32_t)(key >> 32)) ? 1 : 0;
+                }
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -337,10 +337,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
         const bool sel = valid && go && rank < beam_size;
         if (AMB) {
-            // a kept candidate that shares its probability with any other candidate of a > 20-candidate step
+            // [0] a kept candidate that shares its probability with any other candidate of a > 20-candidate step;
+            // [1] (any candidate count) equal probabilities at ranks 0 / 1 or across the truncation boundary:
+            //     the group of n_eq equal candidates occupies ranks [n_gt, n_gt + n_eq)
             const bool tie = sel && n_valid > 20 && n_eq >= 2;
-            const uint64_t m_tie = ballot(tie);
+            const bool crit = valid && go && n_eq >= 2 && (n_gt == 0 || (n_gt < beam_size && n_gt + n_eq > beam_size));
+            const uint64_t m_tie = ballot(tie), m_crit = ballot(crit);
             n_amb += (RPW == 1 ? m_tie : (hbase ? (m_tie >> 32) : (m_tie & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
+            n_crit += (RPW == 1 ? m_crit : (hbase ? (m_crit >> 32) : (m_crit & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
         }
 
         // ---- keep the IN-BEAM/slot bits of every child entry current ----
@@ -420,7 +424,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         p.out.out_len[r] = (uint32_t)depth;
         p.out.status[r] = FCD_ST_OK;
     }
-    if (AMB && q == 0 && has_read) p.out.ambiguous[r] = (uint32_t)n_amb;
+    if (AMB && q == 0 && has_read) {
+        p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+        p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+    }
     int *heads = s_heads[wave];
     // beam[0] lives in group 0: every lane of the half takes ITS leaf and depth
     int h0 = bperm(hbase, node);               // current chunk's first segment head

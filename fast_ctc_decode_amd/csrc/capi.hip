@@ -857,7 +857,7 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     const size_t o_olen = reserve((size_t)B * 4);
     const size_t o_stat = reserve((size_t)B * 4);
     const bool want_amb = out->ambiguous && (c.op == Op::Beam || c.op == Op::CrfBeam);
-    const size_t o_amb = reserve(want_amb ? (size_t)B * 4 : 0);
+    const size_t o_amb = reserve(want_amb ? (size_t)B * 8 : 0);
 
     int rc;
     {
@@ -907,7 +907,7 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     if (out->status)
         FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     if (want_amb)
-        FCD_HIP(h, hipMemcpyAsync(out->ambiguous, dout.ambiguous, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+        FCD_HIP(h, hipMemcpyAsync(out->ambiguous, dout.ambiguous, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
 }

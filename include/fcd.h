@@ -107,14 +107,18 @@ typedef struct fcd_batch {
  *            reference feeds to phred() for each emitted label (src/search.rs:348-356,370-376)
  *   out_len: [n_reads] u32   number of emitted labels
  *   status : [n_reads] i32   FCD_ST_*  (nullable for viterbi)
- *   ambiguous: [n_reads] u32 (nullable; fcd_beam_search_* and fcd_crf_beam_search_* only; device pointer
- *            for *_dev, host pointer for *_host).  A tie instrument, not a reference output: the number
- *            of time steps at which the merged candidate list held more than 20 entries AND a candidate
- *            that survived the truncation had exactly the probability of another candidate.  The
- *            reference sorts candidates with sort_unstable_by (src/search.rs:122,262), which is a
- *            stable insertion sort up to 20 elements and pdqsort (implementation-defined tie order)
- *            above; the kernels break ties by ascending node index.  A read whose count is 0 has the
- *            same beam (set and order) at every step under ANY tie order.
+ *   ambiguous: [n_reads][2] u32 (nullable; fcd_beam_search_* and fcd_crf_beam_search_* only; device pointer
+ *            for *_dev, host pointer for *_host) -- a TIE INSTRUMENT, not a reference output.  The reference
+ *            orders candidates with sort_unstable_by (src/search.rs:122,262): a stable insertion sort up to
+ *            20 elements, pdqsort -- implementation-defined tie order -- above.  The kernels break exact
+ *            probability ties by ascending node index, which is what the stable path does.
+ *              [r][0] steps with MORE than 20 candidates in which a candidate that survives the truncation has
+ *                     exactly the probability of another candidate.  0 for a read => its beam, set and order,
+ *                     follows the reference step for step;
+ *              [r][1] steps (any candidate count) with equal probabilities at ranks 0 / 1 or across the
+ *                     truncation boundary.  0 for a read => no tie rule can change a kept set or the best entry.
+ *            A read with either counter at 0 is pinned to the reference; the others can be settled with the
+ *            oracle's exhaustive replay (oracle/fcd_oracle.h, fcdo_beam_search_all_tie_orders).
  *            Passing the array selects instrumented kernel instantiations (slower by a few percent).
  * out_stride must be >= the longest possible output (T is always enough). */
 typedef struct fcd_result {

@@ -252,6 +252,48 @@ DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
  * Shared tail of every 1D step: :245-282 (== :105-142).  Returns FCDO_* status.
  */
 /*
+ * Exhaustive tie enumeration (fcdo_beam_search_all_tie_orders).  The output of a 1D beam search is a
+ * function of the KEPT SET of every step and of which entry is beam[0] after the last step: the order of
+ * the kept entries only feeds node numbering, and node numbers only feed tie-breaking; the merge sums have
+ * at most two non-zero addends (order-free); normalisation divides by the maximum, which tied entries share;
+ * a node's creation time is the first step at which it is a candidate.  So the only places where ANY tie
+ * rule -- Rust's pdqsort above 20 candidates included -- can change the result are (a) a group of equal
+ * probabilities straddling the truncation boundary (which m of the k tied candidates are kept) and (b) equal
+ * probabilities at the top after the last step (which of them is walked).  A tie_ctx replays the search
+ * under one resolution of every such event; the driver below enumerates them all like an odometer.
+ */
+typedef struct {
+    int64_t *choice, *nopt;
+    int64_t cap, depth, pos;
+    int overflow;
+} tie_ctx;
+
+static int64_t tie_next_choice(tie_ctx *tc, int64_t n_options) {
+    if (tc->pos >= tc->cap) {
+        tc->overflow = 1;
+        return 0;
+    }
+    int64_t i = tc->pos++;
+    if (i >= tc->depth) {
+        tc->choice[i] = 0;
+        tc->depth = i + 1;
+    }
+    tc->nopt[i] = n_options;
+    return tc->choice[i] < n_options ? tc->choice[i] : 0;
+}
+
+static int64_t n_choose_k(int64_t n, int64_t k, int64_t cap) {
+    if (k < 0 || k > n) return 0;
+    if (k > n - k) k = n - k;
+    int64_t r = 1;
+    for (int64_t i = 1; i <= k; ++i) {
+        r = r * (n - k + i) / i;
+        if (r > cap) return cap + 1;
+    }
+    return r;
+}
+
+/*
  * n_amb (nullable) counts the steps whose outcome the restatement cannot pin to the reference: the
  * merged list holds more than 20 candidates (so Rust 1.78's sort_unstable_by is a true pdqsort whose
  * tie order is implementation-defined) AND a candidate that survives the truncation has
@@ -260,7 +302,8 @@ DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
  * the same under any tie order, every <= 20-candidate step is Rust's stable insertion sort, which the
  * stable sort here reproduces, so node numbering, beam and output follow the reference step for step.
  */
-static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *tmpcap, int64_t *n_amb) {
+static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *tmpcap, int64_t *n_amb,
+                           tie_ctx *tc, int last_step) {
     sp1_sort_node(beam->v, beam->len, tmp, tmpcap); /* :245 stable */
     /* :246-260 fold equal nodes into the first occurrence, then retain */
     int64_t w = 0;
@@ -282,13 +325,64 @@ static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *
         }
     }
     sp1_sort_prob(beam->v, beam->len, tmp, tmpcap);
-    if (n_amb && beam->len > 20) {
-        int tie = 0; /* sorted: equal probabilities are adjacent */
-        for (int64_t i = 0; i < beam_size && i + 1 < beam->len; ++i)
-            tie |= sp1_prob(&beam->v[i]) == sp1_prob(&beam->v[i + 1]);
-        if (tie) ++*n_amb;
+    if (n_amb) {
+        /* sorted: equal probabilities are adjacent.  n_amb[0]: > 20 candidates and a kept candidate ties
+         * with another one; n_amb[1]: (any candidate count) a tie across the truncation boundary or
+         * between ranks 0 and 1 -- the ties that can change the kept set or the best entry */
+        if (beam->len > 20) {
+            int tie = 0;
+            for (int64_t i = 0; i < beam_size && i + 1 < beam->len; ++i)
+                tie |= sp1_prob(&beam->v[i]) == sp1_prob(&beam->v[i + 1]);
+            if (tie) ++n_amb[0];
+        }
+        int crit = beam->len >= 2 && sp1_prob(&beam->v[0]) == sp1_prob(&beam->v[1]);
+        crit |= beam->len > beam_size && sp1_prob(&beam->v[beam_size - 1]) == sp1_prob(&beam->v[beam_size]);
+        if (crit) ++n_amb[1];
+    }
+    if (tc && beam->len > beam_size &&
+        sp1_prob(&beam->v[beam_size - 1]) == sp1_prob(&beam->v[beam_size])) {
+        /* (a) k equal candidates [g0, g1) straddle the boundary, m of them fit: take the c-th m-subset
+         * (lexicographic; c = 0 is the stable rule) by moving the chosen ones to the front of the group */
+        float pb = sp1_prob(&beam->v[beam_size]);
+        int64_t g0 = beam_size - 1, g1 = beam_size + 1;
+        while (g0 > 0 && sp1_prob(&beam->v[g0 - 1]) == pb) --g0;
+        while (g1 < beam->len && sp1_prob(&beam->v[g1]) == pb) ++g1;
+        int64_t k = g1 - g0, m = beam_size - g0;
+        int64_t n_sub = n_choose_k(k, m, 1 << 20);
+        if (n_sub > (1 << 20)) tc->overflow = 1;
+        int64_t c = tie_next_choice(tc, n_sub);
+        if (c > 0 && k <= 64) {
+            sp1 grp[64], pick[64], rest[64];
+            memcpy(grp, beam->v + g0, sizeof(sp1) * k);
+            int64_t np = 0, nr = 0, need = m;
+            for (int64_t j = 0; j < k; ++j) { /* unrank: is element j in the c-th subset? */
+                int64_t with_j = need > 0 ? n_choose_k(k - j - 1, need - 1, 1 << 20) : 0;
+                if (need > 0 && c < with_j) {
+                    pick[np++] = grp[j];
+                    --need;
+                } else {
+                    rest[nr++] = grp[j];
+                    c -= with_j;
+                }
+            }
+            memcpy(beam->v + g0, pick, sizeof(sp1) * np);
+            memcpy(beam->v + g0 + np, rest, sizeof(sp1) * nr);
+        } else if (c > 0) {
+            tc->overflow = 1;
+        }
     }
     if (beam->len > beam_size) beam->len = beam_size; /* :273 */
+    if (tc && last_step && beam->len >= 2 && sp1_prob(&beam->v[0]) == sp1_prob(&beam->v[1])) {
+        /* (b) the walk starts at beam[0]: any of the kept entries tied for the top may be it */
+        int64_t h = 2;
+        while (h < beam->len && sp1_prob(&beam->v[h]) == sp1_prob(&beam->v[0])) ++h;
+        int64_t c = tie_next_choice(tc, h);
+        if (c > 0) {
+            sp1 t0 = beam->v[0];
+            beam->v[0] = beam->v[c];
+            beam->v[c] = t0;
+        }
+    }
     if (beam->len == 0) return FCDO_RAN_OUT_OF_BEAM;  /* :274-277 */
     float top = sp1_prob(&beam->v[0]);                /* :278-282 */
     for (int64_t i = 0; i < beam->len; ++i) {
@@ -329,7 +423,7 @@ typedef struct {
 
 static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                           int64_t beam_size, float thr, int collapse_repeats, int32_t *labels,
-                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out, int64_t *n_amb);
+                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out, int64_t *n_amb, tie_ctx *tc);
 
 int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                      int64_t beam_size, float thr, int collapse_repeats,
@@ -345,9 +439,9 @@ int fcdo_beam_search_ex(const float *x, int64_t T, int64_t N, int64_t rs, int64_
     beam_ws ws;
     memset(&ws, 0, sizeof(ws));
     ws.tree = fcdo_tree_new(N - 1);
-    if (n_ambiguous_out) *n_ambiguous_out = 0;
+    if (n_ambiguous_out) n_ambiguous_out[0] = n_ambiguous_out[1] = 0;
     int st = beam_search_ws(&ws, x, T, N, rs, cs, beam_size, thr, collapse_repeats, labels, path,
-                            n_out, n_nodes_out, n_ambiguous_out);
+                            n_out, n_nodes_out, n_ambiguous_out, NULL);
     free(ws.beam.v);
     free(ws.next.v);
     free(ws.tmp);
@@ -355,9 +449,73 @@ int fcdo_beam_search_ex(const float *x, int64_t T, int64_t N, int64_t rs, int64_
     return st;
 }
 
+/* Runs the search under EVERY resolution of the ties that can change the result (see tie_ctx).  labels /
+ * path / n_out receive the stable-rule result (the first branch).  Returns its status; *n_branches = the
+ * number of resolutions explored, *n_distinct = 1 when they all produced the same (status, labels, path),
+ * 2 otherwise; *complete = 0 if max_branches (or the subset bound) stopped the enumeration early. */
+int fcdo_beam_search_all_tie_orders(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                                    int64_t beam_size, float thr, int collapse_repeats,
+                                    int32_t *labels, int64_t *path, int64_t *n_out,
+                                    int64_t max_branches, int64_t *n_branches, int64_t *n_distinct,
+                                    int *complete) {
+    beam_ws ws;
+    memset(&ws, 0, sizeof(ws));
+    ws.tree = fcdo_tree_new(N - 1);
+    tie_ctx tc;
+    memset(&tc, 0, sizeof(tc));
+    tc.cap = 4096;
+    tc.choice = (int64_t *)calloc(tc.cap, sizeof(int64_t));
+    tc.nopt = (int64_t *)calloc(tc.cap, sizeof(int64_t));
+    int64_t cap_out = T > 0 ? T : 1;
+    int32_t *l2 = (int32_t *)malloc(sizeof(int32_t) * cap_out);
+    int64_t *p2 = (int64_t *)malloc(sizeof(int64_t) * cap_out);
+    int64_t branches = 0, distinct = 1, n0 = 0;
+    int st0 = FCDO_OK, done = 0;
+    *complete = 1;
+    while (!done) {
+        tc.pos = 0;
+        int64_t n = 0;
+        int st = beam_search_ws(&ws, x, T, N, rs, cs, beam_size, thr, collapse_repeats,
+                                branches == 0 ? labels : l2, branches == 0 ? path : p2, &n, NULL, NULL, &tc);
+        if (branches == 0) {
+            st0 = st;
+            n0 = (st == FCDO_OK) ? n : 0;
+        } else if (st != st0 || (st == FCDO_OK && (n != n0 || memcmp(l2, labels, sizeof(int32_t) * n) ||
+                                                   memcmp(p2, path, sizeof(int64_t) * n)))) {
+            distinct = 2;
+        }
+        ++branches;
+        /* odometer: bump the last event that still has an untried option, forget everything after it */
+        int64_t i = tc.pos - 1;
+        while (i >= 0 && tc.choice[i] + 1 >= tc.nopt[i]) --i;
+        if (i < 0) {
+            done = 1;
+        } else {
+            tc.choice[i]++;
+            tc.depth = i + 1;
+        }
+        if (tc.overflow || (!done && branches >= max_branches)) {
+            *complete = 0;
+            done = 1;
+        }
+    }
+    *n_out = n0;
+    *n_branches = branches;
+    *n_distinct = distinct;
+    free(tc.choice);
+    free(tc.nopt);
+    free(l2);
+    free(p2);
+    free(ws.beam.v);
+    free(ws.next.v);
+    free(ws.tmp);
+    fcdo_tree_free(ws.tree);
+    return st0;
+}
+
 static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                           int64_t beam_size, float thr, int collapse_repeats, int32_t *labels,
-                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out, int64_t *n_amb) {
+                          int64_t *path, int64_t *n_out, int64_t *n_nodes_out, int64_t *n_amb, tie_ctx *tc) {
     int64_t alphabet_size = N - 1; /* :167 */
     fcdo_tree *tree = ws->tree;
     tree_reset(tree);
@@ -405,7 +563,7 @@ static int beam_search_ws(beam_ws *ws, const float *x, int64_t T, int64_t N, int
         sp1vec t = beam; /* :242 swap */
         beam = next;
         next = t;
-        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap, n_amb);
+        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap, n_amb, tc, idx == T - 1);
         if (status != FCDO_OK) break;
     }
 
@@ -452,7 +610,7 @@ int fcdo_crf_beam_search_ex(const float *x, int64_t T, int64_t S, int64_t N,
                             const float *init, int64_t n_init, int64_t is0,
                             int64_t beam_size, float thr,
                             int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_ambiguous_out) {
-    if (n_ambiguous_out) *n_ambiguous_out = 0;
+    if (n_ambiguous_out) n_ambiguous_out[0] = n_ambiguous_out[1] = 0;
     if (T <= 0 || S <= 0 || N <= 0) return FCDO_PANIC; /* :46 */
     int64_t n_state = S, n_base = N - 1;               /* :50-51 */
     int64_t st0;
@@ -493,7 +651,7 @@ int fcdo_crf_beam_search_ex(const float *x, int64_t T, int64_t S, int64_t N,
         sp1vec t = beam;
         beam = next;
         next = t;
-        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap, n_ambiguous_out); /* :104-142 */
+        status = sp1_merge_prune(&beam, beam_size, &tmp, &tmpcap, n_ambiguous_out, NULL, 0); /* :104-142 */
     }
     if (status == FCDO_OK) *n_out = tree_walk_1d(tree, beam.v[0].node, labels, path);
     free(beam.v);
@@ -1036,17 +1194,20 @@ static void *batch_worker(void *arg) {
         const float *x = j->x + r * j->T * j->N;
         int32_t *ol = store ? j->labels + r * j->T : sl;
         int64_t *op = store ? j->path + r * j->T : sp;
-        int64_t n = 0, amb = 0;
+        int64_t n = 0, amb[2] = {0, 0};
         int st;
         if (j->kind == 0)
             st = beam_search_ws(&ws, x, j->T, j->N, j->N, 1, j->beam_size, j->thr, j->collapse, ol,
-                                op, &n, NULL, (store && j->ambiguous) ? &amb : NULL);
+                                op, &n, NULL, (store && j->ambiguous) ? amb : NULL, NULL);
         else
             st = fcdo_viterbi_search(x, j->T, j->N, j->N, 1, j->collapse, 1.0f, 0.0f, ol, op, NULL, &n);
         if (store) {
             j->lens[r] = (st == FCDO_OK) ? n : 0;
             if (j->status) j->status[r] = st;
-            if (j->ambiguous) j->ambiguous[r] = amb;
+            if (j->ambiguous) {
+                j->ambiguous[2 * r] = amb[0];
+                j->ambiguous[2 * r + 1] = amb[1];
+            }
         }
     }
     free(sl);

@@ -71,12 +71,17 @@ int fcdo_beam_search(const float *x, int64_t T, int64_t N, int64_t rs, int64_t c
                      int32_t *labels, int64_t *path, int64_t *n_out, int64_t *n_nodes_out);
 
 /*
- * The same search plus the tie instrument of SURVEY.md 8a A4: n_ambiguous_out (nullable) receives the
- * number of time steps at which the merged candidate list held MORE than 20 entries (Rust 1.78's
- * sort_unstable_by is a stable insertion sort up to 20 elements, pdqsort above) AND a candidate that
- * survived the truncation had exactly the probability of another candidate.  On a read where the
- * count is 0 the stable tie rule used here and ANY tie order of pdqsort give the same beam -- set and
- * order -- at every step, hence the same node numbering and the same output.
+ * The same search plus the tie instrument of SURVEY.md 8a A4.  Rust 1.78's sort_unstable_by
+ * (src/search.rs:122,262) is a stable insertion sort up to 20 elements and pdqsort -- implementation-defined
+ * tie order -- above; this restatement breaks ties by ascending node index (the stable behaviour).
+ * n_ambiguous_out (nullable, TWO entries) receives
+ *   [0] the number of steps with MORE than 20 merged candidates in which a candidate that survives the
+ *       truncation has exactly the probability of another candidate.  0 => the beam, set and order, follows
+ *       the reference step for step (every other step is pinned by the stable rule);
+ *   [1] the number of steps (any candidate count) with equal probabilities at ranks 0 / 1 or across the
+ *       truncation boundary.  0 => kept sets and best entry do not depend on ANY tie rule.
+ * A read with either entry 0 is pinned to the reference; the rest can be settled exhaustively with
+ * fcdo_beam_search_all_tie_orders below.
  */
 int fcdo_beam_search_ex(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
                         int64_t beam_size, float beam_cut_threshold, int collapse_repeats,
@@ -92,6 +97,19 @@ int fcdo_crf_beam_search(const float *x, int64_t T, int64_t S, int64_t N,
                          const float *init, int64_t n_init, int64_t is0,
                          int64_t beam_size, float beam_cut_threshold,
                          int32_t *labels, int64_t *path, int64_t *n_out);
+
+/*
+ * Exhaustive tie enumeration: the search is replayed under every possible resolution of the ties that can
+ * change its result -- which m of k equal candidates straddling the truncation boundary are kept (at any
+ * step), and which of the entries tied for the top is walked after the last step.  If all replays give the
+ * same (status, labels, path), the result is what the reference returns under ANY tie order, pdqsort's
+ * included (argument in fcd_oracle.c above tie_ctx).  labels / path / n_out: the stable-rule result.
+ */
+int fcdo_beam_search_all_tie_orders(const float *x, int64_t T, int64_t N, int64_t rs, int64_t cs,
+                                    int64_t beam_size, float beam_cut_threshold, int collapse_repeats,
+                                    int32_t *labels, int64_t *path, int64_t *n_out,
+                                    int64_t max_branches, int64_t *n_branches, int64_t *n_distinct,
+                                    int *complete);
 
 int fcdo_crf_beam_search_ex(const float *x, int64_t T, int64_t S, int64_t N,
                             int64_t s0, int64_t s1, int64_t s2,

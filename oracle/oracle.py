@@ -43,6 +43,7 @@ def _load():
     lib.fcdo_viterbi_search.argtypes = [P, i64, i64, i64, i64, i32, f32, f32, P, P, P, P]
     lib.fcdo_beam_search.argtypes = [P, i64, i64, i64, i64, i64, f32, i32, P, P, P, P]
     lib.fcdo_beam_search_ex.argtypes = [P, i64, i64, i64, i64, i64, f32, i32, P, P, P, P, P]
+    lib.fcdo_beam_search_all_tie_orders.argtypes = [P, i64, i64, i64, i64, i64, f32, i32, P, P, P, i64, P, P, P]
     lib.fcdo_crf_beam_search_ex.argtypes = [P, i64, i64, i64, i64, i64, i64, P, i64, i64, i64, f32, P, P, P, P]
     lib.fcdo_beam_search_batch_ex.argtypes = [P, i64, i64, i64, i64, f32, i32, P, P, P, P, P, i32, i64]
     lib.fcdo_crf_beam_search.argtypes = [P, i64, i64, i64, i64, i64, i64, P, i64, i64, i64, f32, P, P, P]
@@ -157,18 +158,37 @@ def beam_search_raw(network_output, beam_size, beam_cut_threshold, collapse_repe
 
 
 def beam_search_ambiguous(network_output, beam_size, beam_cut_threshold, collapse_repeats=True):
-    """-> (status, labels, path, n_ambiguous): fcdo_beam_search_ex, the search plus the number of steps
-    with > 20 candidates and an exact tie at ranks 0/1 or across the truncation boundary."""
+    """-> (status, labels, path, (n_gt20_kept_ties, n_critical_ties)): fcdo_beam_search_ex, the search plus
+    the two tie counters of SURVEY 8a A4 (semantics in fcd_oracle.h)."""
     x = network_output
     T, N = x.shape
     rs, cs = _estrides(x)
     labels = np.empty(max(T, 1), np.int32)
     path = np.empty(max(T, 1), np.int64)
-    n, nn, na = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    n, nn = C.c_int64(0), C.c_int64(0)
+    na = (C.c_int64 * 2)(0, 0)
     st = lib.fcdo_beam_search_ex(_ptr(x), T, N, rs, cs, beam_size, beam_cut_threshold,
                                  int(collapse_repeats), _ptr(labels), _ptr(path), C.byref(n),
-                                 C.byref(nn), C.byref(na))
-    return st, labels[: n.value], path[: n.value], na.value
+                                 C.byref(nn), na)
+    return st, labels[: n.value], path[: n.value], (int(na[0]), int(na[1]))
+
+
+def beam_search_all_tie_orders(network_output, beam_size, beam_cut_threshold, collapse_repeats=True,
+                               max_branches=4096):
+    """Replays the search under every resolution of the ties that can change its result (truncation-boundary
+    groups at any step, the top after the last step).
+    -> (status, labels, path, n_branches, all_equal, complete): all_equal and complete => this is the
+    reference's output under ANY tie order."""
+    x = network_output
+    T, N = x.shape
+    rs, cs = _estrides(x)
+    labels = np.empty(max(T, 1), np.int32)
+    path = np.empty(max(T, 1), np.int64)
+    n, nb, nd, comp = C.c_int64(0), C.c_int64(0), C.c_int64(0), C.c_int(0)
+    st = lib.fcdo_beam_search_all_tie_orders(_ptr(x), T, N, rs, cs, beam_size, beam_cut_threshold,
+                                             int(collapse_repeats), _ptr(labels), _ptr(path), C.byref(n),
+                                             max_branches, C.byref(nb), C.byref(nd), C.byref(comp))
+    return st, labels[: n.value], path[: n.value], nb.value, nd.value == 1, bool(comp.value)
 
 
 def crf_beam_search_ambiguous(network_output, init_state, beam_size, beam_cut_threshold):
@@ -178,11 +198,12 @@ def crf_beam_search_ambiguous(network_output, init_state, beam_size, beam_cut_th
     s0, s1, s2 = _estrides(x)
     labels = np.empty(max(T, 1), np.int32)
     path = np.empty(max(T, 1), np.int64)
-    n, na = C.c_int64(0), C.c_int64(0)
+    n = C.c_int64(0)
+    na = (C.c_int64 * 2)(0, 0)
     st = lib.fcdo_crf_beam_search_ex(_ptr(x), T, S, N, s0, s1, s2, _ptr(init), init.shape[0],
                                      _estrides(init)[0], beam_size, beam_cut_threshold,
-                                     _ptr(labels), _ptr(path), C.byref(n), C.byref(na))
-    return st, labels[: n.value], path[: n.value], na.value
+                                     _ptr(labels), _ptr(path), C.byref(n), na)
+    return st, labels[: n.value], path[: n.value], (int(na[0]), int(na[1]))
 
 
 def _check_beam_args(n_alpha, inner, beam_size, thr):
@@ -332,7 +353,7 @@ def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, ini
 def beam_search_batch(x, beam_size, thr, collapse=True, n_threads=1, n_passes=1, out=None, ambiguous=None):
     """x: (B,T,N) C-contiguous f32 -> (labels (B,T) i32, path (B,T) i64, lens (B,), status (B,)).
     `out` may carry pre-touched output arrays (so that page faults stay out of a timed call).
-    `ambiguous`: optional int64 (B,) array that receives the per-read tie count of beam_search_ambiguous."""
+    `ambiguous`: optional int64 (B, 2) array that receives the per-read tie counters of beam_search_ambiguous."""
     x = np.ascontiguousarray(x, np.float32)
     B, T, N = x.shape
     if out is None:

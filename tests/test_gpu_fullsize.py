@@ -49,29 +49,44 @@ def test_four_kernels_agree_on_every_read(fcd, batch):
         assert np.array_equal(d[0], d[k]), k
 
 
-def test_config2_has_no_unpinned_ties(fcd, batch):
-    """above 20 candidates the reference's sort_unstable_by is pdqsort, whose tie order is
-    not pinned.  The tie instrument (fcd_result.ambiguous) must read 0 on every read of BASELINE config 2
-    -- on the GPU for all 4096, and the oracle's own counter must agree on a sample -- so that "identical
-    to the reference" does not depend on the tie rule there; the instrumented kernels must also return
-    the timed kernels' results."""
+def test_config2_tie_instrument(fcd, batch):
+    """above 20 candidates the reference's sort_unstable_by is pdqsort, whose tie order is not
+    pinned.  On all 4096 reads of BASELINE config 2 the tie counters of every kernel family equal the oracle's,
+    the instrumented kernels return the timed kernels' results, and the reads are classified:
+      * counter [0] == 0: the beam follows the reference step for step (stable rule == insertion sort);
+      * counter [1] == 0: no tie can change a kept set or the best entry;
+      * both non-zero: the oracle replays the read under EVERY resolution of its result-changing ties.
+    Exact f32 ties are not rare (two equal posteriors in a row are enough): 13 reads have [0] > 0, 16 have
+    [1] > 0, 11 have both, and for exactly ONE read (1198) the result depends on how pdqsort orders a tie --
+    there the kernels and the oracle use the stable rule and parity with the Rust is unpinned."""
     x, xd = batch
     base = digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True))
+    want = np.zeros((B, 2), np.int64)
+    oracle.beam_search_batch(x, 5, 0.1, True, n_threads=16, ambiguous=want)
     for k in (0, 1, 4):
         r = fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k, count_ambiguous=True).cpu()
-        assert int(np.asarray(r.ambiguous).sum()) == 0, k
+        np.testing.assert_array_equal(np.asarray(r.ambiguous).astype(np.int64), want, err_msg="kernel %d" % k)
         assert np.array_equal(digest(r), base), k
-    amb = np.zeros(64, np.int64)
-    oracle.beam_search_batch(x[:64], 5, 0.1, True, n_threads=8, ambiguous=amb)
-    assert int(amb.sum()) == 0
+    assert ((want[:, 0] > 0).sum(), (want[:, 1] > 0).sum()) == (13, 16)
+    both = np.flatnonzero((want[:, 0] > 0) & (want[:, 1] > 0))
+    assert len(both) == 11
+    r = fcd.beam_search_batch_raw(xd, 5, 0.1, True).cpu()
+    depends = []
+    for i in both:
+        st, labels, path, n_branches, all_equal, complete = oracle.beam_search_all_tie_orders(x[i], 5, 0.1, True)
+        n = int(r.out_len[i])
+        assert st == 0 and complete and np.array_equal(r.labels[i, :n], labels) and np.array_equal(r.path[i, :n], path)
+        if not all_equal:
+            depends.append(int(i))
+    assert depends == [1198]
 
 
 @pytest.mark.parametrize("beam,n_oracle", [(32, 16), (64, 16)])
 def test_config3_lane_kernel_full_length_vs_oracle(fcd, batch, beam, n_oracle):
     """BASELINE config 3 rows (T = 4000, N = 5) on the kernel AUTO picks for wide beams -- one beam entry
     per lane, two reads per wavefront at beam 32, one at beam 64: 23-bit node ids, ~172 k nodes per read,
-    eviction / reload of child rows over the whole read.  Bit-exact (labels, path, status) against the
-    oracle on n_oracle reads, no unpinned ties on them."""
+    eviction / reload of child rows over the whole read.  Bit-exact (labels, path, status) and equal tie
+    counters against the oracle on n_oracle reads."""
     x, xd = batch
     sub = xd[:n_oracle + 1]  # an odd count: the last wavefront of the two-reads-per-wave variant is half full
     r = fcd.beam_search_batch_raw(sub, beam, 0.1, True, count_ambiguous=True).cpu()
@@ -83,25 +98,32 @@ def test_config3_lane_kernel_full_length_vs_oracle(fcd, batch, beam, n_oracle):
         assert int(r.status[i]) == st == 0 and n == len(labels), i
         np.testing.assert_array_equal(r.labels[i, :n], labels)
         np.testing.assert_array_equal(r.path[i, :n], path)
-        assert n_amb == 0 and int(r.ambiguous[i]) == 0, i
+        assert tuple(int(v) for v in r.ambiguous[i]) == n_amb, i
 
 
 def test_config3_lane_and_generic_agree_on_8192_reads(fcd):
     """BASELINE config 3's per-GPU shard (8192 reads x 4000 x 5, beam 32): the lane kernel (two reads per
-    wavefront) and the LDS kernel agree on every read, and the tie instrument reads 0 on all of them."""
+    wavefront) and the LDS kernel agree on every read and on both tie counters; the oracle's counters agree
+    on a sample.  (At beam 32 the candidate list always exceeds 20 entries and ties persist over many steps:
+    ~15 % of the reads see a tie, ~0.8 % have a result that depends on pdqsort's tie order -- DESIGN.md.)"""
     torch = pytest.importorskip("torch")
     rng = np.random.default_rng(2)
     x = rng.random((8192 * T, N), dtype=np.float32)
     x /= np.linalg.norm(x, ord=2, axis=1, keepdims=True)
-    xd = torch.from_numpy(x.reshape(8192, T, N)).cuda()
+    x = x.reshape(8192, T, N)
+    xd = torch.from_numpy(x).cuda()
     lane = fcd.beam_search_batch_raw(xd, 32, 0.1, True, kernel=fcd.KERNEL_LANE, count_ambiguous=True)
     d_lane = digest(lane)
-    assert int(lane.cpu().ambiguous.astype(np.int64).sum()) == 0
+    amb_lane = lane.cpu().ambiguous.astype(np.int64)
     del lane
     d_plain = digest(fcd.beam_search_batch_raw(xd, 32, 0.1, True))
     assert np.array_equal(d_lane, d_plain)
-    gen = fcd.beam_search_batch_raw(xd[:2048], 32, 0.1, True, kernel=fcd.KERNEL_GENERIC)
+    gen = fcd.beam_search_batch_raw(xd[:2048], 32, 0.1, True, kernel=fcd.KERNEL_GENERIC, count_ambiguous=True)
     assert np.array_equal(digest(gen), d_lane[:2048])
+    np.testing.assert_array_equal(gen.cpu().ambiguous.astype(np.int64), amb_lane[:2048])
+    want = np.zeros((256, 2), np.int64)
+    oracle.beam_search_batch(x[:256], 32, 0.1, True, n_threads=16, ambiguous=want)
+    np.testing.assert_array_equal(amb_lane[:256], want)
 
 
 def test_oracle_spot_check(fcd, batch):
@@ -185,10 +207,14 @@ def test_crf_full_size_kernels_agree(fcd):
     assert np.array_equal(d[0], d[1]) and np.array_equal(d[0], d[2])
     # BASELINE config 4 shape: no unpinned ties, instrumented == timed kernels
     ra = fcd.crf_beam_search_batch_raw(x, init, 5, 0.0, count_ambiguous=True).cpu()
-    assert int(np.asarray(ra.ambiguous).sum()) == 0 and np.array_equal(digest(ra), d[0])
+    assert np.array_equal(digest(ra), d[0])
+    amb = np.asarray(ra.ambiguous).astype(np.int64)
+    rg = fcd.crf_beam_search_batch_raw(x, init, 5, 0.0, kernel=1, count_ambiguous=True).cpu()
+    np.testing.assert_array_equal(np.asarray(rg.ambiguous).astype(np.int64), amb)
     xc, ic = x[:3].cpu().numpy(), init[:3].cpu().numpy()
     r = fcd.crf_beam_search_batch_raw(x[:3].contiguous(), init[:3].contiguous(), 5, 0.0).cpu()
     for i in range(3):
         want = oracle.crf_beam_search(xc[i], ic[i], "NACGT", 5, 0.0)
         n = int(r.out_len[i])
         assert ("".join("NACGT"[l] for l in r.labels[i, :n]), r.path[i, :n].tolist()) == want
+        assert tuple(amb[i]) == oracle.crf_beam_search_ambiguous(xc[i], ic[i], 5, 0.0)[3]

@@ -1,7 +1,12 @@
-"""Secondary measurements for BASELINE.json configs 3-5 (bench.py covers config 2, the metric's
+"""Secondary measurements for BASELINE.json configs 1, 3-5 (bench.py covers config 2, the metric's
 config).  One JSON line per config: kernel-only time from the C ABI's HIP events.
 
-    python tools/bench_configs.py [3] [4] [5] [--check]
+    python tools/bench_configs.py [1] [3] [4] [5] [64] [1024] [--check]
+
+1 = BASELINE config 1: viterbi_search on ONE 100 x 5 matrix timed with the reference's own scheme
+(tests/benchmark.py:60-64,79-85: 10 calls per run, 10 runs, mean(sd)) -- on the CPU oracle (the Rust
+cannot be built here) next to the same call through the GPU drop-in, i.e. single-call latency.
+64 / 1024 = crf_beam_search with that many transition states x 5 symbols, 4096 / 512 reads.
 
 --check also decodes the first reads / pairs of every config with the CPU oracle (test infrastructure,
 used here only as the checker) and reports how many of them the GPU reproduced exactly.
@@ -73,9 +78,72 @@ def _est(x1, x2):
     return env
 
 
+def config1():
+    """tests/benchmark.py's plumbing: benchmark(f, data, limit=10) times 10 calls, repeated 10 times."""
+    import time
+
+    from oracle import oracle
+    rng = np.random.default_rng(0)
+    x = rng.random((100, 5), dtype=np.float32)
+
+    def scheme(f):
+        f(x, "NACGT")  # not in the reference script: keeps first-call set-up out of the GPU numbers
+        runs = []
+        for _ in range(10):
+            t0 = time.perf_counter()
+            for _ in range(10):
+                f(x, "NACGT")
+            runs.append(time.perf_counter() - t0)
+        return float(np.mean(runs)), float(np.std(runs))
+
+    import fast_ctc_decode as compiled
+    out = {"config": 1, "workload": "viterbi_search on one 100 x 5 f32 matrix (seed 0); 10 calls per run, "
+           "10 runs, mean(sd) seconds per run -- tests/benchmark.py:60-64,79-85"}
+    for name, f in (("cpu_oracle_port", oracle.viterbi_search), ("gpu_dropin_compiled_module", compiled.viterbi_search),
+                    ("gpu_dropin_python_mirror", fcd.viterbi_search)):
+        m, sd = scheme(f)
+        out[name] = "%.5f(%.5f)" % (m, sd)
+        out[name + "_us_per_call"] = m / 10 * 1e6
+    assert compiled.viterbi_search(x, "NACGT") == oracle.viterbi_search(x, "NACGT")
+    out["note"] = ("the reference's README quotes 0.0003 s per run for its Rust viterbi on unstated hardware; a single "
+                   "100-row read is launch-latency bound on a GPU -- batches are what the GPU path is for")
+    print(json.dumps(out), flush=True)
+
+
+def crf_states(S, B, check):
+    """crf_beam_search beam 5 with S transition states x 5 symbols: only visited states' rows are read."""
+    g = torch.Generator(device="cuda")
+    g.manual_seed(30 + S)
+    x = torch.rand((B, 4000, S, 5), generator=g, device="cuda", dtype=torch.float32)
+    x /= x.sum(-1, keepdim=True)
+    init = torch.zeros((B, S), device="cuda")
+    init[torch.arange(B), torch.arange(B) % S] = 1.0
+    for beam, thr in ((5, 0.0), (32, 0.1)):
+        r, ms = timed(lambda: fcd.crf_beam_search_batch_raw(x, init, beam, thr), reps=2)
+        mean_len = float(r.out_len.float().mean())
+        # SURVEY 8d cfg 4: algorithmically only the rows of visited states are needed: <= beam rows of 20 B
+        # per step, plus 5 B per emitted label; the dense figure is T*S*N*4 + 5L
+        visited = 4000 * min(beam, S) * 20 + 5 * mean_len
+        out = {"config": "crf S=%d" % S, "workload": "crf_beam_search beam %d thr %g, %d reads T=4000 S=%d N=5 "
+               "(%.1f GB of posteriors)" % (beam, thr, B, S, B * 4000 * S * 20 / 1e9),
+               "kernel_ms": ms, "reads_per_s": B / ms * 1e3, "ok": int((r.status == 0).sum()), "mean_len": mean_len,
+               "algorithmic_bytes_per_read_visited_rows": visited,
+               "algorithmic_GBps_visited_rows": B * visited / ms / 1e6,
+               "dense_bytes_per_read": 4000 * S * 20 + 5 * mean_len}
+        if check:
+            out.update(check_crf(x, init, r, 8, beam, thr))
+        print(json.dumps(out), flush=True)
+
+
 def main():
     check = "--check" in sys.argv
-    which = [int(a) for a in sys.argv[1:] if a != "--check"] or [3, 4, 5]
+    which = [int(a) for a in sys.argv[1:] if a != "--check"] or [1, 3, 4, 5, 64]
+    if 1 in which:
+        config1()
+    if 64 in which:
+        crf_states(64, 4096, check)
+    if 1024 in which:
+        crf_states(1024, 512, check)
     if 3 in which:  # beam 32, 8192 reads per GPU (65536 over 8 GPUs)
         B = 8192
         x = rows((B, 4000, 5), 2)
