@@ -24,7 +24,7 @@ SYMBOLS = [
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
-    "fcd_beam_search_dev", "fcd_beam_search_host",
+    "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
     "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k", "fcd_crf_beam_search_host",
     "fcd_crf_beam_search_host_k",
     "fcd_crf_greedy_search_dev", "fcd_crf_greedy_search_host",
@@ -117,6 +117,7 @@ def bind(lib):
     for sfx in ("dev", "host"):
         getattr(lib, "fcd_crf_beam_search_duplex_" + sfx).argtypes = [
             P, BP, P, i64, i64, BP, P, i64, i64, P, i64, i64, f32, i32, RP]
+    lib.fcd_beam_search_profile_dev.argtypes = [P, BP, i64, f32, i32, RP, P]
     lib.fcd_crf_beam_search_dev_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
     lib.fcd_crf_beam_search_host_k.argtypes = [P, BP, P, i64, i64, i64, f32, i32, RP]
     for sfx in ("dev", "host"):

@@ -89,7 +89,9 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 //
 // AMB: the same search plus the tie instrument of SURVEY.md 8a A4 (fcd_result.ambiguous, two counters per
 // read; semantics in include/fcd.h).  A separate instantiation: the timed kernel pays nothing.
-template <int N, int GW, int RPW, int S, bool AMB>
+// PROF: the same search with a cycle stamp after each block of the step (profiles/): every
+// stamp waits for the block's results, so the blocks' DEPENDENT latencies are measured, not their overlap.
+template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
     constexpr bool GATHER = S == kCrfGather;
@@ -109,6 +111,24 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
     int n_amb = 0, n_crit = 0;
+    uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint32_t cyc_last = 0;
+    auto stamp_i = [&](int slot, int &dep) {
+        if (PROF) {
+            uint64_t now;
+            FCD_STAMP(now, dep);
+            cyc[slot] += (uint32_t)now - cyc_last;
+            cyc_last = (uint32_t)now;
+        }
+    };
+    auto stamp_f = [&](int slot, float &dep) {
+        if (PROF) {
+            uint64_t now;
+            FCD_STAMP(now, dep);
+            cyc[slot] += (uint32_t)now - cyc_last;
+            cyc_last = (uint32_t)now;
+        }
+    };
 
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -221,8 +241,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // ---- the three row values this lane needs ----
         const int rbase = hbase + g * E + (S > 0 ? state * N : 0);
         const float pr0 = GATHER ? rowv : bpermf(rbase, win[0]);
-        const float pk = GATHER ? rowv : bpermf(rbase + (is_child ? k : 0), win[0]);
+        float pk = GATHER ? rowv : bpermf(rbase + (is_child ? k : 0), win[0]);
         const float ptip = CRF ? 0.0f : bpermf(rbase + tip + 1, win[0]);
+        stamp_f(0, pk);  // loop overhead + posterior row
         if (!GATHER && ++g == RPR) {
             g = 0;
 #pragma unroll
@@ -247,8 +268,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const bool cvalid = grp && is_child && pass && (exists || !rep || gp > 0.0f);  // :212-218
         const bool merged = cvalid && inbeam;  // the target's own lane 0 absorbs this extension
         const int dst = merged ? hbase + mslot * GW : dummy;
-        const float inc = __int_as_float(perm(dst, __float_as_int(merged ? contrib : 0.0f)));
+        float inc = __int_as_float(perm(dst, __float_as_int(merged ? contrib : 0.0f)));
         const int incv = perm(dst, merged ? 1 : 0);
+        stamp_f(1, inc);  // extensions + the push into slots that are beam entries
 
         // ---- self lanes: blank (:191-198) + repeat-stay (:206-211) + incoming extension ----
         const bool blank = pr0 > thr;
@@ -286,7 +308,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             if ((depth + 1) % kSeg == 0) jmp[newid] = (depth % kSeg == 0) ? node : jump;
             child = newid;
         }
-        const int id = is_self ? node : (is_new ? newid : cid);
+        int id = is_self ? node : (is_new ? newid : cid);
+        stamp_i(2, id);  // own candidate, node numbering, record stores
 
         // ---- search.rs:261-277 ----
         const uint64_t m_valid = ballot(valid);
@@ -333,6 +356,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             }
         }
         __builtin_amdgcn_wave_barrier();
+        stamp_i(3, rank);  // end-of-read tests, key, exact rank
 
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
         const bool sel = valid && go && rank < beam_size;
@@ -367,6 +391,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
                 rows[(int64_t)node * RW + l] = child < 0 ? -1 : (child & kStored);
         }
 
+        stamp_i(4, child);  // fate of every child entry, row eviction
         // ---- gather the survivors into rank order ----
         const int kind = is_self ? 0 : (first_entry ? 1 : 2);  // 2: re-entering, row is in HBM
         const int src0 = perm(sel ? hbase + rank * GW : dummy, lane);
@@ -378,12 +403,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
         const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
         const int n_node = bperm(src, id);
-        const float n_lp = bpermf(src, clp);
+        float n_lp = bpermf(src, clp);
         const float n_gp = bpermf(src, cgp);
         const int n_meta = bperm(src, meta);
         const int n_state = CRF ? bperm(src, statec) : 0;
         const int n_jump = bperm(src, jumpc);
         int n_child = bperm(src + k, child);  // meaningful when the source is a self lane
+        stamp_f(5, n_lp);  // survivors gathered into rank order
         const int n_kind = n_meta & 3;
         const bool ngrp = go && i < Bn;
         if (n_kind == 1 || !is_child) n_child = -1;
@@ -414,6 +440,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             child = n_child;
             B = Bn;
         }
+        stamp_f(6, lp);  // row reload, top, the two divisions, state update
+    }
+    if (PROF && lane == 0 && p.a.prof) {
+        uint32_t *o = p.a.prof + ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 8;
+#pragma unroll
+        for (int j = 0; j < 7; ++j) o[j] = cyc[j];
+        o[7] = (uint32_t)Tmax;
     }
 
     // ---- walk the best labelling leaf -> root (:285-300), segment-parallel ----
@@ -477,6 +510,9 @@ hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
     const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     if (p.out.ambiguous)
         hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+                           stream, p);
+    else if (p.a.prof && N == 5 && GW == 6 && RPW == 2 && S == 0)   // the headline instantiation only
+        hipLaunchKernelGGL((beam_wave_kernel<5, 6, 2, 0, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
     else
         hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,

@@ -372,6 +372,22 @@ int fcd_beam_search_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
     return beam_dev(h, in, a, kernel, out);
 }
 
+int fcd_beam_search_profile_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
+                                float beam_cut_threshold, int collapse_repeats, const fcd_result *out,
+                                uint32_t *cycles) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(h->mu);
+    if (beam_size < 1 || beam_size > 5 || !in || in->N != 5 || !cycles)
+        return fail(h, FCD_E_UNSUPPORTED, "profile: the instrumented instantiation is beam_size <= 5, N = 5");
+    BeamArgs a{};
+    a.beam_size = (int)beam_size;
+    a.thr = beam_cut_threshold;
+    a.collapse = collapse_repeats ? 1 : 0;
+    a.crf = 0;
+    a.prof = cycles;
+    return beam_dev(h, in, a, FCD_KERNEL_WAVE, out);
+}
+
 int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                             int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                             const fcd_result *out) {

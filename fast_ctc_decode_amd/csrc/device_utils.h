@@ -34,4 +34,11 @@ __device__ __forceinline__ int32_t load_i32_l2(const int32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Cycle stamp for the instrumented (PROF) kernel instantiations: reads the shader clock once every input
+// the stamped block produced (`dep`) has arrived, and makes `dep` opaque so that nothing consuming it is
+// scheduled above the stamp.  (tests/hipemu predefines FCD_STAMP as a no-op: there is no clock to read.)
+#ifndef FCD_STAMP
+#define FCD_STAMP(t64, dep) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t64), "+v"(dep) : : "memory")
+#endif
+
 }  // namespace fcd

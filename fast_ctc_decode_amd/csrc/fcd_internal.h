@@ -45,6 +45,9 @@ struct BeamArgs {
     int64_t n_init;
     int64_t init_stride;
     int force_one_read_per_wave;  // wave kernel: skip the two-reads-per-wavefront variant
+    // developer instrument (fcd_beam_search_profile_dev): per wavefront, shader cycles spent in each block
+    // of the step, summed over the read -- [n_wavefronts][8] u32, nullable
+    uint32_t *prof;
 };
 
 // Per-chunk tree arena of the LDS-resident ("generic") beam kernel: one slab per read.

@@ -166,6 +166,16 @@ int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
                          float beam_cut_threshold, int collapse_repeats, int kernel,
                          const fcd_result *out);
 
+/* Developer instrument, not part of the drop-in surface: the headline instantiation of the register kernel
+ * (beam_size <= 5, N = 5, two reads per wavefront) with a shader-clock stamp after each block of the time
+ * step.  cycles: device array [ceil(n_reads / 2)][8] u32 -- per wavefront, cycles summed over the read in
+ * blocks 0..6 (row fetch, extensions + push, numbering + stores, key + rank, child-entry upkeep, gather,
+ * top + divisions + state) and the step count in [7].  Results in `out` are the search's.  The stamps
+ * serialise the blocks, so this measures their dependent latencies (tools/cycle_account.py, profiles/). */
+int fcd_beam_search_profile_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
+                                float beam_cut_threshold, int collapse_repeats, const fcd_result *out,
+                                uint32_t *cycles);
+
 /* ---- search::crf_beam_search (src/search.rs:38-157) ----
  * init: [n_reads * init_stride] f32, n_init entries used per read (src/search.rs:54-59). */
 int fcd_crf_beam_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,

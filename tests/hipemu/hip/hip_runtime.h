@@ -19,6 +19,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define FCD_STAMP(t64, dep) ((t64) = 0)  // csrc/device_utils.h: cycle stamps of the PROF instantiations
+
 // ---- qualifiers -------------------------------------------------------------------------------
 #define __global__
 #define __device__
