@@ -236,6 +236,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // which on gfx9-family counters also waits for the previous step's tree stores to be acked.
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0); expcnt / lgkmcnt untouched
 
+    if (PROF) {  // first stamp: start of the loop
+        uint64_t now;
+        FCD_STAMP(now, lp);
+        cyc_last = (uint32_t)now;
+    }
     for (int t = 0; t < Tmax; ++t) {
         const bool act = alive && t < T;
         // ---- the three row values this lane needs ----
@@ -287,8 +292,25 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const float cgp = is_self ? sgp : 0.0f;
         const float prob = clp + cgp;
 
-        // ---- tree.rs:125-145 add_node: ids in (beam order, label order) == lane order ----
         const bool is_new = cvalid && !exists;
+
+        // ---- prune, first half: sort keys out, comparands back (exact rank on (probability desc, node asc)) ----
+        // The key needs a node index only to break probability ties, and only its ORDER matters: a node
+        // created in this step gets nn + q here -- above every existing index and increasing with the lane,
+        // exactly like the index it is about to receive -- so the key does not wait for the numbering below.
+        // (A NaN key is garbage but non-zero: it only ever ranks when it is the read's lone candidate, :262.)
+        const int idk = is_self ? node : (is_new ? nn + q : cid);
+        const uint64_t key = (valid && act) ? make_key(prob, idk) : 0ull;
+        keys[lane] = key;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        constexpr int NC = BCAP * N;  // comparand u = (slot u / N, column u % N)
+        uint64_t kk[NC];
+#pragma unroll
+        for (int u = 0; u < NC; ++u) kk[u] = keys[hbase + (u / N) * GW + (u % N)];
+
+        // ---- tree.rs:125-145 add_node: ids in (beam order, label order) == lane order; runs under the LDS reads ----
         const uint64_t m_new = ballot(is_new);
         const uint32_t w_new = RPW == 1 ? 0u : (hbase ? (uint32_t)(m_new >> 32) : (uint32_t)m_new);
         int n_new, pre_new;
@@ -309,7 +331,29 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             child = newid;
         }
         int id = is_self ? node : (is_new ? newid : cid);
-        stamp_i(2, id);  // own candidate, node numbering, record stores
+        stamp_i(2, id);  // own candidate, key, node numbering, record stores
+
+        // ---- prune, second half: count the larger keys ----
+        int rank = 0;
+        int n_eq = 0, n_gt = 0;  // AMB: candidates of exactly this probability (itself included) / of a greater one
+        if (AMB) {
+#pragma unroll
+            for (int u = 0; u < NC; ++u) {
+                rank += (kk[u] > key) ? 1 : 0;
+                n_eq += (kk[u] != 0ull && (uint32_t)(kk[u] >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
+                n_gt += ((uint32_t)(kk[u] >> 32) > (uint32_t)(key >> 32)) ? 1 : 0;
+            }
+        } else {
+            // four independent compare-and-count chains (device_utils.h)
+            int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+#pragma unroll
+            for (int u = 0; u + 4 <= NC; u += 4) FCD_RANK4(key, kk[u], kk[u + 1], kk[u + 2], kk[u + 3], r0, r1, r2, r3);
+#pragma unroll
+            for (int u = NC & ~3; u < NC; ++u) r0 += (kk[u] > key) ? 1 : 0;
+            rank = (r0 + r1) + (r2 + r3);
+        }
+        __builtin_amdgcn_wave_barrier();
+        stamp_i(3, rank);  // exact rank
 
         // ---- search.rs:261-277 ----
         const uint64_t m_valid = ballot(valid);
@@ -333,30 +377,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             }
         }
         const bool go = act && alive;  // this half completes the step
-
-        // ---- prune: exact rank on (probability desc, node asc) ----
-        // (a NaN that gets this far is the lone candidate of its read: any non-zero key ranks it first)
-        const uint64_t key = (valid && go) ? make_key(prob, id) : 0ull;
-        keys[lane] = key;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        int rank = 0;
-        int n_eq = 0, n_gt = 0;  // AMB: candidates of exactly this probability (itself included) / of a greater one
-#pragma unroll
-        for (int j = 0; j < BCAP; ++j) {
-#pragma unroll
-            for (int c = 0; c <= NL; ++c) {
-                const uint64_t kj = keys[hbase + j * GW + c];
-                rank += (kj > key) ? 1 : 0;
-                if (AMB) {
-                    n_eq += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
-                    n_gt += ((uint32_t)(kj >> 32) > (uint32_t)(key >> 32)) ? 1 : 0;
-                }
-            }
-        }
-        __builtin_amdgcn_wave_barrier();
-        stamp_i(3, rank);  // end-of-read tests, key, exact rank
 
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
         const bool sel = valid && go && rank < beam_size;

@@ -34,6 +34,30 @@ __device__ __forceinline__ int32_t load_i32_l2(const int32_t *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Exact-rank building block: r_j += (k_j > key) for four comparands at once.  The compiler's own code for
+// `rank += (k > key)` funnels every compare through VCC (v_cmp -> s_nop -> v_cndmask / v_addc), one long
+// dependent chain; here the four compares land in four SGPR pairs and feed four independent accumulators,
+// so consecutive instructions never wait on each other (each consumer sits three instructions behind its
+// producer, which also covers the VALU-writes-SGPR -> VALU-reads-it wait states).
+// (tests/hipemu predefines FCD_RANK4 in plain C++.)
+#ifndef FCD_RANK4
+#define FCD_RANK4(key, ka, kb, kc, kd, r0, r1, r2, r3)                                         \
+    do {                                                                                       \
+        uint64_t m0__, m1__, m2__, m3__;                                                       \
+        asm("v_cmp_gt_u64_e64 %4, %9, %8\n\t"                                                  \
+            "v_cmp_gt_u64_e64 %5, %10, %8\n\t"                                                 \
+            "v_cmp_gt_u64_e64 %6, %11, %8\n\t"                                                 \
+            "v_cmp_gt_u64_e64 %7, %12, %8\n\t"                                                 \
+            "v_addc_co_u32_e64 %0, vcc, 0, %0, %4\n\t"                                         \
+            "v_addc_co_u32_e64 %1, vcc, 0, %1, %5\n\t"                                         \
+            "v_addc_co_u32_e64 %2, vcc, 0, %2, %6\n\t"                                         \
+            "v_addc_co_u32_e64 %3, vcc, 0, %3, %7"                                              \
+            : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "=&s"(m0__), "=&s"(m1__), "=&s"(m2__), "=&s"(m3__) \
+            : "v"(key), "v"(ka), "v"(kb), "v"(kc), "v"(kd)                                     \
+            : "vcc");                                                                          \
+    } while (0)
+#endif
+
 // Cycle stamp for the instrumented (PROF) kernel instantiations: reads the shader clock once every input
 // the stamped block produced (`dep`) has arrived, and makes `dep` opaque so that nothing consuming it is
 // scheduled above the stamp.  (tests/hipemu predefines FCD_STAMP as a no-op: there is no clock to read.)
