@@ -166,10 +166,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
     const float *post = p.in.post + r * p.in.stride_read;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
-    int2 *rec = p.arena.rec + (has_read ? local : 0) * p.arena.cap_nodes;
-    int32_t *jmp = p.arena.jmp + (has_read ? local : 0) * p.arena.cap_nodes;
-    int32_t *rows = p.arena.rows + (has_read ? local : 0) * p.arena.cap_nodes * RW;
+    // Arena addressing: a wave-uniform base (the slab of the wavefront's first read: scalar registers) plus a
+    // 32-bit element offset per lane (the second read's slab starts cap_nodes elements further on), so that
+    // every tree access is base + offset without 64-bit vector arithmetic.  Child rows are indexed by
+    // node + 1: the root (node -1) owns row 0 and needs no special case.
     const int cap = (int)p.arena.cap_nodes;
+    const int64_t wslab = ((int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wave)) * RPW;
+    int2 *const rec_w = p.arena.rec + wslab * p.arena.cap_nodes;
+    int32_t *const jmp_w = p.arena.jmp + wslab * p.arena.cap_nodes;
+    int32_t *const rows_w = p.arena.rows + wslab * p.arena.cap_nodes * RW;
+    const uint32_t hoff = has_read ? (uint32_t)(lane / HALF) * (uint32_t)cap : 0u;  // this half's slab, in nodes
+    int2 *rec = rec_w + hoff;      // (used by the traceback)
+    int32_t *jmp = jmp_w + hoff;
 
     // ---- beam state (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
     int node = -1;
@@ -245,8 +253,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const bool act = alive && t < T;
         // ---- the three row values this lane needs ----
         const int rbase = hbase + g * E + (S > 0 ? state * N : 0);
-        const float pr0 = GATHER ? rowv : bpermf(rbase, win[0]);
+        // one fetch serves both kinds of lane: column 0 (the blank) on a slot's own lane, the label's column on a child lane
         float pk = GATHER ? rowv : bpermf(rbase + (is_child ? k : 0), win[0]);
+        const float pr0 = pk;
         const float ptip = CRF ? 0.0f : bpermf(rbase + tip + 1, win[0]);
         stamp_f(0, pk);  // loop overhead + posterior row
         if (!GATHER && ++g == RPR) {
@@ -322,12 +331,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             pre_new = __builtin_popcount(w_new & ((1u << q) - 1u));
         }
         const int newid = nn + pre_new;
-        nn += n_new;
-        const bool f_cap = act && nn > cap;
-        if (is_new && !f_cap) {
-            rec[newid] = make_int2(node, (t << 3) | l);
+        nn += n_new;  // cannot pass cap: the host sizes every slab for T * beam * (N-1) nodes (capi.hip)
+        if (is_new) {
+            rec_w[hoff + (uint32_t)newid] = make_int2(node, (t << 3) | l);
             // a segment head (depth % 64 == 0) records where the next head up the tree is
-            if ((depth + 1) % kSeg == 0) jmp[newid] = (depth % kSeg == 0) ? node : jump;
+            if ((depth + 1) % kSeg == 0) jmp_w[hoff + (uint32_t)newid] = (depth % kSeg == 0) ? node : jump;
             child = newid;
         }
         int id = is_self ? node : (is_new ? newid : cid);
@@ -361,16 +369,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
                                      : __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
         // Everything that ends a read is rare: one wave-wide test, the bookkeeping behind it.
         const bool is_nan = valid && prob != prob;
-        if (ballot(act && (n_valid == 0 || f_cap || is_nan)) != 0ull) {
+        if (ballot(act && (n_valid == 0 || is_nan)) != 0ull) {
             const uint64_t m_nan = ballot(is_nan);
             const bool any_nan = RPW == 1 ? m_nan != 0ull
                                           : (hbase ? (uint32_t)(m_nan >> 32) : (uint32_t)m_nan) != 0u;
             const bool f_nan = act && n_valid >= 2 && any_nan;  // a lone NaN is never compared (:262)
             const bool f_empty = act && n_valid == 0;
-            if (f_nan || f_empty || f_cap) {
+            if (f_nan || f_empty) {
                 if (q == 0) {
-                    p.out.status[r] = f_cap ? FCD_ST_INTERNAL
-                                            : (f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
+                    p.out.status[r] = f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE;
                     p.out.out_len[r] = 0;
                 }
                 alive = false;
@@ -407,8 +414,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             // A node's child row only has to exist in HBM while the node is OUT of the beam (it is
             // read back if the node re-enters, below): write it once, when the node is evicted --
             // four lanes, 16 contiguous bytes -- instead of a scattered 4-byte store per created node.
-            if (upd && grp && own < 0 && node >= 0)
-                rows[(int64_t)node * RW + l] = child < 0 ? -1 : (child & kStored);
+            if (upd && grp && own < 0)
+                rows_w[(hoff + (uint32_t)(node + 1)) * RW + l] = child < 0 ? -1 : (child & kStored);
         }
 
         stamp_i(4, child);  // fate of every child entry, row eviction
@@ -438,7 +445,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up (rare path)
             int e = -1;
-            if (reload) e = load_i32_l2(&rows[(int64_t)n_node * RW + l]);
+            if (reload) e = load_i32_l2(&rows_w[(hoff + (uint32_t)(n_node + 1)) * RW + l]);
 #pragma unroll
             for (int j = 0; j < BCAP; ++j) {
                 const int nj = bperm(hbase + j * GW, n_node);
