@@ -182,7 +182,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // ---- beam state (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
     int node = -1;
     float lp = 0.0f, gp = 1.0f;
-    int tip = -1;
+    int tipf = 0;  // (tip label + 1) << 2, 0 for the root: the form meta carries, and the byte offset of the tip's column
     int depth = 0;
     int jump = -1;  // nearest proper ancestor of `node` at a depth that is a multiple of kSeg
     int child = -1;
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // one fetch serves both kinds of lane: column 0 (the blank) on a slot's own lane, the label's column on a child lane
         float pk = GATHER ? rowv : bpermf(rbase + (is_child ? k : 0), win[0]);
         const float pr0 = pk;
-        const float ptip = CRF ? 0.0f : bpermf(rbase + tip + 1, win[0]);
+        const float ptip = CRF ? 0.0f : __int_as_float(__builtin_amdgcn_ds_bpermute((rbase << 2) + tipf, __float_as_int(win[0])));
         stamp_f(0, pk);  // loop overhead + posterior row
         if (!GATHER && ++g == RPR) {
             g = 0;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
         // ---- child lanes: extension by label l (:200-239) ----
         const bool pass = !(pk < thr);  // :201 skips only when pr_b < thr
-        const bool rep = collapse && l == tip;
+        const bool rep = collapse && (k << 2) == tipf;  // l == tip
         const float contrib = rep ? gp * pk : (lp + gp) * pk;
         const bool exists = child >= 0;
         const int cid = child & kIdMask;
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // ---- self lanes: blank (:191-198) + repeat-stay (:206-211) + incoming extension ----
         const bool blank = pr0 > thr;
         const float gpn = (lp + gp) * pr0;
-        const bool stay = collapse && tip >= 0 && !(ptip < thr);
+        const bool stay = collapse && tipf != 0 && !(ptip < thr);
         const float lpn = lp * ptip;
         const bool has_inc = is_self && incv != 0;
         const float slp = (stay ? lpn : 0.0f) + (has_inc ? inc : 0.0f);
@@ -400,35 +400,40 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
         // ---- keep the IN-BEAM/slot bits of every child entry current ----
         // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
-        const int selrank = sel ? rank : -1;
-        const int fate = bperm(hbase + mslot * GW, selrank);
-        const int own = bperm(grp0, selrank);  // ... and this group's own candidate?
-        const bool first_entry = sel && is_child && !(child & kEver);  // child >= 0 here
+        // selflag = rank | 16 for a kept candidate, 0 otherwise: shifted to kSlotShift it IS the (slot, IN-BEAM)
+        // field of a child entry (kInBeam == 16 << kSlotShift), so following an entry needs no compare
+        static_assert(kInBeam == (16 << kSlotShift) && kSlotMask == 15, "child-entry bit layout");
+        const int selflag = sel ? (rank | 16) : 0;
+        const int fate = bperm(hbase + mslot * GW, selflag);
+        const int own = bperm(grp0, selflag);  // ... and this group's own candidate?
+        // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
+        // its row is in HBM); read off the entry BEFORE it is marked below
+        const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
         {
             // a child entry whose node is a beam entry follows it to its new slot (or learns it left);
             // a child entering the beam is marked EVER: from now on it may own children
-            const int followed = (child & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
-            const int entered = id | kEver | kInBeam | (rank << kSlotShift);
+            const int followed = (child & kStored) | (fate << kSlotShift);
+            const int entered = id | kEver | (selflag << kSlotShift);
             const bool upd = go && is_child;
             child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child);
             // A node's child row only has to exist in HBM while the node is OUT of the beam (it is
             // read back if the node re-enters, below): write it once, when the node is evicted --
             // four lanes, 16 contiguous bytes -- instead of a scattered 4-byte store per created node.
-            if (upd && grp && own < 0)
-                rows_w[(hoff + (uint32_t)(node + 1)) * RW + l] = child < 0 ? -1 : (child & kStored);
+            // (-1 keeps its sign bit: "no child" stays negative in the stored form)
+            if (upd && grp && own == 0)
+                rows_w[(hoff + (uint32_t)(node + 1)) * RW + l] = child & (kStored | (int)0x80000000);
         }
 
         stamp_i(4, child);  // fate of every child entry, row eviction
         // ---- gather the survivors into rank order ----
-        const int kind = is_self ? 0 : (first_entry ? 1 : 2);  // 2: re-entering, row is in HBM
         const int src0 = perm(sel ? hbase + rank * GW : dummy, lane);
         const int src = bperm(grp0, src0);  // every lane of new group s knows its source lane
-        const int tipc = is_self ? tip : l;
-        const int depc = is_self ? depth : depth + 1;
+        const int tipfc = is_self ? tipf : (k << 2);
+        const int depc = depth + (is_child ? 1 : 0);
         const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
                                              : state;  // :97
         const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
-        const int meta = kind | ((tipc + 1) << 2) | (depc << 5);
+        const int meta = kind | tipfc | (depc << 5);
         const int n_node = bperm(src, id);
         float n_lp = bpermf(src, clp);
         const float n_gp = bpermf(src, cgp);
@@ -461,7 +466,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             node = n_node;
             lp = n_lp / top;
             gp = n_gp / top;
-            tip = ((n_meta >> 2) & 7) - 1;
+            tipf = n_meta & 0x1C;
             depth = n_meta >> 5;
             jump = n_jump;
             child = n_child;
