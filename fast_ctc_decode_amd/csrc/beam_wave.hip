@@ -462,10 +462,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         if (CRF && go) state = n_state;  // < S: (s*4) % 4 + l = l for (N, S) = (5, 4); masked when GATHER
         if (GATHER) rowv = gather_row(t + 1);  // in flight during the divisions below
         const float top = bpermf(hbase, n_lp + n_gp);  // beam[0].probability() :278
+        // Every lane of a group would compute the same two IEEE quotients: lane k = 1 divides the gap
+        // probability, the others the label probability -- one division per lane -- and the group shares them.
+        const float quot = (k == 1 ? n_gp : n_lp) / top;
+        const float q_lp = bpermf(grp0, quot), q_gp = bpermf(grp0 + 1, quot);
         if (go) {
             node = n_node;
-            lp = n_lp / top;
-            gp = n_gp / top;
+            lp = q_lp;
+            gp = q_gp;
             tipf = n_meta & 0x1C;
             depth = n_meta >> 5;
             jump = n_jump;
