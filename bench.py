@@ -122,6 +122,35 @@ def pmc_traffic(kernel_prefix):
     return None, None
 
 
+def valu_issue_roofline(kernel_prefix, kernel_ms, n_simd, clock_hz=2.4e9):
+    """The bound the beam kernel actually runs against: VALU instruction issue.  achieved = wavefront-level
+    VALU instructions per launch (SQ_INSTS_VALU from the newest committed profiles/*_sq_counters.json of
+    this kernel at this shape: tools/profile_sq.sh, rocprofv3 --pmc in its own passes) / the kernel duration
+    measured here; peak = one wave64 VALU instruction per SIMD every 2 cycles (SIMD-32,
+    MI355X_MICROARCH.md 'v_fma_f32 (wave64): 2 cyc') x SIMDs x 2.4 GHz."""
+    import glob
+    for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))):
+        with open(path) as f:
+            d = json.load(f)
+        if kernel_prefix in (d.get("kernel") or "") and "SQ_INSTS_VALU" in d.get("counters_per_launch", {}):
+            insts = d["counters_per_launch"]["SQ_INSTS_VALU"]
+            per_step = d.get("per_wave_step", {})
+            achieved = insts / (kernel_ms * 1e-3)
+            peak = n_simd * clock_hz / 2.0
+            return {
+                "bound": "valu_issue", "achieved": achieved, "peak": peak, "unit": "wave64 VALU instructions/s",
+                "frac": achieved / peak,
+                "source": "%s: SQ_INSTS_VALU %.4g per launch (%s)" % (os.path.basename(path), insts, d.get("workload", "")),
+                "per_wavefront_step": {k: round(per_step[k], 1) for k in
+                                       ("SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES",
+                                        "SQ_ACTIVE_INST_ANY", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY") if k in per_step},
+                "note": "at 4096 reads only 2 wavefronts share a SIMD: the step time is the wavefront's own dependent "
+                        "instruction chain (a lone wavefront per SIMD takes ~87 % as long per step), so the fraction "
+                        "rises with the batch (profiles/r02*_cycle_account.jsonl, DESIGN.md 4.1)",
+            }
+    return None
+
+
 def viterbi_roofline(fcd, torch, dev, n_reads=16384, reps=5):
     """The HBM-bound kernel of the path: viterbi_search on n_reads x T x N,
     timed with the C ABI's HIP events."""
@@ -278,7 +307,16 @@ def main():
         props = torch.cuda.get_device_properties(dev)
         simds = props.multi_processor_count * 4
         rpw = 2 if args.kernel in (0, 2) else 1
+        # outside the timed region: the tie instrument on the same batch (include/fcd.h)
+        amb = fcd.beam_search_batch_raw(x, BEAM, THR, True, count_ambiguous=True).cpu().ambiguous
+        ties = {"reads_with_gt20_candidate_kept_tie": int((amb[:, 0] > 0).sum()),
+                "reads_with_result_changing_tie": int((amb[:, 1] > 0).sum()),
+                "reads_with_both": int(((amb[:, 0] > 0) & (amb[:, 1] > 0)).sum()),
+                "note": "a read with either counter at 0 is pinned to the reference; the others are settled by the "
+                        "oracle's exhaustive tie replay (tests/test_gpu_fullsize.py::test_config2_tie_instrument)"}
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
+        valu = valu_issue_roofline("beam_wave_kernel<5, 6, 2, 0", k_ms, simds) \
+            if (args.kernel in (0, 2) and args.batch == 4096 and args.data == "reference") else None
         out = {
             "metric": "reads/s (T=4000, N=5, beam=5)",
             "value": world * B * args.steps / elapsed,
@@ -304,6 +342,7 @@ def main():
                 "kernel": {0: "auto (wave, two reads per wavefront)", 1: "generic-lds",
                            2: "wave-registers-2reads", 3: "wave-registers-1read"}[args.kernel],
                 "reads_ok": ok, "mean_labels_per_read": mean_L, "streams": n_streams,
+                "tie_instrument": ties,
             },
             "roofline": {
                 "bound": "hbm",
@@ -316,16 +355,13 @@ def main():
                 "kernel": "beam search kernel, %.3f ms per launch (HIP events), %d reads x %.0f "
                           "algorithmic B/read" % (k_ms, B, bytes_per_read),
                 "kernel_ms": k_ms, "launches_timed": k_calls,
-                # SURVEY.md 8d's honest secondary bound: a read advances one timestep per step latency,
-                # so reads/s <= resident reads / (T x step latency); the search is a serial chain of T
-                # dependent steps per read and is bound by instruction issue, not by HBM.
-                "secondary_bound": {
-                    "kind": "reads/s <= resident_reads / (T * step_latency)",
-                    "resident_reads": B,
-                    "wavefronts_per_simd": B / rpw / simds,
-                    "step_latency_us": k_ms * 1e3 / T,
-                    "reads_per_s_at_this_latency": B / (k_ms * 1e-3),
-                },
+                # The search is a serial chain of T dependent steps per read: it is bound by instruction
+                # issue, not by HBM (SURVEY.md finding 5) -- priced here against the VALU issue peak.
+                "secondary_bound": valu if valu is not None else {
+                    "bound": "valu_issue", "achieved": None, "peak": simds * 2.4e9 / 2.0,
+                    "note": "no SQ counter summary of this kernel / shape under profiles/"},
+                "wavefronts_per_simd": B / rpw / simds,
+                "step_latency_us": k_ms * 1e3 / T,
             },
             "cpu_baseline": cpu,
             "viterbi_roofline": vit,
