@@ -67,6 +67,12 @@ constexpr float kNegInf = -__builtin_huge_valf();
 
 __device__ __forceinline__ float ln_cr(float x) { return (float)log((double)x); }
 
+// The slow paths of LogSpace::add -- the library routines, taken for ~1e-6 of the arguments -- stay out of
+// line: inlined into the window-building loop they cost it ~160 scalar-register spills and a third of its
+// instructions, every iteration, for code that almost never runs.
+__device__ __attribute__((noinline)) float exp_slow_f32(float x) { return (float)exp((double)x); }
+__device__ __attribute__((noinline)) float log1p_slow_f32(float e) { return (float)log1p((double)e); }
+
 template <int MODE>
 __device__ __forceinline__ float ladd(float a, float b) {
     // duplex.rs:42-63: operands ordered so that a NaN ends up in `big`
@@ -91,11 +97,11 @@ __device__ __forceinline__ float ladd(float a, float b) {
     if (x < kExpFastMin && __builtin_fabsf(big) >= 8.0779356694631609e-28f) return big;
     const double ye = exp_fast((double)x);
     float e = (float)ye;
-    if (!(x >= kExpFastMin) || round_to_f32_unsafe(ye)) e = (float)exp((double)x);
+    if (!(x >= kExpFastMin) || round_to_f32_unsafe(ye)) e = exp_slow_f32(x);
     if (e < kLog1pIdentityBelow) return big + e;      // ln_1p(e) rounds to e below 2^-24
     const double yl = log1p_fast((double)e);
     float l = (float)yl;
-    if (round_to_f32_unsafe(yl)) l = (float)log1p((double)e);
+    if (round_to_f32_unsafe(yl)) l = log1p_slow_f32(e);
     return big + l;
 }
 

@@ -35,45 +35,48 @@ FCD_HD bool round_to_f32_unsafe(double y) {
 }
 
 // exp(x), x in [-86, 0]: x = k ln2 + r, |r| <= 0.3466, Taylor polynomial of degree 11 (truncation
-// < 2^-47 relative), scaled by 2^k.
+// < 2^-47 relative), scaled by 2^k.  The polynomial is evaluated by Estrin's scheme: the searches run one
+// wavefront per SIMD, where the DEPENDENT chain of a log-add is what a window row costs -- five levels of
+// independent fused multiply-adds instead of eleven in a row (same operation count).
 FCD_HD double exp_fast(double x) {
     const double k = rint(x * 1.4426950408889634074);
     double r = fma(k, -6.93147180369123816490e-01, x);  // ln2 split as in fdlibm: hi has 21 trailing zeros
     r = fma(k, -1.90821492927058770002e-10, r);
-    double p = 1.0 / 39916800.0;
-    p = fma(p, r, 1.0 / 3628800.0);
-    p = fma(p, r, 1.0 / 362880.0);
-    p = fma(p, r, 1.0 / 40320.0);
-    p = fma(p, r, 1.0 / 5040.0);
-    p = fma(p, r, 1.0 / 720.0);
-    p = fma(p, r, 1.0 / 120.0);
-    p = fma(p, r, 1.0 / 24.0);
-    p = fma(p, r, 1.0 / 6.0);
-    p = fma(p, r, 0.5);
-    p = fma(p, r, 1.0);
-    p = fma(p, r, 1.0);
+    const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
+    const double p01 = 1.0 + r;                                   // c0 + c1 r
+    const double p23 = fma(1.0 / 6.0, r, 0.5);                    // c2 + c3 r
+    const double p45 = fma(1.0 / 120.0, r, 1.0 / 24.0);
+    const double p67 = fma(1.0 / 5040.0, r, 1.0 / 720.0);
+    const double p89 = fma(1.0 / 362880.0, r, 1.0 / 40320.0);
+    const double pab = fma(1.0 / 39916800.0, r, 1.0 / 3628800.0);
+    const double q03 = fma(p23, r2, p01);
+    const double q47 = fma(p67, r2, p45);
+    const double q8b = fma(pab, r2, p89);
+    const double h07 = fma(q47, r4, q03);
+    const double p = fma(q8b, r8, h07);
     return ldexp(p, (int)k);
 }
 
-// ln_1p(e) = 2 atanh(s), s = e / (2 + e) in (0, 1/3]: odd series through s^29 (truncation < 2^-52 relative).
+// ln_1p(e) = 2 atanh(s), s = e / (2 + e) in (0, 1/3]: odd series through s^29 (truncation < 2^-52 relative),
+// Estrin's scheme in z = s^2 (fifteen coefficients: four levels).
 FCD_HD double log1p_fast(double e) {
     const double s = e / (2.0 + e);
-    const double z = s * s;
-    double p = 1.0 / 29.0;
-    p = fma(p, z, 1.0 / 27.0);
-    p = fma(p, z, 1.0 / 25.0);
-    p = fma(p, z, 1.0 / 23.0);
-    p = fma(p, z, 1.0 / 21.0);
-    p = fma(p, z, 1.0 / 19.0);
-    p = fma(p, z, 1.0 / 17.0);
-    p = fma(p, z, 1.0 / 15.0);
-    p = fma(p, z, 1.0 / 13.0);
-    p = fma(p, z, 1.0 / 11.0);
-    p = fma(p, z, 1.0 / 9.0);
-    p = fma(p, z, 1.0 / 7.0);
-    p = fma(p, z, 1.0 / 5.0);
-    p = fma(p, z, 1.0 / 3.0);
-    p = fma(p, z, 1.0);
+    const double z = s * s, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
+    const double a0 = fma(1.0 / 3.0, z, 1.0);
+    const double a1 = fma(1.0 / 7.0, z, 1.0 / 5.0);
+    const double a2 = fma(1.0 / 11.0, z, 1.0 / 9.0);
+    const double a3 = fma(1.0 / 15.0, z, 1.0 / 13.0);
+    const double a4 = fma(1.0 / 19.0, z, 1.0 / 17.0);
+    const double a5 = fma(1.0 / 23.0, z, 1.0 / 21.0);
+    const double a6 = fma(1.0 / 27.0, z, 1.0 / 25.0);
+    const double a7 = 1.0 / 29.0;
+    const double b0 = fma(a1, z2, a0);
+    const double b1 = fma(a3, z2, a2);
+    const double b2 = fma(a5, z2, a4);
+    const double b3 = fma(a7, z2, a6);
+    const double c0 = fma(b1, z4, b0);
+    const double c1 = fma(b3, z4, b2);
+    const double p = fma(c1, z8, c0);
     return (2.0 * s) * p;
 }
 
