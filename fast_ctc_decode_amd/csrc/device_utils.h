@@ -58,6 +58,12 @@ __device__ __forceinline__ int32_t load_i32_l2(const int32_t *p) {
     } while (0)
 #endif
 
+// Makes a value opaque to the optimiser and pins it in vector registers (the duplex kernel's coefficient table).
+// (tests/hipemu predefines FCD_OPAQUE_V as a no-op.)
+#ifndef FCD_OPAQUE_V
+#define FCD_OPAQUE_V(x) asm volatile("" : "+v"(x))
+#endif
+
 // Cycle stamp for the instrumented (PROF) kernel instantiations: reads the shader clock once every input
 // the stamped block produced (`dep`) has arrived, and makes `dep` opaque so that nothing consuming it is
 // scheduled above the stamp.  (tests/hipemu predefines FCD_STAMP as a no-op: there is no clock to read.)

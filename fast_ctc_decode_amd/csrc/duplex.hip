@@ -74,7 +74,7 @@ __device__ __attribute__((noinline)) float exp_slow_f32(float x) { return (float
 __device__ __attribute__((noinline)) float log1p_slow_f32(float e) { return (float)log1p((double)e); }
 
 template <int MODE>
-__device__ __forceinline__ float ladd(float a, float b) {
+__device__ __forceinline__ float ladd(float a, float b, const LogAddCoef &K) {
     // duplex.rs:42-63: operands ordered so that a NaN ends up in `big`
     float big, small;
     if (a <= b) {
@@ -95,14 +95,47 @@ __device__ __forceinline__ float ladd(float a, float b) {
     // x < -86: e = exp(x) <= 4.5e-38 and ln_1p(e) = e; adding it to a `big` of magnitude >= 2^-90
     // (half a unit in the last place >= 2^-115) cannot change `big`
     if (x < kExpFastMin && __builtin_fabsf(big) >= 8.0779356694631609e-28f) return big;
-    const double ye = exp_fast((double)x);
+    const double ye = exp_fast((double)x, K);
     float e = (float)ye;
     if (!(x >= kExpFastMin) || round_to_f32_unsafe(ye)) e = exp_slow_f32(x);
     if (e < kLog1pIdentityBelow) return big + e;      // ln_1p(e) rounds to e below 2^-24
-    const double yl = log1p_fast((double)e);
+    const double yl = log1p_fast((double)e, K);
     float l = (float)yl;
     if (round_to_f32_unsafe(yl)) l = log1p_slow_f32(e);
     return big + l;
+}
+
+template <int MODE>
+__device__ __forceinline__ float ladd(float a, float b) { return ladd<MODE>(a, b, logadd_coef()); }
+
+// The same function for the window-building loop, where every lane of the wavefront calls it in lockstep: the
+// shortcuts become selects, and ONE wave-wide test skips the transcendental part when no lane needs it (rows
+// far from the alignment, where exp(small - big) is 0 for every new node) -- instead of a nest of
+// exec-mask branches per row.  Operation for operation the values are those of ladd().
+template <int MODE>
+__device__ __forceinline__ float ladd_lockstep(float a, float b, const LogAddCoef &K) {
+    const bool ab = a <= b;
+    const float big = ab ? b : a, small = ab ? a : b;  // a NaN ends up in `big` or makes x NaN
+    if (MODE == FCD_LOGADD_MAX) return small == kNegInf ? big : big + 0.0f;
+    const float x = small - big;  // <= 0, or NaN
+    const bool sc_inf = small == kNegInf;                                                   // -> big
+    const bool sc_zero = x < kExpZeroBelow;                                                 // -> big + 0
+    const bool sc_tiny = x < kExpFastMin && __builtin_fabsf(big) >= 8.0779356694631609e-28f;  // -> big
+    const bool full = !(sc_inf || sc_zero || sc_tiny);  // (a NaN fails every test and takes the full path)
+    float res = (!sc_inf && sc_zero) ? big + 0.0f : big;
+    if (ballot(full) != 0ull) {
+        const float xs = full ? x : -1.0f;  // lanes that do not need it still run the arithmetic, on a tame argument
+        const double ye = exp_fast((double)xs, K);
+        float e = (float)ye;
+        if (!(xs >= kExpFastMin) || round_to_f32_unsafe(ye)) e = exp_slow_f32(xs);
+        const bool ident = e < kLog1pIdentityBelow;  // ln_1p(e) rounds to e below 2^-24
+        const float es = ident ? 0.5f : e;
+        const double yl = log1p_fast((double)es, K);
+        float l = (float)yl;
+        if (round_to_f32_unsafe(yl)) l = log1p_slow_f32(es);
+        res = full ? big + (ident ? e : l) : res;
+    }
+    return res;
 }
 
 __device__ __forceinline__ float lmax(float self, float other) { return self < other ? other : self; }
@@ -191,8 +224,11 @@ __device__ __forceinline__ void vec_get(const VecRef &v, int at, int Wcap, float
     sum = load_f32_l2(v.base + 3 * slot + 2);
 }
 
-template <int MODE>
-__global__ __launch_bounds__(64, 3) void duplex_kernel(DuplexParams p) {
+// PIN: the log-add coefficients stay in vector registers across the window-building loop (60 registers: the
+// instantiation for batches that leave a wavefront alone on its SIMD, where a row's instruction count is
+// what the loop costs); without it the kernel fits three wavefronts per SIMD, which wins once the GPU is full.
+template <int MODE, bool PIN>
+__global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
     const int lane = threadIdx.x;
     const int64_t local = blockIdx.x;
@@ -667,6 +703,61 @@ __global__ __launch_bounds__(64, 3) void duplex_kernel(DuplexParams p) {
                 float lb = kNegInf;   // A: label_{t-1};  B: label_{t'} received from A
                 float sm = kNegInf;   // B: sum_{t'-1}
                 float mx = kNegInf;
+                if (staged) {
+                    LogAddCoef K = logadd_coef();
+                    if (PIN) {
+                        FCD_OPAQUE_V(K.log2e); FCD_OPAQUE_V(K.ln2hi); FCD_OPAQUE_V(K.ln2lo); FCD_OPAQUE_V(K.two);
+#pragma unroll
+                        for (int u = 0; u < 12; ++u) FCD_OPAQUE_V(K.e[u]);
+#pragma unroll
+                        for (int u = 0; u < 15; ++u) FCD_OPAQUE_V(K.a[u]);
+                    }
+                    // The loop every new node runs W + 1 times -- 80 % of the kernel in logsumexp mode -- kept lean:
+                    // operands of the NEXT row are requested before this row's log-add, ring slots and tile
+                    // addresses advance incrementally, and label_t reaches the odd lane through a DPP move
+                    // (lane pairs are adjacent) instead of an LDS round trip.
+                    const float *wq = L.w2 + q_state * N + (isA ? q_l + 1 : 0);          // + row * S * N
+                    const float *xq = L.pw + (size_t)q_i * Wmax * 2 + (q_rep ? 0 : 1);   // + row * 2   (even lane only)
+                    const int rstep = S * N;
+                    int jn = isA ? 0 : -1;                      // the row this lane handles in the coming iteration
+                    int slot3 = 3 * ((lo + Wcap + jn) % Wcap);  // 3 * ((lo + jn) mod Wcap)
+                    float c_cur = 0.0f, x_cur = kNegInf;
+                    if (isA) {
+                        c_cur = wq[0];
+                        x_cur = xq[0];
+                    }
+                    for (int sidx = 0; sidx <= W; ++sidx) {
+                        // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
+                        const int j = jn;
+                        const bool on = work && j >= 0 && j < W;
+                        // next row's operands (clamped to the tile: the value is unused past the last row)
+                        const int jr = j + 1 < W ? j + 1 : W - 1;
+                        const float c_nxt = wq[jr * rstep];
+                        const float x_nxt = isA ? xq[jr * 2] : kNegInf;
+                        const float a = on ? lb : kNegInf;
+                        const float bb = on ? (isA ? x_cur : sm + c_cur) : kNegInf;   // A: X_{t-1};  B: gap_{t'}
+                        const float v = ladd_lockstep<MODE>(a, bb, K);
+                        float lb_out = lb;
+                        if (on) {
+                            if (isA) {
+                                lb_out = c_cur + v;  // label_t
+                                my[slot3] = lb_out;
+                            } else {
+                                my[slot3 + 1] = bb;   // gap_{t'}
+                                my[slot3 + 2] = v;    // sum_{t'}
+                                sm = v;
+                                mx = lmax(mx, v);
+                            }
+                        }
+                        // hand label_t to the odd lane for the next iteration; the even lane keeps it
+                        lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
+                                                                        0xf, 0xf, false));
+                        c_cur = c_nxt;
+                        x_cur = x_nxt;
+                        ++jn;
+                        slot3 = slot3 + 3 == 3 * Wcap ? 0 : slot3 + 3;
+                    }
+                } else {
                 for (int sidx = 0; sidx <= W; ++sidx) {
                     // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
                     const int j = isA ? sidx : sidx - 1;
@@ -675,19 +766,13 @@ __global__ __launch_bounds__(64, 3) void duplex_kernel(DuplexParams p) {
                     if (on) {
                         if (isA) {
                             float pg, ps, rl1;
-                            if (staged) {
-                                rl1 = L.w2[(j * S + q_state) * N + q_l + 1];
-                                pg = L.pw[((size_t)q_i * Wmax + j) * 2];
-                                ps = L.pw[((size_t)q_i * Wmax + j) * 2 + 1];
-                            } else {
-                                rl1 = ln2[((int64_t)(lo + j) * S + q_state) * N + q_l + 1];
-                                vec_get(pv, lo + j - 1, Wcap, pg, ps);
-                            }
+                            rl1 = ln2[((int64_t)(lo + j) * S + q_state) * N + q_l + 1];
+                            vec_get(pv, lo + j - 1, Wcap, pg, ps);
                             a = lb;
                             bb = q_rep ? pg : ps;
                             add_after = rl1;
                         } else {
-                            r0 = staged ? L.w2[(j * S + q_state) * N] : ln2[((int64_t)(lo + j) * S + q_state) * N];
+                            r0 = ln2[((int64_t)(lo + j) * S + q_state) * N];
                             a = lb;          // label_{t'} from the even lane
                             bb = sm + r0;    // gap_{t'}
                         }
@@ -709,6 +794,7 @@ __global__ __launch_bounds__(64, 3) void duplex_kernel(DuplexParams p) {
                     // hand label_t to the odd lane for the next iteration; the even lane keeps it
                     const float from_even = __shfl(lb_out, lane & ~1);
                     lb = isA ? lb_out : from_even;
+                }
                 }
                 if (work && !isA) {
                     meta[q_cid] = make_int4(q_node, q_l, lo, hi);
@@ -907,11 +993,16 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     p.n_init2 = a.n_init2; p.init1_stride = a.init1_stride; p.init2_stride = a.init2_stride;
     p.pair_begin = pair_begin;
     const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S);
+    // up to two wavefronts per SIMD (2048 pairs on the 256 CUs): the coefficient-pinning instantiation
+    const bool pin = a.staged && n_pairs <= 2048;
     if (a.mode == FCD_LOGADD_MAX)
-        hipLaunchKernelGGL(duplex_kernel<FCD_LOGADD_MAX>, dim3((unsigned)n_pairs), dim3(64), lds,
+        hipLaunchKernelGGL((duplex_kernel<FCD_LOGADD_MAX, false>), dim3((unsigned)n_pairs), dim3(64), lds,
                            stream, p);
+    else if (pin)
+        hipLaunchKernelGGL((duplex_kernel<FCD_LOGADD_LOGSUMEXP, true>), dim3((unsigned)n_pairs), dim3(64),
+                           lds, stream, p);
     else
-        hipLaunchKernelGGL(duplex_kernel<FCD_LOGADD_LOGSUMEXP>, dim3((unsigned)n_pairs), dim3(64),
+        hipLaunchKernelGGL((duplex_kernel<FCD_LOGADD_LOGSUMEXP, false>), dim3((unsigned)n_pairs), dim3(64),
                            lds, stream, p);
     return hipGetLastError();
 }

@@ -34,21 +34,43 @@ FCD_HD bool round_to_f32_unsafe(double y) {
     return (uint32_t)(dropped - (0x10000000u - 512u)) < 1024u;
 }
 
+// The coefficients as a value: the window-building loop of the duplex kernel keeps them in vector registers
+// for its whole run (made opaque there, so the compiler neither re-materialises 64-bit literals through scalar
+// registers on every row nor spills scalars to make room for them).
+struct LogAddCoef {
+    double log2e, ln2hi, ln2lo;
+    double e[12];   // 1/k!,  k = 0..11
+    double a[15];   // 1/(2k+1), k = 0..14
+    double two;
+};
+
+FCD_HD LogAddCoef logadd_coef() {
+    LogAddCoef c;
+    c.log2e = 1.4426950408889634074;
+    c.ln2hi = -6.93147180369123816490e-01;  // ln2 split as in fdlibm: hi has 21 trailing zeros
+    c.ln2lo = -1.90821492927058770002e-10;
+    c.e[0] = 1.0; c.e[1] = 1.0; c.e[2] = 0.5; c.e[3] = 1.0 / 6.0; c.e[4] = 1.0 / 24.0; c.e[5] = 1.0 / 120.0;
+    c.e[6] = 1.0 / 720.0; c.e[7] = 1.0 / 5040.0; c.e[8] = 1.0 / 40320.0; c.e[9] = 1.0 / 362880.0;
+    c.e[10] = 1.0 / 3628800.0; c.e[11] = 1.0 / 39916800.0;
+    for (int k = 0; k < 15; ++k) c.a[k] = 1.0 / (double)(2 * k + 1);
+    c.two = 2.0;
+    return c;
+}
+
 // exp(x), x in [-86, 0]: x = k ln2 + r, |r| <= 0.3466, Taylor polynomial of degree 11 (truncation
-// < 2^-47 relative), scaled by 2^k.  The polynomial is evaluated by Estrin's scheme: the searches run one
-// wavefront per SIMD, where the DEPENDENT chain of a log-add is what a window row costs -- five levels of
+// < 2^-47 relative), scaled by 2^k.  The polynomial is evaluated by Estrin's scheme: five levels of
 // independent fused multiply-adds instead of eleven in a row (same operation count).
-FCD_HD double exp_fast(double x) {
-    const double k = rint(x * 1.4426950408889634074);
-    double r = fma(k, -6.93147180369123816490e-01, x);  // ln2 split as in fdlibm: hi has 21 trailing zeros
-    r = fma(k, -1.90821492927058770002e-10, r);
+FCD_HD double exp_fast(double x, const LogAddCoef &c) {
+    const double k = rint(x * c.log2e);
+    double r = fma(k, c.ln2hi, x);
+    r = fma(k, c.ln2lo, r);
     const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
-    const double p01 = 1.0 + r;                                   // c0 + c1 r
-    const double p23 = fma(1.0 / 6.0, r, 0.5);                    // c2 + c3 r
-    const double p45 = fma(1.0 / 120.0, r, 1.0 / 24.0);
-    const double p67 = fma(1.0 / 5040.0, r, 1.0 / 720.0);
-    const double p89 = fma(1.0 / 362880.0, r, 1.0 / 40320.0);
-    const double pab = fma(1.0 / 39916800.0, r, 1.0 / 3628800.0);
+    const double p01 = c.e[0] + r;                 // c0 + c1 r
+    const double p23 = fma(c.e[3], r, c.e[2]);     // c2 + c3 r
+    const double p45 = fma(c.e[5], r, c.e[4]);
+    const double p67 = fma(c.e[7], r, c.e[6]);
+    const double p89 = fma(c.e[9], r, c.e[8]);
+    const double pab = fma(c.e[11], r, c.e[10]);
     const double q03 = fma(p23, r2, p01);
     const double q47 = fma(p67, r2, p45);
     const double q8b = fma(pab, r2, p89);
@@ -56,20 +78,21 @@ FCD_HD double exp_fast(double x) {
     const double p = fma(q8b, r8, h07);
     return ldexp(p, (int)k);
 }
+FCD_HD double exp_fast(double x) { return exp_fast(x, logadd_coef()); }
 
 // ln_1p(e) = 2 atanh(s), s = e / (2 + e) in (0, 1/3]: odd series through s^29 (truncation < 2^-52 relative),
 // Estrin's scheme in z = s^2 (fifteen coefficients: four levels).
-FCD_HD double log1p_fast(double e) {
-    const double s = e / (2.0 + e);
+FCD_HD double log1p_fast(double e, const LogAddCoef &c) {
+    const double s = e / (c.two + e);
     const double z = s * s, z2 = z * z, z4 = z2 * z2, z8 = z4 * z4;
-    const double a0 = fma(1.0 / 3.0, z, 1.0);
-    const double a1 = fma(1.0 / 7.0, z, 1.0 / 5.0);
-    const double a2 = fma(1.0 / 11.0, z, 1.0 / 9.0);
-    const double a3 = fma(1.0 / 15.0, z, 1.0 / 13.0);
-    const double a4 = fma(1.0 / 19.0, z, 1.0 / 17.0);
-    const double a5 = fma(1.0 / 23.0, z, 1.0 / 21.0);
-    const double a6 = fma(1.0 / 27.0, z, 1.0 / 25.0);
-    const double a7 = 1.0 / 29.0;
+    const double a0 = fma(c.a[1], z, c.a[0]);
+    const double a1 = fma(c.a[3], z, c.a[2]);
+    const double a2 = fma(c.a[5], z, c.a[4]);
+    const double a3 = fma(c.a[7], z, c.a[6]);
+    const double a4 = fma(c.a[9], z, c.a[8]);
+    const double a5 = fma(c.a[11], z, c.a[10]);
+    const double a6 = fma(c.a[13], z, c.a[12]);
+    const double a7 = c.a[14];
     const double b0 = fma(a1, z2, a0);
     const double b1 = fma(a3, z2, a2);
     const double b2 = fma(a5, z2, a4);
@@ -77,8 +100,9 @@ FCD_HD double log1p_fast(double e) {
     const double c0 = fma(b1, z4, b0);
     const double c1 = fma(b3, z4, b2);
     const double p = fma(c1, z8, c0);
-    return (2.0 * s) * p;
+    return (c.two * s) * p;
 }
+FCD_HD double log1p_fast(double e) { return log1p_fast(e, logadd_coef()); }
 
 constexpr float kExpFastMin = -86.0f;           // below: exp's f32 result may be subnormal
 constexpr float kExpZeroBelow = -104.0f;        // below: exp rounds to +0 (2^-150 = e^-103.97)

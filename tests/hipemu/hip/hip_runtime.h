@@ -19,6 +19,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#define FCD_OPAQUE_V(x) ((void)0)        // csrc/device_utils.h: register pinning of the duplex coefficient table
 #define FCD_STAMP(t64, dep) ((t64) = 0)  // csrc/device_utils.h: cycle stamps of the PROF instantiations
 // csrc/device_utils.h: four compare-and-count steps (hand-scheduled VALU on the GPU)
 #define FCD_RANK4(key, ka, kb, kc, kd, r0, r1, r2, r3) \
