@@ -37,12 +37,19 @@ def _as_f32(a, ndim, name):
     return a
 
 
+def _usize(v, name):
+    """PyO3's extraction of a `usize` argument: it happens before the function body, i.e. before every check
+    of src/lib.rs -- a negative int is an OverflowError, anything but an int a TypeError."""
+    if isinstance(v, bool) or not isinstance(v, (int, np.integer)):
+        raise TypeError("argument '%s': expected an integer" % name)
+    if v < 0:
+        raise OverflowError("can't convert negative int to unsigned")
+    return int(v)
+
+
 def _check_beam_args(n_alpha, inner, beam_size, thr):
     """src/lib.rs:331-349 -- the order of these checks is part of the behaviour."""
-    if isinstance(beam_size, bool) or not isinstance(beam_size, (int, np.integer)):
-        raise TypeError("argument 'beam_size': expected an integer")
-    if beam_size < 0:
-        raise OverflowError("can't convert negative int to unsigned")
+    _usize(beam_size, "beam_size")
     f32 = np.float32
     max_beam_cut = f32(1.0) / f32(n_alpha) if n_alpha else f32(np.inf)
     if n_alpha != inner:
@@ -175,6 +182,7 @@ def crf_beam_search(network_output, init_state, alphabet, beam_size=5, beam_cut_
     """Mirrors src/lib.rs:252-286 -> search.rs:38-157 (this wrapper validates only the alphabet)."""
     x = _as_f32(network_output, 3, "network_output")
     init = _as_f32(init_state, 1, "init_state")
+    beam_size = _usize(beam_size, "beam_size")
     alpha = _seq_to_vec(alphabet)
     _check_greedy_alphabet(len(alpha), x.shape[2])
     if x.size == 0 or init.size == 0:
@@ -265,6 +273,11 @@ def set_duplex_logadd_mode(mode):
     _DEFAULT_LOGADD[0] = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX,
                           nat.LOGADD_LOGSUMEXP: nat.LOGADD_LOGSUMEXP,
                           nat.LOGADD_MAX: nat.LOGADD_MAX}[mode]
+
+
+import os as _os
+if _os.environ.get("FCD_DUPLEX_LOGADD"):   # the same switch the compiled module reads at import
+    set_duplex_logadd_mode(_os.environ["FCD_DUPLEX_LOGADD"])
 
 
 def _check_envelope(envelope, T1):

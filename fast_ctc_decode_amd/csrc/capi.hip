@@ -21,6 +21,24 @@ namespace {
         }                                                                         \
     } while (0)
 
+// Binds the calling thread to the handle's device for the duration of an entry point and puts the previous
+// device back afterwards: a caller that works on several GPUs (torch) must not find its current device changed.
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err;
+    explicit DeviceGuard(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        err = prev == dev ? hipSuccess : hipSetDevice(dev);
+        if (prev == dev) prev = -1;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+#define FCD_DEVICE(h)                \
+    DeviceGuard dev_guard__((h)->device); \
+    FCD_HIP(h, dev_guard__.err)
+
 int fail(fcd_handle *h, int code, const char *msg) {
     if (h) h->err = msg;
     return code;
@@ -29,7 +47,10 @@ int fail(fcd_handle *h, int code, const char *msg) {
 int ensure(fcd_handle *h, void **buf, size_t *have, size_t need) {
     if (*have >= need) return FCD_OK;
     if (*buf) {
+        // work enqueued earlier -- on the current stream or on one set before the last fcd_set_stream -- may
+        // still use the buffer: hipFree waits for the whole device, but be explicit about both streams
         FCD_HIP(h, hipStreamSynchronize(h->stream));
+        if (h->own_stream && h->own_stream != h->stream) FCD_HIP(h, hipStreamSynchronize(h->own_stream));
         FCD_HIP(h, hipFree(*buf));
         *buf = nullptr;
         *have = 0;
@@ -122,7 +143,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     if (a.beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
     if (in->N < 2) return fail(h, FCD_E_UNSUPPORTED, "alphabet needs at least one label besides the blank");
     if (in->n_reads == 0) return FCD_OK;
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
 
     const BatchDesc d = to_desc(in, crf);
     const ResultDesc o = to_desc(out);
@@ -266,22 +287,22 @@ int fcd_destroy(fcd_handle *h) {
 
 int fcd_set_stream(fcd_handle *h, void *hip_stream) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     h->stream = reinterpret_cast<hipStream_t>(hip_stream);  // nullptr is the HIP null stream
     return FCD_OK;
 }
 
 int fcd_reset_stream(fcd_handle *h) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     h->stream = h->own_stream;
     return FCD_OK;
 }
 
 int fcd_synchronize(fcd_handle *h) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
-    FCD_HIP(h, hipSetDevice(h->device));
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    FCD_DEVICE(h);
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
 }
@@ -302,14 +323,14 @@ const char *fcd_status_string(int status) {
 
 int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
     if (!h || bytes < 0) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     h->ws_limit = bytes;
     return FCD_OK;
 }
 
 double fcd_last_kernel_ms(fcd_handle *h) {
     if (!h) return -1.0;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (h->n_timed == 0) return -1.0;
     const int slot = (int)((h->n_timed - 1) % fcd_handle::kTimingRing);
     if (hipEventSynchronize(h->ev1[slot]) != hipSuccess) return -1.0;
@@ -320,14 +341,14 @@ double fcd_last_kernel_ms(fcd_handle *h) {
 
 int fcd_timing_reset(fcd_handle *h) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     h->n_timed = 0;
     return FCD_OK;
 }
 
 double fcd_timing_mean_ms(fcd_handle *h, int64_t *n_calls) {
     if (!h) return -1.0;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     const int64_t n = std::min<int64_t>(h->n_timed, fcd_handle::kTimingRing);
     if (n_calls) *n_calls = n;
     if (n == 0) return -1.0;
@@ -345,13 +366,13 @@ double fcd_timing_mean_ms(fcd_handle *h, int64_t *n_calls) {
 int fcd_viterbi_search_dev(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
                            const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     int rc = check_batch(h, in, false);
     if (rc) return rc;
     rc = check_result(h, in, out, false);
     if (rc) return rc;
     if (in->n_reads == 0) return FCD_OK;
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     Timer tm(h);
     FCD_HIP(h, launch_viterbi(to_desc(in, false), collapse_repeats, to_desc(out), h->stream));
     tm.stop();
@@ -362,7 +383,7 @@ int fcd_beam_search_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
                         float beam_cut_threshold, int collapse_repeats, int kernel,
                         const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
     BeamArgs a{};
     a.beam_size = (int)std::min<int64_t>(beam_size, 1ll << 30);
@@ -376,7 +397,7 @@ int fcd_beam_search_profile_dev(fcd_handle *h, const fcd_batch *in, int64_t beam
                                 float beam_cut_threshold, int collapse_repeats, const fcd_result *out,
                                 uint32_t *cycles) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (beam_size < 1 || beam_size > 5 || !in || in->N != 5 || !cycles)
         return fail(h, FCD_E_UNSUPPORTED, "profile: the instrumented instantiation is beam_size <= 5, N = 5");
     BeamArgs a{};
@@ -399,7 +420,7 @@ int fcd_crf_beam_search_dev_k(fcd_handle *h, const fcd_batch *in, const float *i
                               int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                               int kernel, const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
     if (!init || n_init < 1) return fail(h, FCD_E_INVALID, "init_state missing");
     BeamArgs a{};
@@ -416,14 +437,14 @@ int fcd_crf_beam_search_dev_k(fcd_handle *h, const fcd_batch *in, const float *i
 int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                               int64_t init_stride, const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     int rc = check_batch(h, in, true);
     if (rc) return rc;
     rc = check_result(h, in, out, true);
     if (rc) return rc;
     if (!init || n_init < 1) return fail(h, FCD_E_INVALID, "init_state missing");
     if (in->n_reads == 0) return FCD_OK;
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     Timer tm(h);
     FCD_HIP(h, launch_crf_greedy(to_desc(in, true), init, n_init, init_stride, to_desc(out), h->stream));
     tm.stop();
@@ -442,7 +463,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
                float beam_cut_threshold, int collapse_repeats, int logadd_mode,
                const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     const bool is_crf = crf != nullptr;
     int rc = check_batch(h, in1, is_crf);
     if (rc) return rc;
@@ -468,7 +489,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     const int N = (int)in1->N, NL = N - 1;
     if (duplex_lds_bytes((int)beam_size, N, 0, S) > 64 * 1024)
         return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
 
     // log-space copies + one int for the envelope width
     const int64_t T1 = std::max<int64_t>(in1->T, 1), T2 = std::max<int64_t>(in2->T, 1);
@@ -559,9 +580,10 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
                 float beam_cut_threshold, int collapse_repeats, int logadd_mode,
                 const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> whole_call(h->mu);  // staging .. copy-back, see run_host
     const bool is_crf = crf != nullptr;
     {
-        std::lock_guard<std::mutex> g(h->mu);
+        std::lock_guard<std::recursive_mutex> g(h->mu);
         int rc = check_batch(h, in1, is_crf);
         if (rc) return rc;
         rc = check_batch(h, in2, is_crf);
@@ -594,8 +616,8 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
     const size_t oi1 = reserve(ni1 * 4), oi2 = reserve(ni2 * 4);
     const size_t olab = reserve(n_out), oolen = reserve((size_t)B * 4), ostat = reserve((size_t)B * 4);
     {
-        std::lock_guard<std::mutex> g(h->mu);
-        FCD_HIP(h, hipSetDevice(h->device));
+        std::lock_guard<std::recursive_mutex> g(h->mu);
+        FCD_DEVICE(h);
         int rc = ensure(h, &h->stage, &h->stage_bytes, used);
         if (rc) return rc;
         char *base = reinterpret_cast<char *>(h->stage);
@@ -631,7 +653,7 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
     int rc = duplex_dev(h, &d1, &d2, is_crf ? &dc : nullptr, reinterpret_cast<const uint64_t *>(base + oe),
                         env_stride, beam_size, beam_cut_threshold, collapse_repeats, logadd_mode, &dout);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
@@ -668,7 +690,7 @@ int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
                             int64_t stride2, const int64_t *T2, int64_t T2cap,
                             int64_t band, uint64_t *envelope, int64_t env_stride) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (n_pairs < 0 || T1cap < 0 || T2cap < 0 || band < 0) return fail(h, FCD_E_INVALID, "negative size");
     if (n_pairs == 0 || T1cap == 0) return FCD_OK;
     if (!labels1 || !path1 || !len1 || !labels2 || !path2 || !len2 || !envelope)
@@ -676,7 +698,7 @@ int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
     if (stride1 < T1cap || stride2 < T2cap) return fail(h, FCD_E_INVALID, "label strides shorter than the reads");
     if (env_stride < T1cap) return fail(h, FCD_E_INVALID, "envelope shorter than read 1");
     band = std::min<int64_t>(band, 1 << 20);
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     // the DP is sized by the longest labellings actually present, not by the time axes
     int rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, 256);
     if (rc) return rc;
@@ -723,12 +745,13 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
                              int64_t stride2, const int64_t *T2, int64_t T2cap,
                              int64_t band, uint64_t *envelope, int64_t env_stride) {
     if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> whole_call(h->mu);  // staging .. copy-back, see run_host
     if (n_pairs < 0 || T1cap < 0 || T2cap < 0) return fail(h, FCD_E_INVALID, "negative size");
     if (n_pairs == 0 || T1cap == 0) return FCD_OK;
     if (!labels1 || !path1 || !len1 || !labels2 || !path2 || !len2 || !envelope)
         return fail(h, FCD_E_INVALID, "null array");
     if (stride1 < T1cap || stride2 < T2cap || env_stride < T1cap) return fail(h, FCD_E_INVALID, "strides shorter than the reads");
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     // one device slab: labels, paths, lengths, row counts of both reads, then the envelope
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     const size_t o_l1 = 0, o_l2 = o_l1 + al((size_t)n_pairs * stride1);
@@ -739,7 +762,7 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
     const size_t total = o_env + (size_t)n_pairs * env_stride * 16;
     char *d = nullptr;
     {
-        std::lock_guard<std::mutex> g(h->mu);
+        std::lock_guard<std::recursive_mutex> g(h->mu);
         int rc = ensure(h, &h->stage, &h->stage_bytes, total);
         if (rc) return rc;
         d = reinterpret_cast<char *>(h->stage);
@@ -760,7 +783,7 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
         reinterpret_cast<uint32_t *>(d + o_n2), stride2, T2 ? reinterpret_cast<int64_t *>(d + o_t2) : nullptr, T2cap,
         band, reinterpret_cast<uint64_t *>(d + o_env), env_stride);
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     FCD_HIP(h, hipMemcpyAsync(envelope, d + o_env, (size_t)n_pairs * env_stride * 16, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
@@ -769,9 +792,9 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
                            float *out_ln, int64_t n, int logadd_mode) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (n < 0 || (n > 0 && (!a || !b || !out_add || !out_ln))) return fail(h, FCD_E_INVALID, "null array");
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     FCD_HIP(h, launch_logspace_probe(a, b, out_add, out_ln, n, logadd_mode, h->stream));
     return FCD_OK;
 }
@@ -786,9 +809,9 @@ int64_t fcd_packed_result_bytes(int64_t n_reads, int64_t total_labels, int path_
 int fcd_result_offsets_dev(fcd_handle *h, const uint32_t *out_len, int64_t n_reads, int64_t out_stride,
                            uint64_t *offsets) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (n_reads < 0 || !offsets || (n_reads > 0 && !out_len) || out_stride < 0) return fail(h, FCD_E_INVALID, "bad argument");
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     FCD_HIP(h, launch_result_offsets(out_len, n_reads, out_stride, offsets, h->stream));
     return FCD_OK;
 }
@@ -796,11 +819,11 @@ int fcd_result_offsets_dev(fcd_handle *h, const uint32_t *out_len, int64_t n_rea
 int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, int path_bytes,
                          const uint64_t *offsets, uint8_t *buf) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (!res || n_reads < 0 || !offsets || !buf || (path_bytes != 2 && path_bytes != 4))
         return fail(h, FCD_E_INVALID, "bad argument");
     if (n_reads > 0 && (!res->labels || !res->path || !res->out_len)) return fail(h, FCD_E_INVALID, "null labels/path/out_len");
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     if (n_reads == 0) {
         FCD_HIP(h, hipMemsetAsync(buf, 0, 16, h->stream));
         return FCD_OK;
@@ -812,11 +835,11 @@ int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, 
 int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, uint64_t *offsets,
                            const fcd_result *out) {
     if (!h) return FCD_E_INVALID;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     if (!buf || n_reads < 0 || !offsets || !out) return fail(h, FCD_E_INVALID, "bad argument");
     if (n_reads == 0) return FCD_OK;
     if (!out->labels || !out->out_len) return fail(h, FCD_E_INVALID, "null labels/out_len");
-    FCD_HIP(h, hipSetDevice(h->device));
+    FCD_DEVICE(h);
     // the buffer's own out_len array (offset 16) gives the read offsets
     FCD_HIP(h, launch_result_offsets(reinterpret_cast<const uint32_t *>(buf + 16), n_reads, out->out_stride, offsets,
                                      h->stream));
@@ -841,9 +864,12 @@ struct HostCall {
 
 int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c) {
     if (!h) return FCD_E_INVALID;
+    // held from staging to copy-back: two threads sharing a handle are serialised (fcd.h), they cannot
+    // interleave on the staging buffer
+    std::lock_guard<std::recursive_mutex> whole_call(h->mu);
     const bool crf = c.op == Op::CrfBeam || c.op == Op::CrfGreedy;
     {
-        std::lock_guard<std::mutex> g(h->mu);
+        std::lock_guard<std::recursive_mutex> g(h->mu);
         int rc = check_batch(h, in, crf);
         if (rc) return rc;
         rc = check_result(h, in, out, c.op != Op::Viterbi);
@@ -877,14 +903,14 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
 
     int rc;
     {
-        std::lock_guard<std::mutex> g(h->mu);
-        FCD_HIP(h, hipSetDevice(h->device));
+        std::lock_guard<std::recursive_mutex> g(h->mu);
+        FCD_DEVICE(h);
         rc = ensure(h, &h->stage, &h->stage_bytes, used);
         if (rc) return rc;
     }
     char *base = reinterpret_cast<char *>(h->stage);
     {
-        std::lock_guard<std::mutex> g(h->mu);
+        std::lock_guard<std::recursive_mutex> g(h->mu);
         if (n_in) FCD_HIP(h, hipMemcpyAsync(base + o_in, in->post, n_in * 4, hipMemcpyHostToDevice, h->stream));
         if (in->lengths)
             FCD_HIP(h, hipMemcpyAsync(base + o_len, in->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
@@ -915,7 +941,7 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
             break;
     }
     if (rc) return rc;
-    std::lock_guard<std::mutex> g(h->mu);
+    std::lock_guard<std::recursive_mutex> g(h->mu);
     FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
     if (out->path) FCD_HIP(h, hipMemcpyAsync(out->path, dout.path, n_out * 4, hipMemcpyDeviceToHost, h->stream));
     if (out->qual) FCD_HIP(h, hipMemcpyAsync(out->qual, dout.qual, n_out * 4, hipMemcpyDeviceToHost, h->stream));

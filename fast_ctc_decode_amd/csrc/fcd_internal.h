@@ -176,5 +176,5 @@ struct fcd_handle {
     void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
     size_t lnbuf_bytes = 0;
     std::string err;
-    std::mutex mu;
+    std::recursive_mutex mu;  // a *_host call holds it from staging to copy-back, the *_dev call inside re-enters
 };

@@ -10,6 +10,7 @@
 #include <pybind11/pybind11.h>
 
 #include <charconv>
+#include <cstdlib>
 #include <cstdint>
 #include <stdexcept>
 #include <string>
@@ -21,17 +22,25 @@ namespace py = pybind11;
 
 namespace {
 
+// one handle per host thread: the reference's functions are re-entrant (lib.rs:199 releases the GIL), so
+// concurrent callers must not share a stream / workspace.  The handle (stream + device workspace) goes away
+// with its thread; at interpreter shutdown the HIP runtime may already be gone, so nothing is torn down then.
+struct ThreadHandle {
+    fcd_handle *h = nullptr;
+    ~ThreadHandle() {
+        if (h && Py_IsInitialized()) fcd_destroy(h);
+    }
+};
+
 fcd_handle *thread_handle() {
-    // one handle per host thread: the reference's functions are re-entrant (lib.rs:199 releases
-    // the GIL), so concurrent callers must not share a stream / workspace
-    thread_local fcd_handle *h = nullptr;
-    if (!h) {
-        int rc = fcd_create(0, &h);
-        if (rc != FCD_OK || !h)
+    thread_local ThreadHandle th;
+    if (!th.h) {
+        int rc = fcd_create(0, &th.h);
+        if (rc != FCD_OK || !th.h)
             throw std::runtime_error("fast_ctc_decode: no usable gfx950 device (fcd_create failed with " +
                                      std::to_string(rc) + "); this module has no CPU fallback");
     }
-    return h;
+    return th.h;
 }
 
 void check_rc(fcd_handle *h, int rc) {
@@ -95,7 +104,10 @@ void check_greedy_alphabet(size_t n_alpha, py::ssize_t inner) {  // lib.rs:190-1
 size_t to_usize(const py::object &o, const char *name) {  // PyO3 usize extraction
     if (py::isinstance<py::bool_>(o) || !py::isinstance<py::int_>(o))
         throw py::type_error(std::string("argument '") + name + "': expected an integer");
-    if (o.cast<py::int_>() < py::int_(0)) throw py::value_error("can't convert negative int to unsigned");
+    if (o.cast<py::int_>() < py::int_(0)) {  // PyO3: OverflowError, before any ValueError check of lib.rs:331-349
+        PyErr_SetString(PyExc_OverflowError, "can't convert negative int to unsigned");
+        throw py::error_already_set();
+    }
     return o.cast<size_t>();
 }
 
@@ -426,11 +438,19 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
           "crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, init_state_2, alphabet, "
           "envelope=None, beam_size=5, beam_cut_threshold=0.0)");
     // not part of the reference surface: selects what the reference fixes at build time
-    // (`fastexp` feature on = "max", off = "logsumexp"; SURVEY.md finding 3)
-    m.def("_set_duplex_logadd_mode", [](const std::string &mode) {
+    // (`fastexp` feature on = "max", off = "logsumexp"; SURVEY.md finding 3).  The default is "logsumexp"
+    // (the north star's "fastexp disabled"); the published PyPI wheels are built WITH fastexp and compute
+    // "max" -- callers comparing against them must switch (also: environment variable
+    // FCD_DUPLEX_LOGADD=max, read once at import).
+    auto set_mode = [](const std::string &mode) {
         if (mode == "logsumexp") g_logadd_mode = FCD_LOGADD_LOGSUMEXP;
         else if (mode == "max") g_logadd_mode = FCD_LOGADD_MAX;
         else throw py::value_error("mode must be 'logsumexp' or 'max'");
-    });
+    };
+    m.def("set_duplex_logadd_mode", set_mode, "mode"_a,
+          "set_duplex_logadd_mode(mode): 'logsumexp' (default; the reference built with --no-default-features) or "
+          "'max' (the reference's default `fastexp` feature, i.e. what the PyPI wheels compute)");
+    m.def("_set_duplex_logadd_mode", set_mode);  // earlier name, kept for the tests
+    if (const char *env = std::getenv("FCD_DUPLEX_LOGADD")) set_mode(env);
     m.attr("__version__") = "0.3.7";  // src/lib.rs:626 (CARGO_PKG_VERSION of the mirrored reference)
 }

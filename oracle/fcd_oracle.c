@@ -718,7 +718,16 @@ static inline float log1p_m(float x, int mode) {
     return (mode & FCDO_MATH_CR) ? (float)log1pl((long double)x) : log1pf(x);
 }
 
+/* instrumentation for the duplex roofline (tools/bench_configs.py): LogSpace::add calls of this thread */
+static __thread int64_t g_logadd_calls = 0;
+int64_t fcdo_logadd_calls(int reset) {
+    int64_t n = g_logadd_calls;
+    if (reset) g_logadd_calls = 0;
+    return n;
+}
+
 float fcdo_logspace_add(float a, float b, int mode) {
+    ++g_logadd_calls;
     float big, small;
     if (a <= b) {
         big = b;

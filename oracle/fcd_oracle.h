@@ -181,6 +181,8 @@ void fcdo_secondary_get(const float *pairs, int64_t len, int64_t offset, int64_t
 float fcdo_secondary_update_max(const float *pairs, int64_t len, int64_t offset,
                                 int64_t lower, int64_t upper, int logadd_mode);
 float fcdo_logspace_add(float a, float b, int logadd_mode);
+/* number of LogSpace::add evaluations made by the calling thread since the last reset (instrumentation) */
+int64_t fcdo_logadd_calls(int reset);
 /* out[i] = fcdo_logspace_add(a[i], b[i], logadd_mode) -- lets tests compare millions of operands */
 void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int logadd_mode);
 

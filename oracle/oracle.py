@@ -76,6 +76,8 @@ def _load():
     lib.fcdo_logspace_add.restype = f32
     lib.fcdo_logspace_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i32]
     lib.fcdo_logspace_add_batch.restype = None
+    lib.fcdo_logadd_calls.argtypes = [i32]
+    lib.fcdo_logadd_calls.restype = i64
     return lib
 
 

@@ -1,0 +1,92 @@
+"""One behaviour, two host layers: the compiled drop-in module `fast_ctc_decode` (csrc/pymodule.cpp) and the
+Python mirror `fast_ctc_decode_amd` must reject malformed arguments with the SAME exception type and the SAME
+text -- the reference's (src/lib.rs:143-146,190-195,331-349,423-468; tests/test_decode.py:45-98,217-225).
+Argument checking happens before any device work, so this runs without a GPU."""
+import numpy as np
+import pytest
+
+import fast_ctc_decode as compiled
+import fast_ctc_decode_amd as mirror
+
+X = np.full((6, 5), 0.2, np.float32)
+X3 = np.full((6, 4, 5), 0.2, np.float32)
+INIT = np.array([0, 0, 1, 0], np.float32)
+ENV = np.stack([np.zeros(6, np.uint64), np.full(6, 6, np.uint64)], 1)
+
+CASES = [
+    # (function, args, kwargs)
+    ("beam_search", (X, "NACG"), {}),                                  # alphabet too short
+    ("beam_search", (X, "NACGTT"), {}),                                # too long
+    ("beam_search", (X, "NACGT"), {"beam_size": 0}),
+    ("beam_search", (X, "NACGT"), {"beam_size": -1}),
+    ("beam_search", (X, "NACGT"), {"beam_size": -1, "beam_cut_threshold": 5.0}),  # extraction errors come first
+    ("beam_search", (X, "NACGT"), {"beam_size": 2.5}),
+    ("beam_search", (X, "NACGT"), {"beam_size": True}),
+    ("beam_search", (X, "NACGT"), {"beam_cut_threshold": -0.1}),
+    ("beam_search", (X, "NACGT"), {"beam_cut_threshold": 0.2}),        # == 1/len(alphabet)
+    ("beam_search", (X, "NACGT"), {"beam_cut_threshold": 0.5}),
+    ("beam_search", (X, "NACG"), {"beam_size": 0, "beam_cut_threshold": -1.0}),   # validation ORDER: alphabet first
+    ("beam_search", (X, "NACGT"), {"beam_size": 0, "beam_cut_threshold": -1.0}),  # then beam_size
+    ("beam_search", (X.astype(np.float64), "NACGT"), {}),
+    ("beam_search", (X3, "NACGT"), {}),
+    ("beam_search", (X.tolist(), "NACGT"), {}),
+    ("beam_search", (X, 5), {}),
+    ("beam_search", (X,), {}),                                         # missing argument
+    ("viterbi_search", (X, ""), {}),
+    ("viterbi_search", (X, "NACG"), {}),
+    ("viterbi_search", (X.astype(np.float16), "NACGT"), {}),
+    ("viterbi_search", (X,), {}),
+    ("crf_beam_search", (X3, INIT, ""), {}),
+    ("crf_beam_search", (X3, INIT, "NACG"), {}),
+    ("crf_beam_search", (X, INIT, "NACGT"), {}),
+    ("crf_beam_search", (X3, INIT.astype(np.float64), "NACGT"), {}),
+    ("crf_beam_search", (X3, INIT, "NACGT"), {"beam_size": -3}),
+    ("crf_greedy_search", (X3, INIT, ""), {}),
+    ("crf_greedy_search", (X3, INIT, "NACGTA"), {}),
+    ("beam_search_duplex", (X, np.full((6, 4), 0.25, np.float32), "NACGT"), {}),          # inner axes differ
+    ("beam_search_duplex", (X, X, "NACG"), {}),
+    ("beam_search_duplex", (X, X, "NACGT"), {"beam_size": 0}),
+    ("beam_search_duplex", (X, X, "NACGT"), {"beam_cut_threshold": 0.2}),
+    ("beam_search_duplex", (X, X, "NACGT"), {"envelope": ENV[:5]}),                        # wrong length
+    ("beam_search_duplex", (X, X, "NACGT"), {"envelope": np.zeros((6, 3), np.uint64)}),    # wrong inner axis
+    ("beam_search_duplex", (X, X, "NACGT"), {"envelope": ENV.astype(np.int64)}),           # wrong dtype
+    ("crf_beam_search_duplex", (X3, INIT, X3[:, :, :4].copy(), INIT, "NACGT"), {}),
+    ("crf_beam_search_duplex", (X3, INIT, X3, INIT, "NACGT"), {"beam_size": 0}),
+    ("crf_beam_search_duplex", (X3, INIT, X3, INIT, "NACGT"), {"envelope": ENV[:2]}),
+]
+
+
+def outcome(module, name, args, kwargs):
+    try:
+        getattr(module, name)(*args, **kwargs)
+    except Exception as e:  # noqa: BLE001 -- the point is to compare whatever is raised
+        return type(e).__name__, str(e)
+    return "returned", ""
+
+
+@pytest.mark.parametrize("case", range(len(CASES)))
+def test_same_rejection(case):
+    name, args, kwargs = CASES[case]
+    a = outcome(compiled, name, args, kwargs)
+    b = outcome(mirror, name, args, kwargs)
+    assert a[0] != "returned" and b[0] != "returned", (name, kwargs, a, b)
+    assert a[0] == b[0], (name, kwargs, a, b)
+    if a[0] != "TypeError":   # TypeError texts of missing / mistyped arguments come from the binding generator
+        assert a[1] == b[1], (name, kwargs, a, b)
+
+
+def test_reference_messages():
+    """The texts the reference's own tests pin (tests/test_decode.py:62-98,217-225)."""
+    for m in (compiled, mirror):
+        with pytest.raises(ValueError, match="beam_size cannot be 0"):
+            m.beam_search(X, "NACGT", beam_size=0)
+        with pytest.raises(ValueError, match="beam_cut_threshold must be at least 0.0"):
+            m.beam_search(X, "NACGT", beam_cut_threshold=-0.1)
+        with pytest.raises(ValueError, match="beam_cut_threshold cannot be more than 0.2"):
+            m.beam_search(X, "NACGT", beam_cut_threshold=0.2)
+        with pytest.raises(ValueError, match="alphabet size 4 does not match probability matrix inner dimension 5"):
+            m.beam_search(X, "NACG")
+        with pytest.raises(ValueError, match="Empty alphabet given"):
+            m.viterbi_search(X, "")
+        with pytest.raises(ValueError, match="alphabet size does not match probability matrix dimensions"):
+            m.viterbi_search(X, "NACG")

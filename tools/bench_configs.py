@@ -66,10 +66,18 @@ def check_duplex(x1, x2, env, r, n, mode):
     from oracle import oracle
     a, b, rc, same = x1[:n].cpu().numpy(), x2[:n].cpu().numpy(), r.cpu(), 0
     omode = (oracle.LOGSUMEXP if mode == 0 else oracle.MAXMODE) | oracle.MATH_CR
+    oracle.lib.fcdo_logadd_calls(1)
     for i in range(n):
         seq = oracle.beam_search_duplex(a[i], b[i], "NACGT", env, 5, 0.1, True, omode)
         same += int("".join("NACGT"[l] for l in rc.labels[i, :int(rc.out_len[i])]) == seq)
-    return {"oracle_checked": n, "oracle_identical": same}
+    return {"oracle_checked": n, "oracle_identical": same,
+            "logspace_adds_per_pair": oracle.lib.fcdo_logadd_calls(1) / n}
+
+
+# binary64 operations of one LogSpace::add on the kernel's fast path (csrc/logadd_fast.h): exp = 1 mul + rint +
+# 2 fma (reduction) + 3 mul + 11 fma (Estrin) + ldexp; ln_1p = 1 add + 1 div + 4 mul + 15 fma + 2 mul
+LOGADD_F64_FLOP = (1 + 1 + 2 * 2 + 3 + 11 * 2 + 1) + (1 + 1 + 4 + 15 * 2 + 2)
+FP64_VECTOR_PEAK = 78.6e12   # MI355X spec (half the FP32 vector rate, MI355X_MICROARCH.md)
 
 
 def _est(x1, x2):
@@ -181,6 +189,21 @@ def main():
                    "ok": int((r.status == 0).sum()), "mean_len": float(r.out_len.float().mean())}
             if check:
                 out.update(check_duplex(x1, x2, env, r, 6, mode))
+                # what bounds it: HBM is a bystander (192 KB of posteriors + envelope per pair); in logsumexp mode
+                # the work is the serial log-add recurrence along every new node's window
+                alg = B * (2 * T * 5 * 4 + T * 16 + float(r.out_len.float().mean()))
+                out["roofline_hbm"] = {"bound": "hbm", "achieved": alg / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
+                                       "frac": alg / ms / 1e6 / 8000.0, "algorithmic_bytes_per_pair": alg / B}
+                if mode == 0:
+                    flops = B * out["logspace_adds_per_pair"] * LOGADD_F64_FLOP
+                    out["roofline_fp64"] = {
+                        "bound": "fp64_vector", "achieved": flops / (ms * 1e-3) / 1e12, "peak": FP64_VECTOR_PEAK / 1e12,
+                        "unit": "TFLOP/s", "frac": flops / (ms * 1e-3) / FP64_VECTOR_PEAK,
+                        "flop_per_logspace_add": LOGADD_F64_FLOP,
+                        "note": "latency-bound, not throughput-bound: each new tree node's window is a serial "
+                                "recurrence of W = 128 rows x 2 log-adds (a pair of lanes per node, ~14 of 64 lanes "
+                                "busy), and 1024 pairs are one wavefront per SIMD; the knock-out timings in DESIGN.md 4.4 "
+                                "put 70 % of the kernel in that loop"}
             print(json.dumps(out), flush=True)
         # the alignment-band estimator on the same pairs (not a reference function)
         e, ms = timed(lambda: _est(x1, x2), reps=2)
