@@ -140,7 +140,17 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
     const float *post = p.in.post + r * p.in.stride_read;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
-    const int64_t slab = has_read ? local : 0;
+    int64_t slab = has_read ? local : 0;
+    if (RPW == 1 && p.arena.retry_counter) {
+        // retry pass (capi.hip): the first pass ran in slabs sized for the usual tree; a read that outgrew its
+        // slab was stopped with FCD_ST_INTERNAL and is decoded again here, in a slab that holds the worst case
+        const bool mine = has_read && p.out.status[r] == FCD_ST_INTERNAL;  // wave-uniform: one read per wavefront
+        int slot = -1;
+        if (mine && lane == 0) slot = atomicAdd(p.arena.retry_counter, 1);
+        slot = __builtin_amdgcn_readfirstlane(slot);
+        if (!mine || slot >= p.arena.retry_slots) return;  // (left over: the host runs another round)
+        slab = slot;
+    }
     int2 *rec = p.arena.rec + slab * p.arena.cap_nodes;
     int32_t *jmp = p.arena.jmp + slab * p.arena.cap_nodes;
     int32_t *rows = p.arena.rows + slab * p.arena.cap_nodes * RW;
@@ -611,7 +621,7 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
 
 template <int N, bool AMB, bool CRF>
 hipError_t launch_na(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
-    if (p.a.beam_size <= 32) {  // two reads per wavefront
+    if (p.a.beam_size <= 32 && !p.arena.retry_counter) {  // two reads per wavefront
         hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB, CRF>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
     } else {
         hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB, CRF>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);

@@ -194,26 +194,68 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     }
     args.beam_size = (int)beam;
     const int64_t budget = workspace_budget(h);
-    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
+    // Wide beams, large jobs: the worst case (every entry creates every child at every step) is about three
+    // times what trees actually grow to (172 k of 512 k nodes per read at beam 32) and
+    // would reserve 117 GB for BASELINE config 3's 8192 reads.  The lane kernel therefore runs in slabs of HALF
+    // the worst case; a read that outgrows its slab is stopped (FCD_ST_INTERNAL) and decoded again by a retry
+    // pass in one of a few worst-case slabs.  The retry loop reads a 4-byte counter back -- the one place this
+    // entry point waits for the device -- so it is used only when the worst-case arena would exceed 8 GiB (or the workspace limit).
+    const size_t node_bytes = (use_wave || use_lane) ? sizeof(int2) + 4 + (NL <= 4 ? 4 : 8) * 4 : 0;
+    const size_t worst_total = (size_t)cap_nodes * node_bytes * (size_t)d.n_reads;
+    const bool two_pass = use_lane && (worst_total > ((size_t)8 << 30) || (int64_t)worst_total > budget);
+    const int64_t cap_worst = cap_nodes;
+    int retry_slots = 0;
+    size_t retry_bytes = 0;
+    if (two_pass) {
+        cap_nodes = (cap_worst / std::max(h->first_pass_div, 1) + 63) & ~63ll;
+        per_read = (size_t)cap_nodes * node_bytes;
+        retry_slots = (int)std::max<int64_t>(4, std::min<int64_t>(256, d.n_reads / 32));
+        retry_bytes = (size_t)retry_slots * (size_t)cap_worst * node_bytes;
+    }
+    int64_t chunk = std::max<int64_t>(1, (budget - (int64_t)retry_bytes) / (int64_t)per_read);
     chunk = std::min<int64_t>(chunk, d.n_reads);
-    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_read);
+    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_read + retry_bytes);
     if (rc) return rc;
+    int32_t *d_counter = nullptr;
+    if (two_pass) {
+        rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, 256);
+        if (rc) return rc;
+        d_counter = reinterpret_cast<int32_t *>(h->lnbuf);
+    }
+
+    auto wave_arena = [&](char *base, int64_t slabs, int64_t cap) {
+        WaveArena ar{};
+        ar.cap_nodes = cap;
+        ar.row_words = NL <= 4 ? 4 : 8;
+        ar.rec = reinterpret_cast<int2 *>(base);
+        ar.jmp = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * sizeof(int2));
+        ar.rows = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * (sizeof(int2) + 4));
+        return ar;
+    };
 
     Timer tm(h);
     for (int64_t begin = 0; begin < d.n_reads; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, d.n_reads - begin);
         hipError_t e;
         if (use_wave || use_lane) {
-            WaveArena ar;
-            ar.cap_nodes = cap_nodes;
-            ar.row_words = NL <= 4 ? 4 : 8;
-            ar.rec = reinterpret_cast<int2 *>(h->arena);
-            ar.jmp = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
-                                                 (size_t)chunk * cap_nodes * sizeof(int2));
-            ar.rows = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
-                                                  (size_t)chunk * cap_nodes * (sizeof(int2) + 4));
+            const WaveArena ar = wave_arena(reinterpret_cast<char *>(h->arena), chunk, cap_nodes);
             e = use_lane ? launch_beam_lane(d, begin, n, args, ar, o, h->stream)
                          : launch_beam_wave(d, begin, n, args, ar, o, h->stream);
+            FCD_HIP(h, e);
+            if (two_pass) {
+                WaveArena rr = wave_arena(reinterpret_cast<char *>(h->arena) + (size_t)chunk * per_read, retry_slots, cap_worst);
+                rr.retry_counter = d_counter;
+                rr.retry_slots = retry_slots;
+                for (;;) {  // every round decodes up to retry_slots of the reads that overflowed
+                    int32_t overflowed = 0;
+                    FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t), h->stream));
+                    FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
+                    FCD_HIP(h, hipMemcpyAsync(&overflowed, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                    FCD_HIP(h, hipStreamSynchronize(h->stream));
+                    if (overflowed <= retry_slots) break;
+                }
+            }
+            continue;
         } else {
             GenericArena ar;
             ar.cap_nodes = cap_nodes;
@@ -325,6 +367,13 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
     if (!h || bytes < 0) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);
     h->ws_limit = bytes;
+    return FCD_OK;
+}
+
+int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor) {
+    if (!h || divisor < 1) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    h->first_pass_div = divisor;
     return FCD_OK;
 }
 

@@ -69,6 +69,10 @@ struct WaveArena {
     int32_t *rows;
     int64_t cap_nodes;
     int row_words;  // 4 or 8
+    // retry pass of the lane kernel (one read per wavefront): only reads whose first-pass slab overflowed
+    // (status FCD_ST_INTERNAL) run, each claiming one of retry_slots worst-case slabs through the counter
+    int32_t *retry_counter;  // nullable
+    int retry_slots;
 };
 
 size_t beam_generic_lds_bytes(int beam_size, int N);
@@ -168,6 +172,7 @@ struct fcd_handle {
     std::vector<hipEvent_t> ev0, ev1;
     int64_t n_timed = 0;  // calls recorded since the last fcd_timing_reset
     int64_t ws_limit = 0;  // 0 = auto (half of the free device memory)
+    int first_pass_div = 2;  // lane kernel, two-pass sizing: first-pass slabs hold 1/div of the worst case
     // grow-only device workspace (tree arenas, staging for *_host calls)
     void *arena = nullptr;
     size_t arena_bytes = 0;

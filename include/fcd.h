@@ -143,6 +143,11 @@ const char *fcd_last_error(const fcd_handle *h);         /* text of the last fai
 const char *fcd_status_string(int status);               /* exact SearchError Display text, src/lib.rs:46-53 */
 /* cap (bytes) on the per-call tree-arena workspace; batches needing more are decoded in chunks */
 int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes);
+/* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
+ * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
+ * it) and decode the reads that outgrow their slab again in worst-case slabs.  A larger divisor makes that
+ * retry path run on small inputs (tests). */
+int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor);
 /* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP
  * events on the stream the kernels were launched on; <0 if unavailable */
 double fcd_last_kernel_ms(fcd_handle *h);

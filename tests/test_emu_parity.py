@@ -55,6 +55,10 @@ def test_full_length_read_every_kernel(fcd):
     P.check_beam(fcd, x[:1], 64, 0.1, kernel=4)
 
 
+def test_lane_two_pass_retry(fcd):
+    P.test_lane_two_pass_retry(fcd)
+
+
 def test_ambiguity_counter(fcd):
     P.test_ambiguity_counter(fcd)
 

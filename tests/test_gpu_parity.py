@@ -123,6 +123,31 @@ def test_ambiguity_counter(fcd):
     check_ambiguous(fcd, x, 5, 0.1, (1, 2, 3, 4))
 
 
+def test_lane_two_pass_retry(fcd):
+    """Wide beams size the first-pass tree slabs below the worst case (capi.hip): reads that outgrow their slab
+    are stopped and decoded again in worst-case slabs, a few per retry round.  A small workspace limit and a
+    large first-pass divisor make ten of eleven short reads take that path, three rounds deep; results must be
+    the oracle's, ragged lengths and a failing read included."""
+    from fast_ctc_decode_amd import _native as nat
+    rng = np.random.default_rng(3)
+    B, T = 11, 300
+    x = rng.random((B, T, 5), dtype=np.float32)
+    x /= x.sum(-1, keepdims=True)
+    x[3] = 0.2          # uniform rows: exact ties everywhere
+    x[7, 150] = np.nan  # IncomparableValues half way
+    lengths = np.array([T, T, 1, T, 0, T, 299, T, T, 64, T], np.int64)
+    h = nat.default_handle()
+    h.set_workspace_limit(2 << 20)
+    h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 6))
+    try:
+        for beam, thr in ((32, 0.0), (20, 0.1), (64, 0.0)):
+            check_beam(fcd, x, beam, thr, lengths=lengths, kernel=fcd.KERNEL_LANE)
+            check_beam(fcd, x, beam, thr, lengths=lengths, kernel=fcd.KERNEL_AUTO)
+    finally:
+        h.set_workspace_limit(0)
+        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 2))
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
 def test_beam_thr0(fcd, collapse, kernel):
