@@ -1,0 +1,17 @@
+#!/bin/bash
+# Everything the per-round evidence under profiles/ is made from, in ONE call on the GPU box.
+# Usage: tools/round_profiles.sh TAG      (then, here: tools/summarize_profile.py TAG; tools/summarize_sq.py TAG)
+set -u
+TAG=${1:-r02}
+R=$PWD
+O=$R/gpurun_out
+mkdir -p $O
+bash tools/profile.sh $TAG all > $O/${TAG}_profile.log 2>&1
+bash tools/profile_sq.sh $TAG beam > $O/${TAG}_profile_sq.log 2>&1
+# rocprofv3 summary of the bench command itself: its kernel average must agree with bench.py's HIP events
+( export TMPDIR=/tmp; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_bench -o bench -- \
+    python $R/bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err )
+python tools/cycle_account.py > $O/${TAG}_cycle_account.jsonl 2> $O/${TAG}_cycle_account.err
+python tools/bench_configs.py 1 3 4 5 64 1024 --check > $O/${TAG}_configs.jsonl 2> $O/${TAG}_configs.err
+python tools/probe_latency.py > $O/${TAG}_latency.txt 2>&1
+tail -2 $O/${TAG}_bench_line.json $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt
