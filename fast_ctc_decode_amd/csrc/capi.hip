@@ -198,24 +198,26 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     // times what trees actually grow to (172 k of 512 k nodes per read at beam 32) and
     // would reserve 117 GB for BASELINE config 3's 8192 reads.  The lane kernel therefore runs in slabs of HALF
     // the worst case; a read that outgrows its slab is stopped (FCD_ST_INTERNAL) and decoded again by a retry
-    // pass in one of a few worst-case slabs.  The retry loop reads a 4-byte counter back -- the one place this
-    // entry point waits for the device -- so it is used only when the worst-case arena would exceed 8 GiB (or the workspace limit).
+    // pass in worst-case slabs carved out of the SAME arena (stream order: the first pass has finished with it,
+    // results are already traced back).  The retry loop reads a 4-byte counter back -- the one place this entry
+    // point waits for the device -- so it is used only when the worst-case arena would exceed 8 GiB (or the
+    // workspace limit).  A job in which more than a quarter of the reads overflow (dense posteriors: nearly
+    // every extension passes the cut) makes this handle size later jobs for the worst case straight away.
     const size_t node_bytes = (use_wave || use_lane) ? sizeof(int2) + 4 + (NL <= 4 ? 4 : 8) * 4 : 0;
     const size_t worst_total = (size_t)cap_nodes * node_bytes * (size_t)d.n_reads;
     const bool two_pass = use_lane && (worst_total > ((size_t)8 << 30) || (int64_t)worst_total > budget);
     const int64_t cap_worst = cap_nodes;
-    int retry_slots = 0;
-    size_t retry_bytes = 0;
+    const size_t worst_read = (size_t)cap_worst * node_bytes;
     if (two_pass) {
         cap_nodes = (cap_worst / std::max(h->first_pass_div, 1) + 63) & ~63ll;
         per_read = (size_t)cap_nodes * node_bytes;
-        retry_slots = (int)std::max<int64_t>(4, std::min<int64_t>(256, d.n_reads / 32));
-        retry_bytes = (size_t)retry_slots * (size_t)cap_worst * node_bytes;
     }
-    int64_t chunk = std::max<int64_t>(1, (budget - (int64_t)retry_bytes) / (int64_t)per_read);
+    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
     chunk = std::min<int64_t>(chunk, d.n_reads);
-    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_read + retry_bytes);
+    // (at least a few worst-case slabs for the retry pass, however small the job's share of the budget)
+    rc = ensure(h, &h->arena, &h->arena_bytes, std::max((size_t)chunk * per_read, two_pass ? 4 * worst_read : (size_t)0));
     if (rc) return rc;
+    const int retry_slots = two_pass ? (int)std::min<size_t>(h->arena_bytes / worst_read, 1u << 30) : 0;
     int32_t *d_counter = nullptr;
     if (two_pass) {
         rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, 256);
@@ -243,7 +245,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
                          : launch_beam_wave(d, begin, n, args, ar, o, h->stream);
             FCD_HIP(h, e);
             if (two_pass) {
-                WaveArena rr = wave_arena(reinterpret_cast<char *>(h->arena) + (size_t)chunk * per_read, retry_slots, cap_worst);
+                WaveArena rr = wave_arena(reinterpret_cast<char *>(h->arena), retry_slots, cap_worst);
                 rr.retry_counter = d_counter;
                 rr.retry_slots = retry_slots;
                 for (;;) {  // every round decodes up to retry_slots of the reads that overflowed
@@ -252,6 +254,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
                     FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
                     FCD_HIP(h, hipMemcpyAsync(&overflowed, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
                     FCD_HIP(h, hipStreamSynchronize(h->stream));
+                    if (!h->first_pass_div_pinned && (int64_t)overflowed * 4 > n) h->first_pass_div = 1;
                     if (overflowed <= retry_slots) break;
                 }
             }
@@ -371,9 +374,10 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
 }
 
 int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor) {
-    if (!h || divisor < 1) return FCD_E_INVALID;
+    if (!h || divisor < 0) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);
-    h->first_pass_div = divisor;
+    h->first_pass_div = divisor ? divisor : 2;
+    h->first_pass_div_pinned = divisor != 0;  // 0: back to the default, adaptive sizing
     return FCD_OK;
 }
 

@@ -173,6 +173,7 @@ struct fcd_handle {
     int64_t n_timed = 0;  // calls recorded since the last fcd_timing_reset
     int64_t ws_limit = 0;  // 0 = auto (half of the free device memory)
     int first_pass_div = 2;  // lane kernel, two-pass sizing: first-pass slabs hold 1/div of the worst case
+    bool first_pass_div_pinned = false;  // set by fcd_debug_set_first_pass_divisor: no adaptation
     // grow-only device workspace (tree arenas, staging for *_host calls)
     void *arena = nullptr;
     size_t arena_bytes = 0;

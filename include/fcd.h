@@ -145,8 +145,10 @@ const char *fcd_status_string(int status);               /* exact SearchError Di
 int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes);
 /* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
  * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
- * it) and decode the reads that outgrow their slab again in worst-case slabs.  A larger divisor makes that
- * retry path run on small inputs (tests). */
+ * it) and decode the reads that outgrow their slab again in worst-case slabs carved from the same arena.  A
+ * job in which more than a quarter of the reads overflow switches the handle to worst-case slabs for later
+ * jobs.  A larger divisor makes the retry path run on small inputs (tests) and pins it; 0 restores the
+ * adaptive default. */
 int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor);
 /* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP
  * events on the stream the kernels were launched on; <0 if unavailable */

@@ -143,9 +143,14 @@ def test_lane_two_pass_retry(fcd):
         for beam, thr in ((32, 0.0), (20, 0.1), (64, 0.0)):
             check_beam(fcd, x, beam, thr, lengths=lengths, kernel=fcd.KERNEL_LANE)
             check_beam(fcd, x, beam, thr, lengths=lengths, kernel=fcd.KERNEL_AUTO)
+        # default sizing (half the worst case, adaptive): at threshold 0 every extension creates a node, every
+        # full-length read overflows, and the handle sizes the NEXT job for the worst case -- same results
+        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
+        for _ in range(2):
+            check_beam(fcd, x, 32, 0.0, lengths=lengths, kernel=fcd.KERNEL_LANE)
     finally:
         h.set_workspace_limit(0)
-        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 2))
+        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
 
 
 @pytest.mark.parametrize("kernel", KERNELS)
