@@ -110,6 +110,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     static_assert(HAS_SCRATCH || NIDLE >= 1, "no lane left to absorb idle pushes");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
+    __shared__ int s_srcs[kWavesPerBlock][RPW * 16];  // per half: entry r = the lane whose candidate took rank r
     int n_amb = 0, n_crit = 0;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t cyc_last = 0;
@@ -145,6 +146,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const bool collapse = !CRF && p.a.collapse != 0;
     const float thr = p.a.thr;
     uint64_t *keys = s_keys[wave];
+    int *srcs = s_srcs[wave] + (hbase ? 16 : 0);
+    if (lane < RPW * 16) s_srcs[wave][lane] = 0;
 
     const int64_t local = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW + (lane / HALF);
     const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
@@ -249,14 +252,21 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         FCD_STAMP(now, lp);
         cyc_last = (uint32_t)now;
     }
+    // The row values a lane needs -- column 0 (the blank) on a slot's own lane, the label's column on a child
+    // lane, and the tip's column -- are fetched one step AHEAD, as soon as the next beam's tips are known: the two
+    // ds_bpermutes then travel under the divisions instead of heading the next step's dependent chain.
+    auto fetch_row = [&](float &o_pk, float &o_ptip) {
+        const int rbase = hbase + g * E + (S > 0 ? state * N : 0);
+        o_pk = bpermf(rbase + (is_child ? k : 0), win[0]);
+        o_ptip = CRF ? 0.0f : __int_as_float(__builtin_amdgcn_ds_bpermute((rbase << 2) + tipf, __float_as_int(win[0])));
+    };
+    float pk_next = 0.0f, ptip_next = 0.0f;
+    if (!GATHER) fetch_row(pk_next, ptip_next);
     for (int t = 0; t < Tmax; ++t) {
         const bool act = alive && t < T;
-        // ---- the three row values this lane needs ----
-        const int rbase = hbase + g * E + (S > 0 ? state * N : 0);
-        // one fetch serves both kinds of lane: column 0 (the blank) on a slot's own lane, the label's column on a child lane
-        float pk = GATHER ? rowv : bpermf(rbase + (is_child ? k : 0), win[0]);
+        float pk = GATHER ? rowv : pk_next;
         const float pr0 = pk;
-        const float ptip = CRF ? 0.0f : __int_as_float(__builtin_amdgcn_ds_bpermute((rbase << 2) + tipf, __float_as_int(win[0])));
+        const float ptip = ptip_next;
         stamp_f(0, pk);  // loop overhead + posterior row
         if (!GATHER && ++g == RPR) {
             g = 0;
@@ -404,8 +414,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // field of a child entry (kInBeam == 16 << kSlotShift), so following an entry needs no compare
         static_assert(kInBeam == (16 << kSlotShift) && kSlotMask == 15, "child-entry bit layout");
         const int selflag = sel ? (rank | 16) : 0;
+        // Survivor table: entry r = the lane whose candidate took rank r.  LDS executes a wavefront's operations
+        // in order, so the store, the read-back and the two look-ups below share ONE round trip (a ds_permute
+        // to the new slot followed by a broadcast to its group were two dependent ones).
+        if (sel) srcs[rank] = lane;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int fate = bperm(hbase + mslot * GW, selflag);
         const int own = bperm(grp0, selflag);  // ... and this group's own candidate?
+        const int src = srcs[i];      // every lane of new group i knows its source lane (stale beyond the new beam: unused)
+        const int src_top = srcs[0];  // ... and where the best candidate sits
         // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
         // its row is in HBM); read off the entry BEFORE it is marked below
         const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
@@ -426,8 +445,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
         stamp_i(4, child);  // fate of every child entry, row eviction
         // ---- gather the survivors into rank order ----
-        const int src0 = perm(sel ? hbase + rank * GW : dummy, lane);
-        const int src = bperm(grp0, src0);  // every lane of new group s knows its source lane
         const int tipfc = is_self ? tipf : (k << 2);
         const int depc = depth + (is_child ? 1 : 0);
         const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
@@ -441,6 +458,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const int n_state = CRF ? bperm(src, statec) : 0;
         const int n_jump = bperm(src, jumpc);
         int n_child = bperm(src + k, child);  // meaningful when the source is a self lane
+        const float top = bpermf(src_top, prob);  // beam[0].probability() :278 = its candidate's label + gap probability
         stamp_f(5, n_lp);  // survivors gathered into rank order
         const int n_kind = n_meta & 3;
         const bool ngrp = go && i < Bn;
@@ -460,8 +478,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             if (reload) n_child = e;
         }
         if (CRF && go) state = n_state;  // < S: (s*4) % 4 + l = l for (N, S) = (5, 4); masked when GATHER
+        if (go) tipf = n_meta & 0x1C;
         if (GATHER) rowv = gather_row(t + 1);  // in flight during the divisions below
-        const float top = bpermf(hbase, n_lp + n_gp);  // beam[0].probability() :278
+        else fetch_row(pk_next, ptip_next);    // (the FIFO was already advanced to step t + 1 above)
         // Every lane of a group would compute the same two IEEE quotients: lane k = 1 divides the gap
         // probability, the others the label probability -- one division per lane -- and the group shares them.
         const float quot = (k == 1 ? n_gp : n_lp) / top;
@@ -470,7 +489,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             node = n_node;
             lp = q_lp;
             gp = q_gp;
-            tipf = n_meta & 0x1C;
             depth = n_meta >> 5;
             jump = n_jump;
             child = n_child;

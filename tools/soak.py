@@ -11,15 +11,29 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 import numpy as np
 
+import signal
+
 import fast_ctc_decode_amd as fcd
 import test_gpu_parity as tp
+
+STATE = {"done": 0, "bad": 0, "which": ""}
+
+
+def _on_term(signum, frame):  # `timeout` ends an open-ended soak: say how far it got
+    print("soak %s (stopped by signal): %d seeds, %d failures" % (STATE["which"], STATE["done"], STATE["bad"]), flush=True)
+    os._exit(1 if STATE["bad"] else 0)
+
+
+signal.signal(signal.SIGTERM, _on_term)
 
 
 def other(which, n, first):
     import test_gpu_duplex as td
     bad = 0
     t0 = time.time()
+    STATE["which"] = which
     for seed in range(first, first + n):
+        STATE["done"], STATE["bad"] = seed - first, bad
         try:
             if which == "crf":
                 tp.crf_fuzz_seed(fcd, seed)
@@ -81,7 +95,9 @@ def main():
         return other(which, n, first)
     bad = 0
     t0 = time.time()
+    STATE["which"] = which
     for seed in range(first, first + n):
+        STATE["done"], STATE["bad"] = seed - first, bad
         x, beam, thr, collapse, lengths = tp._fuzz_case(seed)
         for kernel in (0, 1, 2, 3, 4):
             try:
