@@ -17,6 +17,8 @@ from .api import (  # noqa: F401
     beam_search_duplex_batch,
     beam_search_duplex_batch_raw,
     set_duplex_logadd_mode,
+    set_coalescing,
+    coalescing_stats,
     crf_beam_search,
     crf_beam_search_batch,
     crf_beam_search_batch_raw,

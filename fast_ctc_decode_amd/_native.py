@@ -33,6 +33,8 @@ SYMBOLS = [
     "fcd_duplex_envelope_dev", "fcd_duplex_envelope_host",
     "fcd_logspace_probe_dev", "fcd_phred",
     "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
+    "fcd_coalescer_create", "fcd_coalescer_destroy", "fcd_coalescer_beam_search", "fcd_coalescer_viterbi_search",
+    "fcd_coalescer_stats", "fcd_coalescer_last_error",
 ]
 
 
@@ -132,6 +134,12 @@ def bind(lib):
     lib.fcd_unpack_results_dev.argtypes = [P, P, i64, P, RP]
     lib.fcd_phred.argtypes = [f32, f32, f32]
     lib.fcd_phred.restype = C.c_uint32
+    lib.fcd_coalescer_create.argtypes = [i32, i32, i32, C.POINTER(P)]
+    lib.fcd_coalescer_destroy.argtypes = [P]
+    lib.fcd_coalescer_beam_search.argtypes = [P, BP, i64, f32, i32, RP]
+    lib.fcd_coalescer_viterbi_search.argtypes = [P, BP, i32, RP]
+    lib.fcd_coalescer_stats.argtypes = [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
+    lib.fcd_coalescer_last_error.restype = C.c_char_p
     return lib
 
 
@@ -188,6 +196,53 @@ class Handle:
             self.close()
         except Exception:
             pass
+
+
+class Coalescer:
+    """fcd_coalescer (csrc/coalesce.hip): concurrent per-read calls -> batched launches."""
+
+    def __init__(self, device=0, max_batch=256, max_wait_us=0):
+        self.lib = load()
+        self.ptr = C.c_void_p()
+        rc = self.lib.fcd_coalescer_create(int(device), int(max_batch), int(max_wait_us), C.byref(self.ptr))
+        if rc != OK:
+            raise NativeError("fcd_coalescer_create(device=%d) failed with %d: no usable gfx950 device -- this "
+                              "library has no CPU fallback" % (device, rc))
+        self._users = 0
+        self._users_lock = threading.Lock()
+
+    def check(self, rc):
+        if rc != OK:
+            msg = self.lib.fcd_coalescer_last_error()
+            raise NativeError("libfcd_hip error %d: %s" % (rc, msg.decode() if msg else ""))
+
+    def __enter__(self):  # a call's hold on the coalescer: close() waits for the holders
+        with self._users_lock:
+            self._users += 1
+        return self
+
+    def __exit__(self, *exc):
+        with self._users_lock:
+            self._users -= 1
+        return False
+
+    def stats(self):
+        a, b, c = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+        self.check(self.lib.fcd_coalescer_stats(self.ptr, C.byref(a), C.byref(b), C.byref(c)))
+        return {"calls": int(a.value), "launches": int(b.value), "largest_batch": int(c.value)}
+
+    def close(self):
+        import time
+        if self.ptr:
+            while True:
+                with self._users_lock:
+                    if self._users == 0:
+                        break
+                time.sleep(0.001)
+            rc = self.lib.fcd_coalescer_destroy(self.ptr)
+            if rc != OK:
+                raise NativeError("fcd_coalescer_destroy: calls are still in flight")
+            self.ptr = C.c_void_p()
 
 
 _tls = threading.local()

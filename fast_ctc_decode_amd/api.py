@@ -136,6 +136,29 @@ def _qual_chars(probs, qscale, qbias):
     return "".join(chr(lib.fcd_phred(float(p), float(qscale), float(qbias))) for p in probs)
 
 
+_coalescer = None
+
+
+def set_coalescing(max_batch=256, max_wait_us=0, device=0):
+    """Route the per-read `viterbi_search` / `beam_search` calls of ALL threads through one coalescer
+    (include/fcd.h, csrc/coalesce.hip): calls that are in flight at the same time are decoded by one batched
+    launch instead of one single-wavefront launch each.  Results do not change.  `max_batch=0` switches it
+    off again.  Not in the reference (which has no batch notion); meant for callers that keep its per-read,
+    many-threads calling pattern."""
+    global _coalescer
+    old, _coalescer = _coalescer, None
+    if old is not None:
+        old.close()
+    if max_batch:
+        _coalescer = nat.Coalescer(device, max_batch, max_wait_us)
+
+
+def coalescing_stats():
+    """{'calls', 'launches', 'largest_batch'} of the active coalescer, or None."""
+    c = _coalescer
+    return None if c is None else c.stats()
+
+
 def viterbi_search(network_output, alphabet, qstring=False, qscale=1.0, qbias=0.0,
                    collapse_repeats=True):
     """Greedy (best-path) CTC decode.  Mirrors src/lib.rs:170-212 -> search.rs:320-383.
@@ -148,11 +171,17 @@ def viterbi_search(network_output, alphabet, qstring=False, qscale=1.0, qbias=0.
     if x.shape[0] == 0:
         raise RuntimeError("network_output is empty (the reference asserts and aborts here)")
     x = _dense(x)
-    h = nat.default_handle()
     out = _HostOut(1, x.shape[0], want_qual=bool(qstring))
     b = _host_batch(x[None], False)
-    h.check(h.lib.fcd_viterbi_search_host(h.ptr, C.byref(b), int(bool(collapse_repeats)),
-                                          C.byref(out.res)))
+    co = _coalescer
+    if co is not None:
+        with co:
+            co.check(co.lib.fcd_coalescer_viterbi_search(co.ptr, C.byref(b), int(bool(collapse_repeats)),
+                                                         C.byref(out.res)))
+    else:
+        h = nat.default_handle()
+        h.check(h.lib.fcd_viterbi_search_host(h.ptr, C.byref(b), int(bool(collapse_repeats)),
+                                              C.byref(out.res)))
     n = int(out.out_len[0])
     seq = "".join(alpha[l] for l in out.labels[0, :n])
     if qstring:
@@ -167,12 +196,18 @@ def beam_search(network_output, alphabet, beam_size=5, beam_cut_threshold=0.0,
     alpha = _seq_to_vec(alphabet)
     _check_beam_args(len(alpha), x.shape[1], beam_size, beam_cut_threshold)
     x = _dense(x)
-    h = nat.default_handle()
     out = _HostOut(1, x.shape[0])
     b = _host_batch(x[None], False)
-    h.check(h.lib.fcd_beam_search_host(h.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
-                                       int(bool(collapse_repeats)), nat.KERNEL_AUTO,
-                                       C.byref(out.res)))
+    co = _coalescer
+    if co is not None:
+        with co:
+            co.check(co.lib.fcd_coalescer_beam_search(co.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
+                                                      int(bool(collapse_repeats)), C.byref(out.res)))
+    else:
+        h = nat.default_handle()
+        h.check(h.lib.fcd_beam_search_host(h.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
+                                           int(bool(collapse_repeats)), nat.KERNEL_AUTO,
+                                           C.byref(out.res)))
     _raise_status(int(out.status[0]))
     n = int(out.out_len[0])
     return "".join(alpha[l] for l in out.labels[0, :n]), [int(p) for p in out.path[0, :n]]

@@ -1,0 +1,320 @@
+// coalesce.hip -- a front door for PER-READ callers (host code only; layered on the public C ABI).
+//
+// The reference decodes one read per call (src/lib.rs:170-212 viterbi_search, :318-365 beam_search) and
+// releases the GIL around the search (:199, :353) precisely so that callers -- basecallers -- can run it from
+// many threads.  On a GPU a lone read is one wavefront: every such call pays a launch, two copies and a
+// stream synchronisation for 1/2048th of the machine, and HIP multiplexes the callers' streams onto a handful
+// of hardware queues, so concurrent single-read launches mostly run one after another.
+//
+// A coalescer turns concurrent calls into batches without changing the callers: the first thread to arrive
+// becomes the LEADER, takes every compatible request that is pending (same search, alphabet size, beam size,
+// threshold, collapse flag), decodes them with ONE batched launch (ragged lengths) on the coalescer's own
+// handle and hands each caller its own result; the callers that arrive while a launch is in flight form the
+// next batch.  A launch takes about as long for one read as for a thousand (a read is one wavefront), so the
+// policy is "batch first": a leader takes everything that is pending, and before launching it waits briefly
+// for the callers of the PREVIOUS batches to come back with their next read -- until as many requests are
+// pending as recent batches held, for at most max_wait_us (0, the default: an eighth of the last launch's
+// duration, at most 1 ms).  A lone caller never waits (recent batches held one read).  Up to kLanes leaders
+// work at the same time, each with its own handle (stream, workspace) and pinned staging buffers, but only while
+// fewer than kLanes reads are in flight: a handful of callers overlap their launches the way independent
+// per-read calls would, many callers share big batches instead of fragmenting them.
+// Results are those of the batched entry points, i.e. bit-identical to the per-read calls.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <deque>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/fcd.h"
+
+namespace {
+
+enum Kind { kBeam = 0, kViterbi = 1 };
+
+struct Req {
+    int kind;
+    const fcd_batch *in;
+    int64_t beam;
+    float thr;
+    int collapse;
+    const fcd_result *out;
+    int rc = FCD_OK;
+    bool done = false;
+    std::string err;
+    std::chrono::steady_clock::time_point arrived;
+};
+
+bool compatible(const Req &a, const Req &b) {
+    return a.kind == b.kind && a.in->N == b.in->N && a.beam == b.beam && a.collapse == b.collapse &&
+           std::memcmp(&a.thr, &b.thr, sizeof(float)) == 0;
+}
+
+thread_local std::string t_error;
+
+constexpr int kLanes = 4;  // concurrent leaders (HIP multiplexes streams onto about this many hardware queues)
+
+// a grow-only pinned host buffer (page-locked memory is copied by DMA straight from / to the caller's pages)
+struct Pinned {
+    void *p = nullptr;
+    size_t cap = 0;
+    void *need(size_t bytes) {
+        if (bytes > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = bytes + bytes / 2 + 4096;
+            if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) {
+                p = nullptr;
+                return nullptr;
+            }
+            cap = want;
+        }
+        return p;
+    }
+    ~Pinned() {
+        if (p) (void)hipHostFree(p);
+    }
+};
+
+// one leader's working set
+struct Lane {
+    fcd_handle *h = nullptr;
+    bool busy = false;
+    Pinned x, qual, labels, path, out_len, status, lengths;
+};
+
+}  // namespace
+
+struct fcd_coalescer {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Req *> pending;
+    Lane lanes[kLanes];
+    int device = 0;
+    int max_batch = 256;
+    int max_wait_us = 0;
+    int64_t n_calls = 0, n_launches = 0, largest = 0;
+    int64_t in_flight = 0;     // reads in running batches
+    int64_t recent = 1;        // decaying maximum of recent batch sizes: how much company is worth waiting for
+    int64_t last_launch_us = 0;
+};
+
+namespace {
+
+// one batched launch for `batch` (all compatible) on lane `L`; fills every request's outputs and rc
+void run_batch(Lane &L, std::vector<Req *> &batch) {
+    const int64_t n = (int64_t)batch.size();
+    const Req &first = *batch[0];
+    const int64_t N = first.in->N;
+    int64_t Tmax = 1;
+    bool want_path = false, want_qual = false;
+    for (Req *r : batch) {
+        Tmax = std::max<int64_t>(Tmax, r->in->T);
+        want_path = want_path || r->out->path;
+        want_qual = want_qual || r->out->qual;
+    }
+    float *x = static_cast<float *>(L.x.need((size_t)(n * Tmax * N) * sizeof(float)));
+    uint8_t *labels = static_cast<uint8_t *>(L.labels.need((size_t)(n * Tmax)));
+    uint32_t *out_len = static_cast<uint32_t *>(L.out_len.need((size_t)n * sizeof(uint32_t)));
+    int32_t *status = static_cast<int32_t *>(L.status.need((size_t)n * sizeof(int32_t)));
+    int64_t *lengths = static_cast<int64_t *>(L.lengths.need((size_t)n * sizeof(int64_t)));
+    uint32_t *path = want_path ? static_cast<uint32_t *>(L.path.need((size_t)(n * Tmax) * sizeof(uint32_t))) : nullptr;
+    float *qual = want_qual ? static_cast<float *>(L.qual.need((size_t)(n * Tmax) * sizeof(float))) : nullptr;
+    int rc = FCD_OK;
+    std::string err;
+    if (!x || !labels || !out_len || !status || !lengths || (want_path && !path) || (want_qual && !qual)) {
+        rc = FCD_E_NOMEM;
+        err = "coalescer: cannot allocate pinned staging memory";
+    }
+    if (rc == FCD_OK) {
+        for (int64_t i = 0; i < n; ++i) {
+            const fcd_batch *b = batch[i]->in;
+            float *dst = x + i * Tmax * N;
+            lengths[i] = b->T;
+            if (b->stride_n == 1 && b->stride_t == N) {
+                std::memcpy(dst, b->post, (size_t)(b->T * N) * sizeof(float));
+            } else {
+                for (int64_t t = 0; t < b->T; ++t)
+                    for (int64_t j = 0; j < N; ++j) dst[t * N + j] = b->post[t * b->stride_t + j * b->stride_n];
+            }
+        }
+        fcd_batch in{};
+        in.post = x;
+        in.n_reads = n;
+        in.T = Tmax;
+        in.S = 1;
+        in.N = N;
+        in.stride_read = Tmax * N;
+        in.stride_t = N;
+        in.stride_n = 1;
+        in.lengths = lengths;
+        fcd_result out{};
+        out.labels = labels;
+        out.path = path;
+        out.qual = qual;
+        out.out_len = out_len;
+        out.status = status;
+        out.out_stride = Tmax;
+        if (first.kind == kBeam)
+            rc = fcd_beam_search_host(L.h, &in, first.beam, first.thr, first.collapse, FCD_KERNEL_AUTO, &out);
+        else
+            rc = fcd_viterbi_search_host(L.h, &in, first.collapse, &out);
+        if (rc != FCD_OK) err = fcd_last_error(L.h);
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        Req *r = batch[i];
+        r->rc = rc;
+        r->err = err;
+        if (rc != FCD_OK) continue;
+        const fcd_result *o = r->out;
+        const size_t len = std::min<size_t>(out_len[i], (size_t)std::max<int64_t>(o->out_stride, 0));
+        if (o->out_len) *o->out_len = out_len[i];
+        if (o->status) *o->status = status[i];
+        std::memcpy(o->labels, labels + i * Tmax, len);
+        if (o->path) std::memcpy(o->path, path + i * Tmax, len * sizeof(uint32_t));
+        if (o->qual) std::memcpy(o->qual, qual + i * Tmax, len * sizeof(float));
+    }
+}
+
+int submit(fcd_coalescer *c, Req &req) {
+    if (!c || !req.in || !req.out || !req.in->post || !req.out->labels) {
+        t_error = "coalescer: null argument";
+        return FCD_E_INVALID;
+    }
+    if (req.in->n_reads != 1 || req.in->S > 1 || req.in->T < 0 || req.in->N < 1 || req.in->stride_t < 0 ||
+        req.in->stride_n < 0 || req.out->out_stride < req.in->T || req.in->lengths) {
+        t_error = "coalescer: expects exactly one (T, N) read with non-negative strides and out_stride >= T";
+        return FCD_E_INVALID;
+    }
+    req.arrived = std::chrono::steady_clock::now();
+    std::unique_lock<std::mutex> lk(c->mu);
+    c->pending.push_back(&req);
+    ++c->n_calls;
+    c->cv.notify_all();  // a leader waiting for company looks again
+    while (!req.done) {
+        int li = -1;
+        for (int j = 0; j < kLanes && li < 0; ++j)
+            if (!c->lanes[j].busy) li = j;
+        // my request may already be in another leader's batch; lead only while something is pending, and side
+        // by side with other leaders only while little is in flight (batch first, see the header)
+        if (li < 0 || c->pending.empty() || (c->in_flight > 0 && c->in_flight >= kLanes)) {
+            c->cv.wait(lk);
+            continue;
+        }
+        // become a leader: serve the oldest pending request's group (possibly not my own: then go round again)
+        Lane &L = c->lanes[li];
+        L.busy = true;
+        {
+            const int64_t budget_us = c->max_wait_us > 0 ? c->max_wait_us
+                                                         : std::min<int64_t>(c->last_launch_us / 8, 1000);
+            const int64_t target = std::min<int64_t>(c->recent, c->max_batch);
+            const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(budget_us);
+            while (!c->pending.empty() && (int64_t)c->pending.size() < target &&
+                   std::chrono::steady_clock::now() < deadline)
+                c->cv.wait_until(lk, deadline);
+        }
+        std::vector<Req *> batch;
+        if (!c->pending.empty()) {
+            batch.push_back(c->pending.front());
+            c->pending.pop_front();
+            for (auto it = c->pending.begin(); it != c->pending.end() && (int)batch.size() < c->max_batch;) {
+                if (compatible(*batch[0], **it)) {
+                    batch.push_back(*it);
+                    it = c->pending.erase(it);
+                } else {
+                    ++it;
+                }
+            }
+        }
+        if (!batch.empty()) {
+            const int64_t nb = (int64_t)batch.size();
+            ++c->n_launches;
+            c->largest = std::max(c->largest, nb);
+            c->recent = std::max(nb, c->recent - (c->recent + 3) / 4);
+            c->in_flight += nb;
+            int rc = FCD_OK;
+            if (!L.h) rc = fcd_create(c->device, &L.h);  // lanes beyond the first get their handle on first use
+            lk.unlock();
+            const auto t0 = std::chrono::steady_clock::now();
+            if (rc == FCD_OK) {
+                run_batch(L, batch);
+            } else {
+                for (Req *r : batch) {
+                    r->rc = rc;
+                    r->err = "coalescer: fcd_create failed";
+                }
+            }
+            const int64_t us = std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - t0).count();
+            lk.lock();
+            c->last_launch_us = us;
+            c->in_flight -= nb;
+            for (Req *r : batch) r->done = true;
+        }
+        L.busy = false;
+        c->cv.notify_all();
+    }
+    if (req.rc != FCD_OK) t_error = req.err;
+    return req.rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fcd_coalescer_create(int device, int max_batch, int max_wait_us, fcd_coalescer **out) {
+    if (!out || max_batch < 1 || max_wait_us < 0) return FCD_E_INVALID;
+    *out = nullptr;
+    fcd_handle *h = nullptr;
+    const int rc = fcd_create(device, &h);
+    if (rc != FCD_OK) return rc;
+    fcd_coalescer *c = new fcd_coalescer();
+    c->lanes[0].h = h;
+    c->device = device;
+    c->max_batch = max_batch;
+    c->max_wait_us = max_wait_us;
+    *out = c;
+    return FCD_OK;
+}
+
+int fcd_coalescer_destroy(fcd_coalescer *c) {
+    if (!c) return FCD_E_INVALID;
+    {
+        std::lock_guard<std::mutex> g(c->mu);
+        bool busy = !c->pending.empty();
+        for (const Lane &L : c->lanes) busy = busy || L.busy;
+        if (busy) return FCD_E_INVALID;  // calls still in flight
+    }
+    for (Lane &L : c->lanes)
+        if (L.h) fcd_destroy(L.h);
+    delete c;
+    return FCD_OK;
+}
+
+int fcd_coalescer_beam_search(fcd_coalescer *c, const fcd_batch *read, int64_t beam_size, float beam_cut_threshold,
+                              int collapse_repeats, const fcd_result *out) {
+    Req r{kBeam, read, beam_size, beam_cut_threshold, collapse_repeats ? 1 : 0, out};
+    return submit(c, r);
+}
+
+int fcd_coalescer_viterbi_search(fcd_coalescer *c, const fcd_batch *read, int collapse_repeats, const fcd_result *out) {
+    Req r{kViterbi, read, 0, 0.0f, collapse_repeats ? 1 : 0, out};
+    return submit(c, r);
+}
+
+int fcd_coalescer_stats(fcd_coalescer *c, int64_t *n_calls, int64_t *n_launches, int64_t *largest_batch) {
+    if (!c) return FCD_E_INVALID;
+    std::lock_guard<std::mutex> g(c->mu);
+    if (n_calls) *n_calls = c->n_calls;
+    if (n_launches) *n_launches = c->n_launches;
+    if (largest_batch) *largest_batch = c->largest;
+    return FCD_OK;
+}
+
+const char *fcd_coalescer_last_error(void) { return t_error.c_str(); }
+
+}  // extern "C"

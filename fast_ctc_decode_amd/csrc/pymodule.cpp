@@ -9,7 +9,10 @@
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 
+#include <atomic>
 #include <charconv>
+#include <chrono>
+#include <thread>
 #include <cstdlib>
 #include <cstdint>
 #include <stdexcept>
@@ -41,6 +44,26 @@ fcd_handle *thread_handle() {
                                      std::to_string(rc) + "); this module has no CPU fallback");
     }
     return th.h;
+}
+
+// set_coalescing(): when non-null, per-read viterbi_search / beam_search calls of every thread go through it
+// (include/fcd.h: concurrent calls share batched launches).  Swapped under the GIL; a replaced coalescer is
+// destroyed only once its calls have drained.
+std::atomic<fcd_coalescer *> g_coalescer{nullptr};
+std::atomic<int> g_coalescer_users{0};
+struct CoalescerUse {  // a call's hold on whichever coalescer was current when it started
+    fcd_coalescer *co;
+    CoalescerUse() {
+        g_coalescer_users.fetch_add(1);
+        co = g_coalescer.load();
+    }
+    ~CoalescerUse() { g_coalescer_users.fetch_sub(1); }
+};
+
+void check_rc_coalescer(int rc) {
+    if (rc != FCD_OK)
+        throw std::runtime_error(std::string("libfcd_hip error ") + std::to_string(rc) + ": " +
+                                 fcd_coalescer_last_error());
 }
 
 void check_rc(fcd_handle *h, int rc) {
@@ -204,12 +227,21 @@ py::tuple viterbi_search(const py::object &network_output, const py::object &alp
     Out o(x.shape(0), true, qstring);
     fcd_batch b = batch2(x);
     int rc;
-    fcd_handle *h = thread_handle();
-    {
-        py::gil_scoped_release nogil;
-        rc = fcd_viterbi_search_host(h, &b, collapse_repeats ? 1 : 0, &o.res);
+    CoalescerUse use;
+    if (fcd_coalescer *co = use.co) {
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_coalescer_viterbi_search(co, &b, collapse_repeats ? 1 : 0, &o.res);
+        }
+        check_rc_coalescer(rc);
+    } else {
+        fcd_handle *h = thread_handle();
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_viterbi_search_host(h, &b, collapse_repeats ? 1 : 0, &o.res);
+        }
+        check_rc(h, rc);
     }
-    check_rc(h, rc);
     std::string seq;
     for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
     if (qstring)
@@ -227,13 +259,23 @@ py::tuple beam_search(const py::object &network_output, const py::object &alphab
     Out o(x.shape(0), true, false);
     fcd_batch b = batch2(x);
     int rc;
-    fcd_handle *h = thread_handle();
-    {
-        py::gil_scoped_release nogil;
-        rc = fcd_beam_search_host(h, &b, (int64_t)beam_size, beam_cut_threshold,
-                                  collapse_repeats ? 1 : 0, FCD_KERNEL_AUTO, &o.res);
+    CoalescerUse use;
+    if (fcd_coalescer *co = use.co) {
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_coalescer_beam_search(co, &b, (int64_t)beam_size, beam_cut_threshold,
+                                           collapse_repeats ? 1 : 0, &o.res);
+        }
+        check_rc_coalescer(rc);
+    } else {
+        fcd_handle *h = thread_handle();
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_beam_search_host(h, &b, (int64_t)beam_size, beam_cut_threshold,
+                                      collapse_repeats ? 1 : 0, FCD_KERNEL_AUTO, &o.res);
+        }
+        check_rc(h, rc);
     }
-    check_rc(h, rc);
     raise_status(o.status);
     std::string seq;
     for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
@@ -451,6 +493,38 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
           "set_duplex_logadd_mode(mode): 'logsumexp' (default; the reference built with --no-default-features) or "
           "'max' (the reference's default `fastexp` feature, i.e. what the PyPI wheels compute)");
     m.def("_set_duplex_logadd_mode", set_mode);  // earlier name, kept for the tests
+    m.def(
+        "set_coalescing",
+        [](int max_batch, int max_wait_us, int device) {
+            fcd_coalescer *fresh = nullptr;
+            if (max_batch > 0) {
+                const int rc = fcd_coalescer_create(device, max_batch, max_wait_us, &fresh);
+                if (rc != FCD_OK || !fresh)
+                    throw std::runtime_error("fast_ctc_decode: no usable gfx950 device (fcd_coalescer_create failed with " +
+                                             std::to_string(rc) + "); this module has no CPU fallback");
+            }
+            fcd_coalescer *old = g_coalescer.exchange(fresh);
+            if (old) {
+                py::gil_scoped_release nogil;  // calls that may still hold the old pointer finish first
+                while (g_coalescer_users.load() != 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
+                fcd_coalescer_destroy(old);
+            }
+        },
+        "max_batch"_a = 256, "max_wait_us"_a = 0, "device"_a = 0,
+        "Decode concurrent per-read viterbi_search / beam_search calls (any threads) with shared batched launches; "
+        "max_batch=0 switches it off.  Results do not change.  (Not in the reference.)");
+    m.def("coalescing_stats", []() -> py::object {
+        CoalescerUse use;
+        fcd_coalescer *co = use.co;
+        if (!co) return py::none();
+        int64_t a = 0, b = 0, c = 0;
+        fcd_coalescer_stats(co, &a, &b, &c);
+        py::dict d;
+        d["calls"] = a;
+        d["launches"] = b;
+        d["largest_batch"] = c;
+        return std::move(d);
+    });
     if (const char *env = std::getenv("FCD_DUPLEX_LOGADD")) set_mode(env);
     m.attr("__version__") = "0.3.7";  // src/lib.rs:626 (CARGO_PKG_VERSION of the mirrored reference)
 }

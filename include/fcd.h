@@ -277,6 +277,30 @@ int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, 
 int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, uint64_t *offsets,
                            const fcd_result *out);
 
+/* ---- coalescing front door for per-read callers (csrc/coalesce.hip) --------------------------------------
+ * The reference decodes ONE read per call and releases the GIL around the search so that callers can run it
+ * from many threads (src/lib.rs:199 viterbi_search, :353 beam_search).  On a GPU a lone read is one wavefront;
+ * a coalescer turns CONCURRENT per-read calls into batched launches without changing the callers: the first
+ * thread to arrive decodes every compatible pending request (same search, alphabet size, beam size, threshold,
+ * collapse flag) with one ragged batch on one of the coalescer's own handles; whatever arrives while that launch
+ * is in flight forms the next batch.  Before launching, a leader waits briefly for the callers of the previous
+ * batches to come back (until as many requests are pending as recent batches held): at most max_wait_us, or,
+ * with max_wait_us = 0, an eighth of the last launch's duration (<= 1 ms); a lone caller never waits.  A few
+ * leaders run side by side while fewer than four reads are in flight, so a handful of callers overlap like
+ * independent per-read calls.  Results are bit-identical to the per-read calls.
+ * `read` must describe exactly one (T, N) matrix (n_reads = 1, S <= 1, non-negative strides, no lengths);
+ * `out` is a one-read fcd_result with out_stride >= T.  Blocking; any number of threads.  On failure the text
+ * is in fcd_coalescer_last_error() (per calling thread). */
+typedef struct fcd_coalescer fcd_coalescer;
+int fcd_coalescer_create(int device, int max_batch, int max_wait_us, fcd_coalescer **out);
+int fcd_coalescer_destroy(fcd_coalescer *c);   /* FCD_E_INVALID while calls are in flight */
+int fcd_coalescer_beam_search(fcd_coalescer *c, const fcd_batch *read, int64_t beam_size,
+                              float beam_cut_threshold, int collapse_repeats, const fcd_result *out);
+int fcd_coalescer_viterbi_search(fcd_coalescer *c, const fcd_batch *read, int collapse_repeats,
+                                 const fcd_result *out);
+int fcd_coalescer_stats(fcd_coalescer *c, int64_t *n_calls, int64_t *n_launches, int64_t *largest_batch);
+const char *fcd_coalescer_last_error(void);
+
 /* ---- host-side helpers shared with the language bindings ---- */
 /* phred quality character code point for a probability (src/search.rs:31-36) */
 uint32_t fcd_phred(float prob, float qscale, float qbias);

@@ -68,6 +68,9 @@ hipError_t hipSetDevice(int d);
 hipError_t hipGetDevice(int *d);
 hipError_t hipMalloc(void **p, size_t n);
 hipError_t hipFree(void *p);
+constexpr unsigned hipHostMallocDefault = 0;
+hipError_t hipHostMalloc(void **p, size_t n, unsigned flags);
+hipError_t hipHostFree(void *p);
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);

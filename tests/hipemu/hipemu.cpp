@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <time.h>
 
+#include <mutex>
 #include <vector>
 
 namespace hipemu {
@@ -112,7 +113,12 @@ static void prepare_stack(Fiber &f) {
     f.sp = sp;
 }
 
+// kernels run to completion inside the launch call, one launch at a time: host threads that launch
+// concurrently (each on its own stream in the real runtime) simply take turns here
+static std::mutex g_launch_mutex;
+
 void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *), void *closure) {
+    std::lock_guard<std::mutex> one_at_a_time(g_launch_mutex);
     const int nthreads = (int)(block.x * block.y * block.z);
     if (nthreads <= 0 || nthreads > 1024 || (nthreads % 64) != 0) {
         fprintf(stderr, "hipemu: block of %d work-items (must be a multiple of 64, <= 1024)\n", nthreads);
@@ -215,6 +221,11 @@ hipError_t hipMalloc(void **p, size_t n) {
     return hipSuccess;
 }
 hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
+    *p = malloc(n ? n : 1);
+    return *p ? hipSuccess : hipErrorOutOfMemory;
+}
+hipError_t hipHostFree(void *p) { free(p); return hipSuccess; }
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
     *free_b = (size_t)1 << 30;  // small on purpose: exercises the chunked-workspace paths
     *total_b = (size_t)2 << 30;
