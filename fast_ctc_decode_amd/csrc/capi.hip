@@ -322,6 +322,7 @@ int fcd_destroy(fcd_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
+    if (h->pin) (void)hipHostFree(h->pin);
     if (h->lnbuf) (void)hipFree(h->lnbuf);
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
@@ -962,7 +963,30 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
         if (rc) return rc;
     }
     char *base = reinterpret_cast<char *>(h->stage);
-    {
+    // Small calls (the per-read drop-in functions: a few hundred KB) go through a page-locked mirror of the
+    // staging area: ONE DMA in, ONE out, instead of a runtime-staged copy per array from pageable memory.
+    // Large batches are copied straight from / to the caller's arrays (an extra host pass would cost more).
+    const bool pinned = used <= ((size_t)4 << 20);
+    char *pin = nullptr;
+    if (pinned) {
+        std::lock_guard<std::recursive_mutex> g(h->mu);
+        if (h->pin_bytes < used) {
+            if (h->pin) (void)hipHostFree(h->pin);
+            h->pin = nullptr;
+            h->pin_bytes = 0;
+            const size_t want = std::max<size_t>(used + used / 2, (size_t)256 << 10);
+            if (hipHostMalloc(&h->pin, want, hipHostMallocDefault) != hipSuccess) {
+                h->pin = nullptr;
+                return fail(h, FCD_E_NOMEM, "hipHostMalloc failed (staging mirror)");
+            }
+            h->pin_bytes = want;
+        }
+        pin = reinterpret_cast<char *>(h->pin);
+        if (n_in) memcpy(pin + o_in, in->post, n_in * 4);
+        if (in->lengths) memcpy(pin + o_len, in->lengths, (size_t)B * 8);
+        if (crf) memcpy(pin + o_init, c.init, n_init * 4);
+        FCD_HIP(h, hipMemcpyAsync(base, pin, o_lab, hipMemcpyHostToDevice, h->stream));  // inputs lie before o_lab
+    } else {
         std::lock_guard<std::recursive_mutex> g(h->mu);
         if (n_in) FCD_HIP(h, hipMemcpyAsync(base + o_in, in->post, n_in * 4, hipMemcpyHostToDevice, h->stream));
         if (in->lengths)
@@ -995,6 +1019,17 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     }
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (pinned) {
+        FCD_HIP(h, hipMemcpyAsync(pin + o_lab, base + o_lab, used - o_lab, hipMemcpyDeviceToHost, h->stream));
+        FCD_HIP(h, hipStreamSynchronize(h->stream));
+        memcpy(out->labels, pin + o_lab, n_out);
+        if (out->path) memcpy(out->path, pin + o_path, n_out * 4);
+        if (out->qual) memcpy(out->qual, pin + o_qual, n_out * 4);
+        memcpy(out->out_len, pin + o_olen, (size_t)B * 4);
+        if (out->status) memcpy(out->status, pin + o_stat, (size_t)B * 4);
+        if (want_amb) memcpy(out->ambiguous, pin + o_amb, (size_t)B * 8);
+        return FCD_OK;
+    }
     FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
     if (out->path) FCD_HIP(h, hipMemcpyAsync(out->path, dout.path, n_out * 4, hipMemcpyDeviceToHost, h->stream));
     if (out->qual) FCD_HIP(h, hipMemcpyAsync(out->qual, dout.qual, n_out * 4, hipMemcpyDeviceToHost, h->stream));

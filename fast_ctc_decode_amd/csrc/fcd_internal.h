@@ -179,6 +179,8 @@ struct fcd_handle {
     size_t arena_bytes = 0;
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    void *pin = nullptr;  // page-locked host mirror of `stage` for small *_host calls (one DMA each way)
+    size_t pin_bytes = 0;
     void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
     size_t lnbuf_bytes = 0;
     std::string err;
