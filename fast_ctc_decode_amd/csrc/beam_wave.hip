@@ -363,9 +363,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             }
         } else {
             // four independent compare-and-count chains (device_utils.h)
-            int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+            int r0, r1, r2, r3;
+            static_assert(NC >= 4, "at least one block of four comparands");
+            FCD_RANK4_FIRST(key, kk[0], kk[1], kk[2], kk[3], r0, r1, r2, r3);
 #pragma unroll
-            for (int u = 0; u + 4 <= NC; u += 4) FCD_RANK4(key, kk[u], kk[u + 1], kk[u + 2], kk[u + 3], r0, r1, r2, r3);
+            for (int u = 4; u + 4 <= NC; u += 4) FCD_RANK4(key, kk[u], kk[u + 1], kk[u + 2], kk[u + 3], r0, r1, r2, r3);
 #pragma unroll
             for (int u = NC & ~3; u < NC; ++u) r0 += (kk[u] > key) ? 1 : 0;
             rank = (r0 + r1) + (r2 + r3);
@@ -374,7 +376,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         stamp_i(3, rank);  // exact rank
 
         // ---- search.rs:261-277 ----
-        const uint64_t m_valid = ballot(valid);
+        // (key != 0 <=> valid && act: a vote on a compare costs one instruction, a vote on a derived flag two)
+        const uint64_t m_valid = ballot(key != 0ull);
         const int n_valid = RPW == 1 ? popc64(m_valid)
                                      : __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
         // Everything that ends a read is rare: one wave-wide test, the bookkeeping behind it.
@@ -464,7 +467,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const bool ngrp = go && i < Bn;
         if (n_kind == 1 || !is_child) n_child = -1;
         const bool reload = ngrp && n_kind == 2 && is_child;
-        if (ballot(reload) != 0ull) {
+        // (the vote is on the bare compare -- one instruction; a kind-2 record in a slot past the new beam only
+        // sends the wavefront through the rare path for nothing)
+        if (ballot(n_kind == 2) != 0ull) {
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up (rare path)
             int e = -1;

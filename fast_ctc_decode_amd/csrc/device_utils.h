@@ -58,6 +58,27 @@ __device__ __forceinline__ int32_t load_i32_l2(const int32_t *p) {
     } while (0)
 #endif
 
+// First block of a rank: the four accumulators START here (r_j = (k_j > key)), read off a shared zero register
+// instead of being cleared one by one.
+#ifndef FCD_RANK4_FIRST
+#define FCD_RANK4_FIRST(key, ka, kb, kc, kd, r0, r1, r2, r3)                                   \
+    do {                                                                                       \
+        uint64_t m0__, m1__, m2__, m3__;                                                       \
+        const int zero__ = 0;                                                                  \
+        asm("v_cmp_gt_u64_e64 %4, %9, %8\n\t"                                                  \
+            "v_cmp_gt_u64_e64 %5, %10, %8\n\t"                                                 \
+            "v_cmp_gt_u64_e64 %6, %11, %8\n\t"                                                 \
+            "v_cmp_gt_u64_e64 %7, %12, %8\n\t"                                                 \
+            "v_addc_co_u32_e64 %0, vcc, 0, %13, %4\n\t"                                        \
+            "v_addc_co_u32_e64 %1, vcc, 0, %13, %5\n\t"                                        \
+            "v_addc_co_u32_e64 %2, vcc, 0, %13, %6\n\t"                                        \
+            "v_addc_co_u32_e64 %3, vcc, 0, %13, %7"                                             \
+            : "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3), "=&s"(m0__), "=&s"(m1__), "=&s"(m2__), "=&s"(m3__) \
+            : "v"(key), "v"(ka), "v"(kb), "v"(kc), "v"(kd), "v"(zero__)                        \
+            : "vcc");                                                                          \
+    } while (0)
+#endif
+
 // Makes a value opaque to the optimiser and pins it in vector registers (the duplex kernel's coefficient table).
 // (tests/hipemu predefines FCD_OPAQUE_V as a no-op.)
 #ifndef FCD_OPAQUE_V

@@ -24,6 +24,8 @@
 // csrc/device_utils.h: four compare-and-count steps (hand-scheduled VALU on the GPU)
 #define FCD_RANK4(key, ka, kb, kc, kd, r0, r1, r2, r3) \
     do { (r0) += (ka) > (key); (r1) += (kb) > (key); (r2) += (kc) > (key); (r3) += (kd) > (key); } while (0)
+#define FCD_RANK4_FIRST(key, ka, kb, kc, kd, r0, r1, r2, r3) \
+    do { (r0) = (ka) > (key); (r1) = (kb) > (key); (r2) = (kc) > (key); (r3) = (kd) > (key); } while (0)
 
 // ---- qualifiers -------------------------------------------------------------------------------
 #define __global__
