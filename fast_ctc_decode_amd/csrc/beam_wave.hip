@@ -30,7 +30,9 @@
 //   * survivors are gathered into rank order with ds_bpermute and divided by the top
 //     probability (:278-282, IEEE f32 division).
 //
-// Tree arena (HBM, per read): rec[node] = {parent, time<<3 | label}; rows[node] = the node's child
+// Node ids are (time step << KS) | index among the nodes created in that step: creation order, as the reference's
+// tie-break needs, with the creation time -- what `path` reports -- readable off the id itself.
+// Tree arena (HBM, per read): rec[node] = (parent + 1) << 3 | label (4 bytes); rows[node] = the node's child
 // entries (id | EVER, or -1), written once, when the node is evicted from the beam; jmp[node]
 // (written only for nodes whose depth is a multiple of 64) = the nearest proper ancestor whose depth
 // is a multiple of 64.  Every beam entry carries its own jump pointer in a register, so the final
@@ -102,6 +104,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     constexpr int RPR = HALF / E;       // rows per FIFO register
     static_assert(RPR >= 1, "one timestep must fit the lanes of a half");
     constexpr int RW = NL <= 4 ? 4 : 8; // child-row width in the arena
+    constexpr int KS = RPW == 2 ? 5 : 6;  // id slots per time step = 1 << KS >= lanes of a half >= BCAP * NL (beam_wave_id_shift)
+    static_assert((1 << KS) >= HALF && (1 << KS) >= BCAP * NL, "a step's new nodes must fit its block of ids");
     // ds_permute pushes that have nothing to say need a harmless target: the group's spare lane when it
     // has one (N < GW), otherwise one of the lanes past the last group
     static_assert(N <= GW, "a group holds the node's own slot and one lane per label");
@@ -110,7 +114,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     static_assert(HAS_SCRATCH || NIDLE >= 1, "no lane left to absorb idle pushes");
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
-    __shared__ int s_srcs[kWavesPerBlock][RPW * 16];  // per half: entry r = the lane whose candidate took rank r
+    // survivor table, per half: entry r = (byte address of the lane whose candidate took rank r) | that candidate's depth << 8
+    __shared__ int s_srcs[kWavesPerBlock][RPW * 16];
     int n_amb = 0, n_crit = 0;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t cyc_last = 0;
@@ -147,7 +152,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const float thr = p.a.thr;
     uint64_t *keys = s_keys[wave];
     int *srcs = s_srcs[wave] + (hbase ? 16 : 0);
-    if (lane < RPW * 16) s_srcs[wave][lane] = 0;
+    if (lane < RPW * 16) s_srcs[wave][lane] = 0x7FFFFF00;  // never the minimum depth; points at lane 0
 
     const int64_t local = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW + (lane / HALF);
     const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
@@ -175,11 +180,11 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // node + 1: the root (node -1) owns row 0 and needs no special case.
     const int cap = (int)p.arena.cap_nodes;
     const int64_t wslab = ((int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wave)) * RPW;
-    int2 *const rec_w = p.arena.rec + wslab * p.arena.cap_nodes;
+    int32_t *const rec_w = reinterpret_cast<int32_t *>(p.arena.rec) + wslab * p.arena.cap_nodes;
     int32_t *const jmp_w = p.arena.jmp + wslab * p.arena.cap_nodes;
     int32_t *const rows_w = p.arena.rows + wslab * p.arena.cap_nodes * RW;
     const uint32_t hoff = has_read ? (uint32_t)(lane / HALF) * (uint32_t)cap : 0u;  // this half's slab, in nodes
-    int2 *rec = rec_w + hoff;      // (used by the traceback)
+    int32_t *rec = rec_w + hoff;   // (used by the traceback)
     int32_t *jmp = jmp_w + hoff;
 
     // ---- beam state (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
@@ -190,7 +195,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     int jump = -1;  // nearest proper ancestor of `node` at a depth that is a multiple of kSeg
     int child = -1;
     int B = 1;
-    int nn = 0;
     bool alive = has_read;
     int state = 0;
     if (CRF && has_read) {
@@ -315,10 +319,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
 
         // ---- prune, first half: sort keys out, comparands back (exact rank on (probability desc, node asc)) ----
         // The key needs a node index only to break probability ties, and only its ORDER matters: a node
-        // created in this step gets nn + q here -- above every existing index and increasing with the lane,
-        // exactly like the index it is about to receive -- so the key does not wait for the numbering below.
+        // created in this step gets (t << KS) + q here -- above every existing index and increasing with the
+        // lane, exactly like the index it is about to receive -- so the key does not wait for the numbering below.
         // (A NaN key is garbage but non-zero: it only ever ranks when it is the read's lone candidate, :262.)
-        const int idk = is_self ? node : (is_new ? nn + q : cid);
+        const int idk = is_self ? node : (is_new ? (t << KS) + q : cid);
         const uint64_t key = (valid && act) ? make_key(prob, idk) : 0ull;
         keys[lane] = key;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -332,18 +336,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // ---- tree.rs:125-145 add_node: ids in (beam order, label order) == lane order; runs under the LDS reads ----
         const uint64_t m_new = ballot(is_new);
         const uint32_t w_new = RPW == 1 ? 0u : (hbase ? (uint32_t)(m_new >> 32) : (uint32_t)m_new);
-        int n_new, pre_new;
+        int pre_new;
         if (RPW == 1) {
-            n_new = popc64(m_new);
             pre_new = popc64(m_new & lanemask_lt());
         } else {
-            n_new = __builtin_popcount(w_new);
             pre_new = __builtin_popcount(w_new & ((1u << q) - 1u));
         }
-        const int newid = nn + pre_new;
-        nn += n_new;  // cannot pass cap: the host sizes every slab for T * beam * (N-1) nodes (capi.hip)
+        const int newid = (t << KS) + pre_new;  // < cap: the host sizes every slab for (T << KS) ids (capi.hip)
         if (is_new) {
-            rec_w[hoff + (uint32_t)newid] = make_int2(node, (t << 3) | l);
+            rec_w[hoff + (uint32_t)newid] = ((node + 1) << 3) | l;
             // a segment head (depth % 64 == 0) records where the next head up the tree is
             if ((depth + 1) % kSeg == 0) jmp_w[hoff + (uint32_t)newid] = (depth % kSeg == 0) ? node : jump;
             child = newid;
@@ -420,14 +421,20 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // Survivor table: entry r = the lane whose candidate took rank r.  LDS executes a wavefront's operations
         // in order, so the store, the read-back and the two look-ups below share ONE round trip (a ds_permute
         // to the new slot followed by a broadcast to its group were two dependent ones).
-        if (sel) srcs[rank] = lane;
+        const int depc = depth + (is_child ? 1 : 0);
+        if (sel) srcs[rank] = (lane << 2) | (depc << 8);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const int fate = bperm(hbase + mslot * GW, selflag);
         const int own = bperm(grp0, selflag);  // ... and this group's own candidate?
-        const int src = srcs[i];      // every lane of new group i knows its source lane (stale beyond the new beam: unused)
-        const int src_top = srcs[0];  // ... and where the best candidate sits
+        // every lane of new group i learns its source lane (stale beyond the new beam: unused), where the best
+        // candidate sits, and the SMALLEST DEPTH in the new beam: a stale entry can only lower it
+        const int src_a = srcs[i] & 0xFF;  // byte address, as ds_bpermute wants it
+        int e_min = srcs[0];
+        const int top_a = e_min & 0xFF;
+#pragma unroll
+        for (int j = 1; j < BCAP; ++j) e_min = min(e_min, srcs[j]);
         // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
         // its row is in HBM); read off the entry BEFORE it is marked below
         const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
@@ -438,30 +445,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             const int entered = id | kEver | (selflag << kSlotShift);
             const bool upd = go && is_child;
             child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child);
-            // A node's child row only has to exist in HBM while the node is OUT of the beam (it is
-            // read back if the node re-enters, below): write it once, when the node is evicted --
-            // four lanes, 16 contiguous bytes -- instead of a scattered 4-byte store per created node.
+            // A node's child row only has to exist in HBM while the node is OUT of the beam (it is read back if
+            // the node re-enters, below): write it once, when the node is evicted -- four lanes, 16 contiguous
+            // bytes.  And only if the node can come back at all: a node re-enters the beam as the extension of its
+            // parent, so it needs a proper ancestor in the beam -- none exists once every beam entry is at least as
+            // deep as the node, and then none ever will (its ancestors have left for good, top-down from the
+            // root).  Three evicted rows in four are dead by this test and are never written.
             // (-1 keeps its sign bit: "no child" stays negative in the stored form)
-            if (upd && grp && own == 0)
+            const bool dead = (depth << 8) <= e_min;  // e_min = (minimum depth << 8) | a lane address
+            if (upd && grp && own == 0 && !dead)
                 rows_w[(hoff + (uint32_t)(node + 1)) * RW + l] = child & (kStored | (int)0x80000000);
         }
 
         stamp_i(4, child);  // fate of every child entry, row eviction
         // ---- gather the survivors into rank order ----
         const int tipfc = is_self ? tipf : (k << 2);
-        const int depc = depth + (is_child ? 1 : 0);
         const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
                                              : state;  // :97
         const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
         const int meta = kind | tipfc | (depc << 5);
-        const int n_node = bperm(src, id);
-        float n_lp = bpermf(src, clp);
-        const float n_gp = bpermf(src, cgp);
-        const int n_meta = bperm(src, meta);
-        const int n_state = CRF ? bperm(src, statec) : 0;
-        const int n_jump = bperm(src, jumpc);
-        int n_child = bperm(src + k, child);  // meaningful when the source is a self lane
-        const float top = bpermf(src_top, prob);  // beam[0].probability() :278 = its candidate's label + gap probability
+        const int n_node = __builtin_amdgcn_ds_bpermute(src_a, id);
+        float n_lp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(clp)));
+        const float n_gp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(cgp)));
+        const int n_meta = __builtin_amdgcn_ds_bpermute(src_a, meta);
+        const int n_state = CRF ? __builtin_amdgcn_ds_bpermute(src_a, statec) : 0;
+        const int n_jump = __builtin_amdgcn_ds_bpermute(src_a, jumpc);
+        int n_child = __builtin_amdgcn_ds_bpermute(src_a + (k << 2), child);  // meaningful when the source is a self lane
+        const float top = __int_as_float(__builtin_amdgcn_ds_bpermute(top_a, __float_as_int(prob)));  // beam[0].probability() :278 = its candidate's label + gap probability
         stamp_f(5, n_lp);  // survivors gathered into rank order
         const int n_kind = n_meta & 3;
         const bool ngrp = go && i < Bn;
@@ -551,10 +561,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             const int de = q == 0 ? d1 : ds - kSeg;
             int h = heads[hbase + q];
             for (int dd = ds; dd > de && h >= 0; --dd) {
-                const int2 e = rec[h];
-                lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
-                if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
-                h = e.x;
+                const int e = rec[h];
+                lab[dd - 1] = (uint8_t)((e & 7) + 1);
+                if (pth) pth[dd - 1] = (uint32_t)(h >> KS);  // the step that created the node
+                h = (e >> 3) - 1;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -580,6 +590,10 @@ hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
 }
 
 }  // namespace
+
+int beam_wave_id_shift(int beam_size, int N, int force_one_read_per_wave) {
+    return (beam_size <= 5 && N <= 5 && !force_one_read_per_wave) ? 5 : 6;  // KS of the instantiation launch_beam_wave picks
+}
 
 bool beam_wave_supported(int beam_size, int N, int crf, int S) {
     if (beam_size < 1 || beam_size > 12) return false;

@@ -159,8 +159,9 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     } else if (kernel == FCD_KERNEL_AUTO) {
         use_wave = beam_wave_supported((int)std::min<int64_t>(beam, 1 << 20), N, a.crf, d.S);
     }
-    // the wave kernel packs node ids into 25 bits and depths into 26
-    if (use_wave && (d.T >= (1ll << 26) || d.T * std::min<int64_t>(beam, 12) * NL + 16 >= (1ll << 25))) {
+    // the wave kernel packs node ids -- (time step << shift) | index among the step's new nodes -- into 25 bits
+    const int wave_shift = use_wave ? beam_wave_id_shift((int)std::min<int64_t>(beam, 1 << 20), N, kernel == FCD_KERNEL_WAVE1) : 0;
+    if (use_wave && ((d.T << wave_shift) + 16 >= (1ll << 25))) {
         if (kernel != FCD_KERNEL_AUTO) return fail(h, FCD_E_UNSUPPORTED, "wave kernel: T too large");
         use_wave = false;
     }
@@ -181,9 +182,11 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     int64_t cap_nodes;
     size_t per_read;
     if (use_wave || use_lane) {
-        cap_nodes = (T * std::min<int64_t>(beam, use_lane ? 64 : 12) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
+        // (wave kernel: one block of 1 << shift ids per time step, see beam_wave.hip; its records are 4 bytes)
+        cap_nodes = use_wave ? ((T << wave_shift) + 8 + 3) & ~3ll
+                             : (T * std::min<int64_t>(beam, 64) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
         const int row_words = NL <= 4 ? 4 : 8;
-        per_read = (size_t)cap_nodes * (sizeof(int2) + 4 + row_words * 4);
+        per_read = (size_t)cap_nodes * ((use_wave ? 4 : sizeof(int2)) + 4 + row_words * 4);
     } else {
         if (beam > (1 << 16)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 65536");
         if (beam_generic_lds_bytes((int)beam, N) > 64 * 1024)
@@ -203,7 +206,8 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     // point waits for the device -- so it is used only when the worst-case arena would exceed 8 GiB (or the
     // workspace limit).  A job in which more than a quarter of the reads overflow (dense posteriors: nearly
     // every extension passes the cut) makes this handle size later jobs for the worst case straight away.
-    const size_t node_bytes = (use_wave || use_lane) ? sizeof(int2) + 4 + (NL <= 4 ? 4 : 8) * 4 : 0;
+    const size_t rec_bytes = use_wave ? 4 : sizeof(int2);
+    const size_t node_bytes = (use_wave || use_lane) ? rec_bytes + 4 + (NL <= 4 ? 4 : 8) * 4 : 0;
     const size_t worst_total = (size_t)cap_nodes * node_bytes * (size_t)d.n_reads;
     const bool two_pass = use_lane && (worst_total > ((size_t)8 << 30) || (int64_t)worst_total > budget);
     const int64_t cap_worst = cap_nodes;
@@ -230,8 +234,8 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         ar.cap_nodes = cap;
         ar.row_words = NL <= 4 ? 4 : 8;
         ar.rec = reinterpret_cast<int2 *>(base);
-        ar.jmp = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * sizeof(int2));
-        ar.rows = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * (sizeof(int2) + 4));
+        ar.jmp = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * rec_bytes);
+        ar.rows = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * (rec_bytes + 4));
         return ar;
     };
 

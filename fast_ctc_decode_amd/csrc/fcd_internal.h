@@ -60,7 +60,8 @@ struct GenericArena {
 };
 
 // Tree arena of the register-resident ("wave") beam kernel.
-//   rec  : int2 {parent, time<<3 | label} per node
+//   rec  : lane kernel: int2 {parent, time<<3 | label} per node; wave kernel: i32 (parent+1)<<3 | label (the
+//          creation time is the upper part of the node id)
 //   jmp  : i32 per node, written for nodes at depth % 64 == 0: next such ancestor (traceback)
 //   rows : int4 per node (NL <= 4) or 8 x int32 (NL <= 6..7); entry = child | EVER bit, or -1
 struct WaveArena {
@@ -81,6 +82,8 @@ hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t 
                                hipStream_t stream);
 
 bool beam_wave_supported(int beam_size, int N, int crf, int S);
+// node ids of the wave kernel are (time step << shift) | index among the step's new nodes: slots per step = 1 << shift
+int beam_wave_id_shift(int beam_size, int N, int force_one_read_per_wave);
 hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
                             const BeamArgs &a, const WaveArena &arena, const ResultDesc &out,
                             hipStream_t stream);
