@@ -75,6 +75,23 @@ __device__ __forceinline__ int half_prefix_add(int x) {
     return t;
 }
 
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_or_self(int x) {
+    return __builtin_amdgcn_update_dpp(x, x, CTRL, ROW_MASK, BANK_MASK, false);
+}
+
+// minimum over the 64 lanes -- or over each 32-lane half -- delivered in the LAST lane of the wavefront / half
+template <int RPW>
+__device__ __forceinline__ int half_min_in_last_lane(int x) {
+    int t = min(x, dpp_or_self<0x111, 0xf, 0xf>(x));  // row_shr:1
+    t = min(t, dpp_or_self<0x112, 0xf, 0xf>(t));      // row_shr:2
+    t = min(t, dpp_or_self<0x114, 0xf, 0xf>(t));      // row_shr:4
+    t = min(t, dpp_or_self<0x118, 0xf, 0xf>(t));      // row_shr:8: lane 15 of every row holds the row's minimum
+    t = min(t, dpp_or_self<0x142, 0xa, 0xf>(t));      // row_bcast:15 into rows 1 and 3
+    if (RPW == 1) t = min(t, dpp_or_self<0x143, 0xc, 0xf>(t));  // row_bcast:31 into rows 2 and 3
+    return t;
+}
+
 __device__ __forceinline__ int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ float bpermf(int src_lane, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -496,8 +513,17 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
         for (int l = 0; l < RW; ++l) row_word[l] = -1;
 #pragma unroll
         for (int l = 0; l < NL; ++l) row_word[l] = child[l] >= 0 ? (child[l] & kStored) : -1;
-        if (ent && go && rank[0] < 0 && node >= 0) {
-            // this node leaves the beam: its child row has to exist in HBM from now on
+        // A node re-enters the beam only as the extension of its parent, so it needs a proper ancestor in the beam:
+        // once every beam entry is at least as deep as the node none is one, and none ever will be (the minimum
+        // depth of the beam never decreases).  Such a node's row is dead and is not written -- most evicted rows.
+        int mind = 0x7FFFFFFF;  // smallest depth among the survivors this entry contributes ...
+        if (rank[0] >= 0) mind = depth;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if (rank[l + 1] >= 0) mind = min(mind, depth + 1);
+        mind = bperm(hbase + HALF - 1, half_min_in_last_lane<RPW>(mind));  // ... and in the whole new beam
+        if (ent && go && rank[0] < 0 && node >= 0 && depth > mind) {
+            // this node leaves the beam and may come back: its child row has to exist in HBM from now on
             int4 *row = reinterpret_cast<int4 *>(rows + (int64_t)node * RW);
             row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
             if (RW == 8) row[1] = make_int4(row_word[RW - 4], row_word[RW - 3], row_word[RW - 2], row_word[RW - 1]);
