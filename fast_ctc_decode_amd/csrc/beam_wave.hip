@@ -70,6 +70,11 @@ __device__ __forceinline__ int bperm(int src_lane, int v) {
 __device__ __forceinline__ float bpermf(int src_lane, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
 }
+// element `idx` of a wave-uniform array through a 32-bit BYTE offset (slabs stay below 4 GiB: capi.hip), so
+// that the access is base (scalar registers) + offset (one vector register) with no 64-bit vector arithmetic
+__device__ __forceinline__ int32_t *at32(int32_t *base, uint32_t idx) {
+    return reinterpret_cast<int32_t *>(reinterpret_cast<char *>(base) + (idx << 2));
+}
 __device__ __forceinline__ int perm(int dst_lane, int v) {
     return __builtin_amdgcn_ds_permute(dst_lane << 2, v);
 }
@@ -237,6 +242,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // the block in flight joins the FIFO one rotation after its load was launched
     float incoming = GATHER ? 0.0f : load_block(kFifo);
     int g = 0;    // row within the front block (wave-uniform)
+    int gE = 0;   // g * E, carried along instead of multiplied out
     int blk = 0;  // index of the front block (wave-uniform)
     // GATHER: the one value of row tt this lane needs -- column 0 (blank) on a slot's own lane, the
     // label's column on a child lane -- in the row of the slot's current state
@@ -260,7 +266,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // lane, and the tip's column -- are fetched one step AHEAD, as soon as the next beam's tips are known: the two
     // ds_bpermutes then travel under the divisions instead of heading the next step's dependent chain.
     auto fetch_row = [&](float &o_pk, float &o_ptip) {
-        const int rbase = hbase + g * E + (S > 0 ? state * N : 0);
+        const int rbase = hbase + gE + (S > 0 ? state * N : 0);
         o_pk = bpermf(rbase + (is_child ? k : 0), win[0]);
         o_ptip = CRF ? 0.0f : __int_as_float(__builtin_amdgcn_ds_bpermute((rbase << 2) + tipf, __float_as_int(win[0])));
     };
@@ -272,8 +278,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const float pr0 = pk;
         const float ptip = ptip_next;
         stamp_f(0, pk);  // loop overhead + posterior row
+        gE += E;
         if (!GATHER && ++g == RPR) {
             g = 0;
+            gE = 0;
 #pragma unroll
             for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
             // wait for the block launched one rotation ago BEFORE launching the next one (vmcnt
@@ -344,9 +352,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         }
         const int newid = (t << KS) + pre_new;  // < cap: the host sizes every slab for (T << KS) ids (capi.hip)
         if (is_new) {
-            rec_w[hoff + (uint32_t)newid] = ((node + 1) << 3) | l;
+            *at32(rec_w, hoff + (uint32_t)newid) = ((node + 1) << 3) | l;
             // a segment head (depth % 64 == 0) records where the next head up the tree is
-            if ((depth + 1) % kSeg == 0) jmp_w[hoff + (uint32_t)newid] = (depth % kSeg == 0) ? node : jump;
+            if ((depth + 1) % kSeg == 0) *at32(jmp_w, hoff + (uint32_t)newid) = (depth % kSeg == 0) ? node : jump;
             child = newid;
         }
         int id = is_self ? node : (is_new ? newid : cid);
@@ -454,7 +462,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             // (-1 keeps its sign bit: "no child" stays negative in the stored form)
             const bool dead = (depth << 8) <= e_min;  // e_min = (minimum depth << 8) | a lane address
             if (upd && grp && own == 0 && !dead)
-                rows_w[(hoff + (uint32_t)(node + 1)) * RW + l] = child & (kStored | (int)0x80000000);
+                *at32(rows_w, (hoff + (uint32_t)(node + 1)) * RW + l) = child & (kStored | (int)0x80000000);
         }
 
         stamp_i(4, child);  // fate of every child entry, row eviction
@@ -483,7 +491,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up (rare path)
             int e = -1;
-            if (reload) e = load_i32_l2(&rows_w[(hoff + (uint32_t)(n_node + 1)) * RW + l]);
+            if (reload) e = load_i32_l2(at32(rows_w, (hoff + (uint32_t)(n_node + 1)) * RW + l));
 #pragma unroll
             for (int j = 0; j < BCAP; ++j) {
                 const int nj = bperm(hbase + j * GW, n_node);
