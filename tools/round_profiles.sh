@@ -14,4 +14,4 @@ bash tools/profile_sq.sh $TAG beam > $O/${TAG}_profile_sq.log 2>&1
 python tools/cycle_account.py > $O/${TAG}_cycle_account.jsonl 2> $O/${TAG}_cycle_account.err
 python tools/bench_configs.py 1 3 4 5 64 1024 --check > $O/${TAG}_configs.jsonl 2> $O/${TAG}_configs.err
 python tools/probe_latency.py > $O/${TAG}_latency.txt 2>&1
-tail -2 $O/${TAG}_bench_line.json $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt
+for f in $O/${TAG}_bench_line.json $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt; do tail -n 2 $f | cut -c1-300; done
