@@ -239,10 +239,26 @@ def main():
     handles = [nat.default_handle(local_rank)] + [nat.Handle(local_rank) for _ in range(n_streams - 1)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
     step_no = [0]
-    # The gather of step i (RCCL over xGMI, ~20 KB of results per read into rank 0) runs on its own
-    # HIP stream and overlaps the search of step i+1; it only reads step i's result tensors, which
-    # every call allocates afresh.  All gathers have completed before the closing synchronize.
+    # The gather of step i (RCCL over xGMI, the out_len-prefixed payload packed on the GPU: ~6 KB per read into
+    # rank 0) runs on its own HIP stream and overlaps the search of step i+1.  Sizing the payload reads two
+    # small values back to the host, so the host issues it one step LATE -- after the search of step i+1 has
+    # been queued -- and never leaves the GPU without work; it only reads step i's result tensors, which every
+    # call allocates afresh.  flush() issues the last one; all gathers have completed before the closing synchronize.
     comm_stream = torch.cuda.Stream(dev) if distributed and not args.no_overlap else None
+    pending = [None]
+
+    def gather(prev):
+        r, ev = prev
+        comm_stream.wait_event(ev)
+        with torch.cuda.stream(comm_stream):
+            for tns in (r.labels, r.path, r.out_len, r.status):
+                tns.record_stream(comm_stream)
+            fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
+
+    def flush():
+        if pending[0] is not None:
+            gather(pending[0])
+            pending[0] = None
 
     def step():
         s = step_no[0] % n_streams
@@ -250,30 +266,32 @@ def main():
         with torch.cuda.stream(streams[s]):
             r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel, handle=handles[s])
             if distributed and comm_stream is None:
-                # ONE gather of the packed fixed-stride results to rank 0 (RCCL over xGMI)
+                # ONE gather of the packed results to rank 0 (RCCL over xGMI), on the compute stream
                 fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
         if comm_stream is not None:
-            comm_stream.wait_stream(streams[s])
-            with torch.cuda.stream(comm_stream):
-                for tns in (r.labels, r.path, r.out_len, r.status):
-                    tns.record_stream(comm_stream)
-                fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
+            ev = torch.cuda.Event()
+            ev.record(streams[s])
+            flush()  # the previous step's results, while this step's search runs
+            pending[0] = (r, ev)
         return r
 
     for _ in range(args.warmup):
         r = step()
+    flush()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     if args.warmup == 0:
         step()
+        flush()
     torch.cuda.synchronize()
     for hh in handles:
         hh.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = step()
+    flush()  # K searches and K gathers inside the timed region
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
