@@ -98,7 +98,10 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // read; semantics in include/fcd.h).  A separate instantiation: the timed kernel pays nothing.
 // PROF: the same search with a cycle stamp after each block of the step (profiles/): every
 // stamp waits for the block's results, so the blocks' DEPENDENT latencies are measured, not their overlap.
-template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false>
+// UNI: every read of the launch has the same length (no `lengths` array).  A read then stops taking part only by
+// FAILING (its status is already written and its traceback skipped), so nothing has to keep its beam intact:
+// the per-step "this half still runs" guards around the state update disappear.
+template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
     constexpr bool GATHER = S == kCrfGather;
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     float pk_next = 0.0f, ptip_next = 0.0f;
     if (!GATHER) fetch_row(pk_next, ptip_next);
     for (int t = 0; t < Tmax; ++t) {
-        const bool act = alive && t < T;
+        const bool act = UNI ? alive : (alive && t < T);
         float pk = GATHER ? rowv : pk_next;
         const float pr0 = pk;
         const float ptip = ptip_next;
@@ -500,15 +503,15 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             }
             if (reload) n_child = e;
         }
-        if (CRF && go) state = n_state;  // < S: (s*4) % 4 + l = l for (N, S) = (5, 4); masked when GATHER
-        if (go) tipf = n_meta & 0x1C;
+        if (CRF && (UNI || go)) state = n_state;  // < S: (s*4) % 4 + l = l for (N, S) = (5, 4); masked when GATHER
+        if (UNI || go) tipf = n_meta & 0x1C;
         if (GATHER) rowv = gather_row(t + 1);  // in flight during the divisions below
         else fetch_row(pk_next, ptip_next);    // (the FIFO was already advanced to step t + 1 above)
         // Every lane of a group would compute the same two IEEE quotients: lane k = 1 divides the gap
         // probability, the others the label probability -- one division per lane -- and the group shares them.
         const float quot = (k == 1 ? n_gp : n_lp) / top;
         const float q_lp = bpermf(grp0, quot), q_gp = bpermf(grp0 + 1, quot);
-        if (go) {
+        if (UNI || go) {
             node = n_node;
             lp = q_lp;
             gp = q_gp;
@@ -590,6 +593,9 @@ hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
                            stream, p);
     else if (p.a.prof && N == 5 && GW == 6 && RPW == 2 && S == 0)   // the headline instantiation only
         hipLaunchKernelGGL((beam_wave_kernel<5, 6, 2, 0, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+                           stream, p);
+    else if (!p.in.lengths)  // reads of one length
+        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
     else
         hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,

@@ -20,8 +20,11 @@ STATE = {"done": 0, "bad": 0, "which": ""}
 
 
 def _on_term(signum, frame):  # `timeout` ends an open-ended soak: say how far it got
-    print("soak %s (stopped by signal): %d seeds, %d failures" % (STATE["which"], STATE["done"], STATE["bad"]), flush=True)
-    os._exit(1 if STATE["bad"] else 0)
+    try:  # (os.write: print() is not re-entrant and the signal may land inside one)
+        os.write(1, ("soak %s (stopped by signal): %d seeds, %d failures\n"
+                     % (STATE["which"], STATE["done"], STATE["bad"])).encode())
+    finally:
+        os._exit(1 if STATE["bad"] else 0)
 
 
 signal.signal(signal.SIGTERM, _on_term)

@@ -6,7 +6,7 @@ O=gpurun_out/${TAG}_soak; mkdir -p $O
 i=0
 for w in beam beam beam_long crf crf viterbi duplex duplex_long crf_duplex crf_greedy envelope; do
   i=$((i+1))
-  timeout $SECS python tools/soak.py 100000000 $((SEED + i*1000000)) $w > $O/$i.$w.log 2>&1 &
+  timeout -k 10 $SECS python tools/soak.py 100000000 $((SEED + i*1000000)) $w > $O/$i.$w.log 2>&1 &
 done
 wait
 # a soak killed by the time limit prints no summary: failures are whatever lines it printed
