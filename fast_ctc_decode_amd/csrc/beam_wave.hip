@@ -100,7 +100,8 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // stamp waits for the block's results, so the blocks' DEPENDENT latencies are measured, not their overlap.
 // UNI: every read of the launch has the same length (no `lengths` array).  A read then stops taking part only by
 // FAILING (its status is already written and its traceback skipped), so nothing has to keep its beam intact:
-// the per-step "this half still runs" guards around the state update disappear.
+// the per-step "this half still runs" guards disappear -- a failed read is left with an EMPTY beam (B = 0), which
+// makes every later step a no-op for it, and a half without a read starts that way.
 template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
@@ -202,7 +203,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     int depth = 0;
     int jump = -1;  // nearest proper ancestor of `node` at a depth that is a multiple of kSeg
     int child = -1;
-    int B = 1;
+    int B = (UNI && !has_read) ? 0 : 1;
     bool alive = has_read;
     int state = 0;
     if (CRF && has_read) {
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             ++blk;
             incoming = load_block(blk + kFifo);
         }
-        const bool grp = act && i < B;
+        const bool grp = UNI ? i < B : (act && i < B);
 
         // ---- child lanes: extension by label l (:200-239) ----
         const bool pass = !(pk < thr);  // :201 skips only when pr_b < thr
@@ -334,7 +335,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // lane, exactly like the index it is about to receive -- so the key does not wait for the numbering below.
         // (A NaN key is garbage but non-zero: it only ever ranks when it is the read's lone candidate, :262.)
         const int idk = is_self ? node : (is_new ? (t << KS) + q : cid);
-        const uint64_t key = (valid && act) ? make_key(prob, idk) : 0ull;
+        const uint64_t key = (UNI ? valid : (valid && act)) ? make_key(prob, idk) : 0ull;
         keys[lane] = key;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
@@ -390,8 +391,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // ---- search.rs:261-277 ----
         // (key != 0 <=> valid && act: a vote on a compare costs one instruction, a vote on a derived flag two)
         const uint64_t m_valid = ballot(key != 0ull);
-        const int n_valid = RPW == 1 ? popc64(m_valid)
-                                     : __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
+        int n_valid = RPW == 1 ? popc64(m_valid)
+                               : __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
         // Everything that ends a read is rare: one wave-wide test, the bookkeeping behind it.
         const bool is_nan = valid && prob != prob;
         if (ballot(act && (n_valid == 0 || is_nan)) != 0ull) {
@@ -406,9 +407,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
                     p.out.out_len[r] = 0;
                 }
                 alive = false;
+                if (UNI) n_valid = 0;  // the failed read keeps an empty beam from here on
             }
         }
-        const bool go = act && alive;  // this half completes the step
+        const bool go = UNI ? true : (act && alive);  // this half completes the step
 
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
         const bool sel = valid && go && rank < beam_size;
