@@ -13,8 +13,9 @@
 // next batch.  A launch takes about as long for one read as for a thousand (a read is one wavefront), so the
 // policy is "batch first": a leader takes everything that is pending, and before launching it waits briefly
 // for the callers of the PREVIOUS batches to come back with their next read -- until as many requests are
-// pending as recent batches held, for at most max_wait_us (0, the default: an eighth of the last launch's
-// duration, at most 1 ms).  A lone caller never waits (recent batches held one read).  Up to kLanes leaders
+// pending as recent batches held, for at most an eighth of the last launch's duration (<= 1 ms); a lone caller
+// never waits (recent batches held one read).  An explicit max_wait_us > 0 instead makes every leader wait that
+// long for company (or until max_batch requests are pending).  Up to kLanes leaders
 // work at the same time, each with its own handle (stream, workspace) and pinned staging buffers, but only while
 // fewer than kLanes reads are in flight: a handful of callers overlap their launches the way independent
 // per-read calls would, many callers share big batches instead of fragmenting them.
@@ -212,7 +213,9 @@ int submit(fcd_coalescer *c, Req &req) {
         {
             const int64_t budget_us = c->max_wait_us > 0 ? c->max_wait_us
                                                          : std::min<int64_t>(c->last_launch_us / 8, 1000);
-            const int64_t target = std::min<int64_t>(c->recent, c->max_batch);
+            // an explicit max_wait_us asks for company outright; the adaptive default only waits for as many
+            // requests as recent batches held
+            const int64_t target = c->max_wait_us > 0 ? c->max_batch : std::min<int64_t>(c->recent, c->max_batch);
             const auto deadline = std::chrono::steady_clock::now() + std::chrono::microseconds(budget_us);
             while (!c->pending.empty() && (int64_t)c->pending.size() < target &&
                    std::chrono::steady_clock::now() < deadline)

@@ -283,9 +283,10 @@ int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, u
  * a coalescer turns CONCURRENT per-read calls into batched launches without changing the callers: the first
  * thread to arrive decodes every compatible pending request (same search, alphabet size, beam size, threshold,
  * collapse flag) with one ragged batch on one of the coalescer's own handles; whatever arrives while that launch
- * is in flight forms the next batch.  Before launching, a leader waits briefly for the callers of the previous
- * batches to come back (until as many requests are pending as recent batches held): at most max_wait_us, or,
- * with max_wait_us = 0, an eighth of the last launch's duration (<= 1 ms); a lone caller never waits.  A few
+ * is in flight forms the next batch.  max_wait_us = 0 (adaptive): before launching, a leader waits briefly for
+ * the callers of the previous batches to come back (until as many requests are pending as recent batches held,
+ * at most an eighth of the last launch's duration, <= 1 ms); a lone caller never waits.  max_wait_us > 0: every
+ * leader waits up to that long for company (or until max_batch requests are pending).  A few
  * leaders run side by side while fewer than four reads are in flight, so a handful of callers overlap like
  * independent per-read calls.  Results are bit-identical to the per-read calls.
  * `read` must describe exactly one (T, N) matrix (n_reads = 1, S <= 1, non-negative strides, no lengths);
