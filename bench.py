@@ -116,7 +116,7 @@ def pmc_traffic(kernel_prefix):
         with open(path) as f:
             summ = json.load(f)
         for name, e in summ.get("kernels", {}).items():
-            if name.startswith(kernel_prefix) and "hbm_bytes_per_launch" in e:
+            if name.startswith(kernel_prefix) and ", true, false" not in name and "hbm_bytes_per_launch" in e:
                 return e["hbm_bytes_per_launch"], "%s: %s; %s; %s" % (
                     os.path.basename(path), name, e.get("workload", ""), e.get("fetch_correction_note", ""))
     return None, None
@@ -317,8 +317,9 @@ def main():
         achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
         # the CPU leg (and its output cross-check) runs on rank 0 at N = 1 only, as the contract asks
         cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds) if world == 1 else None
-        traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2, 0>" if args.kernel in (0, 2)
-                                            else "beam_wave_kernel<5, 8, 1, 0>" if args.kernel == 3
+        # (the names carry further template arguments after S: counting / profiling / one-length flags)
+        traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2, 0" if args.kernel in (0, 2)
+                                            else "beam_wave_kernel<5, 8, 1, 0" if args.kernel == 3
                                             else "beam_generic_kernel")
         if args.batch != 4096 or args.data != "reference":
             traffic, traffic_note = None, None

@@ -12,15 +12,27 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
 base = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
 
-WORK = {
-    "beam_wave_kernel<5, 6, 2, 0>": "4096 reads T=4000 N=5 beam 5 thr 0.1 (BASELINE config 2)",
-    "beam_wave_kernel<5, 6, 2, 4>": "4096 reads T=4000 S=4 N=5 CRF beam 5 thr 0 (config 4)",
-    "viterbi_stream_kernel<5>": "16384 reads T=4000 N=5",
-    "beam_generic_kernel": "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)",
-    "beam_lane_kernel<5, 2>": "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)",
-    "duplex_kernel<0>": "1024 pairs T=2000 band +-64 beam 5 thr 0.1 logsumexp (config 5)",
-    "duplex_kernel<1>": "1024 pairs T=2000 band +-64 beam 5 thr 0.1 max mode (config 5)",
-}
+# workload of tools/prof_workload.py by kernel-name prefix (the names carry further template arguments)
+WORK_PREFIX = [
+    ("beam_wave_kernel<5, 6, 2, 0", "4096 reads T=4000 N=5 beam 5 thr 0.1 (BASELINE config 2)"),
+    ("beam_wave_kernel<5, 6, 2, 4", "4096 reads T=4000 S=4 N=5 CRF beam 5 thr 0 (config 4)"),
+    ("viterbi_stream_kernel<5", "16384 reads T=4000 N=5"),
+    ("beam_generic_kernel", "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)"),
+    ("beam_lane_kernel<5, 2", "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)"),
+    ("duplex_kernel<0", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 logsumexp (config 5)"),
+    ("duplex_kernel<1", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 max mode (config 5)"),
+]
+
+
+class _Work:
+    def get(self, name, default=""):
+        for prefix, text in WORK_PREFIX:
+            if name.startswith(prefix):
+                return text
+        return default
+
+
+WORK = _Work()
 
 
 def short(n):
