@@ -573,12 +573,33 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             const int ds = q == 0 ? d0 : d1 - (q - 1) * kSeg;
             const int de = q == 0 ? d1 : ds - kSeg;
             int h = heads[hbase + q];
-            for (int dd = ds; dd > de && h >= 0; --dd) {
+            int dd = ds;
+            auto one = [&]() {  // emit position dd - 1, step to the parent
                 const int e = rec[h];
                 lab[dd - 1] = (uint8_t)((e & 7) + 1);
                 if (pth) pth[dd - 1] = (uint32_t)(h >> KS);  // the step that created the node
                 h = (e >> 3) - 1;
+                --dd;
+            };
+            // A lane's 64 byte-sized label stores (and 64 path words), each to a line of its own, cost more than
+            // the pointer chase: when the rows are aligned, four positions are collected and leave as one 4-byte and
+            // one 16-byte store.  Only the leaf's segment can start off a multiple of four.
+            const bool wide = (reinterpret_cast<uintptr_t>(lab) & 3) == 0 && (!pth || (reinterpret_cast<uintptr_t>(pth) & 15) == 0);
+            while (dd > de && h >= 0 && (!wide || (dd & 3) != 0)) one();
+            for (; dd - 4 >= de && h >= 0; dd -= 4) {  // (de is a multiple of 64: whole groups down to the segment's end)
+                uint32_t lw = 0;
+                uint32_t tw[4];
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {  // positions dd-1 (j = 3) ... dd-4 (j = 0)
+                    const int e = rec[h];
+                    lw |= (uint32_t)((e & 7) + 1) << (8 * j);
+                    tw[j] = (uint32_t)(h >> KS);
+                    h = (e >> 3) - 1;
+                }
+                *reinterpret_cast<uint32_t *>(lab + dd - 4) = lw;
+                if (pth) *reinterpret_cast<uint4 *>(pth + dd - 4) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
             }
+            while (dd > de && h >= 0) one();
         }
         __builtin_amdgcn_wave_barrier();
         h0 = nh;
