@@ -108,7 +108,7 @@ __device__ __forceinline__ float rdlanef(float v, int l) {
 // lane, requested for step t+1 as soon as the entry's next state is known; no repeat-stay; an extension
 // moves to state (state * 4) & (S - 1) + label (:97), which cannot leave the table.
 template <int N, int RPW, bool AMB, bool CRF>
-__global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void beam_lane_kernel(LaneParams p) {
     constexpr int NL = N - 1;
     constexpr int HALF = 64 / RPW;          // lanes (= beam slots) per read
     constexpr int RPR = HALF / N;           // rows per FIFO register
@@ -413,6 +413,30 @@ __global__ __launch_bounds__(64) void beam_lane_kernel(LaneParams p) {
             *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
             wave_sync();
             for (int e0 = 0; e0 < lmax; e0 += HALF) {
+                if (!AMB && e0 > 0 && lmax - e0 <= HALF / 4) {
+                    // The list is usually a handful of entries longer than the half has lanes (beam_size survivors
+                    // plus whatever shares the last bucket): a second pass of every lane over the whole list for
+                    // their sake would double the ranking work.  Four lanes share each of them instead, each
+                    // counting a quarter of the list, and add their counts up across the quad.
+                    const int e = e0 + (q >> 2), sub = q & 3;
+                    const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
+                    const int per = ((lmax + 7) >> 3) << 1;  // keys per lane: a quarter of the list, rounded up to a pair
+                    int rk = 0, rk2 = 0;
+                    for (int jj = 0; jj < per; jj += 2) {
+                        const int j = sub * per + jj;
+                        ulonglong2 kk2;
+                        kk2.x = 0ull;
+                        kk2.y = 0ull;
+                        if (j < lmax) kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
+                        rk += (kk2.x > ke) ? 1 : 0;
+                        rk2 += (kk2.y > ke) ? 1 : 0;
+                    }
+                    rk += rk2;
+                    rk += __builtin_amdgcn_update_dpp(0, rk, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+                    rk += __builtin_amdgcn_update_dpp(0, rk, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+                    if (sub == 0 && e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                    break;
+                }
                 const int e = e0 + q;
                 const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
                 int rk = 0, rk2 = 0, n_eq = 0, n_gt = 0;
