@@ -405,10 +405,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 }
                 base += popc64(m_in);
             }
-            // the ranking loop runs to a wave-uniform, even bound: pad this read's list with zero keys
+            // the ranking loop runs to a wave-uniform bound, eight keys at a time: pad this read's list with zero keys
             int lmax = Lc;
             if (RPW == 2) lmax = max(lmax, __shfl_xor(lmax, 32));
-            lmax = (__builtin_amdgcn_readfirstlane(lmax) + 1) & ~1;
+            lmax = (__builtin_amdgcn_readfirstlane(lmax) + 7) & ~7;
             for (int z = Lc + q; z < lmax; z += HALF) l_key[z] = 0ull;
             *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
             wave_sync();
@@ -420,7 +420,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                     // counting a quarter of the list, and add their counts up across the quad.
                     const int e = e0 + (q >> 2), sub = q & 3;
                     const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
-                    const int per = ((lmax + 7) >> 3) << 1;  // keys per lane: a quarter of the list, rounded up to a pair
+                    const int per = lmax >> 2;  // keys per lane: a quarter of the list (lmax is a multiple of 8)
                     int rk = 0, rk2 = 0;
                     for (int jj = 0; jj < per; jj += 2) {
                         const int j = sub * per + jj;
@@ -440,7 +440,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 const int e = e0 + q;
                 const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
                 int rk = 0, rk2 = 0, n_eq = 0, n_gt = 0;
-                for (int j = 0; j < lmax; j += 2) {  // two keys per 16-byte LDS read
+                if (!AMB) {
+                    // eight keys per trip: four 16-byte LDS reads in flight, four independent compare-and-count chains
+                    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                    for (int j = 0; j < lmax; j += 8) {
+                        const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(l_key + j);
+                        const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(l_key + j + 2);
+                        const ulonglong2 kc = *reinterpret_cast<const ulonglong2 *>(l_key + j + 4);
+                        const ulonglong2 kd = *reinterpret_cast<const ulonglong2 *>(l_key + j + 6);
+                        FCD_RANK4(ke, ka.x, ka.y, kb.x, kb.y, r0, r1, r2, r3);
+                        FCD_RANK4(ke, kc.x, kc.y, kd.x, kd.y, r0, r1, r2, r3);
+                    }
+                    rk = (r0 + r1) + (r2 + r3);
+                }
+                for (int j = 0; AMB && j < lmax; j += 2) {  // two keys per 16-byte LDS read
                     const ulonglong2 kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
                     rk += (kk2.x > ke) ? 1 : 0;
                     rk2 += (kk2.y > ke) ? 1 : 0;
