@@ -669,12 +669,31 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const int ds = q == 0 ? d0 : d1 - (q - 1) * kSeg;
             const int de = q == 0 ? d1 : ds - kSeg;
             int h = s_heads[hbase + q];
-            for (int dd = ds; dd > de && h >= 0; --dd) {
+            int dd = ds;
+            auto one = [&]() {  // emit position dd - 1, step to the parent
                 const int2 e = rec[h];
                 lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
                 if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
                 h = e.x;
+                --dd;
+            };
+            // aligned rows: four positions leave as one 4-byte label store and one 16-byte path store (beam_wave.hip)
+            const bool wide = (reinterpret_cast<uintptr_t>(lab) & 3) == 0 && (!pth || (reinterpret_cast<uintptr_t>(pth) & 15) == 0);
+            while (dd > de && h >= 0 && (!wide || (dd & 3) != 0)) one();
+            for (; dd - 4 >= de && h >= 0; dd -= 4) {
+                uint32_t lw = 0;
+                uint32_t tw[4];
+#pragma unroll
+                for (int j = 3; j >= 0; --j) {  // positions dd-1 (j = 3) ... dd-4 (j = 0)
+                    const int2 e = rec[h];
+                    lw |= (uint32_t)((e.y & 7) + 1) << (8 * j);
+                    tw[j] = (uint32_t)(e.y >> 3);
+                    h = e.x;
+                }
+                *reinterpret_cast<uint32_t *>(lab + dd - 4) = lw;
+                if (pth) *reinterpret_cast<uint4 *>(pth + dd - 4) = make_uint4(tw[0], tw[1], tw[2], tw[3]);
             }
+            while (dd > de && h >= 0) one();
         }
         __builtin_amdgcn_wave_barrier();
         h0 = nh;
