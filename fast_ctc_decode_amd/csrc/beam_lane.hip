@@ -168,10 +168,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         if (!mine || slot >= p.arena.retry_slots) return;  // (left over: the host runs another round)
         slab = slot;
     }
-    int2 *rec = p.arena.rec + slab * p.arena.cap_nodes;
-    int32_t *jmp = p.arena.jmp + slab * p.arena.cap_nodes;
-    int32_t *rows = p.arena.rows + slab * p.arena.cap_nodes * RW;
+    // Arena addressing: a wave-uniform base (the slab of the wavefront's first read: scalar registers) plus a
+    // 32-bit BYTE offset per lane (the second read's slab starts cap_nodes elements further on; a pair of slabs
+    // stays below 4 GiB: cap_nodes < 2^23), so that no tree access needs 64-bit vector arithmetic.
     const int cap = (int)p.arena.cap_nodes;
+    const int64_t wslab = (RPW == 1 && p.arena.retry_counter) ? slab : (int64_t)blockIdx.x * RPW;
+    char *const rec_w = reinterpret_cast<char *>(p.arena.rec + wslab * p.arena.cap_nodes);
+    char *const jmp_w = reinterpret_cast<char *>(p.arena.jmp + wslab * p.arena.cap_nodes);
+    char *const rows_w = reinterpret_cast<char *>(p.arena.rows + wslab * p.arena.cap_nodes * RW);
+    const uint32_t hoff = (RPW == 2 && has_read && hh) ? (uint32_t)cap : 0u;  // this half's slab, in nodes
+    auto rec_at = [&](int id) -> int2 * { return reinterpret_cast<int2 *>(rec_w + ((hoff + (uint32_t)id) << 3)); };
+    auto jmp_at = [&](int id) -> int32_t * { return reinterpret_cast<int32_t *>(jmp_w + ((hoff + (uint32_t)id) << 2)); };
+    auto row_at = [&](int id) -> char * { return rows_w + (hoff + (uint32_t)id) * (uint32_t)(RW * 4); };
 
     // votes and counts over this lane's half
     auto hmask = [&](uint64_t m) -> uint64_t { return RPW == 1 ? m : (hh ? (m >> 32) : (m & 0xFFFFFFFFull)); };
@@ -305,8 +313,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const bool is_new = cvalid[l] && child[l] < 0;
             if (is_new && !f_cap) {
                 const int id = next_id++;
-                rec[id] = make_int2(node, (t << 3) | l);
-                if ((depth + 1) % kSeg == 0) jmp[id] = (depth % kSeg == 0) ? node : jump;
+                *rec_at(id) = make_int2(node, (t << 3) | l);
+                if ((depth + 1) % kSeg == 0) *jmp_at(id) = (depth % kSeg == 0) ? node : jump;
                 child[l] = id;
             }
             ccand[l] = child[l] & kIdMask;
@@ -512,10 +520,24 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 
         // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
         s_fate[lane] = rank[0];
+        // a record is {label prob, gap prob, node, meta | jump, source lane, -, CRF state}: written dword by dword
+        // behind an offset the compiler cannot see through, so that the stores pair up from whatever registers hold
+        // the values (ds_write2_b32) instead of being moved into four consecutive ones for a 16-byte store
+        int *const recw = reinterpret_cast<int *>(s_rec);
+        auto publish = [&](int slot, int a, int b, int c, int d, int e, int f) {
+            int off = 8 * slot;
+            FCD_OPAQUE_V(off);
+            recw[off + 0] = a;
+            recw[off + 1] = b;
+            recw[off + 2] = c;
+            recw[off + 3] = d;
+            recw[off + 4] = e;
+            recw[off + 5] = lane;
+            if (CRF) recw[off + 7] = f;
+        };
         if (rank[0] >= 0) {  // the entry's own node stays in the beam
             const int meta = 0 | ((tip + 1) << 2) | (depth << 5);
-            s_rec[2 * (hbase + rank[0])] = make_int4(__float_as_int(slp), __float_as_int(sgp), node, meta);
-            s_rec[2 * (hbase + rank[0]) + 1] = make_int4(jump, lane, 0, state);
+            publish(hbase + rank[0], __float_as_int(slp), __float_as_int(sgp), node, meta, jump, state);
         }
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
@@ -523,9 +545,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             if (rk >= 0) {  // the child by label l enters the beam
                 const int kind = (child[l] & kEver) ? 2 : 1;  // 2: it has been there before, its row is in HBM
                 const int meta = kind | ((l + 1) << 2) | ((depth + 1) << 5);
-                s_rec[2 * (hbase + rk)] = make_int4(__float_as_int(contrib[l]), 0, ccand[l], meta);
-                s_rec[2 * (hbase + rk) + 1] =
-                    make_int4((depth % kSeg == 0) ? node : jump, lane, l + 1, CRF ? ((state * NL) & s_mask) + l : 0);  // :97
+                publish(hbase + rk, __float_as_int(contrib[l]), 0, ccand[l], meta, (depth % kSeg == 0) ? node : jump,
+                        CRF ? ((state * NL) & s_mask) + l : 0);  // :97
             }
         }
         wave_sync();
@@ -561,7 +582,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         mind = bperm(hbase + HALF - 1, half_min_in_last_lane<RPW>(mind));  // ... and in the whole new beam
         if (ent && go && rank[0] < 0 && node >= 0 && depth > mind) {
             // this node leaves the beam and may come back: its child row has to exist in HBM from now on
-            int4 *row = reinterpret_cast<int4 *>(rows + (int64_t)node * RW);
+            int4 *row = reinterpret_cast<int4 *>(row_at(node));
             row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
             if (RW == 8) row[1] = make_int4(row_word[RW - 4], row_word[RW - 3], row_word[RW - 2], row_word[RW - 1]);
         }
@@ -589,7 +610,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             int e[NL], eid[NL], eslot[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
-                e[l] = reload ? load_i32_l2(&rows[(int64_t)n_node * RW + l]) : -1;
+                e[l] = reload ? load_i32_l2(reinterpret_cast<int32_t *>(row_at(n_node)) + l) : -1;
                 // only a child that has been a beam entry (EVER) can be one now
                 eid[l] = (e[l] >= 0 && (e[l] & kEver)) ? (e[l] & kIdMask) : -2;
                 eslot[l] = -1;
@@ -655,7 +676,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         if (q == 0) {
             while (cnt < HALF && nd > 0) {
                 s_heads[hbase + cnt] = nh;
-                nh = (nd % kSeg != 0) ? j0 : jmp[nh];
+                nh = (nd % kSeg != 0) ? j0 : *jmp_at(nh);
                 nd = ((nd - 1) / kSeg) * kSeg;
                 ++cnt;
             }
@@ -671,7 +692,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             int h = s_heads[hbase + q];
             int dd = ds;
             auto one = [&]() {  // emit position dd - 1, step to the parent
-                const int2 e = rec[h];
+                const int2 e = *rec_at(h);
                 lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
                 if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
                 h = e.x;
@@ -685,7 +706,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 uint32_t tw[4];
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {  // positions dd-1 (j = 3) ... dd-4 (j = 0)
-                    const int2 e = rec[h];
+                    const int2 e = *rec_at(h);
                     lw |= (uint32_t)((e.y & 7) + 1) << (8 * j);
                     tw[j] = (uint32_t)(e.y >> 3);
                     h = e.x;
