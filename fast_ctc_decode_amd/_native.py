@@ -21,7 +21,7 @@ LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
 # list AND against the header text)
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
-    "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit",
+    "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
@@ -104,6 +104,7 @@ def bind(lib):
     lib.fcd_status_string.argtypes = [i32]
     lib.fcd_status_string.restype = C.c_char_p
     lib.fcd_set_workspace_limit.argtypes = [P, i64]
+    lib.fcd_release_workspace.argtypes = [P]
     lib.fcd_debug_set_first_pass_divisor.argtypes = [P, i32]
     lib.fcd_last_kernel_ms.argtypes = [P]
     lib.fcd_last_kernel_ms.restype = C.c_double
@@ -185,6 +186,10 @@ class Handle:
 
     def set_workspace_limit(self, nbytes):
         self.check(self.lib.fcd_set_workspace_limit(self.ptr, int(nbytes)))
+
+    def release_workspace(self):
+        """Give the tree arena / staging memory back to the device (the next call allocates afresh)."""
+        self.check(self.lib.fcd_release_workspace(self.ptr))
 
     def close(self):
         if self.ptr:

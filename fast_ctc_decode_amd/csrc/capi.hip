@@ -378,6 +378,21 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
     return FCD_OK;
 }
 
+int fcd_release_workspace(fcd_handle *h) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    FCD_DEVICE(h);
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    if (h->own_stream && h->own_stream != h->stream) FCD_HIP(h, hipStreamSynchronize(h->own_stream));
+    if (h->arena) (void)hipFree(h->arena);
+    if (h->stage) (void)hipFree(h->stage);
+    if (h->lnbuf) (void)hipFree(h->lnbuf);
+    if (h->pin) (void)hipHostFree(h->pin);
+    h->arena = h->stage = h->lnbuf = h->pin = nullptr;
+    h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = 0;
+    return FCD_OK;
+}
+
 int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor) {
     if (!h || divisor < 0) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);

@@ -143,6 +143,10 @@ const char *fcd_last_error(const fcd_handle *h);         /* text of the last fai
 const char *fcd_status_string(int status);               /* exact SearchError Display text, src/lib.rs:46-53 */
 /* cap (bytes) on the per-call tree-arena workspace; batches needing more are decoded in chunks */
 int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes);
+/* The handle's device workspace (tree arena, staging) only grows and is kept between calls; this waits for the
+ * handle's stream and gives it all back (the next call allocates afresh).  For processes that share the GPU
+ * with another allocator (PyTorch's caching allocator) after an unusually large job. */
+int fcd_release_workspace(fcd_handle *h);
 /* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
  * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
  * it) and decode the reads that outgrow their slab again in worst-case slabs carved from the same arena.  A

@@ -750,3 +750,22 @@ def crf_greedy_fuzz_seed(fcd, seed):
 def test_crf_greedy_fuzz(fcd):
     for seed in range(7000, 7060):
         crf_greedy_fuzz_seed(fcd, seed)
+
+
+def test_release_workspace(fcd):
+    """fcd_release_workspace gives the arena / staging memory back; the next call allocates afresh and returns
+    the same results."""
+    from fast_ctc_decode_amd import _native as nat
+    x = gen_batch(4242, 6, 300, 5)
+    h = nat.default_handle()
+    for beam in (5, 32):
+        a = fcd.beam_search_batch_raw(x, beam, 0.1, True)
+        h.release_workspace()
+        b = fcd.beam_search_batch_raw(x, beam, 0.1, True)
+        np.testing.assert_array_equal(a.out_len, b.out_len)
+        np.testing.assert_array_equal(a.status, b.status)
+        for i in range(len(x)):
+            n = int(a.out_len[i])
+            np.testing.assert_array_equal(a.labels[i, :n], b.labels[i, :n])
+            np.testing.assert_array_equal(a.path[i, :n], b.path[i, :n])
+    check_beam(fcd, x, 5, 0.1)
