@@ -124,6 +124,23 @@ def test_duplex_vs_host_libm_tolerance(fcd):
     assert same >= 18, (same, 20)
 
 
+def test_duplex_vs_host_libm_many_pairs(fcd):
+    """The same tolerance statement on a sample large enough to put a number on it: 300 pairs (both searches,
+    two envelope widths) against the oracle on the host's glibc.  The kernels define ln / exp / ln_1p as correctly
+    rounded; glibc 2.35's are within 1 ULP, so a consensus differs only where a last-bit difference flips a
+    near-tie -- observed on the MI355X: 300 of 300 identical."""
+    same = total = 0
+    for seed, n, T, w in ((350, 200, 120, 16), (351, 100, 160, 40)):
+        x1, x2 = pairs(seed, n, T, T)
+        envs = np.stack([band(T, T, w)] * n)
+        got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+        want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+        same += sum(g == w_ for g, w_ in zip(got, want))
+        total += n
+    print("duplex vs host libm: %d of %d pairs identical" % (same, total))
+    assert same >= 0.9 * total, (same, total)
+
+
 def test_duplex_config5_shape_sample(fcd):
     """BASELINE config 5 shape (T1 = T2 = 2000, band +-64) on a few pairs, exact vs the CR oracle."""
     x1, x2 = pairs(4, 3, 2000, 2000)
