@@ -21,6 +21,10 @@
 //   * survivors publish their record in rank order (LDS), lane r picks up record r, the child entries
 //     follow through a second table, a re-entering node re-reads its row from HBM.
 // Tree arena and the segment-parallel leaf -> root walk are beam_wave.hip's.
+#ifdef FCD_HIPEMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 #include "device_utils.h"
 #include "fcd_internal.h"
 
@@ -611,6 +615,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 e[l] = reload ? load_i32_l2(reinterpret_cast<int32_t *>(row_at(n_node)) + l) : -1;
+#ifdef FCD_HIPEMU  // (lockstep emulation: device memory arrives poisoned with 0xA5)
+                if (reload && e[l] == (int)0xA5A5A5A5) {  // never written: the dead-row test was wrong
+                    fprintf(stderr, "beam_lane: node %d re-entered the beam but its child row was never stored\n", n_node);
+                    abort();
+                }
+#endif
                 // only a child that has been a beam entry (EVER) can be one now
                 eid[l] = (e[l] >= 0 && (e[l] & kEver)) ? (e[l] & kIdMask) : -2;
                 eslot[l] = -1;

@@ -41,6 +41,10 @@
 // dependent pointers with a single lane.  EVER marks children that have themselves been in the
 // beam: only those can own children, so only their row is re-read when they re-enter the beam
 // (3.9 % of steps on BASELINE's generator) -- everything else stays in registers.
+#ifdef FCD_HIPEMU
+#include <stdio.h>
+#include <stdlib.h>
+#endif
 #include "device_utils.h"
 #include "fcd_internal.h"
 
@@ -497,6 +501,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             // children are beam entries right now has to be looked up (rare path)
             int e = -1;
             if (reload) e = load_i32_l2(at32(rows_w, (hoff + (uint32_t)(n_node + 1)) * RW + l));
+#ifdef FCD_HIPEMU  // (lockstep emulation, tests/hipemu: device memory arrives poisoned with 0xA5)
+            if (reload && e == (int)0xA5A5A5A5) {  // a row that was never written: the dead-row test (above) was wrong
+                fprintf(stderr, "beam_wave: node %d re-entered the beam but its child row was never stored\n", n_node);
+                abort();
+            }
+#endif
 #pragma unroll
             for (int j = 0; j < BCAP; ++j) {
                 const int nj = bperm(hbase + j * GW, n_node);
