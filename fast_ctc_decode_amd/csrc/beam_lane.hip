@@ -181,7 +181,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     char *const jmp_w = reinterpret_cast<char *>(p.arena.jmp + wslab * p.arena.cap_nodes);
     char *const rows_w = reinterpret_cast<char *>(p.arena.rows + wslab * p.arena.cap_nodes * RW);
     const uint32_t hoff = (RPW == 2 && has_read && hh) ? (uint32_t)cap : 0u;  // this half's slab, in nodes
-    auto rec_at = [&](int id) -> int2 * { return reinterpret_cast<int2 *>(rec_w + ((hoff + (uint32_t)id) << 3)); };
+    auto rec_at = [&](int id) -> int32_t * { return reinterpret_cast<int32_t *>(rec_w + ((hoff + (uint32_t)id) << 2)); };
+    // first[t] = the read's node count when step t began: ids are dense and in creation order, so node h was
+    // created in the last step t with first[t] <= h -- which is what `path` reports.  One 4-byte store per step
+    // instead of a time word in every record (43 per step at beam 32).
+    char *const first_w = reinterpret_cast<char *>(p.arena.first + wslab * p.arena.first_stride);
+    const uint32_t foff = (RPW == 2 && has_read && hh) ? (uint32_t)p.arena.first_stride : 0u;
+    auto first_at = [&](int t) -> int32_t * { return reinterpret_cast<int32_t *>(first_w + ((foff + (uint32_t)t) << 2)); };
     auto jmp_at = [&](int id) -> int32_t * { return reinterpret_cast<int32_t *>(jmp_w + ((hoff + (uint32_t)id) << 2)); };
     auto row_at = [&](int id) -> char * { return rows_w + (hoff + (uint32_t)id) * (uint32_t)(RW * 4); };
 
@@ -309,6 +315,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 
         // ---- tree.rs:125-145 add_node: ids in (beam order, label order) ----
         const int incl = half_prefix_add<RPW>(n_new);
+        if (q == 0 && act) *first_at(t) = nn;
         int next_id = nn + incl - n_new;
         nn += RPW == 1 ? rdlane(incl, 63) : bperm(hbase + HALF - 1, incl);
         const bool f_cap = act && nn > cap;
@@ -317,7 +324,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const bool is_new = cvalid[l] && child[l] < 0;
             if (is_new && !f_cap) {
                 const int id = next_id++;
-                *rec_at(id) = make_int2(node, (t << 3) | l);
+                *rec_at(id) = ((node + 1) << 3) | l;
                 if ((depth + 1) % kSeg == 0) *jmp_at(id) = (depth % kSeg == 0) ? node : jump;
                 child[l] = id;
             }
@@ -701,11 +708,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const int de = q == 0 ? d1 : ds - kSeg;
             int h = s_heads[hbase + q];
             int dd = ds;
+            // creation step of the segment's first node: the last t with first[t] <= h (binary search); every
+            // further node on the way up was created strictly earlier, usually a step or two: scan backwards
+            int tc = 0;
+            if (h >= 0) {
+                int lo = 0, hi = T - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (*first_at(mid) <= h) lo = mid;
+                    else hi = mid - 1;
+                }
+                tc = lo;
+            }
+            int fc = h >= 0 ? *first_at(tc) : 0;        // first[tc], kept in a register
+            auto time_of = [&](int id) -> uint32_t {  // tc: creation step of the node visited before (or of `id`)
+                while (fc > id) fc = *first_at(--tc);   // first[0] = 0 <= id: terminates
+                return (uint32_t)tc;
+            };
             auto one = [&]() {  // emit position dd - 1, step to the parent
-                const int2 e = *rec_at(h);
-                lab[dd - 1] = (uint8_t)((e.y & 7) + 1);
-                if (pth) pth[dd - 1] = (uint32_t)(e.y >> 3);
-                h = e.x;
+                const int e = *rec_at(h);
+                lab[dd - 1] = (uint8_t)((e & 7) + 1);
+                if (pth) pth[dd - 1] = time_of(h);
+                h = (e >> 3) - 1;
                 --dd;
             };
             // aligned rows: four positions leave as one 4-byte label store and one 16-byte path store (beam_wave.hip)
@@ -716,10 +740,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 uint32_t tw[4];
 #pragma unroll
                 for (int j = 3; j >= 0; --j) {  // positions dd-1 (j = 3) ... dd-4 (j = 0)
-                    const int2 e = *rec_at(h);
-                    lw |= (uint32_t)((e.y & 7) + 1) << (8 * j);
-                    tw[j] = (uint32_t)(e.y >> 3);
-                    h = e.x;
+                    const int e = *rec_at(h);
+                    lw |= (uint32_t)((e & 7) + 1) << (8 * j);
+                    tw[j] = pth ? time_of(h) : 0u;
+                    h = (e >> 3) - 1;
                 }
                 *reinterpret_cast<uint32_t *>(lab + dd - 4) = lw;
                 if (pth) *reinterpret_cast<uint4 *>(pth + dd - 4) = make_uint4(tw[0], tw[1], tw[2], tw[3]);

@@ -193,7 +193,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // node + 1: the root (node -1) owns row 0 and needs no special case.
     const int cap = (int)p.arena.cap_nodes;
     const int64_t wslab = ((int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wave)) * RPW;
-    int32_t *const rec_w = reinterpret_cast<int32_t *>(p.arena.rec) + wslab * p.arena.cap_nodes;
+    int32_t *const rec_w = p.arena.rec + wslab * p.arena.cap_nodes;
     int32_t *const jmp_w = p.arena.jmp + wslab * p.arena.cap_nodes;
     int32_t *const rows_w = p.arena.rows + wslab * p.arena.cap_nodes * RW;
     const uint32_t hoff = has_read ? (uint32_t)(lane / HALF) * (uint32_t)cap : 0u;  // this half's slab, in nodes

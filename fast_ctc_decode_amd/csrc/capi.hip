@@ -186,7 +186,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         cap_nodes = use_wave ? ((T << wave_shift) + 8 + 3) & ~3ll
                              : (T * std::min<int64_t>(beam, 64) * NL + 8 + 3) & ~3ll;  // rows stay 16-B aligned
         const int row_words = NL <= 4 ? 4 : 8;
-        per_read = (size_t)cap_nodes * ((use_wave ? 4 : sizeof(int2)) + 4 + row_words * 4);
+        per_read = (size_t)cap_nodes * (4 + 4 + row_words * 4);
     } else {
         if (beam > (1 << 16)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 65536");
         if (beam_generic_lds_bytes((int)beam, N) > 64 * 1024)
@@ -206,15 +206,20 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     // point waits for the device -- so it is used only when the worst-case arena would exceed 8 GiB (or the
     // workspace limit).  A job in which more than a quarter of the reads overflow (dense posteriors: nearly
     // every extension passes the cut) makes this handle size later jobs for the worst case straight away.
-    const size_t rec_bytes = use_wave ? 4 : sizeof(int2);
+    // both register kernels keep 4-byte records (parent, label); the creation time is the upper part of the id
+    // (wave kernel) or comes from the lane kernel's per-step table of first ids: T + 1 more words per slab
+    const size_t rec_bytes = 4;
     const size_t node_bytes = (use_wave || use_lane) ? rec_bytes + 4 + (NL <= 4 ? 4 : 8) * 4 : 0;
-    const size_t worst_total = (size_t)cap_nodes * node_bytes * (size_t)d.n_reads;
+    const int64_t first_stride = use_lane ? ((T + 1 + 3) & ~3ll) : 0;
+    const size_t first_bytes = (size_t)first_stride * 4;
+    if (use_lane) per_read += first_bytes;
+    const size_t worst_total = ((size_t)cap_nodes * node_bytes + first_bytes) * (size_t)d.n_reads;
     const bool two_pass = use_lane && (worst_total > ((size_t)8 << 30) || (int64_t)worst_total > budget);
     const int64_t cap_worst = cap_nodes;
-    const size_t worst_read = (size_t)cap_worst * node_bytes;
+    const size_t worst_read = (size_t)cap_worst * node_bytes + first_bytes;
     if (two_pass) {
         cap_nodes = (cap_worst / std::max(h->first_pass_div, 1) + 63) & ~63ll;
-        per_read = (size_t)cap_nodes * node_bytes;
+        per_read = (size_t)cap_nodes * node_bytes + first_bytes;
     }
     int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
     chunk = std::min<int64_t>(chunk, d.n_reads);
@@ -233,9 +238,11 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         WaveArena ar{};
         ar.cap_nodes = cap;
         ar.row_words = NL <= 4 ? 4 : 8;
-        ar.rec = reinterpret_cast<int2 *>(base);
+        ar.rec = reinterpret_cast<int32_t *>(base);
         ar.jmp = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * rec_bytes);
         ar.rows = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * (rec_bytes + 4));
+        ar.first = reinterpret_cast<int32_t *>(base + (size_t)slabs * cap * node_bytes);
+        ar.first_stride = first_stride;
         return ar;
     };
 

@@ -60,14 +60,16 @@ struct GenericArena {
 };
 
 // Tree arena of the register-resident ("wave") beam kernel.
-//   rec  : lane kernel: int2 {parent, time<<3 | label} per node; wave kernel: i32 (parent+1)<<3 | label (the
-//          creation time is the upper part of the node id)
+//   rec  : i32 (parent + 1) << 3 | label per node; the creation time -- what `path` reports -- is the upper part
+//          of the node id (wave kernel) or looked up in `first` (lane kernel, dense ids)
 //   jmp  : i32 per node, written for nodes at depth % 64 == 0: next such ancestor (traceback)
 //   rows : int4 per node (NL <= 4) or 8 x int32 (NL <= 6..7); entry = child | EVER bit, or -1
 struct WaveArena {
-    int2 *rec;
+    int32_t *rec;
     int32_t *jmp;
     int32_t *rows;
+    int32_t *first;        // lane kernel: first[slab][t] = the read's node count when step t began
+    int64_t first_stride;  // words per slab of `first`
     int64_t cap_nodes;
     int row_words;  // 4 or 8
     // retry pass of the lane kernel (one read per wavefront): only reads whose first-pass slab overflowed
