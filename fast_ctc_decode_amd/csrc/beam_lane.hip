@@ -409,13 +409,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         }
         if (ballot(Lc > LCAP) == 0ull) {
             int base = 0;
+            // "bucket <= bstar" as one compare per candidate: bucket = min((mx - hi) >> shift, KB - 1) <= bstar  <=>
+            // mx - hi < (bstar + 1) << shift (everything qualifies when bstar is the catch-all bucket)  <=>  hi >= lim
+            const uint32_t span = (uint32_t)(bstar + 1) << kBucketShift;
+            const uint32_t lim = (!need_sel || bstar >= KB - 1 || mx < span) ? 0u : mx - span + 1u;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                bool in = key[k] != 0ull;
-                if (in && need_sel) {
-                    const uint32_t d = (mx - (uint32_t)(key[k] >> 32)) >> kBucketShift;
-                    in = (int)(d < (uint32_t)(KB - 1) ? d : (uint32_t)(KB - 1)) <= bstar;
-                }
+                const bool in = key[k] != 0ull && (uint32_t)(key[k] >> 32) >= lim;
                 const uint64_t m_in = hmask(ballot(in));
                 if (in) {
                     const int pos = base + popc64(m_in & below);
