@@ -263,6 +263,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
         for (int c = 0; c < N; ++c)
             pr[c] = CRF ? rowv[c] : (RPW == 1 ? rdlanef(win[0], g * N + c) : bpermf(hbase + g * N + c, win[0]));
+        const int g_row = g;            // (the FIFO may rotate below: the tip's column is fetched from this row later)
+        const float win_row = win[0];
         if (!CRF && ++g == RPR) {
             g = 0;
 #pragma unroll
@@ -301,9 +303,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         const uint64_t iv = s_inc[lane];
         const bool has_inc = ent && (iv >> 32) != 0ull;
         const float inc = __int_as_float((int)(uint32_t)iv);
+        // the tip label's column of the row: one more cross-lane fetch instead of a compare-and-select per label
+        // (CRF: no repeat-stay, unused)
         float ptip = 0.0f;
-#pragma unroll
-        for (int l = 0; l < NL; ++l) ptip = (tip == l) ? pr[l + 1] : ptip;
+        if (!CRF) ptip = bpermf(hbase + g_row * N + tip + 1, win_row);
         const float pr0 = pr[0];
         const bool blank = pr0 > thr;
         const float gpn = (lp + gp) * pr0;
@@ -576,12 +579,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             }
             child[l] = ch;
         }
-        // word l of this entry's child row as it is stored: the entry without its beam-position bits, or -1
+        // word l of this entry's child row as it is stored: the entry as it is (its beam-position bits are stale by
+        // the time the row is read back and are stripped THERE, on the rare path), or -1
         int row_word[RW];
 #pragma unroll
         for (int l = 0; l < RW; ++l) row_word[l] = -1;
 #pragma unroll
-        for (int l = 0; l < NL; ++l) row_word[l] = child[l] >= 0 ? (child[l] & kStored) : -1;
+        for (int l = 0; l < NL; ++l) row_word[l] = child[l];
         // A node re-enters the beam only as the extension of its parent, so it needs a proper ancestor in the beam:
         // once every beam entry is at least as deep as the node none is one, and none ever will be (the minimum
         // depth of the beam never decreases).  Such a node's row is dead and is not written -- most evicted rows.
@@ -622,6 +626,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
             for (int l = 0; l < NL; ++l) {
                 e[l] = reload ? load_i32_l2(reinterpret_cast<int32_t *>(row_at(n_node)) + l) : -1;
+                if (e[l] >= 0) e[l] &= kStored;  // (written with whatever beam-position bits the entry had at eviction)
 #ifdef FCD_HIPEMU  // (lockstep emulation: device memory arrives poisoned with 0xA5)
                 if (reload && e[l] == (int)0xA5A5A5A5) {  // never written: the dead-row test was wrong
                     fprintf(stderr, "beam_lane: node %d re-entered the beam but its child row was never stored\n", n_node);

@@ -468,10 +468,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             // parent, so it needs a proper ancestor in the beam -- none exists once every beam entry is at least as
             // deep as the node, and then none ever will (its ancestors have left for good, top-down from the
             // root).  Three evicted rows in four are dead by this test and are never written.
-            // (-1 keeps its sign bit: "no child" stays negative in the stored form)
             const bool dead = (depth << 8) <= e_min;  // e_min = (minimum depth << 8) | a lane address
             if (upd && grp && own == 0 && !dead)
-                *at32(rows_w, (hoff + (uint32_t)(node + 1)) * RW + l) = child & (kStored | (int)0x80000000);
+                *at32(rows_w, (hoff + (uint32_t)(node + 1)) * RW + l) = child;  // (beam-position bits and all: stripped when read back)
         }
 
         stamp_i(4, child);  // fate of every child entry, row eviction
@@ -507,6 +506,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
                 abort();
             }
 #endif
+            if (e >= 0) e &= kStored;  // the stored entry still carries the beam-position bits it had at eviction
 #pragma unroll
             for (int j = 0; j < BCAP; ++j) {
                 const int nj = bperm(hbase + j * GW, n_node);
