@@ -96,6 +96,19 @@ __device__ __forceinline__ int half_min_in_last_lane(int x) {
     return t;
 }
 
+// the same for unsigned values
+template <int RPW>
+__device__ __forceinline__ int half_umin_in_last_lane(int x) {
+    auto umin = [](int a, int b) { return (int)min((uint32_t)a, (uint32_t)b); };
+    int t = umin(x, dpp_or_self<0x111, 0xf, 0xf>(x));
+    t = umin(t, dpp_or_self<0x112, 0xf, 0xf>(t));
+    t = umin(t, dpp_or_self<0x114, 0xf, 0xf>(t));
+    t = umin(t, dpp_or_self<0x118, 0xf, 0xf>(t));
+    t = umin(t, dpp_or_self<0x142, 0xa, 0xf>(t));
+    if (RPW == 1) t = umin(t, dpp_or_self<0x143, 0xc, 0xf>(t));
+    return t;
+}
+
 __device__ __forceinline__ int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ float bpermf(int src_lane, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
@@ -378,11 +391,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 const uint32_t hi = (uint32_t)(key[k] >> 32);
                 mx = hi > mx ? hi : mx;
             }
-#pragma unroll
-            for (int o = HALF / 2; o > 0; o >>= 1) {
-                const uint32_t other = (uint32_t)__shfl_xor((int)mx, o);
-                mx = other > mx ? other : mx;
-            }
+            // maximum over the half: the DPP reduction of half_min_in_last_lane on the complement (keys are unsigned)
+            mx = ~(uint32_t)bperm(hbase + HALF - 1, half_umin_in_last_lane<RPW>((int)~mx));
             *reinterpret_cast<int4 *>(hist + 4 * lane) = make_int4(0, 0, 0, 0);
             wave_sync();
 #pragma unroll
