@@ -138,7 +138,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     __shared__ __attribute__((aligned(16))) int4 s_u[64 * N / 2 > 160 ? 64 * N / 2 : 160];  // hist+list | all keys
     __shared__ __attribute__((aligned(8))) int8_t s_rank[64 * 8];  // rank of candidate (lane, k), -1 = out
     __shared__ __attribute__((aligned(16))) int4 s_rec[64 * 2];     // survivor records by (half, rank)
-    __shared__ int s_fate[64];                           // new slot of old slot i's own candidate, or -1
+    __shared__ int s_fate[64];   // where old slot i's own candidate went: new slot | 64 (the IN-BEAM bit of the field), or 0
     __shared__ __attribute__((aligned(16))) int s_child[64 * RW];   // child entries of old slot i
     __shared__ int s_heads[64];
 
@@ -543,7 +543,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         }
 
         // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
-        s_fate[lane] = rank[0];
+        // kInBeam == 64 << kSlotShift: the published value, shifted, IS the (slot, IN-BEAM) field of a child entry
+        static_assert(kInBeam == (64 << kSlotShift) && kSlotMask == 63, "child-entry bit layout");
+        s_fate[lane] = rank[0] >= 0 ? (rank[0] | 64) : 0;
         // a record is {label prob, gap prob, node, meta | jump, source lane, -, CRF state}: written dword by dword
         // behind an offset the compiler cannot see through, so that the stores pair up from whatever registers hold
         // the values (ds_write2_b32) instead of being moved into four consecutive ones for a 16-byte store
@@ -582,7 +584,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             if (ent && go && ch >= 0) {
                 if (ch & kInBeam) {
                     const int fate = s_fate[hbase + ((ch >> kSlotShift) & kSlotMask)];
-                    ch = (ch & kStored) | (fate >= 0 ? (kInBeam | (fate << kSlotShift)) : 0);
+                    ch = (ch & kStored) | (fate << kSlotShift);
                 } else if (rank[l + 1] >= 0) {
                     ch = (ch & kIdMask) | kEver | kInBeam | (rank[l + 1] << kSlotShift);
                 }
