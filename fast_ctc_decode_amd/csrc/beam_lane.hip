@@ -421,21 +421,27 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             wave_sync();
         }
         if (ballot(Lc > LCAP) == 0ull) {
-            int base = 0;
             // "bucket <= bstar" as one compare per candidate: bucket = min((mx - hi) >> shift, KB - 1) <= bstar  <=>
             // mx - hi < (bstar + 1) << shift (everything qualifies when bstar is the catch-all bucket)  <=>  hi >= lim
             const uint32_t span = (uint32_t)(bstar + 1) << kBucketShift;
             const uint32_t lim = (!need_sel || bstar >= KB - 1 || mx < span) ? 0u : mx - span + 1u;
+            // the list in lane order (its order does not matter to the ranking): one prefix sum over the lanes'
+            // counts instead of a vote and two population counts per candidate
+            bool in[N];
+            int cnt = 0;
 #pragma unroll
             for (int k = 0; k < N; ++k) {
-                const bool in = key[k] != 0ull && (uint32_t)(key[k] >> 32) >= lim;
-                const uint64_t m_in = hmask(ballot(in));
-                if (in) {
-                    const int pos = base + popc64(m_in & below);
+                in[k] = key[k] != 0ull && (uint32_t)(key[k] >> 32) >= lim;
+                cnt += in[k] ? 1 : 0;
+            }
+            int pos = half_prefix_add<RPW>(cnt) - cnt;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (in[k]) {
                     l_key[pos] = key[k];
                     l_src[pos] = lane * 8 + k;
                 }
-                base += popc64(m_in);
+                pos += in[k] ? 1 : 0;
             }
             // the ranking loop runs to a wave-uniform bound, eight keys at a time: pad this read's list with zero keys
             int lmax = Lc;
