@@ -571,13 +571,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const int meta = 0 | ((tip + 1) << 2) | (depth << 5);
             publish(hbase + rank[0], __float_as_int(slp), __float_as_int(sgp), node, meta, jump, state);
         }
+        const int jumpc = (depth % kSeg == 0) ? node : jump;  // a child's nearest segment head
+        const int metac = 1 | ((depth + 1) << 5);
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const int rk = rank[l + 1];
             if (rk >= 0) {  // the child by label l enters the beam
-                const int kind = (child[l] & kEver) ? 2 : 1;  // 2: it has been there before, its row is in HBM
-                const int meta = kind | ((l + 1) << 2) | ((depth + 1) << 5);
-                publish(hbase + rk, __float_as_int(contrib[l]), 0, ccand[l], meta, (depth % kSeg == 0) ? node : jump,
+                // kind 1, or 2 when it has been there before (EVER: its row is in HBM)
+                const int meta = (metac + (int)(((uint32_t)child[l] >> 30) & 1u)) | ((l + 1) << 2);
+                publish(hbase + rk, __float_as_int(contrib[l]), 0, ccand[l], meta, jumpc,
                         CRF ? ((state * NL) & s_mask) + l : 0);  // :97
             }
         }
