@@ -720,6 +720,17 @@ static inline float log1p_m(float x, int mode) {
 
 /* instrumentation for the duplex roofline (tools/bench_configs.py): LogSpace::add calls of this thread */
 static __thread int64_t g_logadd_calls = 0;
+static int64_t g_duplex_ties[4];
+/* test/analysis instrument (not thread-safe): {pruning steps, steps with > 20 candidates in which a kept candidate
+ * ties with another, steps with a tie across the truncation boundary, reads whose final top two tie} summed
+ * over the duplex searches run since the last reset */
+void fcdo_duplex_tie_steps(int64_t out[4], int reset) {
+    for (int i = 0; i < 4; ++i) {
+        if (out) out[i] = g_duplex_ties[i];
+        if (reset) g_duplex_ties[i] = 0;
+    }
+}
+
 int64_t fcdo_logadd_calls(int reset) {
     int64_t n = g_logadd_calls;
     if (reset) g_logadd_calls = 0;
@@ -1111,6 +1122,20 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
             break;
         }
         sp2k_sort_prob(keyed, beam.len, &ktmp, &ktmpcap);
+        { /* tie statistics (fcdo_duplex_tie_steps): :620 / :807 is sort_unstable_by, i.e. the order of EQUAL
+           * probabilities is Rust's pdqsort's above 20 candidates; this restatement keeps node order */
+            const int64_t n = beam.len, kept = n < beam_size ? n : beam_size;
+            int tie = 0, boundary = 0;
+            for (int64_t i = 0; i + 1 < n; ++i) {
+                if (keyed[i].prob != keyed[i + 1].prob) continue;
+                if (i < kept) tie = 1;
+                if (i + 1 == kept) boundary = 1;
+            }
+            g_duplex_ties[0] += 1;                                  /* pruning steps */
+            if (n > 20 && tie) g_duplex_ties[1] += 1;               /* > 20 candidates and a kept one tied */
+            if (boundary) g_duplex_ties[2] += 1;                    /* a tie across the truncation boundary */
+            if (t1 + 1 == n1->T && n >= 2 && keyed[0].prob == keyed[1].prob) g_duplex_ties[3] += 1; /* a tie for the answer */
+        }
         if (beam.len > beam_size) beam.len = beam_size; /* :632 */
         if (beam.len == 0) {                            /* :633-636 */
             status = FCDO_RAN_OUT_OF_BEAM;

@@ -183,6 +183,8 @@ float fcdo_secondary_update_max(const float *pairs, int64_t len, int64_t offset,
 float fcdo_logspace_add(float a, float b, int logadd_mode);
 /* number of LogSpace::add evaluations made by the calling thread since the last reset (instrumentation) */
 int64_t fcdo_logadd_calls(int reset);
+/* tie statistics of the duplex searches' prune (src/duplex.rs:620,807): see fcd_oracle.c */
+void fcdo_duplex_tie_steps(int64_t out[4], int reset);
 /* out[i] = fcdo_logspace_add(a[i], b[i], logadd_mode) -- lets tests compare millions of operands */
 void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int logadd_mode);
 

@@ -77,6 +77,8 @@ def _load():
     lib.fcdo_logspace_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i32]
     lib.fcdo_logspace_add_batch.restype = None
     lib.fcdo_logadd_calls.argtypes = [i32]
+    lib.fcdo_duplex_tie_steps.argtypes = [C.POINTER(i64), i32]
+    lib.fcdo_duplex_tie_steps.restype = None
     lib.fcdo_logadd_calls.restype = i64
     return lib
 
@@ -384,3 +386,12 @@ def viterbi_batch(x, collapse=True, n_threads=1):
     lib.fcdo_viterbi_batch(_ptr(x), B, T, N, int(collapse), _ptr(labels), _ptr(path), _ptr(lens),
                            n_threads)
     return labels, path, lens
+
+
+def duplex_tie_steps(reset=False):
+    """Tie statistics of the duplex searches run since the last reset (not thread-safe): dict with the number of
+    pruning steps, of steps with > 20 candidates in which a kept candidate ties with another, of steps with a tie
+    across the truncation boundary, and of reads whose final top two candidates tie (src/duplex.rs:620,807)."""
+    out = (C.c_int64 * 4)()
+    lib.fcdo_duplex_tie_steps(out, 1 if reset else 0)
+    return {"steps": out[0], "gt20_kept_tie": out[1], "boundary_tie": out[2], "final_top_tie": out[3]}
