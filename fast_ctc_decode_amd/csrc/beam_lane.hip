@@ -20,7 +20,10 @@
 //     travel back to the owning lanes through a byte table; heavily tied steps fall back to all-pairs;
 //   * survivors publish their record in rank order (LDS), lane r picks up record r, the child entries
 //     follow through a second table, a re-entering node re-reads its row from HBM.
-// Tree arena and the segment-parallel leaf -> root walk are beam_wave.hip's.
+// Tree arena and the segment-parallel leaf -> root walk are beam_wave.hip's, with dense node ids: a record is
+// (parent, label) and the creation time of a node -- what `path` reports -- is looked up in first[t], the read's
+// node count when step t began (one 4-byte store per step).  A leaving node's child row is written only if the
+// node can ever re-enter the beam (some beam entry is shallower; see beam_wave.hip).
 #ifdef FCD_HIPEMU
 #include <stdio.h>
 #include <stdlib.h>
@@ -207,7 +210,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     // votes and counts over this lane's half
     auto hmask = [&](uint64_t m) -> uint64_t { return RPW == 1 ? m : (hh ? (m >> 32) : (m & 0xFFFFFFFFull)); };
     auto hcount = [&](bool pred) -> int { return popc64(hmask(ballot(pred))); };
-    const uint64_t below = (1ull << q) - 1ull;  // lanes of my half before me
 
     // ---- beam state: lane q of a half = beam entry q (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
     int node = -1;
