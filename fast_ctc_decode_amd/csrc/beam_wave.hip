@@ -16,10 +16,10 @@
 // and a 64-entry sort-key table per wave.
 //
 // Per timestep:
-//   * posterior row: a register FIFO holds the next TR*RPR rows of each half's read, element
-//     (row g, column c) of the front register sitting in lane g*N+c, so the three values a lane
-//     needs (blank, its own label, the tip's label) are three ds_bpermutes -- no per-step memory
-//     access; one coalesced load per RPR steps refills the FIFO ~40 rows ahead;
+//   * posterior row: a register FIFO holds the next kFifo*RPR rows of each half's read, element
+//     (row g, column c) of the front register sitting in lane g*N+c, so the values a lane needs (its own
+//     column -- the blank on a slot's own lane -- and the tip's) are two ds_bpermutes, issued one step
+//     AHEAD; one coalesced load per RPR steps refills the FIFO ~40 rows ahead: no per-step memory access;
 //   * child lanes evaluate the extension (:200-239).  A child entry carries IN-BEAM/slot bits, so
 //     "is my target already a beam entry, and where?" costs no search: the extension is pushed to
 //     that slot's lane 0 (ds_permute), which adds it to its own blank/stay terms -- the
@@ -27,13 +27,16 @@
 //     f32 addends ever meet;
 //   * new tree nodes get ids in the reference's creation order via ballot + prefix popcount;
 //   * pruning ranks the candidates exactly on a 64-bit key (probability desc, node asc);
-//   * survivors are gathered into rank order with ds_bpermute and divided by the top
-//     probability (:278-282, IEEE f32 division).
+//   * survivors publish (lane, depth) by rank in a small LDS table: one round trip later every lane knows
+//     its source lane, where the best candidate sits and the minimum depth of the new beam; the survivors are
+//     gathered into rank order with ds_bpermute and divided by the top probability (:278-282, IEEE f32
+//     division: one per lane, the two quotients shared inside each group).
 //
 // Node ids are (time step << KS) | index among the nodes created in that step: creation order, as the reference's
 // tie-break needs, with the creation time -- what `path` reports -- readable off the id itself.
 // Tree arena (HBM, per read): rec[node] = (parent + 1) << 3 | label (4 bytes); rows[node] = the node's child
-// entries (id | EVER, or -1), written once, when the node is evicted from the beam; jmp[node]
+// entries (id | EVER, or -1), written when the node is evicted from the beam -- unless no beam entry is
+// shallower, in which case the node can never come back and its row is dead --; jmp[node]
 // (written only for nodes whose depth is a multiple of 64) = the nearest proper ancestor whose depth
 // is a multiple of 64.  Every beam entry carries its own jump pointer in a register, so the final
 // leaf -> root walk (:285-300) first hops along jump pointers to cut the labelling into 64-node
