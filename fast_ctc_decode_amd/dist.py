@@ -124,8 +124,10 @@ def unpack_results(bufs, counts, width):
 
     n_total = int(sum(counts))
     dev = bufs[0].device
-    labels = torch.zeros((n_total, width), dtype=torch.uint8, device=dev)
-    path = torch.zeros((n_total, width), dtype=torch.int32, device=dev)
+    # (rows are only defined up to out_len: on a GPU the 5 bytes x width x reads are not cleared first)
+    make = torch.empty if _is_device(bufs[0]) else torch.zeros
+    labels = make((n_total, width), dtype=torch.uint8, device=dev)
+    path = make((n_total, width), dtype=torch.int32, device=dev)
     out_len = torch.zeros(n_total, dtype=torch.int32, device=dev)
     status = torch.zeros(n_total, dtype=torch.int32, device=dev)
     row = 0
