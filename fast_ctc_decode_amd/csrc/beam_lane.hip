@@ -42,6 +42,7 @@ constexpr int kSlotShift = 23;
 constexpr int kSlotMask = 63;
 constexpr int kIdMask = (1 << 23) - 1;
 constexpr int kStored = kEver | kIdMask;
+constexpr int kParentStays = 1 << 20;  // s_fate marker: "your node leaves the beam, its parent stays" (no slot field looks like it)
 
 constexpr int kSeg = 64;        // nodes per traceback segment
 constexpr int kFifo = 4;        // registers in the row FIFO
@@ -580,7 +581,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const int rk = rank[l + 1];
             if (rk >= 0) {  // the child by label l enters the beam
                 // kind 1, or 2 when it has been there before (EVER: its row is in HBM)
-                const int meta = (metac + (int)(((uint32_t)child[l] >> 30) & 1u)) | ((l + 1) << 2);
+                const int ever = (int)(((uint32_t)child[l] >> 30) & 1u);
+                const int meta = (metac + ever) | ((l + 1) << 2);
                 publish(hbase + rk, __float_as_int(contrib[l]), 0, ccand[l], meta, jumpc,
                         CRF ? ((state * NL) & s_mask) + l : 0);  // :97
             }
@@ -593,8 +595,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             int ch = child[l];
             if (ent && go && ch >= 0) {
                 if (ch & kInBeam) {
-                    const int fate = s_fate[hbase + ((ch >> kSlotShift) & kSlotMask)];
+                    int *const fp = &s_fate[hbase + ((ch >> kSlotShift) & kSlotMask)];
+                    const int fate = *fp;
                     ch = (ch & kStored) | (fate << kSlotShift);
+                    // the child leaves the beam while this entry -- its parent, the only reader of that slot --
+                    // stays: tell the child's lane (see the row eviction below)
+                    if (fate == 0 && rank[0] >= 0) *fp = kParentStays;
                 } else if (rank[l + 1] >= 0) {
                     ch = (ch & kIdMask) | kEver | kInBeam | (rank[l + 1] << kSlotShift);
                 }
@@ -608,21 +614,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         for (int l = 0; l < RW; ++l) row_word[l] = -1;
 #pragma unroll
         for (int l = 0; l < NL; ++l) row_word[l] = child[l];
-        // A node re-enters the beam only as the extension of its parent, so it needs a proper ancestor in the beam:
-        // once every beam entry is at least as deep as the node none is one, and none ever will be (the minimum
-        // depth of the beam never decreases).  Such a node's row is dead and is not written -- most evicted rows.
-        int mind = 0x7FFFFFFF;  // smallest depth among the survivors this entry contributes ...
-        if (rank[0] >= 0) mind = depth;
-#pragma unroll
-        for (int l = 0; l < NL; ++l)
-            if (rank[l + 1] >= 0) mind = min(mind, depth + 1);
-        mind = bperm(hbase + HALF - 1, half_min_in_last_lane<RPW>(mind));  // ... and in the whole new beam
-        if (ent && go && rank[0] < 0 && node >= 0 && depth > mind) {
-            // this node leaves the beam and may come back: its child row has to exist in HBM from now on
-            int4 *row = reinterpret_cast<int4 *>(row_at(node));
-            row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
-            if (RW == 8) row[1] = make_int4(row_word[RW - 4], row_word[RW - 3], row_word[RW - 2], row_word[RW - 1]);
-        }
 #pragma unroll
         for (int l = 0; l < RW; ++l) s_child[lane * RW + l] = -1;
 #pragma unroll
@@ -641,7 +632,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
         for (int l = 0; l < NL; ++l) n_child[l] = n_kind == 0 ? s_child[src * RW + l] : -1;
         const bool reload = q < Bn && n_kind == 2;
-        if (ballot(reload) != 0ull) {
+        const uint64_t m_reload = ballot(reload);
+        // A node re-enters the beam only as the extension of its parent, so it needs a proper ancestor in the beam:
+        // once every beam entry is at least as deep as the node none is one, and none ever will be (the minimum
+        // depth of the beam never decreases).  Such a node's row is dead and is not written -- most evicted rows.
+        int mind = 0x7FFFFFFF;  // smallest depth among the survivors this entry contributes ...
+        if (rank[0] >= 0) mind = depth;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if (rank[l + 1] >= 0) mind = min(mind, depth + 1);
+        mind = bperm(hbase + HALF - 1, half_min_in_last_lane<RPW>(mind));  // ... and in the whole new beam
+        // One level further the test is still exact: a node exactly one deeper than the shallowest beam entry can
+        // only come back through its PARENT (any other ancestor is shallower than every beam entry).  A parent that
+        // stays in the beam has just said so (above); a parent that is only now coming back itself has not, so a
+        // step in which any node re-enters the beam keeps the plain depth test.
+        const bool any_reent = hmask(m_reload) != 0ull;
+        const bool parent_stays = s_fate[lane] == kParentStays;
+        const bool dead = depth <= mind || (depth == mind + 1 && !parent_stays && !any_reent);
+        if (ent && go && rank[0] < 0 && node >= 0 && !dead) {
+            // this node leaves the beam and may come back: its child row has to exist in HBM from now on
+            int4 *row = reinterpret_cast<int4 *>(row_at(node));
+            row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
+            if (RW == 8) row[1] = make_int4(row_word[RW - 4], row_word[RW - 3], row_word[RW - 2], row_word[RW - 1]);
+        }
+        if (m_reload != 0ull) {
             // a node that was in the beam before comes back: its row is in HBM, and which of its
             // children are beam entries right now has to be looked up
             int e[NL], eid[NL], eslot[NL];
