@@ -143,3 +143,20 @@ def test_logspace_add():  # src/duplex.rs:42-63
     assert abs(add(np.log(0.25), np.log(0.5), 0) - np.log(0.75)) < 1e-6
     assert add(-1.0, -2.0, 1) == -1.0  # max mode
     assert np.isnan(add(float("nan"), -1.0, 0)) and np.isnan(add(-1.0, float("nan"), 0))
+
+
+def test_duplex_tie_statistics_instrument():
+    """fcdo_duplex_tie_steps (analysis instrument, tools/duplex_ties.py): counts pruning steps and reports ties
+    where the inputs force them -- two identical symbol columns make the two extensions of every entry tie."""
+    from oracle import oracle
+    rng = np.random.default_rng(9)
+    T = 30
+    x = rng.random((T, 5)).astype(np.float32)
+    x[:, 2] = x[:, 1]                      # labels 1 and 2 always have equal probability
+    x /= x.sum(-1, keepdims=True)
+    env = np.stack([np.zeros(T, np.uint64), np.full(T, T, np.uint64)], 1)
+    oracle.duplex_tie_steps(reset=True)
+    oracle.beam_search_duplex(x, x, "NACGT", env, 5, 0.0, True, oracle.MAXMODE)
+    st = oracle.duplex_tie_steps(reset=True)
+    assert st["steps"] == T and st["boundary_tie"] + st["gt20_kept_tie"] > 0, st
+    assert oracle.duplex_tie_steps()["steps"] == 0
