@@ -97,3 +97,18 @@ def test_duplex(fcd):
 
 def test_envelope(fcd):
     E.test_envelope_equals_model(fcd, 3)
+
+
+def test_beam_fuzz_slice_and_misc(fcd):
+    """A slice of the randomised differential fuzz (random shapes / beams / thresholds / ragged lengths / quantised
+    ties) on every kernel selection, failing reads, workspace release."""
+    for seed in range(52000, 52030):
+        x, beam, thr, collapse, lengths = P._fuzz_case(seed)
+        for kernel in (0, 1, 2, 3, 4):
+            try:
+                P.check_beam(fcd, x, beam, thr, collapse, lengths=lengths, kernel=kernel)
+            except RuntimeError as e:  # a forced kernel that does not cover the shape says so
+                assert kernel in (2, 3, 4) and " kernel: " in str(e), (seed, kernel, str(e))
+    P.test_beam_peaky(fcd, 2)
+    P.test_beam_peaky(fcd, 3)
+    P.test_release_workspace(fcd)
