@@ -6,8 +6,9 @@
 
 A "step" is one pass of the hot path -- search::beam_search (beam_size 5, beam_cut_threshold 0.1,
 collapse_repeats) over one batch of 4096 synthetic reads of T=4000 x N=5 f32 posteriors per GPU
-(BASELINE.json configs[1]) -- with the posteriors already resident in HBM when the timed region
-starts.  Reads are independent, so N GPUs decode N independent shards (weak scaling, no collective
+(BASELINE.json configs[1]; `--config 3` / `--config 4` select configs[2]'s per-rank shard -- beam 32, 8192
+reads -- and configs[3], the CRF search, under the same contract) -- with the posteriors already resident
+in HBM when the timed region starts.  Reads are independent, so N GPUs decode N independent shards (weak scaling, no collective
 inside the search); for N > 1 each step ends with ONE RCCL gather of the decoded
 (labels, path, lengths) to rank 0 over xGMI, inside the timed region.
 
@@ -16,7 +17,9 @@ Rank 0 prints ONE JSON line.  `value` is whole-job reads/s = N * batch * K / max
 (T*N*4 in + 5 bytes per emitted label out) over the kernel's own duration measured
 with HIP events on the launch stream.  `cpu_baseline` is the CPU oracle (a C restatement of the
 reference's Rust, NOT the Rust itself) timed on this box's host cores on a bounded sample, whose
-outputs are also compared with the GPU's.
+outputs are also compared with the GPU's.  `e2e` (N = 1) is what a caller holding HOST numpy arrays gets from
+the compiled module's batch function -- upload, search, packed download and Python objects, pipelined in
+chunks -- with array paths and with the reference's list[int] paths; it is never `value`.
 """
 import argparse
 import json
@@ -31,6 +34,19 @@ sys.path.insert(0, ROOT)
 
 T, N, BEAM, THR = 4000, 5, 5, 0.1
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 measured copy)
+
+# BASELINE.json configs that fit this contract (one search over one batch per step, T = 4000, N = 5).  The
+# default -- what `value` is quoted on -- is config 2 (configs[1]); `--config 3` is the multi-GPU config's
+# per-rank shard (64k reads over 8 ranks = 8192 per rank, beam 32), `--config 4` the CRF search.
+CONFIGS = {
+    2: dict(beam=5, thr=0.1, batch=4096, seed=1, crf=False, kernel_prefix="beam_wave_kernel<5, 6, 2, 0",
+            kernel_name="beam_wave_kernel (two reads per wavefront)", baseline="BASELINE.json configs[1]"),
+    3: dict(beam=32, thr=0.1, batch=8192, seed=2, crf=False, kernel_prefix="beam_lane_kernel<5, 2",
+            kernel_name="beam_lane_kernel (one beam entry per lane, two reads per wavefront)",
+            baseline="BASELINE.json configs[2]: 64k reads sharded over 8 GPUs = 8192 per rank"),
+    4: dict(beam=5, thr=0.0, batch=4096, seed=3, crf=True, kernel_prefix="beam_wave_kernel<5, 6, 2, 4",
+            kernel_name="beam_wave_kernel (CRF, 4 states, two reads per wavefront)", baseline="BASELINE.json configs[3]"),
+}
 
 
 def make_batch(seed, n_reads):
@@ -53,7 +69,7 @@ def make_batch_peaky(seed, n_reads):
     return z.reshape(n_reads, T, N).astype(np.float32)
 
 
-def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
+def cpu_baseline(cfg, x_host, init_host, gpu_labels, gpu_path, gpu_len, budget_s):
     """Times the oracle (C restatement of src/search.rs -- NOT the Rust) on this box's host cores
     on a bounded sample of the same workload and checks the GPU's outputs against it.
 
@@ -62,16 +78,34 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
     run uses the best count and ~budget_s seconds of wall time."""
     from oracle import oracle
 
+    beam, thr = cfg["beam"], cfg["thr"]
     n_avail = x_host.shape[0]
     max_threads = os.cpu_count() or 1
+    if cfg["crf"]:
+        # the oracle has no threaded CRF driver: one thread, a handful of reads
+        n = 0
+        mism = 0
+        t0 = time.perf_counter()
+        while n < min(n_avail, 64) and time.perf_counter() - t0 < budget_s:
+            st, labels, path, _ = oracle.crf_beam_search_ambiguous(x_host[n], init_host[n], beam, thr)
+            L = len(labels)
+            ok = st == 0 and int(gpu_len[n]) == L and np.array_equal(gpu_labels[n, :L], labels) \
+                and np.array_equal(gpu_path[n, :L].astype(np.int64), path)
+            mism += 0 if ok else 1
+            n += 1
+        dt = time.perf_counter() - t0
+        return {"value": n / dt, "unit": "reads/s", "cores": 1, "kind": "port",
+                "sample": "first %d reads of rank 0's batch (T=%d S=4 N=%d beam=%d thr=%.1f), oracle C restatement of "
+                          "src/search.rs crf_beam_search, 1 thread, %.1f s" % (n, T, N, beam, thr, dt),
+                "single_thread_reads_per_s": n / dt, "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n}
 
     def run(n, threads, passes=1, out=None):
         out = out or oracle.batch_outputs(n, T)
         t0 = time.perf_counter()
-        res = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, threads, n_passes=passes, out=out)
+        res = oracle.beam_search_batch(x_host[:n], beam, thr, True, threads, n_passes=passes, out=out)
         return n * passes / (time.perf_counter() - t0), res
 
-    rate1, _ = run(32, 1)
+    rate1, _ = run(32 if beam <= 8 else 8, 1)
     best_rate, best_threads = rate1, 1
     threads = 2
     while threads <= max_threads:
@@ -86,7 +120,7 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
     passes = int(max(1, min(256, best_rate * budget_s / n)))
     out = oracle.batch_outputs(n, T)  # pre-touched: page faults stay out of the timed call
     t0 = time.perf_counter()
-    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], BEAM, THR, True, best_threads,
+    labels, path, lens, status = oracle.beam_search_batch(x_host[:n], beam, thr, True, best_threads,
                                                           n_passes=passes, out=out)
     dt = time.perf_counter() - t0
     mism = 0
@@ -100,25 +134,99 @@ def cpu_baseline(x_host, gpu_labels, gpu_path, gpu_len, budget_s):
         "value": n * passes / dt, "unit": "reads/s", "cores": best_threads, "kind": "port",
         "sample": "first %d reads of rank 0's batch x %d passes (T=%d N=%d beam=%d thr=%.1f), oracle C "
                   "restatement of src/search.rs, %d pthreads (best of a 1,2,4,.. probe; os.cpu_count()=%d), "
-                  "%.1f s" % (n, passes, T, N, BEAM, THR, best_threads, max_threads, dt),
+                  "%.1f s" % (n, passes, T, N, beam, thr, best_threads, max_threads, dt),
         "single_thread_reads_per_s": rate1,
         "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n,
     }
 
 
+KERNEL_SOURCES = {  # the files a kernel's instruction stream and memory traffic depend on
+    "beam_wave_kernel": ("beam_wave.hip", "device_utils.h"),
+    "beam_lane_kernel": ("beam_lane.hip", "device_utils.h"),
+    "beam_generic_kernel": ("beam_generic.hip", "device_utils.h"),
+    "viterbi": ("viterbi.hip", "device_utils.h"),
+    "crf_greedy": ("viterbi.hip", "device_utils.h"),
+    "duplex_kernel": ("duplex.hip", "logadd_fast.h", "device_utils.h"),
+    "envelope_kernel": ("envelope.hip", "device_utils.h"),
+}
+
+
+def kernel_source_digest(kernel_prefix=None):
+    """{file: md5} of the kernel sources (all of them, or the ones `kernel_prefix` depends on).  Committed counter
+    summaries carry the digests of the sources they were taken on, and bench.py quotes them only while those files
+    are unchanged: a kernel change without a re-profile gives null, not stale bytes."""
+    import hashlib
+    csrc = os.path.join(ROOT, "fast_ctc_decode_amd", "csrc")
+    files = sorted({f for fs in KERNEL_SOURCES.values() for f in fs})
+    if kernel_prefix is not None:
+        files = []
+        for k, fs in KERNEL_SOURCES.items():
+            if kernel_prefix.startswith(k):
+                files = list(fs)
+    out = {}
+    for name in files:
+        with open(os.path.join(csrc, name), "rb") as f:
+            out[name] = hashlib.md5(f.read()).hexdigest()
+    return out
+
+
+def digest_matches(recorded, kernel_prefix):
+    now = kernel_source_digest(kernel_prefix)
+    return bool(now) and isinstance(recorded, dict) and all(recorded.get(k) == v for k, v in now.items())
+
+
+def e2e_leg(fcd, cfg, x_host, init_host, ref_result, reps=3):
+    """What a caller of the reference's surface gets (src/lib.rs:318-365: host numpy in, (str, path) out), outside
+    `value`: the compiled module's *_batch function on the HOST batch -- chunked upload || search || packed
+    download || Python objects (csrc/hostjob.hip, csrc/pymodule.cpp) -- with array paths and with the
+    reference's list[int] paths.  Outputs are compared with the device path's."""
+    from fast_ctc_decode_amd import api
+    cm = api._compiled()
+    B = x_host.shape[0]
+
+    def call(paths):
+        if cfg["crf"]:
+            return cm.crf_beam_search_batch(x_host, init_host, "NACGT", cfg["beam"], cfg["thr"], paths=paths)
+        return cm.beam_search_batch(x_host, "NACGT", cfg["beam"], cfg["thr"], True, paths=paths)
+
+    out = {"unit": "reads/s", "reads": B, "input": "host numpy float32 (pageable), one (B,T,N) array"}
+    call("array")  # lanes, arenas and page-locked buffers are allocated by the first job
+    for mode in ("array", "list"):
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res = call(mode)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["paths_" + mode] = B / best
+        out["ms_paths_" + mode] = best * 1e3
+    want = ref_result.sequences("NACGT", paths="list") if not cfg["crf"] else None
+    if want is not None:
+        out["identical_to_device_path"] = bool(all(a == b for a, b in zip(res, want)))
+    return out
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_summary.json,
     produced by tools/profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the
-    same kernel at the same shape, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes)."""
+    same kernel at the same shape, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes) -- quoted only
+    when the summary was taken on the kernel sources of this tree (kernel_source_digest)."""
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_summary.json")))
+    stale = None
     for path in reversed(files):  # newest summary that holds this kernel
         with open(path) as f:
             summ = json.load(f)
         for name, e in summ.get("kernels", {}).items():
             if name.startswith(kernel_prefix) and ", true, false" not in name and "hbm_bytes_per_launch" in e:
+                if not digest_matches(summ.get("kernel_source_md5"), kernel_prefix):
+                    stale = stale or os.path.basename(path)
+                    continue
                 return e["hbm_bytes_per_launch"], "%s: %s; %s; %s" % (
                     os.path.basename(path), name, e.get("workload", ""), e.get("fetch_correction_note", ""))
+    if stale:
+        return None, "no counter summary of the CURRENT kernel sources (newest: %s, taken on other sources); " \
+                     "re-run tools/round_profiles.sh" % stale
     return None, None
 
 
@@ -132,6 +240,8 @@ def valu_issue_roofline(kernel_prefix, kernel_ms, n_simd, clock_hz=2.4e9):
     for path in reversed(sorted(glob.glob(os.path.join(ROOT, "profiles", "*_sq_counters.json")))):
         with open(path) as f:
             d = json.load(f)
+        if not digest_matches(d.get("kernel_source_md5"), kernel_prefix):
+            continue
         if kernel_prefix in (d.get("kernel") or "") and "SQ_INSTS_VALU" in d.get("counters_per_launch", {}):
             insts = d["counters_per_launch"]["SQ_INSTS_VALU"]
             per_step = d.get("per_wave_step", {})
@@ -184,11 +294,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4096, help="reads per GPU per step")
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
+                    help="BASELINE.json config: 2 = beam 5, 4096 reads per GPU (the metric; default), 3 = beam 32, "
+                         "8192 reads per GPU (the multi-GPU config's shard), 4 = CRF beam 5, 4096 reads")
+    ap.add_argument("--batch", type=int, default=0, help="reads per GPU per step (0 = the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--kernel", type=int, default=0,
-                    help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront)")
+                    help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront), 4 lane")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the secondary viterbi roofline leg")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-numpy -> Python objects leg")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue successive steps round-robin on this many HIP streams (each with its own "
                          "handle and tree arena) so that independent batches overlap on the GPU; 1 = strictly "
@@ -202,6 +316,8 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather even with one rank (path check on a 1-GPU box)")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    beam, thr = cfg["beam"], cfg["thr"]
 
     import torch
     import torch.distributed as dist
@@ -226,8 +342,18 @@ def main():
         os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    B = args.batch
-    x_host = (make_batch if args.data == "reference" else make_batch_peaky)(1 + rank, B)
+    B = args.batch or cfg["batch"]
+    default_shape = B == cfg["batch"] and args.data == "reference"
+    init_host = init = None
+    if cfg["crf"]:
+        # (T, S=4, N=5) uniform rows, one-hot initial state
+        rng = np.random.default_rng(cfg["seed"] + rank)
+        x_host = rng.random((B, T, 4, N), dtype=np.float32)
+        init_host = np.zeros((B, 4), np.float32)
+        init_host[:, 0] = 1.0
+        init = torch.from_numpy(init_host).to(dev)
+    else:
+        x_host = (make_batch if args.data == "reference" else make_batch_peaky)(cfg["seed"] + rank, B)
     x = torch.from_numpy(x_host).to(dev)  # resident in HBM before the timed region
     torch.cuda.synchronize()
 
@@ -247,6 +373,11 @@ def main():
     comm_stream = torch.cuda.Stream(dev) if distributed and not args.no_overlap else None
     pending = [None]
 
+    def search(s):
+        if cfg["crf"]:
+            return fcd.crf_beam_search_batch_raw(x, init, beam, thr, kernel=args.kernel)
+        return fcd.beam_search_batch_raw(x, beam, thr, True, kernel=args.kernel, handle=handles[s])
+
     def gather(prev):
         r, ev = prev
         comm_stream.wait_event(ev)
@@ -264,7 +395,7 @@ def main():
         s = step_no[0] % n_streams
         step_no[0] += 1
         with torch.cuda.stream(streams[s]):
-            r = fcd.beam_search_batch_raw(x, BEAM, THR, True, kernel=args.kernel, handle=handles[s])
+            r = search(s)
             if distributed and comm_stream is None:
                 # ONE gather of the packed results to rank 0 (RCCL over xGMI), on the compute stream
                 fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
@@ -313,31 +444,36 @@ def main():
         rc = r.cpu()
         ok = int((rc.status == 0).sum())
         mean_L = float(rc.out_len.astype(np.float64).mean())
-        bytes_per_read = T * N * 4 + 5.0 * mean_L  # posteriors in, u8 label + u32 time out
+        # posteriors in, u8 label + u32 time out (CRF: the dense T*S*N figure)
+        bytes_per_read = T * N * 4 * (4 if cfg["crf"] else 1) + 5.0 * mean_L
         achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
         # the CPU leg (and its output cross-check) runs on rank 0 at N = 1 only, as the contract asks
-        cpu = cpu_baseline(x_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds) if world == 1 else None
+        cpu = cpu_baseline(cfg, x_host, init_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds) if world == 1 else None
         # (the names carry further template arguments after S: counting / profiling / one-length flags)
-        traffic, traffic_note = pmc_traffic("beam_wave_kernel<5, 6, 2, 0" if args.kernel in (0, 2)
-                                            else "beam_wave_kernel<5, 8, 1, 0" if args.kernel == 3
-                                            else "beam_generic_kernel")
-        if args.batch != 4096 or args.data != "reference":
-            traffic, traffic_note = None, None
+        prefix = cfg["kernel_prefix"] if args.kernel == 0 else {
+            1: "beam_generic_kernel", 2: "beam_wave_kernel<5, 6, 2, %d" % (4 if cfg["crf"] else 0),
+            3: "beam_wave_kernel<5, 8, 1, %d" % (4 if cfg["crf"] else 0), 4: "beam_lane_kernel<5, 2"}[args.kernel]
+        traffic, traffic_note = pmc_traffic(prefix) if default_shape else (None, None)
         props = torch.cuda.get_device_properties(dev)
         simds = props.multi_processor_count * 4
-        rpw = 2 if args.kernel in (0, 2) else 1
+        rpw = 1 if args.kernel in (1, 3) else 2
         # outside the timed region: the tie instrument on the same batch (include/fcd.h)
-        amb = fcd.beam_search_batch_raw(x, BEAM, THR, True, count_ambiguous=True).cpu().ambiguous
+        if cfg["crf"]:
+            amb = fcd.crf_beam_search_batch_raw(x, init, beam, thr, count_ambiguous=True).cpu().ambiguous
+        else:
+            amb = fcd.beam_search_batch_raw(x, beam, thr, True, count_ambiguous=True).cpu().ambiguous
         ties = {"reads_with_gt20_candidate_kept_tie": int((amb[:, 0] > 0).sum()),
                 "reads_with_result_changing_tie": int((amb[:, 1] > 0).sum()),
                 "reads_with_both": int(((amb[:, 0] > 0) & (amb[:, 1] > 0)).sum()),
                 "note": "a read with either counter at 0 is pinned to the reference; the others are settled by the "
                         "oracle's exhaustive tie replay (tests/test_gpu_fullsize.py::test_config2_tie_instrument)"}
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
-        valu = valu_issue_roofline("beam_wave_kernel<5, 6, 2, 0", k_ms, simds) \
-            if (args.kernel in (0, 2) and args.batch == 4096 and args.data == "reference") else None
+        valu = valu_issue_roofline(prefix, k_ms, simds) if default_shape else None
+        e2e = None
+        if world == 1 and not args.no_e2e and args.streams == 1:
+            e2e = e2e_leg(fcd, cfg, x_host, init_host, rc)
         out = {
-            "metric": "reads/s (T=4000, N=5, beam=5)",
+            "metric": "reads/s (T=4000, N=5, beam=%d)" % beam,
             "value": world * B * args.steps / elapsed,
             "unit": "reads/s",
             "n_gpus": world,
@@ -350,16 +486,21 @@ def main():
             "dtype": "f32",
             "data": "synthetic",
             "config": {
-                "workload": "beam_search beam_size=5 beam_cut_threshold=0.1 collapse_repeats, "
-                            "batch=4096 reads T=4000 N=5 per GPU (BASELINE.json configs[1]), "
-                            + ("reference-style rows numpy default_rng(1+rank)" if args.data == "reference"
-                               else "SECONDARY SET: peaky softmax rows (logits 4*N(0,1)), default_rng(1+rank)"),
-                "reads_per_gpu": B, "T": T, "N": N, "beam_size": BEAM, "beam_cut_threshold": THR,
+                "workload": ("crf_beam_search 4 states x 5 symbols beam_size=%d beam_cut_threshold=%.1f, " % (beam, thr)
+                             if cfg["crf"] else
+                             "beam_search beam_size=%d beam_cut_threshold=%.1f collapse_repeats, " % (beam, thr))
+                            + "batch=%d reads T=4000 N=5 per GPU (%s), " % (B, cfg["baseline"])
+                            + ("uniform rows, one-hot init, numpy default_rng(%d+rank)" % cfg["seed"] if cfg["crf"]
+                               else "reference-style rows numpy default_rng(%d+rank)" % cfg["seed"]
+                               if args.data == "reference"
+                               else "SECONDARY SET: peaky softmax rows (logits 4*N(0,1)), default_rng(%d+rank)" % cfg["seed"]),
+                "baseline_config": args.config,
+                "reads_per_gpu": B, "T": T, "N": N, "beam_size": beam, "beam_cut_threshold": thr,
                 "parallelism": ("reads sharded x%d, one RCCL gather of results per step%s"
                                 % (world, "" if args.no_overlap else " (on a second stream, overlapping the next step)"))
                                if world > 1 else "single GPU",
-                "kernel": {0: "auto (wave, two reads per wavefront)", 1: "generic-lds",
-                           2: "wave-registers-2reads", 3: "wave-registers-1read"}[args.kernel],
+                "kernel": cfg["kernel_name"] if args.kernel == 0 else
+                          {1: "generic-lds", 2: "wave-registers-2reads", 3: "wave-registers-1read", 4: "lane"}[args.kernel],
                 "reads_ok": ok, "mean_labels_per_read": mean_L, "streams": n_streams,
                 "tie_instrument": ties,
             },
@@ -378,11 +519,12 @@ def main():
                 # issue, not by HBM (SURVEY.md finding 5) -- priced here against the VALU issue peak.
                 "secondary_bound": valu if valu is not None else {
                     "bound": "valu_issue", "achieved": None, "peak": simds * 2.4e9 / 2.0,
-                    "note": "no SQ counter summary of this kernel / shape under profiles/"},
+                    "note": "no SQ counter summary of this kernel / shape on the current kernel sources under profiles/"},
                 "wavefronts_per_simd": B / rpw / simds,
                 "step_latency_us": k_ms * 1e3 / T,
             },
             "cpu_baseline": cpu,
+            "e2e": e2e,
             "viterbi_roofline": vit,
         }
         print(json.dumps(out), flush=True)

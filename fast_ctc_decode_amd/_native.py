@@ -35,7 +35,10 @@ SYMBOLS = [
     "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
     "fcd_coalescer_create", "fcd_coalescer_destroy", "fcd_coalescer_beam_search", "fcd_coalescer_viterbi_search",
     "fcd_coalescer_stats", "fcd_coalescer_last_error",
+    "fcd_viterbi_search_host_begin", "fcd_beam_search_host_begin", "fcd_crf_beam_search_host_begin",
+    "fcd_crf_greedy_search_host_begin", "fcd_set_host_pipeline", "fcd_job_chunks", "fcd_job_next", "fcd_job_end",
 ]
+JOB_PATH, JOB_QUAL, JOB_AMBIGUOUS, JOB_DONE = 1, 2, 4, 1
 
 
 class Batch(C.Structure):
@@ -51,6 +54,14 @@ class Result(C.Structure):
         ("labels", C.c_void_p), ("path", C.c_void_p), ("qual", C.c_void_p),
         ("out_len", C.c_void_p), ("status", C.c_void_p), ("out_stride", C.c_int64),
         ("ambiguous", C.c_void_p),
+    ]
+
+
+class Chunk(C.Structure):
+    _fields_ = [
+        ("read_begin", C.c_int64), ("n_reads", C.c_int64), ("out_len", C.c_void_p), ("status", C.c_void_p),
+        ("offsets", C.c_void_p), ("labels", C.c_void_p), ("path", C.c_void_p), ("path_bytes", C.c_int),
+        ("qual", C.c_void_p), ("ambiguous", C.c_void_p),
     ]
 
 
@@ -141,6 +152,15 @@ def bind(lib):
     lib.fcd_coalescer_viterbi_search.argtypes = [P, BP, i32, RP]
     lib.fcd_coalescer_stats.argtypes = [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     lib.fcd_coalescer_last_error.restype = C.c_char_p
+    PP = C.POINTER(P)
+    lib.fcd_viterbi_search_host_begin.argtypes = [P, BP, i32, i32, PP]
+    lib.fcd_beam_search_host_begin.argtypes = [P, BP, i64, f32, i32, i32, i32, PP]
+    lib.fcd_crf_beam_search_host_begin.argtypes = [P, BP, P, i64, i64, i64, f32, i32, i32, PP]
+    lib.fcd_crf_greedy_search_host_begin.argtypes = [P, BP, P, i64, i64, i32, PP]
+    lib.fcd_set_host_pipeline.argtypes = [P, i32, i64, i64]
+    lib.fcd_job_chunks.argtypes = [P, C.POINTER(i64), C.POINTER(i32)]
+    lib.fcd_job_next.argtypes = [P, C.POINTER(Chunk)]
+    lib.fcd_job_end.argtypes = [P]
     return lib
 
 
@@ -186,6 +206,10 @@ class Handle:
 
     def set_workspace_limit(self, nbytes):
         self.check(self.lib.fcd_set_workspace_limit(self.ptr, int(nbytes)))
+
+    def set_host_pipeline(self, lanes=0, chunk_reads=0, min_bytes=-1):
+        """Tuning of the chunked host path (include/fcd.h: fcd_set_host_pipeline)."""
+        self.check(self.lib.fcd_set_host_pipeline(self.ptr, int(lanes), int(chunk_reads), int(min_bytes)))
 
     def release_workspace(self):
         """Give the tree arena / staging memory back to the device (the next call allocates afresh)."""

@@ -15,6 +15,28 @@ from . import _native as nat
 
 __version__ = "0.3.7"  # the reference version this surface mirrors (Cargo.toml:3)
 
+_cm = None
+
+
+def _compiled():
+    """The compiled host layer (csrc/pymodule.cpp, module `fast_ctc_decode`): the batch functions on HOST inputs
+    are its batch functions -- one implementation of chunk streaming, string and path building."""
+    global _cm
+    if _cm is None:
+        import importlib.util
+        import os
+
+        from . import build as _build
+        nat.load()  # libfcd_hip.so (and torch's HIP runtime before it) first
+        path = _build.pymodule_path()
+        if not os.path.exists(path):
+            _build.build_pymodule()
+        spec = importlib.util.spec_from_file_location("fast_ctc_decode", path)
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _cm = mod
+    return _cm
+
 
 # ---------------------------------------------------------------------------------------------
 # argument conversion / validation, as the PyO3 wrappers do it
@@ -289,6 +311,9 @@ def crf_greedy_search_batch_raw(network_outputs, init_states, lengths=None, qual
 def crf_greedy_search_batch(network_outputs, init_states, alphabet, qstring=False, qscale=1.0, qbias=0.0,
                             lengths=None, paths="list"):
     """Batched crf_greedy_search: element i equals crf_greedy_search(network_outputs[i], init_states[i], ...)."""
+    if _device_tensor(network_outputs) is None:
+        return _compiled().crf_greedy_search_batch(_host_input(network_outputs), np.asarray(init_states, np.float32),
+                                                   alphabet, bool(qstring), qscale, qbias, lengths, paths)
     alpha = _seq_to_vec(alphabet)
     _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
     r = crf_greedy_search_batch_raw(network_outputs, init_states, lengths, qual=qstring).cpu()
@@ -760,6 +785,13 @@ def _ragged(network_outputs, lengths, ndim):
     return network_outputs, lengths
 
 
+def _host_input(x):
+    """What the compiled batch functions take: one ndarray, or a list of per-read ndarrays."""
+    if isinstance(x, np.ndarray):
+        return x
+    return [np.asarray(v) for v in x]
+
+
 def _device_tensor(x):
     """torch ROCm tensors pass through; any other device array speaking DLPack (e.g. CuPy) is
     wrapped zero-copy.  Host objects return None."""
@@ -806,9 +838,11 @@ def beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold
                       collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, paths="list"):
     """Batched beam_search: element i equals beam_search(network_outputs[i][:lengths[i]], ...).
     paths="array" returns the paths as numpy arrays instead of list[int] (see BatchResult.sequences)."""
+    if _device_tensor(network_outputs) is None:  # host input: the compiled layer streams result chunks
+        return _compiled().beam_search_batch(_host_input(network_outputs), alphabet, beam_size, beam_cut_threshold,
+                                             collapse_repeats, lengths, paths, int(kernel))
     alpha = _seq_to_vec(alphabet)
-    inner = network_outputs[0].shape[-1] if isinstance(network_outputs, (list, tuple)) else network_outputs.shape[-1]
-    _check_beam_args(len(alpha), inner, beam_size, beam_cut_threshold)
+    _check_beam_args(len(alpha), network_outputs.shape[-1], beam_size, beam_cut_threshold)
     r = beam_search_batch_raw(network_outputs, beam_size, beam_cut_threshold, collapse_repeats,
                               lengths, kernel)
     return r.sequences(alpha, paths=paths)
@@ -833,9 +867,11 @@ def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=Non
 
 def viterbi_search_batch(network_outputs, alphabet, qstring=False, qscale=1.0, qbias=0.0,
                          collapse_repeats=True, lengths=None, paths="list"):
+    if _device_tensor(network_outputs) is None:
+        return _compiled().viterbi_search_batch(_host_input(network_outputs), alphabet, bool(qstring), qscale, qbias,
+                                                collapse_repeats, lengths, paths)
     alpha = _seq_to_vec(alphabet)
-    inner = network_outputs[0].shape[-1] if isinstance(network_outputs, (list, tuple)) else network_outputs.shape[-1]
-    _check_greedy_alphabet(len(alpha), inner)
+    _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
     r = viterbi_search_batch_raw(network_outputs, collapse_repeats, lengths, qual=qstring).cpu()
     res = r.sequences(alpha, paths=paths if paths is not None else "array")
     if qstring:
@@ -873,6 +909,9 @@ def crf_beam_search_batch_raw(network_outputs, init_states, beam_size=5, beam_cu
 
 def crf_beam_search_batch(network_outputs, init_states, alphabet, beam_size=5,
                           beam_cut_threshold=0.0, lengths=None):
+    if _device_tensor(network_outputs) is None:
+        return _compiled().crf_beam_search_batch(_host_input(network_outputs), np.asarray(init_states, np.float32),
+                                                 alphabet, beam_size, beam_cut_threshold, lengths)
     alpha = _seq_to_vec(alphabet)
     _check_greedy_alphabet(len(alpha), network_outputs.shape[-1])
     r = crf_beam_search_batch_raw(network_outputs, init_states, beam_size, beam_cut_threshold,

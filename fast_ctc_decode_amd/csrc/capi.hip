@@ -315,7 +315,8 @@ int fcd_create(int device, fcd_handle **out) {
     *out = nullptr;
     int n = fcd_device_count();
     if (n <= 0 || device < 0 || device >= n) return FCD_E_NODEVICE;
-    if (hipSetDevice(device) != hipSuccess) return FCD_E_HIP;
+    DeviceGuard dev_guard(device);  // the caller's current device is put back on return
+    if (dev_guard.err != hipSuccess) return FCD_E_HIP;
     fcd_handle *h = new fcd_handle();
     h->device = device;
     if (hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -329,7 +330,8 @@ int fcd_create(int device, fcd_handle **out) {
 
 int fcd_destroy(fcd_handle *h) {
     if (!h) return FCD_OK;
-    (void)hipSetDevice(h->device);
+    DeviceGuard dev_guard(h->device);
+    host_job_release_lanes(h, true);
     (void)hipStreamSynchronize(h->stream);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
@@ -391,6 +393,7 @@ int fcd_release_workspace(fcd_handle *h) {
     FCD_DEVICE(h);
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->own_stream != h->stream) FCD_HIP(h, hipStreamSynchronize(h->own_stream));
+    host_job_release_lanes(h, false);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
     if (h->lnbuf) (void)hipFree(h->lnbuf);
@@ -908,7 +911,9 @@ int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, 
         FCD_HIP(h, hipMemsetAsync(buf, 0, 16, h->stream));
         return FCD_OK;
     }
-    FCD_HIP(h, launch_pack(to_desc(res), n_reads, path_bytes, offsets, buf, h->stream));
+    ResultDesc wire = to_desc(res);
+    wire.qual = nullptr;  // the wire format carries labels, path, out_len, status
+    FCD_HIP(h, launch_pack(wire, n_reads, path_bytes, offsets, buf, h->stream));
     return FCD_OK;
 }
 
@@ -927,75 +932,62 @@ int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, u
     return FCD_OK;
 }
 
+}  // extern "C"
+
 // ---- *_host: stage host buffers through device memory, run the *_dev path, copy back -------
-namespace {
+namespace fcd {
 
-enum class Op { Viterbi, Beam, CrfBeam, CrfGreedy };
+// Checks shared by every host-side entry of the four 1D searches.
+int host_check(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c) {
+    const bool crf = c.op == HostOp::CrfBeam || c.op == HostOp::CrfGreedy;
+    int rc = check_batch(h, in, crf);
+    if (rc) return rc;
+    rc = check_result(h, in, out, c.op != HostOp::Viterbi);
+    if (rc) return rc;
+    if (in->stride_read < 0 || in->stride_t < 0 || in->stride_n < 0 || (crf && in->stride_s < 0))
+        return fail(h, FCD_E_UNSUPPORTED, "negative strides: pass a contiguous copy");
+    if (crf && (!c.init || c.n_init < 1)) return fail(h, FCD_E_INVALID, "init_state missing");
+    return FCD_OK;
+}
 
-struct HostCall {
-    Op op;
-    int collapse = 1;
-    int64_t beam_size = 5;
-    float thr = 0.0f;
-    int kernel = FCD_KERNEL_AUTO;
-    const float *init = nullptr;
-    int64_t n_init = 0, init_stride = 0;
-};
-
-int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c) {
-    if (!h) return FCD_E_INVALID;
-    // held from staging to copy-back: two threads sharing a handle are serialised (fcd.h), they cannot
-    // interleave on the staging buffer
-    std::lock_guard<std::recursive_mutex> whole_call(h->mu);
-    const bool crf = c.op == Op::CrfBeam || c.op == Op::CrfGreedy;
-    {
-        std::lock_guard<std::recursive_mutex> g(h->mu);
-        int rc = check_batch(h, in, crf);
-        if (rc) return rc;
-        rc = check_result(h, in, out, c.op != Op::Viterbi);
-        if (rc) return rc;
-        if (in->stride_read < 0 || in->stride_t < 0 || in->stride_n < 0 || (crf && in->stride_s < 0))
-            return fail(h, FCD_E_UNSUPPORTED, "negative strides: pass a contiguous copy");
-        if (crf && (!c.init || c.n_init < 1)) return fail(h, FCD_E_INVALID, "init_state missing");
-    }
-    if (in->n_reads == 0) return FCD_OK;
+// Lays the call out in h->stage (inputs first, then the fixed-stride result arrays), uploads the inputs on
+// h->stream and runs the *_dev search there.  `shape` says which result arrays are wanted (non-null members)
+// and their stride; *dout receives the device-side result.  Small calls (the per-read drop-in functions: a
+// few hundred KB) go through a page-locked mirror of the staging area when allow_mirror: ONE DMA in (and ONE
+// out in host_download) instead of a runtime-staged copy per array from pageable memory; large batches are
+// copied straight from / to the caller's arrays (an extra host pass would cost more).
+int host_upload_and_search(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, const HostCall &c,
+                           bool allow_mirror, HostStage *st, fcd_result *dout) {
+    const bool crf = c.op == HostOp::CrfBeam || c.op == HostOp::CrfGreedy;
     const int64_t B = in->n_reads;
-    const size_t n_in = (size_t)span_elems(in, crf);
-    const size_t n_out = (size_t)B * (size_t)out->out_stride;
-    const size_t n_init = crf ? (size_t)((B - 1) * c.init_stride + c.n_init) : 0;
-
+    st->B = B;
+    st->n_in = (size_t)span_elems(in, crf);
+    st->n_out = (size_t)B * (size_t)shape->out_stride;
+    st->n_init = crf ? (size_t)((B - 1) * c.init_stride + c.n_init) : 0;
     size_t used = 0;
     auto reserve = [&](size_t bytes) {
         size_t off = (used + 255) & ~(size_t)255;
         used = off + std::max<size_t>(bytes, 4);
         return off;
     };
-    const size_t o_in = reserve(n_in * 4);
-    const size_t o_len = reserve(in->lengths ? (size_t)B * 8 : 0);
-    const size_t o_init = reserve(n_init * 4);
-    const size_t o_lab = reserve(n_out);
-    const size_t o_path = reserve(out->path ? n_out * 4 : 0);
-    const size_t o_qual = reserve(out->qual ? n_out * 4 : 0);
-    const size_t o_olen = reserve((size_t)B * 4);
-    const size_t o_stat = reserve((size_t)B * 4);
-    const bool want_amb = out->ambiguous && (c.op == Op::Beam || c.op == Op::CrfBeam);
-    const size_t o_amb = reserve(want_amb ? (size_t)B * 8 : 0);
+    st->o_in = reserve(st->n_in * 4);
+    st->o_len = reserve(in->lengths ? (size_t)B * 8 : 0);
+    st->o_init = reserve(st->n_init * 4);
+    st->o_lab = reserve(st->n_out);
+    st->o_path = reserve(shape->path ? st->n_out * 4 : 0);
+    st->o_qual = reserve(shape->qual ? st->n_out * 4 : 0);
+    st->o_olen = reserve((size_t)B * 4);
+    st->o_stat = reserve((size_t)B * 4);
+    st->want_amb = shape->ambiguous && (c.op == HostOp::Beam || c.op == HostOp::CrfBeam);
+    st->o_amb = reserve(st->want_amb ? (size_t)B * 8 : 0);
+    st->used = used;
+    const bool mirror = allow_mirror && used <= ((size_t)4 << 20);
+    st->mirror = mirror;
 
-    int rc;
-    {
-        std::lock_guard<std::recursive_mutex> g(h->mu);
-        FCD_DEVICE(h);
-        rc = ensure(h, &h->stage, &h->stage_bytes, used);
-        if (rc) return rc;
-    }
+    int rc = ensure(h, &h->stage, &h->stage_bytes, used);
+    if (rc) return rc;
     char *base = reinterpret_cast<char *>(h->stage);
-    // Small calls (the per-read drop-in functions: a few hundred KB) go through a page-locked mirror of the
-    // staging area: ONE DMA in, ONE out, instead of a runtime-staged copy per array from pageable memory.
-    // Large batches are copied straight from / to the caller's arrays (an extra host pass would cost more).
-    const bool pinned = used <= ((size_t)4 << 20);
-    char *pin = nullptr;
-    if (pinned) {
-        std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (mirror) {
         if (h->pin_bytes < used) {
             if (h->pin) (void)hipHostFree(h->pin);
             h->pin = nullptr;
@@ -1007,72 +999,96 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
             }
             h->pin_bytes = want;
         }
-        pin = reinterpret_cast<char *>(h->pin);
-        if (n_in) memcpy(pin + o_in, in->post, n_in * 4);
-        if (in->lengths) memcpy(pin + o_len, in->lengths, (size_t)B * 8);
-        if (crf) memcpy(pin + o_init, c.init, n_init * 4);
-        FCD_HIP(h, hipMemcpyAsync(base, pin, o_lab, hipMemcpyHostToDevice, h->stream));  // inputs lie before o_lab
+        char *pin = reinterpret_cast<char *>(h->pin);
+        if (st->n_in) memcpy(pin + st->o_in, in->post, st->n_in * 4);
+        if (in->lengths) memcpy(pin + st->o_len, in->lengths, (size_t)B * 8);
+        if (crf) memcpy(pin + st->o_init, c.init, st->n_init * 4);
+        FCD_HIP(h, hipMemcpyAsync(base, pin, st->o_lab, hipMemcpyHostToDevice, h->stream));  // inputs lie before o_lab
     } else {
-        std::lock_guard<std::recursive_mutex> g(h->mu);
-        if (n_in) FCD_HIP(h, hipMemcpyAsync(base + o_in, in->post, n_in * 4, hipMemcpyHostToDevice, h->stream));
+        if (st->n_in)
+            FCD_HIP(h, hipMemcpyAsync(base + st->o_in, in->post, st->n_in * 4, hipMemcpyHostToDevice, h->stream));
         if (in->lengths)
-            FCD_HIP(h, hipMemcpyAsync(base + o_len, in->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
-        if (crf) FCD_HIP(h, hipMemcpyAsync(base + o_init, c.init, n_init * 4, hipMemcpyHostToDevice, h->stream));
+            FCD_HIP(h, hipMemcpyAsync(base + st->o_len, in->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
+        if (crf)
+            FCD_HIP(h, hipMemcpyAsync(base + st->o_init, c.init, st->n_init * 4, hipMemcpyHostToDevice, h->stream));
     }
     fcd_batch din = *in;
-    din.post = reinterpret_cast<const float *>(base + o_in);
-    din.lengths = in->lengths ? reinterpret_cast<const int64_t *>(base + o_len) : nullptr;
-    fcd_result dout;
-    dout.labels = reinterpret_cast<uint8_t *>(base + o_lab);
-    dout.path = out->path ? reinterpret_cast<uint32_t *>(base + o_path) : nullptr;
-    dout.qual = out->qual ? reinterpret_cast<float *>(base + o_qual) : nullptr;
-    dout.out_len = reinterpret_cast<uint32_t *>(base + o_olen);
-    dout.status = reinterpret_cast<int32_t *>(base + o_stat);
-    dout.out_stride = out->out_stride;
-    dout.ambiguous = want_amb ? reinterpret_cast<uint32_t *>(base + o_amb) : nullptr;
-    const float *dinit = reinterpret_cast<const float *>(base + o_init);
-
+    din.post = reinterpret_cast<const float *>(base + st->o_in);
+    din.lengths = in->lengths ? reinterpret_cast<const int64_t *>(base + st->o_len) : nullptr;
+    dout->labels = reinterpret_cast<uint8_t *>(base + st->o_lab);
+    dout->path = shape->path ? reinterpret_cast<uint32_t *>(base + st->o_path) : nullptr;
+    dout->qual = shape->qual ? reinterpret_cast<float *>(base + st->o_qual) : nullptr;
+    dout->out_len = reinterpret_cast<uint32_t *>(base + st->o_olen);
+    dout->status = reinterpret_cast<int32_t *>(base + st->o_stat);
+    dout->out_stride = shape->out_stride;
+    dout->ambiguous = st->want_amb ? reinterpret_cast<uint32_t *>(base + st->o_amb) : nullptr;
+    const float *dinit = reinterpret_cast<const float *>(base + st->o_init);
     switch (c.op) {
-        case Op::Viterbi: rc = fcd_viterbi_search_dev(h, &din, c.collapse, &dout); break;
-        case Op::Beam: rc = fcd_beam_search_dev(h, &din, c.beam_size, c.thr, c.collapse, c.kernel, &dout); break;
-        case Op::CrfBeam:
-            rc = fcd_crf_beam_search_dev_k(h, &din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel,
-                                           &dout);
-            break;
-        case Op::CrfGreedy:
-            rc = fcd_crf_greedy_search_dev(h, &din, dinit, c.n_init, c.init_stride, &dout);
-            break;
+        case HostOp::Viterbi: return fcd_viterbi_search_dev(h, &din, c.collapse, dout);
+        case HostOp::Beam: return fcd_beam_search_dev(h, &din, c.beam_size, c.thr, c.collapse, c.kernel, dout);
+        case HostOp::CrfBeam:
+            return fcd_crf_beam_search_dev_k(h, &din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel, dout);
+        case HostOp::CrfGreedy: return fcd_crf_greedy_search_dev(h, &din, dinit, c.n_init, c.init_stride, dout);
     }
-    if (rc) return rc;
-    std::lock_guard<std::recursive_mutex> g(h->mu);
-    if (pinned) {
-        FCD_HIP(h, hipMemcpyAsync(pin + o_lab, base + o_lab, used - o_lab, hipMemcpyDeviceToHost, h->stream));
+    return FCD_E_INVALID;
+}
+
+// Copies the fixed-stride device result of host_upload_and_search into the caller's arrays and waits.
+int host_download(fcd_handle *h, const HostStage &st, const fcd_result &dout, const fcd_result *out) {
+    const size_t B = (size_t)st.B;
+    if (st.mirror) {
+        char *pin = reinterpret_cast<char *>(h->pin);
+        char *base = reinterpret_cast<char *>(h->stage);
+        FCD_HIP(h, hipMemcpyAsync(pin + st.o_lab, base + st.o_lab, st.used - st.o_lab, hipMemcpyDeviceToHost, h->stream));
         FCD_HIP(h, hipStreamSynchronize(h->stream));
-        memcpy(out->labels, pin + o_lab, n_out);
-        if (out->path) memcpy(out->path, pin + o_path, n_out * 4);
-        if (out->qual) memcpy(out->qual, pin + o_qual, n_out * 4);
-        memcpy(out->out_len, pin + o_olen, (size_t)B * 4);
-        if (out->status) memcpy(out->status, pin + o_stat, (size_t)B * 4);
-        if (want_amb) memcpy(out->ambiguous, pin + o_amb, (size_t)B * 8);
+        memcpy(out->labels, pin + st.o_lab, st.n_out);
+        if (out->path) memcpy(out->path, pin + st.o_path, st.n_out * 4);
+        if (out->qual) memcpy(out->qual, pin + st.o_qual, st.n_out * 4);
+        memcpy(out->out_len, pin + st.o_olen, B * 4);
+        if (out->status) memcpy(out->status, pin + st.o_stat, B * 4);
+        if (st.want_amb) memcpy(out->ambiguous, pin + st.o_amb, B * 8);
         return FCD_OK;
     }
-    FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
-    if (out->path) FCD_HIP(h, hipMemcpyAsync(out->path, dout.path, n_out * 4, hipMemcpyDeviceToHost, h->stream));
-    if (out->qual) FCD_HIP(h, hipMemcpyAsync(out->qual, dout.qual, n_out * 4, hipMemcpyDeviceToHost, h->stream));
-    FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
-    if (out->status)
-        FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
-    if (want_amb)
-        FCD_HIP(h, hipMemcpyAsync(out->ambiguous, dout.ambiguous, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, st.n_out, hipMemcpyDeviceToHost, h->stream));
+    if (out->path) FCD_HIP(h, hipMemcpyAsync(out->path, dout.path, st.n_out * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out->qual) FCD_HIP(h, hipMemcpyAsync(out->qual, dout.qual, st.n_out * 4, hipMemcpyDeviceToHost, h->stream));
+    FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out->status) FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (st.want_amb)
+        FCD_HIP(h, hipMemcpyAsync(out->ambiguous, dout.ambiguous, B * 8, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
 }
 
+}  // namespace fcd
+
+namespace {
+
+int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c) {
+    if (!h) return FCD_E_INVALID;
+    // held from staging to copy-back: two threads sharing a handle are serialised (fcd.h), they cannot
+    // interleave on the staging buffer
+    std::lock_guard<std::recursive_mutex> whole_call(h->mu);
+    int rc = host_check(h, in, out, c);
+    if (rc) return rc;
+    if (in->n_reads == 0) return FCD_OK;
+    FCD_DEVICE(h);  // every HIP call of this entry point runs on the handle's device
+    // Large batches: chunks on several internal lanes, upload || search || packed download (hostjob.hip)
+    if (host_job_wanted(h, in, c)) return host_job_run_fixed(h, in, out, c);
+    HostStage st;
+    fcd_result dout{};
+    rc = host_upload_and_search(h, in, out, c, true, &st, &dout);
+    if (rc) return rc;
+    return host_download(h, st, dout, out);
+}
+
 }  // namespace
+
+extern "C" {
 
 int fcd_viterbi_search_host(fcd_handle *h, const fcd_batch *in, int collapse_repeats,
                             const fcd_result *out) {
-    HostCall c{Op::Viterbi};
+    HostCall c{HostOp::Viterbi};
     c.collapse = collapse_repeats;
     return run_host(h, in, out, c);
 }
@@ -1080,7 +1096,7 @@ int fcd_viterbi_search_host(fcd_handle *h, const fcd_batch *in, int collapse_rep
 int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
                          float beam_cut_threshold, int collapse_repeats, int kernel,
                          const fcd_result *out) {
-    HostCall c{Op::Beam};
+    HostCall c{HostOp::Beam};
     c.collapse = collapse_repeats;
     c.beam_size = beam_size;
     c.thr = beam_cut_threshold;
@@ -1098,7 +1114,7 @@ int fcd_crf_beam_search_host(fcd_handle *h, const fcd_batch *in, const float *in
 int fcd_crf_beam_search_host_k(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                                int64_t init_stride, int64_t beam_size, float beam_cut_threshold,
                                int kernel, const fcd_result *out) {
-    HostCall c{Op::CrfBeam};
+    HostCall c{HostOp::CrfBeam};
     c.beam_size = beam_size;
     c.thr = beam_cut_threshold;
     c.kernel = kernel;
@@ -1110,7 +1126,7 @@ int fcd_crf_beam_search_host_k(fcd_handle *h, const fcd_batch *in, const float *
 
 int fcd_crf_greedy_search_host(fcd_handle *h, const fcd_batch *in, const float *init,
                                int64_t n_init, int64_t init_stride, const fcd_result *out) {
-    HostCall c{Op::CrfGreedy};
+    HostCall c{HostOp::CrfGreedy};
     c.init = init;
     c.n_init = n_init;
     c.init_stride = init_stride;

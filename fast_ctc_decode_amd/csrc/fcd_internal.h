@@ -158,6 +158,7 @@ hipError_t launch_envelope(const EnvelopeArgs &a, int64_t pair_begin, int64_t n_
 
 // compact wire format of decoded results (pack.hip)
 hipError_t launch_result_offsets(const uint32_t *len, int64_t n, int64_t stride, uint64_t *offsets, hipStream_t stream);
+// (res.qual non-null: an f32 region follows the path region, 4-byte aligned -- host result chunks only)
 hipError_t launch_pack(const ResultDesc &res, int64_t n, int path_bytes, const uint64_t *offsets, uint8_t *buf,
                        hipStream_t stream);
 hipError_t launch_unpack(const uint8_t *buf, int64_t n, const uint64_t *offsets, const ResultDesc &out,
@@ -166,7 +167,39 @@ hipError_t launch_unpack(const uint8_t *buf, int64_t n, const uint64_t *offsets,
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
                                  int64_t n, int mode, hipStream_t stream);
 
+// ---- host side of the four 1D searches (capi.hip, hostjob.hip) ----
+enum class HostOp { Viterbi, Beam, CrfBeam, CrfGreedy };
+
+struct HostCall {
+    HostOp op;
+    int collapse = 1;
+    int64_t beam_size = 5;
+    float thr = 0.0f;
+    int kernel = FCD_KERNEL_AUTO;
+    const float *init = nullptr;  // host pointer
+    int64_t n_init = 0, init_stride = 0;
+};
+
+// where one staged host call lives inside fcd_handle::stage (byte offsets)
+struct HostStage {
+    size_t o_in, o_len, o_init, o_lab, o_path, o_qual, o_olen, o_stat, o_amb, used;
+    size_t n_in, n_out, n_init;
+    int64_t B;
+    bool want_amb, mirror;
+};
+
+int host_check(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c);
+int host_upload_and_search(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, const HostCall &c,
+                           bool allow_mirror, HostStage *st, fcd_result *dout);
+int host_download(fcd_handle *h, const HostStage &st, const fcd_result &dout, const fcd_result *out);
+// large host batches: chunks on internal lanes, upload || search || packed download (hostjob.hip)
+bool host_job_wanted(fcd_handle *h, const fcd_batch *in, const HostCall &c);
+int host_job_run_fixed(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c);
+void host_job_release_lanes(fcd_handle *h, bool destroy);
+
 }  // namespace fcd
+
+struct fcd_host_lane;
 
 struct fcd_handle {
     int device = 0;
@@ -188,6 +221,13 @@ struct fcd_handle {
     size_t pin_bytes = 0;
     void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
     size_t lnbuf_bytes = 0;
+    // chunk lanes of the pipelined host path (hostjob.hip): sub-handles with their own stream and workspace
+    std::vector<fcd_host_lane *> lanes;
+    bool job_active = false;  // a host job owns the lanes from begin to end
+    bool is_lane = false;
+    int pipe_lanes = 0;          // fcd_set_host_pipeline: 0 = default (FCD_HOST_LANES or 4)
+    int64_t pipe_chunk = 0;      // reads per chunk, 0 = automatic
+    int64_t pipe_min_bytes = -1; // fcd_*_host batches of at least this many input bytes take the pipeline; -1 = default
     std::string err;
     std::recursive_mutex mu;  // a *_host call holds it from staging to copy-back, the *_dev call inside re-enters
 };

@@ -9,6 +9,9 @@
 //   [16+4n, 16+8n)       i32  status[n]
 //   [16+8n, +align4(total))   u8   labels of read 0, read 1, ... back to back
 //   [.., + total*path_bytes)  u16/u32 path entries, same order
+//   host result chunks only (hostjob.hip; never on the wire): the path region is absent when no path was asked for
+//   (header word 3 = 0), and with header word 3 bit 8 set an f32 region of `total` quality values follows,
+//   4-byte aligned
 //
 // fcd_result_offsets_dev: exclusive prefix sum of out_len (one workgroup, DPP-free shuffle scan).
 // fcd_pack_results_dev / fcd_unpack_results_dev: one wavefront per read, coalesced 4-byte source loads.
@@ -58,7 +61,8 @@ __global__ __launch_bounds__(kScanThreads) void result_offsets_kernel(const uint
 
 struct PackParams {
     const uint8_t *labels;
-    const uint32_t *path;
+    const uint32_t *path;   // nullable
+    const float *qual;      // nullable
     const uint32_t *out_len;
     const int32_t *status;
     int64_t stride;
@@ -80,7 +84,7 @@ __global__ __launch_bounds__(256) void pack_kernel(PackParams p) {
         hdr[0] = (uint32_t)total;
         hdr[1] = (uint32_t)(total >> 32);
         hdr[2] = (uint32_t)p.n;
-        hdr[3] = (uint32_t)p.path_bytes;
+        hdr[3] = (uint32_t)(p.path ? p.path_bytes : 0) | (p.qual ? 0x100u : 0u);
     }
     const uint64_t off = p.offsets[r];
     const int64_t len = (int64_t)(p.offsets[r + 1] - off);
@@ -92,13 +96,22 @@ __global__ __launch_bounds__(256) void pack_kernel(PackParams p) {
     const uint8_t *lab_in = p.labels + r * p.stride;
     for (int64_t j = lane; j < len; j += 64) lab_out[j] = lab_in[j];
     uint8_t *path_region = p.buf + header_bytes(p.n) + ((total + 3) & ~(uint64_t)3);
-    const uint32_t *pth_in = p.path + r * p.stride;
-    if (p.path_bytes == 2) {
-        uint16_t *o = reinterpret_cast<uint16_t *>(path_region) + off;
-        for (int64_t j = lane; j < len; j += 64) o[j] = (uint16_t)pth_in[j];
-    } else {
-        uint32_t *o = reinterpret_cast<uint32_t *>(path_region) + off;
-        for (int64_t j = lane; j < len; j += 64) o[j] = pth_in[j];
+    uint64_t path_total = 0;
+    if (p.path) {
+        const uint32_t *pth_in = p.path + r * p.stride;
+        path_total = total * (uint64_t)p.path_bytes;
+        if (p.path_bytes == 2) {
+            uint16_t *o = reinterpret_cast<uint16_t *>(path_region) + off;
+            for (int64_t j = lane; j < len; j += 64) o[j] = (uint16_t)pth_in[j];
+        } else {
+            uint32_t *o = reinterpret_cast<uint32_t *>(path_region) + off;
+            for (int64_t j = lane; j < len; j += 64) o[j] = pth_in[j];
+        }
+    }
+    if (p.qual) {
+        float *o = reinterpret_cast<float *>(path_region + ((path_total + 3) & ~(uint64_t)3)) + off;
+        const float *q_in = p.qual + r * p.stride;
+        for (int64_t j = lane; j < len; j += 64) o[j] = q_in[j];
     }
 }
 
@@ -120,7 +133,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(UnpackParams p) {
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(p.buf);
     const uint64_t total = (uint64_t)hdr[0] | ((uint64_t)hdr[1] << 32);
     const int64_t n_in = hdr[2];
-    const int path_bytes = (int)hdr[3];
+    const int path_bytes = (int)(hdr[3] & 0xffu);
     const uint64_t off = p.offsets[r];
     const int64_t len = (int64_t)(p.offsets[r + 1] - off);
     if (lane == 0) {
@@ -130,7 +143,7 @@ __global__ __launch_bounds__(256) void unpack_kernel(UnpackParams p) {
     const uint8_t *lab_in = p.buf + header_bytes(n_in) + off;
     uint8_t *lab_out = p.labels + r * p.stride;
     for (int64_t j = lane; j < len; j += 64) lab_out[j] = lab_in[j];
-    if (!p.path) return;
+    if (!p.path || path_bytes == 0) return;
     const uint8_t *path_region = p.buf + header_bytes(n_in) + ((total + 3) & ~(uint64_t)3);
     uint32_t *pth_out = p.path + r * p.stride;
     if (path_bytes == 2) {
@@ -151,7 +164,7 @@ hipError_t launch_result_offsets(const uint32_t *len, int64_t n, int64_t stride,
 
 hipError_t launch_pack(const ResultDesc &res, int64_t n, int path_bytes, const uint64_t *offsets, uint8_t *buf,
                        hipStream_t stream) {
-    PackParams p{res.labels, res.path, res.out_len, res.status, res.out_stride, n, path_bytes, offsets, buf};
+    PackParams p{res.labels, res.path, res.qual, res.out_len, res.status, res.out_stride, n, path_bytes, offsets, buf};
     hipLaunchKernelGGL(pack_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, p);
     return hipGetLastError();
 }

@@ -15,6 +15,9 @@
 #include <thread>
 #include <cstdlib>
 #include <cstdint>
+#include <cstring>
+#include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -46,18 +49,26 @@ fcd_handle *thread_handle() {
     return th.h;
 }
 
-// set_coalescing(): when non-null, per-read viterbi_search / beam_search calls of every thread go through it
-// (include/fcd.h: concurrent calls share batched launches).  Swapped under the GIL; a replaced coalescer is
-// destroyed only once its calls have drained.
-std::atomic<fcd_coalescer *> g_coalescer{nullptr};
-std::atomic<int> g_coalescer_users{0};
+// set_coalescing(): when set, per-read viterbi_search / beam_search calls of every thread go through it
+// (include/fcd.h: concurrent calls share batched launches).  Every call holds a reference to the coalescer that
+// was current when it started; a replaced coalescer is destroyed when its LAST call returns -- nobody waits for
+// a global count to reach zero, so set_coalescing() cannot starve under a steady stream of calls.
+struct CoalescerBox {
+    fcd_coalescer *co = nullptr;
+    ~CoalescerBox() {
+        if (co && Py_IsInitialized()) fcd_coalescer_destroy(co);  // (at interpreter exit HIP may be gone)
+    }
+};
+std::mutex g_coalescer_mu;
+std::shared_ptr<CoalescerBox> g_coalescer;
 struct CoalescerUse {  // a call's hold on whichever coalescer was current when it started
+    std::shared_ptr<CoalescerBox> box;
     fcd_coalescer *co;
     CoalescerUse() {
-        g_coalescer_users.fetch_add(1);
-        co = g_coalescer.load();
+        std::lock_guard<std::mutex> g(g_coalescer_mu);
+        box = g_coalescer;
+        co = box ? box->co : nullptr;
     }
-    ~CoalescerUse() { g_coalescer_users.fetch_sub(1); }
 };
 
 void check_rc_coalescer(int rc) {
@@ -452,6 +463,398 @@ py::str crf_beam_search_duplex(const py::object &network_output_1, const py::obj
     return py::str(reverse_chars(rev));
 }
 
+
+// =============================================================================================================
+// Batch functions (additive: the reference decodes one read per call).  Element i of the returned list is what
+// the per-read function returns for read i.  A host batch runs as a job of result chunks (include/fcd.h,
+// csrc/hostjob.hip): uploads, searches and packed downloads of different chunks overlap, and this thread turns
+// chunk c into Python objects -- under the GIL -- while the later chunks are still in flight.
+// =============================================================================================================
+struct BatchInput {
+    fcd_batch b{};
+    py::array keep;                   // the caller's array (a view: zero-copy)
+    std::unique_ptr<float[]> padded;  // or a padded copy of a sequence of per-read arrays
+    std::vector<int64_t> lengths;
+    py::ssize_t inner = 0;
+};
+
+// network_outputs: ONE float32 array of rank `ndim` ((B,T,N) or (B,T,S,N), any non-negative strides: not copied),
+// or a sequence of per-read float32 arrays of rank ndim-1 with equal inner shapes (copied into a padded batch;
+// their row counts become the lengths).
+void make_batch(BatchInput &in, const py::object &x, int ndim, const py::object &lengths_o) {
+    if (py::isinstance<py::array>(x)) {
+        py::array a = as_f32(x, ndim, "network_outputs");
+        in.keep = a;
+        in.b.post = static_cast<const float *>(a.data());
+        in.b.n_reads = a.shape(0);
+        in.b.T = a.shape(1);
+        in.b.stride_read = a.strides(0) / 4;
+        in.b.stride_t = a.strides(1) / 4;
+        if (ndim == 4) {
+            in.b.S = a.shape(2);
+            in.b.N = a.shape(3);
+            in.b.stride_s = a.strides(2) / 4;
+            in.b.stride_n = a.strides(3) / 4;
+        } else {
+            in.b.S = 1;
+            in.b.N = a.shape(2);
+            in.b.stride_n = a.strides(2) / 4;
+        }
+        in.inner = in.b.N;
+    } else {
+        py::sequence seq;
+        try {
+            seq = py::reinterpret_borrow<py::sequence>(x);
+            if (!PySequence_Check(x.ptr())) throw py::type_error("");
+        } catch (...) {
+            throw py::type_error("argument 'network_outputs': expected a float32 numpy.ndarray or a sequence of them");
+        }
+        const py::ssize_t B = (py::ssize_t)py::len(seq);
+        std::vector<py::array> reads;
+        reads.reserve((size_t)B);
+        py::ssize_t Tmax = 0, S = 1, N = 0;
+        for (py::ssize_t i = 0; i < B; ++i) {
+            py::array a = as_f32(seq[i], ndim - 1, "network_outputs[i]");
+            const py::ssize_t s = ndim == 4 ? a.shape(1) : 1, n = a.shape(ndim - 2);
+            if (i == 0) {
+                S = s;
+                N = n;
+            } else if (s != S || n != N) {
+                throw py::type_error("argument 'network_outputs': the reads' inner shapes differ");
+            }
+            Tmax = std::max(Tmax, a.shape(0));
+            reads.push_back(a);
+        }
+        if (!lengths_o.is_none()) throw py::value_error("lengths cannot be given with a sequence of per-read arrays");
+        const size_t row = (size_t)S * (size_t)N;
+        in.padded.reset(new float[std::max<size_t>((size_t)B * (size_t)Tmax * row, 1)]);
+        in.lengths.resize((size_t)B);
+        for (py::ssize_t i = 0; i < B; ++i) {
+            const py::array &a = reads[(size_t)i];
+            in.lengths[(size_t)i] = a.shape(0);
+            float *dst = in.padded.get() + (size_t)i * (size_t)Tmax * row;
+            py::array c = py::array::ensure(a, py::array::c_style);  // a no-op for contiguous reads
+            if (a.shape(0) > 0) std::memcpy(dst, c.data(), (size_t)a.shape(0) * row * sizeof(float));
+        }
+        in.b.post = in.padded.get();
+        in.b.n_reads = B;
+        in.b.T = Tmax;
+        in.b.S = S;
+        in.b.N = N;
+        in.b.stride_read = (int64_t)((size_t)Tmax * row);
+        in.b.stride_t = (int64_t)row;
+        in.b.stride_s = ndim == 4 ? N : 0;
+        in.b.stride_n = 1;
+        in.b.lengths = in.lengths.data();
+        in.inner = N;
+        return;
+    }
+    if (!lengths_o.is_none()) {
+        py::array_t<int64_t, py::array::c_style | py::array::forcecast> l(lengths_o);
+        if (l.ndim() != 1 || l.shape(0) != in.b.n_reads) throw py::value_error("lengths must have shape (n_reads,)");
+        in.lengths.assign(l.data(), l.data() + l.shape(0));
+        for (int64_t v : in.lengths)
+            if (v < 0 || v > in.b.T) throw py::value_error("lengths must lie in [0, T]");
+        in.b.lengths = in.lengths.data();
+    }
+}
+
+enum class Paths { List, Array, None };
+
+Paths parse_paths(const py::object &o) {
+    if (o.is_none()) return Paths::None;
+    if (py::isinstance<py::str>(o)) {
+        const std::string v = o.cast<std::string>();
+        if (v == "list") return Paths::List;
+        if (v == "array") return Paths::Array;
+    }
+    throw py::value_error("paths must be 'list', 'array' or None");
+}
+
+struct JobGuard {  // fcd_job_end on every way out
+    fcd_job *job = nullptr;
+    ~JobGuard() {
+        if (job) {
+            py::gil_scoped_release nogil;
+            fcd_job_end(job);
+        }
+    }
+};
+
+// Python ints for path entries: every entry is a row index < T, so the lists share ONE int object per value
+// (ints are immutable; creating eight million of them is what made list paths 10x slower than array paths).
+struct IntTable {
+    std::vector<PyObject *> v;
+    ~IntTable() {
+        for (PyObject *o : v) Py_XDECREF(o);
+    }
+    PyObject *get(size_t i) {
+        if (i >= v.size()) v.resize(std::max(i + 1, v.size() * 2), nullptr);
+        PyObject *&o = v[i];
+        if (!o) {
+            o = PyLong_FromSize_t(i);
+            if (!o) throw py::error_already_set();
+        }
+        return o;
+    }
+};
+
+struct BatchCall {
+    enum Kind { Viterbi, Beam, CrfBeam, CrfGreedy } kind;
+    bool qstring = false;
+    float qscale = 1.0f, qbias = 0.0f;
+    bool reverse_chars_join = false;  // the CRF beam search joins leaf -> root and reverses CHARACTERS
+};
+
+// Turns one result chunk into Python objects and stores them in result[read_begin ..].
+void emit_chunk(const fcd_chunk &ch, const std::vector<std::string> &alpha, const BatchCall &call, Paths paths,
+                bool raise_on_error, IntTable &ints, py::list &result) {
+    // single-byte alphabets (the usual "NACGT"): labels -> characters through a table, straight into the str
+    bool ascii1 = !call.qstring;
+    uint8_t lut[256] = {0};
+    for (size_t k = 0; k < alpha.size() && ascii1; ++k) {
+        if (alpha[k].size() == 1 && (unsigned char)alpha[k][0] < 128 && k < 256) lut[k] = (uint8_t)alpha[k][0];
+        else ascii1 = false;
+    }
+    // path entries of the whole chunk as ONE uint32 array; every read gets a view of it
+    py::array_t<uint32_t> all_paths;
+    uint32_t *ap = nullptr;
+    const uint64_t total = ch.offsets[ch.n_reads];
+    if (paths == Paths::Array && ch.path) {
+        all_paths = py::array_t<uint32_t>((py::ssize_t)total);
+        ap = all_paths.mutable_data();
+        if (ch.path_bytes == 2) {
+            const uint16_t *src = static_cast<const uint16_t *>(ch.path);
+            for (uint64_t k = 0; k < total; ++k) ap[k] = src[k];
+        } else {
+            std::memcpy(ap, ch.path, (size_t)total * 4);
+        }
+    }
+    std::string buf;
+    for (int64_t i = 0; i < ch.n_reads; ++i) {
+        const int64_t r = ch.read_begin + i;
+        const int32_t st = ch.status[i];
+        if (st != FCD_ST_OK) {
+            if (raise_on_error)
+                throw std::runtime_error("read " + std::to_string(r) + ": " + fcd_status_string(st));
+            Py_INCREF(Py_None);
+            PyList_SET_ITEM(result.ptr(), r, Py_None);
+            continue;
+        }
+        const uint64_t off = ch.offsets[i];
+        const size_t len = (size_t)(ch.offsets[i + 1] - off);
+        const uint8_t *lab = ch.labels + off;
+        PyObject *seq;
+        if (ascii1) {
+            seq = PyUnicode_New((Py_ssize_t)len, 127);
+            if (!seq) throw py::error_already_set();
+            Py_UCS1 *d = PyUnicode_1BYTE_DATA(seq);
+            for (size_t k = 0; k < len; ++k) d[k] = lut[lab[k]];
+        } else {
+            buf.clear();
+            if (call.reverse_chars_join) {  // search.rs:146-156
+                std::string rev;
+                for (size_t k = len; k > 0; --k) rev += alpha[lab[k - 1]];
+                buf = reverse_chars(rev);
+            } else {
+                for (size_t k = 0; k < len; ++k) buf += alpha[lab[k]];
+            }
+            if (call.qstring)
+                for (size_t k = 0; k < len; ++k) append_utf8(buf, fcd_phred(ch.qual[off + k], call.qscale, call.qbias));
+            seq = PyUnicode_DecodeUTF8(buf.data(), (Py_ssize_t)buf.size(), "strict");
+            if (!seq) throw py::error_already_set();
+        }
+        PyObject *pth;
+        if (paths == Paths::None || !ch.path) {
+            Py_INCREF(Py_None);
+            pth = Py_None;
+        } else if (paths == Paths::Array) {
+            py::array_t<uint32_t> view({(py::ssize_t)len}, {(py::ssize_t)4}, ap + off, all_paths);
+            pth = view.release().ptr();
+        } else {
+            pth = PyList_New((Py_ssize_t)len);
+            if (!pth) {
+                Py_DECREF(seq);
+                throw py::error_already_set();
+            }
+            if (ch.path_bytes == 2) {
+                const uint16_t *src = static_cast<const uint16_t *>(ch.path) + off;
+                for (size_t k = 0; k < len; ++k) {
+                    PyObject *o = ints.get(src[k]);
+                    Py_INCREF(o);
+                    PyList_SET_ITEM(pth, (Py_ssize_t)k, o);
+                }
+            } else {
+                const uint32_t *src = static_cast<const uint32_t *>(ch.path) + off;
+                for (size_t k = 0; k < len; ++k) {
+                    PyObject *o = ints.get(src[k]);
+                    Py_INCREF(o);
+                    PyList_SET_ITEM(pth, (Py_ssize_t)k, o);
+                }
+            }
+        }
+        PyObject *tup = PyTuple_New(2);
+        if (!tup) {
+            Py_DECREF(seq);
+            Py_DECREF(pth);
+            throw py::error_already_set();
+        }
+        PyTuple_SET_ITEM(tup, 0, seq);
+        PyTuple_SET_ITEM(tup, 1, pth);
+        PyList_SET_ITEM(result.ptr(), r, tup);
+    }
+}
+
+// begin (already done by the caller) -> next / emit ... -> end
+py::list run_job(fcd_handle *h, JobGuard &jg, int64_t B, const std::vector<std::string> &alpha, const BatchCall &call,
+                 Paths paths, bool raise_on_error) {
+    py::list result((py::ssize_t)B);  // slots are NULL until emit_chunk fills them
+    IntTable ints;
+    for (;;) {
+        fcd_chunk ch;
+        int rc;
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_job_next(jg.job, &ch);
+        }
+        if (rc == FCD_JOB_DONE) break;
+        if (rc != FCD_OK) {
+            // the list still has empty slots: fill them before it can be released
+            for (int64_t r = 0; r < B; ++r)
+                if (!PyList_GET_ITEM(result.ptr(), r)) {
+                    Py_INCREF(Py_None);
+                    PyList_SET_ITEM(result.ptr(), r, Py_None);
+                }
+            check_rc(h, rc);
+        }
+        try {
+            emit_chunk(ch, alpha, call, paths, raise_on_error, ints, result);
+        } catch (...) {
+            for (int64_t r = 0; r < B; ++r)
+                if (!PyList_GET_ITEM(result.ptr(), r)) {
+                    Py_INCREF(Py_None);
+                    PyList_SET_ITEM(result.ptr(), r, Py_None);
+                }
+            throw;
+        }
+    }
+    return result;
+}
+
+int want_flags(Paths paths, bool qual) {
+    return (paths != Paths::None ? FCD_JOB_PATH : 0) | (qual ? FCD_JOB_QUAL : 0);
+}
+
+py::list beam_search_batch(const py::object &network_outputs, const py::object &alphabet,
+                           const py::object &beam_size_o, float beam_cut_threshold, bool collapse_repeats,
+                           const py::object &lengths, const py::object &paths_o, int kernel, bool raise_on_error) {
+    BatchInput in;
+    make_batch(in, network_outputs, 3, lengths);
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    check_beam_args(alpha.size(), in.inner, (py::ssize_t)beam_size, beam_cut_threshold);
+    const Paths paths = parse_paths(paths_o);
+    fcd_handle *h = thread_handle();
+    JobGuard jg;
+    int rc;
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_beam_search_host_begin(h, &in.b, (int64_t)beam_size, beam_cut_threshold, collapse_repeats ? 1 : 0,
+                                        kernel, want_flags(paths, false), &jg.job);
+    }
+    check_rc(h, rc);
+    BatchCall call{BatchCall::Beam};
+    return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
+}
+
+py::list viterbi_search_batch(const py::object &network_outputs, const py::object &alphabet, bool qstring, float qscale,
+                              float qbias, bool collapse_repeats, const py::object &lengths, const py::object &paths_o,
+                              bool raise_on_error) {
+    BatchInput in;
+    make_batch(in, network_outputs, 3, lengths);
+    auto alpha = seq_to_vec(alphabet);
+    check_greedy_alphabet(alpha.size(), in.inner);
+    if (in.b.T == 0 && in.b.n_reads > 0)
+        throw std::runtime_error("network_output is empty (the reference asserts and aborts here)");
+    const Paths paths = parse_paths(paths_o);
+    fcd_handle *h = thread_handle();
+    JobGuard jg;
+    int rc;
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_viterbi_search_host_begin(h, &in.b, collapse_repeats ? 1 : 0, want_flags(paths, qstring), &jg.job);
+    }
+    check_rc(h, rc);
+    BatchCall call{BatchCall::Viterbi};
+    call.qstring = qstring;
+    call.qscale = qscale;
+    call.qbias = qbias;
+    return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
+}
+
+py::array init_states_array(const py::object &init_states, int64_t B) {
+    py::array init = py::array::ensure(as_f32(init_states, 2, "init_states"), py::array::c_style);
+    if (init.shape(0) != B) throw py::value_error("init_states must have shape (n_reads, n_init)");
+    if (init.shape(1) == 0 && B > 0)
+        throw std::runtime_error("network_output/init_state is empty (the reference asserts and aborts here)");
+    return init;
+}
+
+py::list crf_beam_search_batch(const py::object &network_outputs, const py::object &init_states,
+                               const py::object &alphabet, const py::object &beam_size_o, float beam_cut_threshold,
+                               const py::object &lengths, const py::object &paths_o, int kernel, bool raise_on_error) {
+    BatchInput in;
+    make_batch(in, network_outputs, 4, lengths);
+    py::array init = init_states_array(init_states, in.b.n_reads);
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    check_greedy_alphabet(alpha.size(), in.inner);
+    if (in.b.n_reads > 0 && (in.b.T == 0 || in.b.S == 0))
+        throw std::runtime_error("network_output/init_state is empty (the reference asserts and aborts here)");
+    if (beam_size == 0) raise_status(FCD_ST_RAN_OUT_OF_BEAM);
+    const Paths paths = parse_paths(paths_o);
+    fcd_handle *h = thread_handle();
+    JobGuard jg;
+    int rc;
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_crf_beam_search_host_begin(h, &in.b, static_cast<const float *>(init.data()), init.shape(1),
+                                            init.shape(1), (int64_t)beam_size, beam_cut_threshold, kernel,
+                                            want_flags(paths, false), &jg.job);
+    }
+    check_rc(h, rc);
+    BatchCall call{BatchCall::CrfBeam};
+    call.reverse_chars_join = true;
+    return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
+}
+
+py::list crf_greedy_search_batch(const py::object &network_outputs, const py::object &init_states,
+                                 const py::object &alphabet, bool qstring, float qscale, float qbias,
+                                 const py::object &lengths, const py::object &paths_o, bool raise_on_error) {
+    BatchInput in;
+    make_batch(in, network_outputs, 4, lengths);
+    py::array init = init_states_array(init_states, in.b.n_reads);
+    auto alpha = seq_to_vec(alphabet);
+    check_greedy_alphabet(alpha.size(), in.inner);
+    if (in.b.n_reads > 0 && (in.b.T == 0 || in.b.S == 0))
+        throw std::runtime_error("network_output/init_state is empty (the reference asserts and aborts here)");
+    const Paths paths = parse_paths(paths_o);
+    fcd_handle *h = thread_handle();
+    JobGuard jg;
+    int rc;
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_crf_greedy_search_host_begin(h, &in.b, static_cast<const float *>(init.data()), init.shape(1),
+                                              init.shape(1), want_flags(paths, qstring), &jg.job);
+    }
+    check_rc(h, rc);
+    BatchCall call{BatchCall::CrfGreedy};
+    call.qstring = qstring;
+    call.qscale = qscale;
+    call.qbias = qbias;
+    return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(fast_ctc_decode, m) {
@@ -503,12 +906,19 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
                     throw std::runtime_error("fast_ctc_decode: no usable gfx950 device (fcd_coalescer_create failed with " +
                                              std::to_string(rc) + "); this module has no CPU fallback");
             }
-            fcd_coalescer *old = g_coalescer.exchange(fresh);
-            if (old) {
-                py::gil_scoped_release nogil;  // calls that may still hold the old pointer finish first
-                while (g_coalescer_users.load() != 0) std::this_thread::sleep_for(std::chrono::milliseconds(1));
-                fcd_coalescer_destroy(old);
+            std::shared_ptr<CoalescerBox> box;
+            if (fresh) {
+                box = std::make_shared<CoalescerBox>();
+                box->co = fresh;
             }
+            std::shared_ptr<CoalescerBox> old;
+            {
+                std::lock_guard<std::mutex> g(g_coalescer_mu);
+                old = std::move(g_coalescer);
+                g_coalescer = std::move(box);
+            }
+            py::gil_scoped_release nogil;  // dropping the last reference destroys the old coalescer
+            old.reset();
         },
         "max_batch"_a = 256, "max_wait_us"_a = 0, "device"_a = 0,
         "Decode concurrent per-read viterbi_search / beam_search calls (any threads) with shared batched launches; "
@@ -525,6 +935,27 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
         d["largest_batch"] = c;
         return std::move(d);
     });
+    // ---- additive batch functions (not in the reference): element i == the per-read call on read i ----
+    m.def("beam_search_batch", &beam_search_batch, "network_outputs"_a, "alphabet"_a, "beam_size"_a = 5,
+          "beam_cut_threshold"_a = 0.0f, "collapse_repeats"_a = true, "lengths"_a = py::none(), "paths"_a = "list",
+          "kernel"_a = 0, "raise_on_error"_a = true,
+          "beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold=0.0, collapse_repeats=True, "
+          "lengths=None, paths='list') -> list of (str, path).  network_outputs: one (B,T,N) float32 array (zero-copy) "
+          "or a sequence of (T_i,N) arrays.  paths: 'list' (list[int], as the reference), 'array' (uint32 ndarray "
+          "views) or None.");
+    m.def("viterbi_search_batch", &viterbi_search_batch, "network_outputs"_a, "alphabet"_a, "qstring"_a = false,
+          "qscale"_a = 1.0f, "qbias"_a = 0.0f, "collapse_repeats"_a = true, "lengths"_a = py::none(),
+          "paths"_a = "list", "raise_on_error"_a = true);
+    m.def("crf_beam_search_batch", &crf_beam_search_batch, "network_outputs"_a, "init_states"_a, "alphabet"_a,
+          "beam_size"_a = 5, "beam_cut_threshold"_a = 0.0f, "lengths"_a = py::none(), "paths"_a = "list",
+          "kernel"_a = 0, "raise_on_error"_a = true);
+    m.def("crf_greedy_search_batch", &crf_greedy_search_batch, "network_outputs"_a, "init_states"_a, "alphabet"_a,
+          "qstring"_a = false, "qscale"_a = 1.0f, "qbias"_a = 0.0f, "lengths"_a = py::none(), "paths"_a = "list",
+          "raise_on_error"_a = true);
+    m.def("_set_host_pipeline", [](int lanes, int64_t chunk_reads, int64_t min_bytes) {
+        fcd_handle *h = thread_handle();
+        check_rc(h, fcd_set_host_pipeline(h, lanes, chunk_reads, min_bytes));
+    }, "lanes"_a = 0, "chunk_reads"_a = 0, "min_bytes"_a = -1, "tuning / tests: include/fcd.h fcd_set_host_pipeline");
     if (const char *env = std::getenv("FCD_DUPLEX_LOGADD")) set_mode(env);
     m.attr("__version__") = "0.3.7";  // src/lib.rs:626 (CARGO_PKG_VERSION of the mirrored reference)
 }

@@ -306,6 +306,52 @@ int fcd_coalescer_viterbi_search(fcd_coalescer *c, const fcd_batch *read, int co
 int fcd_coalescer_stats(fcd_coalescer *c, int64_t *n_calls, int64_t *n_launches, int64_t *largest_batch);
 const char *fcd_coalescer_last_error(void);
 
+/* ---- large HOST batches as a stream of result chunks (csrc/hostjob.hip) -----------------------------------
+ * The reference's callers hold posteriors in host memory (src/lib.rs:182,325: &PyArray2<f32>) and want strings
+ * and paths back (src/lib.rs:208,361).  A job decodes a host batch chunk by chunk on a few internal lanes (own
+ * stream, staging area and tree arena each): the upload of chunk c+1 overlaps the searches of the chunks before
+ * it, only the USED prefix of every result row crosses PCIe (times as u16 when T < 65536), and the caller can
+ * turn chunk c into its own objects while later chunks are still in flight.
+ *   fcd_*_host_begin   same arguments and checks as fcd_*_host (host pointers; they must stay valid until
+ *                      fcd_job_end) plus `want`, an OR of FCD_JOB_*; starts the pipeline and returns.
+ *   fcd_job_next       blocks until the next chunk (in read order) is in host memory and describes it in *out;
+ *                      the view stays valid until the next fcd_job_next / fcd_job_end on the job.  Returns
+ *                      FCD_OK, FCD_JOB_DONE after the last chunk, or a negative FCD_E_*.
+ *   fcd_job_end        always call: waits for / cancels outstanding work and frees the job.
+ * One job at a time per handle; the handle's other entry points may be used again after fcd_job_end.
+ * fcd_*_host on large batches (>= 128 reads and >= 16 MB) runs the same pipeline and expands the chunks into the
+ * caller's fixed-stride arrays.  Environment: FCD_HOST_LANES (default 4; 1 = no pipelining), FCD_HOST_CHUNK
+ * (reads per chunk; default = the batch split evenly over the lanes, at most 2048). */
+enum { FCD_JOB_PATH = 1, FCD_JOB_QUAL = 2, FCD_JOB_AMBIGUOUS = 4 };
+enum { FCD_JOB_DONE = 1 };
+typedef struct fcd_job fcd_job;
+typedef struct fcd_chunk {
+    int64_t read_begin;        /* index of the chunk's first read in the batch */
+    int64_t n_reads;
+    const uint32_t *out_len;   /* [n_reads] */
+    const int32_t *status;     /* [n_reads] FCD_ST_* */
+    const uint64_t *offsets;   /* [n_reads + 1]: read i owns entries offsets[i] .. offsets[i+1] of the arrays below */
+    const uint8_t *labels;     /* label indices of read 0, read 1, ... back to back */
+    const void *path;          /* u16 (path_bytes == 2) or u32 (4) row indices, same order; NULL unless FCD_JOB_PATH */
+    int path_bytes;
+    const float *qual;         /* NULL unless FCD_JOB_QUAL (viterbi / crf_greedy) */
+    const uint32_t *ambiguous; /* [n_reads][2] tie counters (fcd_result.ambiguous); NULL unless FCD_JOB_AMBIGUOUS */
+} fcd_chunk;
+int fcd_viterbi_search_host_begin(fcd_handle *h, const fcd_batch *in, int collapse_repeats, int want, fcd_job **job);
+int fcd_beam_search_host_begin(fcd_handle *h, const fcd_batch *in, int64_t beam_size, float beam_cut_threshold,
+                               int collapse_repeats, int kernel, int want, fcd_job **job);
+int fcd_crf_beam_search_host_begin(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                                   int64_t init_stride, int64_t beam_size, float beam_cut_threshold, int kernel,
+                                   int want, fcd_job **job);
+int fcd_crf_greedy_search_host_begin(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
+                                     int64_t init_stride, int want, fcd_job **job);
+/* Tuning / tests: lanes (0 = default 4 or FCD_HOST_LANES; 1 = never pipeline), reads per chunk (0 = automatic),
+ * and the input size from which fcd_*_host takes the pipeline (-1 = default: >= 128 reads and >= 16 MB). */
+int fcd_set_host_pipeline(fcd_handle *h, int lanes, int64_t chunk_reads, int64_t min_bytes);
+int fcd_job_chunks(const fcd_job *job, int64_t *chunk_reads, int *n_lanes);  /* number of chunks; -1 for NULL */
+int fcd_job_next(fcd_job *job, fcd_chunk *out);
+int fcd_job_end(fcd_job *job);
+
 /* ---- host-side helpers shared with the language bindings ---- */
 /* phred quality character code point for a probability (src/search.rs:31-36) */
 uint32_t fcd_phred(float prob, float qscale, float qbias);

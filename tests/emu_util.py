@@ -16,14 +16,36 @@ def emu_lib_path():
     return emu_build.build()
 
 
+_emu_compiled = None
+
+
+def emu_compiled_module():
+    """csrc/pymodule.cpp linked against the emulator library (tests/hipemu/build.py), loaded under a private
+    name so that it never shadows the product's `fast_ctc_decode`."""
+    global _emu_compiled
+    if _emu_compiled is None:
+        import importlib.util
+
+        import build as emu_build
+        # (a dotted name: the init function is looked up by the last component, while pybind11 caches completed
+        # modules by the FULL name -- under the bare name the product's module would be handed back)
+        spec = importlib.util.spec_from_file_location("fcd_hipemu.fast_ctc_decode", emu_build.build_pymodule())
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        _emu_compiled = mod
+    return _emu_compiled
+
+
 @contextlib.contextmanager
 def emulated_kernels():
     from fast_ctc_decode_amd import _native as nat
+    from fast_ctc_decode_amd import api
 
     lib = nat.bind(C.CDLL(emu_lib_path()))
-    saved_lib, saved_tls = nat._lib, getattr(nat._tls, "handles", None)
+    saved_lib, saved_tls, saved_cm = nat._lib, getattr(nat._tls, "handles", None), api._cm
     nat._lib = lib
     nat._tls.handles = {}
+    api._cm = emu_compiled_module()
     try:
         yield lib
     finally:
@@ -31,3 +53,4 @@ def emulated_kernels():
             h.close()
         nat._lib = saved_lib
         nat._tls.handles = saved_tls
+        api._cm = saved_cm

@@ -112,3 +112,14 @@ def test_beam_fuzz_slice_and_misc(fcd):
     P.test_beam_peaky(fcd, 2)
     P.test_beam_peaky(fcd, 3)
     P.test_release_workspace(fcd)
+
+
+def test_chunked_host_path(fcd):
+    """csrc/hostjob.hip under the emulator: chunk boundaries, ragged and failing reads, the job API, and the
+    compiled module's batch functions (csrc/pymodule.cpp linked against the emulator library)."""
+    import test_gpu_hostjob as H
+    H.test_host_pipeline_equals_one_shot(fcd, 3, 5)
+    H.test_host_pipeline_crf(fcd)
+    H.test_host_pipeline_strided_views(fcd)
+    H.test_job_api_chunks_and_cancel(fcd)
+    H.test_compiled_batch_functions_equal_per_read_calls(fcd, 3, 2)

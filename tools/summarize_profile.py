@@ -66,6 +66,9 @@ out = {
              "bytes of a wide coalesced (16 B/lane) stream (MI355X_MICROARCH.md HBM section) -- confirmed by "
              "viterbi_stream_kernel<5>: 16384 reads x 80000 B = 1 280 000 KiB of input vs its FETCH_SIZE",
     "kernels": {},
+    # {file: md5} of the kernel sources this run was taken on (written next to the counters by tools/profile.sh on
+    # the GPU box); bench.py quotes the numbers only while those files are unchanged
+    "kernel_source_md5": json.load(open(os.path.join(base, "kernel_source_md5.json"))),
 }
 for k in stats:
     fs, ws = f.get(k, []), w.get(k, [])

@@ -31,6 +31,7 @@ out = {
     "command": "tools/profile_sq.sh (rocprofv3 --kernel-trace --pmc <8 SQ counters>, two passes)",
     "counters_per_launch": per_launch,
     "per_wave_step": {k: v / wave_steps for k, v in per_launch.items()},
+    "kernel_source_md5": json.load(open(os.path.join(base, "kernel_source_md5.json"))),
     "notes": "SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles (x4 = shader cycles)",
 }
 dst = os.path.join(ROOT, "profiles", tag + "_sq_counters.json")
