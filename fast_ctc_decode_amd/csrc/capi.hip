@@ -950,14 +950,14 @@ int host_check(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const 
     return FCD_OK;
 }
 
-// Lays the call out in h->stage (inputs first, then the fixed-stride result arrays), uploads the inputs on
-// h->stream and runs the *_dev search there.  `shape` says which result arrays are wanted (non-null members)
-// and their stride; *dout receives the device-side result.  Small calls (the per-read drop-in functions: a
-// few hundred KB) go through a page-locked mirror of the staging area when allow_mirror: ONE DMA in (and ONE
-// out in host_download) instead of a runtime-staged copy per array from pageable memory; large batches are
-// copied straight from / to the caller's arrays (an extra host pass would cost more).
-int host_upload_and_search(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, const HostCall &c,
-                           bool allow_mirror, HostStage *st, fcd_result *dout) {
+// Lays the call out in h->stage (inputs first, then the fixed-stride result arrays) and uploads the inputs on
+// h->stream.  `shape` says which result arrays are wanted (non-null members) and their stride; *din / *dout
+// receive the device-side batch and result.  Small calls (the per-read drop-in functions: a few hundred KB) go
+// through a page-locked mirror of the staging area when allow_mirror: ONE DMA in (and ONE out in host_download)
+// instead of a runtime-staged copy per array from pageable memory; large batches are copied straight from / to
+// the caller's arrays (an extra host pass would cost more).
+int host_upload(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, const HostCall &c, bool allow_mirror,
+                HostStage *st, fcd_batch *din, fcd_result *dout) {
     const bool crf = c.op == HostOp::CrfBeam || c.op == HostOp::CrfGreedy;
     const int64_t B = in->n_reads;
     st->B = B;
@@ -1012,9 +1012,9 @@ int host_upload_and_search(fcd_handle *h, const fcd_batch *in, const fcd_result 
         if (crf)
             FCD_HIP(h, hipMemcpyAsync(base + st->o_init, c.init, st->n_init * 4, hipMemcpyHostToDevice, h->stream));
     }
-    fcd_batch din = *in;
-    din.post = reinterpret_cast<const float *>(base + st->o_in);
-    din.lengths = in->lengths ? reinterpret_cast<const int64_t *>(base + st->o_len) : nullptr;
+    *din = *in;
+    din->post = reinterpret_cast<const float *>(base + st->o_in);
+    din->lengths = in->lengths ? reinterpret_cast<const int64_t *>(base + st->o_len) : nullptr;
     dout->labels = reinterpret_cast<uint8_t *>(base + st->o_lab);
     dout->path = shape->path ? reinterpret_cast<uint32_t *>(base + st->o_path) : nullptr;
     dout->qual = shape->qual ? reinterpret_cast<float *>(base + st->o_qual) : nullptr;
@@ -1022,18 +1022,23 @@ int host_upload_and_search(fcd_handle *h, const fcd_batch *in, const fcd_result 
     dout->status = reinterpret_cast<int32_t *>(base + st->o_stat);
     dout->out_stride = shape->out_stride;
     dout->ambiguous = st->want_amb ? reinterpret_cast<uint32_t *>(base + st->o_amb) : nullptr;
-    const float *dinit = reinterpret_cast<const float *>(base + st->o_init);
+    return FCD_OK;
+}
+
+// Runs the *_dev search of a staged call on h->stream.
+int host_search(fcd_handle *h, const HostStage &st, const fcd_batch *din, const HostCall &c, const fcd_result *dout) {
+    const float *dinit = reinterpret_cast<const float *>(reinterpret_cast<char *>(h->stage) + st.o_init);
     switch (c.op) {
-        case HostOp::Viterbi: return fcd_viterbi_search_dev(h, &din, c.collapse, dout);
-        case HostOp::Beam: return fcd_beam_search_dev(h, &din, c.beam_size, c.thr, c.collapse, c.kernel, dout);
+        case HostOp::Viterbi: return fcd_viterbi_search_dev(h, din, c.collapse, dout);
+        case HostOp::Beam: return fcd_beam_search_dev(h, din, c.beam_size, c.thr, c.collapse, c.kernel, dout);
         case HostOp::CrfBeam:
-            return fcd_crf_beam_search_dev_k(h, &din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel, dout);
-        case HostOp::CrfGreedy: return fcd_crf_greedy_search_dev(h, &din, dinit, c.n_init, c.init_stride, dout);
+            return fcd_crf_beam_search_dev_k(h, din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel, dout);
+        case HostOp::CrfGreedy: return fcd_crf_greedy_search_dev(h, din, dinit, c.n_init, c.init_stride, dout);
     }
     return FCD_E_INVALID;
 }
 
-// Copies the fixed-stride device result of host_upload_and_search into the caller's arrays and waits.
+// Copies the fixed-stride device result of a staged call into the caller's arrays and waits.
 int host_download(fcd_handle *h, const HostStage &st, const fcd_result &dout, const fcd_result *out) {
     const size_t B = (size_t)st.B;
     if (st.mirror) {
@@ -1076,8 +1081,10 @@ int run_host(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const Ho
     // Large batches: chunks on several internal lanes, upload || search || packed download (hostjob.hip)
     if (host_job_wanted(h, in, c)) return host_job_run_fixed(h, in, out, c);
     HostStage st;
+    fcd_batch din{};
     fcd_result dout{};
-    rc = host_upload_and_search(h, in, out, c, true, &st, &dout);
+    rc = host_upload(h, in, out, c, true, &st, &din, &dout);
+    if (rc == FCD_OK) rc = host_search(h, st, &din, c, &dout);
     if (rc) return rc;
     return host_download(h, st, dout, out);
 }

@@ -189,8 +189,9 @@ struct HostStage {
 };
 
 int host_check(fcd_handle *h, const fcd_batch *in, const fcd_result *out, const HostCall &c);
-int host_upload_and_search(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, const HostCall &c,
-                           bool allow_mirror, HostStage *st, fcd_result *dout);
+int host_upload(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, const HostCall &c, bool allow_mirror,
+                HostStage *st, fcd_batch *din, fcd_result *dout);
+int host_search(fcd_handle *h, const HostStage &st, const fcd_batch *din, const HostCall &c, const fcd_result *dout);
 int host_download(fcd_handle *h, const HostStage &st, const fcd_result &dout, const fcd_result *out);
 // large host batches: chunks on internal lanes, upload || search || packed download (hostjob.hip)
 bool host_job_wanted(fcd_handle *h, const fcd_batch *in, const HostCall &c);

@@ -7,10 +7,14 @@
 // used.  So a batch is cut into chunks that travel through a few LANES -- internal sub-handles with their own
 // HIP stream, staging area, tree arena and page-locked result buffer:
 //
-//   issuer thread   chunk c -> lane c % L:  upload (blocking from pageable memory) | search | offsets + pack |
-//                   download of the chunk's header (out_len, status) into page-locked memory | event
+//   lane thread     chunk c = lane, lane + L, ...: upload (blocking from pageable memory; the lanes take turns in
+//                   chunk order, so chunk c is on the GPU before chunk c+1 starts to travel) | search | offsets +
+//                   pack | download of the chunk's header (out_len, status) into page-locked memory | event
 //   caller thread   fcd_job_next: wait for the event, download exactly the used label / path / quality bytes,
 //                   hand out a view (fcd_chunk) of the lane's page-locked buffer
+//
+// (one thread per lane, not one for all: a wide-beam search that sizes its arena in two passes waits for its
+// own stream between them, and must not hold up the other lanes)
 //
 // so the upload of chunk c+1 overlaps the searches of chunks <= c (which run side by side on the GPU: each is
 // a fraction of a wavefront per SIMD), downloads carry only used prefixes (u16 times when T < 65536), and the
@@ -46,7 +50,8 @@ struct fcd_job {
     int64_t chunk = 0;
     int n_chunks = 0, n_lanes = 0;
     int path_bytes = 2;
-    std::thread issuer;
+    std::vector<std::thread> workers;  // one per lane
+    int upload_turn = 0;               // the chunk whose upload may start
     std::mutex mu;
     std::condition_variable cv;
     std::vector<int> state;  // per chunk: 0 not issued yet, 1 issued, 2 failed
@@ -77,8 +82,11 @@ size_t payload_bytes(uint64_t total, int path_bytes, bool has_path, bool has_qua
 }
 
 int lane_fail(fcd_job *j, int rc, const std::string &msg) {
-    j->rc = rc;
-    j->err = msg;
+    std::lock_guard<std::mutex> lk(j->mu);
+    if (j->rc == FCD_OK) {  // the first failure is the one reported
+        j->rc = rc;
+        j->err = msg;
+    }
     return rc;
 }
 
@@ -110,8 +118,20 @@ int issue_chunk(fcd_job *j, int c) {
     shape.ambiguous = has_amb ? reinterpret_cast<uint32_t *>(&dummy) : nullptr;
     shape.out_stride = W;
     HostStage st;
+    fcd_batch din{};
     fcd_result dout{};
-    int rc = host_upload_and_search(lh, &sub, &shape, call, false, &st, &dout);
+    {   // uploads go one at a time, in chunk order
+        std::unique_lock<std::mutex> lk(j->mu);
+        j->cv.wait(lk, [&] { return j->cancel || j->upload_turn == c; });
+        if (j->cancel) return FCD_E_INVALID;  // the job was abandoned (or another lane failed)
+    }
+    int rc = host_upload(lh, &sub, &shape, call, false, &st, &din, &dout);
+    {
+        std::lock_guard<std::mutex> lk(j->mu);
+        j->upload_turn = c + 1;
+        j->cv.notify_all();
+    }
+    if (rc == FCD_OK) rc = host_search(lh, st, &din, call, &dout);
     if (rc) return lane_fail(j, rc, lh->err);
 
     const size_t worst = header_bytes(n) + payload_bytes((uint64_t)n * (uint64_t)W, j->path_bytes, has_path, has_qual);
@@ -151,23 +171,30 @@ int issue_chunk(fcd_job *j, int c) {
     return FCD_OK;
 }
 
-void issuer_main(fcd_job *j) {
+void fail_from(fcd_job *j, int c) {  // (mutex held) chunk c and everything after it will never arrive
+    for (int k = c; k < j->n_chunks; ++k)
+        if (j->state[k] == 0) j->state[k] = 2;
+    j->cancel = true;  // the other lanes stop at their next chunk
+    j->cv.notify_all();
+}
+
+void lane_main(fcd_job *j, int lane) {
     (void)hipSetDevice(j->h->device);
-    for (int c = 0; c < j->n_chunks; ++c) {
+    for (int c = lane; c < j->n_chunks; c += j->n_lanes) {
         {
             std::unique_lock<std::mutex> lk(j->mu);
+            // the lane's buffers are free once the caller has moved on from chunk c - L
             j->cv.wait(lk, [&] { return j->cancel || c - j->n_lanes < j->released; });
             if (j->cancel) {
-                for (int k = c; k < j->n_chunks; ++k) j->state[k] = 2;
-                j->cv.notify_all();
+                fail_from(j, c);
                 return;
             }
         }
         const int rc = issue_chunk(j, c);
         std::lock_guard<std::mutex> lk(j->mu);
         if (rc != FCD_OK) {
-            for (int k = c; k < j->n_chunks; ++k) j->state[k] = 2;
-            j->cv.notify_all();
+            if (j->upload_turn <= c) j->upload_turn = c + 1;
+            fail_from(j, c);
             return;
         }
         j->state[c] = 1;
@@ -260,7 +287,7 @@ int job_begin(fcd_handle *h, const fcd_batch *in, const HostCall &call, int want
             delete j;
             return rc;
         }
-        j->issuer = std::thread(issuer_main, j);
+        for (int k = 0; k < j->n_lanes; ++k) j->workers.emplace_back(lane_main, j, k);
     }
     h->job_active = true;
     *out = j;
@@ -487,7 +514,8 @@ int fcd_job_end(fcd_job *j) {
         if (j->handed < j->n_chunks) j->cancel = true;
         j->cv.notify_all();
     }
-    if (j->issuer.joinable()) j->issuer.join();
+    for (std::thread &t : j->workers)
+        if (t.joinable()) t.join();
     fcd_handle *h = j->h;
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;

@@ -248,6 +248,318 @@ static void sp1_push(sp1vec *b, sp1 p) {
 DEFINE_STABLE_SORT(sp1_sort_node, sp1, SP1_NODE_LESS)
 DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
 
+
+/*
+ * Rust 1.78 core::slice::sort::quicksort -- what `sort_unstable_by` (src/search.rs:122,262, src/duplex.rs:620,807)
+ * runs above 20 elements -- restated FROM MEMORY of library/core/src/slice/sort.rs as of 1.78 (pattern-defeating
+ * quicksort: insertion sort up to 20, choose_pivot = median of three / Tukey ninther from 50 with swap counting
+ * and slice reversal at 12 swaps, partial_insertion_sort on likely-sorted slices, partition_equal against the
+ * predecessor pivot, BlockQuicksort partition_in_blocks with BLOCK = 128 and its cyclic block swaps,
+ * break_patterns with the xorshift generator seeded by the length, heapsort once the imbalance budget
+ * floor(log2 n) + 1 is spent).  UNVERIFIED: neither the Rust source nor a Rust toolchain exists in this
+ * environment, so this cannot be checked against the real thing; every sort it performs is a correct
+ * descending sort, only the order of EQUAL keys is at stake.  It exists to MEASURE how much that order could
+ * matter (fcdo_set_unstable_sort, tools/pdqsort_ties.py): the default of the oracle and
+ * the rule of the kernels stays "ties keep ascending node order".
+ */
+static int g_unstable_sort_mode = 0; /* 0 = stable rule (default), 1 = the pdqsort restatement above */
+void fcdo_set_unstable_sort(int mode) { g_unstable_sort_mode = mode ? 1 : 0; }
+int fcdo_get_unstable_sort(void) { return g_unstable_sort_mode; }
+
+#define DEFINE_PDQSORT(NAME, TYPE, LESS)                                                                      \
+    static void NAME##_swap(TYPE *a, TYPE *b) {                                                               \
+        TYPE t = *a;                                                                                          \
+        *a = *b;                                                                                              \
+        *b = t;                                                                                               \
+    }                                                                                                         \
+    /* insert_tail: v[n-1] into the sorted v[..n-1] */                                                        \
+    static void NAME##_insert_tail(TYPE *v, int64_t n) {                                                      \
+        if (n >= 2 && LESS(&v[n - 1], &v[n - 2])) {                                                           \
+            TYPE tmp = v[n - 1];                                                                              \
+            v[n - 1] = v[n - 2];                                                                              \
+            int64_t hole = n - 2;                                                                             \
+            for (int64_t j = n - 3; j >= 0; --j) {                                                            \
+                if (!LESS(&tmp, &v[j])) break;                                                                \
+                v[j + 1] = v[j];                                                                              \
+                hole = j;                                                                                     \
+            }                                                                                                 \
+            v[hole] = tmp;                                                                                    \
+        }                                                                                                     \
+    }                                                                                                         \
+    /* insert_head: v[0] into the sorted v[1..] */                                                            \
+    static void NAME##_insert_head(TYPE *v, int64_t n) {                                                      \
+        if (n >= 2 && LESS(&v[1], &v[0])) {                                                                   \
+            TYPE tmp = v[0];                                                                                  \
+            v[0] = v[1];                                                                                      \
+            int64_t hole = 1;                                                                                 \
+            for (int64_t i = 2; i < n; ++i) {                                                                 \
+                if (!LESS(&v[i], &tmp)) break;                                                                \
+                v[i - 1] = v[i];                                                                              \
+                hole = i;                                                                                     \
+            }                                                                                                 \
+            v[hole] = tmp;                                                                                    \
+        }                                                                                                     \
+    }                                                                                                         \
+    static void NAME##_shift_left(TYPE *v, int64_t len, int64_t offset) {                                     \
+        for (int64_t i = offset; i < len; ++i) NAME##_insert_tail(v, i + 1);                                  \
+    }                                                                                                         \
+    static void NAME##_shift_right(TYPE *v, int64_t len, int64_t offset) {                                    \
+        for (int64_t i = offset - 1; i >= 0; --i) NAME##_insert_head(v + i, len - i);                         \
+    }                                                                                                         \
+    static int NAME##_partial_insertion_sort(TYPE *v, int64_t len) {                                          \
+        const int64_t MAX_STEPS = 5, SHORTEST_SHIFTING = 50;                                                  \
+        int64_t i = 1;                                                                                        \
+        for (int64_t step = 0; step < MAX_STEPS; ++step) {                                                    \
+            while (i < len && !LESS(&v[i], &v[i - 1])) ++i;                                                   \
+            if (i == len) return 1;                                                                           \
+            if (len < SHORTEST_SHIFTING) return 0;                                                            \
+            NAME##_swap(&v[i - 1], &v[i]);                                                                    \
+            if (i >= 2) {                                                                                     \
+                NAME##_shift_left(v, i, i - 1);  /* the smaller element to the left */                        \
+                NAME##_shift_right(v, i, 1);     /* (1.78 passes v[..i] here too) */                          \
+            }                                                                                                 \
+        }                                                                                                     \
+        return 0;                                                                                             \
+    }                                                                                                         \
+    static void NAME##_heapsort_sift(TYPE *v, int64_t len, int64_t node) {                                    \
+        for (;;) {                                                                                            \
+            int64_t child = 2 * node + 1;                                                                     \
+            if (child >= len) break;                                                                          \
+            if (child + 1 < len) child += LESS(&v[child], &v[child + 1]) ? 1 : 0;                             \
+            if (!LESS(&v[node], &v[child])) break;                                                            \
+            NAME##_swap(&v[node], &v[child]);                                                                 \
+            node = child;                                                                                     \
+        }                                                                                                     \
+    }                                                                                                         \
+    static void NAME##_heapsort(TYPE *v, int64_t len) {                                                       \
+        for (int64_t i = len / 2 - 1; i >= 0; --i) NAME##_heapsort_sift(v, len, i);                           \
+        for (int64_t i = len - 1; i >= 1; --i) {                                                              \
+            NAME##_swap(&v[0], &v[i]);                                                                        \
+            NAME##_heapsort_sift(v, i, 0);                                                                    \
+        }                                                                                                     \
+    }                                                                                                         \
+    static void NAME##_break_patterns(TYPE *v, int64_t len) {                                                 \
+        if (len < 8) return;                                                                                  \
+        uint64_t seed = (uint64_t)len;                                                                        \
+        uint64_t modulus = 1;                                                                                 \
+        while (modulus < (uint64_t)len) modulus <<= 1; /* next_power_of_two */                                \
+        int64_t pos = len / 4 * 2;                                                                            \
+        for (int64_t i = 0; i < 3; ++i) {                                                                     \
+            seed ^= seed << 13;                                                                               \
+            seed ^= seed >> 7;                                                                                \
+            seed ^= seed << 17;                                                                               \
+            uint64_t other = seed & (modulus - 1);                                                            \
+            if (other >= (uint64_t)len) other -= (uint64_t)len;                                               \
+            NAME##_swap(&v[pos - 1 + i], &v[other]);                                                          \
+        }                                                                                                     \
+    }                                                                                                         \
+    static void NAME##_sort2(const TYPE *v, int64_t *a, int64_t *b, int *swaps) {                             \
+        if (LESS(&v[*b], &v[*a])) {                                                                           \
+            int64_t t = *a;                                                                                   \
+            *a = *b;                                                                                          \
+            *b = t;                                                                                           \
+            ++*swaps;                                                                                         \
+        }                                                                                                     \
+    }                                                                                                         \
+    static void NAME##_sort3(const TYPE *v, int64_t *a, int64_t *b, int64_t *c, int *swaps) {                 \
+        NAME##_sort2(v, a, b, swaps);                                                                         \
+        NAME##_sort2(v, b, c, swaps);                                                                         \
+        NAME##_sort2(v, a, b, swaps);                                                                         \
+    }                                                                                                         \
+    static int64_t NAME##_choose_pivot(TYPE *v, int64_t len, int *likely_sorted) {                            \
+        const int64_t SHORTEST_MEDIAN_OF_MEDIANS = 50;                                                        \
+        const int MAX_SWAPS = 4 * 3;                                                                          \
+        int64_t a = len / 4 * 1, b = len / 4 * 2, c = len / 4 * 3;                                            \
+        int swaps = 0;                                                                                        \
+        if (len >= 8) {                                                                                       \
+            if (len >= SHORTEST_MEDIAN_OF_MEDIANS) {                                                          \
+                int64_t lo, hi;                                                                               \
+                lo = a - 1, hi = a + 1;                                                                       \
+                NAME##_sort3(v, &lo, &a, &hi, &swaps);                                                        \
+                lo = b - 1, hi = b + 1;                                                                       \
+                NAME##_sort3(v, &lo, &b, &hi, &swaps);                                                        \
+                lo = c - 1, hi = c + 1;                                                                       \
+                NAME##_sort3(v, &lo, &c, &hi, &swaps);                                                        \
+            }                                                                                                 \
+            NAME##_sort3(v, &a, &b, &c, &swaps);                                                              \
+        }                                                                                                     \
+        if (swaps < MAX_SWAPS) {                                                                              \
+            *likely_sorted = swaps == 0;                                                                      \
+            return b;                                                                                         \
+        }                                                                                                     \
+        for (int64_t i = 0; i < len / 2; ++i) NAME##_swap(&v[i], &v[len - 1 - i]); /* v.reverse() */          \
+        *likely_sorted = 1;                                                                                   \
+        return len - 1 - b;                                                                                   \
+    }                                                                                                         \
+    static int64_t NAME##_partition_in_blocks(TYPE *v, int64_t n, const TYPE *pivot) {                        \
+        enum { BLOCK = 128 };                                                                                 \
+        int64_t l = 0, block_l = BLOCK, r = n, block_r = BLOCK;                                               \
+        int sl = 0, el = 0, sr = 0, er = 0;                                                                   \
+        uint8_t offl[BLOCK], offr[BLOCK];                                                                     \
+        for (;;) {                                                                                            \
+            const int is_done = (r - l) <= 2 * BLOCK;                                                         \
+            if (is_done) {                                                                                    \
+                int64_t rem = r - l;                                                                          \
+                if (sl < el || sr < er) rem -= BLOCK;                                                         \
+                if (sl < el) {                                                                                \
+                    block_r = rem;                                                                            \
+                } else if (sr < er) {                                                                         \
+                    block_l = rem;                                                                            \
+                } else {                                                                                      \
+                    block_l = rem / 2;                                                                        \
+                    block_r = rem - block_l;                                                                  \
+                }                                                                                             \
+            }                                                                                                 \
+            if (sl == el) { /* trace block_l elements from the left */                                        \
+                sl = el = 0;                                                                                  \
+                for (int64_t i = 0; i < block_l; ++i) {                                                       \
+                    offl[el] = (uint8_t)i;                                                                    \
+                    el += LESS(&v[l + i], pivot) ? 0 : 1;                                                     \
+                }                                                                                             \
+            }                                                                                                 \
+            if (sr == er) { /* trace block_r elements from the right */                                       \
+                sr = er = 0;                                                                                  \
+                for (int64_t i = 0; i < block_r; ++i) {                                                       \
+                    offr[er] = (uint8_t)i;                                                                    \
+                    er += LESS(&v[r - 1 - i], pivot) ? 1 : 0;                                                 \
+                }                                                                                             \
+            }                                                                                                 \
+            const int count = (el - sl) < (er - sr) ? (el - sl) : (er - sr);                                  \
+            if (count > 0) { /* one cyclic permutation instead of `count` swaps */                            \
+                TYPE tmp = v[l + offl[sl]];                                                                   \
+                v[l + offl[sl]] = v[r - offr[sr] - 1];                                                        \
+                for (int k = 1; k < count; ++k) {                                                             \
+                    ++sl;                                                                                     \
+                    v[r - offr[sr] - 1] = v[l + offl[sl]];                                                    \
+                    ++sr;                                                                                     \
+                    v[l + offl[sl]] = v[r - offr[sr] - 1];                                                    \
+                }                                                                                             \
+                v[r - offr[sr] - 1] = tmp;                                                                    \
+                ++sl;                                                                                         \
+                ++sr;                                                                                         \
+            }                                                                                                 \
+            if (sl == el) l += block_l;                                                                       \
+            if (sr == er) r -= block_r;                                                                       \
+            if (is_done) break;                                                                               \
+        }                                                                                                     \
+        if (sl < el) {                                                                                        \
+            while (sl < el) {                                                                                 \
+                --el;                                                                                         \
+                NAME##_swap(&v[l + offl[el]], &v[r - 1]);                                                     \
+                --r;                                                                                          \
+            }                                                                                                 \
+            return r;                                                                                         \
+        } else if (sr < er) {                                                                                 \
+            while (sr < er) {                                                                                 \
+                --er;                                                                                         \
+                NAME##_swap(&v[l], &v[r - offr[er] - 1]);                                                     \
+                ++l;                                                                                          \
+            }                                                                                                 \
+            return l;                                                                                         \
+        }                                                                                                     \
+        return l;                                                                                             \
+    }                                                                                                         \
+    static int64_t NAME##_partition(TYPE *v, int64_t len, int64_t pivot_idx, int *was_partitioned) {          \
+        NAME##_swap(&v[0], &v[pivot_idx]);                                                                    \
+        const TYPE pivot = v[0];                                                                              \
+        TYPE *w = v + 1;                                                                                      \
+        int64_t l = 0, r = len - 1;                                                                           \
+        while (l < r && LESS(&w[l], &pivot)) ++l;                                                             \
+        while (l < r && !LESS(&w[r - 1], &pivot)) --r;                                                        \
+        const int64_t mid = l + NAME##_partition_in_blocks(w + l, r - l, &pivot);                             \
+        *was_partitioned = l >= r;                                                                            \
+        NAME##_swap(&v[0], &v[mid]);                                                                          \
+        return mid;                                                                                           \
+    }                                                                                                         \
+    static int64_t NAME##_partition_equal(TYPE *v, int64_t len, int64_t pivot_idx) {                          \
+        NAME##_swap(&v[0], &v[pivot_idx]);                                                                    \
+        const TYPE pivot = v[0];                                                                              \
+        TYPE *w = v + 1;                                                                                      \
+        const int64_t wn = len - 1;                                                                           \
+        if (wn == 0) return 0;                                                                                \
+        int64_t l = 0, r = wn;                                                                                \
+        for (;;) {                                                                                            \
+            while (l < r && !LESS(&pivot, &w[l])) ++l;                                                        \
+            for (;;) {                                                                                        \
+                --r;                                                                                          \
+                if (l >= r || !LESS(&pivot, &w[r])) break;                                                    \
+            }                                                                                                 \
+            if (l >= r) break;                                                                                \
+            NAME##_swap(&w[l], &w[r]);                                                                        \
+            ++l;                                                                                              \
+        }                                                                                                     \
+        return l + 1;                                                                                         \
+    }                                                                                                         \
+    static void NAME##_recurse(TYPE *v, int64_t len, const TYPE *pred, uint32_t limit) {                      \
+        const int64_t MAX_INSERTION = 20;                                                                     \
+        int was_balanced = 1, was_partitioned = 1;                                                            \
+        for (;;) {                                                                                            \
+            if (len <= MAX_INSERTION) {                                                                       \
+                if (len >= 2) NAME##_shift_left(v, len, 1);                                                   \
+                return;                                                                                       \
+            }                                                                                                 \
+            if (limit == 0) {                                                                                 \
+                NAME##_heapsort(v, len);                                                                      \
+                return;                                                                                       \
+            }                                                                                                 \
+            if (!was_balanced) {                                                                              \
+                NAME##_break_patterns(v, len);                                                                \
+                --limit;                                                                                      \
+            }                                                                                                 \
+            int likely_sorted = 0;                                                                            \
+            const int64_t pivot = NAME##_choose_pivot(v, len, &likely_sorted);                                \
+            if (was_balanced && was_partitioned && likely_sorted) {                                           \
+                if (NAME##_partial_insertion_sort(v, len)) return;                                            \
+            }                                                                                                 \
+            if (pred && !LESS(pred, &v[pivot])) {                                                             \
+                const int64_t mid = NAME##_partition_equal(v, len, pivot);                                    \
+                v += mid;                                                                                     \
+                len -= mid;                                                                                   \
+                continue;                                                                                     \
+            }                                                                                                 \
+            int was_p = 0;                                                                                    \
+            const int64_t mid = NAME##_partition(v, len, pivot, &was_p);                                      \
+            const int64_t smaller = mid < len - mid ? mid : len - mid;                                        \
+            was_balanced = smaller >= len / 8;                                                                \
+            was_partitioned = was_p;                                                                          \
+            TYPE *left = v, *pv = v + mid, *right = v + mid + 1;                                              \
+            const int64_t nl = mid, nr = len - mid - 1;                                                       \
+            if (nl < nr) {                                                                                    \
+                NAME##_recurse(left, nl, pred, limit);                                                        \
+                v = right;                                                                                    \
+                len = nr;                                                                                     \
+                pred = pv;                                                                                    \
+            } else {                                                                                          \
+                NAME##_recurse(right, nr, pv, limit);                                                         \
+                v = left;                                                                                     \
+                len = nl;                                                                                     \
+            }                                                                                                 \
+        }                                                                                                     \
+    }                                                                                                         \
+    static void NAME(TYPE *v, int64_t len) {                                                                  \
+        uint32_t limit = 0; /* usize::BITS - len.leading_zeros() = floor(log2 len) + 1 */                     \
+        for (uint64_t n = (uint64_t)len; n; n >>= 1) ++limit;                                                 \
+        NAME##_recurse(v, len, NULL, limit);                                                                  \
+    }
+
+DEFINE_PDQSORT(sp1_pdq_prob, sp1, SP1_PROB_GREATER)
+
+/* Test hook: sorts n (probability, node) pairs by descending probability with the pdqsort restatement;
+ * `node` rides along so that the order of equal probabilities can be inspected. */
+void fcdo_test_pdqsort(float *prob, int32_t *node, int64_t n) {
+    sp1 *v = (sp1 *)malloc(sizeof(sp1) * (n > 0 ? n : 1));
+    for (int64_t i = 0; i < n; ++i) {
+        sp1 e = {node[i], 0, prob[i], 0.0f};
+        v[i] = e;
+    }
+    sp1_pdq_prob(v, n);
+    for (int64_t i = 0; i < n; ++i) {
+        prob[i] = v[i].label_prob;
+        node[i] = v[i].node;
+    }
+    free(v);
+}
+
 /*
  * Shared tail of every 1D step: :245-282 (== :105-142).  Returns FCDO_* status.
  */
@@ -324,6 +636,14 @@ static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *
             if (p != p) return FCDO_INCOMPARABLE;
         }
     }
+    sp1 *stable_copy = NULL;
+    if (g_unstable_sort_mode == 1 && beam->len > 20) {
+        /* the counters below are defined on the stably sorted list: take them there, then impose the order of
+         * the pdqsort restatement (same multiset of probabilities, possibly another order of equal ones) */
+        stable_copy = (sp1 *)malloc(sizeof(sp1) * beam->len);
+        memcpy(stable_copy, beam->v, sizeof(sp1) * beam->len);
+        sp1_pdq_prob(stable_copy, beam->len);
+    }
     sp1_sort_prob(beam->v, beam->len, tmp, tmpcap);
     if (n_amb) {
         /* sorted: equal probabilities are adjacent.  n_amb[0]: > 20 candidates and a kept candidate ties
@@ -338,6 +658,10 @@ static int sp1_merge_prune(sp1vec *beam, int64_t beam_size, sp1 **tmp, int64_t *
         int crit = beam->len >= 2 && sp1_prob(&beam->v[0]) == sp1_prob(&beam->v[1]);
         crit |= beam->len > beam_size && sp1_prob(&beam->v[beam_size - 1]) == sp1_prob(&beam->v[beam_size]);
         if (crit) ++n_amb[1];
+    }
+    if (stable_copy) {
+        memcpy(beam->v, stable_copy, sizeof(sp1) * beam->len);
+        free(stable_copy);
     }
     if (tc && beam->len > beam_size &&
         sp1_prob(&beam->v[beam_size - 1]) == sp1_prob(&beam->v[beam_size])) {
@@ -914,6 +1238,7 @@ typedef struct {
 #define SP2K_PROB_GREATER(a, b) ((a)->prob > (b)->prob)
 DEFINE_STABLE_SORT(sp2_sort_node, sp2, SP2_NODE_LESS)
 DEFINE_STABLE_SORT(sp2k_sort_prob, sp2k, SP2K_PROB_GREATER)
+DEFINE_PDQSORT(sp2k_pdq_prob, sp2k, SP2K_PROB_GREATER)
 
 typedef struct {
     secprobs *v;
@@ -1121,6 +1446,12 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
             status = FCDO_INCOMPARABLE;
             break;
         }
+        sp2k *pdq_copy = NULL;
+        if (g_unstable_sort_mode == 1 && beam.len > 20) { /* see sp1_merge_prune */
+            pdq_copy = (sp2k *)malloc(sizeof(sp2k) * beam.len);
+            memcpy(pdq_copy, keyed, sizeof(sp2k) * beam.len);
+            sp2k_pdq_prob(pdq_copy, beam.len);
+        }
         sp2k_sort_prob(keyed, beam.len, &ktmp, &ktmpcap);
         { /* tie statistics (fcdo_duplex_tie_steps): :620 / :807 is sort_unstable_by, i.e. the order of EQUAL
            * probabilities is Rust's pdqsort's above 20 candidates; this restatement keeps node order */
@@ -1135,6 +1466,10 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
             if (n > 20 && tie) g_duplex_ties[1] += 1;               /* > 20 candidates and a kept one tied */
             if (boundary) g_duplex_ties[2] += 1;                    /* a tie across the truncation boundary */
             if (t1 + 1 == n1->T && n >= 2 && keyed[0].prob == keyed[1].prob) g_duplex_ties[3] += 1; /* a tie for the answer */
+        }
+        if (pdq_copy) {
+            memcpy(keyed, pdq_copy, sizeof(sp2k) * beam.len);
+            free(pdq_copy);
         }
         if (beam.len > beam_size) beam.len = beam_size; /* :632 */
         if (beam.len == 0) {                            /* :633-636 */

@@ -188,6 +188,15 @@ void fcdo_duplex_tie_steps(int64_t out[4], int reset);
 /* out[i] = fcdo_logspace_add(a[i], b[i], logadd_mode) -- lets tests compare millions of operands */
 void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int logadd_mode);
 
+/* Order of EQUAL probabilities in the prune of the beam searches (src/search.rs:122,262, src/duplex.rs:620,807:
+ * sort_unstable_by).  0 (default): the stable rule -- what Rust's insertion sort does up to 20 candidates, and
+ * what the kernels implement.  1: above 20 candidates, the order left by a restatement of Rust 1.78's pdqsort
+ * written from memory (UNVERIFIED: no Rust source or toolchain here; see fcd_oracle.c).  Process-wide switch for
+ * measurements (tools/pdqsort_ties.py); the tie counters are taken on the stably sorted list in both modes. */
+void fcdo_set_unstable_sort(int mode);
+int fcdo_get_unstable_sort(void);
+void fcdo_test_pdqsort(float *prob, int32_t *node, int64_t n);
+
 #ifdef __cplusplus
 }
 #endif

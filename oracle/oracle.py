@@ -80,6 +80,11 @@ def _load():
     lib.fcdo_duplex_tie_steps.argtypes = [C.POINTER(i64), i32]
     lib.fcdo_duplex_tie_steps.restype = None
     lib.fcdo_logadd_calls.restype = i64
+    lib.fcdo_set_unstable_sort.argtypes = [i32]
+    lib.fcdo_set_unstable_sort.restype = None
+    lib.fcdo_get_unstable_sort.restype = i32
+    lib.fcdo_test_pdqsort.argtypes = [P, P, i64]
+    lib.fcdo_test_pdqsort.restype = None
     return lib
 
 
@@ -395,3 +400,27 @@ def duplex_tie_steps(reset=False):
     out = (C.c_int64 * 4)()
     lib.fcdo_duplex_tie_steps(out, 1 if reset else 0)
     return {"steps": out[0], "gt20_kept_tie": out[1], "boundary_tie": out[2], "final_top_tie": out[3]}
+
+
+class unstable_sort:
+    """with unstable_sort("pdqsort"): the beam searches order EQUAL probabilities above 20 candidates the way the
+    oracle's restatement of Rust 1.78's pdqsort leaves them (UNVERIFIED, fcd_oracle.c); default "stable"."""
+
+    def __init__(self, mode):
+        self.mode = {"stable": 0, "pdqsort": 1}[mode]
+
+    def __enter__(self):
+        self.prev = lib.fcdo_get_unstable_sort()
+        lib.fcdo_set_unstable_sort(self.mode)
+
+    def __exit__(self, *exc):
+        lib.fcdo_set_unstable_sort(self.prev)
+        return False
+
+
+def pdqsort_desc(prob, node):
+    """(test hook) -> (prob, node) sorted by descending prob with the pdqsort restatement"""
+    p = np.ascontiguousarray(prob, np.float32).copy()
+    n = np.ascontiguousarray(node, np.int32).copy()
+    lib.fcdo_test_pdqsort(_ptr(p), _ptr(n), len(p))
+    return p, n
