@@ -22,7 +22,7 @@ LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
-    "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor",
+    "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
     "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k", "fcd_crf_beam_search_host",
@@ -117,6 +117,7 @@ def bind(lib):
     lib.fcd_set_workspace_limit.argtypes = [P, i64]
     lib.fcd_release_workspace.argtypes = [P]
     lib.fcd_debug_set_first_pass_divisor.argtypes = [P, i32]
+    lib.fcd_debug_set_duplex_profile.argtypes = [P, P]
     lib.fcd_last_kernel_ms.argtypes = [P]
     lib.fcd_last_kernel_ms.restype = C.c_double
     lib.fcd_timing_reset.argtypes = [P]

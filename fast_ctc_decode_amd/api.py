@@ -367,8 +367,9 @@ def _default_envelope(B, T1, T2, lengths_2=None):
 
 def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes=None, beam_size=5,
                                  beam_cut_threshold=0.0, collapse_repeats=True, lengths_1=None,
-                                 lengths_2=None, logadd_mode=None):
-    """(B,T1,N) and (B,T2,N) posteriors + (B,T1,2) uint64 envelopes -> BatchResult (labels only)."""
+                                 lengths_2=None, logadd_mode=None, count_ambiguous=False):
+    """(B,T1,N) and (B,T2,N) posteriors + (B,T1,2) uint64 envelopes -> BatchResult (labels only).
+    `count_ambiguous`: also fill BatchResult.ambiguous, the tie counters of the prune (include/fcd.h)."""
     mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
     if _is_torch_cuda(network_outputs_1):
         import torch
@@ -405,13 +406,15 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
         labels = torch.empty((B, w), dtype=torch.uint8, device=dev)
         out_len = torch.zeros(B, dtype=torch.int32, device=dev)
         status = torch.zeros(B, dtype=torch.int32, device=dev)
-        res = nat.Result(labels.data_ptr(), None, None, out_len.data_ptr(), status.data_ptr(), w)
+        amb = torch.zeros((B, 2), dtype=torch.int32, device=dev) if count_ambiguous else None
+        res = nat.Result(labels.data_ptr(), None, None, out_len.data_ptr(), status.data_ptr(), w,
+                         amb.data_ptr() if count_ambiguous else None)
         h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         h.check(h.lib.fcd_beam_search_duplex_dev(
             h.ptr, C.byref(b1), C.byref(b2), C.c_void_p(env.data_ptr()), int(env.shape[1]),
             int(beam_size), float(beam_cut_threshold), int(bool(collapse_repeats)), int(mode),
             C.byref(res)))
-        r = BatchResult(labels, None, out_len, status)
+        r = BatchResult(labels, None, out_len, status, ambiguous=amb)
         r._handle, r._keep = h, keep
         return r
     x1 = _stack_host(network_outputs_1, 3)
@@ -424,13 +427,13 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
     if env.shape[0] != B or env.ndim != 3 or env.shape[2] != 2 or env.shape[1] < T1:
         raise ValueError("envelopes must have shape (n_pairs, T1, 2)")
     h = nat.default_handle()
-    out = _HostOut(B, T1, want_path=False)
+    out = _HostOut(B, T1, want_path=False, want_amb=count_ambiguous)
     l1, l2 = _np_lengths(lengths_1, B), _np_lengths(lengths_2, B)
     b1, b2 = _host_batch(x1, False, l1), _host_batch(x2, False, l2)
     h.check(h.lib.fcd_beam_search_duplex_host(
         h.ptr, C.byref(b1), C.byref(b2), env.ctypes.data, int(env.shape[1]), int(beam_size),
         float(beam_cut_threshold), int(bool(collapse_repeats)), int(mode), C.byref(out.res)))
-    r = BatchResult(out.labels, None, out.out_len, out.status)
+    r = BatchResult(out.labels, None, out.out_len, out.status, ambiguous=out.ambiguous)
     r._handle = h
     return r
 
@@ -540,7 +543,7 @@ def estimate_envelope(network_output_1, network_output_2, band=64):
 def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_outputs_2,
                                      init_states_2, envelopes=None, beam_size=5,
                                      beam_cut_threshold=0.0, lengths_1=None, lengths_2=None,
-                                     logadd_mode=None):
+                                     logadd_mode=None, count_ambiguous=False):
     """(B,T1,S,N) / (B,T2,S,N) posteriors (numpy, or torch ROCm tensors: zero-copy), (B,n_init)
     initial state scores, (B,T1,2) uint64 envelopes -> BatchResult (labels only)."""
     mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
@@ -583,13 +586,15 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
         labels = torch.empty((B, w), dtype=torch.uint8, device=dev)
         out_len = torch.zeros(B, dtype=torch.int32, device=dev)
         status = torch.zeros(B, dtype=torch.int32, device=dev)
-        res = nat.Result(labels.data_ptr(), None, None, out_len.data_ptr(), status.data_ptr(), w)
+        amb = torch.zeros((B, 2), dtype=torch.int32, device=dev) if count_ambiguous else None
+        res = nat.Result(labels.data_ptr(), None, None, out_len.data_ptr(), status.data_ptr(), w,
+                         amb.data_ptr() if count_ambiguous else None)
         h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
         h.check(h.lib.fcd_crf_beam_search_duplex_dev(
             h.ptr, C.byref(b1), C.c_void_p(i1.data_ptr()), int(i1.shape[1]), int(i1.shape[1]), C.byref(b2),
             C.c_void_p(i2.data_ptr()), int(i2.shape[1]), int(i2.shape[1]), C.c_void_p(env.data_ptr()),
             int(env.shape[1]), int(beam_size), float(beam_cut_threshold), int(mode), C.byref(res)))
-        r = BatchResult(labels, None, out_len, status)
+        r = BatchResult(labels, None, out_len, status, ambiguous=amb)
         r._handle, r._keep = h, keep
         return r
     x1 = _stack_host(network_outputs_1, 4)
@@ -604,14 +609,14 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
     if env.shape[0] != B or env.ndim != 3 or env.shape[2] != 2 or env.shape[1] < T1:
         raise ValueError("envelopes must have shape (n_pairs, T1, 2)")
     h = nat.default_handle()
-    out = _HostOut(B, T1, want_path=False)
+    out = _HostOut(B, T1, want_path=False, want_amb=count_ambiguous)
     l1, l2 = _np_lengths(lengths_1, B), _np_lengths(lengths_2, B)
     b1, b2 = _host_batch(x1, True, l1), _host_batch(x2, True, l2)
     h.check(h.lib.fcd_crf_beam_search_duplex_host(
         h.ptr, C.byref(b1), i1.ctypes.data, int(i1.shape[1]), int(i1.shape[1]), C.byref(b2),
         i2.ctypes.data, int(i2.shape[1]), int(i2.shape[1]), env.ctypes.data, int(env.shape[1]),
         int(beam_size), float(beam_cut_threshold), int(mode), C.byref(out.res)))
-    r = BatchResult(out.labels, None, out.out_len, out.status)
+    r = BatchResult(out.labels, None, out.out_len, out.status, ambiguous=out.ambiguous)
     r._handle = h
     return r
 

@@ -411,6 +411,13 @@ int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor) {
     return FCD_OK;
 }
 
+int fcd_debug_set_duplex_profile(fcd_handle *h, uint32_t *cycles) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    h->duplex_prof = cycles;
+    return FCD_OK;
+}
+
 double fcd_last_kernel_ms(fcd_handle *h) {
     if (!h) return -1.0;
     std::lock_guard<std::recursive_mutex> g(h->mu);
@@ -627,6 +634,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     // tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
     a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S) <= 48 * 1024 ? 1 : 0;
     a.out = to_desc(out);
+    a.prof = h->duplex_prof;
     for (int64_t begin = 0; begin < B; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, B - begin);
         FCD_HIP(h, launch_duplex(a, begin, n, h->stream));
@@ -682,6 +690,7 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
     const int64_t B = in1->n_reads;
     if (B == 0) return FCD_OK;
     if (!out->labels || !out->out_len || !out->status) return fail(h, FCD_E_INVALID, "null output array");
+    FCD_DEVICE(h);  // staging, search and copy-back all run on the handle's device
     const size_t e1 = (size_t)span_elems(in1, is_crf), e2 = (size_t)span_elems(in2, is_crf);
     const size_t n_env = (size_t)B * (size_t)env_stride * 2;
     const size_t n_out = (size_t)B * (size_t)out->out_stride;
@@ -698,9 +707,9 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
     const size_t ol2 = reserve(in2->lengths ? (size_t)B * 8 : 0);
     const size_t oi1 = reserve(ni1 * 4), oi2 = reserve(ni2 * 4);
     const size_t olab = reserve(n_out), oolen = reserve((size_t)B * 4), ostat = reserve((size_t)B * 4);
+    const size_t oamb = reserve(out->ambiguous ? (size_t)B * 8 : 0);
     {
         std::lock_guard<std::recursive_mutex> g(h->mu);
-        FCD_DEVICE(h);
         int rc = ensure(h, &h->stage, &h->stage_bytes, used);
         if (rc) return rc;
         char *base = reinterpret_cast<char *>(h->stage);
@@ -727,6 +736,7 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
     dout.out_len = reinterpret_cast<uint32_t *>(base + oolen);
     dout.status = reinterpret_cast<int32_t *>(base + ostat);
     dout.out_stride = out->out_stride;
+    dout.ambiguous = out->ambiguous ? reinterpret_cast<uint32_t *>(base + oamb) : nullptr;
     CrfInit dc;
     if (is_crf) {
         dc = *crf;
@@ -740,6 +750,8 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
     FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
+    if (out->ambiguous)
+        FCD_HIP(h, hipMemcpyAsync(out->ambiguous, dout.ambiguous, (size_t)B * 8, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
 }

@@ -61,6 +61,7 @@ struct DuplexParams {
     int staged;      // 1: the step's read-2 window and the beam's forward windows are tiled in LDS
     ResultDesc out;
     int64_t pair_begin;
+    uint32_t *prof;  // developer instrument (fcd_debug_set_duplex_profile): [pair][8] shader cycles per phase, nullable
 };
 
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -255,10 +256,18 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
     float *rootgap = p.rootgap + local * (p.T2cap + 1);
     uint8_t *lab_out = p.out.labels + r * p.out.out_stride;
 
+    // tie instrument (fcd_result.ambiguous; the counters of the 1D kernels, include/fcd.h): the prune below is the
+    // reference's sort_unstable_by (:620,:807), whose order of EQUAL probabilities above 20 candidates is pdqsort's
+    const bool count_amb = p.out.ambiguous != nullptr;
+    int n_amb = 0, n_crit = 0;
     auto fail = [&](int code) {
         if (lane == 0) {
             p.out.status[r] = code;
             p.out.out_len[r] = 0;
+            if (count_amb) {
+                p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+                p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+            }
         }
     };
 
@@ -309,6 +318,19 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
 
     int cur = 0, B = 1, nn = 0;
     int last_hi = 0;
+    // cycle account (p.prof): 0 envelope + vector extension, 1 LDS tiles, 2 expansion without the window builds,
+    // 3 window builds of the new nodes, 4 rank + next beam, 5 build-loop iterations, 6 new nodes, 7 steps
+    const bool prof = p.prof != nullptr;
+    uint64_t acc[5] = {0, 0, 0, 0, 0}, t_prev = 0, t_now = 0;
+    uint32_t n_iter = 0, n_newnodes = 0;
+    int stamp_dep = 0;
+    if (prof) FCD_STAMP(t_prev, stamp_dep);
+#define FCD_DUPLEX_PHASE(k)                  \
+    if (prof) {                              \
+        FCD_STAMP(t_now, stamp_dep);         \
+        acc[k] += t_now - t_prev;            \
+        t_prev = t_now;                      \
+    }
 
     auto node_vec = [&](int node, int off, int end) {
         VecRef v;
@@ -501,6 +523,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             }
         }
         last_hi = hi;
+        FCD_DUPLEX_PHASE(0)
 
         const int W = hi - lo;
         if (staged) {
@@ -531,6 +554,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             __syncthreads();
         }
 
+        FCD_DUPLEX_PHASE(1)
         int *b_node = L.b_node(cur), *b_tip = L.b_tip(cur), *b_par = L.b_par(cur);
         int *b_child = L.b_child(cur);
         int *b_state = L.b_state(cur);
@@ -606,6 +630,11 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 }
             }
             const uint64_t m_new = ballot(is_new);
+            FCD_DUPLEX_PHASE(2)
+            if (prof) {
+                n_newnodes += (uint32_t)popc64(m_new);
+                n_iter += (uint32_t)(hi - lo + 1) * (uint32_t)((popc64(m_new) + 31) / 32);
+            }
             if (MODE == FCD_LOGADD_MAX) {
             // max-product mode has no transcendental in the recurrence: one lane per new node
             if (is_new) {
@@ -815,6 +844,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             __syncthreads();
             }
             nn += popc64(m_new);
+            FCD_DUPLEX_PHASE(3)
             const float prob = ladd<MODE>(clp, cgp) + p2;  // :146-148
             if (act) {
                 L.c_lp[c] = clp;
@@ -826,6 +856,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             n_valid += popc64(__ballot(valid));
             any_nan = any_nan || (__ballot(valid && prob != prob) != 0ull);
         }
+        FCD_DUPLEX_PHASE(2)
         if (nn > p.cap_nodes) return fail(FCD_ST_INTERNAL);
         if (n_valid >= 2 && any_nan) return fail(FCD_ST_INCOMPARABLE);  // :619-631
         if (n_valid == 0) return fail(FCD_ST_RAN_OUT_OF_BEAM);          // :633-636
@@ -834,6 +865,30 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         // ---- rank and build the next beam (no renormalisation in log space) ----
         const int nxt = cur ^ 1;
         const int Bn = n_valid < BC ? n_valid : BC;
+        if (count_amb) {
+            // candidates with one probability occupy ranks [gt, gt + eq): a kept one is tied when gt < BC and
+            // eq >= 2; the tie can change the kept set or the best entry when the group holds rank 0 or straddles
+            // the truncation boundary
+            bool kept_tie = false, crit = false;
+            for (int base = 0; base < nslots; base += kWave) {
+                const int c = base + lane;
+                const uint64_t key = c < nslots ? L.c_key[c] : 0ull;
+                if (key == 0ull) continue;
+                const uint32_t ph = (uint32_t)(key >> 32);
+                int gt = 0, eq = 0;
+                for (int j = 0; j < nslots; ++j) {
+                    const uint64_t kj = L.c_key[j];
+                    if (kj == 0ull) continue;
+                    const uint32_t pj = (uint32_t)(kj >> 32);
+                    gt += pj > ph ? 1 : 0;
+                    eq += pj == ph ? 1 : 0;
+                }
+                kept_tie = kept_tie || (gt < BC && eq >= 2);
+                crit = crit || (eq >= 2 && (gt == 0 || (gt < BC && gt + eq > BC)));
+            }
+            if (n_valid > 20 && ballot(kept_tie) != 0ull) ++n_amb;
+            if (ballot(crit) != 0ull) ++n_crit;
+        }
         for (int base = 0; base < nslots; base += kWave) {
             const int c = base + lane;
             if (c >= nslots) continue;
@@ -880,6 +935,14 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         B = Bn;
         cur = nxt;
         __syncthreads();
+        FCD_DUPLEX_PHASE(4)
+    }
+    if (prof && lane == 0) {
+        uint32_t *o = p.prof + 8 * r;
+        for (int k = 0; k < 5; ++k) o[k] = (uint32_t)(acc[k] >> 6);  // units of 64 cycles: a pair runs ~2e8 cycles
+        o[5] = n_iter;
+        o[6] = n_newnodes;
+        o[7] = (uint32_t)T1;
     }
 
     // ---- labels leaf -> root (:638-649), written in sequence order ----
@@ -894,6 +957,10 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         }
         p.out.out_len[r] = (uint32_t)n;
         p.out.status[r] = FCD_ST_OK;
+        if (count_amb) {
+            p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+            p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+        }
     }
 }
 
@@ -992,6 +1059,7 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     p.S = a.S; p.crf = a.crf; p.init1 = a.init1; p.init2 = a.init2; p.n_init1 = a.n_init1;
     p.n_init2 = a.n_init2; p.init1_stride = a.init1_stride; p.init2_stride = a.init2_stride;
     p.pair_begin = pair_begin;
+    p.prof = a.prof;
     const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S);
     // up to two wavefronts per SIMD (2048 pairs on the 256 CUs): the coefficient-pinning instantiation
     const bool pin = a.staged && n_pairs <= 2048;

@@ -125,6 +125,7 @@ struct DuplexArgs {
     int Wcap;
     int staged;
     ResultDesc out;
+    uint32_t *prof;  // developer instrument: [pair][8] cycle account, nullable
 };
 
 size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S);
@@ -226,6 +227,7 @@ struct fcd_handle {
     std::vector<fcd_host_lane *> lanes;
     bool job_active = false;  // a host job owns the lanes from begin to end
     bool is_lane = false;
+    uint32_t *duplex_prof = nullptr;  // fcd_debug_set_duplex_profile
     int pipe_lanes = 0;          // fcd_set_host_pipeline: 0 = default (FCD_HOST_LANES or 4)
     int64_t pipe_chunk = 0;      // reads per chunk, 0 = automatic
     int64_t pipe_min_bytes = -1; // fcd_*_host batches of at least this many input bytes take the pipeline; -1 = default

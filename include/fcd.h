@@ -107,7 +107,8 @@ typedef struct fcd_batch {
  *            reference feeds to phred() for each emitted label (src/search.rs:348-356,370-376)
  *   out_len: [n_reads] u32   number of emitted labels
  *   status : [n_reads] i32   FCD_ST_*  (nullable for viterbi)
- *   ambiguous: [n_reads][2] u32 (nullable; fcd_beam_search_* and fcd_crf_beam_search_* only; device pointer
+ *   ambiguous: [n_reads][2] u32 (nullable; the beam searches -- fcd_beam_search_*, fcd_crf_beam_search_* and the
+ *            two duplex searches, whose prune is the same sort_unstable_by, src/duplex.rs:620,807; device pointer
  *            for *_dev, host pointer for *_host) -- a TIE INSTRUMENT, not a reference output.  The reference
  *            orders candidates with sort_unstable_by (src/search.rs:122,262): a stable insertion sort up to
  *            20 elements, pdqsort -- implementation-defined tie order -- above.  The kernels break exact
@@ -154,6 +155,12 @@ int fcd_release_workspace(fcd_handle *h);
  * jobs.  A larger divisor makes the retry path run on small inputs (tests) and pins it; 0 restores the
  * adaptive default. */
 int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor);
+/* Developer instrument: while `cycles` (DEVICE array [n_pairs][8] u32, indexed by the pair's position in the batch)
+ * is set, the duplex searches on this handle record a cycle account per pair: shader cycles / 64 spent in
+ * [0] envelope + forward-vector extension, [1] LDS tiles, [2] expansion without the window builds, [3] window
+ * builds of the new nodes, [4] rank + next beam; [5] window-build loop iterations, [6] new nodes, [7] steps.
+ * NULL switches it off.  The stamps wait for each phase's results (tools/duplex_account.py). */
+int fcd_debug_set_duplex_profile(fcd_handle *h, uint32_t *cycles);
 /* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP
  * events on the stream the kernels were launched on; <0 if unavailable */
 double fcd_last_kernel_ms(fcd_handle *h);
@@ -212,7 +219,8 @@ int fcd_crf_greedy_search_host(fcd_handle *h, const fcd_batch *in, const float *
 /* ---- duplex::beam_search (src/duplex.rs:443-650) ----
  * in1/in2 describe the two reads of each pair (same n_reads and N); envelope is
  * [n_reads * env_stride] pairs of u64 (lo,hi), row t of pair r at envelope[(r*env_stride + t)*2].
- * Only labels/out_len/status of `out` are written (the reference returns the string only). */
+ * Only labels/out_len/status (and the tie counters `ambiguous`, when given) of `out` are written (the reference
+ * returns the string only). */
 int fcd_beam_search_duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2,
                                const uint64_t *envelope, int64_t env_stride, int64_t beam_size,
                                float beam_cut_threshold, int collapse_repeats, int logadd_mode,

@@ -1045,6 +1045,15 @@ static inline float log1p_m(float x, int mode) {
 /* instrumentation for the duplex roofline (tools/bench_configs.py): LogSpace::add calls of this thread */
 static __thread int64_t g_logadd_calls = 0;
 static int64_t g_duplex_ties[4];
+/* the per-search twin of fcd_result.ambiguous (include/fcd.h) for the duplex searches, of the calling thread's
+ * most recent search: [0] pruning steps with more than 20 candidates in which a kept candidate has exactly the
+ * probability of another candidate, [1] steps with equal probabilities at ranks 0 / 1 or across the truncation
+ * boundary */
+static __thread int64_t t_duplex_amb[2];
+void fcdo_duplex_last_ambiguous(int64_t out[2]) {
+    out[0] = t_duplex_amb[0];
+    out[1] = t_duplex_amb[1];
+}
 /* test/analysis instrument (not thread-safe): {pruning steps, steps with > 20 candidates in which a kept candidate
  * ties with another, steps with a tie across the truncation boundary, reads whose final top two tie} summed
  * over the duplex searches run since the last reset */
@@ -1274,6 +1283,7 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
     const int64_t N = n1->N, n_base = N - 1, n_state = n1->S;
     const float thr = ln_m(thr_real, mode); /* :454 */
     int status = FCDO_OK;
+    t_duplex_amb[0] = t_duplex_amb[1] = 0;
     if (n1->T <= 0) return FCDO_PANIC; /* envelope[(0,1)] out of bounds :477 */
 
     fcdo_tree *tree = fcdo_tree_new(n_base);
@@ -1462,6 +1472,8 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
                 if (i < kept) tie = 1;
                 if (i + 1 == kept) boundary = 1;
             }
+            if (n > 20 && tie) t_duplex_amb[0] += 1;
+            if (boundary || (n >= 2 && keyed[0].prob == keyed[1].prob)) t_duplex_amb[1] += 1;
             g_duplex_ties[0] += 1;                                  /* pruning steps */
             if (n > 20 && tie) g_duplex_ties[1] += 1;               /* > 20 candidates and a kept one tied */
             if (boundary) g_duplex_ties[2] += 1;                    /* a tie across the truncation boundary */

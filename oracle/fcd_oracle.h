@@ -185,6 +185,10 @@ float fcdo_logspace_add(float a, float b, int logadd_mode);
 int64_t fcdo_logadd_calls(int reset);
 /* tie statistics of the duplex searches' prune (src/duplex.rs:620,807): see fcd_oracle.c */
 void fcdo_duplex_tie_steps(int64_t out[4], int reset);
+/* tie counters of the calling thread's most recent duplex search, defined like fcd_result.ambiguous
+ * (include/fcd.h): [0] steps with > 20 candidates and a kept candidate tied, [1] steps with a tie at ranks 0 / 1
+ * or across the truncation boundary */
+void fcdo_duplex_last_ambiguous(int64_t out[2]);
 /* out[i] = fcdo_logspace_add(a[i], b[i], logadd_mode) -- lets tests compare millions of operands */
 void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int logadd_mode);
 

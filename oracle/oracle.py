@@ -80,6 +80,8 @@ def _load():
     lib.fcdo_duplex_tie_steps.argtypes = [C.POINTER(i64), i32]
     lib.fcdo_duplex_tie_steps.restype = None
     lib.fcdo_logadd_calls.restype = i64
+    lib.fcdo_duplex_last_ambiguous.argtypes = [C.POINTER(i64)]
+    lib.fcdo_duplex_last_ambiguous.restype = None
     lib.fcdo_set_unstable_sort.argtypes = [i32]
     lib.fcdo_set_unstable_sort.restype = None
     lib.fcdo_get_unstable_sort.restype = i32
@@ -424,3 +426,10 @@ def pdqsort_desc(prob, node):
     n = np.ascontiguousarray(node, np.int32).copy()
     lib.fcdo_test_pdqsort(_ptr(p), _ptr(n), len(p))
     return p, n
+
+
+def duplex_last_ambiguous():
+    """(amb0, amb1) of this thread's most recent duplex search -- the duplex twin of BatchResult.ambiguous."""
+    out = (C.c_int64 * 2)()
+    lib.fcdo_duplex_last_ambiguous(out)
+    return int(out[0]), int(out[1])

@@ -394,3 +394,45 @@ def crf_duplex_fuzz_seed(fcd, seed, mode):
 def test_crf_duplex_fuzz(fcd, mode):
     for seed in range(8000, 8012):
         crf_duplex_fuzz_seed(fcd, seed, mode)
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_tie_counters(fcd, mode):
+    """fcd_result.ambiguous through the duplex kernels == the oracle's per-search counters
+    (fcdo_duplex_last_ambiguous), pair by pair -- on generator data, on quantised data that forces exact ties,
+    with beam 8 (up to 40 candidates: the > 20 case) and beam 3 (never above 20), on failing pairs too."""
+    rng = np.random.default_rng(17 + mode)
+    T = 140
+    x1, x2 = pairs(900 + mode, 8, T, T)
+    # pairs 4..7: probabilities quantised to 1/8 steps -- equal candidates at nearly every step
+    for x in (x1, x2):
+        q = np.round(rng.random((4, T, 5)) * 8) / 8 + 0.125
+        x[4:] = (q / np.linalg.norm(q, axis=2, keepdims=True)).astype(np.float32)
+    # pairs 4, 5: the four symbols share one probability in every row -- sibling candidates tie exactly in both
+    # log-add modes (same parent, same factors, identical windows over read 2)
+    for x in (x1, x2):
+        b = rng.random((2, T, 1)) * 0.5 + 0.2
+        sym = np.broadcast_to(np.sqrt((1 - b * b) / 4), (2, T, 4))
+        x[4:6] = np.concatenate([b, sym], 2).astype(np.float32)
+    x1[7, 50:] = 0.0  # runs out of beam half way
+    envs = np.stack([band(T, T, 20)] * 8)
+    seen = np.zeros(2, np.int64)
+    thr = 0.02
+    for beam in (8, 3):
+        r = fcd.beam_search_duplex_batch_raw(x1, x2, envs, beam, thr, True, logadd_mode=mode,
+                                             count_ambiguous=True).cpu()
+        plain = fcd.beam_search_duplex_batch_raw(x1, x2, envs, beam, thr, True, logadd_mode=mode).cpu()
+        assert np.array_equal(r.status, plain.status) and np.array_equal(r.out_len, plain.out_len)
+        for i in range(8):
+            try:
+                oracle.beam_search_duplex(x1[i], x2[i], "NACGT", envs[i], beam, thr, True, mode | CR)
+                st = 0
+            except RuntimeError:
+                st = 1
+            assert (int(r.status[i]) != 0) == (st != 0)
+            want = oracle.duplex_last_ambiguous()
+            assert tuple(int(v) for v in r.ambiguous[i]) == want, (beam, i, r.ambiguous[i], want)
+            seen += np.array(want)
+            if beam == 3:
+                assert want[0] == 0  # 15 candidates at most: never the pdqsort case
+    assert seen[0] > 0 and seen[1] > 0  # the test data really exercises both counters
