@@ -35,6 +35,8 @@ SYMBOLS = [
     "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
     "fcd_coalescer_create", "fcd_coalescer_destroy", "fcd_coalescer_beam_search", "fcd_coalescer_viterbi_search",
     "fcd_coalescer_stats", "fcd_coalescer_last_error",
+    "fcd_comm_unique_id", "fcd_comm_create", "fcd_comm_wrap", "fcd_comm_destroy", "fcd_gather_results_dev",
+    "fcd_comm_synchronize", "fcd_unpack_gathered_dev",
     "fcd_viterbi_search_host_begin", "fcd_beam_search_host_begin", "fcd_crf_beam_search_host_begin",
     "fcd_crf_greedy_search_host_begin", "fcd_set_host_pipeline", "fcd_job_chunks", "fcd_job_next", "fcd_job_end",
 ]
@@ -154,6 +156,13 @@ def bind(lib):
     lib.fcd_coalescer_stats.argtypes = [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     lib.fcd_coalescer_last_error.restype = C.c_char_p
     PP = C.POINTER(P)
+    lib.fcd_comm_unique_id.argtypes = [P]
+    lib.fcd_comm_create.argtypes = [P, i32, i32, P, PP]
+    lib.fcd_comm_wrap.argtypes = [P, P, i32, i32, PP]
+    lib.fcd_comm_destroy.argtypes = [P]
+    lib.fcd_gather_results_dev.argtypes = [P, RP, i64, P, i32, RP]
+    lib.fcd_comm_synchronize.argtypes = [P]
+    lib.fcd_unpack_gathered_dev.argtypes = [P, P, i64, i32, P, i64, P, RP, P]
     lib.fcd_viterbi_search_host_begin.argtypes = [P, BP, i32, i32, PP]
     lib.fcd_beam_search_host_begin.argtypes = [P, BP, i64, f32, i32, i32, i32, PP]
     lib.fcd_crf_beam_search_host_begin.argtypes = [P, BP, P, i64, i64, i64, f32, i32, i32, PP]

@@ -944,6 +944,19 @@ int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, u
     return FCD_OK;
 }
 
+int fcd_unpack_gathered_dev(fcd_handle *h, const uint8_t *gathered, int64_t stride, int world, const int64_t *first,
+                            int64_t n_total, uint64_t *offsets, const fcd_result *out, int32_t *bad) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (!gathered || stride < 16 || world < 1 || !first || n_total < 0 || !offsets || !out || !bad)
+        return fail(h, FCD_E_INVALID, "bad argument");
+    if (n_total == 0) return FCD_OK;
+    if (!out->labels || !out->out_len) return fail(h, FCD_E_INVALID, "null labels/out_len");
+    FCD_DEVICE(h);
+    FCD_HIP(h, launch_unpack_gathered(gathered, stride, world, first, n_total, offsets, to_desc(out), bad, h->stream));
+    return FCD_OK;
+}
+
 }  // extern "C"
 
 // ---- *_host: stage host buffers through device memory, run the *_dev path, copy back -------

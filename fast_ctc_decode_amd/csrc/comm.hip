@@ -1,0 +1,323 @@
+// comm.hip -- the multi-GPU step of the path at the C-ABI level (host code).
+//
+// Reads shard across the ranks with no exchange inside the search; what is left is ONE gather of every rank's
+// decoded results on the destination rank.  fast_ctc_decode_amd/dist.py does that through torch.distributed;
+// a host that is not Python (north star: "host code stays Rust calling HIP through a thin C-ABI") gets the same
+// step here, over RCCL directly:
+//
+//   fcd_gather_results_dev   offsets + pack of the used prefixes (pack.hip)            this rank's stream
+//                            ncclAllReduce(MAX) of the label totals -> 8 bytes to the host (the one host wait:
+//                            a gather needs one count for all ranks)
+//                            ncclGather of the packed buffers over xGMI
+//                            unpack of ALL shards with one pair of launches            destination rank only
+//
+// RCCL is looked up at run time (dlopen: librccl.so.1, the one PyTorch bundles if it is already in the process),
+// so libfcd_hip.so has no link-time dependency on it and single-GPU users never load it.  An fcd_comm can also
+// wrap a communicator the host already owns (fcd_comm_wrap), or none at all for world = 1.
+#include <dlfcn.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "fcd_internal.h"
+
+using namespace fcd;
+
+#define FCD_HIP(h, expr)                                                   \
+    do {                                                                   \
+        hipError_t e__ = (expr);                                           \
+        if (e__ != hipSuccess) {                                           \
+            (h)->err = std::string(#expr) + ": " + hipGetErrorString(e__); \
+            return FCD_E_HIP;                                              \
+        }                                                                  \
+    } while (0)
+
+namespace {
+
+// the few RCCL declarations used (values as in rccl/rccl.h of ROCm 7: ncclUint8 = 1, ncclUint64 = 5, ncclMax = 2)
+struct NcclId {
+    char internal[FCD_COMM_ID_BYTES];
+};
+typedef void *NcclComm;
+enum { kNcclUint8 = 1, kNcclUint64 = 5, kNcclMax = 2 };
+
+struct Rccl {
+    void *lib = nullptr;
+    int (*GetUniqueId)(NcclId *) = nullptr;
+    int (*CommInitRank)(NcclComm *, int, NcclId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Gather)(const void *, void *, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool ok = false;
+};
+
+Rccl &rccl() {
+    static Rccl r;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        // a copy already in the process (PyTorch's) first: two RCCLs in one process would not share state
+        for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
+            if (r.lib) break;
+        }
+        for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            if (r.lib) break;
+            r.lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+        }
+        if (!r.lib) return;
+        r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(dlsym(r.lib, "ncclGetUniqueId"));
+        r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(dlsym(r.lib, "ncclCommInitRank"));
+        r.CommDestroy = reinterpret_cast<decltype(r.CommDestroy)>(dlsym(r.lib, "ncclCommDestroy"));
+        r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(dlsym(r.lib, "ncclAllReduce"));
+        r.Gather = reinterpret_cast<decltype(r.Gather)>(dlsym(r.lib, "ncclGather"));
+        r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(dlsym(r.lib, "ncclGetErrorString"));
+        r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.AllReduce && r.Gather;
+    });
+    return r;
+}
+
+struct Buf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+}  // namespace
+
+struct fcd_comm {
+    fcd_handle *h = nullptr;
+    NcclComm comm = nullptr;
+    bool owns_comm = false;
+    int world = 1, rank = 0;
+    Buf send, recv, meta;  // grow-only device buffers: packed shard | world packed shards | offsets
+    Buf fixed;             // [0, 8) the agreed label total, [8, 12) bad-header flag, [64, ...) first[world + 1]
+    std::vector<int64_t> counts;  // the counts `first` on the device was computed from
+    void *pin = nullptr;   // page-locked bytes for the size / flag read-back
+};
+
+namespace {
+
+int comm_fail(fcd_comm *c, int code, const std::string &msg) {
+    c->h->err = msg;
+    return code;
+}
+
+int need(fcd_comm *c, Buf &b, size_t bytes) {
+    if (b.cap >= bytes) return FCD_OK;
+    if (b.p) {
+        (void)hipStreamSynchronize(c->h->stream);
+        (void)hipFree(b.p);
+        b.p = nullptr;
+        b.cap = 0;
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipMalloc(&b.p, want) != hipSuccess) return comm_fail(c, FCD_E_NOMEM, "hipMalloc failed (gather buffers)");
+    b.cap = want;
+    return FCD_OK;
+}
+
+int nccl_check(fcd_comm *c, int rc, const char *what) {
+    if (rc == 0) return FCD_OK;
+    const Rccl &r = rccl();
+    return comm_fail(c, FCD_E_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error"));
+}
+
+fcd_comm *new_comm(fcd_handle *h, int world, int rank) {
+    fcd_comm *c = new fcd_comm();
+    c->h = h;
+    c->world = world;
+    c->rank = rank;
+    return c;
+}
+
+}  // namespace
+
+extern "C" {
+
+int fcd_comm_unique_id(uint8_t id[FCD_COMM_ID_BYTES]) {
+    if (!id) return FCD_E_INVALID;
+    Rccl &r = rccl();
+    if (!r.ok) return FCD_E_UNSUPPORTED;
+    NcclId nid;
+    memset(&nid, 0, sizeof(nid));
+    if (r.GetUniqueId(&nid) != 0) return FCD_E_HIP;
+    memcpy(id, nid.internal, FCD_COMM_ID_BYTES);
+    return FCD_OK;
+}
+
+int fcd_comm_create(fcd_handle *h, int world, int rank, const uint8_t id[FCD_COMM_ID_BYTES], fcd_comm **out) {
+    if (!h || !out || !id || world < 1 || rank < 0 || rank >= world) return FCD_E_INVALID;
+    *out = nullptr;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    Rccl &r = rccl();
+    if (!r.ok) {
+        h->err = "RCCL (librccl.so) could not be loaded";
+        return FCD_E_UNSUPPORTED;
+    }
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != h->device && hipSetDevice(h->device) != hipSuccess) return FCD_E_HIP;
+    fcd_comm *c = new_comm(h, world, rank);
+    NcclId nid;
+    memcpy(nid.internal, id, FCD_COMM_ID_BYTES);
+    const int rc = r.CommInitRank(&c->comm, world, nid, rank);  // one process per GPU: the handle's device
+    if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
+    if (rc != 0) {
+        h->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error");
+        delete c;
+        return FCD_E_HIP;
+    }
+    c->owns_comm = true;
+    *out = c;
+    return FCD_OK;
+}
+
+int fcd_comm_wrap(fcd_handle *h, void *nccl_comm, int world, int rank, fcd_comm **out) {
+    if (!h || !out || world < 1 || rank < 0 || rank >= world) return FCD_E_INVALID;
+    *out = nullptr;
+    if (!nccl_comm && world != 1) return FCD_E_INVALID;  // no communicator: a single rank only
+    if (nccl_comm && !rccl().ok) return FCD_E_UNSUPPORTED;
+    fcd_comm *c = new_comm(h, world, rank);
+    c->comm = nccl_comm;
+    *out = c;
+    return FCD_OK;
+}
+
+int fcd_comm_destroy(fcd_comm *c) {
+    if (!c) return FCD_OK;
+    fcd_handle *h = c->h;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != h->device) (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    if (c->owns_comm && c->comm) (void)rccl().CommDestroy(c->comm);
+    for (Buf *b : {&c->send, &c->recv, &c->meta, &c->fixed})
+        if (b->p) (void)hipFree(b->p);
+    if (c->pin) (void)hipHostFree(c->pin);
+    if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
+    delete c;
+    return FCD_OK;
+}
+
+int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, const int64_t *counts, int dst,
+                           const fcd_result *out) {
+    if (!c || !res || !counts || n_reads < 0 || dst < 0 || dst >= c->world) return FCD_E_INVALID;
+    fcd_handle *h = c->h;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (counts[c->rank] != n_reads) return comm_fail(c, FCD_E_INVALID, "counts[rank] differs from n_reads");
+    int64_t n_total = 0, n_max = 0;
+    for (int k = 0; k < c->world; ++k) {
+        if (counts[k] < 0) return comm_fail(c, FCD_E_INVALID, "negative read count");
+        n_total += counts[k];
+        n_max = std::max(n_max, counts[k]);
+    }
+    const bool is_dst = c->rank == dst;
+    if (n_reads > 0 && (!res->labels || !res->path || !res->out_len))
+        return comm_fail(c, FCD_E_INVALID, "null labels/path/out_len");
+    if (is_dst && n_total > 0 && (!out || !out->labels || !out->out_len || out->out_stride < res->out_stride))
+        return comm_fail(c, FCD_E_INVALID, "destination result missing or narrower than the shards");
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != h->device && hipSetDevice(h->device) != hipSuccess) return FCD_E_HIP;
+    struct Restore {
+        int prev, dev;
+        ~Restore() {
+            if (prev >= 0 && prev != dev) (void)hipSetDevice(prev);
+        }
+    } restore{prev, h->device};
+    hipStream_t st = h->stream;
+    const int W = (int)std::min<int64_t>(res->out_stride, 1 << 30);
+    const int pb = res->out_stride <= 65535 ? 2 : 4;  // time indices are < out_stride (csrc/pack.hip)
+    // meta: offsets of this shard [n_reads + 1] | unpack offsets [n_total + world] (destination)
+    const size_t o_uoffs = ((size_t)(n_reads + 1) * 8 + 15) & ~(size_t)15;
+    int rc = need(c, c->meta, o_uoffs + (is_dst ? (size_t)(n_total + c->world) * 8 : 0) + 16);
+    if (rc) return rc;
+    if (c->world > 64) return comm_fail(c, FCD_E_UNSUPPORTED, "more than 64 ranks");
+    if (!c->fixed.p) {
+        rc = need(c, c->fixed, 64 + 65 * 8);
+        if (rc) return rc;
+        FCD_HIP(h, hipMemsetAsync(c->fixed.p, 0, 64 + 65 * 8, st));
+    }
+    if (!c->pin && hipHostMalloc(&c->pin, 64, hipHostMallocDefault) != hipSuccess)
+        return comm_fail(c, FCD_E_NOMEM, "hipHostMalloc failed (gather)");
+    char *meta = reinterpret_cast<char *>(c->meta.p);
+    char *fixed = reinterpret_cast<char *>(c->fixed.p);
+    uint64_t *d_offs = reinterpret_cast<uint64_t *>(meta);
+    uint64_t *d_max = reinterpret_cast<uint64_t *>(fixed);
+    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 8);
+    int64_t *d_first = reinterpret_cast<int64_t *>(fixed + 64);
+    FCD_HIP(h, launch_result_offsets(res->out_len, n_reads, W, d_offs, st));
+    // one count for every rank: the largest label total decides the buffer size (with the largest shard)
+    if (c->comm) {
+        rc = nccl_check(c, rccl().AllReduce(d_offs + n_reads, d_max, 1, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
+        if (rc) return rc;
+    } else {
+        FCD_HIP(h, hipMemcpyAsync(d_max, d_offs + n_reads, 8, hipMemcpyDeviceToDevice, st));
+    }
+    // (the flag next to it is the PREVIOUS gather's header check: reported one call late, or by fcd_comm_synchronize)
+    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 16, hipMemcpyDeviceToHost, st));
+    FCD_HIP(h, hipStreamSynchronize(st));  // the one host wait of the gather
+    const uint64_t max_total = *reinterpret_cast<const uint64_t *>(c->pin);
+    if (reinterpret_cast<const int32_t *>(c->pin)[2] != 0) {
+        FCD_HIP(h, hipMemsetAsync(d_bad, 0, 4, st));
+        return comm_fail(c, FCD_E_INVALID, "gather: a shard's header contradicted the read counts (earlier call)");
+    }
+    if (max_total > (uint64_t)n_max * (uint64_t)W) return comm_fail(c, FCD_E_HIP, "gather: impossible label total");
+    const int64_t nbytes = fcd_packed_result_bytes(n_max, (int64_t)max_total, pb);
+    rc = need(c, c->send, (size_t)nbytes);
+    if (rc) return rc;
+    if (is_dst) {
+        rc = need(c, c->recv, (size_t)nbytes * (size_t)c->world);
+        if (rc) return rc;
+    }
+    ResultDesc wire{res->labels, res->path, nullptr, res->out_len, res->status, res->out_stride, nullptr};
+    if (n_reads > 0) FCD_HIP(h, launch_pack(wire, n_reads, pb, d_offs, reinterpret_cast<uint8_t *>(c->send.p), st));
+    else FCD_HIP(h, hipMemsetAsync(c->send.p, 0, 16, st));
+    const uint8_t *gathered = reinterpret_cast<const uint8_t *>(c->send.p);
+    if (c->comm) {
+        rc = nccl_check(c, rccl().Gather(c->send.p, is_dst ? c->recv.p : nullptr, (size_t)nbytes, kNcclUint8, dst,
+                                         c->comm, st), "ncclGather");
+        if (rc) return rc;
+        gathered = reinterpret_cast<const uint8_t *>(c->recv.p);
+    }
+    if (!is_dst || n_total == 0) return FCD_OK;
+    // shard s owns rows [first[s], first[s + 1]) of the destination; the prefix sums live on the device and
+    // are refreshed only when the counts change
+    if (c->counts.size() != (size_t)c->world || !std::equal(c->counts.begin(), c->counts.end(), counts)) {
+        int64_t first[65];
+        first[0] = 0;
+        for (int k = 0; k < c->world; ++k) first[k + 1] = first[k] + counts[k];
+        FCD_HIP(h, hipStreamSynchronize(st));
+        FCD_HIP(h, hipMemcpy(d_first, first, (size_t)(c->world + 1) * 8, hipMemcpyHostToDevice));
+        c->counts.assign(counts, counts + c->world);
+    }
+    ResultDesc o{out->labels, out->path, nullptr, out->out_len, out->status, out->out_stride, nullptr};
+    FCD_HIP(h, launch_unpack_gathered(gathered, nbytes, c->world, d_first, n_total,
+                                      reinterpret_cast<uint64_t *>(meta + o_uoffs), o, d_bad, st));
+    return FCD_OK;
+}
+
+int fcd_comm_synchronize(fcd_comm *c) {
+    if (!c) return FCD_E_INVALID;
+    fcd_handle *h = c->h;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != h->device && hipSetDevice(h->device) != hipSuccess) return FCD_E_HIP;
+    int rc = FCD_OK;
+    int32_t bad = 0;
+    if (hipStreamSynchronize(h->stream) != hipSuccess) rc = FCD_E_HIP;
+    if (rc == FCD_OK && c->fixed.p) {
+        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
+        if (bad) {
+            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 8, 0, 4);
+            rc = comm_fail(c, FCD_E_INVALID, "gather: the header of shard " + std::to_string(bad - 1) +
+                                                 " contradicts the read counts / buffer size");
+        }
+    }
+    if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
+    return rc;
+}
+
+}  // extern "C"

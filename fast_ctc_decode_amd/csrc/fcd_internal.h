@@ -164,6 +164,11 @@ hipError_t launch_pack(const ResultDesc &res, int64_t n, int path_bytes, const u
                        hipStream_t stream);
 hipError_t launch_unpack(const uint8_t *buf, int64_t n, const uint64_t *offsets, const ResultDesc &out,
                          hipStream_t stream);
+// every shard of a gathered buffer (world x stride bytes) at once; first = [world + 1] prefix sums of the
+// per-rank read counts (device), offsets = workspace of n_total + world u64, *bad = 1 + shard on a bad header
+hipError_t launch_unpack_gathered(const uint8_t *gathered, int64_t stride, int world, const int64_t *first,
+                                  int64_t n_total, uint64_t *offsets, const ResultDesc &out, int32_t *bad,
+                                  hipStream_t stream);
 
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
                                  int64_t n, int mode, hipStream_t stream);

@@ -155,7 +155,116 @@ __global__ __launch_bounds__(256) void unpack_kernel(UnpackParams p) {
     }
 }
 
+// ---- the receiving side of the gather: every shard of the gathered buffer in ONE pair of launches ----
+// gathered = world buffers of `stride` bytes back to back (the layout of ncclGather / dist.gather into one
+// allocation); shard s holds counts[s] reads and lands in rows [first[s], first[s] + counts[s]) of `out`.
+struct GatherUnpack {
+    const uint8_t *gathered;
+    int64_t stride;
+    int world;
+    const int64_t *first;   // [world + 1] exclusive prefix sums of the per-rank read counts (device)
+    uint64_t *offsets;      // workspace [n_total + world]: per shard, counts[s] + 1 prefix sums of its out_len
+    uint8_t *labels;
+    uint32_t *path;
+    uint32_t *out_len;
+    int32_t *status;
+    int64_t out_stride;
+    int32_t *bad;           // set to 1 + shard when a shard's header contradicts counts / the buffer size
+};
+
+// one workgroup per shard: header check + prefix sums of the shard's out_len
+__global__ __launch_bounds__(kScanThreads) void gathered_offsets_kernel(GatherUnpack p) {
+    __shared__ uint64_t s_part[kScanThreads / 64];
+    __shared__ uint64_t s_carry;
+    const int s = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = p.first[s + 1] - p.first[s];
+    const uint8_t *buf = p.gathered + (int64_t)s * p.stride;
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(buf);
+    uint64_t *offs = p.offsets + p.first[s] + s;
+    bool ok = true;
+    if (n > 0) {
+        const uint64_t total = (uint64_t)hdr[0] | ((uint64_t)hdr[1] << 32);
+        const uint32_t pb = hdr[3] & 0xffu;
+        ok = (int64_t)hdr[2] == n && (pb == 2 || pb == 4) &&
+             16 + 8 * (uint64_t)n + ((total + 3) & ~(uint64_t)3) + total * pb <= (uint64_t)p.stride;
+    }
+    if (!ok && tid == 0) atomicMax(p.bad, 1 + s);
+    if (tid == 0) s_carry = 0;
+    __syncthreads();
+    const uint32_t *len = hdr + 4;
+    for (int64_t base = 0; base < n; base += kScanThreads) {
+        const int64_t i = base + tid;
+        uint64_t v = 0;
+        if (i < n && ok) {
+            const uint64_t l = len[i];
+            v = l < (uint64_t)p.out_stride ? l : (uint64_t)p.out_stride;
+        }
+        uint64_t incl = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t lo = (uint32_t)__shfl_up((int)(uint32_t)incl, o);
+            const uint32_t hi = (uint32_t)__shfl_up((int)(uint32_t)(incl >> 32), o);
+            if (lane >= o) incl += ((uint64_t)hi << 32) | lo;
+        }
+        if (lane == 63) s_part[wave] = incl;
+        __syncthreads();
+        uint64_t before = s_carry;
+        for (int w = 0; w < wave; ++w) before += s_part[w];
+        if (i < n) offs[i] = before + incl - v;
+        __syncthreads();
+        if (tid == kScanThreads - 1) s_carry = before + incl;
+        __syncthreads();
+    }
+    if (tid == 0) offs[n] = s_carry;
+}
+
+__global__ __launch_bounds__(256) void gathered_unpack_kernel(GatherUnpack p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t g = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // global read index
+    const int64_t n_total = p.first[p.world];
+    if (g >= n_total) return;
+    int s = 0;
+    while (s + 1 < p.world && g >= p.first[s + 1]) ++s;  // world is a handful of ranks
+    const int64_t r = g - p.first[s], n = p.first[s + 1] - p.first[s];
+    const uint8_t *buf = p.gathered + (int64_t)s * p.stride;
+    const uint32_t *hdr = reinterpret_cast<const uint32_t *>(buf);
+    const uint64_t *offs = p.offsets + p.first[s] + s;
+    const uint64_t total = (uint64_t)hdr[0] | ((uint64_t)hdr[1] << 32);
+    const int path_bytes = (int)(hdr[3] & 0xffu);
+    const uint64_t off = offs[r];
+    const int64_t len = (int64_t)(offs[r + 1] - off);
+    if (lane == 0) {
+        p.out_len[g] = (uint32_t)len;
+        if (p.status) p.status[g] = reinterpret_cast<const int32_t *>(hdr + 4 + n)[r];
+    }
+    const uint8_t *lab_in = buf + header_bytes(n) + off;
+    uint8_t *lab_out = p.labels + g * p.out_stride;
+    for (int64_t j = lane; j < len; j += 64) lab_out[j] = lab_in[j];
+    if (!p.path) return;
+    const uint8_t *path_region = buf + header_bytes(n) + ((total + 3) & ~(uint64_t)3);
+    uint32_t *pth_out = p.path + g * p.out_stride;
+    if (path_bytes == 2) {
+        const uint16_t *in = reinterpret_cast<const uint16_t *>(path_region) + off;
+        for (int64_t j = lane; j < len; j += 64) pth_out[j] = in[j];
+    } else {
+        const uint32_t *in = reinterpret_cast<const uint32_t *>(path_region) + off;
+        for (int64_t j = lane; j < len; j += 64) pth_out[j] = in[j];
+    }
+}
+
 }  // namespace
+
+hipError_t launch_unpack_gathered(const uint8_t *gathered, int64_t stride, int world, const int64_t *first,
+                                  int64_t n_total, uint64_t *offsets, const ResultDesc &out, int32_t *bad,
+                                  hipStream_t stream) {
+    if (world <= 0 || n_total <= 0) return hipSuccess;
+    GatherUnpack p{gathered, stride, world, first, offsets, out.labels, out.path, out.out_len, out.status,
+                   out.out_stride, bad};
+    hipLaunchKernelGGL(gathered_offsets_kernel, dim3((unsigned)world), dim3(kScanThreads), 0, stream, p);
+    hipLaunchKernelGGL(gathered_unpack_kernel, dim3((unsigned)((n_total + 3) / 4)), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
 
 hipError_t launch_result_offsets(const uint32_t *len, int64_t n, int64_t stride, uint64_t *offsets, hipStream_t stream) {
     hipLaunchKernelGGL(result_offsets_kernel, dim3(1), dim3(kScanThreads), 0, stream, len, n, stride, offsets);

@@ -73,7 +73,10 @@ def result_total(r):
     if _is_device(r.labels):
         h = _handle_for(r.labels)
         offs = torch.empty(B + 1, dtype=torch.int64, device=r.labels.device)
-        h.check(h.lib.fcd_result_offsets_dev(h.ptr, r.out_len.data_ptr(), B, W, offs.data_ptr()))
+        try:
+            h.check(h.lib.fcd_result_offsets_dev(h.ptr, r.out_len.data_ptr(), B, W, offs.data_ptr()))
+        finally:
+            h.reset_stream()  # the thread's default handle does not stay bound to the caller's (comm) stream
     else:
         lens = torch.clamp(r.out_len.to(torch.int64), max=W)
         offs = torch.zeros(B + 1, dtype=torch.int64)
@@ -96,7 +99,10 @@ def pack_result(r, offsets, nbytes, out=None):
     if _is_device(r.labels):
         h = _handle_for(r.labels)
         res = _result_struct(r, W)
-        h.check(h.lib.fcd_pack_results_dev(h.ptr, C.byref(res), B, pb, offsets.data_ptr(), buf.data_ptr()))
+        try:
+            h.check(h.lib.fcd_pack_results_dev(h.ptr, C.byref(res), B, pb, offsets.data_ptr(), buf.data_ptr()))
+        finally:
+            h.reset_stream()
         return buf
     # host tensors (gloo): the same layout with numpy
     o = offsets.numpy()
@@ -117,50 +123,122 @@ def pack_result(r, offsets, nbytes, out=None):
     return buf
 
 
-def unpack_results(bufs, counts, width):
+def _check_header(b, B, width, capacity, rank):
+    """A packed shard must describe exactly the reads the receiver expects: anything else would make the
+    unpacking read or write out of bounds."""
+    total = int(b[:8].view(np.uint64)[0])
+    n_in = int(b[8:12].view(np.uint32)[0])
+    pb = int(b[12:16].view(np.uint32)[0]) & 0xFF
+    if n_in != B or pb not in (2, 4) or _HEADER + 8 * B + ((total + 3) & ~3) + total * pb > capacity \
+            or total > B * width:
+        raise ValueError("gathered shard %d: header (reads %d, path bytes %d, labels %d) contradicts the expected "
+                         "%d reads of width %d in %d bytes" % (rank, n_in, pb, total, B, width, capacity))
+    return total, pb
+
+
+def check_gather(scratch):
+    """Raises if the last device-side unpack met a shard whose header contradicted the read counts (the flag is
+    written by the unpack kernels; gather_batch_result looks at it at its next call, this looks now)."""
+    bad = None if scratch is None else scratch.get("bad")
+    if bad is not None:
+        v = int(bad.item())
+        if v:
+            bad.zero_()
+            raise ValueError("gathered shard %d: header contradicts the expected read count / buffer size" % (v - 1))
+
+
+def unpack_results(bufs, counts, width, scratch=None):
     """Inverse of pack_result for the gathered per-rank buffers -> one BatchResult (same device) with
-    fixed-stride rows of `width` entries, in global read order."""
+    fixed-stride rows of `width` entries, in global read order.
+
+    On a GPU the shards are unpacked by ONE pair of launches (fcd_unpack_gathered_dev) when `bufs` are
+    consecutive slices of one allocation (as gather_batch_result makes them), into result arrays that `scratch`
+    keeps across calls (rank 0 does not allocate world x B x width x 5 bytes per step)."""
     import torch
 
     n_total = int(sum(counts))
     dev = bufs[0].device
-    # (rows are only defined up to out_len: on a GPU the 5 bytes x width x reads are not cleared first)
-    make = torch.empty if _is_device(bufs[0]) else torch.zeros
-    labels = make((n_total, width), dtype=torch.uint8, device=dev)
-    path = make((n_total, width), dtype=torch.int32, device=dev)
-    out_len = torch.zeros(n_total, dtype=torch.int32, device=dev)
-    status = torch.zeros(n_total, dtype=torch.int32, device=dev)
+    world = len(bufs)
+    on_gpu = _is_device(bufs[0])
+    have = None if scratch is None else scratch.get("result")
+    if have is not None and have.labels.shape == (n_total, width) and have.labels.device == dev:
+        out = have
+    else:
+        # (rows are only defined up to out_len: on a GPU the 5 bytes x width x reads are not cleared first)
+        make = torch.empty if on_gpu else torch.zeros
+        out = BatchResult(make((n_total, width), dtype=torch.uint8, device=dev),
+                          make((n_total, width), dtype=torch.int32, device=dev),
+                          torch.zeros(n_total, dtype=torch.int32, device=dev),
+                          torch.zeros(n_total, dtype=torch.int32, device=dev))
+        if scratch is not None:
+            scratch["result"] = out
+    labels, path, out_len, status = out.labels, out.path, out.out_len, out.status
+    if on_gpu:
+        nbytes = bufs[0].numel()
+        contiguous = all(b.numel() == nbytes and b.data_ptr() == bufs[0].data_ptr() + k * nbytes
+                         for k, b in enumerate(bufs))
+        h = _handle_for(bufs[0])
+        try:
+            key = tuple(int(c) for c in counts)
+            if scratch is not None and scratch.get("first_key") == key and scratch["first"].device == dev:
+                first = scratch["first"]
+            else:
+                first = torch.tensor(np.concatenate([[0], np.cumsum(counts)]), dtype=torch.int64, device=dev)
+                if scratch is not None:
+                    scratch["first"], scratch["first_key"] = first, key
+            offs = torch.empty(n_total + world + 1, dtype=torch.int64, device=dev)
+            bad = scratch.get("bad") if scratch is not None else None
+            if bad is None or bad.device != dev:
+                bad = torch.zeros(1, dtype=torch.int32, device=dev)
+                if scratch is not None:
+                    scratch["bad"] = bad
+            res = _result_struct(out, width)
+            if contiguous:
+                h.check(h.lib.fcd_unpack_gathered_dev(h.ptr, bufs[0].data_ptr(), nbytes, world, first.data_ptr(),
+                                                      n_total, offs.data_ptr(), C.byref(res), bad.data_ptr()))
+            else:  # separate allocations: shard by shard, each as a "world" of one
+                row = 0
+                for k, (buf, B) in enumerate(zip(bufs, counts)):
+                    if B:
+                        view = BatchResult(labels[row:row + B], path[row:row + B], out_len[row:row + B],
+                                           status[row:row + B])
+                        f1 = torch.tensor([0, B], dtype=torch.int64, device=dev)
+                        o1 = torch.empty(B + 2, dtype=torch.int64, device=dev)
+                        r1 = _result_struct(view, width)
+                        h.check(h.lib.fcd_unpack_gathered_dev(h.ptr, buf.data_ptr(), buf.numel(), 1, f1.data_ptr(), B,
+                                                              o1.data_ptr(), C.byref(r1), bad.data_ptr()))
+                    row += B
+            out._keep = (offs, first, bad)
+            if scratch is None:
+                v = int(bad.item())
+                if v:
+                    raise ValueError("gathered shard %d: header contradicts the expected read count / buffer size"
+                                     % (v - 1))
+        finally:
+            h.reset_stream()
+        return out
     row = 0
-    for buf, B in zip(bufs, counts):
+    for k, (buf, B) in enumerate(zip(bufs, counts)):
         if B == 0:
             continue
-        view = BatchResult(labels[row:row + B], path[row:row + B], out_len[row:row + B], status[row:row + B])
-        if _is_device(buf):
-            h = _handle_for(buf)
-            offs = torch.empty(B + 1, dtype=torch.int64, device=dev)
-            res = _result_struct(view, width)
-            h.check(h.lib.fcd_unpack_results_dev(h.ptr, buf.data_ptr(), B, offs.data_ptr(), C.byref(res)))
-            view._keep = offs
-        else:
-            b = buf.numpy()
-            total = int(b[:8].view(np.uint64)[0])
-            n_in = int(b[8:12].view(np.uint32)[0])
-            pb = int(b[12:16].view(np.uint32)[0])
-            assert n_in == B, (n_in, B)
-            lens = b[16:16 + 4 * B].view(np.uint32).copy()
-            out_len[row:row + B] = torch.from_numpy(lens.astype(np.int32))
-            status[row:row + B] = torch.from_numpy(b[16 + 4 * B:16 + 8 * B].view(np.int32).copy())
-            mask = np.arange(width)[None, :] < lens[:, None]
-            lab0 = _HEADER + 8 * B
-            lab = np.zeros((B, width), np.uint8)
-            lab[mask] = b[lab0:lab0 + total]
-            p0 = lab0 + ((total + 3) & ~3)
-            pth = np.zeros((B, width), np.int32)
-            pth[mask] = b[p0:p0 + total * pb].view(np.uint16 if pb == 2 else np.uint32).astype(np.int32)
-            labels[row:row + B] = torch.from_numpy(lab)
-            path[row:row + B] = torch.from_numpy(pth)
+        b = buf.numpy()
+        total, pb = _check_header(b, B, width, b.size, k)
+        lens = b[16:16 + 4 * B].view(np.uint32).copy()
+        if int(lens.sum()) != total or (lens > width).any():
+            raise ValueError("gathered shard %d: lengths do not add up to the header's total" % k)
+        out_len[row:row + B] = torch.from_numpy(lens.astype(np.int32))
+        status[row:row + B] = torch.from_numpy(b[16 + 4 * B:16 + 8 * B].view(np.int32).copy())
+        mask = np.arange(width)[None, :] < lens[:, None]
+        lab0 = _HEADER + 8 * B
+        lab = np.zeros((B, width), np.uint8)
+        lab[mask] = b[lab0:lab0 + total]
+        p0 = lab0 + ((total + 3) & ~3)
+        pth = np.zeros((B, width), np.int32)
+        pth[mask] = b[p0:p0 + total * pb].view(np.uint16 if pb == 2 else np.uint32).astype(np.int32)
+        labels[row:row + B] = torch.from_numpy(lab)
+        path[row:row + B] = torch.from_numpy(pth)
         row += B
-    return BatchResult(labels, path, out_len, status)
+    return out
 
 
 def _to_torch(r):
@@ -187,6 +265,7 @@ def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
 
     rank = dist.get_rank(group)
     world = dist.get_world_size(group)
+    check_gather(scratch)  # the previous call's header check (no extra wait: this call reads a size back anyway)
     r = _to_torch(r)
     W = r.labels.shape[1]
     offsets, total = result_total(r)
@@ -204,18 +283,17 @@ def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
         scratch["send"] = send
     recv = None
     if rank == dst:
-        have = None if scratch is None else scratch.get("bufs")
-        if have is not None and have[0].numel() >= nbytes and have[0].device == send.device and len(have) == world:
-            recv = [b[:nbytes] for b in have]
-        else:
-            full = [torch.empty(nbytes, dtype=torch.uint8, device=send.device) for _ in range(world)]
+        # ONE allocation holds all shards back to back, so that they can be unpacked by one pair of launches
+        have = None if scratch is None else scratch.get("recv")
+        if have is None or have.numel() < nbytes * world or have.device != send.device:
+            have = torch.empty(nbytes * world + nbytes // 4, dtype=torch.uint8, device=send.device)
             if scratch is not None:
-                scratch["bufs"] = full
-            recv = full
+                scratch["recv"] = have
+        recv = [have[k * nbytes:(k + 1) * nbytes] for k in range(world)]
     dist.gather(send, recv, dst=dst, group=group)
     if rank != dst:
         return None
-    return unpack_results(recv, counts, W)
+    return unpack_results(recv, counts, W, scratch=scratch)
 
 
 def decode_sharded(x_local, decode_fn, counts, dst=0, group=None, scratch=None):

@@ -289,6 +289,38 @@ int fcd_pack_results_dev(fcd_handle *h, const fcd_result *res, int64_t n_reads, 
 int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, uint64_t *offsets,
                            const fcd_result *out);
 
+/* ---- the multi-GPU step without Python (csrc/comm.hip) ----------------------------------------
+ * One process per GPU; reads shard across the ranks with no exchange inside the searches; what is left is ONE
+ * gather of every rank's decoded results on a destination rank over RCCL / xGMI.  RCCL is loaded at run time
+ * (dlopen), so single-GPU users never need it.
+ *   fcd_comm_unique_id   rank 0 makes the 128-byte id (ncclGetUniqueId); the host hands it to the other ranks
+ *   fcd_comm_create      ncclCommInitRank on the handle's device (collective: every rank calls it)
+ *   fcd_comm_wrap        use an ncclComm_t the host already owns (passed as void*); NULL is allowed for world = 1
+ *   fcd_gather_results_dev  this rank's `res` (n_reads fixed-stride rows in device memory, e.g. what
+ *                        fcd_beam_search_dev wrote) -> on rank `dst`, `out` receives all ranks' rows in global read
+ *                        order (counts[k] = reads of rank k; out->out_stride >= res->out_stride).  Steps, all on
+ *                        the handle's stream: prefix sums + pack of the used prefixes (u16 times below 65536 rows),
+ *                        an 8-byte ncclAllReduce(MAX) so that all ranks send one size, ONE ncclGather, and on `dst`
+ *                        the unpack of every shard with one pair of launches.  The call waits for the device once
+ *                        (the agreed size: 8 bytes); the gather and the unpack are left in flight on the stream.
+ *   fcd_comm_synchronize waits for the stream and reports a shard whose header contradicted `counts`
+ *                        (FCD_E_INVALID; such a shard's rows are left empty, never read out of bounds). */
+#define FCD_COMM_ID_BYTES 128
+typedef struct fcd_comm fcd_comm;
+int fcd_comm_unique_id(uint8_t id[FCD_COMM_ID_BYTES]);
+int fcd_comm_create(fcd_handle *h, int world, int rank, const uint8_t id[FCD_COMM_ID_BYTES], fcd_comm **out);
+int fcd_comm_wrap(fcd_handle *h, void *nccl_comm, int world, int rank, fcd_comm **out);
+int fcd_comm_destroy(fcd_comm *c);
+int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, const int64_t *counts, int dst,
+                           const fcd_result *out);
+int fcd_comm_synchronize(fcd_comm *c);
+/* The unpack step on its own (what fast_ctc_decode_amd/dist.py calls after torch.distributed's gather):
+ * gathered = world packed shards of `stride` bytes each, back to back; first = DEVICE array [world + 1] of
+ * prefix sums of the per-rank read counts; offsets = DEVICE workspace of first[world] + world u64; bad = DEVICE
+ * int32 that receives 1 + shard for a shard whose header contradicts the counts or the buffer size. */
+int fcd_unpack_gathered_dev(fcd_handle *h, const uint8_t *gathered, int64_t stride, int world, const int64_t *first,
+                            int64_t n_total, uint64_t *offsets, const fcd_result *out, int32_t *bad);
+
 /* ---- coalescing front door for per-read callers (csrc/coalesce.hip) --------------------------------------
  * The reference decodes ONE read per call and releases the GIL around the search so that callers can run it
  * from many threads (src/lib.rs:199 viterbi_search, :353 beam_search).  On a GPU a lone read is one wavefront;

@@ -76,6 +76,7 @@ hipError_t hipHostFree(void *p);
 hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
+hipError_t hipMemset(void *dst, int v, size_t n);
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);

@@ -150,6 +150,36 @@ def test_duplex_config5_shape_sample(fcd):
     assert got == want
 
 
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_config5_full_size(fcd, mode):
+    """BASELINE config 5 at its stated size: 1024 pairs, T1 = T2 = 2000, band +-64, beam 5, threshold 0.1, both
+    log-add modes.  Every pair decodes; reversing the batch reverses the answers (pairs are independent: the
+    property that does not need an oracle); 8 pairs spread over the batch equal the correctly-rounded oracle,
+    strings and tie counters."""
+    torch = pytest.importorskip("torch")
+    n_pairs, T, n_oracle = 1024, 2000, 8
+    x1, x2 = pairs(4, n_pairs, T, T)
+    env = band(T, T, 64)
+    x1d, x2d = torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()
+    envd = torch.from_numpy(np.broadcast_to(env, (n_pairs, T, 2)).copy().view(np.int64)).cuda()
+    r = fcd.beam_search_duplex_batch_raw(x1d, x2d, envd, 5, 0.1, True, logadd_mode=mode, count_ambiguous=True).cpu()
+    assert (np.asarray(r.status) == 0).all()
+    rev = fcd.beam_search_duplex_batch_raw(x1d.flip(0).contiguous(), x2d.flip(0).contiguous(), envd, 5, 0.1, True,
+                                           logadd_mode=mode).cpu()
+    assert np.array_equal(np.asarray(rev.out_len)[::-1], np.asarray(r.out_len))
+    lens = np.asarray(r.out_len).astype(np.int64)
+    mask = np.arange(r.labels.shape[1])[None, :] < lens[:, None]
+    assert np.array_equal(np.where(mask, r.labels, 0), np.where(mask, np.asarray(rev.labels)[::-1], 0))
+    for i in np.linspace(0, n_pairs - 1, n_oracle).astype(np.int64):
+        want = oracle.beam_search_duplex(x1[i], x2[i], "NACGT", env, 5, 0.1, True, mode | CR)
+        assert "".join("NACGT"[l] for l in r.labels[i, :lens[i]]) == want, i
+        assert tuple(int(v) for v in r.ambiguous[i]) == oracle.duplex_last_ambiguous(), i
+    amb = np.asarray(r.ambiguous)
+    print("config 5 %s: pairs with a > 20-candidate kept tie %d, with a result-changing tie %d, both %d of %d"
+          % ("max" if mode == MAX else "logsumexp", int((amb[:, 0] > 0).sum()), int((amb[:, 1] > 0).sum()),
+             int(((amb[:, 0] > 0) & (amb[:, 1] > 0)).sum()), n_pairs))
+
+
 def test_duplex_wobbly_envelope_exact(fcd):
     """Envelopes whose bounds do not slide monotonically (lower bound moving back, upper bound
     jumping by several rows, plateaus) exercise both the incremental and the rescanning paths of
