@@ -527,6 +527,11 @@ def main():
             "e2e": e2e,
             "viterbi_roofline": vit,
         }
+        try:  # RCCL's start-up banner sits in C stdio's buffer: push it out so that the JSON line comes LAST
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if distributed:
         dist.barrier()

@@ -374,7 +374,9 @@ const char *fcd_status_string(int status) {
         case FCD_ST_RAN_OUT_OF_BEAM: return "Ran out of search space (beam_cut_threshold too high)";
         case FCD_ST_INCOMPARABLE: return "Failed to compare values (NaNs in input?)";
         case FCD_ST_INVALID_ENVELOPE: return "Invalid envelope values";
-        case FCD_ST_BAD_STATE: return "CRF state or init_state out of range (the reference would abort)";
+        case FCD_ST_BAD_STATE:
+            return "the reference would abort on this input (CRF state or init_state out of range, or an envelope whose "
+                   "upper bound moves back below a beam entry's window)";
         case FCD_ST_INTERNAL: return "internal error: tree arena exhausted";
         default: return "unknown status";
     }

@@ -487,6 +487,9 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     mx = part;
                     if (lane == 0) rlo[node] = lo;
                 }
+                // `assert!(current_end < upper_bound)` (:363-366, :311-314): a window that already reaches the new
+                // bound -- the envelope's upper bound moved back and then forward by less -- aborts the reference
+                if (ballot(end >= hi) != 0ull) return fail(FCD_ST_BAD_STATE);  // (a vote: every lane has read `end`)
                 // continue the recurrence from the stored end (:361-386); wave-uniform work
                 float l_lab = kNegInf, l_gap = kNegInf, l_sum = kNegInf;
                 if (end > off) {

@@ -60,7 +60,10 @@ enum {
     FCD_ST_RAN_OUT_OF_BEAM = 1,   /* "Ran out of search space (beam_cut_threshold too high)" */
     FCD_ST_INCOMPARABLE = 2,      /* "Failed to compare values (NaNs in input?)" */
     FCD_ST_INVALID_ENVELOPE = 3,  /* "Invalid envelope values" */
-    FCD_ST_BAD_STATE = 4,         /* CRF state index left [0,S): the reference panics (aborts) */
+    FCD_ST_BAD_STATE = 4,         /* the reference panics (aborts the process) here: a CRF state index outside [0,S),
+                                     NaN / out-of-range init_state, or -- duplex -- an envelope whose upper bound moves
+                                     back and then forward by less than a beam entry's window already covers
+                                     (assert!(current_end < upper_bound), src/duplex.rs:363-366) */
     FCD_ST_INTERNAL = 5           /* tree arena exhausted -- a bug in workspace sizing */
 };
 

@@ -1201,14 +1201,19 @@ static secprobs sec_build(const lognet *n2, const secprobs *parent, int64_t labe
 }
 
 /* extend_secondary_probs :338-387 / crf_extend_secondary_probs :293-336 */
-static void sec_extend(secprobs *s, const lognet *n2, const secprobs *parent, int64_t label,
-                       int is_repeat, int64_t tstate, int64_t lower, int64_t upper, int mode) {
+/* Returns 0, or -1 where the reference panics: `assert!(current_end < upper_bound)` (:363-366, :311-314) fails
+ * for a beam entry whose window already reaches the new bound -- possible only after the envelope's upper bound
+ * moved BACK (last_upper_bound is the previous row's bound, not the largest seen, :524) and forward again by less.
+ * (Found by tests/test_naive_crosscheck.py: rounds 1 and 2 of this restatement skipped the extension silently.) */
+static int sec_extend(secprobs *s, const lognet *n2, const secprobs *parent, int64_t label,
+                      int is_repeat, int64_t tstate, int64_t lower, int64_t upper, int mode) {
     if (lower > s->offset) { /* :351-359 */
         sec_discard_until(s, lower - 1);
         if (s->len == 0) s->offset = lower;
         s->max_prob = pairs_update_max(s->probs, s->len, s->offset, lower, upper, mode);
     }
     int64_t current_end = s->offset + s->len;
+    if (current_end >= upper) return -1;
     ppair last = s->len > 0 ? s->probs[s->len - 1] : PP_ZERO;
     for (int64_t idx = current_end; idx < upper; ++idx) {
         last = sec_step(lognet_row(n2, idx, tstate), last, sec_get(parent, idx - 1), label,
@@ -1216,6 +1221,7 @@ static void sec_extend(secprobs *s, const lognet *n2, const secprobs *parent, in
         sec_push(s, last);
         s->max_prob = lmax(s->max_prob, LADD(last.label, last.gap));
     }
+    return 0;
 }
 
 typedef struct { /* duplex SearchPoint :128-150 */
@@ -1351,7 +1357,10 @@ static int duplex_core(const lognet *n1, const lognet *n2, int crf, int64_t init
                 } else {
                     is_repeat = (par >= 0 && tree->label[par] == lab); /* :512 */
                 }
-                sec_extend(&data.v[node], n2, pp, lab, is_repeat, tstate, lower_t, upper_t, mode);
+                if (sec_extend(&data.v[node], n2, pp, lab, is_repeat, tstate, lower_t, upper_t, mode) != 0) {
+                    status = FCDO_PANIC;
+                    break;
+                }
             }
             if (status != FCDO_OK) break;
         }

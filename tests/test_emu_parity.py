@@ -87,6 +87,8 @@ def test_duplex(fcd):
     D.test_duplex_banded_exact(fcd, D.MAX, False)
     D.test_duplex_envelope_errors_and_edges(fcd)
     D.test_duplex_shapes_exact(fcd, 3, 3)
+    D.test_duplex_receding_upper_bound(fcd, D.LSE)
+    D.test_duplex_tie_counters(fcd, D.MAX)
     from oracle import oracle
     x1, i1, x2, i2 = D.crf_pairs(405, 70, 64)   # duplex::crf_beam_search, banded
     env = D.band(70, 64, 20)

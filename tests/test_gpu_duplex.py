@@ -204,6 +204,43 @@ def test_duplex_wobbly_envelope_exact(fcd):
         assert got == want
 
 
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_receding_upper_bound(fcd, mode):
+    """The reference keeps the PREVIOUS row's upper bound (src/duplex.rs:524), not the largest seen: after the bound
+    moved back, moving forward again by less than a beam entry's window already covers trips
+    `assert!(current_end < upper_bound)` (:363-366) and aborts.  The oracle reports that as a panic (found by the
+    naive cross-check, tests/test_naive_crosscheck.py), the kernels as FCD_ST_BAD_STATE; envelopes that recede
+    without tripping the assertion decode to the oracle's strings."""
+    n, T = 16, 60
+    x1, x2 = pairs(77 + mode, n, T, T)
+    rng = np.random.default_rng(5)
+    envs = np.zeros((n, T, 2), np.uint64)
+    for p in range(n):
+        base = np.minimum(T, np.arange(T) + 7)
+        hi = base.copy()
+        for t in rng.choice(np.arange(3, T - 12), 3, replace=False):
+            hi[t] = base[t - 1] - 1                      # the bound moves back by one row ...
+            if p % 2:
+                hi[t + 1] = base[t - 1]                  # ... and returns to where the windows already end: abort
+        envs[p, :, 0] = np.maximum(0, np.arange(T) - 6)
+        envs[p, :, 1] = hi
+    r = fcd.beam_search_duplex_batch_raw(x1, x2, envs, 5, 0.05, True, logadd_mode=mode).cpu()
+    panics = 0
+    for i in range(n):
+        try:
+            want = oracle.beam_search_duplex(x1[i], x2[i], "NACGT", envs[i], 5, 0.05, True, mode | CR)
+            assert int(r.status[i]) == 0, i
+            assert "".join("NACGT"[l] for l in r.labels[i, :int(r.out_len[i])]) == want, i
+        except RuntimeError as e:
+            assert "panic" in str(e), e
+            assert int(r.status[i]) == fcd.api.nat.ST_BAD_STATE, i
+            panics += 1
+    assert 0 < panics < n  # both outcomes occur
+    with pytest.raises(RuntimeError, match="the reference would abort"):
+        bad = [i for i in range(n) if int(r.status[i]) != 0][0]
+        fcd.beam_search_duplex(x1[bad], x2[bad], "NACGT", envs[bad], 5, 0.05, logadd_mode=mode)
+
+
 def test_duplex_wide_band_unstaged_path(fcd):
     """A band too wide for the LDS tile (beam 16, +-300 rows) takes the HBM-only path."""
     x1, x2 = pairs(360, 2, 400, 400)
