@@ -261,13 +261,16 @@ def valu_issue_roofline(kernel_prefix, kernel_ms, n_simd, clock_hz=2.4e9):
     return None
 
 
-def viterbi_roofline(fcd, torch, dev, n_reads=16384, reps=5):
+def viterbi_roofline(fcd, torch, dev, n_reads=16384, reps=5, half=False):
     """The HBM-bound kernel of the path: viterbi_search on n_reads x T x N,
-    timed with the C ABI's HIP events."""
+    timed with the C ABI's HIP events.  half: the same reads as float16 -- what basecaller networks emit -- read
+    directly by the kernel (fcd_batch.dtype), algorithmic bytes counted at two bytes per posterior."""
     g = torch.Generator(device=dev)
     g.manual_seed(7)
     x = torch.rand((n_reads, T, N), generator=g, device=dev, dtype=torch.float32)
     x /= torch.linalg.vector_norm(x, ord=2, dim=-1, keepdim=True)
+    if half:
+        x = x.to(torch.float16)
     r = fcd.viterbi_search_batch_raw(x)
     torch.cuda.synchronize()
     h = r._handle
@@ -277,11 +280,12 @@ def viterbi_roofline(fcd, torch, dev, n_reads=16384, reps=5):
     torch.cuda.synchronize()
     ms, calls = h.timing_mean_ms()
     mean_L = float(r.out_len.float().mean())
-    bytes_per_read = T * N * 4 + 5.0 * mean_L
+    bytes_per_read = T * N * (2 if half else 4) + 5.0 * mean_L
     achieved = n_reads * bytes_per_read / (ms * 1e-3) / 1e9
-    traffic, note = pmc_traffic("viterbi_stream_kernel")
+    traffic, note = pmc_traffic("viterbi_stream_kernel<5, 1" if half else "viterbi_stream_kernel<5, 0")
     return {
-        "kernel": "viterbi_stream_kernel<5> (search::viterbi_search)", "bound": "hbm",
+        "kernel": "viterbi_stream_kernel<5, %s> (search::viterbi_search)" % ("f16" if half else "f32"), "bound": "hbm",
+        "input_dtype": "f16" if half else "f32",
         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
         "traffic": traffic, "traffic_source": note,
         "reads": n_reads, "kernel_ms": ms, "launches_timed": calls,
@@ -468,6 +472,7 @@ def main():
                 "note": "a read with either counter at 0 is pinned to the reference; the others are settled by the "
                         "oracle's exhaustive tie replay (tests/test_gpu_fullsize.py::test_config2_tie_instrument)"}
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
+        vit16 = viterbi_roofline(fcd, torch, dev, half=True) if not args.no_viterbi else None
         valu = valu_issue_roofline(prefix, k_ms, simds) if default_shape else None
         e2e = None
         if world == 1 and not args.no_e2e and args.streams == 1:
@@ -526,6 +531,7 @@ def main():
             "cpu_baseline": cpu,
             "e2e": e2e,
             "viterbi_roofline": vit,
+            "viterbi_roofline_f16": vit16,
         }
         try:  # RCCL's start-up banner sits in C stdio's buffer: push it out so that the JSON line comes LAST
             import ctypes

@@ -16,6 +16,7 @@ E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
 ST_OK, ST_RAN_OUT_OF_BEAM, ST_INCOMPARABLE, ST_INVALID_ENVELOPE, ST_BAD_STATE, ST_INTERNAL = range(6)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE1, KERNEL_LANE = 0, 1, 2, 3, 4
 LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
+DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 
 # every symbol include/fcd.h declares (tests/test_capi_symbols.py checks the .so against this
 # list AND against the header text)
@@ -47,7 +48,7 @@ class Batch(C.Structure):
     _fields_ = [
         ("post", C.c_void_p), ("n_reads", C.c_int64), ("T", C.c_int64), ("S", C.c_int64),
         ("N", C.c_int64), ("stride_read", C.c_int64), ("stride_t", C.c_int64),
-        ("stride_s", C.c_int64), ("stride_n", C.c_int64), ("lengths", C.c_void_p),
+        ("stride_s", C.c_int64), ("stride_n", C.c_int64), ("lengths", C.c_void_p), ("dtype", C.c_int32),
     ]
 
 

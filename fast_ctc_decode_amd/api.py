@@ -127,8 +127,23 @@ class _HostOut:
             self.status.ctypes.data, w, self.ambiguous.ctypes.data if want_amb else None)
 
 
-def _host_batch(x, crf, lengths=None):
-    """x: (B,T,N) or (B,T,S,N) numpy f32 view -> nat.Batch (keeps x alive via the caller)."""
+def _np_dtype_code(x, input_dtype=None):
+    """float32 / float16 arrays carry their type; bfloat16 (numpy has none) travels as uint16 bit patterns with
+    input_dtype="bfloat16"."""
+    if input_dtype in ("bfloat16", nat.DTYPE_BF16):
+        if x.dtype != np.uint16:
+            raise TypeError("bfloat16 posteriors are passed as a uint16 array of bit patterns")
+        return nat.DTYPE_BF16
+    if x.dtype == np.float32:
+        return nat.DTYPE_F32
+    if x.dtype == np.float16:
+        return nat.DTYPE_F16
+    raise TypeError("expected a float32 or float16 array, got %s" % x.dtype)
+
+
+def _host_batch(x, crf, lengths=None, input_dtype=None):
+    """x: (B,T,N) or (B,T,S,N) numpy view (float32, float16, or uint16 bfloat16 bits) -> nat.Batch (the caller
+    keeps x alive)."""
     st = _estrides(x)
     if crf:
         B, T, S, N = x.shape
@@ -138,6 +153,7 @@ def _host_batch(x, crf, lengths=None):
         b = nat.Batch(x.ctypes.data, B, T, 1, N, st[0], st[1], 0, st[2], None)
     if lengths is not None:
         b.lengths = lengths.ctypes.data
+    b.dtype = _np_dtype_code(x, input_dtype)
     return b
 
 
@@ -374,12 +390,7 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
     if _is_torch_cuda(network_outputs_1):
         import torch
         x1, x2 = network_outputs_1, network_outputs_2
-        if x1.dtype in (torch.float16, torch.bfloat16):
-            x1 = x1.float()
-        if x2.dtype in (torch.float16, torch.bfloat16):
-            x2 = x2.float()
-        if x1.dtype != torch.float32 or x2.dtype != torch.float32:
-            raise TypeError("device posteriors must be float32 (float16 / bfloat16 are upcast)")
+        d1, d2 = _torch_dtype_code(x1), _torch_dtype_code(x2)
         B, T1, N = x1.shape
         T2 = x2.shape[1]
         dev = x1.device
@@ -391,8 +402,8 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
             env = envelopes.contiguous()  # int64 tensor holding the u64 bit patterns
         h = nat.default_handle(dev.index or 0)
         s1, s2 = x1.stride(), x2.stride()
-        b1 = nat.Batch(x1.data_ptr(), B, T1, 1, N, s1[0], s1[1], 0, s1[2], None)
-        b2 = nat.Batch(x2.data_ptr(), B, T2, 1, N, s2[0], s2[1], 0, s2[2], None)
+        b1 = nat.Batch(x1.data_ptr(), B, T1, 1, N, s1[0], s1[1], 0, s1[2], None, d1)
+        b2 = nat.Batch(x2.data_ptr(), B, T2, 1, N, s2[0], s2[1], 0, s2[2], None, d2)
         keep = [x1, x2, env]
         if lengths_1 is not None:
             l1 = torch.as_tensor(lengths_1, dtype=torch.int64, device=dev).contiguous()
@@ -550,12 +561,7 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
     if _is_torch_cuda(network_outputs_1):
         import torch
         x1, x2 = network_outputs_1, network_outputs_2
-        if x1.dtype in (torch.float16, torch.bfloat16):
-            x1 = x1.float()
-        if x2.dtype in (torch.float16, torch.bfloat16):
-            x2 = x2.float()
-        if x1.dtype != torch.float32 or x2.dtype != torch.float32:
-            raise TypeError("device posteriors must be float32 (float16 / bfloat16 are upcast)")
+        d1, d2 = _torch_dtype_code(x1), _torch_dtype_code(x2)
         B, T1, S, N = x1.shape
         T2 = x2.shape[1]
         dev = x1.device
@@ -571,8 +577,8 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
             env = envelopes.contiguous()
         h = nat.default_handle(dev.index or 0)
         s1, s2 = x1.stride(), x2.stride()
-        b1 = nat.Batch(x1.data_ptr(), B, T1, S, N, s1[0], s1[1], s1[2], s1[3], None)
-        b2 = nat.Batch(x2.data_ptr(), B, T2, S, N, s2[0], s2[1], s2[2], s2[3], None)
+        b1 = nat.Batch(x1.data_ptr(), B, T1, S, N, s1[0], s1[1], s1[2], s1[3], None, d1)
+        b2 = nat.Batch(x2.data_ptr(), B, T2, S, N, s2[0], s2[1], s2[2], s2[3], None, d2)
         keep = [x1, x2, env, i1, i2]
         if lengths_1 is not None:
             l1 = torch.as_tensor(lengths_1, dtype=torch.int64, device=dev).contiguous()
@@ -721,26 +727,31 @@ class BatchResult:
         return out
 
 
+def _torch_dtype_code(x):
+    import torch
+    code = {torch.float32: nat.DTYPE_F32, torch.float16: nat.DTYPE_F16, torch.bfloat16: nat.DTYPE_BF16}.get(x.dtype)
+    if code is None:
+        raise TypeError("device posteriors must be float32, float16 or bfloat16")
+    return code
+
+
 def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path=True,
                 need_status=True, handle=None, want_amb=False):
     import torch
 
-    if x.dtype in (torch.float16, torch.bfloat16):
-        # half-precision posteriors (what basecaller networks emit): upcast on the device -- exact, so
-        # the result is the reference's on the upcast matrix; the kernels themselves compute in f32
-        x = x.float()
-    if x.dtype != torch.float32:
-        raise TypeError("device posteriors must be float32 (float16 / bfloat16 are upcast)")
+    # half-precision posteriors (what basecaller networks emit) are read as they are: the kernels convert in
+    # registers while loading -- exactly, so the result is the reference's on the upcast matrix -- and compute in f32
+    dcode = _torch_dtype_code(x)
     dev = x.device.index or 0
     h = handle if handle is not None else nat.default_handle(dev)
     if crf:
         B, T, S, N = x.shape
         st = x.stride()
-        b = nat.Batch(x.data_ptr(), B, T, S, N, st[0], st[1], st[2], st[3], None)
+        b = nat.Batch(x.data_ptr(), B, T, S, N, st[0], st[1], st[2], st[3], None, dcode)
     else:
         B, T, N = x.shape
         st = x.stride()
-        b = nat.Batch(x.data_ptr(), B, T, 1, N, st[0], st[1], 0, st[2], None)
+        b = nat.Batch(x.data_ptr(), B, T, 1, N, st[0], st[1], 0, st[2], None, dcode)
     if lengths is not None:
         lengths = torch.as_tensor(lengths, dtype=torch.int64, device=x.device).contiguous()
         b.lengths = lengths.data_ptr()
@@ -768,8 +779,8 @@ def _stack_host(x, ndim):
         a = x
     else:
         a = np.stack([np.asarray(v) for v in x])
-    if a.dtype != np.float32 or a.ndim != ndim:
-        raise TypeError("expected a float32 array of rank %d" % ndim)
+    if a.dtype not in (np.float32, np.float16, np.uint16) or a.ndim != ndim:
+        raise TypeError("expected a float32 (or float16 / bfloat16-bits uint16) array of rank %d" % ndim)
     return _dense(a)
 
 
@@ -815,7 +826,7 @@ def _device_tensor(x):
 
 def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
                           collapse_repeats=True, lengths=None, kernel=nat.KERNEL_AUTO, handle=None,
-                          count_ambiguous=False):
+                          count_ambiguous=False, input_dtype=None):
     """Decode a (B,T,N) batch with search::beam_search semantics; returns a BatchResult.
     `handle` (device tensors only): an explicit fast_ctc_decode_amd._native.Handle -- one per
     concurrent torch stream, since a handle owns the tree-arena workspace its kernels use.
@@ -833,7 +844,7 @@ def beam_search_batch_raw(network_outputs, beam_size=5, beam_cut_threshold=0.0,
     h = nat.default_handle()
     out = _HostOut(B, T, want_amb=count_ambiguous)
     l = _np_lengths(lengths, B)
-    b = _host_batch(x, False, l)
+    b = _host_batch(x, False, l, input_dtype)
     h.check(h.lib.fcd_beam_search_host(h.ptr, C.byref(b), int(beam_size), float(beam_cut_threshold),
                                        int(bool(collapse_repeats)), int(kernel), C.byref(out.res)))
     return BatchResult(out.labels, out.path, out.out_len, out.status, ambiguous=out.ambiguous)
@@ -853,7 +864,7 @@ def beam_search_batch(network_outputs, alphabet, beam_size=5, beam_cut_threshold
     return r.sequences(alpha, paths=paths)
 
 
-def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=None, qual=False):
+def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=None, qual=False, input_dtype=None):
     dev_x = _device_tensor(network_outputs)
     if dev_x is not None:
         return _torch_call("fcd_viterbi_search_dev", dev_x, False, lengths,
@@ -864,7 +875,7 @@ def viterbi_search_batch_raw(network_outputs, collapse_repeats=True, lengths=Non
     h = nat.default_handle()
     out = _HostOut(B, T, want_qual=qual)
     l = _np_lengths(lengths, B)
-    b = _host_batch(x, False, l)
+    b = _host_batch(x, False, l, input_dtype)
     h.check(h.lib.fcd_viterbi_search_host(h.ptr, C.byref(b), int(bool(collapse_repeats)),
                                           C.byref(out.res)))
     return BatchResult(out.labels, out.path, out.out_len, out.status, out.qual)

@@ -161,7 +161,8 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         int64_t t = p.in.lengths[r];
         T = t < 0 ? 0 : (t < T ? t : T);
     }
-    const float *post = p.in.post + r * p.in.stride_read;
+    const int dt = p.in.dtype;
+    const float *post = post_at(p.in.post, r * p.in.stride_read, dt);
     const int64_t st_t = p.in.stride_t, st_s = p.in.stride_s, st_n = p.in.stride_n;
     int4 *rec = p.arena.rec + (int64_t)blockIdx.x * p.arena.cap_nodes;
     int32_t *rows = p.arena.rows + (int64_t)blockIdx.x * p.arena.cap_nodes * NL;
@@ -199,11 +200,11 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
     }
     for (int j = lane; j < NL; j += kWave) L.b_child(0)[j] = -1;
     if (!crf && T > 0)
-        for (int j = lane; j < N; j += kWave) L.row[j] = post[j * st_n];
+        for (int j = lane; j < N; j += kWave) L.row[j] = load_post(post, j * st_n, dt);
     // row t+1 travels in a register while step t runs, so its HBM latency is never waited for
     // (alphabets above 64 labels fall back to loading it when it is needed)
     const bool row_in_reg = !crf && N <= kWave;
-    float next_row = (row_in_reg && lane < N && T > 1) ? post[st_t + lane * st_n] : 0.0f;
+    float next_row = (row_in_reg && lane < N && T > 1) ? load_post(post, st_t + lane * st_n, dt) : 0.0f;
     wave_sync();
 
     int nn = 0;  // nodes in this read's tree (wave-uniform)
@@ -216,7 +217,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         int *b_state = L.b_state(cur), *b_depth = L.b_depth(cur), *b_child = L.b_child(cur);
         float *b_lp = L.b_lp(cur), *b_gp = L.b_gp(cur);
         const int nslots = B * N;
-        const float *frame = post + t * st_t;
+        const float *frame = post_at(post, t * st_t, dt);
 
         int n_valid = 0;
         bool any_nan = false, bad_state = false;
@@ -259,7 +260,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                     bad_state = true;
                 } else if (k == 0) {
                     // the entry's own node: blank (:191-198) + repeat-stay (:206-211)
-                    const float pr0 = crf ? frame[st * st_s] : L.row[0];
+                    const float pr0 = crf ? load_post(frame, st * st_s, dt) : L.row[0];
                     const bool blank = pr0 > thr;
                     cgp = blank ? (lp + gp) * pr0 : 0.0f;
                     bool stay = !crf && collapse && tip >= 0;
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                         if (crf && (stj < 0 || stj >= S)) {
                             bad_state = true;
                         } else {
-                            const float pl = crf ? frame[stj * st_s + (tip + 1) * st_n] : L.row[tip + 1];
+                            const float pl = crf ? load_post(frame, stj * st_s + (tip + 1) * st_n, dt) : L.row[tip + 1];
                             if (!(pl < thr)) {  // :201 skip only if pr_b < thr
                                 const bool rep = !crf && collapse && b_tip[j] == tip;
                                 const float lpj = b_lp[j], gpj = b_gp[j];
@@ -291,7 +292,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                 } else {
                     // child by label k-1 (:200-239 / crf :84-99)
                     const int l = k - 1;
-                    const float pk = crf ? frame[st * st_s + k * st_n] : L.row[k];
+                    const float pk = crf ? load_post(frame, st * st_s + k * st_n, dt) : L.row[k];
                     const bool pass = !(pk < thr);
                     const bool rep = !crf && collapse && l == tip;
                     const float contrib = rep ? gp * pk : (lp + gp) * pk;
@@ -528,9 +529,9 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
         }
         if (row_in_reg) {
             if (lane < N) L.row[lane] = next_row;
-            next_row = (lane < N && t + 2 < T) ? post[(t + 2) * st_t + lane * st_n] : 0.0f;
+            next_row = (lane < N && t + 2 < T) ? load_post(post, (t + 2) * st_t + lane * st_n, dt) : 0.0f;
         } else if (!crf && t + 1 < T) {
-            for (int j = lane; j < N; j += kWave) L.row[j] = post[(t + 1) * st_t + j * st_n];
+            for (int j = lane; j < N; j += kWave) L.row[j] = load_post(post, (t + 1) * st_t + j * st_n, dt);
         }
         B = Bn;
         cur = nxt;

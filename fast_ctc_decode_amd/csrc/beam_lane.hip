@@ -176,7 +176,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     int Tmax = T;
     if (RPW == 2) Tmax = max(Tmax, __shfl_xor(Tmax, 32));
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
-    const float *post = p.in.post + r * p.in.stride_read;
+    const int dt = p.in.dtype;
+    const float *post = post_at(p.in.post, r * p.in.stride_read, dt);
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
     int64_t slab = has_read ? local : 0;
     if (RPW == 1 && p.arena.retry_counter) {
@@ -258,7 +259,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     const bool f_lane = q < RPR * N;
     auto load_block = [&](int blk) -> float {
         const int row = blk * RPR + fg;
-        return (f_lane && row < T) ? post[(int64_t)row * st_t + fc * st_n] : 0.0f;
+        return (f_lane && row < T) ? load_post(post, (int64_t)row * st_t + fc * st_n, dt) : 0.0f;
     };
     float win[kFifo];
 #pragma unroll
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     float rowv[N];
 #pragma unroll
     for (int c = 0; c < N; ++c)
-        rowv[c] = (CRF && T > 0) ? post[(int64_t)state * st_s + c * st_n] : 0.0f;
+        rowv[c] = (CRF && T > 0) ? load_post(post, (int64_t)state * st_s + c * st_n, dt) : 0.0f;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see beam_wave.hip
 
     for (int t = 0; t < Tmax; ++t) {
@@ -697,7 +698,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             if (q < Bn) state = rb.w;
 #pragma unroll
             for (int c = 0; c < N; ++c)   // in flight during the divisions below
-                rowv[c] = t + 1 < T ? post[(int64_t)(t + 1) * st_t + (int64_t)state * st_s + c * st_n] : 0.0f;
+                rowv[c] = t + 1 < T ? load_post(post, (int64_t)(t + 1) * st_t + (int64_t)state * st_s + c * st_n, dt) : 0.0f;
         }
         const float top = __int_as_float(r0.x) + __int_as_float(r0.y);  // beam[0].probability() :278
         if (q < Bn) {

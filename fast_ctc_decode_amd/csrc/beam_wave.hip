@@ -188,7 +188,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
 
-    const float *post = p.in.post + r * p.in.stride_read;
+    const int dt = p.in.dtype;  // element type of the posteriors (f32 / f16 / bf16: converted exactly on load)
+    const float *post = post_at(p.in.post, r * p.in.stride_read, dt);
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
     // Arena addressing: a wave-uniform base (the slab of the wavefront's first read: scalar registers) plus a
     // 32-bit element offset per lane (the second read's slab starts cap_nodes elements further on), so that
@@ -245,7 +246,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const bool f_lane = q < RPR * E;
     auto load_block = [&](int blk) -> float {
         const int row = blk * RPR + fg;
-        return (f_lane && row < T) ? post[(int64_t)row * st_t + fs * st_s + fc * st_n] : 0.0f;
+        return (f_lane && row < T) ? load_post(post, (int64_t)row * st_t + fs * st_s + fc * st_n, dt) : 0.0f;
     };
     float win[kFifo];
 #pragma unroll
@@ -260,7 +261,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const int s_mask = GATHER ? (int)p.in.S - 1 : 0;
     const int kcol = is_child ? k : 0;
     auto gather_row = [&](int tt) -> float {
-        return tt < T ? post[(int64_t)tt * st_t + (int64_t)state * st_s + kcol * st_n] : 0.0f;
+        return tt < T ? load_post(post, (int64_t)tt * st_t + (int64_t)state * st_s + kcol * st_n, dt) : 0.0f;
     };
     float rowv = GATHER ? gather_row(0) : 0.0f;
     // Drain the prologue loads HERE, with a wait the compiler's scoreboard sees: otherwise the loop

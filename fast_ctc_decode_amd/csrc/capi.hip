@@ -72,6 +72,8 @@ int check_batch(fcd_handle *h, const fcd_batch *in, bool crf) {
     if (in->n_reads > 0 && in->T > 0 && !in->post) return fail(h, FCD_E_INVALID, "null post");
     if (in->N > 256) return fail(h, FCD_E_UNSUPPORTED, "alphabets above 256 labels are unsupported (u8 labels)");
     if (in->T >= (1ll << 28)) return fail(h, FCD_E_UNSUPPORTED, "T must be < 2^28");
+    if (in->dtype != FCD_DTYPE_F32 && in->dtype != FCD_DTYPE_F16 && in->dtype != FCD_DTYPE_BF16)
+        return fail(h, FCD_E_INVALID, "unknown posterior dtype");
     if (crf && in->S < 1) return fail(h, FCD_E_INVALID, "S must be >= 1");
     return FCD_OK;
 }
@@ -97,6 +99,7 @@ BatchDesc to_desc(const fcd_batch *in, bool crf) {
     d.stride_n = in->stride_n;
     d.S = crf ? (int)in->S : 1;
     d.N = (int)in->N;
+    d.dtype = in->dtype;
     return d;
 }
 
@@ -592,9 +595,9 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     float *ln2 = ln1 + n1;
     int *d_width = reinterpret_cast<int *>(ln2 + n2);
     Timer tm(h);
-    FCD_HIP(h, launch_ln_convert(in1->post, B, in1->T, S, N, in1->stride_read, in1->stride_t,
+    FCD_HIP(h, launch_ln_convert(in1->post, in1->dtype, B, in1->T, S, N, in1->stride_read, in1->stride_t,
                                  is_crf ? in1->stride_s : 0, in1->stride_n, ln1, h->stream));
-    FCD_HIP(h, launch_ln_convert(in2->post, B, in2->T, S, N, in2->stride_read, in2->stride_t,
+    FCD_HIP(h, launch_ln_convert(in2->post, in2->dtype, B, in2->T, S, N, in2->stride_read, in2->stride_t,
                                  is_crf ? in2->stride_s : 0, in2->stride_n, ln2, h->stream));
     FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), h->stream));
     FCD_HIP(h, launch_env_width(envelope, B, env_stride, in1->T, in2->T, in1->lengths,
@@ -704,7 +707,8 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
         used = off + std::max<size_t>(bytes, 8);
         return off;
     };
-    const size_t o1 = reserve(e1 * 4), o2 = reserve(e2 * 4), oe = reserve(n_env * 8);
+    const size_t z1 = in1->dtype == FCD_DTYPE_F32 ? 4 : 2, z2 = in2->dtype == FCD_DTYPE_F32 ? 4 : 2;
+    const size_t o1 = reserve(e1 * z1), o2 = reserve(e2 * z2), oe = reserve(n_env * 8);
     const size_t ol1 = reserve(in1->lengths ? (size_t)B * 8 : 0);
     const size_t ol2 = reserve(in2->lengths ? (size_t)B * 8 : 0);
     const size_t oi1 = reserve(ni1 * 4), oi2 = reserve(ni2 * 4);
@@ -715,8 +719,8 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
         int rc = ensure(h, &h->stage, &h->stage_bytes, used);
         if (rc) return rc;
         char *base = reinterpret_cast<char *>(h->stage);
-        if (e1) FCD_HIP(h, hipMemcpyAsync(base + o1, in1->post, e1 * 4, hipMemcpyHostToDevice, h->stream));
-        if (e2) FCD_HIP(h, hipMemcpyAsync(base + o2, in2->post, e2 * 4, hipMemcpyHostToDevice, h->stream));
+        if (e1) FCD_HIP(h, hipMemcpyAsync(base + o1, in1->post, e1 * z1, hipMemcpyHostToDevice, h->stream));
+        if (e2) FCD_HIP(h, hipMemcpyAsync(base + o2, in2->post, e2 * z2, hipMemcpyHostToDevice, h->stream));
         FCD_HIP(h, hipMemcpyAsync(base + oe, envelope, n_env * 8, hipMemcpyHostToDevice, h->stream));
         if (in1->lengths)
             FCD_HIP(h, hipMemcpyAsync(base + ol1, in1->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
@@ -997,7 +1001,8 @@ int host_upload(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, con
         used = off + std::max<size_t>(bytes, 4);
         return off;
     };
-    st->o_in = reserve(st->n_in * 4);
+    const size_t esz = in->dtype == FCD_DTYPE_F32 ? 4 : 2;  // bytes per posterior element
+    st->o_in = reserve(st->n_in * esz);
     st->o_len = reserve(in->lengths ? (size_t)B * 8 : 0);
     st->o_init = reserve(st->n_init * 4);
     st->o_lab = reserve(st->n_out);
@@ -1027,13 +1032,13 @@ int host_upload(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, con
             h->pin_bytes = want;
         }
         char *pin = reinterpret_cast<char *>(h->pin);
-        if (st->n_in) memcpy(pin + st->o_in, in->post, st->n_in * 4);
+        if (st->n_in) memcpy(pin + st->o_in, in->post, st->n_in * esz);
         if (in->lengths) memcpy(pin + st->o_len, in->lengths, (size_t)B * 8);
         if (crf) memcpy(pin + st->o_init, c.init, st->n_init * 4);
         FCD_HIP(h, hipMemcpyAsync(base, pin, st->o_lab, hipMemcpyHostToDevice, h->stream));  // inputs lie before o_lab
     } else {
         if (st->n_in)
-            FCD_HIP(h, hipMemcpyAsync(base + st->o_in, in->post, st->n_in * 4, hipMemcpyHostToDevice, h->stream));
+            FCD_HIP(h, hipMemcpyAsync(base + st->o_in, in->post, st->n_in * esz, hipMemcpyHostToDevice, h->stream));
         if (in->lengths)
             FCD_HIP(h, hipMemcpyAsync(base + st->o_len, in->lengths, (size_t)B * 8, hipMemcpyHostToDevice, h->stream));
         if (crf)

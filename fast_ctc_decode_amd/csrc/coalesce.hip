@@ -187,6 +187,10 @@ int submit(fcd_coalescer *c, Req &req) {
         t_error = "coalescer: null argument";
         return FCD_E_INVALID;
     }
+    if (req.in->dtype != FCD_DTYPE_F32) {
+        t_error = "coalescer: float32 reads only (the per-read surface is the reference's, which takes float32)";
+        return FCD_E_UNSUPPORTED;
+    }
     if (req.in->n_reads != 1 || req.in->S > 1 || req.in->T < 0 || req.in->N < 1 || req.in->stride_t < 0 ||
         req.in->stride_n < 0 || req.out->out_stride < req.in->T || req.in->lengths) {
         t_error = "coalescer: expects exactly one (T, N) read with non-negative strides and out_stride >= T";

@@ -17,6 +17,29 @@ __device__ __forceinline__ int popc64(uint64_t m) { return __builtin_popcountll(
 // wave-wide vote straight from an i1 (no 0/1 materialisation + compare as __ballot(int) does)
 __device__ __forceinline__ uint64_t ballot(bool pred) { return __builtin_amdgcn_ballot_w64(pred); }
 
+// Posterior element types (include/fcd.h: fcd_batch.dtype).  Basecaller networks emit half precision; the
+// reference forces a host float32 copy (src/lib.rs:182,325).  Both 16-bit formats convert to binary32 EXACTLY, so
+// a search on half-precision input is the reference's search on the upcast matrix, without a separate upcast pass.
+enum { kF32 = 0, kF16 = 1, kBF16 = 2 };
+
+#ifndef FCD_F16_TO_F32  // (tests/hipemu predefines a software conversion: its host compiler has no _Float16)
+#define FCD_F16_TO_F32(h) ((float)__builtin_bit_cast(_Float16, (uint16_t)(h)))  // v_cvt_f32_f16: exact, subnormals included
+#endif
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) { return FCD_F16_TO_F32(h); }
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+
+// the address of element `offset` of a posterior array (a read's first element), still typed as float *
+__device__ __forceinline__ const float *post_at(const float *base, int64_t offset, int dtype) {
+    return reinterpret_cast<const float *>(reinterpret_cast<const char *>(base) + offset * (dtype == kF32 ? 4 : 2));
+}
+
+// element `idx` of a posterior array of type `dtype` (wave-uniform: a scalar branch), as binary32
+__device__ __forceinline__ float load_post(const float *base, int64_t idx, int dtype) {
+    if (dtype == kF32) return base[idx];
+    const uint16_t h = reinterpret_cast<const uint16_t *>(base)[idx];
+    return dtype == kF16 ? f16_bits_to_f32(h) : bf16_bits_to_f32(h);
+}
+
 // Sort key for the prune step: descending probability, ties -> ascending node index
 // (src/search.rs:245 stable sort by node followed by :262-269 sort by probability; see
 // SURVEY.md 8a A4).  Larger key == earlier in the beam.  prob must not be NaN.

@@ -968,14 +968,14 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
 }
 
 // ---- prepass: ln of the posteriors into contiguous log-space copies (:452-453) ----
-__global__ void ln_convert_kernel(const float *x, int64_t n_reads, int64_t T, int S, int N,
+__global__ void ln_convert_kernel(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N,
                                   int64_t s_read, int64_t s_t, int64_t s_s, int64_t s_n, float *out) {
     const int64_t total = n_reads * T * S * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = idx % N, st = (idx / N) % S, t = (idx / ((int64_t)N * S)) % T,
                       r = idx / ((int64_t)N * S * T);
-        out[idx] = ln_cr(x[r * s_read + t * s_t + st * s_s + j * s_n]);
+        out[idx] = ln_cr(load_post(x, r * s_read + t * s_t + st * s_s + j * s_n, dtype));
     }
 }
 
@@ -1019,12 +1019,12 @@ size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S) {
     return dlds_words(beam_size, N, Wmax, S) * 4 + 16;
 }
 
-hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
+hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
                              int64_t s_t, int64_t s_s, int64_t s_n, float *out, hipStream_t stream) {
     const int64_t total = n_reads * T * S * N;
     if (total <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
-    hipLaunchKernelGGL(ln_convert_kernel, dim3(blocks), dim3(256), 0, stream, x, n_reads, T, S, N,
+    hipLaunchKernelGGL(ln_convert_kernel, dim3(blocks), dim3(256), 0, stream, x, dtype, n_reads, T, S, N,
                        s_read, s_t, s_s, s_n, out);
     return hipGetLastError();
 }

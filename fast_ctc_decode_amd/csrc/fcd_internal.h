@@ -22,6 +22,7 @@ struct BatchDesc {
     int64_t stride_read, stride_t, stride_s, stride_n;
     int S;
     int N;
+    int dtype;  // element type of `post`: 0 f32, 1 f16, 2 bf16 (strides are in elements of that type)
 };
 
 // Device-side output arrays (see fcd_result in include/fcd.h).
@@ -129,7 +130,7 @@ struct DuplexArgs {
 };
 
 size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S);
-hipError_t launch_ln_convert(const float *x, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
+hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
                              int64_t s_t, int64_t s_s, int64_t s_n, float *out, hipStream_t stream);
 hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,
                             int64_t T2cap, const int64_t *len1, const int64_t *len2, int *out,

@@ -101,7 +101,8 @@ int issue_chunk(fcd_job *j, int c) {
     const bool has_path = (j->want & FCD_JOB_PATH) != 0, has_qual = (j->want & FCD_JOB_QUAL) != 0;
     const bool has_amb = (j->want & FCD_JOB_AMBIGUOUS) != 0;
     fcd_batch sub = j->in;
-    sub.post = j->in.post + b0 * j->in.stride_read;
+    sub.post = reinterpret_cast<const float *>(reinterpret_cast<const char *>(j->in.post) +
+                                               b0 * j->in.stride_read * (j->in.dtype == FCD_DTYPE_F32 ? 4 : 2));
     sub.n_reads = n;
     sub.lengths = j->in.lengths ? j->in.lengths + b0 : nullptr;
     HostCall call = j->call;
@@ -302,7 +303,8 @@ bool host_job_wanted(fcd_handle *h, const fcd_batch *in, const HostCall &c) {
     if (h->is_lane || h->job_active) return false;
     if (lanes_default(h) < 2) return false;
     const bool crf = c.op == HostOp::CrfBeam || c.op == HostOp::CrfGreedy;
-    const double bytes = (double)in->n_reads * (double)in->T * (double)(crf ? in->S : 1) * (double)in->N * 4.0;
+    const double bytes = (double)in->n_reads * (double)in->T * (double)(crf ? in->S : 1) * (double)in->N *
+                         (in->dtype == FCD_DTYPE_F32 ? 4.0 : 2.0);
     if (h->pipe_min_bytes >= 0) return in->n_reads >= 2 && bytes >= (double)h->pipe_min_bytes;
     return in->n_reads >= 128 && bytes >= (double)(16 << 20);
 }

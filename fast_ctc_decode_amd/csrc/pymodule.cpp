@@ -470,6 +470,24 @@ py::str crf_beam_search_duplex(const py::object &network_output_1, const py::obj
 // csrc/hostjob.hip): uploads, searches and packed downloads of different chunks overlap, and this thread turns
 // chunk c into Python objects -- under the GIL -- while the later chunks are still in flight.
 // =============================================================================================================
+// batch inputs may be float32 or float16 (read by the kernels as they are, include/fcd.h FCD_DTYPE_*); the per-read
+// functions keep the reference's float32-only rule
+py::array as_post(const py::object &o, int ndim, const char *name, int &dtype, py::ssize_t &esz) {
+    if (!py::isinstance<py::array>(o))
+        throw py::type_error(std::string("argument '") + name + "': expected numpy.ndarray");
+    py::array a = py::reinterpret_borrow<py::array>(o);
+    const bool f32 = a.dtype().is(py::dtype::of<float>());
+    const bool f16 = !f32 && a.dtype().kind() == 'f' && a.dtype().itemsize() == 2;
+    if ((!f32 && !f16) || a.ndim() != ndim)
+        throw py::type_error(std::string("argument '") + name + "': expected a " + std::to_string(ndim) +
+                             "-dimensional float32 (or float16) array");
+    dtype = f32 ? FCD_DTYPE_F32 : FCD_DTYPE_F16;
+    esz = f32 ? 4 : 2;
+    for (int d = 0; d < ndim; ++d)
+        if (a.strides(d) < 0) return py::array::ensure(a, py::array::c_style);
+    return a;
+}
+
 struct BatchInput {
     fcd_batch b{};
     py::array keep;                   // the caller's array (a view: zero-copy)
@@ -483,22 +501,25 @@ struct BatchInput {
 // their row counts become the lengths).
 void make_batch(BatchInput &in, const py::object &x, int ndim, const py::object &lengths_o) {
     if (py::isinstance<py::array>(x)) {
-        py::array a = as_f32(x, ndim, "network_outputs");
+        int dtype = FCD_DTYPE_F32;
+        py::ssize_t esz = 4;
+        py::array a = as_post(x, ndim, "network_outputs", dtype, esz);
         in.keep = a;
         in.b.post = static_cast<const float *>(a.data());
+        in.b.dtype = dtype;
         in.b.n_reads = a.shape(0);
         in.b.T = a.shape(1);
-        in.b.stride_read = a.strides(0) / 4;
-        in.b.stride_t = a.strides(1) / 4;
+        in.b.stride_read = a.strides(0) / esz;
+        in.b.stride_t = a.strides(1) / esz;
         if (ndim == 4) {
             in.b.S = a.shape(2);
             in.b.N = a.shape(3);
-            in.b.stride_s = a.strides(2) / 4;
-            in.b.stride_n = a.strides(3) / 4;
+            in.b.stride_s = a.strides(2) / esz;
+            in.b.stride_n = a.strides(3) / esz;
         } else {
             in.b.S = 1;
             in.b.N = a.shape(2);
-            in.b.stride_n = a.strides(2) / 4;
+            in.b.stride_n = a.strides(2) / esz;
         }
         in.inner = in.b.N;
     } else {

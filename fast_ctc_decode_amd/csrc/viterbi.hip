@@ -118,7 +118,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc 
         T = t < 0 ? 0 : (t < T ? t : T);
     }
     const int N = in.N;
-    const float *post = in.post + r * in.stride_read;
+    const int dt = in.dtype;
+    const float *post = post_at(in.post, r * in.stride_read, dt);
     uint8_t *lab = out.labels + r * out.out_stride;
     uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
     float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
@@ -129,10 +130,10 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc 
         int label = 0;
         float prob = 0.0f;
         if (act) {
-            const float *pr = post + row * in.stride_t;
-            prob = pr[0];
+            const float *pr = post_at(post, row * in.stride_t, dt);
+            prob = load_post(pr, 0, dt);
             for (int j = 1; j < N; ++j) {  // find_max: strict '>' keeps the first maximum
-                const float v = pr[j * in.stride_n];
+                const float v = load_post(pr, j * in.stride_n, dt);
                 if (v > prob) {
                     prob = v;
                     label = j;
@@ -151,11 +152,17 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc 
 // before the current tile is scanned.
 constexpr int kTileRows = 256;
 
-template <int N>
+// DT: the posteriors' element type.  Half-precision reads (what basecaller networks emit; the reference forces a
+// host float32 copy, src/lib.rs:182) stream at HALF the bytes: a 16-byte load brings eight elements, which are
+// converted in registers -- exactly -- and parked in the same f32 tile, so everything after the tile is shared.
+template <int N, int DT>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(BatchDesc in,
                                                                            int collapse,
                                                                            ResultDesc out) {
-    __shared__ __attribute__((aligned(16))) float s_tile[kWavesPerBlock][kTileRows * N];
+    constexpr int EPL = DT == kF32 ? 4 : 8;                             // elements per 16-byte load
+    constexpr int NLOAD = (kTileRows * N + 64 * EPL - 1) / (64 * EPL);  // 16-byte loads per lane and tile
+    // (f32: NLOAD = N and the tile is covered exactly; 16-bit, odd N: the last load is half used)
+    __shared__ __attribute__((aligned(16))) float s_tile[kWavesPerBlock][NLOAD * 64 * EPL];
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
@@ -165,37 +172,71 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(Bat
         int64_t t = in.lengths[r];
         T = t < 0 ? 0 : (t < T ? t : T);
     }
-    const float *post = in.post + r * in.stride_read;
+    const float *post = post_at(in.post, r * in.stride_read, DT);
     uint8_t *lab = out.labels + r * out.out_stride;
     uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
     float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
     float *tile = s_tile[wave];
-    const int64_t total = T * N;  // floats in this read
+    const int64_t total = T * N;  // elements in this read
 
-    auto fetch = [&](int64_t tile_row0, float4 (&v)[N]) {
+    auto fetch = [&](int64_t tile_row0, uint4 (&v)[NLOAD]) {
         const int64_t f0 = tile_row0 * N;
 #pragma unroll
-        for (int m = 0; m < N; ++m) {
-            const int64_t f = f0 + (int64_t)(lane + 64 * m) * 4;
-            if (f + 3 < total) {
-                v[m] = *reinterpret_cast<const float4 *>(post + f);
+        for (int m = 0; m < NLOAD; ++m) {
+            const int64_t f = f0 + (int64_t)(lane + 64 * m) * EPL;
+            const bool in_tile = (lane + 64 * m) * EPL < kTileRows * N;
+            if (in_tile && f + EPL - 1 < total) {
+                v[m] = *reinterpret_cast<const uint4 *>(reinterpret_cast<const char *>(post) + f * (DT == kF32 ? 4 : 2));
+            } else {  // the ragged end of the read: element by element, zeros beyond it
+                uint32_t w[4] = {0u, 0u, 0u, 0u};
+                if (in_tile) {
+                    if (DT == kF32) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (f + e < total) w[e] = __float_as_uint(post[f + e]);
+                    } else {
+                        const uint16_t *ph = reinterpret_cast<const uint16_t *>(post);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e)
+                            if (f + e < total) w[e >> 1] |= (uint32_t)ph[f + e] << (16 * (e & 1));
+                    }
+                }
+                v[m] = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+        }
+    };
+    auto park = [&](const uint4 (&v)[NLOAD]) {
+#pragma unroll
+        for (int m = 0; m < NLOAD; ++m) {
+            float *dst = tile + (lane + 64 * m) * EPL;
+            if (DT == kF32) {
+                *reinterpret_cast<uint4 *>(dst) = v[m];
             } else {
-                v[m].x = f < total ? post[f] : 0.0f;
-                v[m].y = f + 1 < total ? post[f + 1] : 0.0f;
-                v[m].z = f + 2 < total ? post[f + 2] : 0.0f;
-                v[m].w = 0.0f;
+                const uint32_t w[4] = {v[m].x, v[m].y, v[m].z, v[m].w};
+                float4 lo4, hi4;
+                if (DT == kF16) {
+                    lo4 = make_float4(f16_bits_to_f32((uint16_t)w[0]), f16_bits_to_f32((uint16_t)(w[0] >> 16)),
+                                      f16_bits_to_f32((uint16_t)w[1]), f16_bits_to_f32((uint16_t)(w[1] >> 16)));
+                    hi4 = make_float4(f16_bits_to_f32((uint16_t)w[2]), f16_bits_to_f32((uint16_t)(w[2] >> 16)),
+                                      f16_bits_to_f32((uint16_t)w[3]), f16_bits_to_f32((uint16_t)(w[3] >> 16)));
+                } else {
+                    lo4 = make_float4(__uint_as_float(w[0] << 16), __uint_as_float(w[0] & 0xFFFF0000u),
+                                      __uint_as_float(w[1] << 16), __uint_as_float(w[1] & 0xFFFF0000u));
+                    hi4 = make_float4(__uint_as_float(w[2] << 16), __uint_as_float(w[2] & 0xFFFF0000u),
+                                      __uint_as_float(w[3] << 16), __uint_as_float(w[3] & 0xFFFF0000u));
+                }
+                *reinterpret_cast<float4 *>(dst) = lo4;
+                *reinterpret_cast<float4 *>(dst + 4) = hi4;
             }
         }
     };
 
     ScanState st;
-    float4 cur[N], nxt[N];
+    uint4 cur[NLOAD], nxt[NLOAD];
     if (T > 0) fetch(0, cur);
     for (int64_t base = 0; base < T; base += kTileRows) {
         if (base + kTileRows < T) fetch(base + kTileRows, nxt);
-#pragma unroll
-        for (int m = 0; m < N; ++m)
-            *reinterpret_cast<float4 *>(tile + (lane + 64 * m) * 4) = cur[m];
+        park(cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -223,7 +264,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(Bat
         }
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int m = 0; m < N; ++m) cur[m] = nxt[m];
+        for (int m = 0; m < NLOAD; ++m) cur[m] = nxt[m];
     }
     scan_finish(st, r, qual, out);
 }
@@ -241,7 +282,8 @@ __global__ __launch_bounds__(64) void crf_greedy_kernel(BatchDesc in, const floa
         T = t < 0 ? 0 : (t < T ? t : T);
     }
     const int N = in.N, S = in.S, n_base = N - 1;
-    const float *post = in.post + r * in.stride_read;
+    const int dt = in.dtype;
+    const float *post = post_at(in.post, r * in.stride_read, dt);
     uint8_t *lab = out.labels + r * out.out_stride;
     uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
     float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
@@ -268,13 +310,13 @@ __global__ __launch_bounds__(64) void crf_greedy_kernel(BatchDesc in, const floa
             bad = true;
             break;
         }
-        const float *pr = post + t * in.stride_t + (int64_t)state * in.stride_s;
+        const float *pr = post_at(post, t * in.stride_t + (int64_t)state * in.stride_s, dt);
         // argmax over N columns, N may exceed 64: strided per-lane first-max, then wave reduce
         float best = 0.0f;
         int arg = 1 << 30;
         bool nan = false;
         for (int j = lane; j < N; j += kWave) {
-            const float v = pr[j * in.stride_n];
+            const float v = load_post(pr, j * in.stride_n, dt);
             nan = nan || (v != v);
             if (arg == (1 << 30) || v > best) {
                 best = v;
@@ -536,13 +578,19 @@ hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &o
     if (in.n_reads <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)((in.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
     const dim3 grid(blocks), block(64 * kWavesPerBlock);
-    const bool stream_ok = in.stride_n == 1 && in.stride_t == in.N && (in.stride_read % 4) == 0 &&
+    // 16-byte loads: every read must start on a 16-byte boundary (4 f32 / 8 half elements)
+    const bool stream_ok = in.stride_n == 1 && in.stride_t == in.N && (in.stride_read % (in.dtype == kF32 ? 4 : 8)) == 0 &&
                            (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
     if (stream_ok) {
         switch (in.N) {
-#define FCD_VSTREAM(NN)                                                                         \
-    case NN:                                                                                    \
-        hipLaunchKernelGGL(viterbi_stream_kernel<NN>, grid, block, 0, stream, in, collapse, out); \
+#define FCD_VSTREAM(NN)                                                                                         \
+    case NN:                                                                                                    \
+        if (in.dtype == kF32)                                                                                   \
+            hipLaunchKernelGGL((viterbi_stream_kernel<NN, kF32>), grid, block, 0, stream, in, collapse, out);   \
+        else if (in.dtype == kF16)                                                                              \
+            hipLaunchKernelGGL((viterbi_stream_kernel<NN, kF16>), grid, block, 0, stream, in, collapse, out);   \
+        else                                                                                                    \
+            hipLaunchKernelGGL((viterbi_stream_kernel<NN, kBF16>), grid, block, 0, stream, in, collapse, out);  \
         return hipGetLastError();
             FCD_VSTREAM(2) FCD_VSTREAM(3) FCD_VSTREAM(4) FCD_VSTREAM(5) FCD_VSTREAM(6) FCD_VSTREAM(7)
             FCD_VSTREAM(8)
@@ -559,7 +607,8 @@ hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_i
     if (in.n_reads <= 0) return hipSuccess;
     // small state counts, C-contiguous rows: the streaming kernel (function-composition scan)
     const int64_t E = (int64_t)in.S * in.N;
-    const bool stream_ok = in.S >= 1 && in.S <= 8 && in.N >= 1 && in.N <= 15 && E <= 32 && in.stride_n == 1 &&
+    // (half-precision input takes the serial kernel below: the function-composition scan reads f32 tiles)
+    const bool stream_ok = in.dtype == kF32 && in.S >= 1 && in.S <= 8 && in.N >= 1 && in.N <= 15 && E <= 32 && in.stride_n == 1 &&
                            in.stride_s == in.N && in.stride_t == E && (in.stride_read % 4) == 0 &&
                            (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
     if (stream_ok) {

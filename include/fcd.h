@@ -90,8 +90,14 @@ typedef struct fcd_handle fcd_handle;
  *   CRF searches: element (read r, row t, state s, col j) at base[r*stride_read + t*stride_t + s*stride_s + j*stride_n]
  * lengths (nullable): per-read row count T_r <= T (ragged batches); device pointer for *_dev,
  * host pointer for *_host. */
+/* Element type of the posteriors.  Basecaller networks emit half precision; the reference only takes float32
+ * (src/lib.rs:182,325: &PyArray<f32>), which costs its callers a host-side upcast.  f16 and bf16 convert to float32
+ * EXACTLY, so a search on half-precision input IS the reference's search on the upcast matrix; the kernels convert
+ * in registers while loading (no separate pass; the HBM-bound viterbi search streams half the bytes). */
+enum { FCD_DTYPE_F32 = 0, FCD_DTYPE_F16 = 1, FCD_DTYPE_BF16 = 2 };
+
 typedef struct fcd_batch {
-    const float *post;
+    const float *post;  /* element type `dtype`: cast a uint16_t pointer for the 16-bit types */
     int64_t n_reads;
     int64_t T;          /* rows allocated per read */
     int64_t S;          /* CRF states; 1 for the plain searches */
@@ -101,6 +107,8 @@ typedef struct fcd_batch {
     int64_t stride_s;
     int64_t stride_n;
     const int64_t *lengths;
+    int32_t dtype;      /* FCD_DTYPE_*; strides are in elements of that type (0 = float32: zero-initialised structs
+                           keep their meaning) */
 } fcd_batch;
 
 /* Output of the 1D searches; every array has n_reads rows.

@@ -20,6 +20,32 @@
 #include <string.h>
 
 #define FCD_OPAQUE_V(x) ((void)0)        // csrc/device_utils.h: register pinning of the duplex coefficient table
+// csrc/device_utils.h: binary16 -> binary32 without _Float16 (g++ 11), exact incl. subnormals, infinities, NaNs
+static inline float hipemu_f16_to_f32(unsigned short h) {
+    const unsigned sign = (unsigned)(h & 0x8000u) << 16, ex = (h >> 10) & 0x1Fu, man = h & 0x3FFu;
+    unsigned bits;
+    if (ex == 0) {
+        if (man == 0) {
+            bits = sign;
+        } else {  // subnormal: normalise
+            int e = -1;
+            unsigned m = man;
+            do {
+                ++e;
+                m <<= 1;
+            } while (!(m & 0x400u));
+            bits = sign | (unsigned)(127 - 15 - e) << 23 | (m & 0x3FFu) << 13;
+        }
+    } else if (ex == 31) {
+        bits = sign | 0x7F800000u | man << 13;
+    } else {
+        bits = sign | (ex + 127 - 15) << 23 | man << 13;
+    }
+    float f;
+    __builtin_memcpy(&f, &bits, 4);
+    return f;
+}
+#define FCD_F16_TO_F32(h) hipemu_f16_to_f32((unsigned short)(h))
 #define FCD_STAMP(t64, dep) ((t64) = 0)  // csrc/device_utils.h: cycle stamps of the PROF instantiations
 // csrc/device_utils.h: four compare-and-count steps (hand-scheduled VALU on the GPU)
 #define FCD_RANK4(key, ka, kb, kc, kd, r0, r1, r2, r3) \

@@ -125,3 +125,10 @@ def test_chunked_host_path(fcd):
     H.test_host_pipeline_strided_views(fcd)
     H.test_job_api_chunks_and_cancel(fcd)
     H.test_compiled_batch_functions_equal_per_read_calls(fcd, 3, 2)
+
+
+def test_half_precision_inputs(fcd):
+    """fcd_batch.dtype: float16 / bfloat16 posteriors converted in the kernels' loads == the upcast float32 input"""
+    import test_gpu_halfprec as HP
+    HP.test_half_precision_host_inputs_every_kernel(fcd)
+    HP.test_half_precision_crf_and_duplex(fcd)

@@ -30,6 +30,12 @@ def main():
             r = fcd.viterbi_search_batch_raw(x)
         torch.cuda.synchronize()
         print("viterbi mean L", float(r.out_len.float().mean()))
+        xh = x.to(torch.float16)   # half-precision posteriors read directly (fcd_batch.dtype)
+        for _ in range(reps):
+            r = fcd.viterbi_search_batch_raw(xh)
+        torch.cuda.synchronize()
+        print("viterbi f16 mean L", float(r.out_len.float().mean()))
+        del xh
     if which in ("all", "beam32"):
         x = gen(8192, 4000, 5, 3)
         for _ in range(2):
