@@ -226,15 +226,19 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     }
     int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
     chunk = std::min<int64_t>(chunk, d.n_reads);
-    // (at least a few worst-case slabs for the retry pass, however small the job's share of the budget)
-    rc = ensure(h, &h->arena, &h->arena_bytes, std::max((size_t)chunk * per_read, two_pass ? 4 * worst_read : (size_t)0));
+    // the retry pass needs worst-case slabs out of the same arena: a few of them however small the job, but no more
+    // than the workspace limit allows (never less than one: a read that overflowed must be decodable)
+    const bool retry_needed = two_pass && cap_nodes < cap_worst;  // (divisor 1: the first pass IS the worst case)
+    size_t retry_floor = retry_needed ? 4 * worst_read : 0;
+    if (retry_needed && (int64_t)retry_floor > budget) retry_floor = std::max<size_t>(worst_read, (size_t)budget / worst_read * worst_read);
+    rc = ensure(h, &h->arena, &h->arena_bytes, std::max((size_t)chunk * per_read, retry_floor));
     if (rc) return rc;
-    const int retry_slots = two_pass ? (int)std::min<size_t>(h->arena_bytes / worst_read, 1u << 30) : 0;
+    const int retry_slots = retry_needed ? (int)std::min<size_t>(h->arena_bytes / worst_read, 1u << 30) : 0;
     int32_t *d_counter = nullptr;
-    if (two_pass) {
-        rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, 256);
+    if (retry_needed) {  // the overflow counter of the retry rounds has its own small allocation
+        rc = ensure(h, &h->retry_counter, &h->retry_counter_bytes, 256);
         if (rc) return rc;
-        d_counter = reinterpret_cast<int32_t *>(h->lnbuf);
+        d_counter = reinterpret_cast<int32_t *>(h->retry_counter);
     }
 
     auto wave_arena = [&](char *base, int64_t slabs, int64_t cap) {
@@ -258,7 +262,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
             e = use_lane ? launch_beam_lane(d, begin, n, args, ar, o, h->stream)
                          : launch_beam_wave(d, begin, n, args, ar, o, h->stream);
             FCD_HIP(h, e);
-            if (two_pass) {
+            if (retry_needed) {
                 WaveArena rr = wave_arena(reinterpret_cast<char *>(h->arena), retry_slots, cap_worst);
                 rr.retry_counter = d_counter;
                 rr.retry_slots = retry_slots;
@@ -340,6 +344,7 @@ int fcd_destroy(fcd_handle *h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->lnbuf) (void)hipFree(h->lnbuf);
+    if (h->retry_counter) (void)hipFree(h->retry_counter);
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -403,8 +408,9 @@ int fcd_release_workspace(fcd_handle *h) {
     if (h->stage) (void)hipFree(h->stage);
     if (h->lnbuf) (void)hipFree(h->lnbuf);
     if (h->pin) (void)hipHostFree(h->pin);
-    h->arena = h->stage = h->lnbuf = h->pin = nullptr;
-    h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = 0;
+    if (h->retry_counter) (void)hipFree(h->retry_counter);
+    h->arena = h->stage = h->lnbuf = h->pin = h->retry_counter = nullptr;
+    h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = h->retry_counter_bytes = 0;
     return FCD_OK;
 }
 

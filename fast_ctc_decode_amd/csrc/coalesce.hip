@@ -107,8 +107,22 @@ struct fcd_coalescer {
 
 namespace {
 
-// one batched launch for `batch` (all compatible) on lane `L`; fills every request's outputs and rc
+void run_batch_once(Lane &L, std::vector<Req *> &batch);
+
+// one batched launch for `batch` (all compatible) on lane `L`; fills every request's outputs and rc.  A failure of
+// the BATCH (staging memory, a shape limit decided by the longest read of the batch) is not every caller's
+// failure: the requests are then decoded one by one, so that each caller gets exactly what a per-read call gives.
 void run_batch(Lane &L, std::vector<Req *> &batch) {
+    run_batch_once(L, batch);
+    if (batch.size() > 1 && batch[0]->rc != FCD_OK) {
+        for (Req *r : batch) {
+            std::vector<Req *> one{r};
+            run_batch_once(L, one);
+        }
+    }
+}
+
+void run_batch_once(Lane &L, std::vector<Req *> &batch) {
     const int64_t n = (int64_t)batch.size();
     const Req &first = *batch[0];
     const int64_t N = first.in->N;
@@ -185,6 +199,10 @@ void run_batch(Lane &L, std::vector<Req *> &batch) {
 int submit(fcd_coalescer *c, Req &req) {
     if (!c || !req.in || !req.out || !req.in->post || !req.out->labels) {
         t_error = "coalescer: null argument";
+        return FCD_E_INVALID;
+    }
+    if (req.kind == kBeam && !req.out->status) {  // a per-read FCD_ST_* outcome must have somewhere to go
+        t_error = "coalescer: beam_search needs out->status";
         return FCD_E_INVALID;
     }
     if (req.in->dtype != FCD_DTYPE_F32) {

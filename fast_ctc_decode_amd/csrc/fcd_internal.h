@@ -229,6 +229,8 @@ struct fcd_handle {
     size_t pin_bytes = 0;
     void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
     size_t lnbuf_bytes = 0;
+    void *retry_counter = nullptr;  // lane kernel, two-pass sizing: overflow counter of the retry rounds
+    size_t retry_counter_bytes = 0;
     // chunk lanes of the pipelined host path (hostjob.hip): sub-handles with their own stream and workspace
     std::vector<fcd_host_lane *> lanes;
     bool job_active = false;  // a host job owns the lanes from begin to end
