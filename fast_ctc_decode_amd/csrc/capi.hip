@@ -643,7 +643,8 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.rootgap = reinterpret_cast<float *>(base);
     a.cap_nodes = cap_nodes; a.Wcap = Wcap;
     // tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
-    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S) <= 48 * 1024 ? 1 : 0;
+    // (and keep the beam entries' windows resident there: one LDS buffer per beam slot, handed over by lane votes)
+    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S) <= 48 * 1024 && beam_size <= 64 ? 1 : 0;
     a.out = to_desc(out);
     a.prof = h->duplex_prof;
     for (int64_t begin = 0; begin < B; begin += chunk) {

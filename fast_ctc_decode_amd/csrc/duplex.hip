@@ -12,6 +12,14 @@
 // {label, gap, label(+)gap}; entry for row t sits at slot t mod Wcap, so the reference's
 // discard_until (:181-191) is a pure offset update.  Storing label(+)gap makes update_max
 // (:193-204) a transcendental-free max-reduction done by all 64 lanes.
+// RESIDENT WINDOWS (r03): while a node is a beam entry its ring ALSO lives in LDS (one buffer per beam slot,
+// carried from step to step; entries keep their buffer when the beam is re-ranked, a node entering the beam has
+// its ring copied in once), together with its window bounds and running maximum.  The per-step work on beam
+// entries -- appending one row, the incremental update_max, serving rows to the children's builds -- then
+// touches LDS only; the HBM arena is written through (it stays the truth for nodes outside the beam, which may
+// come back) but is read again only when a node enters the beam.  Before r03 every step re-read every beam
+// entry's window from HBM into an LDS tile (10.8 k cycles) after a chain of dependent global loads in the
+// extension (30 k of the step's 175 k cycles, profiles/r03b_duplex_account.jsonl).
 // Per row of read 1:
 //   1. envelope check (:485-488);
 //   2. if the upper bound grew (:490-522): beam re-sorted by node (parents first) and every beam
@@ -151,7 +159,7 @@ __device__ __forceinline__ int4 load_meta_l2(const int4 *p) {
 
 // (no runtime-indexed pointer arrays: they would force the struct into scratch memory)
 struct DLds {
-    int *beam0;  // [2][beam_stride] words: node, lp, gp, tip, par (BC each), child (BC*NL)
+    int *beam0;  // [2][beam_stride] words: node, lp, gp, tip, par, state, buf, off, end, rlo, max (BC each), child (BC*NL)
     int beam_stride;
     int BC;
     __device__ __forceinline__ int *b_node(int b) const { return beam0 + b * beam_stride; }
@@ -160,22 +168,29 @@ struct DLds {
     __device__ __forceinline__ int *b_tip(int b) const { return b_node(b) + 3 * BC; }
     __device__ __forceinline__ int *b_par(int b) const { return b_node(b) + 4 * BC; }
     __device__ __forceinline__ int *b_state(int b) const { return b_node(b) + 5 * BC; }
-    __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 6 * BC; }
+    // resident window of the entry's node: LDS buffer index, rows [off, end) present, the running maximum and the
+    // first row it covers (the LDS twins of meta.z / meta.w / nmax / rlo)
+    __device__ __forceinline__ int *b_buf(int b) const { return b_node(b) + 6 * BC; }
+    __device__ __forceinline__ int *b_off(int b) const { return b_node(b) + 7 * BC; }
+    __device__ __forceinline__ int *b_end(int b) const { return b_node(b) + 8 * BC; }
+    __device__ __forceinline__ int *b_rlo(int b) const { return b_node(b) + 9 * BC; }
+    __device__ __forceinline__ float *b_max(int b) const { return reinterpret_cast<float *>(b_node(b) + 10 * BC); }
+    __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 11 * BC; }
     uint64_t *c_key;
     float *c_lp, *c_gp, *c_p2;
     int *c_id, *c_new;
     int *nb_src;
-    int *s_off, *s_end;  // BC each: window bounds of the beam entries' vectors
+    int *s_off, *s_end;  // BC each: scratch of the buffer hand-over (which buffers stay taken / the free list)
     int *bt;             // 64: lane that owns the m-th new node of the current pass
     float *w2;           // Wmax*S*N: log posteriors of read 2, rows [lo, hi), all states
-    float *pw;           // BC*Wmax*2: (gap, label(+)gap) of every beam entry at rows [lo-1, hi-1)
+    float *bw;           // BC*(Wmax+2)*3: the beam entries' resident rings {label, gap, label(+)gap}, slot = row mod Wcap
 };
 
 __host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax, int S) {
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
-    return 2 * (size_t)BC * (6 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 + 64 +
-           (size_t)Wmax * S * N + (size_t)BC * Wmax * 2;
+    return 2 * (size_t)BC * (11 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 + 64 +
+           (size_t)Wmax * S * N + (Wmax > 0 ? (size_t)BC * (Wmax + 2) * 3 : 0);
 }
 
 __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S) {
@@ -190,7 +205,7 @@ __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S) {
     L.c_id = p; p += C;
     L.c_new = p; p += C;
     L.BC = BC;
-    L.beam_stride = BC * (6 + NL);
+    L.beam_stride = BC * (11 + NL);
     L.beam0 = p;
     p += 2 * (size_t)L.beam_stride;
     L.nb_src = p; p += BC;
@@ -198,7 +213,7 @@ __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S) {
     L.s_end = p; p += BC;
     L.bt = p; p += 64;
     L.w2 = reinterpret_cast<float *>(p); p += (size_t)Wmax * S * N;
-    L.pw = reinterpret_cast<float *>(p);
+    L.bw = reinterpret_cast<float *>(p);
     return L;
 }
 
@@ -312,6 +327,11 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         L.b_gp(0)[0] = 0.0f;     // gap: one
         L.b_tip(0)[0] = -1;
         L.b_par(0)[0] = -2;
+        L.b_buf(0)[0] = 0;       // the root's rows are staged into its buffer every step (below)
+        L.b_off(0)[0] = -1;
+        L.b_end(0)[0] = root_end;
+        L.b_rlo(0)[0] = 0;
+        L.b_max(0)[0] = 0.0f;
     }
     for (int j = lane; j < NL; j += kWave) L.b_child(0)[j] = -1;
     __syncthreads();
@@ -348,6 +368,42 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         return v;
     };
 
+    // ---- resident windows (staged launches): LDS twins of the beam entries' rings ----
+    const bool resident = staged;
+    auto ring = [&](int buf) { return L.bw + (size_t)buf * Wcap * 3; };
+    // the reference's SecondaryProbs::get (:167-179) on a resident ring: (gap, label(+)gap) of row `at`
+    auto ring_get = [&](const float *rg, int off, int end, int at, float &gap, float &sum) {
+        if (at < off || at >= end) {
+            gap = kNegInf;
+            sum = kNegInf;
+            return;
+        }
+        const int sl = (((at % Wcap) + Wcap) % Wcap) * 3;  // (the root's row -1 sits in the last slot)
+        gap = rg[sl + 1];
+        sum = rg[sl + 2];
+    };
+    // node enters the beam (or its ring was rewritten by the sequential extension): bounds, maximum and rows
+    // [off, end) come in from the arena, which is always written through; wave-cooperative, wave-uniform arguments
+    auto load_entry = [&](int bsel, int e) {
+        const int node = L.b_node(bsel)[e];
+        if (node < 0) return;  // the root's rows are staged per step
+        const int4 m = load_meta_l2(&meta[node]);
+        const int off = m.z, end = m.w;
+        float *dst = ring(L.b_buf(bsel)[e]);
+        const float *src = vec + (int64_t)node * Wcap * 3;
+        for (int idx = lane; idx < (end - off) * 3; idx += kWave) {
+            const int row = idx / 3;
+            const int sl = ((off + row) % Wcap) * 3 + (idx - row * 3);
+            dst[sl] = load_f32_l2(src + sl);
+        }
+        if (lane == 0) {
+            L.b_off(bsel)[e] = off;
+            L.b_end(bsel)[e] = end;
+            L.b_max(bsel)[e] = load_f32_l2(&nmax[node]);
+            L.b_rlo(bsel)[e] = load_i32_l2(&rlo[node]);
+        }
+    };
+
     for (int64_t t1 = 0; t1 < T1; ++t1) {
         // ---- envelope (:485-488) ----
         const uint64_t lo_u = env[2 * t1], hi_u = env[2 * t1 + 1];
@@ -368,6 +424,11 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 L.b_tip(nx)[rk] = L.b_tip(cur)[e];
                 L.b_par(nx)[rk] = L.b_par(cur)[e];
                 L.b_state(nx)[rk] = L.b_state(cur)[e];
+                L.b_buf(nx)[rk] = L.b_buf(cur)[e];
+                L.b_off(nx)[rk] = L.b_off(cur)[e];
+                L.b_end(nx)[rk] = L.b_end(cur)[e];
+                L.b_rlo(nx)[rk] = L.b_rlo(cur)[e];
+                L.b_max(nx)[rk] = L.b_max(cur)[e];
                 for (int l = 0; l < NL; ++l) L.b_child(nx)[rk * NL + l] = L.b_child(cur)[e * NL + l];
             }
             cur = nx;
@@ -383,15 +444,24 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 const int e = lane;
                 const bool mine = e < B && L.b_node(cur)[e] >= 0;
                 int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0,
-                    p_lab = -1;
+                    p_lab = -1, pslot = -1;
                 float mx = kNegInf;
                 bool bad = false;
+                const float *my_l = nullptr;  // the entry's own ring: LDS when resident, else the arena
                 if (fast_ok && mine) {
                     node = L.b_node(cur)[e];
-                    const int4 m = load_meta_l2(&meta[node]);
-                    parent = m.x; lab = m.y; off = m.z; end = m.w;
-                    mx = load_f32_l2(&nmax[node]);
-                    rl = load_i32_l2(&rlo[node]);
+                    if (resident) {
+                        parent = L.b_par(cur)[e]; lab = L.b_tip(cur)[e];
+                        off = L.b_off(cur)[e]; end = L.b_end(cur)[e];
+                        mx = L.b_max(cur)[e]; rl = L.b_rlo(cur)[e];
+                        my_l = ring(L.b_buf(cur)[e]);
+                    } else {
+                        const int4 m = load_meta_l2(&meta[node]);
+                        parent = m.x; lab = m.y; off = m.z; end = m.w;
+                        mx = load_f32_l2(&nmax[node]);
+                        rl = load_i32_l2(&rlo[node]);
+                        my_l = vec + (int64_t)node * Wcap * 3;
+                    }
                     bad = end != last_hi;
                     if (!bad && lo > off) {
                         const int keep = lo - 1;
@@ -405,48 +475,68 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         if (!bad && lo < rl) bad = true;  // the range grows downwards: rescan (slow path)
                         if (!bad && lo > rl) {
                             if (lo - rl > 4) bad = true;  // a long stale range: rescan on the slow path
-                            const float *my = vec + (int64_t)node * Wcap * 3;
                             for (int t = rl; t < lo && !bad; ++t) {
                                 if (t < off_old || t >= end) continue;
-                                const float sv = load_f32_l2(my + 3 * (t % Wcap) + 2);
+                                const float sv = resident ? my_l[3 * (t % Wcap) + 2] : load_f32_l2(my_l + 3 * (t % Wcap) + 2);
                                 if (sv == sv && !(sv < mx)) bad = true;  // the leaving row holds the max
                             }
                             rl = lo;
                         }
                     }
                     if (!bad && parent >= 0) {
-                        const int4 pm = load_meta_l2(&meta[parent]);
-                        p_lab = pm.y; p_off = pm.z; p_end = pm.w;
+                        if (resident)
+                            for (int j = 0; j < B; ++j)
+                                if (L.b_node(cur)[j] == parent) pslot = j;
+                        if (pslot >= 0) {  // the parent is a beam entry: its window is resident too
+                            p_lab = L.b_tip(cur)[pslot]; p_off = L.b_off(cur)[pslot]; p_end = L.b_end(cur)[pslot];
+                        } else {
+                            const int4 pm = load_meta_l2(&meta[parent]);
+                            p_lab = pm.y; p_off = pm.z; p_end = pm.w;
+                        }
                     }
                 }
                 fast_ok = fast_ok && ballot(bad) == 0ull;
                 if (fast_ok && mine) {
-                    const VecRef pv = node_vec(parent, p_off, p_end);
                     const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512 (crf: :320-334, no repeat case)
                     const int tst = L.b_state(cur)[e];                        // crf: the entry's own state (:725-728)
                     float *my = vec + (int64_t)node * Wcap * 3;
                     float l_lab = kNegInf, l_sum = kNegInf;
                     if (end > off) {
                         const int sl = (end - 1) % Wcap;
-                        l_lab = load_f32_l2(my + 3 * sl);
-                        l_sum = load_f32_l2(my + 3 * sl + 2);
+                        l_lab = resident ? my_l[3 * sl] : load_f32_l2(my + 3 * sl);
+                        l_sum = resident ? my_l[3 * sl + 2] : load_f32_l2(my + 3 * sl + 2);
                     }
                     const int idx = end;  // == last_hi == hi - 1
                     const float *row = ln2 + ((int64_t)idx * S + tst) * N;
                     float pg, ps;
-                    vec_get(pv, idx - 1, Wcap, pg, ps);
+                    if (pslot >= 0) {
+                        ring_get(ring(L.b_buf(cur)[pslot]), p_off, p_end, idx - 1, pg, ps);
+                    } else {
+                        const VecRef pv = node_vec(parent, p_off, p_end);
+                        vec_get(pv, idx - 1, Wcap, pg, ps);
+                    }
                     const float g = l_sum + row[0];
                     const float xx = is_rep ? pg : ps;
                     const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
                     const float sm = ladd<MODE>(lb, g);
                     const int sl = idx % Wcap;
-                    my[3 * sl] = lb;
+                    my[3 * sl] = lb;  // the arena is written through
                     my[3 * sl + 1] = g;
                     my[3 * sl + 2] = sm;
                     mx = lmax(mx, sm);
                     meta[node] = make_int4(parent, lab, off, hi);
                     nmax[node] = mx;
                     rlo[node] = rl;
+                    if (resident) {
+                        float *mw = ring(L.b_buf(cur)[e]);
+                        mw[3 * sl] = lb;
+                        mw[3 * sl + 1] = g;
+                        mw[3 * sl + 2] = sm;
+                        L.b_off(cur)[e] = off;
+                        L.b_end(cur)[e] = hi;
+                        L.b_max(cur)[e] = mx;
+                        L.b_rlo(cur)[e] = rl;
+                    }
                 }
             }
             __syncthreads();
@@ -524,34 +614,31 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 }
                 __syncthreads();  // the next node may read this one's new rows (parents first)
             }
+            if (!fast_ok && resident) {  // the sequential path worked on the arena: refresh the resident copies
+                for (int e = 0; e < B; ++e) load_entry(cur, e);
+                __syncthreads();
+            }
         }
         last_hi = hi;
         FCD_DUPLEX_PHASE(0)
 
         const int W = hi - lo;
         if (staged) {
-            // ---- LDS tile of the DP envelope for this row of read 1 ----
-            for (int e = lane; e < B; e += kWave) {
-                const int nd = L.b_node(cur)[e];
-                int off = -1, end = root_end;
-                if (nd >= 0) {
-                    const int4 m = load_meta_l2(&meta[nd]);
-                    off = m.z;
-                    end = m.w;
-                }
-                L.s_off[e] = off;
-                L.s_end[e] = end;
-            }
+            // ---- LDS tile of read 2's rows for this row of read 1; the beam entries' own windows are resident ----
             for (int xw = lane; xw < W * S * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * S * N + xw];
-            __syncthreads();
+            // the root (in the beam for the first few rows only) has no ring in the arena: the rows its children's
+            // builds will ask for, [lo-1, hi-1), are staged into its buffer from the cumulative blank products
             for (int e = 0; e < B; ++e) {
-                const int nd = L.b_node(cur)[e];
-                const VecRef pv = node_vec(nd, L.s_off[e], L.s_end[e]);
+                if (L.b_node(cur)[e] >= 0) continue;
+                float *rg = ring(L.b_buf(cur)[e]);
                 for (int j = lane; j < W; j += kWave) {
-                    float pg, ps;
-                    vec_get(pv, lo - 1 + j, Wcap, pg, ps);
-                    L.pw[((size_t)e * Wmax + j) * 2] = pg;
-                    L.pw[((size_t)e * Wmax + j) * 2 + 1] = ps;
+                    const int at = lo - 1 + j;
+                    if (at < -1 || at >= root_end) continue;
+                    const float g = load_f32_l2(rootgap + (at + 1));
+                    const int sl = (((at % Wcap) + Wcap) % Wcap) * 3;
+                    rg[sl] = kNegInf;
+                    rg[sl + 1] = g;
+                    rg[sl + 2] = g;
                 }
             }
             __syncthreads();
@@ -655,14 +742,15 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     float *my = vec + (int64_t)cid * Wcap * 3;
                     float l_lab = kNegInf, l_sum = kNegInf, mx = kNegInf;
                     int s = lo % Wcap;
+                    const float *prg = staged ? ring(L.b_buf(cur)[i]) : nullptr;  // the parent's resident ring
+                    const int q_off = staged ? L.b_off(cur)[i] : 0, q_end = staged ? L.b_end(cur)[i] : 0;
                     for (int idx = lo; idx < hi; ++idx) {
                         float pg, ps, r0, rl1;
                         if (staged) {
                             const int j = idx - lo;
                             r0 = L.w2[(j * S + state) * N];
                             rl1 = L.w2[(j * S + state) * N + l + 1];
-                            pg = L.pw[((size_t)i * Wmax + j) * 2];
-                            ps = L.pw[((size_t)i * Wmax + j) * 2 + 1];
+                            ring_get(prg, q_off, q_end, idx - 1, pg, ps);
                         } else {
                             const float *row = ln2 + ((int64_t)idx * S + state) * N;  // crf: tip.state (:772)
                             r0 = row[0];
@@ -749,15 +837,21 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     // addresses advance incrementally, and label_t reaches the odd lane through a DPP move
                     // (lane pairs are adjacent) instead of an LDS round trip.
                     const float *wq = L.w2 + q_state * N + (isA ? q_l + 1 : 0);          // + row * S * N
-                    const float *xq = L.pw + (size_t)q_i * Wmax * 2 + (q_rep ? 0 : 1);   // + row * 2   (even lane only)
+                    // X_{t-1}: the parent's gap (repeat) or label(+)gap at row t - 1, out of its resident ring; rows
+                    // outside the parent's window [q_off, q_end) read as zero (SecondaryProbs::get :167-179)
+                    const float *xq = ring(L.b_buf(cur)[q_i]) + (q_rep ? 1 : 2);
+                    const int q_off = L.b_off(cur)[q_i], q_end = L.b_end(cur)[q_i];
                     const int rstep = S * N;
                     int jn = isA ? 0 : -1;                      // the row this lane handles in the coming iteration
                     int slot3 = 3 * ((lo + Wcap + jn) % Wcap);  // 3 * ((lo + jn) mod Wcap)
+                    int at_n = lo;                              // parent row of the NEXT fetch (row lo - 1 is fetched here)
+                    int pslot3 = 3 * (((lo - 1) % Wcap + Wcap) % Wcap);
                     float c_cur = 0.0f, x_cur = kNegInf;
                     if (isA) {
                         c_cur = wq[0];
-                        x_cur = xq[0];
+                        x_cur = (lo - 1 >= q_off && lo - 1 < q_end) ? xq[pslot3] : kNegInf;
                     }
+                    pslot3 = pslot3 + 3 == 3 * Wcap ? 0 : pslot3 + 3;
                     for (int sidx = 0; sidx <= W; ++sidx) {
                         // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
                         const int j = jn;
@@ -765,7 +859,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         // next row's operands (clamped to the tile: the value is unused past the last row)
                         const int jr = j + 1 < W ? j + 1 : W - 1;
                         const float c_nxt = wq[jr * rstep];
-                        const float x_nxt = isA ? xq[jr * 2] : kNegInf;
+                        const float x_nxt = (isA && at_n >= q_off && at_n < q_end) ? xq[pslot3] : kNegInf;  // row at_n
                         const float a = on ? lb : kNegInf;
                         const float bb = on ? (isA ? x_cur : sm + c_cur) : kNegInf;   // A: X_{t-1};  B: gap_{t'}
                         const float v = ladd_lockstep<MODE>(a, bb, K);
@@ -787,6 +881,8 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         c_cur = c_nxt;
                         x_cur = x_nxt;
                         ++jn;
+                        ++at_n;
+                        pslot3 = pslot3 + 3 == 3 * Wcap ? 0 : pslot3 + 3;
                         slot3 = slot3 + 3 == 3 * Wcap ? 0 : slot3 + 3;
                     }
                 } else {
@@ -908,7 +1004,14 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     L.b_tip(nxt)[rank] = b_tip[i];
                     L.b_par(nxt)[rank] = b_par[i];
                     L.b_state(nxt)[rank] = b_state[i];
+                    // the entry stays: so does its resident window
+                    L.b_buf(nxt)[rank] = L.b_buf(cur)[i];
+                    L.b_off(nxt)[rank] = L.b_off(cur)[i];
+                    L.b_end(nxt)[rank] = L.b_end(cur)[i];
+                    L.b_rlo(nxt)[rank] = L.b_rlo(cur)[i];
+                    L.b_max(nxt)[rank] = L.b_max(cur)[i];
                 } else {
+                    L.b_buf(nxt)[rank] = -1;  // a node entering the beam: gets a buffer and its ring below
                     L.b_tip(nxt)[rank] = k - 1;
                     L.b_par(nxt)[rank] = b_node[i];
                     L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;  // :782
@@ -934,6 +1037,24 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             bool bs = false;
             for (int s2 = lane; s2 < Bn; s2 += kWave) bs = bs || L.b_state(nxt)[s2] >= S;
             if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
+        }
+        if (resident) {
+            // ---- hand the LDS buffers of the entries that left to the nodes that entered, and bring their rings in ----
+            for (int j = lane; j < BC; j += kWave) L.s_off[j] = 0;
+            __syncthreads();
+            const bool in_next = lane < Bn;
+            const int mybuf = in_next ? L.b_buf(nxt)[lane] : 0;
+            if (in_next && mybuf >= 0) L.s_off[mybuf] = 1;  // stays taken
+            __syncthreads();
+            const bool is_free = lane < BC && L.s_off[lane] == 0;
+            const uint64_t free_m = ballot(is_free);
+            if (is_free) L.s_end[popc64(free_m & lanemask_lt())] = lane;  // the free list
+            const bool entering = in_next && mybuf < 0;
+            const uint64_t enter_m = ballot(entering);
+            __syncthreads();
+            if (entering) L.b_buf(nxt)[lane] = L.s_end[popc64(enter_m & lanemask_lt())];
+            __syncthreads();
+            for (uint64_t m = enter_m; m != 0ull; m &= m - 1) load_entry(nxt, (int)__builtin_ctzll(m));
         }
         B = Bn;
         cur = nxt;
