@@ -342,7 +342,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
     // 3 window builds of the new nodes, 4 rank + next beam, 5 build-loop iterations, 6 new nodes, 7 steps
     const bool prof = p.prof != nullptr;
     uint64_t acc[5] = {0, 0, 0, 0, 0}, t_prev = 0, t_now = 0;
-    uint32_t n_iter = 0, n_newnodes = 0;
+    uint32_t n_iter = 0, n_newnodes = 0, n_slow = 0, n_enter = 0, n_ext = 0;
     int stamp_dep = 0;
     if (prof) FCD_STAMP(t_prev, stamp_dep);
 #define FCD_DUPLEX_PHASE(k)                  \
@@ -391,10 +391,20 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         const int off = m.z, end = m.w;
         float *dst = ring(L.b_buf(bsel)[e]);
         const float *src = vec + (int64_t)node * Wcap * 3;
-        for (int idx = lane; idx < (end - off) * 3; idx += kWave) {
-            const int row = idx / 3;
-            const int sl = ((off + row) % Wcap) * 3 + (idx - row * 3);
-            dst[sl] = load_f32_l2(src + sl);
+        const int n3 = (end - off) * 3;
+        for (int base = 0; base < n3; base += 8 * kWave) {  // eight loads in flight per lane, then the LDS stores
+            float v[8];
+            int sl[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const int idx = base + u * kWave + lane;
+                const int row = idx / 3;
+                sl[u] = ((off + row) % Wcap) * 3 + (idx - row * 3);
+                v[u] = idx < n3 ? load_f32_l2(src + sl[u]) : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                if (base + u * kWave + lane < n3) dst[sl[u]] = v[u];
         }
         if (lane == 0) {
             L.b_off(bsel)[e] = off;
@@ -446,7 +456,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0,
                     p_lab = -1, pslot = -1;
                 float mx = kNegInf;
-                bool bad = false;
+                bool bad = false, rescan = false;
                 const float *my_l = nullptr;  // the entry's own ring: LDS when resident, else the arena
                 if (fast_ok && mine) {
                     node = L.b_node(cur)[e];
@@ -472,15 +482,25 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         }
                         if (end == off) { off = lo; end = lo; }
                         bad = end != last_hi;
-                        if (!bad && lo < rl) bad = true;  // the range grows downwards: rescan (slow path)
-                        if (!bad && lo > rl) {
-                            if (lo - rl > 4) bad = true;  // a long stale range: rescan on the slow path
-                            for (int t = rl; t < lo && !bad; ++t) {
-                                if (t < off_old || t >= end) continue;
-                                const float sv = resident ? my_l[3 * (t % Wcap) + 2] : load_f32_l2(my_l + 3 * (t % Wcap) + 2);
-                                if (sv == sv && !(sv < mx)) bad = true;  // the leaving row holds the max
-                            }
+                        if (resident) {
+                            // update_max(lo, hi) (:356): with the ring in LDS the maximum over [lo, end) is simply
+                            // recomputed by the whole wavefront below -- the incremental test ("does a leaving row
+                            // hold the maximum?") failed on 68 % (logsumexp) / 97 % (max mode: the best single path
+                            // loses probability with every row, so the maximum sits at the window's first row) of
+                            // the steps of BASELINE config 5 and sent all beam entries down the sequential path
+                            rescan = !bad;
                             rl = lo;
+                        } else {
+                            if (!bad && lo < rl) bad = true;  // the range grows downwards: rescan (slow path)
+                            if (!bad && lo > rl) {
+                                if (lo - rl > 4) bad = true;  // a long stale range: rescan on the slow path
+                                for (int t = rl; t < lo && !bad; ++t) {
+                                    if (t < off_old || t >= end) continue;
+                                    const float sv = load_f32_l2(my_l + 3 * (t % Wcap) + 2);
+                                    if (sv == sv && !(sv < mx)) bad = true;  // the leaving row holds the max
+                                }
+                                rl = lo;
+                            }
                         }
                     }
                     if (!bad && parent >= 0) {
@@ -496,6 +516,19 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     }
                 }
                 fast_ok = fast_ok && ballot(bad) == 0ull;
+                if (fast_ok && resident) {
+                    // update_max over the rows that stay, [max(lo, off), end), for every entry that discarded rows:
+                    // 64 lanes per entry, two LDS reads each at W = 128 (NaN entries never replace the maximum)
+                    for (uint64_t m = ballot(rescan); m != 0ull; m &= m - 1) {
+                        const int e2 = (int)__builtin_ctzll(m);
+                        const int o2 = __shfl(off, e2), n2 = __shfl(end, e2);
+                        const float *rg = ring(L.b_buf(cur)[e2]);
+                        float part = kNegInf;
+                        for (int t = (lo > o2 ? lo : o2) + lane; t < n2; t += kWave) part = lmax(part, rg[3 * (t % Wcap) + 2]);
+                        for (int o = 32; o > 0; o >>= 1) part = lmax(part, __shfl_xor(part, o));
+                        if (lane == e2) mx = part;
+                    }
+                }
                 if (fast_ok && mine) {
                     const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512 (crf: :320-334, no repeat case)
                     const int tst = L.b_state(cur)[e];                        // crf: the entry's own state (:725-728)
@@ -613,6 +646,10 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     nmax[node] = mx;
                 }
                 __syncthreads();  // the next node may read this one's new rows (parents first)
+            }
+            if (prof) {
+                ++n_ext;
+                n_slow += fast_ok ? 0u : 1u;
             }
             if (!fast_ok && resident) {  // the sequential path worked on the arena: refresh the resident copies
                 for (int e = 0; e < B; ++e) load_entry(cur, e);
@@ -1054,6 +1091,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             __syncthreads();
             if (entering) L.b_buf(nxt)[lane] = L.s_end[popc64(enter_m & lanemask_lt())];
             __syncthreads();
+            if (prof) n_enter += (uint32_t)popc64(enter_m);
             for (uint64_t m = enter_m; m != 0ull; m &= m - 1) load_entry(nxt, (int)__builtin_ctzll(m));
         }
         B = Bn;
@@ -1062,11 +1100,14 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         FCD_DUPLEX_PHASE(4)
     }
     if (prof && lane == 0) {
-        uint32_t *o = p.prof + 8 * r;
+        uint32_t *o = p.prof + 16 * r;
         for (int k = 0; k < 5; ++k) o[k] = (uint32_t)(acc[k] >> 6);  // units of 64 cycles: a pair runs ~2e8 cycles
         o[5] = n_iter;
         o[6] = n_newnodes;
         o[7] = (uint32_t)T1;
+        o[8] = n_slow;   // steps whose extension took the sequential path
+        o[9] = n_enter;  // nodes that entered the beam (their rings were copied into LDS)
+        o[10] = n_ext;   // steps in which the envelope's upper bound grew
     }
 
     // ---- labels leaf -> root (:638-649), written in sequence order ----

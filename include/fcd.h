@@ -166,10 +166,11 @@ int fcd_release_workspace(fcd_handle *h);
  * jobs.  A larger divisor makes the retry path run on small inputs (tests) and pins it; 0 restores the
  * adaptive default. */
 int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor);
-/* Developer instrument: while `cycles` (DEVICE array [n_pairs][8] u32, indexed by the pair's position in the batch)
+/* Developer instrument: while `cycles` (DEVICE array [n_pairs][16] u32, indexed by the pair's position in the batch)
  * is set, the duplex searches on this handle record a cycle account per pair: shader cycles / 64 spent in
  * [0] envelope + forward-vector extension, [1] LDS tiles, [2] expansion without the window builds, [3] window
- * builds of the new nodes, [4] rank + next beam; [5] window-build loop iterations, [6] new nodes, [7] steps.
+ * builds of the new nodes, [4] rank + next beam; [5] window-build loop iterations, [6] new nodes, [7] steps, [8] steps
+ * whose extension took the sequential path, [9] nodes that entered the beam, [10] steps with a growing upper bound.
  * NULL switches it off.  The stamps wait for each phase's results (tools/duplex_account.py). */
 int fcd_debug_set_duplex_profile(fcd_handle *h, uint32_t *cycles);
 /* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP

@@ -37,7 +37,7 @@ def main():
             r = fcd.beam_search_duplex_batch_raw(x1, x2, envs, 5, 0.1, True, logadd_mode=mode)
         torch.cuda.synchronize()
         plain_ms = h.last_kernel_ms()
-        prof = torch.zeros((B, 8), dtype=torch.int32, device="cuda")
+        prof = torch.zeros((B, 16), dtype=torch.int32, device="cuda")
         h.check(h.lib.fcd_debug_set_duplex_profile(h.ptr, C.c_void_p(prof.data_ptr())))
         r2 = fcd.beam_search_duplex_batch_raw(x1, x2, envs, 5, 0.1, True, logadd_mode=mode)
         torch.cuda.synchronize()
@@ -53,7 +53,9 @@ def main():
                "cycles_per_step_total": round(float(per_step.sum()), 1),
                "new_nodes_per_step": round(float((a[:, 6] / steps).mean()), 2),
                "build_loop_iterations_per_step": round(float((a[:, 5] / steps).mean()), 1),
-               "cycles_per_build_iteration": round(float((cyc[:, 3] / np.maximum(a[:, 5], 1)).mean()), 1)}
+               "cycles_per_build_iteration": round(float((cyc[:, 3] / np.maximum(a[:, 5], 1)).mean()), 1),
+               "sequential_extension_fraction": round(float((a[:, 8] / np.maximum(a[:, 10], 1)).mean()), 4),
+               "entering_nodes_per_step": round(float((a[:, 9] / steps).mean()), 3)}
         print(json.dumps(rec), flush=True)
 
 
