@@ -449,76 +449,58 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             // reads rows its parent already holds -- all nodes proceed in parallel, one per lane.
             // update_max (:193-204) is evaluated incrementally: the maximum over [lo, end) equals
             // the stored maximum over [rlo, end) unless one of the rows leaving the range attains it.
-            bool fast_ok = hi == last_hi + 1 && B <= kWave;
-            {
+            bool fast_ok = B <= kWave;
+            if (resident) {
+                // ---- all beam entries in parallel, one per lane, on the resident rings ----
+                // An entry appends rows [end, hi): one row when its window ends at the previous bound, several when
+                // the node sat outside the beam for a while and catches up (on BASELINE config 5 two steps in three
+                // bring such a node in: picked as an EXISTING child, its window is as stale as its creation).  Row idx
+                // reads the parent's row idx - 1 <= hi - 2, which exists BEFORE this step whenever the parent's
+                // window reaches hi - 1 -- then nothing depends on a row written in this step and the reference's
+                // parents-first order (:493) is immaterial.  Only a parent that is itself behind, or a bound that
+                // jumped, takes the sequential path below.
                 const int e = lane;
                 const bool mine = e < B && L.b_node(cur)[e] >= 0;
-                int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0,
-                    p_lab = -1, pslot = -1;
+                int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0, p_lab = -1,
+                    pslot = -1;
                 float mx = kNegInf;
-                bool bad = false, rescan = false;
-                const float *my_l = nullptr;  // the entry's own ring: LDS when resident, else the arena
+                bool bad = false, rescan = false, panic = false;
                 if (fast_ok && mine) {
                     node = L.b_node(cur)[e];
-                    if (resident) {
-                        parent = L.b_par(cur)[e]; lab = L.b_tip(cur)[e];
-                        off = L.b_off(cur)[e]; end = L.b_end(cur)[e];
-                        mx = L.b_max(cur)[e]; rl = L.b_rlo(cur)[e];
-                        my_l = ring(L.b_buf(cur)[e]);
-                    } else {
-                        const int4 m = load_meta_l2(&meta[node]);
-                        parent = m.x; lab = m.y; off = m.z; end = m.w;
-                        mx = load_f32_l2(&nmax[node]);
-                        rl = load_i32_l2(&rlo[node]);
-                        my_l = vec + (int64_t)node * Wcap * 3;
-                    }
-                    bad = end != last_hi;
-                    if (!bad && lo > off) {
+                    parent = L.b_par(cur)[e]; lab = L.b_tip(cur)[e];
+                    off = L.b_off(cur)[e]; end = L.b_end(cur)[e];
+                    mx = L.b_max(cur)[e]; rl = L.b_rlo(cur)[e];
+                    if (lo > off) {  // :351-359
                         const int keep = lo - 1;
-                        const int off_old = off;
                         if (keep > off) {
                             if (keep < end) off = keep;
                             else { off = keep; end = keep; }
                         }
                         if (end == off) { off = lo; end = lo; }
-                        bad = end != last_hi;
-                        if (resident) {
-                            // update_max(lo, hi) (:356): with the ring in LDS the maximum over [lo, end) is simply
-                            // recomputed by the whole wavefront below -- the incremental test ("does a leaving row
-                            // hold the maximum?") failed on 68 % (logsumexp) / 97 % (max mode: the best single path
-                            // loses probability with every row, so the maximum sits at the window's first row) of
-                            // the steps of BASELINE config 5 and sent all beam entries down the sequential path
-                            rescan = !bad;
-                            rl = lo;
-                        } else {
-                            if (!bad && lo < rl) bad = true;  // the range grows downwards: rescan (slow path)
-                            if (!bad && lo > rl) {
-                                if (lo - rl > 4) bad = true;  // a long stale range: rescan on the slow path
-                                for (int t = rl; t < lo && !bad; ++t) {
-                                    if (t < off_old || t >= end) continue;
-                                    const float sv = load_f32_l2(my_l + 3 * (t % Wcap) + 2);
-                                    if (sv == sv && !(sv < mx)) bad = true;  // the leaving row holds the max
-                                }
-                                rl = lo;
-                            }
-                        }
+                        rescan = true;  // update_max(lo, hi): recomputed from the ring by the whole wavefront below
+                        rl = lo;
                     }
-                    if (!bad && parent >= 0) {
-                        if (resident)
-                            for (int j = 0; j < B; ++j)
-                                if (L.b_node(cur)[j] == parent) pslot = j;
+                    panic = end >= hi;  // assert!(current_end < upper_bound) :363-366
+                    if (parent >= 0) {
+                        for (int j = 0; j < B; ++j)
+                            if (L.b_node(cur)[j] == parent) pslot = j;
                         if (pslot >= 0) {  // the parent is a beam entry: its window is resident too
                             p_lab = L.b_tip(cur)[pslot]; p_off = L.b_off(cur)[pslot]; p_end = L.b_end(cur)[pslot];
+                            bad = p_end < hi - 1;  // it has yet to write a row this entry needs: parents first
                         } else {
                             const int4 pm = load_meta_l2(&meta[parent]);
                             p_lab = pm.y; p_off = pm.z; p_end = pm.w;
                         }
                     }
                 }
+                if (ballot(panic) != 0ull) return fail(FCD_ST_BAD_STATE);
                 fast_ok = fast_ok && ballot(bad) == 0ull;
-                if (fast_ok && resident) {
+                if (fast_ok) {
                     // update_max over the rows that stay, [max(lo, off), end), for every entry that discarded rows:
-                    // 64 lanes per entry, two LDS reads each at W = 128 (NaN entries never replace the maximum)
+                    // 64 lanes per entry, two LDS reads each at W = 128 (NaN entries never replace the maximum).  The
+                    // incremental form of r02 ("does a leaving row hold the maximum?") sent 68 % (logsumexp) / 97 %
+                    // (max mode: the best single path loses probability with every row, so the maximum sits at the
+                    // window's first row) of config 5's steps down the sequential path.
                     for (uint64_t m = ballot(rescan); m != 0ull; m &= m - 1) {
                         const int e2 = (int)__builtin_ctzll(m);
                         const int o2 = __shfl(off, e2), n2 = __shfl(end, e2);
@@ -532,43 +514,114 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 if (fast_ok && mine) {
                     const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512 (crf: :320-334, no repeat case)
                     const int tst = L.b_state(cur)[e];                        // crf: the entry's own state (:725-728)
-                    float *my = vec + (int64_t)node * Wcap * 3;
+                    float *my = vec + (int64_t)node * Wcap * 3;               // the arena is written through
+                    float *mw = ring(L.b_buf(cur)[e]);
                     float l_lab = kNegInf, l_sum = kNegInf;
                     if (end > off) {
                         const int sl = (end - 1) % Wcap;
-                        l_lab = resident ? my_l[3 * sl] : load_f32_l2(my + 3 * sl);
-                        l_sum = resident ? my_l[3 * sl + 2] : load_f32_l2(my + 3 * sl + 2);
+                        l_lab = mw[3 * sl];
+                        l_sum = mw[3 * sl + 2];
                     }
-                    const int idx = end;  // == last_hi == hi - 1
-                    const float *row = ln2 + ((int64_t)idx * S + tst) * N;
-                    float pg, ps;
-                    if (pslot >= 0) {
-                        ring_get(ring(L.b_buf(cur)[pslot]), p_off, p_end, idx - 1, pg, ps);
-                    } else {
-                        const VecRef pv = node_vec(parent, p_off, p_end);
-                        vec_get(pv, idx - 1, Wcap, pg, ps);
-                    }
-                    const float g = l_sum + row[0];
-                    const float xx = is_rep ? pg : ps;
-                    const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
-                    const float sm = ladd<MODE>(lb, g);
-                    const int sl = idx % Wcap;
-                    my[3 * sl] = lb;  // the arena is written through
-                    my[3 * sl + 1] = g;
-                    my[3 * sl + 2] = sm;
-                    mx = lmax(mx, sm);
-                    meta[node] = make_int4(parent, lab, off, hi);
-                    nmax[node] = mx;
-                    rlo[node] = rl;
-                    if (resident) {
-                        float *mw = ring(L.b_buf(cur)[e]);
+                    const float *prg = pslot >= 0 ? ring(L.b_buf(cur)[pslot]) : nullptr;
+                    const VecRef pv = node_vec(parent, p_off, p_end);
+                    for (int idx = end; idx < hi; ++idx) {  // :361-386
+                        const float *row = ln2 + ((int64_t)idx * S + tst) * N;
+                        float pg, ps;
+                        if (pslot >= 0) ring_get(prg, p_off, p_end, idx - 1, pg, ps);
+                        else vec_get(pv, idx - 1, Wcap, pg, ps);
+                        const float g = l_sum + row[0];
+                        const float xx = is_rep ? pg : ps;
+                        const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
+                        const float sm = ladd<MODE>(lb, g);
+                        const int sl = idx % Wcap;
+                        my[3 * sl] = lb;
+                        my[3 * sl + 1] = g;
+                        my[3 * sl + 2] = sm;
                         mw[3 * sl] = lb;
                         mw[3 * sl + 1] = g;
                         mw[3 * sl + 2] = sm;
-                        L.b_off(cur)[e] = off;
-                        L.b_end(cur)[e] = hi;
-                        L.b_max(cur)[e] = mx;
-                        L.b_rlo(cur)[e] = rl;
+                        mx = lmax(mx, sm);
+                        l_lab = lb;
+                        l_sum = sm;
+                    }
+                    meta[node] = make_int4(parent, lab, off, hi);
+                    nmax[node] = mx;
+                    rlo[node] = rl;
+                    L.b_off(cur)[e] = off;
+                    L.b_end(cur)[e] = hi;
+                    L.b_max(cur)[e] = mx;
+                    L.b_rlo(cur)[e] = rl;
+                }
+            } else {
+                fast_ok = fast_ok && hi == last_hi + 1;
+                {
+                    const int e = lane;
+                    const bool mine = e < B && L.b_node(cur)[e] >= 0;
+                    int node = -1, parent = -1, lab = 0, off = 0, end = 0, rl = 0, p_off = 0, p_end = 0,
+                        p_lab = -1;
+                    float mx = kNegInf;
+                    bool bad = false;
+                    if (fast_ok && mine) {
+                        node = L.b_node(cur)[e];
+                        const int4 m = load_meta_l2(&meta[node]);
+                        parent = m.x; lab = m.y; off = m.z; end = m.w;
+                        mx = load_f32_l2(&nmax[node]);
+                        rl = load_i32_l2(&rlo[node]);
+                        bad = end != last_hi;
+                        if (!bad && lo > off) {
+                            const int keep = lo - 1;
+                            const int off_old = off;
+                            if (keep > off) {
+                                if (keep < end) off = keep;
+                                else { off = keep; end = keep; }
+                            }
+                            if (end == off) { off = lo; end = lo; }
+                            bad = end != last_hi;
+                            if (!bad && lo < rl) bad = true;  // the range grows downwards: rescan (slow path)
+                            if (!bad && lo > rl) {
+                                if (lo - rl > 4) bad = true;  // a long stale range: rescan on the slow path
+                                const float *my = vec + (int64_t)node * Wcap * 3;
+                                for (int t = rl; t < lo && !bad; ++t) {
+                                    if (t < off_old || t >= end) continue;
+                                    const float sv = load_f32_l2(my + 3 * (t % Wcap) + 2);
+                                    if (sv == sv && !(sv < mx)) bad = true;  // the leaving row holds the max
+                                }
+                                rl = lo;
+                            }
+                        }
+                        if (!bad && parent >= 0) {
+                            const int4 pm = load_meta_l2(&meta[parent]);
+                            p_lab = pm.y; p_off = pm.z; p_end = pm.w;
+                        }
+                    }
+                    fast_ok = fast_ok && ballot(bad) == 0ull;
+                    if (fast_ok && mine) {
+                        const VecRef pv = node_vec(parent, p_off, p_end);
+                        const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512 (crf: :320-334, no repeat case)
+                        const int tst = L.b_state(cur)[e];                        // crf: the entry's own state (:725-728)
+                        float *my = vec + (int64_t)node * Wcap * 3;
+                        float l_lab = kNegInf, l_sum = kNegInf;
+                        if (end > off) {
+                            const int sl = (end - 1) % Wcap;
+                            l_lab = load_f32_l2(my + 3 * sl);
+                            l_sum = load_f32_l2(my + 3 * sl + 2);
+                        }
+                        const int idx = end;  // == last_hi == hi - 1
+                        const float *row = ln2 + ((int64_t)idx * S + tst) * N;
+                        float pg, ps;
+                        vec_get(pv, idx - 1, Wcap, pg, ps);
+                        const float g = l_sum + row[0];
+                        const float xx = is_rep ? pg : ps;
+                        const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
+                        const float sm = ladd<MODE>(lb, g);
+                        const int sl = idx % Wcap;
+                        my[3 * sl] = lb;
+                        my[3 * sl + 1] = g;
+                        my[3 * sl + 2] = sm;
+                        mx = lmax(mx, sm);
+                        meta[node] = make_int4(parent, lab, off, hi);
+                        nmax[node] = mx;
+                        rlo[node] = rl;
                     }
                 }
             }
