@@ -823,7 +823,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     // build_secondary_probs (:212-249): whole window [lo, hi), one node per lane
                     const int l = k - 1;
                     int p_off = 0, p_end = 0;
-                    if (node >= 0) {
+                    if (node >= 0 && !staged) {  // (staged: the parent's bounds are in LDS with its ring)
                         const int4 pm = load_meta_l2(&meta[node]);
                         p_off = pm.z;
                         p_end = pm.w;
@@ -831,22 +831,42 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     const VecRef pv = node_vec(node, p_off, p_end);
                     float *my = vec + (int64_t)cid * Wcap * 3;
                     float l_lab = kNegInf, l_sum = kNegInf, mx = kNegInf;
-                    int s = lo % Wcap;
-                    const float *prg = staged ? ring(L.b_buf(cur)[i]) : nullptr;  // the parent's resident ring
-                    const int q_off = staged ? L.b_off(cur)[i] : 0, q_end = staged ? L.b_end(cur)[i] : 0;
-                    for (int idx = lo; idx < hi; ++idx) {
-                        float pg, ps, r0, rl1;
-                        if (staged) {
-                            const int j = idx - lo;
-                            r0 = L.w2[(j * S + state) * N];
-                            rl1 = L.w2[(j * S + state) * N + l + 1];
-                            ring_get(prg, q_off, q_end, idx - 1, pg, ps);
-                        } else {
-                            const float *row = ln2 + ((int64_t)idx * S + state) * N;  // crf: tip.state (:772)
-                            r0 = row[0];
-                            rl1 = row[l + 1];
-                            vec_get(pv, idx - 1, Wcap, pg, ps);
+                    if (staged) {
+                        // operands of the NEXT row are requested before this row's arithmetic, slots advance
+                        // incrementally: the parent's row t - 1 sits where this node's row t - 1 sits (same ring
+                        // geometry), i.e. in the slot this loop has just left
+                        const float *wq = L.w2 + state * N;                               // + row * S * N
+                        const float *xq = ring(L.b_buf(cur)[i]) + (rep ? 1 : 2);          // the parent's resident ring
+                        const int q_off = L.b_off(cur)[i], q_end = L.b_end(cur)[i];
+                        const int rstep = S * N;
+                        int s3 = 3 * (lo % Wcap);
+                        float r0 = wq[0], rl1 = wq[l + 1];
+                        float x = (lo - 1 >= q_off && lo - 1 < q_end) ? xq[3 * (((lo - 1) % Wcap + Wcap) % Wcap)] : kNegInf;
+                        for (int j = 0; j < W; ++j) {
+                            const int jn = j + 1 < W ? j + 1 : j;
+                            const float r0n = wq[jn * rstep], rl1n = wq[jn * rstep + l + 1];
+                            const float xn = (lo + j >= q_off && lo + j < q_end) ? xq[s3] : kNegInf;  // parent's row lo + j
+                            const float g = l_sum + r0;
+                            const float lb = rl1 + ladd<MODE>(l_lab, x);
+                            const float sm = ladd<MODE>(lb, g);
+                            my[s3] = lb;
+                            my[s3 + 1] = g;
+                            my[s3 + 2] = sm;
+                            mx = lmax(mx, sm);
+                            l_lab = lb;
+                            l_sum = sm;
+                            s3 = s3 + 3 == 3 * Wcap ? 0 : s3 + 3;
+                            r0 = r0n;
+                            rl1 = rl1n;
+                            x = xn;
                         }
+                    } else {
+                    int s = lo % Wcap;
+                    for (int idx = lo; idx < hi; ++idx) {
+                        float pg, ps;
+                        const float *row = ln2 + ((int64_t)idx * S + state) * N;  // crf: tip.state (:772)
+                        const float r0 = row[0], rl1 = row[l + 1];
+                        vec_get(pv, idx - 1, Wcap, pg, ps);
                         const float g = l_sum + r0;
                         const float x = rep ? pg : ps;
                         const float lb = rl1 + ladd<MODE>(l_lab, x);
@@ -858,6 +878,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         l_lab = lb;
                         l_sum = sm;
                         if (++s == Wcap) s = 0;
+                    }
                     }
                     meta[cid] = make_int4(node, l, lo, hi);
                     nmax[cid] = mx;
