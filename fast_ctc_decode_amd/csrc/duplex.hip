@@ -240,6 +240,71 @@ __device__ __forceinline__ void vec_get(const VecRef &v, int at, int Wcap, float
     sum = load_f32_l2(v.base + 3 * slot + 2);
 }
 
+// Two pieces of the resident-window bookkeeping live OUT OF LINE: inlined, they pushed the logsumexp instantiations
+// (whose window-building loop pins ~60 coefficient registers) over the register file and spilled 226 - 276 VGPRs to
+// scratch memory.  Both run a few times per step; a call costs far less than the spills did.
+//
+// A node entering the beam: rows [off, off + n3 / 3) of its ring, arena -> LDS (eight loads in flight per lane).
+__device__ __attribute__((noinline)) void ring_copy_in(const float *src, float *dst, int off, int n3, int Wcap, int lane) {
+    for (int base = 0; base < n3; base += 8 * kWave) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * kWave + lane;
+            const int row = idx / 3;
+            v[u] = idx < n3 ? load_f32_l2(src + ((off + row) % Wcap) * 3 + (idx - row * 3)) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int idx = base + u * kWave + lane;
+            const int row = idx / 3;
+            if (idx < n3) dst[((off + row) % Wcap) * 3 + (idx - row * 3)] = v[u];
+        }
+    }
+}
+
+// extend_secondary_probs' recurrence (:361-386) for ONE beam entry on its own lane: rows [end, hi) appended to the
+// resident ring `mw` and, written through, to the arena ring `my`; returns the running maximum.  The parent's rows
+// come from its resident ring `prg` (bounds p_off / p_end) or, when it is not a beam entry, from the arena (`pv`).
+template <int MODE>
+__device__ __attribute__((noinline)) float extend_rows(float *my, float *mw, const float *prg, VecRef pv, int p_off,
+                                                       int p_end, const float *tile, int tile_step, int lo, int end,
+                                                       int hi, int lab, bool is_rep, int Wcap, float l_lab, float l_sum,
+                                                       float mx) {
+    for (int idx = end; idx < hi; ++idx) {  // idx >= lo: the rows of read 2 are in the LDS tile
+        const float *row = tile + (idx - lo) * tile_step;
+        float pg, ps;
+        if (prg) {
+            const int at = idx - 1;
+            if (at < p_off || at >= p_end) {
+                pg = kNegInf;
+                ps = kNegInf;
+            } else {
+                const int sl = (((at % Wcap) + Wcap) % Wcap) * 3;
+                pg = prg[sl + 1];
+                ps = prg[sl + 2];
+            }
+        } else {
+            vec_get(pv, idx - 1, Wcap, pg, ps);
+        }
+        const float g = l_sum + row[0];
+        const float xx = is_rep ? pg : ps;
+        const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
+        const float sm = ladd<MODE>(lb, g);
+        const int sl = (idx % Wcap) * 3;
+        my[sl] = lb;
+        my[sl + 1] = g;
+        my[sl + 2] = sm;
+        mw[sl] = lb;
+        mw[sl + 1] = g;
+        mw[sl + 2] = sm;
+        mx = lmax(mx, sm);
+        l_lab = lb;
+        l_sum = sm;
+    }
+    return mx;
+}
+
 // PIN: the log-add coefficients stay in vector registers across the window-building loop (60 registers: the
 // instantiation for batches that leave a wavefront alone on its SIMD, where a row's instruction count is
 // what the loop costs); without it the kernel fits three wavefronts per SIMD, which wins once the GPU is full.
@@ -389,23 +454,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         if (node < 0) return;  // the root's rows are staged per step
         const int4 m = load_meta_l2(&meta[node]);
         const int off = m.z, end = m.w;
-        float *dst = ring(L.b_buf(bsel)[e]);
-        const float *src = vec + (int64_t)node * Wcap * 3;
-        const int n3 = (end - off) * 3;
-        for (int base = 0; base < n3; base += 8 * kWave) {  // eight loads in flight per lane, then the LDS stores
-            float v[8];
-            int sl[8];
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const int idx = base + u * kWave + lane;
-                const int row = idx / 3;
-                sl[u] = ((off + row) % Wcap) * 3 + (idx - row * 3);
-                v[u] = idx < n3 ? load_f32_l2(src + sl[u]) : 0.0f;
-            }
-#pragma unroll
-            for (int u = 0; u < 8; ++u)
-                if (base + u * kWave + lane < n3) dst[sl[u]] = v[u];
-        }
+        ring_copy_in(vec + (int64_t)node * Wcap * 3, ring(L.b_buf(bsel)[e]), off, (end - off) * 3, Wcap, lane);
         if (lane == 0) {
             L.b_off(bsel)[e] = off;
             L.b_end(bsel)[e] = end;
@@ -414,13 +463,26 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         }
     };
 
+    // (the envelope row of step t1 + 1 is requested during step t1: no global round trip at the head of a step)
+    uint64_t env_lo_next = env[0], env_hi_next = env[1];
     for (int64_t t1 = 0; t1 < T1; ++t1) {
         // ---- envelope (:485-488) ----
-        const uint64_t lo_u = env[2 * t1], hi_u = env[2 * t1 + 1];
+        const uint64_t lo_u = env_lo_next, hi_u = env_hi_next;
+        if (t1 + 1 < T1) {
+            env_lo_next = env[2 * (t1 + 1)];
+            env_hi_next = env[2 * (t1 + 1) + 1];
+        }
         const int hi = (int)(hi_u > (uint64_t)T2 ? (uint64_t)T2 : hi_u);
         if (lo_u >= (uint64_t)hi || lo_u > (uint64_t)last_hi) return fail(FCD_ST_INVALID_ENVELOPE);
         const int lo = (int)lo_u;
 
+        const int W = hi - lo;
+        if (staged) {
+            // ---- LDS tile of read 2's rows [lo, hi) for this row of read 1 (the extension below reads it too) ----
+            __syncthreads();
+            for (int xw = lane; xw < W * S * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * S * N + xw];
+            __syncthreads();
+        }
         if (hi > last_hi) {
             // ---- :493 beam.sort_by_key(node): parents before children ----
             const int nx = cur ^ 1;
@@ -524,26 +586,8 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     }
                     const float *prg = pslot >= 0 ? ring(L.b_buf(cur)[pslot]) : nullptr;
                     const VecRef pv = node_vec(parent, p_off, p_end);
-                    for (int idx = end; idx < hi; ++idx) {  // :361-386
-                        const float *row = ln2 + ((int64_t)idx * S + tst) * N;
-                        float pg, ps;
-                        if (pslot >= 0) ring_get(prg, p_off, p_end, idx - 1, pg, ps);
-                        else vec_get(pv, idx - 1, Wcap, pg, ps);
-                        const float g = l_sum + row[0];
-                        const float xx = is_rep ? pg : ps;
-                        const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
-                        const float sm = ladd<MODE>(lb, g);
-                        const int sl = idx % Wcap;
-                        my[3 * sl] = lb;
-                        my[3 * sl + 1] = g;
-                        my[3 * sl + 2] = sm;
-                        mw[3 * sl] = lb;
-                        mw[3 * sl + 1] = g;
-                        mw[3 * sl + 2] = sm;
-                        mx = lmax(mx, sm);
-                        l_lab = lb;
-                        l_sum = sm;
-                    }
+                    mx = extend_rows<MODE>(my, mw, prg, pv, p_off, p_end, L.w2 + tst * N, S * N, lo, end, hi, lab, is_rep,
+                                           Wcap, l_lab, l_sum, mx);  // :361-386
                     meta[node] = make_int4(parent, lab, off, hi);
                     nmax[node] = mx;
                     rlo[node] = rl;
@@ -712,10 +756,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         last_hi = hi;
         FCD_DUPLEX_PHASE(0)
 
-        const int W = hi - lo;
         if (staged) {
-            // ---- LDS tile of read 2's rows for this row of read 1; the beam entries' own windows are resident ----
-            for (int xw = lane; xw < W * S * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * S * N + xw];
             // the root (in the beam for the first few rows only) has no ring in the arena: the rows its children's
             // builds will ask for, [lo-1, hi-1), are staged into its buffer from the cumulative blank products
             for (int e = 0; e < B; ++e) {
@@ -1164,9 +1205,24 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             const uint64_t enter_m = ballot(entering);
             __syncthreads();
             if (entering) L.b_buf(nxt)[lane] = L.s_end[popc64(enter_m & lanemask_lt())];
+            // bounds and maxima of ALL entering nodes in one round trip (each on its own lane) ...
+            if (entering) {
+                const int nd = L.b_node(nxt)[lane];
+                const int4 m4 = load_meta_l2(&meta[nd]);
+                L.b_off(nxt)[lane] = m4.z;
+                L.b_end(nxt)[lane] = m4.w;
+                L.b_max(nxt)[lane] = load_f32_l2(&nmax[nd]);
+                L.b_rlo(nxt)[lane] = load_i32_l2(&rlo[nd]);
+            }
             __syncthreads();
             if (prof) n_enter += (uint32_t)popc64(enter_m);
-            for (uint64_t m = enter_m; m != 0ull; m &= m - 1) load_entry(nxt, (int)__builtin_ctzll(m));
+            // ... then their rings
+            for (uint64_t m = enter_m; m != 0ull; m &= m - 1) {
+                const int e2 = (int)__builtin_ctzll(m);
+                const int eo = L.b_off(nxt)[e2];
+                ring_copy_in(vec + (int64_t)L.b_node(nxt)[e2] * Wcap * 3, ring(L.b_buf(nxt)[e2]), eo,
+                             (L.b_end(nxt)[e2] - eo) * 3, Wcap, lane);
+            }
         }
         B = Bn;
         cur = nxt;
