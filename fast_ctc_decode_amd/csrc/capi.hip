@@ -907,6 +907,15 @@ int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float 
     return FCD_OK;
 }
 
+int fcd_logadd_latency_probe_dev(fcd_handle *h, int n_chain, int logadd_mode, uint64_t *cycles, float *sink) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (n_chain < 1 || !cycles || !sink) return fail(h, FCD_E_INVALID, "bad argument");
+    FCD_DEVICE(h);
+    FCD_HIP(h, launch_logadd_chain(n_chain, logadd_mode, cycles, sink, h->stream));
+    return FCD_OK;
+}
+
 // ---- compact wire format of a shard's results (pack.hip) ----
 int64_t fcd_packed_result_bytes(int64_t n_reads, int64_t total_labels, int path_bytes) {
     if (n_reads < 0 || total_labels < 0 || (path_bytes != 2 && path_bytes != 4)) return -1;

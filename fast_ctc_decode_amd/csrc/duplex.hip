@@ -436,17 +436,6 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
     // ---- resident windows (staged launches): LDS twins of the beam entries' rings ----
     const bool resident = staged;
     auto ring = [&](int buf) { return L.bw + (size_t)buf * Wcap * 3; };
-    // the reference's SecondaryProbs::get (:167-179) on a resident ring: (gap, label(+)gap) of row `at`
-    auto ring_get = [&](const float *rg, int off, int end, int at, float &gap, float &sum) {
-        if (at < off || at >= end) {
-            gap = kNegInf;
-            sum = kNegInf;
-            return;
-        }
-        const int sl = (((at % Wcap) + Wcap) % Wcap) * 3;  // (the root's row -1 sits in the last slot)
-        gap = rg[sl + 1];
-        sum = rg[sl + 2];
-    };
     // node enters the beam (or its ring was rewritten by the sequential extension): bounds, maximum and rows
     // [off, end) come in from the arena, which is always written through; wave-cooperative, wave-uniform arguments
     auto load_entry = [&](int bsel, int e) {
@@ -1282,6 +1271,25 @@ __global__ void logspace_probe_kernel(const float *a, const float *b, float *out
     }
 }
 
+// developer instrument: the DEPENDENT latency of one LogSpace::add as the window-building loop evaluates it
+// (ladd_lockstep, coefficients in registers): every lane folds n_chain values into an accumulator, each add
+// waiting for the previous one; cycles[lane] = shader cycles of the whole chain.  The duplex searches are bound by
+// this latency (a tree node's window is W sequential rows), not by HBM or by the binary64 issue rate.
+template <int MODE>
+__global__ __launch_bounds__(64) void logadd_chain_kernel(int n_chain, uint64_t *cycles, float *sink) {
+    const LogAddCoef K = logadd_coef();
+    float acc = -1.0f - 0.001f * (float)threadIdx.x;
+    const float v = -1.25f;
+    uint64_t t0 = 0, t1 = 0;
+    int dep = (int)__float_as_uint(acc);
+    FCD_STAMP(t0, dep);
+    for (int i = 0; i < n_chain; ++i) acc = ladd_lockstep<MODE>(acc, v, K) - 0.125f;  // stays on the full path
+    dep = (int)__float_as_uint(acc);
+    FCD_STAMP(t1, dep);
+    cycles[threadIdx.x] = t1 - t0;
+    sink[threadIdx.x] = acc;
+}
+
 // widest clamped envelope row over the whole batch -> *out (int), for sizing the rings
 __global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t env_stride,
                                  int64_t T1cap, int64_t T2cap, const int64_t *len1,
@@ -1338,6 +1346,14 @@ hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add,
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(logspace_probe_kernel, dim3(blocks), dim3(256), 0, stream, a, b, out_add, out_ln,
                        n, mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_logadd_chain(int n_chain, int mode, uint64_t *cycles, float *sink, hipStream_t stream) {
+    if (mode == FCD_LOGADD_MAX)
+        hipLaunchKernelGGL(logadd_chain_kernel<FCD_LOGADD_MAX>, dim3(1), dim3(64), 0, stream, n_chain, cycles, sink);
+    else
+        hipLaunchKernelGGL(logadd_chain_kernel<FCD_LOGADD_LOGSUMEXP>, dim3(1), dim3(64), 0, stream, n_chain, cycles, sink);
     return hipGetLastError();
 }
 

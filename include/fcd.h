@@ -285,6 +285,12 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
                            float *out_ln, int64_t n, int logadd_mode);
 
+/* Developer instrument: one wavefront folds n_chain values into an accumulator with the duplex kernel's
+ * LogSpace::add, each add waiting for the previous one; cycles[lane] (DEVICE u64[64]) = shader cycles of the chain,
+ * sink (DEVICE f32[64]) keeps the result alive.  cycles / n_chain is the dependent latency that bounds the duplex
+ * searches (tools/duplex_account.py: the dependent-chain roofline). */
+int fcd_logadd_latency_probe_dev(fcd_handle *h, int n_chain, int logadd_mode, uint64_t *cycles, float *sink);
+
 /* ---- compact wire format of a shard's results, for the ONE gather of the multi-GPU path ----
  * The searches write fixed-stride rows; only out_len[r] entries of row r are meaningful (~48 % at BASELINE
  * config 2).  These three calls turn a result into one contiguous buffer holding just the used prefixes

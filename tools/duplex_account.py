@@ -32,6 +32,15 @@ def main():
     envs = torch.from_numpy(np.broadcast_to(env, (B, T, 2)).copy().view(np.int64)).cuda()
     h = nat.default_handle()
     names = ["envelope+extend", "lds_tiles", "expansion", "window_builds", "rank+next_beam"]
+    # dependent latency of one LogSpace::add, both flavours (one wavefront, a chain of 4096 adds)
+    lat = {}
+    cyc = torch.zeros(64, dtype=torch.int64, device="cuda")
+    sink = torch.zeros(64, dtype=torch.float32, device="cuda")
+    for mode in (0, 1):
+        for _ in range(2):
+            h.check(h.lib.fcd_logadd_latency_probe_dev(h.ptr, 4096, mode, C.c_void_p(cyc.data_ptr()), C.c_void_p(sink.data_ptr())))
+            torch.cuda.synchronize()
+        lat[mode] = float(cyc.cpu().numpy().astype(np.float64).mean()) / 4096.0
     for mode, mname in ((0, "logsumexp"), (1, "max")):
         for _ in range(2):
             r = fcd.beam_search_duplex_batch_raw(x1, x2, envs, 5, 0.1, True, logadd_mode=mode)
@@ -54,6 +63,14 @@ def main():
                "new_nodes_per_step": round(float((a[:, 6] / steps).mean()), 2),
                "build_loop_iterations_per_step": round(float((a[:, 5] / steps).mean()), 1),
                "cycles_per_build_iteration": round(float((cyc[:, 3] / np.maximum(a[:, 5], 1)).mean()), 1),
+               # The dependent-chain roofline: a new node's window is W + 1 sequential rows, each one LogSpace::add
+               # behind the previous (the two chains of a row run on a pair of lanes); every step builds at least one
+               # pass of new nodes.  bound = steps x rows x the add's dependent latency; frac = bound / kernel time.
+               "chain_roofline": {
+                   "bound": "dependent log-add chain", "cycles_per_dependent_logadd": round(lat[mode], 1),
+                   "rows_per_step": w * 2 + 1, "steps": T,
+                   "bound_cycles_per_step": round((w * 2 + 1) * lat[mode], 1),
+                   "frac": round((w * 2 + 1) * lat[mode] / float(per_step.sum()), 4)},
                "sequential_extension_fraction": round(float((a[:, 8] / np.maximum(a[:, 10], 1)).mean()), 4),
                "entering_nodes_per_step": round(float((a[:, 9] / steps).mean()), 3)}
         print(json.dumps(rec), flush=True)
