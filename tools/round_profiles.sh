@@ -2,7 +2,7 @@
 # Everything the per-round evidence under profiles/ is made from, in ONE call on the GPU box.
 # Usage: tools/round_profiles.sh TAG      (then, here: tools/summarize_profile.py TAG; tools/summarize_sq.py TAG)
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
 R=$PWD
 O=$R/gpurun_out
 mkdir -p $O
@@ -11,7 +11,14 @@ bash tools/profile_sq.sh $TAG beam > $O/${TAG}_profile_sq.log 2>&1
 # rocprofv3 summary of the bench command itself: its kernel average must agree with bench.py's HIP events
 ( export TMPDIR=/tmp; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_bench -o bench -- \
     python $R/bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err )
+# the BASELINE multi-GPU config's per-rank shard and the CRF config under the same contract
+python bench.py --config 3 --no-viterbi --steps 5 > $O/${TAG}_bench_config3.json 2> $O/${TAG}_bench_config3.err
+python bench.py --config 4 --no-viterbi > $O/${TAG}_bench_config4.json 2> $O/${TAG}_bench_config4.err
+# the RCCL path of the bench at world size 1 (communicator, pack, ONE gather, one-launch unpack)
+python bench.py --force-dist --no-viterbi --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_rccl_world1.json 2> $O/${TAG}_bench_rccl_world1.err
+python tools/probe_e2e.py 4096 --grid > $O/${TAG}_e2e_probe.txt 2>&1
+python tools/duplex_account.py > $O/${TAG}_duplex_account.jsonl 2> $O/${TAG}_duplex_account.err
 python tools/cycle_account.py > $O/${TAG}_cycle_account.jsonl 2> $O/${TAG}_cycle_account.err
 python tools/bench_configs.py 1 3 4 5 64 1024 --check > $O/${TAG}_configs.jsonl 2> $O/${TAG}_configs.err
 python tools/probe_latency.py > $O/${TAG}_latency.txt 2>&1
-for f in $O/${TAG}_bench_line.json $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt; do tail -n 2 $f | cut -c1-300; done
+for f in $O/${TAG}_bench_line.json $O/${TAG}_bench_config3.json $O/${TAG}_duplex_account.jsonl $O/${TAG}_e2e_probe.txt $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt; do tail -n 2 $f | cut -c1-300; done
