@@ -9,8 +9,11 @@ mkdir -p $O
 bash tools/profile.sh $TAG all > $O/${TAG}_profile.log 2>&1
 bash tools/profile_sq.sh $TAG beam > $O/${TAG}_profile_sq.log 2>&1
 # rocprofv3 summary of the bench command itself: its kernel average must agree with bench.py's HIP events
+# (--no-e2e: the host-batch leg launches the same kernel on 1024-read chunks, which would blur the average)
 ( export TMPDIR=/tmp; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_bench -o bench -- \
-    python $R/bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err )
+    python $R/bench.py --no-e2e > $O/${TAG}_bench_line_rocprof.json 2> $O/${TAG}_bench_rocprof.err )
+# the default command, as the driver runs it (with the e2e leg)
+python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err
 # the BASELINE multi-GPU config's per-rank shard and the CRF config under the same contract
 python bench.py --config 3 --no-viterbi --steps 5 > $O/${TAG}_bench_config3.json 2> $O/${TAG}_bench_config3.err
 python bench.py --config 4 --no-viterbi > $O/${TAG}_bench_config4.json 2> $O/${TAG}_bench_config4.err
