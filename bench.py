@@ -206,6 +206,17 @@ def e2e_leg(fcd, cfg, x_host, init_host, ref_result, reps=3):
     return out
 
 
+def _counting_instantiation(name):
+    """beam_wave_kernel<N, GW, RPW, S, AMB, ...> / beam_lane_kernel<N, RPW, AMB, CRF>: the tie-counting (AMB = true)
+    instantiations are not the timed kernels."""
+    args = [a.strip() for a in name[name.find("<") + 1:name.rfind(">")].split(",")] if "<" in name else []
+    if name.startswith("beam_wave_kernel"):
+        return len(args) > 4 and args[4] == "true"
+    if name.startswith("beam_lane_kernel"):
+        return len(args) > 2 and args[2] == "true"
+    return False
+
+
 def pmc_traffic(kernel_prefix):
     """HBM bytes per launch from the newest committed PMC summary (profiles/*_pmc_summary.json,
     produced by tools/profile.sh: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the
@@ -218,7 +229,7 @@ def pmc_traffic(kernel_prefix):
         with open(path) as f:
             summ = json.load(f)
         for name, e in summ.get("kernels", {}).items():
-            if name.startswith(kernel_prefix) and ", true, false" not in name and "hbm_bytes_per_launch" in e:
+            if name.startswith(kernel_prefix) and not _counting_instantiation(name) and "hbm_bytes_per_launch" in e:
                 if not digest_matches(summ.get("kernel_source_md5"), kernel_prefix):
                     stale = stale or os.path.basename(path)
                     continue

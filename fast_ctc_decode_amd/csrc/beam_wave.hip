@@ -109,7 +109,10 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // FAILING (its status is already written and its traceback skipped), so nothing has to keep its beam intact:
 // the per-step "this half still runs" guards disappear -- a failed read is left with an EMPTY beam (B = 0), which
 // makes every later step a no-op for it, and a half without a read starts that way.
-template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false>
+// H16: the posteriors may be a 16-bit type (fcd_batch.dtype, converted exactly on load).  A separate instantiation:
+// with the element type a run-time value the float32 kernels paid for the test on every FIFO refill -- every step
+// in the CRF shape, whose rows fill a whole FIFO register (config 4: 4.2 -> 5.3 ms).
+template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false, bool H16 = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
     constexpr bool GATHER = S == kCrfGather;
@@ -188,7 +191,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     for (int o = 32; o > 0; o >>= 1) Tmax = max(Tmax, __shfl_xor(Tmax, o));
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
 
-    const int dt = p.in.dtype;  // element type of the posteriors (f32 / f16 / bf16: converted exactly on load)
+    const int dt = H16 ? p.in.dtype : (int)kF32;  // element type of the posteriors (f16 / bf16: converted exactly on load)
     const float *post = post_at(p.in.post, r * p.in.stride_read, dt);
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
     // Arena addressing: a wave-uniform base (the slab of the wavefront's first read: scalar registers) plus a
@@ -625,6 +628,15 @@ template <int N, int GW, int RPW, int S = 0>
 hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
     const int64_t waves = (n_reads + RPW - 1) / RPW;
     const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
+    if (p.in.dtype != kF32) {  // half-precision posteriors: the general instantiations only
+        if (p.out.ambiguous)
+            hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true, false, false, true>), dim3(blocks),
+                               dim3(64 * kWavesPerBlock), 0, stream, p);
+        else
+            hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, false, true>), dim3(blocks),
+                               dim3(64 * kWavesPerBlock), 0, stream, p);
+        return hipGetLastError();
+    }
     if (p.out.ambiguous)
         hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
