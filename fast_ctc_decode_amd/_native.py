@@ -32,7 +32,7 @@ SYMBOLS = [
     "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
     "fcd_crf_beam_search_duplex_dev", "fcd_crf_beam_search_duplex_host",
     "fcd_duplex_envelope_dev", "fcd_duplex_envelope_host",
-    "fcd_logspace_probe_dev", "fcd_logadd_latency_probe_dev", "fcd_phred",
+    "fcd_logspace_probe_dev", "fcd_logadd_latency_probe_dev", "fcd_logadd_sweep_dev", "fcd_phred",
     "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
     "fcd_coalescer_create", "fcd_coalescer_destroy", "fcd_coalescer_beam_search", "fcd_coalescer_viterbi_search",
     "fcd_coalescer_stats", "fcd_coalescer_last_error",
@@ -144,6 +144,7 @@ def bind(lib):
             P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]
     lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
     lib.fcd_logadd_latency_probe_dev.argtypes = [P, i32, i32, P, P]
+    lib.fcd_logadd_sweep_dev.argtypes = [P, i32, C.c_uint32, C.c_uint32, P]
     lib.fcd_packed_result_bytes.argtypes = [i64, i64, i32]
     lib.fcd_packed_result_bytes.restype = i64
     lib.fcd_result_offsets_dev.argtypes = [P, P, i64, i64, P]

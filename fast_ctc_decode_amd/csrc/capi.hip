@@ -907,6 +907,16 @@ int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float 
     return FCD_OK;
 }
 
+int fcd_logadd_sweep_dev(fcd_handle *h, int which, uint32_t first_bits, uint32_t last_bits, uint64_t *counts) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if ((which != 0 && which != 1) || !counts || first_bits > last_bits) return fail(h, FCD_E_INVALID, "bad argument");
+    FCD_DEVICE(h);
+    FCD_HIP(h, hipMemsetAsync(counts, 0, 24, h->stream));
+    FCD_HIP(h, launch_logadd_sweep(which, first_bits, last_bits, reinterpret_cast<unsigned long long *>(counts), h->stream));
+    return FCD_OK;
+}
+
 int fcd_logadd_latency_probe_dev(fcd_handle *h, int n_chain, int logadd_mode, uint64_t *cycles, float *sink) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);

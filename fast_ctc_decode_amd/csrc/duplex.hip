@@ -985,25 +985,28 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     const int rstep = S * N;
                     int jn = isA ? 0 : -1;                      // the row this lane handles in the coming iteration
                     int slot3 = 3 * ((lo + Wcap + jn) % Wcap);  // 3 * ((lo + jn) mod Wcap)
-                    int at_n = lo;                              // parent row of the NEXT fetch (row lo - 1 is fetched here)
-                    int pslot3 = 3 * (((lo - 1) % Wcap + Wcap) % Wcap);
+                    // loop-invariant forms of the per-row tests: a lane works on row j iff (unsigned)j < wlim; the parent
+                    // holds row lo + j iff (unsigned)(j - jv0) < jspan (the even lane asks for X of the NEXT row, which
+                    // sits in the slot this lane's own row occupies: same ring geometry)
+                    const unsigned wlim = work ? (unsigned)W : 0u;
+                    const int jv0 = q_off - lo;
+                    const unsigned jspan = isA && q_end > q_off ? (unsigned)(q_end - q_off) : 0u;
+                    const float *wnext = wq + (isA ? rstep : 0);  // the coefficient of the row after the coming one
                     float c_cur = 0.0f, x_cur = kNegInf;
                     if (isA) {
                         c_cur = wq[0];
-                        x_cur = (lo - 1 >= q_off && lo - 1 < q_end) ? xq[pslot3] : kNegInf;
+                        x_cur = (lo - 1 >= q_off && lo - 1 < q_end) ? xq[3 * (((lo - 1) % Wcap + Wcap) % Wcap)] : kNegInf;
                     }
-                    pslot3 = pslot3 + 3 == 3 * Wcap ? 0 : pslot3 + 3;
                     for (int sidx = 0; sidx <= W; ++sidx) {
                         // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
-                        const int j = jn;
-                        const bool on = work && j >= 0 && j < W;
-                        // next row's operands (clamped to the tile: the value is unused past the last row)
-                        const int jr = j + 1 < W ? j + 1 : W - 1;
-                        const float c_nxt = wq[jr * rstep];
-                        const float x_nxt = (isA && at_n >= q_off && at_n < q_end) ? xq[pslot3] : kNegInf;  // row at_n
-                        const float a = on ? lb : kNegInf;
-                        const float bb = on ? (isA ? x_cur : sm + c_cur) : kNegInf;   // A: X_{t-1};  B: gap_{t'}
-                        const float v = ladd_lockstep<MODE>(a, bb, K);
+                        const bool on = (unsigned)jn < wlim;
+                        // next row's operands (one row past the tile at the very end: inside LDS, value unused)
+                        const float c_nxt = *wnext;
+                        const float x_nxt = (unsigned)(jn - jv0) < jspan ? xq[slot3] : kNegInf;  // the parent's row lo + jn
+                        // (lanes without work carry -inf everywhere; the one idle row of a working lane -- the odd lane's
+                        // first, the even lane's last -- computes a value nobody keeps)
+                        const float bb = isA ? x_cur : sm + c_cur;                    // A: X_{t-1};  B: gap_{t'}
+                        const float v = ladd_lockstep<MODE>(lb, bb, K);
                         float lb_out = lb;
                         if (on) {
                             if (isA) {
@@ -1022,8 +1025,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         c_cur = c_nxt;
                         x_cur = x_nxt;
                         ++jn;
-                        ++at_n;
-                        pslot3 = pslot3 + 3 == 3 * Wcap ? 0 : pslot3 + 3;
+                        wnext += rstep;
                         slot3 = slot3 + 3 == 3 * Wcap ? 0 : slot3 + 3;
                     }
                 } else {
@@ -1290,6 +1292,32 @@ __global__ __launch_bounds__(64) void logadd_chain_kernel(int n_chain, uint64_t 
     sink[threadIdx.x] = acc;
 }
 
+// Exhaustive check of the fast paths ON THE DEVICE (the host verifier covers the host build of logadd_fast.h; the
+// device build takes the hardware reciprocal in ln_1p): every f32 bit pattern in [first, last] of one domain --
+// which = 0: exp on [-86, -0], 1: ln_1p on [2^-24, 1].  Wherever Ziv's test trusts the fast binary64 value, its f32
+// rounding must equal the library routine's; counts[0] = arguments, [1] = sent to the slow path, [2] = mismatches.
+__global__ void logadd_sweep_kernel(int which, uint32_t first, uint32_t last, unsigned long long *counts) {
+    const LogAddCoef K = logadd_coef();
+    unsigned long long n = 0, slow = 0, bad = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t u = (uint64_t)first + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; u <= (uint64_t)last; u += stride) {
+        const float x = __uint_as_float((uint32_t)u);
+        ++n;
+        if (which == 0) {
+            const double y = exp_fast((double)x, K);
+            if (round_to_f32_unsafe(y)) ++slow;
+            else if (__float_as_uint((float)y) != __float_as_uint((float)exp((double)x))) ++bad;
+        } else {
+            const double y = log1p_fast((double)x, K);
+            if (round_to_f32_unsafe(y)) ++slow;
+            else if (__float_as_uint((float)y) != __float_as_uint((float)log1p((double)x))) ++bad;
+        }
+    }
+    atomicAdd(&counts[0], n);
+    atomicAdd(&counts[1], slow);
+    atomicAdd(&counts[2], bad);
+}
+
 // widest clamped envelope row over the whole batch -> *out (int), for sizing the rings
 __global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t env_stride,
                                  int64_t T1cap, int64_t T2cap, const int64_t *len1,
@@ -1346,6 +1374,11 @@ hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add,
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
     hipLaunchKernelGGL(logspace_probe_kernel, dim3(blocks), dim3(256), 0, stream, a, b, out_add, out_ln,
                        n, mode);
+    return hipGetLastError();
+}
+
+hipError_t launch_logadd_sweep(int which, uint32_t first, uint32_t last, unsigned long long *counts, hipStream_t stream) {
+    hipLaunchKernelGGL(logadd_sweep_kernel, dim3(256 * 16), dim3(256), 0, stream, which, first, last, counts);
     return hipGetLastError();
 }
 

@@ -174,6 +174,7 @@ hipError_t launch_unpack_gathered(const uint8_t *gathered, int64_t stride, int w
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
                                  int64_t n, int mode, hipStream_t stream);
 hipError_t launch_logadd_chain(int n_chain, int mode, uint64_t *cycles, float *sink, hipStream_t stream);
+hipError_t launch_logadd_sweep(int which, uint32_t first, uint32_t last, unsigned long long *counts, hipStream_t stream);
 
 // ---- host side of the four 1D searches (capi.hip, hostjob.hip) ----
 enum class HostOp { Viterbi, Beam, CrfBeam, CrfGreedy };

@@ -290,6 +290,10 @@ int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float 
  * sink (DEVICE f32[64]) keeps the result alive.  cycles / n_chain is the dependent latency that bounds the duplex
  * searches (tools/duplex_account.py: the dependent-chain roofline). */
 int fcd_logadd_latency_probe_dev(fcd_handle *h, int n_chain, int logadd_mode, uint64_t *cycles, float *sink);
+/* Test hook: exhaustive sweep of one fast path of LogSpace::add on the device -- which = 0: exp, 1: ln_1p -- over
+ * every f32 bit pattern in [first_bits, last_bits]; counts (DEVICE u64[3]) = arguments, arguments Ziv's test sends
+ * to the slow path, arguments whose trusted fast result differs from the library routine's (must be 0). */
+int fcd_logadd_sweep_dev(fcd_handle *h, int which, uint32_t first_bits, uint32_t last_bits, uint64_t *counts);
 
 /* ---- compact wire format of a shard's results, for the ONE gather of the multi-GPU path ----
  * The searches write fixed-stride rows; only out_len[r] entries of row r are meaningful (~48 % at BASELINE

@@ -503,3 +503,24 @@ def test_duplex_tie_counters(fcd, mode):
             if beam == 3:
                 assert want[0] == 0  # 15 candidates at most: never the pdqsort case
     assert seen[0] > 0 and seen[1] > 0  # the test data really exercises both counters
+
+
+def test_logadd_fast_paths_exhaustive_on_device(fcd):
+    """Every f32 argument of both fast-path domains of LogSpace::add, on the device build itself (whose ln_1p takes
+    the hardware reciprocal instead of the IEEE division the host verifier sees): wherever Ziv's test trusts the fast
+    binary64 value, its f32 rounding equals the library routine's.  1.1e9 + 2.0e8 arguments, 0 mismatches."""
+    import ctypes as C
+    import struct
+
+    torch = pytest.importorskip("torch")
+    from fast_ctc_decode_amd import _native as nat
+    h = nat.default_handle()
+    bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]
+    for which, lo, hi in ((0, 0x80000000, bits(-86.0)), (1, bits(2.0 ** -24), bits(1.0))):
+        counts = torch.zeros(3, dtype=torch.int64, device="cuda")
+        h.check(h.lib.fcd_logadd_sweep_dev(h.ptr, which, lo, hi, C.c_void_p(counts.data_ptr())))
+        h.synchronize()
+        n, slow, bad = (int(v) for v in counts.cpu())
+        assert n == hi - lo + 1 and bad == 0, (which, n, slow, bad)
+        assert slow < n * 1e-5          # the slow path stays rare (r01 host sweep: 517 / 397 arguments)
+        print("device sweep", "exp" if which == 0 else "ln_1p", n, "arguments,", slow, "to the slow path, 0 wrong")
