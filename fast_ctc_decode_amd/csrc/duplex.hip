@@ -134,20 +134,32 @@ __device__ __forceinline__ float ladd_lockstep(float a, float b, const LogAddCoe
     float res = (!sc_inf && sc_zero) ? big + 0.0f : big;
     if (ballot(full) != 0ull) {
         const float xs = full ? x : -1.0f;  // lanes that do not need it still run the arithmetic, on a tame argument
+        // e = exp(xs) rounded to f32, carried as a binary64 value (it is ln_1p's argument); ln_1p's fast path covers
+        // every normal e, so "ln_1p(e) = e below 2^-24" needs no select here.  (Bitwise |: nothing to skip.)
         const double ye = exp_fast((double)xs, K);
-        float e = (float)ye;
-        if (!(xs >= kExpFastMin) || round_to_f32_unsafe(ye)) e = exp_slow_f32(xs);
-        const bool ident = e < kLog1pIdentityBelow;  // ln_1p(e) rounds to e below 2^-24
-        const float es = ident ? 0.5f : e;
-        const double yl = log1p_fast((double)es, K);
+        double ed = round_to_f32_as_f64(ye);
+        if ((int)!(xs >= kExpFastMin) | (int)round_to_f32_unsafe(ye)) ed = (double)exp_slow_f32(xs);
+        const double yl = log1p_fast(ed, K);
         float l = (float)yl;
-        if (round_to_f32_unsafe(yl)) l = log1p_slow_f32(es);
-        res = full ? big + (ident ? e : l) : res;
+        // (e below 2^-126 -- only after exp's slow path -- by its exponent field: one 32-bit compare)
+        if ((int)((uint32_t)(bits_of(ed) >> 32) < 0x38100000u) | (int)round_to_f32_unsafe(yl)) {
+            const float e = (float)ed;  // exact
+            l = e < kLog1pIdentityBelow ? e : log1p_slow_f32(e);
+        }
+        res = full ? big + l : res;
     }
     return res;
 }
 
 __device__ __forceinline__ float lmax(float self, float other) { return self < other ? other : self; }
+
+// one window row {label, gap, sum} in one 12-byte store (rows are 12 bytes apart: 4-byte alignment is all there is)
+struct __attribute__((packed, aligned(4))) Row3 {
+    float lb, g, sm;
+};
+__device__ __forceinline__ void store_row(float *p, float lb, float g, float sm) {
+    *reinterpret_cast<Row3 *>(p) = Row3{lb, g, sm};
+}
 
 __device__ __forceinline__ float load_f32_l2(const float *p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -879,9 +891,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                             const float g = l_sum + r0;
                             const float lb = rl1 + ladd<MODE>(l_lab, x);
                             const float sm = ladd<MODE>(lb, g);
-                            my[s3] = lb;
-                            my[s3 + 1] = g;
-                            my[s3 + 2] = sm;
+                            store_row(my + s3, lb, g, sm);
                             mx = lmax(mx, sm);
                             l_lab = lb;
                             l_sum = sm;
@@ -1002,23 +1012,19 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         const bool on = (unsigned)jn < wlim;
                         // next row's operands (one row past the tile at the very end: inside LDS, value unused)
                         const float c_nxt = *wnext;
-                        const float x_nxt = (unsigned)(jn - jv0) < jspan ? xq[slot3] : kNegInf;  // the parent's row lo + jn
+                        const float x_raw = xq[slot3];  // (always inside the ring: read first, judge afterwards -- no branch)
+                        const float x_nxt = (unsigned)(jn - jv0) < jspan ? x_raw : kNegInf;      // the parent's row lo + jn
                         // (lanes without work carry -inf everywhere; the one idle row of a working lane -- the odd lane's
                         // first, the even lane's last -- computes a value nobody keeps)
                         const float bb = isA ? x_cur : sm + c_cur;                    // A: X_{t-1};  B: gap_{t'}
                         const float v = ladd_lockstep<MODE>(lb, bb, K);
-                        float lb_out = lb;
-                        if (on) {
-                            if (isA) {
-                                lb_out = c_cur + v;  // label_t
-                                my[slot3] = lb_out;
-                            } else {
-                                my[slot3 + 1] = bb;   // gap_{t'}
-                                my[slot3 + 2] = v;    // sum_{t'}
-                                sm = v;
-                                mx = lmax(mx, v);
-                            }
-                        }
+                        // The odd lane holds the whole row t' -- label_{t'} came from the even lane -- and writes it
+                        // with one 12-byte store; everything else is a select.
+                        const bool onB = on && !isA;
+                        if (onB) store_row(my + slot3, lb, bb, v);  // {label_{t'}, gap_{t'}, sum_{t'}}
+                        sm = onB ? v : sm;
+                        mx = onB ? lmax(mx, v) : mx;
+                        const float lb_out = (on && isA) ? c_cur + v : lb;  // label_t
                         // hand label_t to the odd lane for the next iteration; the even lane keeps it
                         lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
                                                                         0xf, 0xf, false));
@@ -1294,7 +1300,7 @@ __global__ __launch_bounds__(64) void logadd_chain_kernel(int n_chain, uint64_t 
 
 // Exhaustive check of the fast paths ON THE DEVICE (the host verifier covers the host build of logadd_fast.h; the
 // device build takes the hardware reciprocal in ln_1p): every f32 bit pattern in [first, last] of one domain --
-// which = 0: exp on [-86, -0], 1: ln_1p on [2^-24, 1].  Wherever Ziv's test trusts the fast binary64 value, its f32
+// which = 0: exp on [-86, -0], 1: ln_1p on [2^-126, 1].  Wherever Ziv's test trusts the fast binary64 value, its f32
 // rounding must equal the library routine's; counts[0] = arguments, [1] = sent to the slow path, [2] = mismatches.
 __global__ void logadd_sweep_kernel(int which, uint32_t first, uint32_t last, unsigned long long *counts) {
     const LogAddCoef K = logadd_coef();
@@ -1306,7 +1312,8 @@ __global__ void logadd_sweep_kernel(int which, uint32_t first, uint32_t last, un
         if (which == 0) {
             const double y = exp_fast((double)x, K);
             if (round_to_f32_unsafe(y)) ++slow;
-            else if (__float_as_uint((float)y) != __float_as_uint((float)exp((double)x))) ++bad;
+            else if (__float_as_uint((float)y) != __float_as_uint((float)exp((double)x)) ||
+                     round_to_f32_as_f64(y) != (double)(float)y) ++bad;
         } else {
             const double y = log1p_fast((double)x, K);
             if (round_to_f32_unsafe(y)) ++slow;

@@ -6,7 +6,7 @@
 // Definition being implemented: exp and ln_1p return the f32 nearest to the exact
 // value.  The fast paths evaluate in binary64 with a relative error below 2^-46 and round once; when the
 // binary64 value lies within 512 ulps (2^-43 relative) of an f32 rounding boundary the caller falls back
-// to the slow path (Ziv's test).  Domains: exp x in [-86, 0] (normal f32 results), ln_1p e in [2^-24, 1].
+// to the slow path (Ziv's test).  Domains: exp x in [-86, 0] (normal f32 results), ln_1p e in [2^-126, 1].
 #pragma once
 
 #include <math.h>
@@ -26,6 +26,11 @@ FCD_HD uint64_t bits_of(double x) {
     memcpy(&u, &x, sizeof u);
     return u;
 }
+FCD_HD double double_of(uint64_t u) {
+    double x;
+    memcpy(&x, &u, sizeof x);
+    return x;
+}
 
 // y: positive normal binary64 whose f32 rounding is a normal number.  True when y is so close to the
 // midpoint of two adjacent f32 values that an error of 2^-43 (relative) could change the rounding.
@@ -34,11 +39,17 @@ FCD_HD bool round_to_f32_unsafe(double y) {
     return (uint32_t)(dropped - (0x10000000u - 512u)) < 1024u;
 }
 
+// y as above and NOT round_to_f32_unsafe: the f32 nearest to y, as a binary64 value, by integer arithmetic (add
+// half a unit of the 29 dropped bits, clear them; a carry out of the mantissa lands in the exponent, as it should;
+// an exact tie cannot occur, the test rejects everything near one).  Two full-rate integer operations where
+// (double)(float)y is two quarter-rate conversions on the GPU.
+FCD_HD double round_to_f32_as_f64(double y) { return double_of((bits_of(y) + 0x10000000ull) & ~0x1FFFFFFFull); }
+
 // The coefficients as a value: the window-building loop of the duplex kernel keeps them in vector registers
 // for its whole run (made opaque there, so the compiler neither re-materialises 64-bit literals through scalar
 // registers on every row nor spills scalars to make room for them).
 struct LogAddCoef {
-    double log2e, ln2hi, ln2lo;
+    double log2e, ln2hi, ln2lo, magic;
     double e[12];   // 1/k!,  k = 0..11
     double a[15];   // 1/(2k+1), k = 0..14
     double two;
@@ -54,14 +65,21 @@ FCD_HD LogAddCoef logadd_coef() {
     c.e[10] = 1.0 / 3628800.0; c.e[11] = 1.0 / 39916800.0;
     for (int k = 0; k < 15; ++k) c.a[k] = 1.0 / (double)(2 * k + 1);
     c.two = 2.0;
+    c.magic = 6755399441055744.0;  // 1.5 * 2^52: adding it leaves the nearest integer in the low mantissa bits
     return c;
 }
 
 // exp(x), x in [-86, 0]: x = k ln2 + r, |r| <= 0.3466, Taylor polynomial of degree 11 (truncation
 // < 2^-47 relative), scaled by 2^k.  The polynomial is evaluated by Estrin's scheme: five levels of
-// independent fused multiply-adds instead of eleven in a row (same operation count).
+// independent fused multiply-adds instead of eleven in a row (same operation count).  k -- the integer nearest
+// to x log2(e) -- comes out of one fused multiply-add against 1.5 * 2^52 (value: t - magic; as an integer: the low
+// word of t), and since k is in [-125, 0] and the polynomial in [0.70, 1.42] the result is a normal number:
+// scaling by 2^k is an integer addition to the exponent field.  Five full-rate operations where rint, the
+// double -> int conversion and ldexp are three quarter-rate ones on the GPU.  (Outside the domain the value is
+// meaningless, not harmful: callers send x < -86 and NaN to the slow path.)
 FCD_HD double exp_fast(double x, const LogAddCoef &c) {
-    const double k = rint(x * c.log2e);
+    const double t = fma(x, c.log2e, c.magic);
+    const double k = t - c.magic;
     double r = fma(k, c.ln2hi, x);
     r = fma(k, c.ln2lo, r);
     const double r2 = r * r, r4 = r2 * r2, r8 = r4 * r4;
@@ -76,12 +94,13 @@ FCD_HD double exp_fast(double x, const LogAddCoef &c) {
     const double q8b = fma(pab, r2, p89);
     const double h07 = fma(q47, r4, q03);
     const double p = fma(q8b, r8, h07);
-    return ldexp(p, (int)k);
+    return double_of(bits_of(p) + ((uint64_t)((uint32_t)bits_of(t) << 20) << 32));
 }
 FCD_HD double exp_fast(double x) { return exp_fast(x, logadd_coef()); }
 
 // ln_1p(e) = 2 atanh(s), s = e / (2 + e) in (0, 1/3]: odd series through s^29 (truncation < 2^-52 relative),
-// Estrin's scheme in z = s^2 (fifteen coefficients: four levels).
+// Estrin's scheme in z = s^2 (fifteen coefficients: four levels).  Verified for every f32 e in [2^-126, 1] (below
+// 2^-24 the correctly rounded result is e itself, and this evaluation delivers it: no special case needed).
 FCD_HD double log1p_fast(double e, const LogAddCoef &c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     // On the GPU the quotient goes through the hardware reciprocal and two Newton steps: five dependent operations
@@ -121,5 +140,6 @@ FCD_HD double log1p_fast(double e) { return log1p_fast(e, logadd_coef()); }
 constexpr float kExpFastMin = -86.0f;           // below: exp's f32 result may be subnormal
 constexpr float kExpZeroBelow = -104.0f;        // below: exp rounds to +0 (2^-150 = e^-103.97)
 constexpr float kLog1pIdentityBelow = 5.9604644775390625e-08f;  // 2^-24: below, ln_1p(e) rounds to e
+constexpr float kLog1pFastMin = 1.17549435082228750797e-38f;     // 2^-126: smallest argument of the fast ln_1p
 
 }  // namespace fcd

@@ -516,7 +516,7 @@ def test_logadd_fast_paths_exhaustive_on_device(fcd):
     from fast_ctc_decode_amd import _native as nat
     h = nat.default_handle()
     bits = lambda f: struct.unpack("<I", struct.pack("<f", f))[0]
-    for which, lo, hi in ((0, 0x80000000, bits(-86.0)), (1, bits(2.0 ** -24), bits(1.0))):
+    for which, lo, hi in ((0, 0x80000000, bits(-86.0)), (1, bits(2.0 ** -126), bits(1.0))):
         counts = torch.zeros(3, dtype=torch.int64, device="cuda")
         h.check(h.lib.fcd_logadd_sweep_dev(h.ptr, which, lo, hi, C.c_void_p(counts.data_ptr())))
         h.synchronize()
