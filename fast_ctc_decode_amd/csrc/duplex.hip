@@ -153,6 +153,18 @@ __device__ __forceinline__ float ladd_lockstep(float a, float b, const LogAddCoe
 
 __device__ __forceinline__ float lmax(float self, float other) { return self < other ? other : self; }
 
+// v_max_f32 as it is: through __builtin_fmaxf the compiler first "canonicalises" every operand it cannot prove free of
+// signalling NaNs (v_max_f32 x, x, x) -- on the dependent chain.  Callers guarantee ordinary operands.
+__device__ __forceinline__ float vmax_raw(float a, float b) {
+#ifdef FCD_HIPEMU
+    return a < b ? b : a;
+#else
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
+
 // one window row {label, gap, sum} in one 12-byte store (rows are 12 bytes apart: 4-byte alignment is all there is)
 struct __attribute__((packed, aligned(4))) Row3 {
     float lb, g, sm;
@@ -855,10 +867,11 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             FCD_DUPLEX_PHASE(2)
             if (prof) {
                 n_newnodes += (uint32_t)popc64(m_new);
-                n_iter += (uint32_t)(hi - lo + 1) * (uint32_t)((popc64(m_new) + 31) / 32);
+                n_iter += (uint32_t)(hi - lo + 1) * (uint32_t)((popc64(m_new) + 31) / 32);  // (max mode: rows, 16 nodes per pass)
             }
-            if (MODE == FCD_LOGADD_MAX) {
-            // max-product mode has no transcendental in the recurrence: one lane per new node
+            if (MODE == FCD_LOGADD_MAX && !(staged && Wcap >= 8)) {
+            // max-product mode has no transcendental in the recurrence: one lane per new node (the general form; with
+            // resident windows the four-lanes-per-node loop below takes over)
             if (is_new) {
                 cid = nn + popc64(m_new & lanemask_lt());
                 if (cid < p.cap_nodes) {
@@ -953,28 +966,126 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 par_end = pm.w;
             }
             __syncthreads();
-            for (int rd = 0; rd * 32 < n_new; ++rd) {
-                const int m = rd * 32 + (lane >> 1);
+            // lanes per new node: a pair (logsumexp: two log-add chains in lockstep) or a quad (max: see below)
+            constexpr int LPN = MODE == FCD_LOGADD_MAX ? 4 : 2;
+            constexpr int PER = 64 / LPN;
+            for (int rd = 0; rd * PER < n_new; ++rd) {
+                const int m = rd * PER + lane / LPN;
                 const bool have = m < n_new;
                 const int owner = have ? L.bt[m] : lane;
                 const bool isA = (lane & 1) == 0;
                 // the owner's parameters
-                const int q_cid = __shfl(cid, owner);
-                const int q_i = __shfl(i, owner);
-                const int q_l = __shfl(k - 1, owner);
                 const int q_flags = __shfl((can ? 1 : 0) | (rep ? 2 : 0), owner);
-                const int q_state = __shfl(state, owner);
+                const bool work = have && (q_flags & 1);
+                // (idle lanes run the loops too, on the tables of beam entry 0: every address they form is a real one)
+                const int q_cid = __shfl(cid, owner);
+                const int o_i = __shfl(i, owner), o_l = __shfl(k - 1, owner), o_state = __shfl(state, owner);
+                const int q_i = work ? o_i : 0;
+                const int q_l = work ? o_l : 0;
+                const int q_state = work ? o_state : 0;
                 const int q_node = __shfl(node, owner);
                 const int q_poff = __shfl(par_off, owner);
                 const int q_pend = __shfl(par_end, owner);
-                const bool work = have && (q_flags & 1);
                 const bool q_rep = (q_flags & 2) != 0;
                 const VecRef pv = node_vec(q_node, q_poff, q_pend);
                 float *my = vec + (int64_t)(work ? q_cid : 0) * Wcap * 3;
                 float lb = kNegInf;   // A: label_{t-1};  B: label_{t'} received from A
                 float sm = kNegInf;   // B: sum_{t'-1}
                 float mx = kNegInf;
-                if (staged) {
+                if (MODE == FCD_LOGADD_MAX) {
+                    // Max-product mode (staged, Wcap >= 8): no transcendental, so the loop is all bookkeeping -- and with
+                    // one wavefront per SIMD every instruction costs 4-8 cycles whatever it does.  Four lanes per node:
+                    // lane q of the quad owns rows q, q + 4, ... -- it fetches their operands, checks them, stores the
+                    // finished row -- and the recurrence walks round the quad: in step u every lane computes
+                    //   label = p[l] + max(label', X),  sum = max(label, sum' + p[blank])
+                    // with label' / sum' taken from its LEFT neighbour (a DPP operand, quad_perm [3,0,1,2]: no extra
+                    // instruction), which is the true row exactly on the diagonal lane q = u; what the other lanes
+                    // compute in that step is never read.  Per four rows: one set of fetches, four 4-instruction
+                    // steps, one select of the diagonal values, one store -- ~13 instructions per row instead of ~48.
+                    // LogSpace::add's max flavour is v_max_f32 unless a NaN or a zero takes part (a <= b and "+ 0.0"
+                    // see those differently): impossible while every operand is below zero (-inf included), which
+                    // the log-probabilities are unless a posterior is 1, above 1 or NaN -- checked per group on the
+                    // side, and a group that fails is redone with the exact form (its stores simply land twice).
+                    const int qd = lane & 3;
+                    const float *wq = L.w2 + q_state * N;
+                    const float *xq = ring(L.b_buf(cur)[q_i]) + (q_rep ? 1 : 2);
+                    const int q_off = L.b_off(cur)[q_i], q_end = L.b_end(cur)[q_i];
+                    const unsigned q_span = q_end > q_off ? (unsigned)(q_end - q_off) : 0u;
+                    const int rstep = S * N;
+                    const int W3 = 3 * Wcap;
+                    int jrow = qd;                               // this lane's row of the coming group
+                    int s3 = 3 * ((lo + qd) % Wcap);             // its slot (x 3)
+                    int sx = s3 == 0 ? W3 - 3 : s3 - 3;          // the slot of the row before: the parent's row it needs
+                    const float *wlast = wq + (W > 0 ? W - 1 : 0) * rstep;
+                    const float *wrow = wq + jrow * rstep;
+                    float n0, nl, nx;
+                    bool nv;
+                    auto fetch = [&]() {
+                        const float *wr = wrow < wlast ? wrow : wlast;  // (rows past the window: any valid address)
+                        n0 = wr[0];
+                        nl = wr[q_l + 1];
+                        nx = xq[sx];  // (always inside the ring: read now, judge when the value is used)
+                        nv = (unsigned)(lo + jrow - 1 - q_off) < q_span;
+                    };
+                    fetch();
+                    float lab3 = kNegInf, sum3 = kNegInf;  // row - 1 of the coming group, valid in lane 3
+                    const bool is0 = qd == 0, is1 = qd == 1, is2 = qd == 2;
+                    auto rot = [](float v) {  // lane q <- lane q - 1 (mod 4)
+                        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93 /* quad_perm [3,0,1,2] */, 0xf,
+                                                                          0xf, true));
+                    };
+                    for (int j = 0; j < W; j += 4) {
+                        const float c0 = n0, cl = nl, cx = nv ? nx : kNegInf;
+                        const bool mine = work && jrow < W;
+                        const int st3 = s3;
+                        jrow += 4;
+                        wrow += 4 * rstep;
+                        s3 = s3 + 12 >= W3 ? s3 + 12 - W3 : s3 + 12;
+                        sx = sx + 12 >= W3 ? sx + 12 - W3 : sx + 12;
+                        if (j + 4 < W) fetch();
+                        const bool special = mine && (!(cl < 0.0f) | !(c0 < 0.0f) | !(cx < 0.0f));
+                        float lab0, lab1, lab2, g0, g1, g2, g3, sum0, sum1, sum2;
+                        const float lab_in = lab3, sum_in = sum3;
+                        lab0 = cl + vmax_raw(rot(lab_in), cx);
+                        g0 = rot(sum_in) + c0;
+                        sum0 = vmax_raw(lab0, g0);
+                        lab1 = cl + vmax_raw(rot(lab0), cx);
+                        g1 = rot(sum0) + c0;
+                        sum1 = vmax_raw(lab1, g1);
+                        lab2 = cl + vmax_raw(rot(lab1), cx);
+                        g2 = rot(sum1) + c0;
+                        sum2 = vmax_raw(lab2, g2);
+                        lab3 = cl + vmax_raw(rot(lab2), cx);
+                        g3 = rot(sum2) + c0;
+                        sum3 = vmax_raw(lab3, g3);
+                        if (ballot(special) != 0ull) {  // rare: the same four steps on LogSpace::add itself
+                            lab0 = cl + ladd<MODE>(rot(lab_in), cx);
+                            g0 = rot(sum_in) + c0;
+                            sum0 = ladd<MODE>(lab0, g0);
+                            lab1 = cl + ladd<MODE>(rot(lab0), cx);
+                            g1 = rot(sum0) + c0;
+                            sum1 = ladd<MODE>(lab1, g1);
+                            lab2 = cl + ladd<MODE>(rot(lab1), cx);
+                            g2 = rot(sum1) + c0;
+                            sum2 = ladd<MODE>(lab2, g2);
+                            lab3 = cl + ladd<MODE>(rot(lab2), cx);
+                            g3 = rot(sum2) + c0;
+                            sum3 = ladd<MODE>(lab3, g3);
+                        }
+                        // the diagonal: lane q keeps what step q produced
+                        const float lbv = is0 ? lab0 : is1 ? lab1 : is2 ? lab2 : lab3;
+                        const float gv = is0 ? g0 : is1 ? g1 : is2 ? g2 : g3;
+                        const float smv = is0 ? sum0 : is1 ? sum1 : is2 ? sum2 : sum3;
+                        if (mine) {
+                            store_row(my + st3, lbv, gv, smv);
+                            mx = lmax(mx, smv);
+                        }
+                    }
+                    // the node's running maximum: over the quad's four partial maxima (ln never yields -0 and sums of
+                    // non-positive terms never do either, so the order of the comparisons cannot show)
+                    mx = lmax(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0xB1, 0xf, 0xf, true)));
+                    mx = lmax(mx, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(mx), 0x4E, 0xf, 0xf, true)));
+                } else if (staged) {
                     LogAddCoef K = logadd_coef();
                     if (PIN) {
                         FCD_OPAQUE_V(K.log2e); FCD_OPAQUE_V(K.ln2hi); FCD_OPAQUE_V(K.ln2lo); FCD_OPAQUE_V(K.two);
@@ -1073,7 +1184,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     lb = isA ? lb_out : from_even;
                 }
                 }
-                if (work && !isA) {
+                if (work && (LPN == 2 ? !isA : (lane & 3) == 0)) {
                     meta[q_cid] = make_int4(q_node, q_l, lo, hi);
                     nmax[q_cid] = mx;
                     rlo[q_cid] = lo;
@@ -1081,9 +1192,9 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     if (q_node >= 0) rows[(int64_t)q_node * NL + q_l] = q_cid;
                 }
                 // the owner slot needs the new node's running maximum as its prob_2_max
-                const int pair_b = 2 * (pre & 31) + 1;
+                const int pair_b = LPN * (pre % PER) + (LPN == 2 ? 1 : 0);
                 const float got = __shfl(mx, pair_b);
-                if (can && (pre >> 5) == rd) p2 = got;
+                if (can && pre / PER == rd) p2 = got;
             }
             if (can) b_child[i * NL + (k - 1)] = cid;
             if (!is_new && act && cid >= 0) {

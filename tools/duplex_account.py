@@ -52,7 +52,8 @@ def main():
         torch.cuda.synchronize()
         stamped_ms = h.last_kernel_ms()
         h.check(h.lib.fcd_debug_set_duplex_profile(h.ptr, None))
-        assert torch.equal(r.labels[:, :8], r2.labels[:, :8]) and torch.equal(r.out_len, r2.out_len)
+        if not os.environ.get("FCD_ACCOUNT_NOCHECK"):  # (knock-out experiments produce wrong results on purpose)
+            assert torch.equal(r.labels[:, :8], r2.labels[:, :8]) and torch.equal(r.out_len, r2.out_len)
         a = prof.cpu().numpy().astype(np.float64)
         cyc = a[:, :5] * 64.0
         steps = a[:, 7]
