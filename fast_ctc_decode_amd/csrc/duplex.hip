@@ -127,11 +127,13 @@ __device__ __forceinline__ float ladd_lockstep(float a, float b, const LogAddCoe
     const float big = ab ? b : a, small = ab ? a : b;  // a NaN ends up in `big` or makes x NaN
     if (MODE == FCD_LOGADD_MAX) return small == kNegInf ? big : big + 0.0f;
     const float x = small - big;  // <= 0, or NaN
-    const bool sc_inf = small == kNegInf;                                                   // -> big
-    const bool sc_zero = x < kExpZeroBelow;                                                 // -> big + 0
-    const bool sc_tiny = x < kExpFastMin && __builtin_fabsf(big) >= 8.0779356694631609e-28f;  // -> big
-    const bool full = !(sc_inf || sc_zero || sc_tiny);  // (a NaN fails every test and takes the full path)
-    float res = (!sc_inf && sc_zero) ? big + 0.0f : big;
+    // ladd()'s shortcuts, folded: the transcendental part is needed unless x < -86 -- and then it is still needed when
+    // `big` is so small (below 2^-90) that exp(x) could show in the sum, which the slow exponential handles down to
+    // x < -104 where it returns +0 and the sum is big + 0.  small = -inf returns `big` whatever x is (NaN for
+    // -inf - -inf).
+    const bool sc_inf = small == kNegInf;
+    const bool full = (!(x < kExpFastMin) | (__builtin_fabsf(big) < 8.0779356694631609e-28f)) & !sc_inf;
+    float res = big;
     if (ballot(full) != 0ull) {
         const float xs = full ? x : -1.0f;  // lanes that do not need it still run the arithmetic, on a tame argument
         // e = exp(xs) rounded to f32, carried as a binary64 value (it is ln_1p's argument); ln_1p's fast path covers
@@ -1131,11 +1133,13 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         const float v = ladd_lockstep<MODE>(lb, bb, K);
                         // The odd lane holds the whole row t' -- label_{t'} came from the even lane -- and writes it
                         // with one 12-byte store; everything else is a select.
-                        const bool onB = on && !isA;
-                        if (onB) store_row(my + slot3, lb, bb, v);  // {label_{t'}, gap_{t'}, sum_{t'}}
-                        sm = onB ? v : sm;
-                        mx = onB ? lmax(mx, v) : mx;
-                        const float lb_out = (on && isA) ? c_cur + v : lb;  // label_t
+                        if (on && !isA) store_row(my + slot3, lb, bb, v);  // {label_{t'}, gap_{t'}, sum_{t'}}
+                        // No selects on `on`: the odd lane's idle first row yields -inf (-inf (+) -inf), which changes
+                        // neither sum nor maximum; the even lane never reads sum / maximum; and what the odd lane puts
+                        // into label_t is overwritten by the even lane's through the DPP move below.
+                        sm = v;
+                        mx = lmax(mx, v);
+                        const float lb_out = c_cur + v;  // label_t (even lane)
                         // hand label_t to the odd lane for the next iteration; the even lane keeps it
                         lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
                                                                         0xf, 0xf, false));
