@@ -95,6 +95,23 @@ __device__ __forceinline__ void scan_subtile(ScanState &st, int label, float pro
     st.carry_label = __shfl(label, last_lane);
 }
 
+// The same for a sub-tile whose 64 rows all exist, without quality values: the neighbour's label through a DPP
+// wave shift (no LDS round trip), 32-bit output offsets against wave-uniform bases -- a third of the instructions.
+__device__ __forceinline__ void scan_subtile_full(ScanState &st, int label, uint32_t row, int collapse, uint8_t *lab,
+                                                  uint32_t *pth) {
+    // wave_shr:1 -- lane 0 has no source lane and keeps `old`, the label carried over from the previous sub-tile
+    const int prev = __builtin_amdgcn_update_dpp(st.carry_label, label, 0x138, 0xf, 0xf, false);
+    const bool emit = label != 0 && (!collapse || prev != label);  // :347
+    const uint64_t m_emit = ballot(emit);
+    const uint32_t my_out = (uint32_t)st.n_out + (uint32_t)popc64(m_emit & lanemask_lt());
+    if (emit) {
+        lab[my_out] = (uint8_t)label;
+        if (pth) pth[my_out] = row;
+    }
+    st.n_out += popc64(m_emit);
+    st.carry_label = __builtin_amdgcn_readlane(label, 63);
+}
+
 __device__ __forceinline__ void scan_finish(ScanState &st, int64_t r, float *qual,
                                             const ResultDesc &out) {
     const int lane = threadIdx.x & 63;
@@ -110,7 +127,7 @@ __device__ __forceinline__ void scan_finish(ScanState &st, int64_t r, float *qua
 __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_kernel(BatchDesc in, int collapse,
                                                                     ResultDesc out) {
     const int lane = threadIdx.x & 63;
-    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     if (r >= in.n_reads) return;
     int64_t T = in.T;
     if (in.lengths) {
@@ -164,7 +181,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(Bat
     // (f32: NLOAD = N and the tile is covered exactly; 16-bit, odd N: the last load is half used)
     __shared__ __attribute__((aligned(16))) float s_tile[kWavesPerBlock][NLOAD * 64 * EPL];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (wave-uniform, and said so: the read's index, its length and every pointer derived from them live in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     if (r >= in.n_reads) return;
     int64_t T = in.T;
@@ -231,10 +249,53 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(Bat
         }
     };
 
+    // a tile that lies inside the read entirely: no bounds to check (256 * N elements are a whole number of loads'
+    // in-tile lanes for every element type)
+    auto fetch_full = [&](int64_t tile_row0, uint4 (&v)[NLOAD]) {
+        const char *src = reinterpret_cast<const char *>(post) + tile_row0 * N * (DT == kF32 ? 4 : 2) + lane * 16;
+#pragma unroll
+        for (int m = 0; m < NLOAD; ++m) {
+            if ((lane + 64 * m) * EPL < kTileRows * N) v[m] = *reinterpret_cast<const uint4 *>(src + m * 1024);
+            else v[m] = make_uint4(0u, 0u, 0u, 0u);
+        }
+    };
+
     ScanState st;
     uint4 cur[NLOAD], nxt[NLOAD];
-    if (T > 0) fetch(0, cur);
-    for (int64_t base = 0; base < T; base += kTileRows) {
+    if (T >= kTileRows) fetch_full(0, cur);
+    else if (T > 0) fetch(0, cur);
+    int64_t base = 0;
+    // ---- whole tiles: nothing to test per row ----
+    for (; base + kTileRows <= T; base += kTileRows) {
+        const int64_t nb = base + kTileRows;
+        if (nb + kTileRows <= T) fetch_full(nb, nxt);
+        else if (nb < T) fetch(nb, nxt);
+        park(cur);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int u = 0; u < kTileRows / 64; ++u) {
+            const float *pr = tile + (64 * u + lane) * N;
+            float prob = pr[0];
+            int label = 0;
+#pragma unroll
+            for (int j = 1; j < N; ++j) {  // find_max: strict '>' keeps the first maximum
+                const float v = pr[j];
+                if (v > prob) {
+                    prob = v;
+                    label = j;
+                }
+            }
+            if (qual) scan_subtile(st, label, prob, true, base + 64 * u, T, collapse, lab, pth, qual);
+            else scan_subtile_full(st, label, (uint32_t)(base + 64 * u) + (uint32_t)lane, collapse, lab, pth);
+        }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int m = 0; m < NLOAD; ++m) cur[m] = nxt[m];
+    }
+    // ---- the ragged last tile ----
+    for (; base < T; base += kTileRows) {
         if (base + kTileRows < T) fetch(base + kTileRows, nxt);
         park(cur);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -411,7 +472,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
     BatchDesc in, const float *init_all, int64_t n_init, int64_t init_stride, ResultDesc out) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63;
-    const int wave = threadIdx.x >> 6;
+    // (wave-uniform, and said so: the read's index, its length and every pointer derived from them live in scalar registers)
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
     if (r >= in.n_reads) return;
     int64_t T = in.T;

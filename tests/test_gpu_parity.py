@@ -659,6 +659,35 @@ def test_viterbi_fuzz(fcd):
         viterbi_fuzz_seed(fcd, seed)
 
 
+def test_viterbi_whole_tiles_without_quality(fcd):
+    """The streaming kernel's whole-tile path (256-row tiles, no quality values: labels through a DPP wave shift):
+    lengths on both sides of every tile and sub-tile boundary, runs and blank stretches crossing them, argmax ties,
+    NaN rows, both element widths."""
+    rng = np.random.default_rng(77)
+    lens = [255, 256, 257, 319, 320, 321, 511, 512, 513, 767, 768, 1024, 1100, 1]
+    B, T, N = len(lens), 1100, 5
+    x = (rng.integers(0, 4, size=(B, T, N)) / 4.0).astype(np.float32)      # quantised: ties everywhere
+    x[1] = reference_style_rows(rng, T, N)
+    x[2, 200:600, 1:] = 0.0                                                # a blank stretch across two tiles
+    x[3, 250:530, :] = 0.0
+    x[3, 250:530, 3] = 1.0                                                 # one label for 280 rows
+    x[4, 255, :] = np.nan                                                  # NaN rows at the seams
+    x[4, 256, 2] = np.nan
+    x[5, 63:66, 0] = np.nan
+    lengths = np.array(lens, np.int64)
+    for collapse in (True, False):
+        for dtype in (np.float32, np.float16):
+            xs = x.astype(dtype)
+            up = xs.astype(np.float32)
+            r = fcd.viterbi_search_batch_raw(xs, collapse, lengths=lengths)
+            for i in range(B):
+                labels, path, _ = oracle.viterbi_search_raw(np.ascontiguousarray(up[i, :lens[i]]), collapse)
+                n = int(r.out_len[i])
+                assert n == len(labels), (collapse, dtype, i)
+                np.testing.assert_array_equal(r.labels[i, :n], labels)
+                np.testing.assert_array_equal(r.path[i, :n], path)
+
+
 def test_batch_sequences_path_flavours(fcd):
     """BatchResult.sequences: the vectorised string build and the three path flavours agree with the
     single-read calls; multi-character alphabets take the generic route."""
