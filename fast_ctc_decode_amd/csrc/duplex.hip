@@ -266,25 +266,64 @@ __device__ __forceinline__ void vec_get(const VecRef &v, int at, int Wcap, float
     sum = load_f32_l2(v.base + 3 * slot + 2);
 }
 
+// Ring slot of row t, for t within a ring's length of the step's lower bound lo (lo_m = lo mod Wcap, computed once per
+// step): an add and two conditional corrections where `t % Wcap` on a run-time Wcap is a ~25-instruction division --
+// which the per-step bookkeeping used to pay a few dozen times per step.
+__device__ __forceinline__ int slot_near(int t, int lo, int lo_m, int Wcap) {
+    int s = lo_m + (t - lo);
+    s = s < 0 ? s + Wcap : s;
+    return s >= Wcap ? s - Wcap : s;
+}
+
 // Two pieces of the resident-window bookkeeping live OUT OF LINE: inlined, they pushed the logsumexp instantiations
 // (whose window-building loop pins ~60 coefficient registers) over the register file and spilled 226 - 276 VGPRs to
 // scratch memory.  Both run a few times per step; a call costs far less than the spills did.
 //
 // A node entering the beam: rows [off, off + n3 / 3) of its ring, arena -> LDS (eight loads in flight per lane).
 __device__ __attribute__((noinline)) void ring_copy_in(const float *src, float *dst, int off, int n3, int Wcap, int lane) {
+    // arena ring and LDS ring have the same geometry: element i of the window sits at flat index (off mod Wcap) * 3 + i,
+    // wrapped once at 3 * Wcap, on both sides
+    const int W3 = 3 * Wcap;
+    const int s03 = (__builtin_amdgcn_readfirstlane(off) % Wcap) * 3;
     for (int base = 0; base < n3; base += 8 * kWave) {
         float v[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * kWave + lane;
-            const int row = idx / 3;
-            v[u] = idx < n3 ? load_f32_l2(src + ((off + row) % Wcap) * 3 + (idx - row * 3)) : 0.0f;
+            int f = s03 + idx;
+            f = f >= W3 ? f - W3 : f;
+            v[u] = idx < n3 ? load_f32_l2(src + f) : 0.0f;
         }
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
             const int idx = base + u * kWave + lane;
-            const int row = idx / 3;
-            if (idx < n3) dst[((off + row) % Wcap) * 3 + (idx - row * 3)] = v[u];
+            int f = s03 + idx;
+            f = f >= W3 ? f - W3 : f;
+            if (idx < n3) dst[f] = v[u];
+        }
+    }
+}
+
+// Up to two nodes entering the beam in the same step: their WHOLE rings (rows outside a window's bounds are never read,
+// so they may come along), all loads of both in flight before the first store -- one trip to the arena for the pair,
+// and none of it waits for the nodes' bounds.
+__device__ __attribute__((noinline)) void ring_copy_whole2(const float *src_a, float *dst_a, const float *src_b, float *dst_b,
+                                                           int W3, int lane) {
+    for (int base = 0; base < W3; base += 7 * kWave) {
+        float va[7], vb[7];  // (a ring of 130 rows is 390 words: one pass)
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int idx = base + u * kWave + lane;
+            va[u] = idx < W3 ? load_f32_l2(src_a + idx) : 0.0f;
+            vb[u] = (src_b && idx < W3) ? load_f32_l2(src_b + idx) : 0.0f;
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const int idx = base + u * kWave + lane;
+            if (idx < W3) {
+                dst_a[idx] = va[u];
+                if (src_b) dst_b[idx] = vb[u];
+            }
         }
     }
 }
@@ -296,7 +335,7 @@ template <int MODE>
 __device__ __attribute__((noinline)) float extend_rows(float *my, float *mw, const float *prg, VecRef pv, int p_off,
                                                        int p_end, const float *tile, int tile_step, int lo, int end,
                                                        int hi, int lab, bool is_rep, int Wcap, float l_lab, float l_sum,
-                                                       float mx) {
+                                                       float mx, int lo_m) {
     for (int idx = end; idx < hi; ++idx) {  // idx >= lo: the rows of read 2 are in the LDS tile
         const float *row = tile + (idx - lo) * tile_step;
         float pg, ps;
@@ -306,7 +345,7 @@ __device__ __attribute__((noinline)) float extend_rows(float *my, float *mw, con
                 pg = kNegInf;
                 ps = kNegInf;
             } else {
-                const int sl = (((at % Wcap) + Wcap) % Wcap) * 3;
+                const int sl = slot_near(at, lo, lo_m, Wcap) * 3;  // at >= lo - 1
                 pg = prg[sl + 1];
                 ps = prg[sl + 2];
             }
@@ -317,10 +356,8 @@ __device__ __attribute__((noinline)) float extend_rows(float *my, float *mw, con
         const float xx = is_rep ? pg : ps;
         const float lb = row[lab + 1] + ladd<MODE>(l_lab, xx);
         const float sm = ladd<MODE>(lb, g);
-        const int sl = (idx % Wcap) * 3;
-        my[sl] = lb;
-        my[sl + 1] = g;
-        my[sl + 2] = sm;
+        const int sl = slot_near(idx, lo, lo_m, Wcap) * 3;
+        store_row(my + sl, lb, g, sm);
         mw[sl] = lb;
         mw[sl + 1] = g;
         mw[sl + 2] = sm;
@@ -434,6 +471,9 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
     const bool prof = p.prof != nullptr;
     uint64_t acc[5] = {0, 0, 0, 0, 0}, t_prev = 0, t_now = 0;
     uint32_t n_iter = 0, n_newnodes = 0, n_slow = 0, n_enter = 0, n_ext = 0;
+    uint64_t sub[5] = {0, 0, 0, 0, 0}, t_sub = 0, t_sub2 = 0;  // finer stamps inside phases 0 and 4 (developer instrument)
+#define FCD_SUB_BEGIN() if (prof) FCD_STAMP(t_sub, stamp_dep);
+#define FCD_SUB(k) if (prof) { FCD_STAMP(t_sub2, stamp_dep); sub[k] += t_sub2 - t_sub; t_sub = t_sub2; }
     int stamp_dep = 0;
     if (prof) FCD_STAMP(t_prev, stamp_dep);
 #define FCD_DUPLEX_PHASE(k)                  \
@@ -492,11 +532,14 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         const int lo = (int)lo_u;
 
         const int W = hi - lo;
+        const int lo_m = lo % Wcap;  // (wave-uniform, once per step: see slot_near)
         if (staged) {
             // ---- LDS tile of read 2's rows [lo, hi) for this row of read 1 (the extension below reads it too) ----
             __syncthreads();
+            FCD_SUB_BEGIN()
             for (int xw = lane; xw < W * S * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * S * N + xw];
             __syncthreads();
+            FCD_SUB(0)
         }
         if (hi > last_hi) {
             // ---- :493 beam.sort_by_key(node): parents before children ----
@@ -583,7 +626,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         const int o2 = __shfl(off, e2), n2 = __shfl(end, e2);
                         const float *rg = ring(L.b_buf(cur)[e2]);
                         float part = kNegInf;
-                        for (int t = (lo > o2 ? lo : o2) + lane; t < n2; t += kWave) part = lmax(part, rg[3 * (t % Wcap) + 2]);
+                        for (int t = (lo > o2 ? lo : o2) + lane; t < n2; t += kWave) part = lmax(part, rg[3 * slot_near(t, lo, lo_m, Wcap) + 2]);
                         for (int o = 32; o > 0; o >>= 1) part = lmax(part, __shfl_xor(part, o));
                         if (lane == e2) mx = part;
                     }
@@ -595,14 +638,14 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     float *mw = ring(L.b_buf(cur)[e]);
                     float l_lab = kNegInf, l_sum = kNegInf;
                     if (end > off) {
-                        const int sl = (end - 1) % Wcap;
+                        const int sl = slot_near(end - 1, lo, lo_m, Wcap);  // end - 1 >= off >= lo - 1 after the discard above
                         l_lab = mw[3 * sl];
                         l_sum = mw[3 * sl + 2];
                     }
                     const float *prg = pslot >= 0 ? ring(L.b_buf(cur)[pslot]) : nullptr;
                     const VecRef pv = node_vec(parent, p_off, p_end);
                     mx = extend_rows<MODE>(my, mw, prg, pv, p_off, p_end, L.w2 + tst * N, S * N, lo, end, hi, lab, is_rep,
-                                           Wcap, l_lab, l_sum, mx);  // :361-386
+                                           Wcap, l_lab, l_sum, mx, lo_m);  // :361-386
                     meta[node] = make_int4(parent, lab, off, hi);
                     nmax[node] = mx;
                     rlo[node] = rl;
@@ -1016,7 +1059,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     const int rstep = S * N;
                     const int W3 = 3 * Wcap;
                     int jrow = qd;                               // this lane's row of the coming group
-                    int s3 = 3 * ((lo + qd) % Wcap);             // its slot (x 3)
+                    int s3 = 3 * slot_near(lo + qd, lo, lo_m, Wcap);  // its slot (x 3)
                     int sx = s3 == 0 ? W3 - 3 : s3 - 3;          // the slot of the row before: the parent's row it needs
                     const float *wlast = wq + (W > 0 ? W - 1 : 0) * rstep;
                     const float *wrow = wq + jrow * rstep;
@@ -1107,7 +1150,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     const int q_off = L.b_off(cur)[q_i], q_end = L.b_end(cur)[q_i];
                     const int rstep = S * N;
                     int jn = isA ? 0 : -1;                      // the row this lane handles in the coming iteration
-                    int slot3 = 3 * ((lo + Wcap + jn) % Wcap);  // 3 * ((lo + jn) mod Wcap)
+                    int slot3 = 3 * slot_near(lo + jn, lo, lo_m, Wcap);  // 3 * ((lo + jn) mod Wcap)
                     // loop-invariant forms of the per-row tests: a lane works on row j iff (unsigned)j < wlim; the parent
                     // holds row lo + j iff (unsigned)(j - jv0) < jspan (the even lane asks for X of the NEXT row, which
                     // sits in the slot this lane's own row occupies: same ring geometry)
@@ -1118,7 +1161,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     float c_cur = 0.0f, x_cur = kNegInf;
                     if (isA) {
                         c_cur = wq[0];
-                        x_cur = (lo - 1 >= q_off && lo - 1 < q_end) ? xq[3 * (((lo - 1) % Wcap + Wcap) % Wcap)] : kNegInf;
+                        x_cur = (lo - 1 >= q_off && lo - 1 < q_end) ? xq[3 * slot_near(lo - 1, lo, lo_m, Wcap)] : kNegInf;
                     }
                     for (int sidx = 0; sidx <= W; ++sidx) {
                         // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
@@ -1284,6 +1327,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             }
         }
         __syncthreads();
+        FCD_SUB_BEGIN()
         for (int item = lane; item < Bn * NL; item += kWave) {
             const int s = item / NL, l = item - s * NL;
             const int src = L.nb_src[s];
@@ -1295,6 +1339,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             else v = load_i32_l2(&rows[(int64_t)L.b_node(nxt)[s] * NL + l]);
             L.b_child(nxt)[s * NL + l] = v;
         }
+        FCD_SUB(3)
         // a state outside [0, S) is an ndarray index panic in the reference when the entry is next
         // expanded (:749) -- which never happens for the entries the last row leaves behind
         if (crf && t1 + 1 < T1) {
@@ -1302,6 +1347,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             for (int s2 = lane; s2 < Bn; s2 += kWave) bs = bs || L.b_state(nxt)[s2] >= S;
             if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
         }
+        FCD_SUB_BEGIN()
         if (resident) {
             // ---- hand the LDS buffers of the entries that left to the nodes that entered, and bring their rings in ----
             for (int j = lane; j < BC; j += kWave) L.s_off[j] = 0;
@@ -1317,25 +1363,37 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             const uint64_t enter_m = ballot(entering);
             __syncthreads();
             if (entering) L.b_buf(nxt)[lane] = L.s_end[popc64(enter_m & lanemask_lt())];
-            // bounds and maxima of ALL entering nodes in one round trip (each on its own lane) ...
+            __syncthreads();
+            // bounds and maxima of ALL entering nodes (each on its own lane) and their rings, two nodes at a time, in
+            // the same trip to the arena: the loads of the bounds are issued first and used last
+            int4 m4 = make_int4(0, 0, 0, 0);
+            float e_mx = kNegInf;
+            int e_rl = 0;
             if (entering) {
                 const int nd = L.b_node(nxt)[lane];
-                const int4 m4 = load_meta_l2(&meta[nd]);
+                m4 = load_meta_l2(&meta[nd]);
+                e_mx = load_f32_l2(&nmax[nd]);
+                e_rl = load_i32_l2(&rlo[nd]);
+            }
+            if (prof) n_enter += (uint32_t)popc64(enter_m);
+            for (uint64_t m = enter_m; m != 0ull;) {
+                const int ea = (int)__builtin_ctzll(m);
+                m &= m - 1;
+                const int eb = m ? (int)__builtin_ctzll(m) : -1;
+                if (eb >= 0) m &= m - 1;
+                ring_copy_whole2(vec + (int64_t)L.b_node(nxt)[ea] * Wcap * 3, ring(L.b_buf(nxt)[ea]),
+                                 eb >= 0 ? vec + (int64_t)L.b_node(nxt)[eb] * Wcap * 3 : nullptr,
+                                 eb >= 0 ? ring(L.b_buf(nxt)[eb]) : nullptr, 3 * Wcap, lane);
+            }
+            FCD_SUB(1)
+            if (entering) {
                 L.b_off(nxt)[lane] = m4.z;
                 L.b_end(nxt)[lane] = m4.w;
-                L.b_max(nxt)[lane] = load_f32_l2(&nmax[nd]);
-                L.b_rlo(nxt)[lane] = load_i32_l2(&rlo[nd]);
-            }
-            __syncthreads();
-            if (prof) n_enter += (uint32_t)popc64(enter_m);
-            // ... then their rings
-            for (uint64_t m = enter_m; m != 0ull; m &= m - 1) {
-                const int e2 = (int)__builtin_ctzll(m);
-                const int eo = L.b_off(nxt)[e2];
-                ring_copy_in(vec + (int64_t)L.b_node(nxt)[e2] * Wcap * 3, ring(L.b_buf(nxt)[e2]), eo,
-                             (L.b_end(nxt)[e2] - eo) * 3, Wcap, lane);
+                L.b_max(nxt)[lane] = e_mx;
+                L.b_rlo(nxt)[lane] = e_rl;
             }
         }
+        FCD_SUB(2)
         B = Bn;
         cur = nxt;
         __syncthreads();
@@ -1350,6 +1408,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         o[8] = n_slow;   // steps whose extension took the sequential path
         o[9] = n_enter;  // nodes that entered the beam (their rings were copied into LDS)
         o[10] = n_ext;   // steps in which the envelope's upper bound grew
+        for (int k = 0; k < 5; ++k) o[11 + k] = (uint32_t)(sub[k] >> 6);  // 11 read-2 tile, 12 hand-over + meta, 13 ring copies, 14 child rows
     }
 
     // ---- labels leaf -> root (:638-649), written in sequence order ----

@@ -73,7 +73,11 @@ def main():
                    "bound_cycles_per_step": round((w * 2 + 1) * lat[mode], 1),
                    "frac": round((w * 2 + 1) * lat[mode] / float(per_step.sum()), 4)},
                "sequential_extension_fraction": round(float((a[:, 8] / np.maximum(a[:, 10], 1)).mean()), 4),
-               "entering_nodes_per_step": round(float((a[:, 9] / steps).mean()), 3)}
+               "entering_nodes_per_step": round(float((a[:, 9] / steps).mean()), 3),
+               # finer stamps inside "envelope+extend" (the read-2 tile) and "rank+next_beam" (cycles per step)
+               "inside": {n: round(float((a[:, 11 + k] * 64.0 / steps).mean()), 1) for k, n in enumerate(
+                   ["read-2 tile load", "buffer hand-over + entering nodes' bounds", "entering nodes' ring copies",
+                    "child rows of the next beam"])}}
         print(json.dumps(rec), flush=True)
 
 
