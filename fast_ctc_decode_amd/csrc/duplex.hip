@@ -155,6 +155,23 @@ __device__ __forceinline__ float ladd_lockstep(float a, float b, const LogAddCoe
 
 __device__ __forceinline__ float lmax(float self, float other) { return self < other ? other : self; }
 
+// LogSpace-style maximum over the 64 lanes, delivered to every lane: the classic GCN DPP reduction (row shifts, then
+// the two row broadcasts) ends in lane 63, which a readlane hands out -- no LDS round trips (six ds_bpermute steps cost
+// ~800 cycles per call with one wavefront on the SIMD).  Operands are never NaN here (callers fold with lmax from -inf).
+__device__ __forceinline__ float wave_lmax(float x) {
+    float t = x;
+#define FCD_DPP_LMAX(CTRL, RM)                                                                                          \
+    t = lmax(t, __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(t), __float_as_int(t), CTRL, RM, 0xf, false)));
+    FCD_DPP_LMAX(0x111, 0xf)  // row_shr:1
+    FCD_DPP_LMAX(0x112, 0xf)  // row_shr:2
+    FCD_DPP_LMAX(0x114, 0xf)  // row_shr:4
+    FCD_DPP_LMAX(0x118, 0xf)  // row_shr:8   -> lane 15 of every row holds the row's maximum
+    FCD_DPP_LMAX(0x142, 0xa)  // row_bcast:15 into rows 1 and 3
+    FCD_DPP_LMAX(0x143, 0xc)  // row_bcast:31 into rows 2 and 3 -> lane 63 holds the maximum
+#undef FCD_DPP_LMAX
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(t), 63));
+}
+
 // v_max_f32 as it is: through __builtin_fmaxf the compiler first "canonicalises" every operand it cannot prove free of
 // signalling NaNs (v_max_f32 x, x, x) -- on the dependent chain.  Callers guarantee ordinary operands.
 __device__ __forceinline__ float vmax_raw(float a, float b) {
@@ -533,15 +550,19 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
 
         const int W = hi - lo;
         const int lo_m = lo % Wcap;  // (wave-uniform, once per step: see slot_near)
-        if (staged) {
-            // ---- LDS tile of read 2's rows [lo, hi) for this row of read 1 (the extension below reads it too) ----
+        // ---- LDS tile of read 2's rows [lo, hi) for this row of read 1 (the extension below reads it too) ----
+        // Loaded AFTER the beam entries have asked for their parents' bounds (below): one trip to memory for both.
+        bool tile_done = !staged;
+        auto load_tile = [&]() {
             __syncthreads();
             FCD_SUB_BEGIN()
             for (int xw = lane; xw < W * S * N; xw += kWave) L.w2[xw] = ln2[(int64_t)lo * S * N + xw];
             __syncthreads();
             FCD_SUB(0)
-        }
+            tile_done = true;
+        };
         if (hi > last_hi) {
+            FCD_SUB_BEGIN()
             // ---- :493 beam.sort_by_key(node): parents before children ----
             const int nx = cur ^ 1;
             for (int e = lane; e < B; e += kWave) {
@@ -585,6 +606,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     pslot = -1;
                 float mx = kNegInf;
                 bool bad = false, rescan = false, panic = false;
+                int4 pm = make_int4(0, 0, 0, 0);
                 if (fast_ok && mine) {
                     node = L.b_node(cur)[e];
                     parent = L.b_par(cur)[e]; lab = L.b_tip(cur)[e];
@@ -604,14 +626,19 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     if (parent >= 0) {
                         for (int j = 0; j < B; ++j)
                             if (L.b_node(cur)[j] == parent) pslot = j;
+                        // (asked for whether or not the parent turns out to be a beam entry, and not looked at before the
+                        // read-2 tile has been requested too: nothing here waits for it)
+                        pm = load_meta_l2(&meta[parent]);
                         if (pslot >= 0) {  // the parent is a beam entry: its window is resident too
                             p_lab = L.b_tip(cur)[pslot]; p_off = L.b_off(cur)[pslot]; p_end = L.b_end(cur)[pslot];
                             bad = p_end < hi - 1;  // it has yet to write a row this entry needs: parents first
-                        } else {
-                            const int4 pm = load_meta_l2(&meta[parent]);
-                            p_lab = pm.y; p_off = pm.z; p_end = pm.w;
                         }
                     }
+                }
+                FCD_SUB(4)
+                load_tile();  // (the parents' bounds above are still in flight: they arrive with the tile)
+                if (parent >= 0 && pslot < 0) {
+                    p_lab = pm.y; p_off = pm.z; p_end = pm.w;
                 }
                 if (ballot(panic) != 0ull) return fail(FCD_ST_BAD_STATE);
                 fast_ok = fast_ok && ballot(bad) == 0ull;
@@ -621,16 +648,25 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     // incremental form of r02 ("does a leaving row hold the maximum?") sent 68 % (logsumexp) / 97 %
                     // (max mode: the best single path loses probability with every row, so the maximum sits at the
                     // window's first row) of config 5's steps down the sequential path.
+                    const int my_buf = mine ? L.b_buf(cur)[e] : 0;
                     for (uint64_t m = ballot(rescan); m != 0ull; m &= m - 1) {
+                        // (wave-uniform entry: its bounds and buffer come by v_readlane, not through LDS)
                         const int e2 = (int)__builtin_ctzll(m);
-                        const int o2 = __shfl(off, e2), n2 = __shfl(end, e2);
-                        const float *rg = ring(L.b_buf(cur)[e2]);
+                        const int o2 = __builtin_amdgcn_readlane(off, e2), n2 = __builtin_amdgcn_readlane(end, e2);
+                        const float *rg = ring(__builtin_amdgcn_readlane(my_buf, e2));
                         float part = kNegInf;
-                        for (int t = (lo > o2 ? lo : o2) + lane; t < n2; t += kWave) part = lmax(part, rg[3 * slot_near(t, lo, lo_m, Wcap) + 2]);
-                        for (int o = 32; o > 0; o >>= 1) part = lmax(part, __shfl_xor(part, o));
+                        for (int t0 = (lo > o2 ? lo : o2) + lane; t0 < n2; t0 += 3 * kWave) {  // three reads in flight
+                            const int t1r = t0 + kWave, t2r = t0 + 2 * kWave;
+                            const float v0 = rg[3 * slot_near(t0, lo, lo_m, Wcap) + 2];
+                            const float v1 = t1r < n2 ? rg[3 * slot_near(t1r, lo, lo_m, Wcap) + 2] : kNegInf;
+                            const float v2 = t2r < n2 ? rg[3 * slot_near(t2r, lo, lo_m, Wcap) + 2] : kNegInf;
+                            part = lmax(lmax(lmax(part, v0), v1), v2);
+                        }
+                        part = wave_lmax(part);
                         if (lane == e2) mx = part;
                     }
                 }
+                FCD_SUB(2)
                 if (fast_ok && mine) {
                     const bool is_rep = !crf && parent >= 0 && p_lab == lab;  // :512 (crf: :320-334, no repeat case)
                     const int tst = L.b_state(cur)[e];                        // crf: the entry's own state (:725-728)
@@ -811,6 +847,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 __syncthreads();
             }
         }
+        if (!tile_done) load_tile();  // (a step whose upper bound did not move)
         last_hi = hi;
         FCD_DUPLEX_PHASE(0)
 
@@ -1393,7 +1430,6 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 L.b_rlo(nxt)[lane] = e_rl;
             }
         }
-        FCD_SUB(2)
         B = Bn;
         cur = nxt;
         __syncthreads();
@@ -1408,7 +1444,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         o[8] = n_slow;   // steps whose extension took the sequential path
         o[9] = n_enter;  // nodes that entered the beam (their rings were copied into LDS)
         o[10] = n_ext;   // steps in which the envelope's upper bound grew
-        for (int k = 0; k < 5; ++k) o[11 + k] = (uint32_t)(sub[k] >> 6);  // 11 read-2 tile, 12 hand-over + meta, 13 ring copies, 14 child rows
+        for (int k = 0; k < 5; ++k) o[11 + k] = (uint32_t)(sub[k] >> 6);  // 11 read-2 tile, 12 hand-over + entering nodes, 13 update_max rescans, 14 child rows, 15 beam sort + parents' bounds
     }
 
     // ---- labels leaf -> root (:638-649), written in sequence order ----

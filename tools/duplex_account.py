@@ -76,8 +76,8 @@ def main():
                "entering_nodes_per_step": round(float((a[:, 9] / steps).mean()), 3),
                # finer stamps inside "envelope+extend" (the read-2 tile) and "rank+next_beam" (cycles per step)
                "inside": {n: round(float((a[:, 11 + k] * 64.0 / steps).mean()), 1) for k, n in enumerate(
-                   ["read-2 tile load", "buffer hand-over + entering nodes' bounds", "entering nodes' ring copies",
-                    "child rows of the next beam"])}}
+                   ["read-2 tile load", "buffer hand-over + entering nodes' bounds and rings", "update_max rescans",
+                    "child rows of the next beam", "beam sort + parents' bounds"])}}
         print(json.dumps(rec), flush=True)
 
 
