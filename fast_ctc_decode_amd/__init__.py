@@ -23,6 +23,7 @@ from .api import (  # noqa: F401
     crf_beam_search_batch,
     crf_beam_search_batch_raw,
     crf_beam_search_duplex,
+    crf_beam_search_duplex_batch,
     crf_beam_search_duplex_batch_raw,
     crf_greedy_search,
     crf_greedy_search_batch,

@@ -342,6 +342,10 @@ def crf_greedy_search_batch(network_outputs, init_states, alphabet, qstring=Fals
 _DEFAULT_LOGADD = [nat.LOGADD_LOGSUMEXP]
 
 
+_MODE_CODES = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX,
+               nat.LOGADD_LOGSUMEXP: nat.LOGADD_LOGSUMEXP, nat.LOGADD_MAX: nat.LOGADD_MAX}
+
+
 def set_duplex_logadd_mode(mode):
     """Select the duplex log-space addition: "logsumexp" (the reference built with
     --no-default-features; BASELINE.json's north star) or "max" (the reference's default `fastexp`
@@ -386,7 +390,7 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
                                  lengths_2=None, logadd_mode=None, count_ambiguous=False):
     """(B,T1,N) and (B,T2,N) posteriors + (B,T1,2) uint64 envelopes -> BatchResult (labels only).
     `count_ambiguous`: also fill BatchResult.ambiguous, the tie counters of the prune (include/fcd.h)."""
-    mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
+    mode = _DEFAULT_LOGADD[0] if logadd_mode is None else _MODE_CODES[logadd_mode]
     if _is_torch_cuda(network_outputs_1):
         import torch
         x1, x2 = network_outputs_1, network_outputs_2
@@ -474,6 +478,11 @@ def beam_search_duplex_batch(network_outputs_1, network_outputs_2, alphabet, env
                              beam_size=5, beam_cut_threshold=0.0, collapse_repeats=True,
                              lengths_1=None, lengths_2=None, logadd_mode=None):
     """Batched beam_search_duplex -> list[str]."""
+    if _device_tensor(network_outputs_1) is None:  # host input: the compiled layer (one host layer, not two)
+        mode = int(_DEFAULT_LOGADD[0] if logadd_mode is None else _MODE_CODES[logadd_mode])
+        return _compiled().beam_search_duplex_batch(_host_input(network_outputs_1), _host_input(network_outputs_2),
+                                                    alphabet, envelopes, beam_size, beam_cut_threshold,
+                                                    collapse_repeats, lengths_1, lengths_2, True, mode)
     alpha = _seq_to_vec(alphabet)
     if network_outputs_1.shape[-1] != network_outputs_2.shape[-1]:
         raise ValueError("inner axes of the network outputs do not match")
@@ -557,7 +566,7 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
                                      logadd_mode=None, count_ambiguous=False):
     """(B,T1,S,N) / (B,T2,S,N) posteriors (numpy, or torch ROCm tensors: zero-copy), (B,n_init)
     initial state scores, (B,T1,2) uint64 envelopes -> BatchResult (labels only)."""
-    mode = _DEFAULT_LOGADD[0] if logadd_mode is None else logadd_mode
+    mode = _DEFAULT_LOGADD[0] if logadd_mode is None else _MODE_CODES[logadd_mode]
     if _is_torch_cuda(network_outputs_1):
         import torch
         x1, x2 = network_outputs_1, network_outputs_2
@@ -625,6 +634,16 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
     r = BatchResult(out.labels, None, out.out_len, out.status, ambiguous=out.ambiguous)
     r._handle = h
     return r
+
+
+def crf_beam_search_duplex_batch(network_outputs_1, init_states_1, network_outputs_2, init_states_2, alphabet,
+                                 envelopes=None, beam_size=5, beam_cut_threshold=0.0, lengths_1=None, lengths_2=None,
+                                 logadd_mode=None):
+    """Batched crf_beam_search_duplex on HOST arrays -> list[str] (the compiled layer's function)."""
+    mode = int(_DEFAULT_LOGADD[0] if logadd_mode is None else _MODE_CODES[logadd_mode])
+    return _compiled().crf_beam_search_duplex_batch(_host_input(network_outputs_1), init_states_1,
+                                                    _host_input(network_outputs_2), init_states_2, alphabet, envelopes,
+                                                    beam_size, beam_cut_threshold, lengths_1, lengths_2, True, mode)
 
 
 def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, init_state_2,

@@ -876,6 +876,163 @@ py::list crf_greedy_search_batch(const py::object &network_outputs, const py::ob
     return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
 }
 
+// ---- duplex batches: n pairs per call (one launch), sequences only (the duplex searches report no path) ----
+// envelopes: None (every row of read 1 searches the whole of read 2, lib.rs:459-468) or ONE uint64 array (B, T1, 2).
+struct DuplexOut {
+    std::vector<uint8_t> labels;
+    std::vector<uint32_t> len;
+    std::vector<int32_t> status;
+    fcd_result res{};
+    DuplexOut(int64_t B, int64_t T1) {
+        const size_t w = T1 > 0 ? (size_t)T1 : 1, n = B > 0 ? (size_t)B : 1;
+        labels.resize(n * w);
+        len.assign(n, 0);
+        status.assign(n, 0);
+        res.labels = labels.data();
+        res.out_len = len.data();
+        res.status = status.data();
+        res.out_stride = (int64_t)w;
+    }
+};
+
+const uint64_t *duplex_envelopes(const py::object &envelopes, int64_t B, int64_t T1, int64_t T2, const std::vector<int64_t> &len2,
+                                 std::vector<uint64_t> &fallback, py::array &keep) {
+    if (!envelopes.is_none()) {
+        if (!py::isinstance<py::array>(envelopes)) throw py::type_error("argument 'envelopes': expected numpy.ndarray");
+        py::array e = py::reinterpret_borrow<py::array>(envelopes);
+        if (!e.dtype().is(py::dtype::of<uint64_t>()) || e.ndim() != 3)
+            throw py::type_error("argument 'envelopes': expected a 3-dimensional uint64 array");
+        if (e.shape(0) != B || e.shape(1) != T1 || e.shape(2) != 2)
+            throw py::value_error("envelopes must have shape (n_pairs, T1, 2)");
+        keep = py::array::ensure(e, py::array::c_style);
+        return static_cast<const uint64_t *>(keep.data());
+    }
+    fallback.resize((size_t)std::max<int64_t>(B * T1, 1) * 2);
+    for (int64_t r = 0; r < B; ++r) {
+        const uint64_t hi = (uint64_t)(len2.empty() ? T2 : std::min<int64_t>(std::max<int64_t>(len2[(size_t)r], 0), T2));
+        for (int64_t t = 0; t < T1; ++t) {
+            fallback[(size_t)(r * T1 + t) * 2] = 0;
+            fallback[(size_t)(r * T1 + t) * 2 + 1] = hi;
+        }
+    }
+    return fallback.data();
+}
+
+py::list duplex_sequences(const DuplexOut &o, int64_t B, const std::vector<std::string> &alpha, bool reversed,
+                          bool raise_on_error) {
+    py::list out((py::ssize_t)B);
+    for (int64_t r = 0; r < B; ++r) {
+        PyObject *item;
+        if (o.status[(size_t)r] != FCD_ST_OK) {
+            if (raise_on_error) {
+                for (int64_t q = r; q < B; ++q) {  // (the list must not be released with empty slots)
+                    Py_INCREF(Py_None);
+                    PyList_SET_ITEM(out.ptr(), q, Py_None);
+                }
+                throw std::runtime_error("pair " + std::to_string(r) + ": " + fcd_status_string(o.status[(size_t)r]));
+            }
+            Py_INCREF(Py_None);
+            item = Py_None;
+        } else {
+            const uint8_t *lab = o.labels.data() + (size_t)r * (size_t)o.res.out_stride;
+            const uint32_t n = o.len[(size_t)r];
+            std::string seq;
+            if (reversed) {  // duplex.rs:825-833: appended leaf -> root, then the CHARACTERS are reversed
+                for (uint32_t i = n; i > 0; --i) seq += alpha[lab[i - 1]];
+                seq = reverse_chars(seq);
+            } else {
+                for (uint32_t i = 0; i < n; ++i) seq += alpha[lab[i]];
+            }
+            item = PyUnicode_FromStringAndSize(seq.data(), (Py_ssize_t)seq.size());
+            if (!item) throw py::error_already_set();
+        }
+        PyList_SET_ITEM(out.ptr(), r, item);
+    }
+    return out;
+}
+
+int duplex_mode_of(const py::object &m) {  // None: the module's setting; "logsumexp" / "max"; or the C ABI's integer
+    if (m.is_none()) return g_logadd_mode;
+    if (py::isinstance<py::str>(m)) {
+        const std::string v = m.cast<std::string>();
+        if (v == "logsumexp") return FCD_LOGADD_LOGSUMEXP;
+        if (v == "max") return FCD_LOGADD_MAX;
+        throw py::value_error("logadd_mode must be 'logsumexp' or 'max'");
+    }
+    const int v = m.cast<int>();
+    if (v != FCD_LOGADD_LOGSUMEXP && v != FCD_LOGADD_MAX) throw py::value_error("logadd_mode must be 'logsumexp' or 'max'");
+    return v;
+}
+
+py::list beam_search_duplex_batch(const py::object &network_outputs_1, const py::object &network_outputs_2,
+                                  const py::object &alphabet, const py::object &envelopes, const py::object &beam_size_o,
+                                  float beam_cut_threshold, bool collapse_repeats, const py::object &lengths_1,
+                                  const py::object &lengths_2, bool raise_on_error, const py::object &logadd_mode) {
+    const int mode = duplex_mode_of(logadd_mode);
+    BatchInput in1, in2;
+    make_batch(in1, network_outputs_1, 3, lengths_1);
+    make_batch(in2, network_outputs_2, 3, lengths_2);
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    if (in1.inner != in2.inner) throw py::value_error("inner axes of the network outputs do not match");
+    check_beam_args(alpha.size(), in1.inner, (py::ssize_t)beam_size, beam_cut_threshold);
+    const int64_t B = in1.b.n_reads, T1 = in1.b.T, T2 = in2.b.T;
+    if (in2.b.n_reads != B) throw py::value_error("both batches must hold the same number of reads");
+    if (B > 0 && T1 == 0)
+        throw std::runtime_error("network_output_1 is empty (the reference indexes envelope[(0,1)] and aborts)");
+    std::vector<uint64_t> env_default;
+    py::array env_keep;
+    const uint64_t *env = duplex_envelopes(envelopes, B, T1, T2, in2.lengths, env_default, env_keep);
+    DuplexOut o(B, T1);
+    if (B == 0) return py::list();
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_beam_search_duplex_host(h, &in1.b, &in2.b, env, T1, (int64_t)beam_size, beam_cut_threshold,
+                                         collapse_repeats ? 1 : 0, mode, &o.res);
+    }
+    check_rc(h, rc);
+    return duplex_sequences(o, B, alpha, false, raise_on_error);
+}
+
+py::list crf_beam_search_duplex_batch(const py::object &network_outputs_1, const py::object &init_states_1,
+                                      const py::object &network_outputs_2, const py::object &init_states_2,
+                                      const py::object &alphabet, const py::object &envelopes,
+                                      const py::object &beam_size_o, float beam_cut_threshold,
+                                      const py::object &lengths_1, const py::object &lengths_2, bool raise_on_error,
+                                      const py::object &logadd_mode) {
+    const int mode = duplex_mode_of(logadd_mode);
+    BatchInput in1, in2;
+    make_batch(in1, network_outputs_1, 4, lengths_1);
+    make_batch(in2, network_outputs_2, 4, lengths_2);
+    const int64_t B = in1.b.n_reads, T1 = in1.b.T, T2 = in2.b.T;
+    if (in2.b.n_reads != B) throw py::value_error("both batches must hold the same number of reads");
+    py::array i1 = init_states_array(init_states_1, B), i2 = init_states_array(init_states_2, B);
+    auto alpha = seq_to_vec(alphabet);
+    const size_t beam_size = to_usize(beam_size_o, "beam_size");
+    if (in1.inner != in2.inner) throw py::value_error("inner axes of the network outputs do not match");
+    check_beam_args(alpha.size(), in1.inner, (py::ssize_t)beam_size, beam_cut_threshold);
+    if (in1.b.S != in2.b.S)
+        throw std::runtime_error("state axes of the network outputs do not match (the reference asserts and aborts)");
+    if (B > 0 && T1 == 0) throw std::runtime_error("empty network_output_1 / init_state (the reference aborts here)");
+    std::vector<uint64_t> env_default;
+    py::array env_keep;
+    const uint64_t *env = duplex_envelopes(envelopes, B, T1, T2, in2.lengths, env_default, env_keep);
+    DuplexOut o(B, T1);
+    if (B == 0) return py::list();
+    int rc;
+    fcd_handle *h = thread_handle();
+    {
+        py::gil_scoped_release nogil;
+        rc = fcd_crf_beam_search_duplex_host(h, &in1.b, static_cast<const float *>(i1.data()), i1.shape(1), i1.shape(1),
+                                             &in2.b, static_cast<const float *>(i2.data()), i2.shape(1), i2.shape(1), env,
+                                             T1, (int64_t)beam_size, beam_cut_threshold, mode, &o.res);
+    }
+    check_rc(h, rc);
+    return duplex_sequences(o, B, alpha, true, raise_on_error);
+}
+
 }  // namespace
 
 PYBIND11_MODULE(fast_ctc_decode, m) {
@@ -973,6 +1130,16 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
     m.def("crf_greedy_search_batch", &crf_greedy_search_batch, "network_outputs"_a, "init_states"_a, "alphabet"_a,
           "qstring"_a = false, "qscale"_a = 1.0f, "qbias"_a = 0.0f, "lengths"_a = py::none(), "paths"_a = "list",
           "raise_on_error"_a = true);
+    m.def("beam_search_duplex_batch", &beam_search_duplex_batch, "network_outputs_1"_a, "network_outputs_2"_a, "alphabet"_a,
+          "envelopes"_a = py::none(), "beam_size"_a = 5, "beam_cut_threshold"_a = 0.0f, "collapse_repeats"_a = true,
+          "lengths_1"_a = py::none(), "lengths_2"_a = py::none(), "raise_on_error"_a = true, "logadd_mode"_a = py::none(),
+          "beam_search_duplex for n pairs in one launch -> list[str] (None for a failed pair when raise_on_error is "
+          "false).  envelopes: None or ONE uint64 array (n_pairs, T1, 2).");
+    m.def("crf_beam_search_duplex_batch", &crf_beam_search_duplex_batch, "network_outputs_1"_a, "init_states_1"_a,
+          "network_outputs_2"_a, "init_states_2"_a, "alphabet"_a, "envelopes"_a = py::none(), "beam_size"_a = 5,
+          "beam_cut_threshold"_a = 0.0f, "lengths_1"_a = py::none(), "lengths_2"_a = py::none(),
+          "raise_on_error"_a = true, "logadd_mode"_a = py::none(),
+          "crf_beam_search_duplex for n pairs in one launch -> list[str].");
     m.def("_set_host_pipeline", [](int lanes, int64_t chunk_reads, int64_t min_bytes) {
         fcd_handle *h = thread_handle();
         check_rc(h, fcd_set_host_pipeline(h, lanes, chunk_reads, min_bytes));

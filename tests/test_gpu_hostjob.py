@@ -264,3 +264,51 @@ def test_compiled_batch_functions_equal_per_read_calls(fcd, lanes, chunk):
         assert fcd.beam_search_batch(np.zeros((0, 10, 5), np.float32), "NACGT") == []
     finally:
         cm._set_host_pipeline(0, 0, -1)
+
+
+def test_compiled_duplex_batch_functions_equal_per_read_calls(fcd):
+    """The compiled module's duplex batch functions (and fast_ctc_decode_amd's, which call them on host inputs): element
+    i is the per-read function's result for pair i -- both log-add modes, explicit and default envelopes, ragged
+    pairs, a failing pair by exception or as None."""
+    import test_gpu_duplex as D
+    cm = _compiled_layer()
+    rng = np.random.default_rng(5)
+    B, T1, T2, N = 5, 40, 44, 5
+    x1 = rng.random((B, T1, N), dtype=np.float32)
+    x2 = rng.random((B, T2, N), dtype=np.float32)
+    x1 /= np.linalg.norm(x1, axis=-1, keepdims=True)
+    x2 /= np.linalg.norm(x2, axis=-1, keepdims=True)
+    env1 = D.band(T1, T2, 12)
+    envs = np.broadcast_to(env1, (B, T1, 2)).copy()
+    for mode in ("logsumexp", "max"):
+        want = [fcd.beam_search_duplex(x1[i], x2[i], "NACGT", env1, 5, 0.1, logadd_mode=mode) for i in range(B)]
+        assert fcd.beam_search_duplex_batch(x1, x2, "NACGT", envs, 5, 0.1, logadd_mode=mode) == want
+        assert cm.beam_search_duplex_batch(x1, x2, "NACGT", envs, 5, 0.1, logadd_mode=mode) == want
+        want_full = [fcd.beam_search_duplex(x1[i], x2[i], "NACGT", None, 5, 0.1, logadd_mode=mode) for i in range(B)]
+        assert fcd.beam_search_duplex_batch(x1, x2, "NACGT", None, 5, 0.1, logadd_mode=mode) == want_full
+    # ragged second reads: the default envelope ends at each pair's own length
+    l2 = np.array([44, 30, 44, 17, 40])
+    got = cm.beam_search_duplex_batch(x1, x2, "NACGT", None, 5, 0.1, lengths_2=l2, logadd_mode="max")
+    assert got == [fcd.beam_search_duplex(x1[i], x2[i, :l2[i]], "NACGT", None, 5, 0.1, logadd_mode="max") for i in range(B)]
+    # a failing pair
+    bad = envs.copy()
+    bad[3, 7] = (30, 20)  # an envelope row whose bounds cross
+    with pytest.raises(RuntimeError, match=r"pair 3: "):
+        cm.beam_search_duplex_batch(x1, x2, "NACGT", bad, 5, 0.1)
+    res = cm.beam_search_duplex_batch(x1, x2, "NACGT", bad, 5, 0.1, raise_on_error=False)
+    assert res[3] is None and res[4] == fcd.beam_search_duplex(x1[4], x2[4], "NACGT", env1, 5, 0.1)
+    with pytest.raises(ValueError, match="envelopes must have shape"):
+        cm.beam_search_duplex_batch(x1, x2, "NACGT", envs[:, :-1], 5, 0.1)
+    with pytest.raises(ValueError, match="alphabet size 4 does not match"):
+        cm.beam_search_duplex_batch(x1, x2, "NACG", envs, 5, 0.1)
+    # CRF pairs
+    S = 4
+    c1 = rng.random((B, T1, S, N), dtype=np.float32)
+    c2 = rng.random((B, T2, S, N), dtype=np.float32)
+    i1 = rng.random((B, S), dtype=np.float32)
+    i2 = rng.random((B, S), dtype=np.float32)
+    for mode in ("logsumexp", "max"):
+        want = [fcd.crf_beam_search_duplex(c1[i], i1[i], c2[i], i2[i], "NACGT", env1, 5, 0.05, logadd_mode=mode)
+                for i in range(B)]
+        assert fcd.crf_beam_search_duplex_batch(c1, i1, c2, i2, "NACGT", envs, 5, 0.05, logadd_mode=mode) == want
+        assert cm.crf_beam_search_duplex_batch(c1, i1, c2, i2, "NACGT", envs, 5, 0.05, logadd_mode=mode) == want
