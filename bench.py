@@ -203,6 +203,25 @@ def e2e_leg(fcd, cfg, x_host, init_host, ref_result, reps=3):
     want = ref_result.sequences("NACGT", paths="list") if not cfg["crf"] else None
     if want is not None:
         out["identical_to_device_path"] = bool(all(a == b for a, b in zip(res, want)))
+    if not cfg["crf"]:
+        # the same reads held as float16 -- what basecaller networks emit; the reference would be given an upcast
+        # float32 copy (src/lib.rs:182) -- uploaded at half the bytes and converted exactly in the kernel's loads
+        # (fcd_batch.dtype).  Compared with the float32 call on the upcast matrix, as the reference would see it.
+        xh = x_host.astype(np.float16)
+        cm.beam_search_batch(xh, "NACGT", cfg["beam"], cfg["thr"], True, paths="array")
+        best = None
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            res_h = cm.beam_search_batch(xh, "NACGT", cfg["beam"], cfg["thr"], True, paths="array")
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        out["float16_input_paths_array"] = B / best
+        out["ms_float16_input_paths_array"] = best * 1e3
+        n_chk = min(B, 256)
+        up = xh[:n_chk].astype(np.float32)
+        res_u = cm.beam_search_batch(up, "NACGT", cfg["beam"], cfg["thr"], True, paths="array")
+        out["float16_identical_to_upcast_float32"] = bool(all(
+            a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(res_h[:n_chk], res_u)))
     return out
 
 
