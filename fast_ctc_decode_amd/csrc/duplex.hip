@@ -176,7 +176,7 @@ __device__ __forceinline__ float wave_lmax(float x) {
 // signalling NaNs (v_max_f32 x, x, x) -- on the dependent chain.  Callers guarantee ordinary operands.
 __device__ __forceinline__ float vmax_raw(float a, float b) {
 #ifdef FCD_HIPEMU
-    return a < b ? b : a;
+    return a != a ? b : (b != b ? a : (a < b ? b : a));  // (the instruction's IEEE maxNum: a NaN operand is dropped)
 #else
     float r;
     asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -1125,7 +1125,10 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         s3 = s3 + 12 >= W3 ? s3 + 12 - W3 : s3 + 12;
                         sx = sx + 12 >= W3 ? sx + 12 - W3 : sx + 12;
                         if (j + 4 < W) fetch();
-                        const bool special = mine && (!(cl < 0.0f) | !(c0 < 0.0f) | !(cx < 0.0f));
+                        // (the incoming chain state counts as an operand: after a group that took the exact form it may be
+                        // a NaN or a zero, and v_max_f32 would drop the NaN that LogSpace::add carries along)
+                        const bool special = (mine && (!(cl < 0.0f) | !(c0 < 0.0f) | !(cx < 0.0f))) ||
+                                             (work && qd == 3 && (!(lab3 < 0.0f) | !(sum3 < 0.0f)));
                         float lab0, lab1, lab2, g0, g1, g2, g3, sum0, sum1, sum2;
                         const float lab_in = lab3, sum_in = sum3;
                         lab0 = cl + vmax_raw(rot(lab_in), cx);

@@ -81,6 +81,33 @@ def test_duplex_banded_exact(fcd, mode, collapse):
 
 
 @pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_special_values_in_wide_windows(fcd, mode):
+    """Posteriors of exactly 1 (log 0), exactly 0 (log -inf), above 1 and NaN inside a +-24 band: max mode's
+    four-lanes-per-node loop runs its rows on v_max_f32 and must fall back to LogSpace::add's compare-and-select form
+    for every group of rows such a value touches -- and for the groups AFTER it, whose incoming chain state may be a
+    NaN or a zero.  Both modes, exact vs the oracle."""
+    x1, x2 = pairs(340 + mode, 8, 120, 120)
+    x2[0, 30:34, :] = 0.0
+    x2[0, 30:34, 2] = 1.0            # probability one: its logarithm is 0
+    x2[1, 50, 1] = 0.0               # probability zero: -inf
+    x2[1, 51, :] = 0.0               # a whole row of zeros
+    x2[2, 60:63, 3] = 1.5            # a "probability" above 1: a positive logarithm
+    x2[3, 40, 0] = np.nan            # NaN in the blank column
+    x2[4, 41, 2] = np.nan            # NaN in a label column
+    x2[4, 0, 2] = np.nan             # ... and in the first row: every window that starts there is NaN from its first
+                                     # row on for that label -- a state the following groups of rows must carry
+    x1[5, 20, :] = 0.0
+    x1[5, 20, 1] = 1.0               # read 1 too
+    x2[6, 0, :] = 0.0
+    x2[6, 0, 0] = 1.0                # at the very first row
+    x2[7, 119, 4] = 1.0              # and at the very last
+    envs = np.stack([band(120, 120, 24)] * 8)
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.05, True, mode)
+    want = oracle_strings(x1, x2, "NACGT", envs, 5, 0.05, True, mode | CR)
+    assert got == want
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
 def test_duplex_default_envelope_exact(fcd, mode):
     x1, x2 = pairs(310 + mode, 4, 60, 70)
     got = gpu_strings(fcd, x1, x2, "NACGT", None, 5, 0.0, True, mode)
