@@ -1481,14 +1481,25 @@ __global__ void ln_convert_kernel(const float *x, int dtype, int64_t n_reads, in
     }
 }
 
-// test hook: out[i] = LogSpace::add(a[i], b[i]) and ln(a[i]) exactly as the duplex kernels compute them
+// test hook: out[i] = LogSpace::add(a[i], b[i]) and ln(a[i]) exactly as the duplex kernels compute them.  mode: the
+// log-add flavour, + 2 for the form the window-building loop uses (ladd_lockstep: every lane of the wavefront in step,
+// shortcuts folded into selects) instead of the general one.
 __global__ void logspace_probe_kernel(const float *a, const float *b, float *out_add, float *out_ln,
                                       int64_t n, int mode) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        out_add[i] = mode == FCD_LOGADD_MAX ? ladd<FCD_LOGADD_MAX>(a[i], b[i])
-                                            : ladd<FCD_LOGADD_LOGSUMEXP>(a[i], b[i]);
-        out_ln[i] = ln_cr(a[i]);
+    const LogAddCoef K = logadd_coef();
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const int64_t trips = (n + stride - 1) / stride;  // the same for every lane: the lockstep form votes
+    for (int64_t k = 0; k < trips; ++k) {
+        const int64_t i = k * stride + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool valid = i < n;
+        const float x = valid ? a[i] : -1.0f, y = valid ? b[i] : -2.0f;
+        float r;
+        if (mode & 2) r = (mode & 1) ? ladd_lockstep<FCD_LOGADD_MAX>(x, y, K) : ladd_lockstep<FCD_LOGADD_LOGSUMEXP>(x, y, K);
+        else r = (mode & 1) ? ladd<FCD_LOGADD_MAX>(x, y) : ladd<FCD_LOGADD_LOGSUMEXP>(x, y);
+        if (valid) {
+            out_add[i] = r;
+            out_ln[i] = ln_cr(x);
+        }
     }
 }
 

@@ -281,7 +281,8 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
 
 /* Test hook (device pointers, n elements): out_add[i] = LogSpace::add(a[i], b[i]) (src/duplex.rs:42-63)
  * and out_ln[i] = LogSpace::new(a[i]) = ln(a[i]) (:24-26), computed by the very device functions the
- * duplex kernel uses, so the log-space arithmetic can be checked bit for bit against the oracle. */
+ * duplex kernel uses, so the log-space arithmetic can be checked bit for bit against the oracle.
+ * logadd_mode: FCD_LOGADD_*, + 2 for the lockstep form of the window-building loop instead of the general one. */
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
                            float *out_ln, int64_t n, int logadd_mode);
 

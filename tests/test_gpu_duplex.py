@@ -313,7 +313,8 @@ def test_logspace_arithmetic_bits(fcd):
         oracle.lib.fcdo_logspace_add_batch(x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size, omode)
         return out
 
-    for mode, omode in ((0, LSE | CR), (1, MAX | CR)):
+    # (modes 2 / 3: the same two flavours in the form the window-building loop evaluates them)
+    for mode, omode in ((0, LSE | CR), (1, MAX | CR), (2, LSE | CR), (3, MAX | CR)):
         h.check(h.lib.fcd_logspace_probe_dev(h.ptr, ad.data_ptr(), bd.data_ptr(), out_add.data_ptr(),
                                              out_ln.data_ptr(), n, mode))
         torch.cuda.synchronize()
