@@ -896,16 +896,24 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
             int cid = -2;
             if (act) {
                 if (k == 0) {
+                    // The node's own candidate is the MERGE (:596-611) of up to three items that share the node -- the
+                    // blank extension {zero, gap}, the repeat-stay {label, zero} and the extension that arrives from
+                    // the parent's entry {label, zero} -- folded with LogSpace::add in the order the reference appends
+                    // them: tips in beam order, and within a tip blank first, labels after.  The order is immaterial
+                    // for ordinary numbers and for logsumexp, but max mode's add keeps a NaN only as its FIRST operand
+                    // (`exp` is identically 0 there, so a NaN in the smaller-or-unordered operand never shows).
                     const float pr0 = row1[0];
                     const bool blank = pr0 > thr;  // :529
-                    if (blank) cgp = ladd<MODE>(lp, gp) + pr0;
+                    const float g_item = blank ? ladd<MODE>(lp, gp) + pr0 : kNegInf;
                     bool stay = collapse && tip >= 0;
+                    float s_item = kNegInf;
                     if (stay) {
                         const float pt = row1[tip + 1];
                         stay = !(pt < thr);
-                        if (stay) clp = lp + pt;  // :541-544
+                        if (stay) s_item = lp + pt;  // :541-544
                     }
-                    bool inc = false;
+                    bool inc = false, inc_first = false;
+                    float c_item = kNegInf;
                     if (node >= 0) {
                         const int par = b_par[i];
                         for (int j = 0; j < B; ++j) {
@@ -914,14 +922,29 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                                 if (!(pl < thr)) {
                                     const bool rj = collapse && b_tip[j] == tip;
                                     const float lpj = b_lp[j], gpj = b_gp[j];
-                                    const float contrib = rj ? gpj + pl : ladd<MODE>(lpj, gpj) + pl;
-                                    clp = ladd<MODE>(clp, contrib);  // :604 prob_1 += (commutative)
+                                    c_item = rj ? gpj + pl : ladd<MODE>(lpj, gpj) + pl;
                                     inc = true;
+                                    inc_first = j < i;  // the parent's entry comes earlier in the beam: its item was appended first
                                 }
                                 break;
                             }
                         }
                     }
+                    bool have = false;
+                    auto push = [&](float l_it, float g_it) {
+                        if (!have) {
+                            clp = l_it;
+                            cgp = g_it;
+                            have = true;
+                        } else {
+                            clp = ladd<MODE>(clp, l_it);
+                            cgp = ladd<MODE>(cgp, g_it);
+                        }
+                    };
+                    if (inc && inc_first) push(c_item, kNegInf);
+                    if (blank) push(kNegInf, g_item);
+                    if (stay) push(s_item, kNegInf);
+                    if (inc && !inc_first) push(c_item, kNegInf);
                     valid = blank || stay || inc;
                     cid = node;
                 } else {

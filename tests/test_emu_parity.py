@@ -87,6 +87,8 @@ def test_duplex(fcd):
     D.test_duplex_banded_exact(fcd, D.MAX, False)
     D.test_duplex_special_values_in_wide_windows(fcd, D.MAX)
     D.test_duplex_special_values_in_wide_windows(fcd, D.LSE)
+    for seed in (7000, 7001, 100369, 101027):
+        assert D.special_values_case(fcd, seed, D.MAX) and D.special_values_case(fcd, seed, D.LSE)
     D.test_duplex_envelope_errors_and_edges(fcd)
     D.test_duplex_shapes_exact(fcd, 3, 3)
     D.test_duplex_receding_upper_bound(fcd, D.LSE)

@@ -415,6 +415,47 @@ def duplex_fuzz_seed(fcd, seed, mode):
         assert got == want, (seed, N, B, T1, T2, beam, thr, collapse, kind)
 
 
+def special_values_case(fcd, seed, mode):
+    """A random banded pair batch with special posteriors injected -- exactly 1, exactly 0, above 1, NaN, in either read --
+    vs the correctly-rounded oracle.  (NaN is where the ORDER of LogSpace::add's operands shows: max mode keeps one only
+    as the first operand, so the merge of a node's candidates must fold in the reference's order.)"""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(3, 7))
+    B = int(rng.integers(1, 4))
+    T1, T2 = int(rng.integers(20, 90)), int(rng.integers(20, 90))
+    beam = int(rng.choice([1, 3, 5, 9]))
+    thr = float(rng.choice([0.0, 0.05, 0.15]))
+    collapse = bool(rng.integers(0, 2))
+    x1, x2 = pairs(seed, B, T1, T2, N)
+    for x in (x1, x2):
+        for _ in range(int(rng.integers(1, 6))):
+            b, t = int(rng.integers(0, B)), int(rng.integers(0, x.shape[1]))
+            kind = int(rng.integers(0, 4))
+            c = int(rng.integers(0, N))
+            if kind == 0:
+                x[b, t, :] = 0.0
+                x[b, t, c] = 1.0
+            elif kind == 1:
+                x[b, t, c] = 0.0
+            elif kind == 2:
+                x[b, t, c] = 1.0 + float(rng.random())
+            else:
+                x[b, t, c] = np.nan
+    w = int(rng.integers(6, 40))
+    envs = np.stack([band(T1, T2, w)] * B)
+    alpha = "N" + "ACGTUV"[:N - 1]
+    want = oracle_strings(x1, x2, alpha, envs, beam, thr, collapse, mode | CR)
+    got = gpu_strings(fcd, x1, x2, alpha, envs, beam, thr, collapse, mode)
+    return got == want
+
+
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_special_values_fuzz(fcd, mode):
+    # (100369, 101027: cases the first soak of tools/duplex_soak.py found -- a NaN repeat-stay merged into the blank item)
+    for seed in list(range(7000, 7024)) + [100369, 101027, 101074, 101121]:
+        assert special_values_case(fcd, seed, mode), (seed, mode)
+
+
 @pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
 def test_duplex_fuzz(fcd, mode):
     for seed in range(5000, 5016):
