@@ -1,0 +1,88 @@
+"""Randomised differential soak of the 1-D searches (beam_search on every kernel selection, crf_beam_search,
+viterbi_search, crf_greedy_search) against the oracle, on the GPU, with special posteriors injected:
+
+    python tools/beam_soak.py [first_seed] [n_seeds]
+
+tests/test_gpu_parity.py's fuzz draws (random shapes, beams, thresholds, ragged lengths, quantised ties) with a few
+entries overwritten by NaN, +inf, values above 1, exact zeros and negative numbers.  Prints cases / mismatches."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+import fast_ctc_decode_amd as fcd
+import test_gpu_parity as P
+
+
+def inject(rng, x):
+    n = int(rng.integers(0, 5))
+    for _ in range(n):
+        idx = tuple(int(rng.integers(0, s)) for s in x.shape)
+        kind = int(rng.integers(0, 5))
+        x[idx] = [np.nan, np.inf, 1.0 + float(rng.random()), 0.0, -0.25][kind]
+    return x
+
+
+def main():
+    first = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
+    n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
+    cases = bad = 0
+    for seed in range(first, first + n):
+        x, beam, thr, collapse, lengths = P._fuzz_case(seed)
+        rng = np.random.default_rng(seed + 7)
+        x = inject(rng, x)
+        for kernel in (0, 1, 2, 3, 4):
+            cases += 1
+            try:
+                P.check_beam(fcd, x, beam, thr, collapse, lengths=lengths, kernel=kernel)
+            except RuntimeError as e:  # a forced kernel that does not cover the shape says so
+                if not (kernel in (2, 3, 4) and " kernel: " in str(e)):
+                    bad += 1
+                    print("ERROR beam", seed, kernel, str(e)[:160], flush=True)
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH beam", seed, kernel, beam, thr, collapse, str(e)[:160], flush=True)
+        # viterbi (+ quality values) on the same reads
+        cases += 1
+        try:
+            r = fcd.viterbi_search_batch_raw(x, collapse, lengths=lengths, qual=True)
+            for i in range(x.shape[0]):
+                Ti = x.shape[1] if lengths is None else int(lengths[i])
+                if Ti == 0:
+                    assert int(r.out_len[i]) == 0
+                    continue
+                labels, path, quals = P.oracle.viterbi_search_raw(np.ascontiguousarray(x[i, :Ti]), collapse)
+                m = int(r.out_len[i])
+                assert m == len(labels) and np.array_equal(r.labels[i, :m], labels) and np.array_equal(r.path[i, :m], path)
+                got = [P.oracle.lib.fcdo_phred(float(q), 1.0, 0.0) for q in r.qual[i, :m]]
+                assert [ord(c) for c in got] == list(quals)
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH viterbi", seed, str(e)[:160], flush=True)
+        # CRF searches: S states x N symbols out of the same generator
+        S = int(rng.choice([4, 16]))
+        T, B = int(rng.integers(1, 90)), int(rng.integers(1, 4))
+        xc = inject(rng, rng.random((B, T, S, 5), dtype=np.float32))
+        init = rng.random((B, S), dtype=np.float32)
+        for kernel in (0, 1):
+            cases += 1
+            try:
+                r = fcd.crf_beam_search_batch_raw(xc, init, beam, thr, kernel=kernel)
+                for i in range(B):
+                    st, labels, path, _ = P.oracle.crf_beam_search_ambiguous(xc[i], init[i], beam, thr)
+                    assert int(r.status[i]) == st, (i, int(r.status[i]), st)
+                    if st == 0:
+                        m = int(r.out_len[i])
+                        assert m == len(labels) and np.array_equal(r.labels[i, :m], labels) and \
+                            np.array_equal(r.path[i, :m], path)
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH crf", seed, kernel, S, beam, thr, str(e)[:160], flush=True)
+    print("beam soak: seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
