@@ -1135,6 +1135,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                     fetch();
                     float lab3 = kNegInf, sum3 = kNegInf;  // row - 1 of the coming group, valid in lane 3
                     const bool is0 = qd == 0, is1 = qd == 1, is2 = qd == 2;
+                    bool exact_from_here = false;  // (wave-uniform)
                     auto rot = [](float v) {  // lane q <- lane q - 1 (mod 4)
                         return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x93 /* quad_perm [3,0,1,2] */, 0xf,
                                                                           0xf, true));
@@ -1148,10 +1149,10 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         s3 = s3 + 12 >= W3 ? s3 + 12 - W3 : s3 + 12;
                         sx = sx + 12 >= W3 ? sx + 12 - W3 : sx + 12;
                         if (j + 4 < W) fetch();
-                        // (the incoming chain state counts as an operand: after a group that took the exact form it may be
-                        // a NaN or a zero, and v_max_f32 would drop the NaN that LogSpace::add carries along)
-                        const bool special = (mine && (!(cl < 0.0f) | !(c0 < 0.0f) | !(cx < 0.0f))) ||
-                                             (work && qd == 3 && (!(lab3 < 0.0f) | !(sum3 < 0.0f)));
+                        // (the incoming chain state counts as an operand too -- after a group that took the exact form it
+                        // may be a NaN or a zero, and v_max_f32 would drop the NaN that LogSpace::add carries along -- so
+                        // once a group has failed the check, every later group of this pass takes the exact form as well)
+                        const bool special = mine && (!(cl < 0.0f) | !(c0 < 0.0f) | !(cx < 0.0f));
                         float lab0, lab1, lab2, g0, g1, g2, g3, sum0, sum1, sum2;
                         const float lab_in = lab3, sum_in = sum3;
                         lab0 = cl + vmax_raw(rot(lab_in), cx);
@@ -1166,7 +1167,8 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                         lab3 = cl + vmax_raw(rot(lab2), cx);
                         g3 = rot(sum2) + c0;
                         sum3 = vmax_raw(lab3, g3);
-                        if (ballot(special) != 0ull) {  // rare: the same four steps on LogSpace::add itself
+                        exact_from_here = exact_from_here || ballot(special) != 0ull;
+                        if (exact_from_here) {  // rare: the same four steps on LogSpace::add itself
                             lab0 = cl + ladd<MODE>(rot(lab_in), cx);
                             g0 = rot(sum_in) + c0;
                             sum0 = ladd<MODE>(lab0, g0);
