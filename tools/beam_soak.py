@@ -44,6 +44,31 @@ def main():
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH beam", seed, kernel, beam, thr, collapse, str(e)[:160], flush=True)
+        # wide beams (the lane-per-entry kernel, one or two reads per wavefront) and wide alphabets (the LDS kernel)
+        rng2 = np.random.default_rng(seed + 13)
+        Nw = int(rng2.integers(2, 13))
+        beam_w = int(rng2.choice([17, 24, 32, 33, 48, 64]))
+        Tw, Bw = int(rng2.integers(1, 260)), int(rng2.integers(1, 5))
+        style = int(rng2.integers(0, 3))
+        if style == 0:
+            xw = P.reference_style_rows(rng2, Bw * Tw, Nw).reshape(Bw, Tw, Nw)
+        elif style == 1:
+            xw = (rng2.integers(0, 4, size=(Bw, Tw, Nw)) / 4.0).astype(np.float32)
+        else:
+            xw = np.ldexp(1.0, -rng2.integers(0, 5, size=(Bw, Tw, Nw))).astype(np.float32)
+        xw = inject(rng2, np.ascontiguousarray(xw, np.float32))
+        thr_w = float(rng2.choice([0.0, 0.02, 0.1]))
+        for kernel in (0, 1, 4):
+            cases += 1
+            try:
+                P.check_beam(fcd, xw, beam_w, thr_w, bool(rng2.integers(0, 2)), kernel=kernel)
+            except RuntimeError as e:
+                if not (kernel == 4 and " kernel: " in str(e)):
+                    bad += 1
+                    print("ERROR wide", seed, kernel, str(e)[:160], flush=True)
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH wide", seed, kernel, Nw, beam_w, thr_w, str(e)[:160], flush=True)
         # viterbi (+ quality values) on the same reads
         cases += 1
         try:
