@@ -44,6 +44,22 @@ def main():
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH beam", seed, kernel, beam, thr, collapse, str(e)[:160], flush=True)
+        # the same reads held as float16 / bfloat16-representable values: the kernels convert on load (fcd_batch.dtype)
+        xh = x.astype(np.float16)
+        cases += 1
+        try:
+            r = fcd.beam_search_batch_raw(xh, beam, thr, collapse, lengths=lengths)
+            up = xh.astype(np.float32)
+            for i in range(x.shape[0]):
+                xi = up[i] if lengths is None else up[i, :lengths[i]]
+                st, labels, path, _ = P.oracle.beam_search_raw(np.ascontiguousarray(xi), beam, thr, collapse)
+                assert int(r.status[i]) == st
+                if st == 0:
+                    m = int(r.out_len[i])
+                    assert m == len(labels) and np.array_equal(r.labels[i, :m], labels) and np.array_equal(r.path[i, :m], path)
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH float16", seed, beam, thr, str(e)[:160], flush=True)
         # wide beams (the lane-per-entry kernel, one or two reads per wavefront) and wide alphabets (the LDS kernel)
         rng2 = np.random.default_rng(seed + 13)
         Nw = int(rng2.integers(2, 13))
