@@ -16,7 +16,47 @@ import fast_ctc_decode_amd as fcd
 import test_gpu_duplex as D
 
 
+def long_case(seed, mode):
+    """Long reads inside a band (stale windows re-entering the beam, catch-up of several rows, discards, wobble)."""
+    rng = np.random.default_rng(seed)
+    N = 5
+    B = 2
+    T1 = int(rng.integers(300, 700))
+    T2 = int(T1 * (0.9 + 0.2 * rng.random()))
+    beam = int(rng.choice([3, 5, 8]))
+    thr = float(rng.choice([0.0, 0.05, 0.1]))
+    x1, x2 = D.pairs(seed, B, T1, T2, N)
+    w = int(rng.integers(16, 65))
+    env = D.band(T1, T2, w).astype(np.int64)
+    if rng.integers(0, 2):  # a wobbly band: monotone bounds that move by 0..3 rows per step
+        lo = np.minimum.accumulate(env[::-1, 0])[::-1]
+        hi = np.maximum.accumulate(env[:, 1])
+        jitter = rng.integers(0, 3, size=T1)
+        hi = np.minimum(T2, np.maximum.accumulate(hi + jitter))
+        env = np.stack([lo, hi], 1)
+    envs = np.stack([env.astype(np.uint64)] * B)
+    if rng.integers(0, 3) == 0:
+        b, t, c = int(rng.integers(0, B)), int(rng.integers(0, T2)), int(rng.integers(0, N))
+        x2[b, t, c] = [np.nan, 0.0, 1.0, 1.5][int(rng.integers(0, 4))]
+    want = D.oracle_strings(x1, x2, "NACGT", envs, beam, thr, True, mode | D.CR)
+    got = D.gpu_strings(fcd, x1, x2, "NACGT", envs, beam, thr, True, mode)
+    return got == want
+
+
 def main():
+    if "--long" in sys.argv:
+        sys.argv.remove("--long")
+        first = int(sys.argv[1]) if len(sys.argv) > 1 else 900000
+        n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
+        cases = bad = 0
+        for seed in range(first, first + n):
+            for mode in (D.LSE, D.MAX):
+                cases += 1
+                if not long_case(seed, mode):
+                    bad += 1
+                    print("MISMATCH long", seed, mode, flush=True)
+        print("duplex soak (long reads): seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
+        return 1 if bad else 0
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     cases = bad = 0
