@@ -330,6 +330,124 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void viterbi_stream_kernel(Bat
     scan_finish(st, r, qual, out);
 }
 
+// Time-major storage: element (read r, row t, column c) at post[t * stride_t + r * N + c] -- the (T, B, N) tensor a
+// basecaller network emits, handed over as a (B, T, N) batch by its strides, no transposition.  A row of one read is
+// N elements, but a row of EIGHT neighbouring reads is 8 * N contiguous elements: a workgroup of four wavefronts takes
+// 8 reads, pulls 64-row tiles of them with 16-byte loads (each time step of the group is one contiguous run), parks the
+// tile in LDS as [step][read][column] with a pitch of 8 * N + 1 words -- so that the row-per-lane read back, lanes one
+// time step apart, hits all banks -- and every wavefront scans two of the reads exactly as the read-major kernel does.
+constexpr int kTmReads = 8;
+constexpr int kTmSteps = 64;
+
+template <int N, int DT>
+__global__ __launch_bounds__(256) void viterbi_tm_kernel(BatchDesc in, int collapse, ResultDesc out) {
+    constexpr int EPL = DT == kF32 ? 4 : 8;      // elements per 16-byte load
+    constexpr int ESZ = DT == kF32 ? 4 : 2;
+    constexpr int G = kTmReads * N;               // elements of one time step of the group (a whole number of 16-byte units)
+    constexpr int U = G / EPL;                    // 16-byte units per time step
+    constexpr int UNITS = kTmSteps * U;           // per tile
+    constexpr int NLD = (UNITS + 255) / 256;      // loads per thread and tile
+    constexpr int PITCH = G + 1;
+    __shared__ float s_tile[kTmSteps * PITCH];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int64_t r0 = (int64_t)blockIdx.x * kTmReads;  // (the launch covers whole groups only)
+    const int64_t T = in.T;
+    const char *base = reinterpret_cast<const char *>(in.post) + r0 * in.stride_read * ESZ;
+    const int64_t pitch_b = in.stride_t * ESZ;
+
+    auto fetch = [&](int64_t t0, uint4 (&v)[NLD]) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int u = tid + 256 * m;
+            const int sidx = u / U, o = u - sidx * U;
+            v[m] = make_uint4(0u, 0u, 0u, 0u);
+            if (u < UNITS && t0 + sidx < T)
+                v[m] = *reinterpret_cast<const uint4 *>(base + (t0 + sidx) * pitch_b + o * 16);
+        }
+    };
+    auto park = [&](const uint4 (&v)[NLD]) {
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) {
+            const int u = tid + 256 * m;
+            if (u >= UNITS) continue;
+            const int sidx = u / U, o = u - sidx * U;
+            float *dst = s_tile + sidx * PITCH + o * EPL;  // (the odd pitch leaves only 4-byte alignment)
+            const uint32_t w[4] = {v[m].x, v[m].y, v[m].z, v[m].w};
+            if (DT == kF32) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) dst[e] = __uint_as_float(w[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const uint16_t h = (uint16_t)(w[e >> 1] >> (16 * (e & 1)));
+                    dst[e] = DT == kF16 ? f16_bits_to_f32(h) : bf16_bits_to_f32(h);
+                }
+            }
+        }
+    };
+
+    constexpr int RPW = kTmReads / 4;  // reads per wavefront
+    ScanState st[RPW];
+    int64_t Tr[RPW];
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int64_t r = r0 + wave * RPW + i;
+        int64_t t = T;
+        if (in.lengths) {
+            const int64_t tl = in.lengths[r];
+            t = tl < 0 ? 0 : (tl < T ? tl : T);
+        }
+        Tr[i] = t;
+    }
+    uint4 cur[NLD], nxt[NLD];
+    if (T > 0) fetch(0, cur);
+    for (int64_t t0 = 0; t0 < T; t0 += kTmSteps) {
+        if (t0 + kTmSteps < T) fetch(t0 + kTmSteps, nxt);
+        park(cur);
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < RPW; ++i) {
+            if (t0 >= Tr[i]) continue;  // (wave-uniform)
+            const int rr = wave * RPW + i;
+            const int64_t r = r0 + rr;
+            const float *pr = s_tile + lane * PITCH + rr * N;
+            float prob = pr[0];
+            int label = 0;
+#pragma unroll
+            for (int j = 1; j < N; ++j) {  // find_max: strict '>' keeps the first maximum
+                const float v = pr[j];
+                if (v > prob) {
+                    prob = v;
+                    label = j;
+                }
+            }
+            uint8_t *lab = out.labels + r * out.out_stride;
+            uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
+            float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
+            if (!qual && t0 + kTmSteps <= Tr[i]) {
+                scan_subtile_full(st[i], label, (uint32_t)t0 + (uint32_t)lane, collapse, lab, pth);
+            } else {
+                const bool act = t0 + lane < Tr[i];
+                if (!act) {
+                    label = 0;
+                    prob = 0.0f;
+                }
+                scan_subtile(st[i], label, prob, act, t0, Tr[i], collapse, lab, pth, qual);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < NLD; ++m) cur[m] = nxt[m];
+    }
+#pragma unroll
+    for (int i = 0; i < RPW; ++i) {
+        const int64_t r = r0 + wave * RPW + i;
+        scan_finish(st[i], r, out.qual ? out.qual + r * out.out_stride : nullptr, out);
+    }
+}
+
 // crf_greedy_search (:385-423): the state walk is a serial dependency; one wave per read,
 // lanes 0..N-1 hold the current state's row and reduce it with a first-maximum argmax.
 __global__ __launch_bounds__(64) void crf_greedy_kernel(BatchDesc in, const float *init_all,
@@ -643,6 +761,44 @@ hipError_t launch_viterbi(const BatchDesc &in, int collapse, const ResultDesc &o
     // 16-byte loads: every read must start on a 16-byte boundary (4 f32 / 8 half elements)
     const bool stream_ok = in.stride_n == 1 && in.stride_t == in.N && (in.stride_read % (in.dtype == kF32 ? 4 : 8)) == 0 &&
                            (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
+    // time-major storage ((T, B, N) seen as a batch): neighbouring reads are N elements apart
+    const int64_t esz = in.dtype == kF32 ? 4 : 2;
+    const bool tm_ok = in.stride_n == 1 && in.stride_read == in.N && in.N >= 2 && in.N <= 8 && in.n_reads >= kTmReads &&
+                       in.stride_t >= in.n_reads * in.N && (in.stride_t * esz) % 16 == 0 &&
+                       (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
+    if (tm_ok) {
+        const int64_t groups = in.n_reads / kTmReads, done = groups * kTmReads;
+        switch (in.N) {
+#define FCD_VTM(NN)                                                                                                 \
+    case NN:                                                                                                        \
+        if (in.dtype == kF32)                                                                                       \
+            hipLaunchKernelGGL((viterbi_tm_kernel<NN, kF32>), dim3((unsigned)groups), dim3(256), 0, stream, in, collapse, out);  \
+        else if (in.dtype == kF16)                                                                                  \
+            hipLaunchKernelGGL((viterbi_tm_kernel<NN, kF16>), dim3((unsigned)groups), dim3(256), 0, stream, in, collapse, out);  \
+        else                                                                                                        \
+            hipLaunchKernelGGL((viterbi_tm_kernel<NN, kBF16>), dim3((unsigned)groups), dim3(256), 0, stream, in, collapse, out); \
+        break;
+            FCD_VTM(2) FCD_VTM(3) FCD_VTM(4) FCD_VTM(5) FCD_VTM(6) FCD_VTM(7) FCD_VTM(8)
+#undef FCD_VTM
+            default: break;
+        }
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess || done == in.n_reads) return e;
+        // the last n_reads mod 8 reads: the strided kernel on the tail of the batch
+        BatchDesc in2 = in;
+        in2.post = reinterpret_cast<const float *>(reinterpret_cast<const char *>(in.post) + done * in.stride_read * esz);
+        in2.lengths = in.lengths ? in.lengths + done : nullptr;
+        in2.n_reads = in.n_reads - done;
+        ResultDesc out2 = out;
+        out2.labels = out.labels + done * out.out_stride;
+        out2.path = out.path ? out.path + done * out.out_stride : nullptr;
+        out2.qual = out.qual ? out.qual + done * out.out_stride : nullptr;
+        out2.out_len = out.out_len + done;
+        out2.status = out.status ? out.status + done : nullptr;
+        const unsigned blocks2 = (unsigned)((in2.n_reads + kWavesPerBlock - 1) / kWavesPerBlock);
+        hipLaunchKernelGGL(viterbi_kernel, dim3(blocks2), block, 0, stream, in2, collapse, out2);
+        return hipGetLastError();
+    }
     if (stream_ok) {
         switch (in.N) {
 #define FCD_VSTREAM(NN)                                                                                         \

@@ -659,6 +659,40 @@ def test_viterbi_fuzz(fcd):
         viterbi_fuzz_seed(fcd, seed)
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.float16])
+def test_viterbi_time_major_storage(fcd, dtype):
+    """(T, B, N) storage -- what a basecaller network emits -- handed over as a (B, T, N) batch by its strides: the
+    time-major kernel (8 reads per workgroup; the last B mod 8 reads on the strided kernel), ragged lengths, with and
+    without quality values, vs the oracle on every read."""
+    rng = np.random.default_rng(91)
+    for B, T, N in ((37, 200, 5), (16, 64, 5), (48, 131, 3), (20, 65, 8)):
+        xt = (rng.integers(0, 5, size=(T, B, N)) / 4.0).astype(np.float32)     # quantised: argmax ties
+        xt[:, 1] = reference_style_rows(rng, T, N)
+        xt[T // 2, 2, :] = np.nan
+        xt = xt.astype(dtype)
+        view = xt.transpose(1, 0, 2)                                            # (B, T, N), no copy
+        assert not view.flags["C_CONTIGUOUS"]
+        up = np.ascontiguousarray(view).astype(np.float32)
+        lengths = rng.integers(0, T + 1, size=B).astype(np.int64)
+        lengths[:3] = (T, T, T - 1)
+        for collapse in (True, False):
+            for lens, qual in ((None, False), (lengths, False), (lengths, True)):
+                r = fcd.viterbi_search_batch_raw(view, collapse, lengths=lens, qual=qual)
+                for i in range(B):
+                    Ti = T if lens is None else int(lens[i])
+                    n = int(r.out_len[i])
+                    if Ti == 0:
+                        assert n == 0
+                        continue
+                    labels, path, quals = oracle.viterbi_search_raw(np.ascontiguousarray(up[i, :Ti]), collapse)
+                    assert n == len(labels), (B, T, N, collapse, i)
+                    np.testing.assert_array_equal(r.labels[i, :n], labels)
+                    np.testing.assert_array_equal(r.path[i, :n], path)
+                    if qual:
+                        got = [oracle.lib.fcdo_phred(float(q), 1.0, 0.0) for q in r.qual[i, :n]]
+                        assert [ord(c) for c in got] == list(quals)
+
+
 def test_viterbi_whole_tiles_without_quality(fcd):
     """The streaming kernel's whole-tile path (256-row tiles, no quality values: labels through a DPP wave shift):
     lengths on both sides of every tile and sub-tile boundary, runs and blank stretches crossing them, argmax ties,

@@ -102,6 +102,33 @@ def main():
         except AssertionError as e:
             bad += 1
             print("MISMATCH viterbi", seed, str(e)[:160], flush=True)
+        # time-major storage, (T, B, N) seen as a batch by its strides: the time-major viterbi kernel (groups of 8 reads)
+        rng3 = np.random.default_rng(seed + 29)
+        Bt, Tt, Nt = int(rng3.integers(8, 41)), int(rng3.integers(1, 200)), int(rng3.integers(2, 9))
+        xt = inject(rng3, (rng3.integers(0, 5, size=(Tt, Bt, Nt)) / 4.0).astype(np.float32))
+        if rng3.integers(0, 2):
+            xt = xt.astype(np.float16)
+        view = xt.transpose(1, 0, 2)
+        lens_t = rng3.integers(0, Tt + 1, size=Bt).astype(np.int64) if rng3.integers(0, 2) else None
+        want_q = bool(rng3.integers(0, 2))
+        cases += 1
+        try:
+            r = fcd.viterbi_search_batch_raw(view, collapse, lengths=lens_t, qual=want_q)
+            up = np.ascontiguousarray(view).astype(np.float32)
+            for i in range(Bt):
+                Ti = Tt if lens_t is None else int(lens_t[i])
+                if Ti == 0:
+                    assert int(r.out_len[i]) == 0
+                    continue
+                labels, path, quals = P.oracle.viterbi_search_raw(np.ascontiguousarray(up[i, :Ti]), collapse)
+                m = int(r.out_len[i])
+                assert m == len(labels) and np.array_equal(r.labels[i, :m], labels) and np.array_equal(r.path[i, :m], path)
+                if want_q:
+                    got = [P.oracle.lib.fcdo_phred(float(q), 1.0, 0.0) for q in r.qual[i, :m]]
+                    assert [ord(c) for c in got] == list(quals)
+        except AssertionError as e:
+            bad += 1
+            print("MISMATCH viterbi time-major", seed, Bt, Tt, Nt, str(e)[:160], flush=True)
         # CRF searches: S states x N symbols out of the same generator
         S = int(rng.choice([4, 16]))
         T, B = int(rng.integers(1, 90)), int(rng.integers(1, 4))
