@@ -191,9 +191,12 @@ def e2e_leg(fcd, cfg, x_host, init_host, ref_result, reps=3):
 
     out = {"unit": "reads/s", "reads": B, "input": "host numpy float32 (pageable), one (B,T,N) array"}
     call("array")  # lanes, arenas and page-locked buffers are allocated by the first job
+    res = None
     for mode in ("array", "list"):
         best = None
         for _ in range(reps):
+            res = None  # (the previous result is torn down OUTSIDE the timed call: 8 million reference-count decrements
+            #              for list paths -- the caller pays them whenever it lets go of a result, not per call)
             t0 = time.perf_counter()
             res = call(mode)
             dt = time.perf_counter() - t0

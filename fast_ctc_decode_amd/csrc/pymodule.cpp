@@ -609,6 +609,15 @@ struct IntTable {
     ~IntTable() {
         for (PyObject *o : v) Py_XDECREF(o);
     }
+    // every int below n exists afterwards: list paths are filled from v.data() without further checks
+    void fill_below(size_t n) {
+        if (n > v.size()) v.resize(n, nullptr);
+        for (size_t i = 0; i < n; ++i)
+            if (!v[i]) {
+                v[i] = PyLong_FromSize_t(i);
+                if (!v[i]) throw py::error_already_set();
+            }
+    }
     PyObject *get(size_t i) {
         if (i >= v.size()) v.resize(std::max(i + 1, v.size() * 2), nullptr);
         PyObject *&o = v[i];
@@ -625,7 +634,74 @@ struct BatchCall {
     bool qstring = false;
     float qscale = 1.0f, qbias = 0.0f;
     bool reverse_chars_join = false;  // the CRF beam search joins leaf -> root and reverses CHARACTERS
+    int64_t T = 0;                    // rows per read: every path entry is a row index below it
 };
+
+// list[int] paths of one chunk.  The lists exist (created under the GIL, items NULL); their item arrays are plain memory,
+// so a few threads fill them with pointers out of the shared int table -- every path entry is a row index below T, ints
+// are immutable, so one object per index serves every list -- counting per thread how often each index was used; the
+// reference counts are then settled in ONE pass over the table (T additions instead of one increment per entry: eight
+// million at config 2).  Nothing in between can raise or touch a Python object.
+struct ListFill {
+    PyObject **items;
+    uint64_t off;
+    size_t len;
+};
+
+void fill_list_paths(const fcd_chunk &ch, const std::vector<ListFill> &fills, IntTable &ints, int64_t T) {
+    if (fills.empty()) return;
+    size_t n_idx = T > 0 ? (size_t)T : 0;
+    if (n_idx == 0 || n_idx > (1u << 24)) {  // no bound known (or an absurd one): find the largest entry first
+        n_idx = 0;
+        for (const ListFill &f : fills)
+            for (size_t k = 0; k < f.len; ++k) {
+                const size_t v = ch.path_bytes == 2 ? static_cast<const uint16_t *>(ch.path)[f.off + k]
+                                                    : static_cast<const uint32_t *>(ch.path)[f.off + k];
+                n_idx = std::max(n_idx, v + 1);
+            }
+    }
+    ints.fill_below(n_idx);
+    PyObject *const *tab = ints.v.data();
+    size_t total = 0;
+    for (const ListFill &f : fills) total += f.len;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (unsigned)std::min<size_t>(std::min(4u, hw), std::max<size_t>(1, total / 200000));
+    std::vector<std::vector<uint32_t>> counts(nt, std::vector<uint32_t>(n_idx, 0u));
+    auto work = [&](unsigned t) {
+        uint32_t *cnt = counts[t].data();
+        for (size_t i = t; i < fills.size(); i += nt) {
+            const ListFill &f = fills[i];
+            if (ch.path_bytes == 2) {
+                const uint16_t *src = static_cast<const uint16_t *>(ch.path) + f.off;
+                for (size_t k = 0; k < f.len; ++k) {
+                    const uint32_t v = src[k] < n_idx ? src[k] : 0u;
+                    f.items[k] = tab[v];
+                    ++cnt[v];
+                }
+            } else {
+                const uint32_t *src = static_cast<const uint32_t *>(ch.path) + f.off;
+                for (size_t k = 0; k < f.len; ++k) {
+                    const uint32_t v = src[k] < n_idx ? src[k] : 0u;
+                    f.items[k] = tab[v];
+                    ++cnt[v];
+                }
+            }
+        }
+    };
+    if (nt == 1) {
+        work(0);
+    } else {
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nt; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto &x : th) x.join();
+    }
+    for (size_t i = 0; i < n_idx; ++i) {
+        Py_ssize_t add = 0;
+        for (unsigned t = 0; t < nt; ++t) add += (Py_ssize_t)counts[t][i];
+        if (add) Py_SET_REFCNT(tab[i], Py_REFCNT(tab[i]) + add);
+    }
+}
 
 // Turns one result chunk into Python objects and stores them in result[read_begin ..].
 void emit_chunk(const fcd_chunk &ch, const std::vector<std::string> &alpha, const BatchCall &call, Paths paths,
@@ -652,6 +728,7 @@ void emit_chunk(const fcd_chunk &ch, const std::vector<std::string> &alpha, cons
         }
     }
     std::string buf;
+    std::vector<ListFill> fills;
     for (int64_t i = 0; i < ch.n_reads; ++i) {
         const int64_t r = ch.read_begin + i;
         const int32_t st = ch.status[i];
@@ -693,26 +770,12 @@ void emit_chunk(const fcd_chunk &ch, const std::vector<std::string> &alpha, cons
             py::array_t<uint32_t> view({(py::ssize_t)len}, {(py::ssize_t)4}, ap + off, all_paths);
             pth = view.release().ptr();
         } else {
-            pth = PyList_New((Py_ssize_t)len);
+            pth = PyList_New((Py_ssize_t)len);  // (items NULL: filled below, all reads of the chunk at once)
             if (!pth) {
                 Py_DECREF(seq);
                 throw py::error_already_set();
             }
-            if (ch.path_bytes == 2) {
-                const uint16_t *src = static_cast<const uint16_t *>(ch.path) + off;
-                for (size_t k = 0; k < len; ++k) {
-                    PyObject *o = ints.get(src[k]);
-                    Py_INCREF(o);
-                    PyList_SET_ITEM(pth, (Py_ssize_t)k, o);
-                }
-            } else {
-                const uint32_t *src = static_cast<const uint32_t *>(ch.path) + off;
-                for (size_t k = 0; k < len; ++k) {
-                    PyObject *o = ints.get(src[k]);
-                    Py_INCREF(o);
-                    PyList_SET_ITEM(pth, (Py_ssize_t)k, o);
-                }
-            }
+            if (len) fills.push_back(ListFill{reinterpret_cast<PyListObject *>(pth)->ob_item, off, len});
         }
         PyObject *tup = PyTuple_New(2);
         if (!tup) {
@@ -724,6 +787,7 @@ void emit_chunk(const fcd_chunk &ch, const std::vector<std::string> &alpha, cons
         PyTuple_SET_ITEM(tup, 1, pth);
         PyList_SET_ITEM(result.ptr(), r, tup);
     }
+    fill_list_paths(ch, fills, ints, call.T);
 }
 
 // begin (already done by the caller) -> next / emit ... -> end
@@ -785,6 +849,7 @@ py::list beam_search_batch(const py::object &network_outputs, const py::object &
     }
     check_rc(h, rc);
     BatchCall call{BatchCall::Beam};
+    call.T = in.b.T;
     return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
 }
 
@@ -807,6 +872,7 @@ py::list viterbi_search_batch(const py::object &network_outputs, const py::objec
     }
     check_rc(h, rc);
     BatchCall call{BatchCall::Viterbi};
+    call.T = in.b.T;
     call.qstring = qstring;
     call.qscale = qscale;
     call.qbias = qbias;
@@ -845,6 +911,7 @@ py::list crf_beam_search_batch(const py::object &network_outputs, const py::obje
     }
     check_rc(h, rc);
     BatchCall call{BatchCall::CrfBeam};
+    call.T = in.b.T;
     call.reverse_chars_join = true;
     return run_job(h, jg, in.b.n_reads, alpha, call, paths, raise_on_error);
 }
@@ -870,6 +937,7 @@ py::list crf_greedy_search_batch(const py::object &network_outputs, const py::ob
     }
     check_rc(h, rc);
     BatchCall call{BatchCall::CrfGreedy};
+    call.T = in.b.T;
     call.qstring = qstring;
     call.qscale = qscale;
     call.qbias = qbias;

@@ -312,3 +312,26 @@ def test_compiled_duplex_batch_functions_equal_per_read_calls(fcd):
                 for i in range(B)]
         assert fcd.crf_beam_search_duplex_batch(c1, i1, c2, i2, "NACGT", envs, 5, 0.05, logadd_mode=mode) == want
         assert cm.crf_beam_search_duplex_batch(c1, i1, c2, i2, "NACGT", envs, 5, 0.05, logadd_mode=mode) == want
+
+
+def test_list_paths_reference_counts(fcd):
+    """list[int] paths share ONE int object per row index, their lists are filled by worker threads and the reference
+    counts settled in bulk: the counts must come out exactly as if every entry had been stored with its own
+    Py_INCREF -- the results equal the per-read calls' and dropping them returns the shared ints to their baseline."""
+    import gc
+    import sys
+    cm = _compiled_layer()
+    rng = np.random.default_rng(1)
+    x = rng.random((12, 700, 5), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    res = cm.beam_search_batch(x, "NACGT", 5, 0.1, paths="list")
+    assert res == [fcd.beam_search(x[i], "NACGT", 5, 0.1) for i in range(12)]
+    entries = [v for _, p in res for v in p if v > 256]        # (ints above the interpreter's small-int cache)
+    some = entries[len(entries) // 2]
+    uses = sum(1 for _, p in res for v in p if v is some)
+    assert uses >= 1
+    with_results = sys.getrefcount(some)
+    n_in_entries = sum(1 for v in entries if v is some)
+    del entries, res
+    gc.collect()
+    assert with_results - sys.getrefcount(some) == uses + n_in_entries
