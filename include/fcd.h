@@ -383,7 +383,7 @@ const char *fcd_coalescer_last_error(void);
  *   fcd_job_end        always call: waits for / cancels outstanding work and frees the job.
  * One job at a time per handle; the handle's other entry points may be used again after fcd_job_end.
  * fcd_*_host on large batches (>= 128 reads and >= 16 MB) runs the same pipeline and expands the chunks into the
- * caller's fixed-stride arrays.  Environment: FCD_HOST_LANES (default 4; 1 = no pipelining), FCD_HOST_CHUNK
+ * caller's fixed-stride arrays.  Environment: FCD_HOST_LANES (default 3; 1 = no pipelining), FCD_HOST_CHUNK
  * (reads per chunk; default = the batch split evenly over the lanes, at most 2048). */
 enum { FCD_JOB_PATH = 1, FCD_JOB_QUAL = 2, FCD_JOB_AMBIGUOUS = 4 };
 enum { FCD_JOB_DONE = 1 };
@@ -408,7 +408,7 @@ int fcd_crf_beam_search_host_begin(fcd_handle *h, const fcd_batch *in, const flo
                                    int want, fcd_job **job);
 int fcd_crf_greedy_search_host_begin(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                                      int64_t init_stride, int want, fcd_job **job);
-/* Tuning / tests: lanes (0 = default 4 or FCD_HOST_LANES; 1 = never pipeline), reads per chunk (0 = automatic),
+/* Tuning / tests: lanes (0 = default 3 or FCD_HOST_LANES; 1 = never pipeline), reads per chunk (0 = automatic),
  * and the input size from which fcd_*_host takes the pipeline (-1 = default: >= 128 reads and >= 16 MB). */
 int fcd_set_host_pipeline(fcd_handle *h, int lanes, int64_t chunk_reads, int64_t min_bytes);
 int fcd_job_chunks(const fcd_job *job, int64_t *chunk_reads, int *n_lanes);  /* number of chunks; -1 for NULL */
