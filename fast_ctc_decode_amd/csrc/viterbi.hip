@@ -352,7 +352,13 @@ __global__ __launch_bounds__(256) void viterbi_tm_kernel(BatchDesc in, int colla
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int64_t r0 = (int64_t)blockIdx.x * kTmReads;  // (the launch covers whole groups only)
+    // Neighbouring groups share cache lines (a group's run of 8 * N elements is not a whole number of 128-byte lines),
+    // and consecutive workgroup ids go round the eight XCDs, each with its own L2: hand every XCD a CONTIGUOUS range of
+    // groups, so that a shared line is fetched into one L2, not two.
+    const unsigned n_groups = gridDim.x, per_xcd = (n_groups + 7) / 8;
+    unsigned gidx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+    if (n_groups < 64 || gidx >= n_groups || (n_groups & 7)) gidx = blockIdx.x;  // (small or ragged launches: as they come)
+    const int64_t r0 = (int64_t)gidx * kTmReads;  // (the launch covers whole groups only)
     const int64_t T = in.T;
     const char *base = reinterpret_cast<const char *>(in.post) + r0 * in.stride_read * ESZ;
     const int64_t pitch_b = in.stride_t * ESZ;
