@@ -16,4 +16,4 @@ torch.cuda.synchronize()
 ms,_ = h.timing_mean_ms()
 L = float(r.out_len.float().mean())
 byt = B*(4000*4*5*4 + 5*L)
-print("crf_greedy 4096x4000x4x5: %.3f ms, %.2f TB/s algorithmic (%.0f %% of the 8 TB/s peak), mean labels %.0f" % (ms, byt/ms/1e9, byt/ms/1e9/8000*100, L))
+print("crf_greedy 4096x4000x4x5: %.3f ms, %.2f TB/s algorithmic (%.0f %% of the 8 TB/s peak), mean labels %.0f" % (ms, byt/ms/1e9, byt/ms/1e9/8*100, L))
