@@ -103,6 +103,47 @@ def check_crf_duplex(seed, max_mode):
     return want
 
 
+def inject_specials(rng, *arrays):
+    """A few special posteriors -- NaN, exactly 1 (a row's whole mass), exactly 0, above 1, +inf -- at random places."""
+    for _ in range(int(rng.integers(1, 5))):
+        a = arrays[int(rng.integers(0, len(arrays)))]
+        idx = tuple(int(rng.integers(0, n)) for n in a.shape)
+        kind = int(rng.integers(0, 5))
+        if kind == 0:
+            a[idx] = np.nan
+        elif kind == 1:
+            a[idx[:-1]] = 0.0
+            a[idx] = 1.0
+        elif kind == 2:
+            a[idx] = 0.0
+        elif kind == 3:
+            a[idx] = 1.0 + float(rng.random())
+        else:
+            a[idx] = np.inf
+
+
+def check_duplex_special(seed, max_mode):
+    x1, x2, env, alpha, beam, thr, collapse = duplex_case(seed)
+    inject_specials(np.random.default_rng(seed + 99), x1, x2)
+    mode = oracle.MAXMODE if max_mode else (oracle.LOGSUMEXP | oracle.MATH_CR)
+    want = oracle_outcome(lambda: oracle.beam_search_duplex(x1, x2, alpha, env, beam, thr, collapse, mode))
+    got = naive_outcome(lambda: naive.Duplex(max_mode).beam_search(
+        x1.tolist(), x2.tolist(), alpha, env.tolist(), beam, thr, collapse))
+    assert got == want, (seed, max_mode, got, want)
+    return want
+
+
+def check_crf_duplex_special(seed, max_mode):
+    x1, i1, x2, i2, env, beam, thr = crf_case(seed)
+    inject_specials(np.random.default_rng(seed + 99), x1, x2)
+    mode = oracle.MAXMODE if max_mode else (oracle.LOGSUMEXP | oracle.MATH_CR)
+    want = oracle_outcome(lambda: oracle.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, beam, thr, mode))
+    got = naive_outcome(lambda: naive.Duplex(max_mode).crf_beam_search(
+        x1.tolist(), i1.tolist(), x2.tolist(), i2.tolist(), "NACGT", env.tolist(), beam, thr))
+    assert got == want, (seed, max_mode, got, want)
+    return want
+
+
 def check_crf_1d(seed):
     rng = np.random.default_rng(seed)
     S = int(rng.choice([4, 16]))
@@ -135,3 +176,12 @@ def test_crf_duplex_oracle_equals_the_naive_restatement(max_mode):
 def test_crf_beam_search_oracle_equals_the_naive_restatement():
     outcomes = [check_crf_1d(seed) for seed in range(2000, 2400)]
     assert sum(not (isinstance(o, str) and o.startswith("error")) for o in outcomes) > 250
+
+
+@pytest.mark.parametrize("max_mode", [False, True], ids=["logsumexp", "max"])
+def test_duplex_special_posteriors_oracle_equals_the_naive_restatement(max_mode):
+    """NaN / 1 / 0 / > 1 / +inf posteriors: where the ORDER of LogSpace::add's operands shows (max mode keeps a NaN only as
+    its first operand) -- the oracle, which the GPU soaks are measured against, and the independent restatement agree."""
+    outcomes = [check_duplex_special(seed, max_mode) for seed in range(5000, 5300)]
+    outcomes += [check_crf_duplex_special(seed, max_mode) for seed in range(6000, 6150)]
+    assert sum(not o.startswith("error") for o in outcomes) > 150

@@ -22,7 +22,11 @@ def main():
             ("duplex max", lambda s: X.check_duplex(s, True), 10 ** 6),
             ("crf duplex logsumexp", lambda s: X.check_crf_duplex(s, False), 2 * 10 ** 6),
             ("crf duplex max", lambda s: X.check_crf_duplex(s, True), 2 * 10 ** 6),
-            ("crf_beam_search", X.check_crf_1d, 3 * 10 ** 6)]
+            ("crf_beam_search", X.check_crf_1d, 3 * 10 ** 6),
+            ("duplex logsumexp, special posteriors", lambda s: X.check_duplex_special(s, False), 4 * 10 ** 6),
+            ("duplex max, special posteriors", lambda s: X.check_duplex_special(s, True), 4 * 10 ** 6),
+            ("crf duplex logsumexp, special posteriors", lambda s: X.check_crf_duplex_special(s, False), 5 * 10 ** 6),
+            ("crf duplex max, special posteriors", lambda s: X.check_crf_duplex_special(s, True), 5 * 10 ** 6)]
     for name, fn, base in runs:
         kinds = collections.Counter()
         bad = 0
