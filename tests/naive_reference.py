@@ -1,4 +1,5 @@
-"""A SECOND, deliberately naive restatement of the reference's CRF and duplex searches -- test infrastructure.
+"""A SECOND, deliberately naive restatement of the reference's searches (CRF, duplex; r03: beam_search too) -- test
+infrastructure.
 
 Written from /root/reference/src/search.rs:38-157 (crf_beam_search) and src/duplex.rs:7-834 (LogSpace, ProbPair,
 SecondaryProbs, build / extend / root probs, beam_search, crf_beam_search) WITHOUT consulting oracle/fcd_oracle.c,
@@ -143,6 +144,73 @@ def crf_beam_search(network_output, init_state, alphabet, beam_size, beam_cut_th
         sequence += alphabet[label + 1]
     path.reverse()
     return sequence[::-1], path
+
+
+# ------------------------------------------------------------------------------------------------
+# src/search.rs:159-301  beam_search (the north-star path; added in r03 so that the oracle's behaviour on special
+# posteriors -- NaN, zeros, values above 1 -- has an independent witness as well)
+# ------------------------------------------------------------------------------------------------
+def beam_search(network_output, alphabet, beam_size, beam_cut_threshold, collapse_repeats):
+    """network_output: [T][N] nested lists of binary32 values; -> (sequence, path)"""
+    thr = f32(beam_cut_threshold)
+    alphabet_size = len(alphabet) - 1
+    tree = SuffixTree(alphabet_size)
+    beam = [Point1(ROOT_NODE, 0, 0.0, 1.0)]
+    for idx, pr in enumerate(network_output):
+        next_beam = []
+        for b in beam:
+            tip_label = tree.label(b.node)
+            if pr[0] > thr:
+                next_beam.append(Point1(b.node, b.state, 0.0, f32(f32(b.label_prob + b.gap_prob) * pr[0])))
+            for label in range(alphabet_size):
+                pr_b = pr[label + 1]
+                if pr_b < thr:
+                    continue
+                if collapse_repeats and label == tip_label:
+                    next_beam.append(Point1(b.node, b.state, f32(b.label_prob * pr_b), 0.0))
+                    new_node = tree.get_child(b.node, label)
+                    if new_node is None and b.gap_prob > 0.0:
+                        new_node = tree.add_node(b.node, label, idx)
+                    if new_node is not None:
+                        next_beam.append(Point1(new_node, b.state, f32(b.gap_prob * pr_b), 0.0))
+                else:
+                    new_node = tree.get_child(b.node, label)
+                    if new_node is None:
+                        new_node = tree.add_node(b.node, label, idx)
+                    next_beam.append(Point1(new_node, b.state, f32(f32(b.label_prob + b.gap_prob) * pr_b), 0.0))
+        beam = stable_sort_by_node(next_beam)
+        merged = []
+        for item in beam:
+            if merged and merged[-1].node == item.node:
+                merged[-1].label_prob = f32(merged[-1].label_prob + item.label_prob)
+                merged[-1].gap_prob = f32(merged[-1].gap_prob + item.gap_prob)
+            else:
+                merged.append(item)
+        beam = sort_by_probability_desc(merged, Point1.probability)[:beam_size]
+        if not beam:
+            raise SearchError(RAN_OUT_OF_BEAM)
+        top = beam[0].probability()
+        for x in beam:
+            x.label_prob = f32_div(x.label_prob, top)
+            x.gap_prob = f32_div(x.gap_prob, top)
+    path, tokens = [], []
+    for label, time in tree.iter_from(beam[0].node):
+        path.append(time)
+        tokens.append(alphabet[label + 1])
+    path.reverse()
+    tokens.reverse()
+    return "".join(tokens), path
+
+
+def f32_div(a, b):
+    """binary32 division with IEEE results for a zero or NaN divisor (Python raises on x / 0.0)"""
+    if b != b or a != a:
+        return float("nan")
+    if b == 0.0:
+        if a == 0.0:
+            return float("nan")
+        return math.copysign(float("inf"), a) * math.copysign(1.0, b)
+    return f32(a / b)
 
 
 # ------------------------------------------------------------------------------------------------

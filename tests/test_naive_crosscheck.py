@@ -185,3 +185,39 @@ def test_duplex_special_posteriors_oracle_equals_the_naive_restatement(max_mode)
     outcomes = [check_duplex_special(seed, max_mode) for seed in range(5000, 5300)]
     outcomes += [check_crf_duplex_special(seed, max_mode) for seed in range(6000, 6150)]
     assert sum(not o.startswith("error") for o in outcomes) > 150
+
+
+def check_beam_1d(seed, special):
+    """search::beam_search: the oracle against the naive restatement (sequence AND path), optionally with special
+    posteriors injected"""
+    rng = np.random.default_rng(seed)
+    N = int(rng.integers(2, 8))
+    T = int(rng.integers(1, 120))
+    style = int(rng.integers(0, 3))
+    if style == 0:
+        x = reference_style_rows(rng, T, N)
+    elif style == 1:
+        x = (rng.integers(0, 4, size=(T, N)) / 4.0).astype(np.float32)
+    else:
+        x = rows(rng, T, N, True)
+    if special:
+        inject_specials(np.random.default_rng(seed + 99), x)
+    beam = int(rng.choice([1, 2, 3, 5, 8, 16]))   # (<= 20 candidates per step up to beam 4; above: see DESIGN.md section 2)
+    thr = float(rng.choice([0.0, 0.01, 0.1, 0.3])) * (1.0 / N) / 0.34   # (the wrapper demands thr < 1 / N)
+    thr = min(thr, 0.99 / N)
+    collapse = bool(rng.integers(0, 2))
+    alpha = "NACGTUVW"[:N]
+    want = oracle_outcome(lambda: oracle.beam_search(x, alpha, beam, thr, collapse))
+    got = naive_outcome(lambda: naive.beam_search(x.tolist(), alpha, beam, thr, collapse))
+    if not isinstance(want, str):
+        want = (want[0], [int(v) for v in want[1]])
+    if not isinstance(got, str):
+        got = (got[0], [int(v) for v in got[1]])
+    assert got == want, (seed, special, got, want)
+    return want
+
+
+@pytest.mark.parametrize("special", [False, True], ids=["ordinary", "special-posteriors"])
+def test_beam_search_oracle_equals_the_naive_restatement(special):
+    outcomes = [check_beam_1d(seed, special) for seed in range(7000, 7500)]
+    assert sum(not isinstance(o, str) for o in outcomes) > (100 if special else 300)

@@ -23,6 +23,8 @@ def main():
             ("crf duplex logsumexp", lambda s: X.check_crf_duplex(s, False), 2 * 10 ** 6),
             ("crf duplex max", lambda s: X.check_crf_duplex(s, True), 2 * 10 ** 6),
             ("crf_beam_search", X.check_crf_1d, 3 * 10 ** 6),
+            ("beam_search", lambda s: X.check_beam_1d(s, False), 6 * 10 ** 6),
+            ("beam_search, special posteriors", lambda s: X.check_beam_1d(s, True), 6 * 10 ** 6),
             ("duplex logsumexp, special posteriors", lambda s: X.check_duplex_special(s, False), 4 * 10 ** 6),
             ("duplex max, special posteriors", lambda s: X.check_duplex_special(s, True), 4 * 10 ** 6),
             ("crf duplex logsumexp, special posteriors", lambda s: X.check_crf_duplex_special(s, False), 5 * 10 ** 6),
