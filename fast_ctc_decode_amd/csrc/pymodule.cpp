@@ -699,7 +699,11 @@ void fill_list_paths(const fcd_chunk &ch, const std::vector<ListFill> &fills, In
     for (size_t i = 0; i < n_idx; ++i) {
         Py_ssize_t add = 0;
         for (unsigned t = 0; t < nt; ++t) add += (Py_ssize_t)counts[t][i];
-        if (add) Py_SET_REFCNT(tab[i], Py_REFCNT(tab[i]) + add);
+        if (!add) continue;
+#if PY_VERSION_HEX >= 0x030C0000
+        if (_Py_IsImmortal(tab[i])) continue;  // (3.12+: the small ints are immortal, their count is not to be touched)
+#endif
+        Py_SET_REFCNT(tab[i], Py_REFCNT(tab[i]) + add);
     }
 }
 
