@@ -78,6 +78,9 @@ def test_crf_kernels_and_fuzz(fcd):
 def test_viterbi_and_crf(fcd):
     P.test_viterbi_random(fcd)
     P.test_viterbi_qual_bits(fcd)
+    P.test_viterbi_whole_tiles_without_quality(fcd)
+    P.test_viterbi_time_major_storage(fcd, np.float32)
+    P.test_viterbi_time_major_storage(fcd, np.float16)
     P.test_crf_beam_random(fcd, 5, 0.1)
     P.test_crf_greedy_random(fcd)
 
