@@ -591,15 +591,26 @@ __device__ __forceinline__ uint64_t shfl_up_u64(uint64_t v, int o) {
 
 constexpr int kCrfTileRows = 64;
 
-template <int S>
+// TM: time-major storage, (T, B, S, N) seen as a batch (stride_read = S * N): the four wavefronts of a workgroup take four
+// NEIGHBOURING reads, whose rows of one time step are one contiguous run of 4 * S * N floats; the workgroup pulls 64-step
+// tiles of the four together (coalesced 16-byte loads), parks them as [step][read][S * N] with an odd pitch, and every
+// wavefront scans its read exactly as below.  (viterbi_tm_kernel is the same idea for the plain search.)
+template <int S, bool TM>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
     BatchDesc in, const float *init_all, int64_t n_init, int64_t init_stride, ResultDesc out) {
     extern __shared__ __attribute__((aligned(16))) float s_dyn[];
     const int lane = threadIdx.x & 63;
     // (wave-uniform, and said so: the read's index, its length and every pointer derived from them live in scalar registers)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
-    if (r >= in.n_reads) return;
+    int64_t r = (int64_t)blockIdx.x * kWavesPerBlock + wave;
+    if (TM) {  // every XCD takes a contiguous range of read groups: neighbouring groups share cache lines
+        const unsigned n_groups = gridDim.x, per_xcd = (n_groups + 7) / 8;
+        unsigned gidx = (blockIdx.x & 7) * per_xcd + (blockIdx.x >> 3);
+        if (n_groups < 64 || gidx >= n_groups || (n_groups & 7)) gidx = blockIdx.x;
+        r = (int64_t)gidx * kWavesPerBlock + wave;  // (the launch covers whole groups only: every read exists)
+    } else if (r >= in.n_reads) {
+        return;
+    }
     int64_t T = in.T;
     if (in.lengths) {
         int64_t t = in.lengths[r];
@@ -608,10 +619,14 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
     const int N = in.N, n_base = N - 1;
     const int E = S * N;                      // floats per row
     const int tile_f = kCrfTileRows * E;      // floats per tile
-    const int nload = (tile_f / 4 + 63) / 64; // float4 loads per lane and tile
-    float *tile = s_dyn + (size_t)wave * tile_f;
+    const int nload = TM ? (E + 3) / 4 : (tile_f / 4 + 63) / 64;  // float4 loads per lane and tile
+    const int pitch = TM ? kWavesPerBlock * E + 1 : E;            // floats between consecutive rows of a read in the tile
+    float *tile = TM ? s_dyn + wave * E : s_dyn + (size_t)wave * tile_f;
     const float *post = in.post + r * in.stride_read;
     const int64_t total = T * E;
+    const int64_t T_loop = TM ? in.T : T;     // (TM: the workgroup's tiles cover the longest read of the batch)
+    const int tm_step = (int)(threadIdx.x >> 2), tm_sub = (int)(threadIdx.x & 3);  // TM: four threads per time step
+    const float *tm_base = in.post + (r - wave) * in.stride_read;                  // TM: the group's first read
     uint8_t *lab = out.labels + r * out.out_stride;
     uint32_t *pth = out.path ? out.path + r * out.out_stride : nullptr;
     float *qual = out.qual ? out.qual + r * out.out_stride : nullptr;
@@ -637,6 +652,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
     constexpr int kMaxLoads = 8;  // S * N <= 32 floats per row (the launcher checks)
     float4 cur[kMaxLoads], nxt[kMaxLoads];
     auto fetch = [&](int64_t row0, float4 (&v)[kMaxLoads]) {
+        if (TM) {
+            // thread (step, sub) takes the 16-byte units sub, sub + 4, ... of its time step's run of 4 * E floats
+            const float *src = tm_base + (row0 + tm_step) * in.stride_t;
+#pragma unroll
+            for (int m = 0; m < kMaxLoads; ++m) {
+                if (m >= nload) break;
+                const int o = tm_sub + 4 * m;
+                v[m] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                if (o < E && row0 + tm_step < in.T) v[m] = *reinterpret_cast<const float4 *>(src + o * 4);
+            }
+            return;
+        }
         const int64_t f0 = row0 * E;
 #pragma unroll
         for (int m = 0; m < kMaxLoads; ++m) {
@@ -655,12 +682,27 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
     };
 
     int n_out = 0;
-    if (T > 0) fetch(0, cur);
-    for (int64_t base = 0; base < T; base += kCrfTileRows) {
-        if (base + kCrfTileRows < T) fetch(base + kCrfTileRows, nxt);
+    if (T_loop > 0) fetch(0, cur);
+    for (int64_t base = 0; base < T_loop; base += kCrfTileRows) {
+        if (base + kCrfTileRows < T_loop) fetch(base + kCrfTileRows, nxt);
+        if (TM) {
+#pragma unroll
+            for (int m = 0; m < kMaxLoads; ++m) {
+                if (m >= nload) break;
+                const int o = tm_sub + 4 * m;
+                if (o < E) {
+                    float *dst = s_dyn + tm_step * pitch + o * 4;  // (odd pitch: 4-byte alignment only)
+                    dst[0] = cur[m].x;
+                    dst[1] = cur[m].y;
+                    dst[2] = cur[m].z;
+                    dst[3] = cur[m].w;
+                }
+            }
+            __syncthreads();
+        }
 #pragma unroll
         for (int m = 0; m < kMaxLoads; ++m) {
-            if (m >= nload) break;
+            if (TM || m >= nload) break;
             const int fl = (lane + 64 * m) * 4;
             if (fl + 3 < tile_f) {
                 *reinterpret_cast<float4 *>(tile + fl) = cur[m];
@@ -676,8 +718,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
 
         const int64_t row = base + lane;
         const bool act = row < T;
+        if (!TM || base < T) {  // (TM: a wavefront whose read has ended still takes part in the tile loads)
         // this row, for every state: first-maximum argmax (:405), its probability, NaN anywhere in the row
-        const float *pr = tile + lane * E;
+        const float *pr = tile + lane * pitch;
         float prob_s[S];
         uint32_t labels_packed = 0, nan_mask = 0;
         uint64_t f = 0;
@@ -747,7 +790,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void crf_greedy_stream_kernel(
         }
         n_out += popc64(m_emit);
         state = state_out;
-        __builtin_amdgcn_wave_barrier();
+        }
+        if (TM) __syncthreads();
+        else __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int m = 0; m < kMaxLoads; ++m) cur[m] = nxt[m];
     }
@@ -841,7 +886,7 @@ hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_i
         switch (in.S) {
 #define FCD_GSTREAM(SS)                                                                                   \
     case SS:                                                                                              \
-        hipLaunchKernelGGL(crf_greedy_stream_kernel<SS>, dim3(blocks), dim3(64 * kWavesPerBlock), lds, stream, \
+        hipLaunchKernelGGL((crf_greedy_stream_kernel<SS, false>), dim3(blocks), dim3(64 * kWavesPerBlock), lds, stream, \
                            in, init, n_init, init_stride, out);                                           \
         return hipGetLastError();
             FCD_GSTREAM(1) FCD_GSTREAM(2) FCD_GSTREAM(3) FCD_GSTREAM(4) FCD_GSTREAM(5) FCD_GSTREAM(6)
@@ -850,8 +895,42 @@ hipError_t launch_crf_greedy(const BatchDesc &in, const float *init, int64_t n_i
             default: break;
         }
     }
-    hipLaunchKernelGGL(crf_greedy_kernel, dim3((unsigned)in.n_reads), dim3(64), 0, stream, in, init,
-                       n_init, init_stride, out);
+    // time-major storage ((T, B, S, N) seen as a batch): neighbouring reads are S * N floats apart
+    const bool tm_ok = in.dtype == kF32 && in.S >= 1 && in.S <= 8 && in.N >= 1 && in.N <= 15 && E <= 32 && in.stride_n == 1 &&
+                       in.stride_s == in.N && in.stride_read == E && in.n_reads >= kWavesPerBlock &&
+                       in.stride_t >= in.n_reads * E && (in.stride_t % 4) == 0 &&
+                       (reinterpret_cast<uintptr_t>(in.post) % 16) == 0;
+    int64_t done = 0;
+    if (tm_ok) {
+        const int64_t groups = in.n_reads / kWavesPerBlock;
+        const size_t lds = (size_t)kCrfTileRows * (kWavesPerBlock * E + 1) * sizeof(float);
+        switch (in.S) {
+#define FCD_GTM(SS)                                                                                              \
+    case SS:                                                                                                     \
+        hipLaunchKernelGGL((crf_greedy_stream_kernel<SS, true>), dim3((unsigned)groups), dim3(64 * kWavesPerBlock), lds, \
+                           stream, in, init, n_init, init_stride, out);                                          \
+        done = groups * kWavesPerBlock;                                                                          \
+        break;
+            FCD_GTM(1) FCD_GTM(2) FCD_GTM(3) FCD_GTM(4) FCD_GTM(5) FCD_GTM(6) FCD_GTM(7) FCD_GTM(8)
+#undef FCD_GTM
+            default: break;
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess || done == in.n_reads) return e;
+    }
+    // (everything else, and the last n_reads mod 4 reads of a time-major batch: the serial walk)
+    BatchDesc in2 = in;
+    in2.post = in.post + done * in.stride_read;  // (done > 0 only for float32 input: plain element arithmetic)
+    in2.lengths = in.lengths ? in.lengths + done : nullptr;
+    in2.n_reads = in.n_reads - done;
+    ResultDesc out2 = out;
+    out2.labels = out.labels + done * out.out_stride;
+    out2.path = out.path ? out.path + done * out.out_stride : nullptr;
+    out2.qual = out.qual ? out.qual + done * out.out_stride : nullptr;
+    out2.out_len = out.out_len + done;
+    out2.status = out.status ? out.status + done : nullptr;
+    hipLaunchKernelGGL(crf_greedy_kernel, dim3((unsigned)in2.n_reads), dim3(64), 0, stream, in2, init + done * init_stride,
+                       n_init, init_stride, out2);
     return hipGetLastError();
 }
 

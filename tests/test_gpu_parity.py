@@ -810,6 +810,38 @@ def crf_greedy_fuzz_seed(fcd, seed):
         assert "".join(oracle.phred(float(q)) for q in r.qual[i, :n]) == qs, ctx
 
 
+def test_crf_greedy_time_major_storage(fcd):
+    """(T, B, S, N) storage handed over as a (B, T, S, N) batch by its strides: the time-major instantiation of the
+    streaming kernel (four neighbouring reads per workgroup; the last B mod 4 reads on the serial kernel), ragged lengths,
+    quality values, a NaN and an out-of-range state -- vs the oracle on every read."""
+    rng = np.random.default_rng(93)
+    for B, T, S, N in ((21, 150, 4, 5), (8, 64, 4, 5), (12, 70, 2, 3), (9, 33, 8, 4)):
+        xt = rng.random((T, B, S, N), dtype=np.float32)
+        xt[:, 1] = (rng.integers(0, 4, size=(T, S, N)) / 4.0).astype(np.float32)   # argmax ties
+        xt[T // 2, 2, :, :] = np.nan
+        view = xt.transpose(1, 0, 2, 3)
+        assert not view.flags["C_CONTIGUOUS"]
+        init = rng.random((B, S), dtype=np.float32)
+        lengths = rng.integers(0, T + 1, size=B).astype(np.int64)
+        lengths[:3] = (T, T, T)
+        for lens in (None, lengths):
+            r = fcd.crf_greedy_search_batch_raw(view, init, lengths=lens, qual=True)
+            for i in range(B):
+                Ti = T if lens is None else int(lens[i])
+                xi = np.ascontiguousarray(view[i, :Ti])
+                if Ti == 0:
+                    continue
+                try:
+                    seq, path = oracle.crf_greedy_search(xi, init[i], "NACGTUV"[:N], qstring=False)
+                except RuntimeError:
+                    assert int(r.status[i]) != 0, (B, T, S, N, i)
+                    continue
+                assert int(r.status[i]) == 0, (B, T, S, N, i)
+                n = int(r.out_len[i])
+                assert "".join("NACGTUV"[l] for l in r.labels[i, :n]) == seq
+                np.testing.assert_array_equal(r.path[i, :n], path)
+
+
 def test_crf_greedy_fuzz(fcd):
     for seed in range(7000, 7060):
         crf_greedy_fuzz_seed(fcd, seed)

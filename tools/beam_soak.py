@@ -148,6 +148,34 @@ def main():
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH crf", seed, kernel, S, beam, thr, str(e)[:160], flush=True)
+        # crf_greedy_search, read-major and time-major storage of the same reads (B >= 4: the time-major kernel)
+        rng4 = np.random.default_rng(seed + 41)
+        Sg = int(rng4.choice([2, 4, 8]))
+        Ng = int(rng4.integers(2, 5)) if Sg == 8 else int(rng4.integers(2, 7))
+        Bg, Tg = int(rng4.integers(4, 14)), int(rng4.integers(1, 150))
+        xg = inject(rng4, (rng4.integers(0, 6, size=(Bg, Tg, Sg, Ng)) / 5.0).astype(np.float32) + np.float32(0.01))
+        ig = rng4.random((Bg, Sg), dtype=np.float32)
+        lens_g = rng4.integers(0, Tg + 1, size=Bg).astype(np.int64) if rng4.integers(0, 2) else None
+        tm = np.ascontiguousarray(xg.transpose(1, 0, 2, 3)).transpose(1, 0, 2, 3)
+        for name, arr in (("read-major", xg), ("time-major", tm)):
+            cases += 1
+            try:
+                r = fcd.crf_greedy_search_batch_raw(arr, ig, lengths=lens_g)
+                for i in range(Bg):
+                    Ti = Tg if lens_g is None else int(lens_g[i])
+                    if Ti == 0:
+                        continue
+                    try:
+                        seq, path = P.oracle.crf_greedy_search(np.ascontiguousarray(xg[i, :Ti]), ig[i], "NACGTUV"[:Ng])
+                    except RuntimeError:
+                        assert int(r.status[i]) != 0, (i, "should have failed")
+                        continue
+                    m = int(r.out_len[i])
+                    assert int(r.status[i]) == 0 and "".join("NACGTUV"[l] for l in r.labels[i, :m]) == seq and \
+                        np.array_equal(r.path[i, :m], path), (i, name)
+            except AssertionError as e:
+                bad += 1
+                print("MISMATCH crf_greedy", name, seed, Bg, Tg, Sg, Ng, str(e)[:160], flush=True)
     print("beam soak: seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
     return 1 if bad else 0
 

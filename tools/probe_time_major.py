@@ -51,5 +51,27 @@ def main():
                   % (str(dt).replace("torch.", ""), name, ms_r, ms_t, ms_t / ms_r, same), flush=True)
 
 
+def crf():
+    """CRF scores, (T, B, S, N) time-major storage seen as (B, T, S, N)"""
+    B, T, S, N = 4096, 4000, 4, 5
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    x = torch.rand((B, T, S, N), generator=g, device="cuda", dtype=torch.float32)
+    init = torch.rand((B, S), generator=g, device="cuda")
+    xt = x.permute(1, 0, 2, 3).contiguous()
+    view = xt.permute(1, 0, 2, 3)
+    for name, fn_r, fn_t in (
+            ("crf_beam_search(5, 0.0)", lambda: fcd.crf_beam_search_batch_raw(x, init, 5, 0.0), lambda: fcd.crf_beam_search_batch_raw(view, init, 5, 0.0)),
+            ("crf_greedy_search", lambda: fcd.crf_greedy_search_batch_raw(x, init), lambda: fcd.crf_greedy_search_batch_raw(view, init))):
+        ms_r, rr = timed(fn_r, 3)
+        ms_t, rt = timed(fn_t, 3)
+        a, b = rr.cpu(), rt.cpu()
+        same = bool((a.out_len == b.out_len).all()) and all(
+            (a.labels[i, :int(a.out_len[i])] == b.labels[i, :int(a.out_len[i])]).all() for i in range(0, B, 37))
+        print("float32  %-23s read-major %.3f ms | time-major view %.3f ms (x%.2f) | identical %s"
+              % (name, ms_r, ms_t, ms_t / ms_r, same), flush=True)
+
+
 if __name__ == "__main__":
     main()
+    crf()
