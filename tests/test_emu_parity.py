@@ -83,6 +83,7 @@ def test_viterbi_and_crf(fcd):
     P.test_viterbi_time_major_storage(fcd, np.float16)
     P.test_crf_beam_random(fcd, 5, 0.1)
     P.test_crf_greedy_random(fcd)
+    P.test_crf_greedy_time_major_storage(fcd)
 
 
 def test_duplex(fcd):
