@@ -89,7 +89,12 @@ typedef struct fcd_handle fcd_handle;
  *   1D searches: element (read r, row t, column j)        at base[r*stride_read + t*stride_t + j*stride_n]
  *   CRF searches: element (read r, row t, state s, col j) at base[r*stride_read + t*stride_t + s*stride_s + j*stride_n]
  * lengths (nullable): per-read row count T_r <= T (ragged batches); device pointer for *_dev,
- * host pointer for *_host. */
+ * host pointer for *_host.
+ * Any non-negative strides are accepted.  Two layouts have kernels of their own in the HBM-bound searches
+ * (viterbi_search, crf_greedy_search; 16-byte aligned base): READ-MAJOR, every read a contiguous (T, N) / (T, S, N) block
+ * (stride_n = 1, stride_s = N, stride_t = S*N), and TIME-MAJOR, the (T, B, N) / (T, B, S, N) tensor a basecaller network
+ * emits seen as a batch (stride_read = S*N, stride_t = B*S*N: no transposition needed).  The beam searches fetch one row
+ * per step and read and run at the same speed on either. */
 /* Element type of the posteriors.  Basecaller networks emit half precision; the reference only takes float32
  * (src/lib.rs:182,325: &PyArray<f32>), which costs its callers a host-side upcast.  f16 and bf16 convert to float32
  * EXACTLY, so a search on half-precision input IS the reference's search on the upcast matrix; the kernels convert
