@@ -38,3 +38,14 @@ def test_hostjob_soak_slice():
         import hostjob_soak
         import fast_ctc_decode_amd as fcd
         assert hostjob_soak.run(fcd, 700000, 20) == 0
+
+
+def test_tools_compile():
+    """every developer script under tools/ at least parses (they are not imported by the suite otherwise)"""
+    import glob
+    import py_compile
+    root = os.path.join(os.path.dirname(HERE), "tools")
+    scripts = sorted(glob.glob(os.path.join(root, "*.py")))
+    assert len(scripts) > 15
+    for path in scripts:
+        py_compile.compile(path, doraise=True)
