@@ -135,6 +135,7 @@ def test_chunked_host_path(fcd):
     H.test_compiled_batch_functions_equal_per_read_calls(fcd, 3, 2)
     H.test_compiled_duplex_batch_functions_equal_per_read_calls(fcd)
     H.test_list_paths_reference_counts(fcd)
+    H.test_time_major_host_views_through_the_batch_functions(fcd)
 
 
 def test_half_precision_inputs(fcd):

@@ -335,3 +335,20 @@ def test_list_paths_reference_counts(fcd):
     del entries, res
     gc.collect()
     assert with_results - sys.getrefcount(some) == uses + n_in_entries
+
+
+def test_time_major_host_views_through_the_batch_functions(fcd):
+    """A time-major (T, B, N) score array handed over as `scores.transpose(1, 0, 2)` -- float32 and float16 -- goes
+    through the compiled batch functions without a copy on the Python side and decodes as its contiguous copy does."""
+    cm = _compiled_layer()
+    rng = np.random.default_rng(3)
+    T, B, N = 90, 11, 5
+    xt = rng.random((T, B, N), dtype=np.float32)
+    xt /= np.linalg.norm(xt, axis=-1, keepdims=True)
+    for dt in (np.float32, np.float16):
+        view = xt.astype(dt).transpose(1, 0, 2)
+        assert not view.flags["C_CONTIGUOUS"]
+        want = cm.beam_search_batch(np.ascontiguousarray(view), "NACGT", 5, 0.1)
+        assert cm.beam_search_batch(view, "NACGT", 5, 0.1) == want
+        assert fcd.beam_search_batch(view, "NACGT", 5, 0.1) == want
+        assert cm.viterbi_search_batch(view, "NACGT") == cm.viterbi_search_batch(np.ascontiguousarray(view), "NACGT")
