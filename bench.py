@@ -503,8 +503,9 @@ def main():
         ties = {"reads_with_gt20_candidate_kept_tie": int((amb[:, 0] > 0).sum()),
                 "reads_with_result_changing_tie": int((amb[:, 1] > 0).sum()),
                 "reads_with_both": int(((amb[:, 0] > 0) & (amb[:, 1] > 0)).sum()),
-                "note": "a read with either counter at 0 is pinned to the reference; the others are settled by the "
-                        "oracle's exhaustive tie replay (tests/test_gpu_fullsize.py::test_config2_tie_instrument)"}
+                "note": "a read with either counter at 0 decodes the same under any order of equal probabilities; on "
+                        "the others the kernels follow the restated order of Rust 1.78's sort_unstable_by "
+                        "(FCD_TIE_PDQ178, csrc/pdq178.h; tests/test_gpu_fullsize.py::test_config2_tie_instrument)"}
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
         vit16 = viterbi_roofline(fcd, torch, dev, half=True) if not args.no_viterbi else None
         valu = valu_issue_roofline(prefix, k_ms, simds) if default_shape else None
@@ -542,6 +543,7 @@ def main():
                           {1: "generic-lds", 2: "wave-registers-2reads", 3: "wave-registers-1read", 4: "lane"}[args.kernel],
                 "reads_ok": ok, "mean_labels_per_read": mean_L, "streams": n_streams,
                 "tie_instrument": ties,
+                "tie_order": fcd.tie_order(),  # include/fcd.h FCD_TIE_*: pdq178 = Rust 1.78's sort_unstable_by (default)
             },
             "roofline": {
                 "bound": "hbm",

@@ -17,6 +17,8 @@ from .api import (  # noqa: F401
     beam_search_duplex_batch,
     beam_search_duplex_batch_raw,
     set_duplex_logadd_mode,
+    set_tie_order,
+    tie_order,
     set_coalescing,
     coalescing_stats,
     crf_beam_search,
@@ -36,4 +38,5 @@ from .api import (  # noqa: F401
 )
 from ._native import (  # noqa: F401
     KERNEL_AUTO, KERNEL_GENERIC, KERNEL_LANE, KERNEL_WAVE, KERNEL_WAVE1, LOGADD_LOGSUMEXP, LOGADD_MAX,
+    TIE_DEFAULT, TIE_PDQ178, TIE_STABLE, default_tie_order, set_default_tie_order,
 )

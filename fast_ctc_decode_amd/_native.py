@@ -17,12 +17,14 @@ ST_OK, ST_RAN_OUT_OF_BEAM, ST_INCOMPARABLE, ST_INVALID_ENVELOPE, ST_BAD_STATE, S
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE1, KERNEL_LANE = 0, 1, 2, 3, 4
 LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
+TIE_DEFAULT, TIE_PDQ178, TIE_STABLE = -1, 0, 1
 
 # every symbol include/fcd.h declares (tests/test_capi_symbols.py checks the .so against this
 # list AND against the header text)
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
+    "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
@@ -119,6 +121,10 @@ def bind(lib):
     lib.fcd_status_string.restype = C.c_char_p
     lib.fcd_set_workspace_limit.argtypes = [P, i64]
     lib.fcd_release_workspace.argtypes = [P]
+    lib.fcd_set_tie_order.argtypes = [P, i32]
+    lib.fcd_get_tie_order.argtypes = [P]
+    lib.fcd_set_default_tie_order.argtypes = [i32]
+    lib.fcd_debug_pdq178_sort_dev.argtypes = [P, P, i64, i64, P]
     lib.fcd_debug_set_first_pass_divisor.argtypes = [P, i32]
     lib.fcd_debug_set_duplex_profile.argtypes = [P, P]
     lib.fcd_last_kernel_ms.argtypes = [P]
@@ -224,6 +230,13 @@ class Handle:
         """Tuning of the chunked host path (include/fcd.h: fcd_set_host_pipeline)."""
         self.check(self.lib.fcd_set_host_pipeline(self.ptr, int(lanes), int(chunk_reads), int(min_bytes)))
 
+    def set_tie_order(self, order):
+        """TIE_PDQ178 / TIE_STABLE for this handle, TIE_DEFAULT to follow the process default (include/fcd.h)."""
+        self.check(self.lib.fcd_set_tie_order(self.ptr, int(order)))
+
+    def tie_order(self):
+        return int(self.lib.fcd_get_tie_order(self.ptr))
+
     def release_workspace(self):
         """Give the tree arena / staging memory back to the device (the next call allocates afresh)."""
         self.check(self.lib.fcd_release_workspace(self.ptr))
@@ -300,6 +313,21 @@ def default_handle(device=0):
     if h is None:
         h = cache[device] = Handle(device)
     return h
+
+
+_TIE_NAMES = {"pdq178": TIE_PDQ178, "stable": TIE_STABLE}
+
+
+def set_default_tie_order(order):
+    """Process-wide order of equal probabilities in the beam searches' prune: "pdq178" (Rust 1.78's
+    sort_unstable_by, the default) or "stable" (ascending node index); include/fcd.h, FCD_TIE_*."""
+    order = _TIE_NAMES.get(order, order)
+    if load().fcd_set_default_tie_order(int(order)) != OK:
+        raise ValueError("tie order must be 'pdq178' or 'stable'")
+
+
+def default_tie_order():
+    return "stable" if int(load().fcd_get_tie_order(None)) == TIE_STABLE else "pdq178"
 
 
 def status_string(st):

@@ -355,6 +355,17 @@ def set_duplex_logadd_mode(mode):
                           nat.LOGADD_MAX: nat.LOGADD_MAX}[mode]
 
 
+def set_tie_order(order):
+    """How the beam searches order EQUAL probabilities among more than 20 candidates: "pdq178" (default: what Rust
+    1.78's sort_unstable_by -- the reference wheels' toolchain -- leaves them in) or "stable" (ascending node index).
+    Process-wide; the same switch as the compiled module's set_tie_order and the C ABI's fcd_set_default_tie_order."""
+    nat.set_default_tie_order(order)
+
+
+def tie_order():
+    return nat.default_tie_order()
+
+
 import os as _os
 if _os.environ.get("FCD_DUPLEX_LOGADD"):   # the same switch the compiled module reads at import
     set_duplex_logadd_mode(_os.environ["FCD_DUPLEX_LOGADD"])

@@ -20,6 +20,7 @@
 // ballot/popcount prefix sum, so ties resolve exactly as in the reference.
 #include "device_utils.h"
 #include "fcd_internal.h"
+#include "pdq178.h"
 
 namespace fcd {
 
@@ -63,6 +64,9 @@ struct Lds {
     int *hist;          // kBuckets: candidates per probability bucket (prune pre-selection)
     uint64_t *l_key;    // list_cap(BC): keys of the candidates that can still reach the beam
     int *l_c;           // list_cap(BC): their slot index
+    // FCD_TIE_PDQ178 (pdq178.h): the node-ordered candidate list of a tie-flagged step and the quicksort's scratch
+    uint64_t *pq_list;  // C
+    pdq178::Scratch *pq_scr;
 };
 
 // Prune pre-selection (phase B): candidates are bucketed by how far their probability lies below the
@@ -93,6 +97,7 @@ __host__ __device__ inline size_t lds_words(int BC, int N) {
     w += 2;      // top + pad
     w += shared_region_words(BC, N) + 3;  // m_flag / hist / l_key, 16-byte aligned
     w += (size_t)list_cap(BC);            // l_c
+    w += 2 * C + 2 + (sizeof(pdq178::Scratch) + 3) / 4;  // pq_list (u64, 8-byte aligned) + pq_scr
     return w;
 }
 
@@ -122,6 +127,11 @@ __device__ inline Lds carve(int *smem, int BC, int N) {
     L.l_key = reinterpret_cast<uint64_t *>(p);
     p += shared_region_words(BC, N);
     L.l_c = p;
+    p += list_cap(BC);
+    if ((p - smem) & 1) ++p;
+    L.pq_list = reinterpret_cast<uint64_t *>(p);
+    p += 2 * C;
+    L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p);
     return L;
 }
 
@@ -211,6 +221,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
     // tie instrument (fcd_result.ambiguous; two counters, semantics in include/fcd.h)
     const bool count_amb = p.out.ambiguous != nullptr;
     int n_amb = 0, n_crit = 0;
+    const bool pdq = p.a.tie_order == FCD_TIE_PDQ178;  // equal probabilities above 20 candidates: Rust 1.78's order
 
     for (int64_t t = 0; t < T; ++t) {
         int *b_node = L.b_node(cur), *b_tip = L.b_tip(cur), *b_par = L.b_par(cur);
@@ -390,6 +401,28 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             bstar = __shfl(4 * lane + kk, owner);
             Lc = __shfl(cum, owner);
         }
+        // candidate slot c becomes entry `rank` of the next beam
+        auto emit = [&](int c, int rank) {
+            const int i = c / N, k = c - i * N;
+            L.b_node(nxt)[rank] = L.c_id[c];
+            L.b_lp(nxt)[rank] = L.c_lp[c];
+            L.b_gp(nxt)[rank] = L.c_gp[c];
+            if (k == 0) {
+                L.b_tip(nxt)[rank] = b_tip[i];
+                L.b_par(nxt)[rank] = b_par[i];
+                L.b_state(nxt)[rank] = b_state[i];
+                L.b_depth(nxt)[rank] = b_depth[i];
+            } else {
+                L.b_tip(nxt)[rank] = k - 1;
+                L.b_par(nxt)[rank] = b_node[i];
+                L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
+                L.b_depth(nxt)[rank] = b_depth[i] + 1;
+            }
+            L.nb_src[rank] = c | ((int)((L.c_newmask[c >> 6] >> (c & 63)) & 1ull) << 30);
+            if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
+        };
+        // a kept candidate tied with another one: counted by the tie instrument, and re-ranked below under PDQ178
+        const bool want_tie = count_amb || (pdq && n_valid > 20);
         if (Lc <= cap) {
             // compaction in slot order (the list overwrites the histogram), then exact rank inside the list
             wave_sync();
@@ -415,7 +448,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                 const uint64_t key = L.l_key[e];
                 int rank = 0;
                 for (int j = 0; j < Lc; ++j) rank += (L.l_key[j] > key) ? 1 : 0;
-                if (count_amb) {
+                if (want_tie) {
                     // equal probabilities share a bucket: every candidate tied with a kept one is in the list,
                     // and so is every candidate of greater probability
                     int n_eq = 0, n_gt = 0;
@@ -427,26 +460,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                     tie = tie || (rank < BC && n_valid > 20 && n_eq >= 2);
                     crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < BC && n_gt + n_eq > BC)));
                 }
-                if (rank < BC) {
-                    const int c = L.l_c[e];
-                    const int i = c / N, k = c - i * N;
-                    L.b_node(nxt)[rank] = L.c_id[c];
-                    L.b_lp(nxt)[rank] = L.c_lp[c];
-                    L.b_gp(nxt)[rank] = L.c_gp[c];
-                    if (k == 0) {
-                        L.b_tip(nxt)[rank] = b_tip[i];
-                        L.b_par(nxt)[rank] = b_par[i];
-                        L.b_state(nxt)[rank] = b_state[i];
-                        L.b_depth(nxt)[rank] = b_depth[i];
-                    } else {
-                        L.b_tip(nxt)[rank] = k - 1;
-                        L.b_par(nxt)[rank] = b_node[i];
-                        L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
-                        L.b_depth(nxt)[rank] = b_depth[i] + 1;
-                    }
-                    L.nb_src[rank] = c | ((int)((L.c_newmask[c >> 6] >> (c & 63)) & 1ull) << 30);
-                    if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
-                }
+                if (rank < BC) emit(L.l_c[e], rank);
             }
         } else {
         // every lane owns slots lane, lane+64, ...: rank up to four of them in one sweep over the keys
@@ -469,7 +483,7 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
             const uint64_t key = myk[u];
             const int rank = myr[u];
             if (c >= nslots || key == 0ull) continue;
-            if (count_amb) {
+            if (want_tie) {
                 int n_eq = 0, n_gt = 0;
                 for (int j = 0; j < nslots; ++j) {
                     const uint64_t kj = L.c_key[j];
@@ -479,32 +493,36 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
                 tie = tie || (rank < BC && n_valid > 20 && n_eq >= 2);
                 crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < BC && n_gt + n_eq > BC)));
             }
-            if (rank < BC) {
-                const int i = c / N, k = c - i * N;
-                L.b_node(nxt)[rank] = L.c_id[c];
-                L.b_lp(nxt)[rank] = L.c_lp[c];
-                L.b_gp(nxt)[rank] = L.c_gp[c];
-                if (k == 0) {
-                    L.b_tip(nxt)[rank] = b_tip[i];
-                    L.b_par(nxt)[rank] = b_par[i];
-                    L.b_state(nxt)[rank] = b_state[i];
-                    L.b_depth(nxt)[rank] = b_depth[i];
-                } else {
-                    L.b_tip(nxt)[rank] = k - 1;
-                    L.b_par(nxt)[rank] = b_node[i];
-                    L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;
-                    L.b_depth(nxt)[rank] = b_depth[i] + 1;
-                }
-                L.nb_src[rank] = c | ((int)((L.c_newmask[c >> 6] >> (c & 63)) & 1ull) << 30);
-                if (rank == 0) *L.top = L.c_lp[c] + L.c_gp[c];
-            }
+            if (rank < BC) emit(c, rank);
           }
         }
         }
         wave_sync();
+        const bool any_tie = __ballot(tie) != 0ull;
         if (count_amb) {
-            n_amb += __ballot(tie) != 0ull ? 1 : 0;
+            n_amb += any_tie ? 1 : 0;
             n_crit += __ballot(crit) != 0ull ? 1 : 0;
+        }
+        if (pdq && any_tie) {
+            // sort_unstable_by's own order (src/search.rs:122,262): the merged candidates in ascending node order go
+            // through the restated quicksort, one lane, and the first BC of its result ARE the next beam (every
+            // entry written above is written again)
+            for (int base0 = 0; base0 < nslots; base0 += kWave) {
+                const int c = base0 + lane;
+                const uint64_t key = c < nslots ? L.c_key[c] : 0ull;
+                if (key == 0ull) continue;
+                int pos = 0;
+                for (int j = 0; j < nslots; ++j) {
+                    const uint64_t kj = L.c_key[j];
+                    pos += (kj != 0ull && (uint32_t)kj > (uint32_t)key) ? 1 : 0;  // low word: larger = smaller node
+                }
+                L.pq_list[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)c;
+            }
+            wave_sync();
+            if (lane == 0) pdq178::sort_desc(L.pq_list, n_valid, L.pq_scr);
+            wave_sync();
+            for (int rank = lane; rank < Bn; rank += kWave) emit((int)(uint32_t)L.pq_list[rank], rank);
+            wave_sync();
         }
 
         // ---- phase C: child rows of the new beam + renormalise by the top entry (:278-282) ----

@@ -30,6 +30,7 @@
 #endif
 #include "device_utils.h"
 #include "fcd_internal.h"
+#include "pdq178.h"
 
 namespace fcd {
 
@@ -128,7 +129,11 @@ __device__ __forceinline__ float rdlanef(float v, int l) {
 // beam_wave.hip's gather mode): every entry reads the row of ITS state, probs[t, state, :] -- N values per
 // lane, requested for step t+1 as soon as the entry's next state is known; no repeat-stay; an extension
 // moves to state (state * 4) & (S - 1) + label (:97), which cannot leave the table.
-template <int N, int RPW, bool AMB, bool CRF>
+// PDQ: FCD_TIE_PDQ178 (include/fcd.h; see beam_wave.hip) -- the candidates of rank <= beam_size leave their probability
+// in a table by rank; when a kept candidate ties with its successor among more than 20 candidates, the half builds
+// the node-ordered list of ALL its candidates in LDS, one lane replays Rust 1.78's quicksort on it (pdq178.h) and the
+// ranks it produces replace the exact ones.
+template <int N, int RPW, bool AMB, bool CRF, bool PDQ>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void beam_lane_kernel(LaneParams p) {
     constexpr int NL = N - 1;
     constexpr int HALF = 64 / RPW;          // lanes (= beam slots) per read
@@ -145,6 +150,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     __shared__ int s_fate[64];   // where old slot i's own candidate went: new slot | 64 (the IN-BEAM bit of the field), or 0
     __shared__ __attribute__((aligned(16))) int s_child[64 * RW];   // child entries of old slot i
     __shared__ int s_heads[64];
+    __shared__ uint32_t s_tie[PDQ ? 2 * 66 : 2];  // probability (orderable bits) of the candidate of rank r <= beam_size
+    static_assert(sizeof(pdq178::Scratch) <= sizeof(int4) * 64, "the quicksort's scratch borrows half of s_rec");
 
     int *hist = reinterpret_cast<int *>(s_u);                        // 256 ints      (1 KB)
     uint64_t *l_key_all = reinterpret_cast<uint64_t *>(s_u + 64);    // 128 u64      (1 KB)
@@ -157,6 +164,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     const int hh = lane / HALF;
     uint64_t *l_key = l_key_all + hh * LCAP;
     int *l_src = l_src_all + hh * LCAP;
+    uint32_t *tie_tab = s_tie + (PDQ ? hh * 66 : 0);
     const int64_t local = (int64_t)blockIdx.x * RPW + hh;
     const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
     const int64_t r = p.read_begin + (has_read ? local : 0);
@@ -424,7 +432,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             }
             wave_sync();
         }
-        if (ballot(Lc > LCAP) == 0ull) {
+        const bool listed = ballot(Lc > LCAP) == 0ull;
+        if (listed) {
             // "bucket <= bstar" as one compare per candidate: bucket = min((mx - hi) >> shift, KB - 1) <= bstar  <=>
             // mx - hi < (bstar + 1) << shift (everything qualifies when bstar is the catch-all bucket)  <=>  hi >= lim
             const uint32_t span = (uint32_t)(bstar + 1) << kBucketShift;
@@ -477,6 +486,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                     rk += __builtin_amdgcn_update_dpp(0, rk, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
                     rk += __builtin_amdgcn_update_dpp(0, rk, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
                     if (sub == 0 && e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                    if (PDQ && sub == 0 && e < Lc && rk <= beam_size) tie_tab[rk] = (uint32_t)(ke >> 32);
                     break;
                 }
                 const int e = e0 + q;
@@ -508,6 +518,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 }
                 rk += rk2;
                 if (e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                if (PDQ && e < Lc && rk <= beam_size) tie_tab[rk] = (uint32_t)(ke >> 32);
                 if (AMB && e < Lc) {
                     tie = tie || (rk < beam_size && n_valid > 20 && n_eq >= 2);
                     crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < beam_size && n_gt + n_eq > beam_size)));
@@ -539,6 +550,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 rank[k] = (key[k] != 0ull && rk[k] < beam_size) ? rk[k] : -1;
+                if (PDQ && key[k] != 0ull && rk[k] <= beam_size) tie_tab[rk[k]] = (uint32_t)(key[k] >> 32);
                 if (AMB && key[k] != 0ull) {
                     tie = tie || (rank[k] >= 0 && n_valid > 20 && n_eq[k] >= 2);
                     crit = crit || (n_eq[k] >= 2 && (n_gt[k] == 0 || (n_gt[k] < beam_size && n_gt[k] + n_eq[k] > beam_size)));
@@ -550,6 +562,49 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         if (AMB) {
             n_amb += hcount(tie) != 0 ? 1 : 0;
             n_crit += hcount(crit) != 0 ? 1 : 0;
+        }
+        if (PDQ) {
+            // ranks q and q + 1 hold one probability, rank q is kept and rank q + 1 was ranked in this step (a
+            // candidate outside the list shares no probability with a listed one): sort_unstable_by's order of the
+            // two is pdqsort's business once the list is longer than 20 (:262)
+            const int n_ranked = listed ? Lc : n_valid;
+            const bool tied = go && n_valid > 20 && q < beam_size && q + 1 < n_ranked && tie_tab[q] == tie_tab[q + 1];
+            const uint64_t m_tied = ballot(tied);
+            if (m_tied != 0ull) {
+                const bool mine_h = hmask(m_tied) != 0ull;
+                // every candidate's key side by side (the histogram / list region is free again)
+#pragma unroll
+                for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
+                wave_sync();
+                // the list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260)
+                int pos[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) pos[k] = 0;
+#pragma unroll 1
+                for (int j = 0; j < HALF * N; ++j) {
+                    const uint64_t kj = c_key[hbase * N + j];
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        pos[k] += (kj != 0ull && (uint32_t)kj > (uint32_t)key[k]) ? 1 : 0;  // low word: larger = smaller node
+                }
+                wave_sync();
+                uint64_t *list = c_key + hbase * N;
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (mine_h && key[k] != 0ull) list[pos[k]] = (key[k] & 0xFFFFFFFF00000000ull) | (uint32_t)(lane * 8 + k);
+                if (mine_h) *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
+                wave_sync();
+                if (mine_h && q == 0)
+                    pdq178::sort_desc(list, n_valid, reinterpret_cast<pdq178::Scratch *>(s_rec + 64 * hh));
+                wave_sync();
+                for (int j = q; mine_h && j < Bn; j += HALF) s_rank[(int)(uint32_t)list[j]] = (int8_t)j;
+                wave_sync();
+                const uint64_t again = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (mine_h) rank[k] = (int)(int8_t)(uint8_t)(again >> (8 * k));
+                wave_sync();
+            }
         }
 
         // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
@@ -798,14 +853,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     }
 }
 
-template <int N, bool AMB, bool CRF>
-hipError_t launch_na(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
+template <int N, bool AMB, bool CRF, bool PDQ>
+hipError_t launch_nap(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
     if (p.a.beam_size <= 32 && !p.arena.retry_counter) {  // two reads per wavefront
-        hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB, CRF>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB, CRF, PDQ>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
     } else {
-        hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB, CRF>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
+        hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB, CRF, PDQ>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
     }
     return hipGetLastError();
+}
+
+template <int N, bool AMB, bool CRF>
+hipError_t launch_na(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
+    return p.a.tie_order == FCD_TIE_PDQ178 ? launch_nap<N, AMB, CRF, true>(p, n_reads, stream)
+                                           : launch_nap<N, AMB, CRF, false>(p, n_reads, stream);
 }
 
 template <int N>

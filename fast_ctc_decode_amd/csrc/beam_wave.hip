@@ -50,6 +50,7 @@
 #endif
 #include "device_utils.h"
 #include "fcd_internal.h"
+#include "pdq178.h"
 
 namespace fcd {
 
@@ -112,7 +113,14 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // H16: the posteriors may be a 16-bit type (fcd_batch.dtype, converted exactly on load).  A separate instantiation:
 // with the element type a run-time value the float32 kernels paid for the test on every FIFO refill -- every step
 // in the CRF shape, whose rows fill a whole FIFO register (config 4: 4.2 -> 5.3 ms).
-template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false, bool H16 = false>
+// PDQ: FCD_TIE_PDQ178 (include/fcd.h) -- equal probabilities among more than 20 candidates come out in the order
+// Rust 1.78's sort_unstable_by leaves them in (:122,262).  Every step still takes its exact rank on (probability
+// desc, node asc); the candidates of rank <= beam_size also leave their probability in a small table by rank, so
+// one compare per slot says whether a KEPT candidate ties with its successor.  Only then (a few steps per thousand
+// reads on the BASELINE generator) the half builds the node-ordered candidate list in LDS, one lane replays the
+// quicksort on it (pdq178.h) and the ranks it produces replace the exact ones.  Instantiated only for shapes that
+// can hold more than 20 candidates.
+template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false, bool H16 = false, bool PDQ = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
     constexpr bool GATHER = S == kCrfGather;
@@ -135,6 +143,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     __shared__ int s_heads[kWavesPerBlock][64];
     // survivor table, per half: entry r = (byte address of the lane whose candidate took rank r) | that candidate's depth << 8
     __shared__ int s_srcs[kWavesPerBlock][RPW * 16];
+    // PDQ: probability (orderable bits) of the candidate of rank r, r <= beam_size; the node-ordered candidate list
+    // and the quicksort's scratch of a tie-flagged step
+    __shared__ uint32_t s_tie[PDQ ? kWavesPerBlock : 1][RPW * 16];
+    __shared__ uint64_t s_list[PDQ ? kWavesPerBlock : 1][64];
+    __shared__ pdq178::Scratch s_scr[PDQ ? kWavesPerBlock : 1][RPW];
+    static_assert(!PDQ || BCAP * N > 20, "the tie order only matters above 20 candidates");
     int n_amb = 0, n_crit = 0;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t cyc_last = 0;
@@ -171,6 +185,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const float thr = p.a.thr;
     uint64_t *keys = s_keys[wave];
     int *srcs = s_srcs[wave] + (hbase ? 16 : 0);
+    uint32_t *tie_tab = s_tie[PDQ ? wave : 0] + (hbase ? 16 : 0);
     if (lane < RPW * 16) s_srcs[wave][lane] = 0x7FFFFF00;  // never the minimum depth; points at lane 0
 
     const int64_t local = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW + (lane / HALF);
@@ -424,7 +439,73 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         const bool go = UNI ? true : (act && alive);  // this half completes the step
 
         const int Bn = n_valid < beam_size ? n_valid : beam_size;
-        const bool sel = valid && go && rank < beam_size;
+        // ---- keep the IN-BEAM/slot bits of every child entry current ----
+        // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
+        // selflag = rank | 16 for a kept candidate, 0 otherwise: shifted to kSlotShift it IS the (slot, IN-BEAM)
+        // field of a child entry (kInBeam == 16 << kSlotShift), so following an entry needs no compare
+        static_assert(kInBeam == (16 << kSlotShift) && kSlotMask == 15, "child-entry bit layout");
+        // Survivor table: entry r = the lane whose candidate took rank r.  LDS executes a wavefront's operations
+        // in order, so the store, the read-back and the two look-ups below share ONE round trip (a ds_permute
+        // to the new slot followed by a broadcast to its group were two dependent ones).
+        const int depc = depth + (is_child ? 1 : 0);
+        bool sel;
+        int selflag, fate, own, src_a, e_min, top_a;
+        uint32_t tie0 = 0, tie1 = 1;
+        auto settle = [&]() {
+            sel = valid && go && rank < beam_size;
+            selflag = sel ? (rank | 16) : 0;
+            if (sel) srcs[rank] = (lane << 2) | (depc << 8);
+            if (PDQ && key != 0ull && go && rank <= beam_size) tie_tab[rank] = (uint32_t)(key >> 32);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            fate = bperm(hbase + mslot * GW, selflag);
+            own = bperm(grp0, selflag);  // ... and this group's own candidate?
+            // every lane of new group i learns its source lane (stale beyond the new beam: unused), where the best
+            // candidate sits, and the SMALLEST DEPTH in the new beam: a stale entry can only lower it
+            src_a = srcs[i] & 0xFF;  // byte address, as ds_bpermute wants it
+            e_min = srcs[0];
+            top_a = e_min & 0xFF;
+#pragma unroll
+            for (int j = 1; j < BCAP; ++j) e_min = min(e_min, srcs[j]);
+            if (PDQ) {
+                tie0 = tie_tab[i];
+                tie1 = tie_tab[i + 1];
+            }
+        };
+        settle();
+        if (PDQ) {
+            // ranks i and i + 1 hold one probability, rank i is kept and rank i + 1 exists: sort_unstable_by's order
+            // of the two is pdqsort's business once the list is longer than 20 (:262)
+            const bool tied = go && n_valid > 20 && i < beam_size && i + 1 < n_valid && tie0 == tie1;
+            const uint64_t m_tied = ballot(tied);
+            if (m_tied != 0ull) {
+                const bool mine = RPW == 1 ? true : (hbase ? (m_tied >> 32) != 0ull : (uint32_t)m_tied != 0u);
+                uint64_t *list = s_list[wave] + hbase;
+                int *newrank = s_heads[wave];  // (free until the traceback)
+                // the list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260)
+                int pos = 0;
+#pragma unroll 1
+                for (int u = 0; u < NC; ++u) {
+                    const uint64_t ku = keys[hbase + (u / N) * GW + (u % N)];
+                    pos += (ku != 0ull && (uint32_t)ku > (uint32_t)key) ? 1 : 0;  // low word: larger = smaller node
+                }
+                if (mine && key != 0ull) list[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (mine && q == 0) pdq178::sort_desc(list, n_valid, &s_scr[wave][RPW == 1 ? 0 : (hbase ? 1 : 0)]);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (mine && q < n_valid) newrank[(int)(uint32_t)list[q]] = q;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (mine && key != 0ull) rank = newrank[lane];
+                settle();
+            }
+        }
         if (AMB) {
             // [0] a kept candidate that shares its probability with any other candidate of a > 20-candidate step;
             // [1] (any candidate count) equal probabilities at ranks 0 / 1 or across the truncation boundary:
@@ -435,30 +516,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             n_amb += (RPW == 1 ? m_tie : (hbase ? (m_tie >> 32) : (m_tie & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
             n_crit += (RPW == 1 ? m_crit : (hbase ? (m_crit >> 32) : (m_crit & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
         }
-
-        // ---- keep the IN-BEAM/slot bits of every child entry current ----
-        // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
-        // selflag = rank | 16 for a kept candidate, 0 otherwise: shifted to kSlotShift it IS the (slot, IN-BEAM)
-        // field of a child entry (kInBeam == 16 << kSlotShift), so following an entry needs no compare
-        static_assert(kInBeam == (16 << kSlotShift) && kSlotMask == 15, "child-entry bit layout");
-        const int selflag = sel ? (rank | 16) : 0;
-        // Survivor table: entry r = the lane whose candidate took rank r.  LDS executes a wavefront's operations
-        // in order, so the store, the read-back and the two look-ups below share ONE round trip (a ds_permute
-        // to the new slot followed by a broadcast to its group were two dependent ones).
-        const int depc = depth + (is_child ? 1 : 0);
-        if (sel) srcs[rank] = (lane << 2) | (depc << 8);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const int fate = bperm(hbase + mslot * GW, selflag);
-        const int own = bperm(grp0, selflag);  // ... and this group's own candidate?
-        // every lane of new group i learns its source lane (stale beyond the new beam: unused), where the best
-        // candidate sits, and the SMALLEST DEPTH in the new beam: a stale entry can only lower it
-        const int src_a = srcs[i] & 0xFF;  // byte address, as ds_bpermute wants it
-        int e_min = srcs[0];
-        const int top_a = e_min & 0xFF;
-#pragma unroll
-        for (int j = 1; j < BCAP; ++j) e_min = min(e_min, srcs[j]);
         // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
         // its row is in HBM); read off the entry BEFORE it is marked below
         const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
@@ -624,32 +681,41 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     }
 }
 
-template <int N, int GW, int RPW, int S = 0>
-hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
+template <int N, int GW, int RPW, int S, bool PDQ>
+hipError_t launch_tp(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
     const int64_t waves = (n_reads + RPW - 1) / RPW;
     const unsigned blocks = (unsigned)((waves + kWavesPerBlock - 1) / kWavesPerBlock);
     if (p.in.dtype != kF32) {  // half-precision posteriors: the general instantiations only
         if (p.out.ambiguous)
-            hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true, false, false, true>), dim3(blocks),
+            hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true, false, false, true, PDQ>), dim3(blocks),
                                dim3(64 * kWavesPerBlock), 0, stream, p);
         else
-            hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, false, true>), dim3(blocks),
+            hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, false, true, PDQ>), dim3(blocks),
                                dim3(64 * kWavesPerBlock), 0, stream, p);
         return hipGetLastError();
     }
     if (p.out.ambiguous)
-        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, true, false, false, false, PDQ>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
     else if (p.a.prof && N == 5 && GW == 6 && RPW == 2 && S == 0)   // the headline instantiation only
-        hipLaunchKernelGGL((beam_wave_kernel<5, 6, 2, 0, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+        hipLaunchKernelGGL((beam_wave_kernel<5, 6, 2, 0, false, true, false, false, PDQ>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
     else if (!p.in.lengths)  // reads of one length
-        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, true>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, true, false, PDQ>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
     else
-        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
+        hipLaunchKernelGGL((beam_wave_kernel<N, GW, RPW, S, false, false, false, false, PDQ>), dim3(blocks), dim3(64 * kWavesPerBlock), 0,
                            stream, p);
     return hipGetLastError();
+}
+
+template <int N, int GW, int RPW, int S = 0>
+hipError_t launch_t(const WaveParams &p, int64_t n_reads, hipStream_t stream) {
+    // the tie order of sort_unstable_by differs from the exact rank only above 20 candidates (pdq178.h): shapes
+    // that cannot hold that many have no second instantiation
+    constexpr bool CAN_TIE = ((64 / RPW) / GW) * N > 20;
+    if (CAN_TIE && p.a.tie_order == FCD_TIE_PDQ178) return launch_tp<N, GW, RPW, S, CAN_TIE>(p, n_reads, stream);
+    return launch_tp<N, GW, RPW, S, false>(p, n_reads, stream);
 }
 
 }  // namespace

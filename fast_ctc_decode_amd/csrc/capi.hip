@@ -3,7 +3,10 @@
 #include <math.h>
 #include <string.h>
 
+#include <stdlib.h>
+
 #include <algorithm>
+#include <atomic>
 #include <vector>
 
 #include "fcd_internal.h"
@@ -11,6 +14,15 @@
 using namespace fcd;
 
 namespace {
+
+// process default of the prune's tie order (include/fcd.h, FCD_TIE_*): the environment at load time, then
+// fcd_set_default_tie_order
+int tie_order_from_env() {
+    const char *e = getenv("FCD_TIE_ORDER");
+    if (e && (!strcmp(e, "stable") || !strcmp(e, "STABLE") || !strcmp(e, "1"))) return FCD_TIE_STABLE;
+    return FCD_TIE_PDQ178;
+}
+std::atomic<int> g_tie_order{tie_order_from_env()};
 
 #define FCD_HIP(h, expr)                                                          \
     do {                                                                          \
@@ -153,6 +165,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     const int N = d.N, NL = N - 1;
     int64_t beam = a.beam_size;
     BeamArgs args = a;
+    args.tie_order = effective_tie_order(h);
 
     bool use_wave = false;
     if (kernel == FCD_KERNEL_WAVE || kernel == FCD_KERNEL_WAVE1) {
@@ -306,6 +319,12 @@ int64_t span_elems(const fcd_batch *in, bool crf) {
 
 }  // namespace
 
+namespace fcd {
+int effective_tie_order(const fcd_handle *h) {
+    return (h && h->tie_order != FCD_TIE_DEFAULT) ? h->tie_order : g_tie_order.load();
+}
+}  // namespace fcd
+
 // =============================================================================================
 extern "C" {
 
@@ -411,6 +430,30 @@ int fcd_release_workspace(fcd_handle *h) {
     if (h->retry_counter) (void)hipFree(h->retry_counter);
     h->arena = h->stage = h->lnbuf = h->pin = h->retry_counter = nullptr;
     h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = h->retry_counter_bytes = 0;
+    return FCD_OK;
+}
+
+int fcd_set_tie_order(fcd_handle *h, int order) {
+    if (!h || (order != FCD_TIE_DEFAULT && order != FCD_TIE_PDQ178 && order != FCD_TIE_STABLE)) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    h->tie_order = order;
+    return FCD_OK;
+}
+
+int fcd_get_tie_order(const fcd_handle *h) { return effective_tie_order(h); }
+
+int fcd_set_default_tie_order(int order) {
+    if (order != FCD_TIE_PDQ178 && order != FCD_TIE_STABLE) return FCD_E_INVALID;
+    g_tie_order.store(order);
+    return FCD_OK;
+}
+
+int fcd_debug_pdq178_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (n_lists < 0 || stride < 0 || (n_lists > 0 && (!lists || !lens))) return fail(h, FCD_E_INVALID, "bad argument");
+    FCD_DEVICE(h);
+    FCD_HIP(h, launch_pdq178_probe(lists, n_lists, stride, lens, h->stream));
     return FCD_OK;
 }
 
@@ -647,6 +690,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S) <= 48 * 1024 && beam_size <= 64 ? 1 : 0;
     a.out = to_desc(out);
     a.prof = h->duplex_prof;
+    a.tie_order = effective_tie_order(h);
     for (int64_t begin = 0; begin < B; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, B - begin);
         FCD_HIP(h, launch_duplex(a, begin, n, h->stream));

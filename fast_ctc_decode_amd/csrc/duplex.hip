@@ -36,6 +36,7 @@
 // default `fastexp` feature, where exp() is identically 0 and the addition degenerates to max().
 #include "device_utils.h"
 #include "fcd_internal.h"
+#include "pdq178.h"
 #include "logadd_fast.h"
 
 namespace fcd {
@@ -70,6 +71,7 @@ struct DuplexParams {
     ResultDesc out;
     int64_t pair_begin;
     uint32_t *prof;  // developer instrument (fcd_debug_set_duplex_profile): [pair][8] shader cycles per phase, nullable
+    int tie_order;   // FCD_TIE_PDQ178 / FCD_TIE_STABLE (include/fcd.h)
 };
 
 constexpr float kNegInf = -__builtin_huge_valf();
@@ -220,6 +222,9 @@ struct DLds {
     __device__ __forceinline__ float *b_max(int b) const { return reinterpret_cast<float *>(b_node(b) + 10 * BC); }
     __device__ __forceinline__ int *b_child(int b) const { return b_node(b) + 11 * BC; }
     uint64_t *c_key;
+    // FCD_TIE_PDQ178 (pdq178.h): the node-ordered candidate list of a tie-flagged step and the quicksort's scratch
+    uint64_t *pq_list;  // C
+    pdq178::Scratch *pq_scr;
     float *c_lp, *c_gp, *c_p2;
     int *c_id, *c_new;
     int *nb_src;
@@ -232,7 +237,7 @@ struct DLds {
 __host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax, int S) {
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
-    return 2 * (size_t)BC * (11 + NL) + 2 * C + 5 * C + 3 * (size_t)BC + 4 + 64 +
+    return 2 * (size_t)BC * (11 + NL) + 2 * C + 2 * C + (sizeof(pdq178::Scratch) + 3) / 4 + 5 * C + 3 * (size_t)BC + 4 + 64 +
            (size_t)Wmax * S * N + (Wmax > 0 ? (size_t)BC * (Wmax + 2) * 3 : 0);
 }
 
@@ -242,6 +247,8 @@ __device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S) {
     const size_t C = (size_t)BC * N;
     L.c_key = reinterpret_cast<uint64_t *>(smem);
     int *p = smem + 2 * C;
+    L.pq_list = reinterpret_cast<uint64_t *>(p); p += 2 * C;
+    L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p); p += (sizeof(pdq178::Scratch) + 3) / 4;
     L.c_lp = reinterpret_cast<float *>(p); p += C;
     L.c_gp = reinterpret_cast<float *>(p); p += C;
     L.c_p2 = reinterpret_cast<float *>(p); p += C;
@@ -1336,7 +1343,9 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
         // ---- rank and build the next beam (no renormalisation in log space) ----
         const int nxt = cur ^ 1;
         const int Bn = n_valid < BC ? n_valid : BC;
-        if (count_amb) {
+        const bool pdq = p.tie_order == FCD_TIE_PDQ178;  // equal probabilities above 20 candidates: Rust 1.78's order
+        bool any_kept_tie = false;
+        if (count_amb || (pdq && n_valid > 20)) {
             // candidates with one probability occupy ranks [gt, gt + eq): a kept one is tied when gt < BC and
             // eq >= 2; the tie can change the kept set or the best entry when the group holds rank 0 or straddles
             // the truncation boundary
@@ -1357,38 +1366,63 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
                 kept_tie = kept_tie || (gt < BC && eq >= 2);
                 crit = crit || (eq >= 2 && (gt == 0 || (gt < BC && gt + eq > BC)));
             }
-            if (n_valid > 20 && ballot(kept_tie) != 0ull) ++n_amb;
-            if (ballot(crit) != 0ull) ++n_crit;
+            any_kept_tie = n_valid > 20 && ballot(kept_tie) != 0ull;
+            if (count_amb) {
+                if (any_kept_tie) ++n_amb;
+                if (ballot(crit) != 0ull) ++n_crit;
+            }
         }
-        for (int base = 0; base < nslots; base += kWave) {
-            const int c = base + lane;
-            if (c >= nslots) continue;
-            const uint64_t key = L.c_key[c];
-            if (key == 0ull) continue;
-            int rank = 0;
-            for (int j = 0; j < nslots; ++j) rank += (L.c_key[j] > key) ? 1 : 0;
-            if (rank < BC) {
-                const int i = c / N, k = c - i * N;
-                L.b_node(nxt)[rank] = L.c_id[c];
-                L.b_lp(nxt)[rank] = L.c_lp[c];
-                L.b_gp(nxt)[rank] = L.c_gp[c];
-                if (k == 0) {
-                    L.b_tip(nxt)[rank] = b_tip[i];
-                    L.b_par(nxt)[rank] = b_par[i];
-                    L.b_state(nxt)[rank] = b_state[i];
-                    // the entry stays: so does its resident window
-                    L.b_buf(nxt)[rank] = L.b_buf(cur)[i];
-                    L.b_off(nxt)[rank] = L.b_off(cur)[i];
-                    L.b_end(nxt)[rank] = L.b_end(cur)[i];
-                    L.b_rlo(nxt)[rank] = L.b_rlo(cur)[i];
-                    L.b_max(nxt)[rank] = L.b_max(cur)[i];
-                } else {
-                    L.b_buf(nxt)[rank] = -1;  // a node entering the beam: gets a buffer and its ring below
-                    L.b_tip(nxt)[rank] = k - 1;
-                    L.b_par(nxt)[rank] = b_node[i];
-                    L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;  // :782
+        // candidate slot c becomes entry `rank` of the next beam
+        auto emit = [&](int c, int rank) {
+            const int i = c / N, k = c - i * N;
+            L.b_node(nxt)[rank] = L.c_id[c];
+            L.b_lp(nxt)[rank] = L.c_lp[c];
+            L.b_gp(nxt)[rank] = L.c_gp[c];
+            if (k == 0) {
+                L.b_tip(nxt)[rank] = b_tip[i];
+                L.b_par(nxt)[rank] = b_par[i];
+                L.b_state(nxt)[rank] = b_state[i];
+                // the entry stays: so does its resident window
+                L.b_buf(nxt)[rank] = L.b_buf(cur)[i];
+                L.b_off(nxt)[rank] = L.b_off(cur)[i];
+                L.b_end(nxt)[rank] = L.b_end(cur)[i];
+                L.b_rlo(nxt)[rank] = L.b_rlo(cur)[i];
+                L.b_max(nxt)[rank] = L.b_max(cur)[i];
+            } else {
+                L.b_buf(nxt)[rank] = -1;  // a node entering the beam: gets a buffer and its ring below
+                L.b_tip(nxt)[rank] = k - 1;
+                L.b_par(nxt)[rank] = b_node[i];
+                L.b_state(nxt)[rank] = crf ? (int)(((int64_t)b_state[i] * NL) % S) + (k - 1) : 0;  // :782
+            }
+            L.nb_src[rank] = c | (L.c_new[c] << 30);
+        };
+        if (pdq && any_kept_tie) {
+            // sort_unstable_by's own order (src/duplex.rs:620,807): the merged candidates in ascending node order go
+            // through the restated quicksort (one lane); the first BC of its result are the next beam
+            for (int base = 0; base < nslots; base += kWave) {
+                const int c = base + lane;
+                const uint64_t key = c < nslots ? L.c_key[c] : 0ull;
+                if (key == 0ull) continue;
+                int pos = 0;
+                for (int j = 0; j < nslots; ++j) {
+                    const uint64_t kj = L.c_key[j];
+                    pos += (kj != 0ull && (uint32_t)kj > (uint32_t)key) ? 1 : 0;  // low word: larger = smaller node
                 }
-                L.nb_src[rank] = c | (L.c_new[c] << 30);
+                L.pq_list[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)c;
+            }
+            __syncthreads();
+            if (lane == 0) pdq178::sort_desc(L.pq_list, n_valid, L.pq_scr);
+            __syncthreads();
+            for (int rank = lane; rank < Bn; rank += kWave) emit((int)(uint32_t)L.pq_list[rank], rank);
+        } else {
+            for (int base = 0; base < nslots; base += kWave) {
+                const int c = base + lane;
+                if (c >= nslots) continue;
+                const uint64_t key = L.c_key[c];
+                if (key == 0ull) continue;
+                int rank = 0;
+                for (int j = 0; j < nslots; ++j) rank += (L.c_key[j] > key) ? 1 : 0;
+                if (rank < BC) emit(c, rank);
             }
         }
         __syncthreads();
@@ -1660,6 +1694,7 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     p.n_init2 = a.n_init2; p.init1_stride = a.init1_stride; p.init2_stride = a.init2_stride;
     p.pair_begin = pair_begin;
     p.prof = a.prof;
+    p.tie_order = a.tie_order;
     const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S);
     // up to two wavefronts per SIMD (2048 pairs on the 256 CUs): the coefficient-pinning instantiation
     const bool pin = a.staged && n_pairs <= 2048;

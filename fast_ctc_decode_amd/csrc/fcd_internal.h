@@ -49,6 +49,7 @@ struct BeamArgs {
     // developer instrument (fcd_beam_search_profile_dev): per wavefront, shader cycles spent in each block
     // of the step, summed over the read -- [n_wavefronts][8] u32, nullable
     uint32_t *prof;
+    int tie_order;  // FCD_TIE_PDQ178 / FCD_TIE_STABLE (include/fcd.h): order of equal probabilities above 20 candidates
 };
 
 // Per-chunk tree arena of the LDS-resident ("generic") beam kernel: one slab per read.
@@ -127,6 +128,7 @@ struct DuplexArgs {
     int staged;
     ResultDesc out;
     uint32_t *prof;  // developer instrument: [pair][8] cycle account, nullable
+    int tie_order;   // FCD_TIE_PDQ178 / FCD_TIE_STABLE
 };
 
 size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S);
@@ -175,6 +177,9 @@ hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add,
                                  int64_t n, int mode, hipStream_t stream);
 hipError_t launch_logadd_chain(int n_chain, int mode, uint64_t *cycles, float *sink, hipStream_t stream);
 hipError_t launch_logadd_sweep(int which, uint32_t first, uint32_t last, unsigned long long *counts, hipStream_t stream);
+hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, hipStream_t stream);
+// the tie order searches on this handle use (capi.hip)
+int effective_tie_order(const fcd_handle *h);
 
 // ---- host side of the four 1D searches (capi.hip, hostjob.hip) ----
 enum class HostOp { Viterbi, Beam, CrfBeam, CrfGreedy };
@@ -238,6 +243,7 @@ struct fcd_handle {
     bool job_active = false;  // a host job owns the lanes from begin to end
     bool is_lane = false;
     uint32_t *duplex_prof = nullptr;  // fcd_debug_set_duplex_profile
+    int tie_order = FCD_TIE_DEFAULT;  // fcd_set_tie_order; FCD_TIE_DEFAULT = follow the process default
     int pipe_lanes = 0;          // fcd_set_host_pipeline: 0 = default (FCD_HOST_LANES or 4)
     int64_t pipe_chunk = 0;      // reads per chunk, 0 = automatic
     int64_t pipe_min_bytes = -1; // fcd_*_host batches of at least this many input bytes take the pipeline; -1 = default

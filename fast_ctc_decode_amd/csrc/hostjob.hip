@@ -224,6 +224,7 @@ int ensure_lanes(fcd_handle *h, int n_lanes) {
     }
     // the lanes share the handle's workspace limit
     for (fcd_host_lane *L : h->lanes) L->h->ws_limit = h->ws_limit > 0 ? std::max<int64_t>(h->ws_limit / n_lanes, 1) : 0;
+    for (fcd_host_lane *L : h->lanes) L->h->tie_order = effective_tie_order(h);  // the lanes search as their owner would
     return FCD_OK;
 }
 

@@ -1147,6 +1147,20 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
           "'max' (the reference's default `fastexp` feature, i.e. what the PyPI wheels compute)");
     m.def("_set_duplex_logadd_mode", set_mode);  // earlier name, kept for the tests
     m.def(
+        "set_tie_order",
+        [](const std::string &order) {
+            int o;
+            if (order == "pdq178") o = FCD_TIE_PDQ178;
+            else if (order == "stable") o = FCD_TIE_STABLE;
+            else throw py::value_error("order must be 'pdq178' or 'stable'");
+            fcd_set_default_tie_order(o);
+        },
+        "order"_a,
+        "set_tie_order(order): how the beam searches order EQUAL probabilities among more than 20 candidates -- "
+        "'pdq178' (default: the order Rust 1.78's sort_unstable_by, i.e. the reference wheels, leaves them in) or "
+        "'stable' (ascending node index).  Process-wide (include/fcd.h, FCD_TIE_*).");
+    m.def("tie_order", []() { return std::string(fcd_get_tie_order(nullptr) == FCD_TIE_STABLE ? "stable" : "pdq178"); });
+    m.def(
         "set_coalescing",
         [](int max_batch, int max_wait_us, int device) {
             fcd_coalescer *fresh = nullptr;

@@ -83,6 +83,23 @@ enum {
     FCD_KERNEL_LANE = 4      /* one beam entry per lane: beam_size <= 64, N <= 8, plain (non-CRF) search */
 };
 
+/* Order of EQUAL probabilities in the prune of the beam searches (src/search.rs:122,262, src/duplex.rs:620,807:
+ * sort_unstable_by on a list that is in ascending node order).  Up to 20 candidates Rust's sort is an insertion
+ * sort and ties keep node order; above 20 it is the pattern-defeating quicksort of the pinned toolchain (Rust
+ * 1.78.0, .github/workflows/test.yml:16), whose permutation of equal keys is a deterministic function of the list.
+ *   FCD_TIE_PDQ178 (default)  on a step with more than 20 candidates in which a candidate that survives the
+ *                  truncation ties with another one, one lane replays that quicksort (csrc/pdq178.h, restated from
+ *                  memory of library/core/src/slice/sort.rs -- no Rust source or toolchain in the build image; the
+ *                  same restatement, written independently, is the oracle's) and the search adopts its order;
+ *                  every other step is ranked exactly on (probability desc, node asc), which is the same thing.
+ *   FCD_TIE_STABLE ties always keep ascending node order (what rounds 1-3 shipped): one of the admissible answers
+ *                  of an unstable sort, but not the one Rust 1.78 gives on about 0.05 % of BASELINE config-2 reads.
+ * A handle follows the process default until fcd_set_tie_order names an order for it (FCD_TIE_DEFAULT: follow
+ * again); the process default is FCD_TIE_PDQ178, or what the environment variable FCD_TIE_ORDER (pdq178 | stable)
+ * says at load time, or what fcd_set_default_tie_order set last.  Coalescer and host-pipeline handles follow
+ * their creator. */
+enum { FCD_TIE_DEFAULT = -1, FCD_TIE_PDQ178 = 0, FCD_TIE_STABLE = 1 };
+
 typedef struct fcd_handle fcd_handle;
 
 /* Shape/stride description of a batch of posterior matrices.
@@ -127,8 +144,10 @@ typedef struct fcd_batch {
  *            two duplex searches, whose prune is the same sort_unstable_by, src/duplex.rs:620,807; device pointer
  *            for *_dev, host pointer for *_host) -- a TIE INSTRUMENT, not a reference output.  The reference
  *            orders candidates with sort_unstable_by (src/search.rs:122,262): a stable insertion sort up to
- *            20 elements, pdqsort -- implementation-defined tie order -- above.  The kernels break exact
- *            probability ties by ascending node index, which is what the stable path does.
+ *            20 elements, pdqsort -- implementation-defined tie order -- above.  Under FCD_TIE_STABLE the kernels
+ *            break exact probability ties by ascending node index, which is what the stable path does; under
+ *            FCD_TIE_PDQ178 (default) the steps counted in [r][0] are exactly the ones re-ranked by the restated
+ *            quicksort.  The counters do not depend on the tie order within a step.
  *              [r][0] steps with MORE than 20 candidates in which a candidate that survives the truncation has
  *                     exactly the probability of another candidate.  0 for a read => its beam, set and order,
  *                     follows the reference step for step;
@@ -164,6 +183,14 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes);
  * handle's stream and gives it all back (the next call allocates afresh).  For processes that share the GPU
  * with another allocator (PyTorch's caching allocator) after an unusually large job. */
 int fcd_release_workspace(fcd_handle *h);
+/* tie order of the beam searches' prune (FCD_TIE_*, above) */
+int fcd_set_tie_order(fcd_handle *h, int order);         /* FCD_TIE_DEFAULT: follow the process default again */
+int fcd_get_tie_order(const fcd_handle *h);              /* the order searches on this handle use right now */
+int fcd_set_default_tie_order(int order);                /* FCD_TIE_PDQ178 or FCD_TIE_STABLE; process-wide */
+/* Test hook: lists (DEVICE u64 [n_lists][stride], lens DEVICE i32 [n_lists]) are sorted in place by the device
+ * function the kernels run on tie-flagged steps: descending by the UPPER 32 bits of each element, equal keys in
+ * the order Rust 1.78's sort_unstable_by leaves them in; the lower 32 bits ride along. */
+int fcd_debug_pdq178_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens);
 /* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
  * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
  * it) and decode the reads that outgrow their slab again in worst-case slabs carved from the same arena.  A

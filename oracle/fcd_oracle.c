@@ -259,10 +259,14 @@ DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
  * floor(log2 n) + 1 is spent).  UNVERIFIED: neither the Rust source nor a Rust toolchain exists in this
  * environment, so this cannot be checked against the real thing; every sort it performs is a correct
  * descending sort, only the order of EQUAL keys is at stake.  It exists to MEASURE how much that order could
- * matter (fcdo_set_unstable_sort, tools/pdqsort_ties.py): the default of the oracle and
- * the rule of the kernels stays "ties keep ascending node order".
+ * matter (fcdo_set_unstable_sort, tools/pdqsort_ties.py).  Round 3 measured with it; since
+ * round 4 it is the oracle's default and the kernels follow the same order (FCD_TIE_PDQ178, csrc/pdq178.h: a second
+ * restatement, written separately, compared with this one element for element in tests/test_pdq178.py); "ties keep
+ * ascending node order" (FCD_TIE_STABLE) remains selectable on both sides.
  */
-static int g_unstable_sort_mode = 0; /* 0 = stable rule (default), 1 = the pdqsort restatement above */
+static int g_unstable_sort_mode = 1; /* 1 = the pdqsort restatement above (default since round 4: the product's
+                                      * default is FCD_TIE_PDQ178, which csrc/pdq178.h restates separately),
+                                      * 0 = the stable rule (FCD_TIE_STABLE) */
 void fcdo_set_unstable_sort(int mode) { g_unstable_sort_mode = mode ? 1 : 0; }
 int fcdo_get_unstable_sort(void) { return g_unstable_sort_mode; }
 

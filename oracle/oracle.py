@@ -406,7 +406,8 @@ def duplex_tie_steps(reset=False):
 
 class unstable_sort:
     """with unstable_sort("pdqsort"): the beam searches order EQUAL probabilities above 20 candidates the way the
-    oracle's restatement of Rust 1.78's pdqsort leaves them (UNVERIFIED, fcd_oracle.c); default "stable"."""
+    oracle's restatement of Rust 1.78's pdqsort leaves them (UNVERIFIED, fcd_oracle.c) -- the default since round 4,
+    like the product's FCD_TIE_PDQ178; with unstable_sort("stable"): ties keep ascending node order (FCD_TIE_STABLE)."""
 
     def __init__(self, mode):
         self.mode = {"stable": 0, "pdqsort": 1}[mode]

@@ -143,3 +143,16 @@ def test_half_precision_inputs(fcd):
     import test_gpu_halfprec as HP
     HP.test_half_precision_host_inputs_every_kernel(fcd)
     HP.test_half_precision_crf_and_duplex(fcd)
+
+
+def test_tie_orders(fcd):
+    """FCD_TIE_PDQ178 / FCD_TIE_STABLE (tests/test_gpu_tieorder.py) under the emulator: every kernel family under both
+    orders on inputs built to tie, the CRF and duplex searches, and the BASELINE reads whose result depends on it."""
+    import test_gpu_tieorder as TO
+    TO.test_both_tie_orders_every_kernel(fcd, 5, 5, (0, 1, 2, 3, 4))
+    TO.test_both_tie_orders_every_kernel(fcd, 5, 32, (1, 4))
+    TO.test_both_tie_orders_every_kernel(fcd, 8, 64, (4,))
+    TO.test_both_tie_orders_every_kernel(fcd, 4, 5, (2, 4))
+    TO.test_tie_order_is_per_handle_too(fcd)
+    TO.test_crf_beam_both_orders(fcd, "pdq178")
+    TO.test_duplex_both_orders(fcd, D.MAX)

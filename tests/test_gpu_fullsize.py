@@ -50,35 +50,48 @@ def test_four_kernels_agree_on_every_read(fcd, batch):
 
 
 def test_config2_tie_instrument(fcd, batch):
-    """above 20 candidates the reference's sort_unstable_by is pdqsort, whose tie order is not
-    pinned.  On all 4096 reads of BASELINE config 2 the tie counters of every kernel family equal the oracle's,
-    the instrumented kernels return the timed kernels' results, and the reads are classified:
-      * counter [0] == 0: the beam follows the reference step for step (stable rule == insertion sort);
+    """above 20 candidates the reference's sort_unstable_by is pdqsort, which orders equal probabilities
+    its own way.  On all 4096 reads of BASELINE config 2, under BOTH selectable orders (include/fcd.h FCD_TIE_*), the
+    tie counters of every kernel family equal the oracle's, the instrumented kernels return the timed kernels'
+    results, and the reads are classified:
+      * counter [0] == 0: no step hands the sort a tie among survivors -- the beam follows the reference step for
+        step whatever the order;
       * counter [1] == 0: no tie can change a kept set or the best entry;
       * both non-zero: the oracle replays the read under EVERY resolution of its result-changing ties.
     Exact f32 ties are not rare (two equal posteriors in a row are enough): 13 reads have [0] > 0, 16 have
-    [1] > 0, 11 have both, and for exactly TWO reads (1198, 3588) the result depends on how pdqsort orders a
-    tie -- there the kernels and the oracle use the stable rule and parity with the Rust is unpinned."""
+    [1] > 0, 11 have both, and for exactly TWO reads (1198, 3588) the result depends on the order: there the default
+    (FCD_TIE_PDQ178) follows the restatement of Rust 1.78's quicksort, FCD_TIE_STABLE keeps node order, and each
+    equals the oracle under the same rule."""
+    from tie_util import tie_order
     x, xd = batch
-    base = digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True))
-    want = np.zeros((B, 2), np.int64)
-    oracle.beam_search_batch(x, 5, 0.1, True, n_threads=16, ambiguous=want)
-    for k in (0, 1, 4):
-        r = fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k, count_ambiguous=True).cpu()
-        np.testing.assert_array_equal(np.asarray(r.ambiguous).astype(np.int64), want, err_msg="kernel %d" % k)
-        assert np.array_equal(digest(r), base), k
-    assert ((want[:, 0] > 0).sum(), (want[:, 1] > 0).sum()) == (13, 16)
-    both = np.flatnonzero((want[:, 0] > 0) & (want[:, 1] > 0))
-    assert len(both) == 11
-    r = fcd.beam_search_batch_raw(xd, 5, 0.1, True).cpu()
-    depends = []
-    for i in both:
-        st, labels, path, n_branches, all_equal, complete = oracle.beam_search_all_tie_orders(x[i], 5, 0.1, True)
-        n = int(r.out_len[i])
-        assert st == 0 and complete and np.array_equal(r.labels[i, :n], labels) and np.array_equal(r.path[i, :n], path)
-        if not all_equal:
-            depends.append(int(i))
-    assert depends == [1198, 3588]
+    digests = {}
+    for order in ("stable", "pdq178"):
+        with tie_order(fcd, order):
+            base = digests[order] = digest(fcd.beam_search_batch_raw(xd, 5, 0.1, True))
+            want = np.zeros((B, 2), np.int64)
+            olab, opath, olen, ostat = oracle.beam_search_batch(x, 5, 0.1, True, n_threads=16, ambiguous=want)
+            for k in (0, 1, 4):
+                r = fcd.beam_search_batch_raw(xd, 5, 0.1, True, kernel=k, count_ambiguous=True).cpu()
+                np.testing.assert_array_equal(np.asarray(r.ambiguous).astype(np.int64), want, err_msg="kernel %d" % k)
+                assert np.array_equal(digest(r), base), k
+            assert ((want[:, 0] > 0).sum(), (want[:, 1] > 0).sum()) == (13, 16)
+            both = np.flatnonzero((want[:, 0] > 0) & (want[:, 1] > 0))
+            assert len(both) == 11
+            r = fcd.beam_search_batch_raw(xd, 5, 0.1, True).cpu()
+            for i in range(B):  # every read against the oracle under the same order
+                n = int(r.out_len[i])
+                assert int(r.status[i]) == int(ostat[i]) == 0 and n == int(olen[i]), (order, i)
+                assert np.array_equal(r.labels[i, :n], olab[i, :n]) and np.array_equal(r.path[i, :n], opath[i, :n]), (order, i)
+            if order == "stable":
+                depends = []
+                for i in both:
+                    st, labels, path, n_branches, all_equal, complete = oracle.beam_search_all_tie_orders(x[i], 5, 0.1, True)
+                    n = int(r.out_len[i])
+                    assert st == 0 and complete and np.array_equal(r.labels[i, :n], labels) and np.array_equal(r.path[i, :n], path)
+                    if not all_equal:
+                        depends.append(int(i))
+                assert depends == [1198, 3588]
+    assert np.flatnonzero(digests["stable"] != digests["pdq178"]).tolist() == [1198, 3588]
 
 
 @pytest.mark.parametrize("beam,n_oracle", [(32, 16), (64, 16)])

@@ -1,0 +1,94 @@
+"""csrc/pdq178.h -- the device routine the beam kernels run on their tie-flagged steps (FCD_TIE_PDQ178) -- against
+the oracle's restatement of Rust 1.78's sort_unstable_by (oracle/fcd_oracle.c, DEFINE_PDQSORT).  The two were written
+separately (explicit stack vs recursion, u64 elements vs structs); they must produce the same PERMUTATION, equal keys
+included, on every list.  Here through tests/hipemu (no GPU); tests/test_gpu_tieorder.py runs the same lists on the
+MI355X."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from test_pdqsort_restatement import _patterns
+
+
+def orderable(p):
+    """device_utils.h make_key's upper word: a total order on non-NaN f32, larger = greater probability"""
+    u = (np.asarray(p, np.float32) + np.float32(0)).view(np.uint32).astype(np.uint64)
+    neg = (u & 0x80000000) != 0
+    return np.where(neg, u ^ 0xFFFFFFFF, u ^ 0x80000000).astype(np.uint64)
+
+
+def tie_lists(seed=0):
+    """(prob, tag) lists: adversarial patterns at the lengths where pdqsort changes gear (20 / 21, 50, 128-element
+    blocks, 2 * 128 + ...), plus what the searches really produce: few distinct values among 21..512 candidates."""
+    rng = np.random.default_rng(seed)
+    for n in list(range(0, 70)) + [100, 127, 128, 129, 160, 255, 256, 257, 258, 320, 511, 512, 700, 2000, 2500]:
+        for p in _patterns(rng, n):
+            yield np.ascontiguousarray(p, np.float32)
+    for _ in range(400):
+        n = int(rng.integers(21, 513))
+        k = int(rng.integers(1, 12))
+        vals = rng.random(k, dtype=np.float32)
+        p = vals[rng.integers(0, k, n)]
+        if rng.random() < 0.5:  # mostly distinct with a few repeated values, like a beam step
+            q = rng.random(n, dtype=np.float32)
+            m = rng.random(n) < 0.3
+            p = np.where(m, p, q).astype(np.float32)
+        yield np.ascontiguousarray(p, np.float32)
+
+
+def device_sort(lib, handle, lists, to_dev, from_dev):
+    stride = max(1, max(len(p) for p in lists))
+    buf = np.zeros((len(lists), stride), np.uint64)
+    lens = np.zeros(len(lists), np.int32)
+    for i, p in enumerate(lists):
+        buf[i, :len(p)] = (orderable(p) << np.uint64(32)) | np.arange(len(p), dtype=np.uint64)
+        lens[i] = len(p)
+    d_buf, d_lens = to_dev(buf), to_dev(lens)
+    rc = lib.fcd_debug_pdq178_sort_dev(handle.ptr, d_buf.ptr, len(lists), stride, d_lens.ptr)
+    assert rc == 0, lib.fcd_last_error(handle.ptr)
+    handle.synchronize()
+    return from_dev(d_buf, buf.shape, np.uint64), lens
+
+
+def check_against_oracle(out, lens, lists):
+    differs = 0
+    for i, p in enumerate(lists):
+        n = int(lens[i])
+        got = (out[i, :n] & np.uint64(0xFFFFFFFF)).astype(np.int64)
+        _, want = oracle.pdqsort_desc(p, np.arange(n, dtype=np.int32))
+        assert np.array_equal(got, want), (i, n)
+        differs += int(not np.array_equal(got, np.argsort(-p, kind="stable")))
+    return differs
+
+
+class _HostBuf:
+    def __init__(self, a):
+        self.a = np.ascontiguousarray(a).copy()
+        self.ptr = self.a.ctypes.data
+
+
+def test_device_routine_equals_the_oracle_restatement_emulated():
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    lists = list(tie_lists())
+    with emulated_kernels() as lib:
+        h = nat.default_handle(0)
+        # the emulator's "device" memory is host memory
+        out, lens = device_sort(lib, h, lists, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
+    assert check_against_oracle(out, lens, lists) > 100  # and it really is another order than the stable one
+
+
+def test_tie_order_api_emulated():
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    with emulated_kernels() as lib:
+        h = nat.default_handle(0)
+        assert h.tie_order() == nat.TIE_PDQ178          # the process default
+        h.set_tie_order(nat.TIE_STABLE)
+        assert h.tie_order() == nat.TIE_STABLE
+        h.set_tie_order(nat.TIE_DEFAULT)
+        assert lib.fcd_set_default_tie_order(nat.TIE_STABLE) == 0 and h.tie_order() == nat.TIE_STABLE
+        assert lib.fcd_set_default_tie_order(nat.TIE_PDQ178) == 0 and h.tie_order() == nat.TIE_PDQ178
+        assert lib.fcd_set_default_tie_order(7) != 0 and lib.fcd_set_tie_order(h.ptr, 7) != 0

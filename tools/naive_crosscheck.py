@@ -18,6 +18,7 @@ import test_naive_crosscheck as X
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
     out = {}
+    X.oracle.lib.fcdo_set_unstable_sort(0)  # the naive restatement sorts stably (tests/test_naive_crosscheck.py)
     runs = [("duplex logsumexp", lambda s: X.check_duplex(s, False), 10 ** 6),
             ("duplex max", lambda s: X.check_duplex(s, True), 10 ** 6),
             ("crf duplex logsumexp", lambda s: X.check_crf_duplex(s, False), 2 * 10 ** 6),
