@@ -31,6 +31,7 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
+#include "pdq178_coop.h"
 
 namespace fcd {
 
@@ -151,7 +152,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     __shared__ __attribute__((aligned(16))) int s_child[64 * RW];   // child entries of old slot i
     __shared__ int s_heads[64];
     __shared__ uint32_t s_tie[PDQ ? 2 * 66 : 2];  // probability (orderable bits) of the candidate of rank r <= beam_size
-    static_assert(sizeof(pdq178::Scratch) <= sizeof(int4) * 64, "the quicksort's scratch borrows half of s_rec");
+    // the wave-cooperative quicksort's tables (pdq178_coop.h); with them the N = 5 instantiation holds 10 KB of LDS:
+    // sixteen wavefronts per CU still fit
+    __shared__ pdq178::CoopScratch<PDQ ? N : 1> s_coop;
 
     int *hist = reinterpret_cast<int *>(s_u);                        // 256 ints      (1 KB)
     uint64_t *l_key_all = reinterpret_cast<uint64_t *>(s_u + 64);    // 128 u64      (1 KB)
@@ -343,6 +346,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 
         // ---- tree.rs:125-145 add_node: ids in (beam order, label order) ----
         const int incl = half_prefix_add<RPW>(n_new);
+        const int nn0 = nn;  // ids from here on are this step's new nodes
         if (q == 0 && act) *first_at(t) = nn;
         int next_id = nn + incl - n_new;
         nn += RPW == 1 ? rdlane(incl, 63) : bperm(hbase + HALF - 1, incl);
@@ -570,33 +574,58 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const int n_ranked = listed ? Lc : n_valid;
             const bool tied = go && n_valid > 20 && q < beam_size && q + 1 < n_ranked && tie_tab[q] == tie_tab[q + 1];
             const uint64_t m_tied = ballot(tied);
-            if (m_tied != 0ull) {
+            if (__builtin_expect(m_tied != 0ull, 0)) {
                 const bool mine_h = hmask(m_tied) != 0ull;
-                // every candidate's key side by side (the histogram / list region is free again)
+                // The list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260).  This
+                // step's new nodes are numbered in candidate order and follow every older node, so only the candidates
+                // on OLDER nodes need ranking -- against each other, four to a 16-byte LDS read.
+                pdq178::CoopScratch<N> *cs = reinterpret_cast<pdq178::CoopScratch<N> *>(&s_coop);
+                uint32_t *eid = reinterpret_cast<uint32_t *>(cs->pos_a) + hh * (HALF * N);  // (both position tables: 64 * N words)
+                bool older[N];
+                int n_older = 0;
 #pragma unroll
-                for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
+                for (int k = 0; k < N; ++k) {
+                    older[k] = mine_h && key[k] != 0ull && (k == 0 || ccand[k > 0 ? k - 1 : 0] < nn0);
+                    n_older += older[k] ? 1 : 0;
+                }
+                const int o_incl = half_prefix_add<RPW>(n_older);
+                int o_pos = o_incl - n_older;
+                const int n_old = RPW == 1 ? rdlane(o_incl, 63) : bperm(hbase + HALF - 1, o_incl);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (older[k]) eid[o_pos++] = (uint32_t)key[k];  // low word: larger = smaller node
+                if (q < 4) eid[n_old + q] = 0u;                     // (padding of the last 16-byte read: never "smaller")
                 wave_sync();
-                // the list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260)
+                int n_old_max = n_old;
+                if (RPW == 2) n_old_max = max(n_old_max, __shfl_xor(n_old_max, 32));
+                n_old_max = __builtin_amdgcn_readfirstlane(n_old_max);
                 int pos[N];
 #pragma unroll
                 for (int k = 0; k < N; ++k) pos[k] = 0;
 #pragma unroll 1
-                for (int j = 0; j < HALF * N; ++j) {
-                    const uint64_t kj = c_key[hbase * N + j];
+                for (int j = 0; j < n_old_max; j += 4) {
+                    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                    if (j < n_old) e = *reinterpret_cast<const uint4 *>(eid + j);
 #pragma unroll
-                    for (int k = 0; k < N; ++k)
-                        pos[k] += (kj != 0ull && (uint32_t)kj > (uint32_t)key[k]) ? 1 : 0;  // low word: larger = smaller node
+                    for (int k = 0; k < N; ++k) {
+                        const uint32_t me = (uint32_t)key[k];
+                        pos[k] += ((e.x > me) ? 1 : 0) + ((e.y > me) ? 1 : 0) + ((e.z > me) ? 1 : 0) + ((e.w > me) ? 1 : 0);
+                    }
                 }
-                wave_sync();
+                wave_sync();  // (the table the ids sat in is the sort's scratch from here on)
                 uint64_t *list = c_key + hbase * N;
 #pragma unroll
-                for (int k = 0; k < N; ++k)
-                    if (mine_h && key[k] != 0ull) list[pos[k]] = (key[k] & 0xFFFFFFFF00000000ull) | (uint32_t)(lane * 8 + k);
+                for (int k = 0; k < N; ++k) {
+                    if (!mine_h || key[k] == 0ull) continue;
+                    const int at = older[k] ? pos[k] : n_old + (ccand[k > 0 ? k - 1 : 0] - nn0);
+                    list[at] = (key[k] & 0xFFFFFFFF00000000ull) | (uint32_t)(lane * 8 + k);
+                }
                 if (mine_h) *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
                 wave_sync();
-                if (mine_h && q == 0)
-                    pdq178::sort_desc(list, n_valid, reinterpret_cast<pdq178::Scratch *>(s_rec + 64 * hh));
-                wave_sync();
+                // both reads of the wavefront at once, all 64 lanes (pdq178_coop.h)
+                const bool f0 = (m_tied & 0xFFFFFFFFull) != 0ull || (RPW == 1 && m_tied != 0ull), f1 = RPW == 2 && (m_tied >> 32) != 0ull;
+                const int len0 = f0 ? rdlane(n_valid, 0) : 0, len1 = f1 ? rdlane(n_valid, 32) : 0;
+                pdq178::coop_sort<N>(c_key, 0, len0, HALF * N, len1, cs, lane);
                 for (int j = q; mine_h && j < Bn; j += HALF) s_rank[(int)(uint32_t)list[j]] = (int8_t)j;
                 wave_sync();
                 const uint64_t again = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);

@@ -51,6 +51,7 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
+#include "pdq178_coop.h"
 
 namespace fcd {
 
@@ -117,9 +118,9 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // Rust 1.78's sort_unstable_by leaves them in (:122,262).  Every step still takes its exact rank on (probability
 // desc, node asc); the candidates of rank <= beam_size also leave their probability in a small table by rank, so
 // one compare per slot says whether a KEPT candidate ties with its successor.  Only then (a few steps per thousand
-// reads on the BASELINE generator) the half builds the node-ordered candidate list in LDS, one lane replays the
-// quicksort on it (pdq178.h) and the ranks it produces replace the exact ones.  Instantiated only for shapes that
-// can hold more than 20 candidates.
+// reads on the BASELINE generator) the half builds the node-ordered candidate list in LDS, the wavefront replays the
+// quicksort on it (pdq178_coop.h) and the ranks it produces replace the exact ones.  Instantiated only for shapes
+// that can hold more than 20 candidates.
 template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false, bool H16 = false, bool PDQ = false>
 __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     // and the quicksort's scratch of a tie-flagged step
     __shared__ uint32_t s_tie[PDQ ? kWavesPerBlock : 1][RPW * 16];
     __shared__ uint64_t s_list[PDQ ? kWavesPerBlock : 1][64];
-    __shared__ pdq178::Scratch s_scr[PDQ ? kWavesPerBlock : 1][RPW];
+    __shared__ pdq178::CoopScratch<1> s_coop[PDQ ? kWavesPerBlock : 1];
     static_assert(!PDQ || BCAP * N > 20, "the tie order only matters above 20 candidates");
     int n_amb = 0, n_crit = 0;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -186,6 +187,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     uint64_t *keys = s_keys[wave];
     int *srcs = s_srcs[wave] + (hbase ? 16 : 0);
     uint32_t *tie_tab = s_tie[PDQ ? wave : 0] + (hbase ? 16 : 0);
+    // smallest candidate count from which "rank i ties with rank i + 1" is the quicksort's business: more than 20
+    // candidates, rank i kept, rank i + 1 present (never, for a lane outside the beam's groups)
+    const int tie_lim = (!idle && i < p.a.beam_size) ? (i + 1 > 20 ? i + 1 : 20) : 0x7FFFFFFF;
     if (lane < RPW * 16) s_srcs[wave][lane] = 0x7FFFFF00;  // never the minimum depth; points at lane 0
 
     const int64_t local = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW + (lane / HALF);
@@ -448,38 +452,83 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         // in order, so the store, the read-back and the two look-ups below share ONE round trip (a ds_permute
         // to the new slot followed by a broadcast to its group were two dependent ones).
         const int depc = depth + (is_child ? 1 : 0);
+        const int tipfc = is_self ? tipf : (k << 2);
+        const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
+                                             : state;  // :97
+        const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
+        // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
+        // its row is in HBM); read off the entry BEFORE it is marked below
+        const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
+        const int meta = kind | tipfc | (depc << 5);
+        const int child_in = child;  // (PDQ: a tie-flagged step settles twice)
         bool sel;
-        int selflag, fate, own, src_a, e_min, top_a;
+        int n_node, n_meta, n_state, n_jump, n_child;
+        float n_lp, n_gp, top;
         uint32_t tie0 = 0, tie1 = 1;
+        // Everything that depends on the ranks: survivor table, fate of the child entries, row eviction, the gather of
+        // the survivors into rank order.  PDQ: it runs on the exact ranks first; the tie table comes back with the
+        // same LDS round trip and is looked at only when the gather has landed -- a flagged step (rare) replaces the
+        // ranks and settles again.  (An eviction store of the first pass that the second does not repeat leaves a row
+        // in HBM nobody reads before it is written again: rows are read back only after their node's LAST eviction.)
         auto settle = [&]() {
             sel = valid && go && rank < beam_size;
-            selflag = sel ? (rank | 16) : 0;
+            const int selflag = sel ? (rank | 16) : 0;
             if (sel) srcs[rank] = (lane << 2) | (depc << 8);
-            if (PDQ && key != 0ull && go && rank <= beam_size) tie_tab[rank] = (uint32_t)(key >> 32);
+            if (PDQ && key != 0ull && rank <= beam_size) tie_tab[rank] = (uint32_t)(key >> 32);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            fate = bperm(hbase + mslot * GW, selflag);
-            own = bperm(grp0, selflag);  // ... and this group's own candidate?
+            const int fate = bperm(hbase + mslot * GW, selflag);
+            const int own = bperm(grp0, selflag);  // ... and this group's own candidate?
             // every lane of new group i learns its source lane (stale beyond the new beam: unused), where the best
             // candidate sits, and the SMALLEST DEPTH in the new beam: a stale entry can only lower it
-            src_a = srcs[i] & 0xFF;  // byte address, as ds_bpermute wants it
-            e_min = srcs[0];
-            top_a = e_min & 0xFF;
+            const int src_a = srcs[i] & 0xFF;  // byte address, as ds_bpermute wants it
+            int e_min = srcs[0];
+            const int top_a = e_min & 0xFF;
 #pragma unroll
             for (int j = 1; j < BCAP; ++j) e_min = min(e_min, srcs[j]);
             if (PDQ) {
                 tie0 = tie_tab[i];
                 tie1 = tie_tab[i + 1];
             }
+            {
+                // a child entry whose node is a beam entry follows it to its new slot (or learns it left);
+                // a child entering the beam is marked EVER: from now on it may own children
+                const int followed = (child_in & kStored) | (fate << kSlotShift);
+                const int entered = id | kEver | (selflag << kSlotShift);
+                const bool upd = go && is_child;
+                child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child_in);
+                // A node's child row only has to exist in HBM while the node is OUT of the beam (it is read back if
+                // the node re-enters, below): write it once, when the node is evicted -- four lanes, 16 contiguous
+                // bytes.  And only if the node can come back at all: a node re-enters the beam as the extension of its
+                // parent, so it needs a proper ancestor in the beam -- none exists once every beam entry is at least as
+                // deep as the node, and then none ever will (its ancestors have left for good, top-down from the
+                // root).  Three evicted rows in four are dead by this test and are never written.
+                const bool dead = (depth << 8) <= e_min;  // e_min = (minimum depth << 8) | a lane address
+                if (upd && grp && own == 0 && !dead)
+                    *at32(rows_w, (hoff + (uint32_t)(node + 1)) * RW + l) = child;  // (beam-position bits and all: stripped when read back)
+            }
+            stamp_i(4, child);  // fate of every child entry, row eviction
+            // ---- gather the survivors into rank order ----
+            n_node = __builtin_amdgcn_ds_bpermute(src_a, id);
+            n_lp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(clp)));
+            n_gp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(cgp)));
+            n_meta = __builtin_amdgcn_ds_bpermute(src_a, meta);
+            n_state = CRF ? __builtin_amdgcn_ds_bpermute(src_a, statec) : 0;
+            n_jump = __builtin_amdgcn_ds_bpermute(src_a, jumpc);
+            n_child = __builtin_amdgcn_ds_bpermute(src_a + (k << 2), child);  // meaningful when the source is a self lane
+            top = __int_as_float(__builtin_amdgcn_ds_bpermute(top_a, __float_as_int(prob)));  // beam[0].probability() :278 = its candidate's label + gap probability
+            stamp_f(5, n_lp);  // survivors gathered into rank order
         };
         settle();
         if (PDQ) {
             // ranks i and i + 1 hold one probability, rank i is kept and rank i + 1 exists: sort_unstable_by's order
-            // of the two is pdqsort's business once the list is longer than 20 (:262)
-            const bool tied = go && n_valid > 20 && i < beam_size && i + 1 < n_valid && tie0 == tie1;
-            const uint64_t m_tied = ballot(tied);
-            if (m_tied != 0ull) {
+            // of the two is pdqsort's business once the list is longer than 20 (:262).  tie_lim folds "i < beam_size",
+            // "i + 1 < n_valid" and "n_valid > 20" into one compare; the votes are unconditional (convergent), so the
+            // table reads above cannot be sunk behind a branch and a wait of their own.  (A half that is not running,
+            // or has just failed, has no candidates or loses nothing by re-ranking them.)
+            const uint64_t m_tied = ballot(tie0 == tie1) & ballot(tie_lim < n_valid);
+            if (__builtin_expect(m_tied != 0ull, 0)) {
                 const bool mine = RPW == 1 ? true : (hbase ? (m_tied >> 32) != 0ull : (uint32_t)m_tied != 0u);
                 uint64_t *list = s_list[wave] + hbase;
                 int *newrank = s_heads[wave];  // (free until the traceback)
@@ -494,7 +543,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (mine && q == 0) pdq178::sort_desc(list, n_valid, &s_scr[wave][RPW == 1 ? 0 : (hbase ? 1 : 0)]);
+                {   // the whole wavefront replays the quicksort, on both halves' lists at once (pdq178_coop.h)
+                    const bool f0 = RPW == 1 || (uint32_t)m_tied != 0u, f1 = RPW == 2 && (m_tied >> 32) != 0ull;
+                    const int len0 = f0 ? __builtin_amdgcn_readlane(n_valid, 0) : 0;
+                    const int len1 = f1 ? __builtin_amdgcn_readlane(n_valid, 32) : 0;
+                    pdq178::coop_sort<1>(s_list[wave], 0, len0, 32, len1, &s_coop[wave], lane);
+                }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -516,43 +570,6 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             n_amb += (RPW == 1 ? m_tie : (hbase ? (m_tie >> 32) : (m_tie & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
             n_crit += (RPW == 1 ? m_crit : (hbase ? (m_crit >> 32) : (m_crit & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
         }
-        // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
-        // its row is in HBM); read off the entry BEFORE it is marked below
-        const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
-        {
-            // a child entry whose node is a beam entry follows it to its new slot (or learns it left);
-            // a child entering the beam is marked EVER: from now on it may own children
-            const int followed = (child & kStored) | (fate << kSlotShift);
-            const int entered = id | kEver | (selflag << kSlotShift);
-            const bool upd = go && is_child;
-            child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child);
-            // A node's child row only has to exist in HBM while the node is OUT of the beam (it is read back if
-            // the node re-enters, below): write it once, when the node is evicted -- four lanes, 16 contiguous
-            // bytes.  And only if the node can come back at all: a node re-enters the beam as the extension of its
-            // parent, so it needs a proper ancestor in the beam -- none exists once every beam entry is at least as
-            // deep as the node, and then none ever will (its ancestors have left for good, top-down from the
-            // root).  Three evicted rows in four are dead by this test and are never written.
-            const bool dead = (depth << 8) <= e_min;  // e_min = (minimum depth << 8) | a lane address
-            if (upd && grp && own == 0 && !dead)
-                *at32(rows_w, (hoff + (uint32_t)(node + 1)) * RW + l) = child;  // (beam-position bits and all: stripped when read back)
-        }
-
-        stamp_i(4, child);  // fate of every child entry, row eviction
-        // ---- gather the survivors into rank order ----
-        const int tipfc = is_self ? tipf : (k << 2);
-        const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
-                                             : state;  // :97
-        const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
-        const int meta = kind | tipfc | (depc << 5);
-        const int n_node = __builtin_amdgcn_ds_bpermute(src_a, id);
-        float n_lp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(clp)));
-        const float n_gp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(cgp)));
-        const int n_meta = __builtin_amdgcn_ds_bpermute(src_a, meta);
-        const int n_state = CRF ? __builtin_amdgcn_ds_bpermute(src_a, statec) : 0;
-        const int n_jump = __builtin_amdgcn_ds_bpermute(src_a, jumpc);
-        int n_child = __builtin_amdgcn_ds_bpermute(src_a + (k << 2), child);  // meaningful when the source is a self lane
-        const float top = __int_as_float(__builtin_amdgcn_ds_bpermute(top_a, __float_as_int(prob)));  // beam[0].probability() :278 = its candidate's label + gap probability
-        stamp_f(5, n_lp);  // survivors gathered into rank order
         const int n_kind = n_meta & 3;
         const bool ngrp = go && i < Bn;
         if (n_kind == 1 || !is_child) n_child = -1;

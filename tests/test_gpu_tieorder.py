@@ -9,7 +9,7 @@ import pytest
 import test_gpu_duplex as D
 import test_gpu_parity as P
 from oracle import oracle
-from test_pdq178 import check_against_oracle, device_sort, tie_lists
+from test_pdq178 import check_against_oracle, coop_lists, device_coop_sort, device_sort, tie_lists
 from tie_util import ORDERS, tie_order
 
 pytestmark = pytest.mark.gpu
@@ -45,6 +45,28 @@ def test_device_routine_equals_the_oracle_restatement(fcd):
     finally:
         h.reset_stream()
     assert check_against_oracle(out, lens, lists) > 100
+
+
+@pytest.mark.parametrize("planes", [1, 5, 8])
+def test_cooperative_routine_equals_the_oracle_restatement(fcd, planes):
+    """csrc/pdq178_coop.h as compiled for gfx950: the whole wavefront on two lists at once"""
+    torch = pytest.importorskip("torch")
+    from fast_ctc_decode_amd import _native as nat
+
+    class Dev:
+        def __init__(self, a):
+            self.t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+            self.ptr = self.t.data_ptr()
+
+    lists = coop_lists(planes)
+    h = nat.default_handle(0)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        out, lens = device_coop_sort(nat.load(), h, lists, planes, Dev,
+                                     lambda d, shape, dt: d.t.cpu().numpy().view(dt).reshape(shape))
+    finally:
+        h.reset_stream()
+    assert check_against_oracle(out, lens, lists) > (10 if planes == 1 else 100)
 
 
 def results(fcd, x, beam, thr, collapse, kernel, lengths=None):

@@ -63,6 +63,44 @@ def check_against_oracle(out, lens, lists):
     return differs
 
 
+def coop_lists(planes, seed=1):
+    """lists for the wave-cooperative routine: consecutive pairs share a wavefront (their lengths add up to at most
+    64 * planes positions); every regime of the serial routine, plus pairs of beam-like lists with few distinct values"""
+    cap = 64 * planes
+    rng = np.random.default_rng(seed)
+    out = []
+    pool = [p for p in tie_lists(seed) if len(p) <= cap]
+    for i, p in enumerate(pool):
+        room = cap - len(p)
+        partner = pool[(i * 7 + 3) % len(pool)]
+        out.append(p)
+        out.append(partner if len(partner) <= room else partner[:room])
+    for _ in range(300):  # what the kernels hand over: two lists of up to half the positions each
+        for _side in range(2):
+            n = int(rng.integers(0, cap // 2 + 1))
+            k = int(rng.integers(1, 9))
+            vals = rng.random(k, dtype=np.float32)
+            p = vals[rng.integers(0, k, n)] if n else np.zeros(0, np.float32)
+            if rng.random() < 0.6 and n:
+                p = np.where(rng.random(n) < 0.35, p, rng.random(n, dtype=np.float32)).astype(np.float32)
+            out.append(np.ascontiguousarray(p, np.float32))
+    return out
+
+
+def device_coop_sort(lib, handle, lists, planes, to_dev, from_dev):
+    stride = max(1, max(len(p) for p in lists))
+    buf = np.zeros((len(lists), stride), np.uint64)
+    lens = np.zeros(len(lists), np.int32)
+    for i, p in enumerate(lists):
+        buf[i, :len(p)] = (orderable(p) << np.uint64(32)) | np.arange(len(p), dtype=np.uint64)
+        lens[i] = len(p)
+    d_buf, d_lens = to_dev(buf), to_dev(lens)
+    rc = lib.fcd_debug_pdq178_coop_sort_dev(handle.ptr, d_buf.ptr, len(lists), stride, d_lens.ptr, planes)
+    assert rc == 0, lib.fcd_last_error(handle.ptr)
+    handle.synchronize()
+    return from_dev(d_buf, buf.shape, np.uint64), lens
+
+
 class _HostBuf:
     def __init__(self, a):
         self.a = np.ascontiguousarray(a).copy()
@@ -78,6 +116,19 @@ def test_device_routine_equals_the_oracle_restatement_emulated():
         # the emulator's "device" memory is host memory
         out, lens = device_sort(lib, h, lists, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
     assert check_against_oracle(out, lens, lists) > 100  # and it really is another order than the stable one
+
+
+@pytest.mark.parametrize("planes", [1, 5, 8])
+def test_cooperative_routine_equals_the_oracle_restatement_emulated(planes):
+    """csrc/pdq178_coop.h -- the whole wavefront replaying the quicksort on two lists at once (level by level, ballots
+    for partition_in_blocks' offsets, leaves ranked in parallel) -- must produce the serial routine's permutation"""
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    lists = coop_lists(planes)
+    with emulated_kernels() as lib:
+        h = nat.default_handle(0)
+        out, lens = device_coop_sort(lib, h, lists, planes, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
+    assert check_against_oracle(out, lens, lists) > (10 if planes == 1 else 100)
 
 
 def test_tie_order_api_emulated():
