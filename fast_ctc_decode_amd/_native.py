@@ -125,7 +125,7 @@ def bind(lib):
     lib.fcd_get_tie_order.argtypes = [P]
     lib.fcd_set_default_tie_order.argtypes = [i32]
     lib.fcd_debug_pdq178_sort_dev.argtypes = [P, P, i64, i64, P]
-    lib.fcd_debug_pdq178_coop_sort_dev.argtypes = [P, P, i64, i64, P, i32]
+    lib.fcd_debug_pdq178_coop_sort_dev.argtypes = [P, P, i64, i64, P, i32, i32]
     lib.fcd_debug_set_first_pass_divisor.argtypes = [P, i32]
     lib.fcd_debug_set_duplex_profile.argtypes = [P, P]
     lib.fcd_last_kernel_ms.argtypes = [P]

@@ -625,7 +625,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 // both reads of the wavefront at once, all 64 lanes (pdq178_coop.h)
                 const bool f0 = (m_tied & 0xFFFFFFFFull) != 0ull || (RPW == 1 && m_tied != 0ull), f1 = RPW == 2 && (m_tied >> 32) != 0ull;
                 const int len0 = f0 ? rdlane(n_valid, 0) : 0, len1 = f1 ? rdlane(n_valid, 32) : 0;
-                pdq178::coop_sort<N>(c_key, 0, len0, HALF * N, len1, cs, lane);
+                pdq178::coop_sort<N>(c_key, 0, len0, HALF * N, len1, beam_size, cs, lane);
                 for (int j = q; mine_h && j < Bn; j += HALF) s_rank[(int)(uint32_t)list[j]] = (int8_t)j;
                 wave_sync();
                 const uint64_t again = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);

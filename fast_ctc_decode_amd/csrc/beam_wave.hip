@@ -547,7 +547,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
                     const bool f0 = RPW == 1 || (uint32_t)m_tied != 0u, f1 = RPW == 2 && (m_tied >> 32) != 0ull;
                     const int len0 = f0 ? __builtin_amdgcn_readlane(n_valid, 0) : 0;
                     const int len1 = f1 ? __builtin_amdgcn_readlane(n_valid, 32) : 0;
-                    pdq178::coop_sort<1>(s_list[wave], 0, len0, 32, len1, &s_coop[wave], lane);
+                    pdq178::coop_sort<1>(s_list[wave], 0, len0, 32, len1, beam_size, &s_coop[wave], lane);
                 }
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();

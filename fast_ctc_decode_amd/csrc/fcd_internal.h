@@ -179,7 +179,7 @@ hipError_t launch_logadd_chain(int n_chain, int mode, uint64_t *cycles, float *s
 hipError_t launch_logadd_sweep(int which, uint32_t first, uint32_t last, unsigned long long *counts, hipStream_t stream);
 hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, hipStream_t stream);
 hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, int planes,
-                                    hipStream_t stream);
+                                    int keep, hipStream_t stream);
 // the tie order searches on this handle use (capi.hip)
 int effective_tie_order(const fcd_handle *h);
 

@@ -40,17 +40,21 @@ struct Scratch {
 };
 
 #define FCD_PDQ_FN static __device__ inline
+// The list may sit behind a generic pointer (elem_t *) or an LDS one (pdq178_coop.h: ds_* instructions instead of
+// flat_* ones -- a third of the latency): the helpers take either.
 
 FCD_PDQ_FN bool less(elem_t a, elem_t b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); }
 
-FCD_PDQ_FN void swp(elem_t *v, int a, int b) {
+template <typename V>
+FCD_PDQ_FN void swp(V v, int a, int b) {
     const elem_t t = v[a];
     v[a] = v[b];
     v[b] = t;
 }
 
 // insert_tail: v[n - 1] into the sorted v[0 .. n - 1)
-FCD_PDQ_FN void insert_tail(elem_t *v, int n) {
+template <typename V>
+FCD_PDQ_FN void insert_tail(V v, int n) {
     const elem_t x = v[n - 1];
     int j = n - 1;
     while (j > 0 && less(x, v[j - 1])) {
@@ -61,7 +65,8 @@ FCD_PDQ_FN void insert_tail(elem_t *v, int n) {
 }
 
 // insert_head: v[0] into the sorted v[1 .. n)
-FCD_PDQ_FN void insert_head(elem_t *v, int n) {
+template <typename V>
+FCD_PDQ_FN void insert_head(V v, int n) {
     if (n < 2 || !less(v[1], v[0])) return;
     const elem_t x = v[0];
     int j = 1;
@@ -73,15 +78,18 @@ FCD_PDQ_FN void insert_head(elem_t *v, int n) {
     v[j] = x;
 }
 
-FCD_PDQ_FN void shift_left(elem_t *v, int len, int offset) {   // insertion_sort_shift_left
+template <typename V>
+FCD_PDQ_FN void shift_left(V v, int len, int offset) {   // insertion_sort_shift_left
     for (int i = offset; i < len; ++i) insert_tail(v, i + 1);
 }
 
-FCD_PDQ_FN void shift_right(elem_t *v, int len, int offset) {  // insertion_sort_shift_right
+template <typename V>
+FCD_PDQ_FN void shift_right(V v, int len, int offset) {  // insertion_sort_shift_right
     for (int i = offset - 1; i >= 0; --i) insert_head(v + i, len - i);
 }
 
-FCD_PDQ_FN bool partial_insertion_sort(elem_t *v, int len) {
+template <typename V>
+FCD_PDQ_FN bool partial_insertion_sort(V v, int len) {
     const int kMaxSteps = 5, kShortestShifting = 50;
     int i = 1;
     for (int step = 0; step < kMaxSteps; ++step) {
@@ -97,7 +105,8 @@ FCD_PDQ_FN bool partial_insertion_sort(elem_t *v, int len) {
     return false;
 }
 
-FCD_PDQ_FN void sift_down(elem_t *v, int len, int node) {
+template <typename V>
+FCD_PDQ_FN void sift_down(V v, int len, int node) {
     for (;;) {
         int child = 2 * node + 1;
         if (child >= len) break;
@@ -108,7 +117,8 @@ FCD_PDQ_FN void sift_down(elem_t *v, int len, int node) {
     }
 }
 
-FCD_PDQ_FN void heapsort(elem_t *v, int len) {
+template <typename V>
+FCD_PDQ_FN void heapsort(V v, int len) {
     for (int i = len / 2 - 1; i >= 0; --i) sift_down(v, len, i);
     for (int i = len - 1; i >= 1; --i) {
         swp(v, 0, i);
@@ -116,7 +126,8 @@ FCD_PDQ_FN void heapsort(elem_t *v, int len) {
     }
 }
 
-FCD_PDQ_FN void break_patterns(elem_t *v, int len) {
+template <typename V>
+FCD_PDQ_FN void break_patterns(V v, int len) {
     if (len < 8) return;
     uint64_t seed = (uint64_t)len;  // usize is 64 bits on every platform the reference ships wheels for
     uint64_t modulus = 1;
@@ -132,7 +143,8 @@ FCD_PDQ_FN void break_patterns(elem_t *v, int len) {
     }
 }
 
-FCD_PDQ_FN void sort2(const elem_t *v, int &a, int &b, int &swaps) {
+template <typename V>
+FCD_PDQ_FN void sort2(V v, int &a, int &b, int &swaps) {
     if (less(v[b], v[a])) {
         const int t = a;
         a = b;
@@ -141,13 +153,15 @@ FCD_PDQ_FN void sort2(const elem_t *v, int &a, int &b, int &swaps) {
     }
 }
 
-FCD_PDQ_FN void sort3(const elem_t *v, int &a, int &b, int &c, int &swaps) {
+template <typename V>
+FCD_PDQ_FN void sort3(V v, int &a, int &b, int &c, int &swaps) {
     sort2(v, a, b, swaps);
     sort2(v, b, c, swaps);
     sort2(v, a, b, swaps);
 }
 
-FCD_PDQ_FN int choose_pivot(elem_t *v, int len, bool &likely_sorted) {
+template <typename V>
+FCD_PDQ_FN int choose_pivot(V v, int len, bool &likely_sorted) {
     const int kShortestMedianOfMedians = 50, kMaxSwaps = 4 * 3;
     int a = len / 4 * 1, b = len / 4 * 2, c = len / 4 * 3;
     int swaps = 0;
@@ -254,10 +268,11 @@ FCD_PDQ_FN int partition(elem_t *v, int len, int pivot_idx, bool &was_partitione
     return mid;
 }
 
-FCD_PDQ_FN int partition_equal(elem_t *v, int len, int pivot_idx) {
+template <typename V>
+FCD_PDQ_FN int partition_equal(V v, int len, int pivot_idx) {
     swp(v, 0, pivot_idx);
     const elem_t pivot = v[0];
-    elem_t *w = v + 1;
+    V w = v + 1;
     const int wn = len - 1;
     if (wn == 0) return 0;
     int l = 0, r = wn;

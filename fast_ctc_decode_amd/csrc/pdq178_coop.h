@@ -30,19 +30,22 @@ namespace pdq178 {
 constexpr int kCoopMaxLen = 2 * kBlock + 1;  // the pivot + at most 2 * BLOCK elements: partition_in_blocks is done in one round
 
 template <int MAXP>  // planes of 64 positions: the lists live in v[0 .. 64 * MAXP)
-struct CoopScratch {
+struct alignas(16) CoopScratch {
     static constexpr int kPos = 64 * MAXP;
     static constexpr int kMaxSeg = kPos / 21 + 2;  // segments longer than 20 elements that can coexist
     uint16_t pos_a[kPos];        // position of the k-th misplaced element of a segment's left side (at [wb + k])
     uint16_t pos_b[kPos];        // ... of its right side, counted from the right end
     uint8_t cut[kPos + 8];       // 1 = a finished boundary: a leaf / pivot / list starts here
-    int16_t seg[2][kMaxSeg][4];  // {base, len, pred, limit | was_balanced << 8 | was_partitioned << 9}, this round / next
-    uint32_t key[kMaxSeg];       // this round: the pivot's key ...
-    int16_t rt[kMaxSeg][14];     // ... and what the segment's leader decided (fields: enum below)
-};  // (16-bit fields: the wide-beam kernel has 2.5 KB of LDS left at four wavefronts per SIMD)
+    int16_t seg[kMaxSeg][4];     // {base, len, pred, limit | was_balanced << 8 | was_partitioned << 9}: lane i leads segment i
+};  // (what a leader decides in a round stays in its registers; elements fetch it with ds_bpermute / v_readlane)
 
 enum { kActDone = 0, kActNormal = 1, kActEqual = 2 };
-enum { R_ACT = 0, R_WB, R_WE, R_A0, R_A1, R_A2, R_P0, R_P1, R_P2, R_COUNT, R_CL, R_CR };
+
+#ifdef FCD_HIPEMU
+#define FCD_LDS_AS
+#else
+#define FCD_LDS_AS __attribute__((address_space(3)))  // ds_* instructions instead of flat_* ones: a third of the latency
+#endif
 
 namespace coop_detail {
 
@@ -102,15 +105,20 @@ struct Masks {
 }  // namespace coop_detail
 
 // Sorts up to two lists v[start0 .. start0 + len0) and v[start1 .. start1 + len1) (len 0 = absent; the ranges must not
-// overlap and must lie inside [0, 64 * MAXP)) into the order sort_unstable_by leaves them in.  Called by all 64 lanes
-// of a wavefront with the same arguments; `lane` = the caller's lane; v and s are LDS.
+// overlap, start0 < start1, both inside [0, 64 * MAXP)) into the order sort_unstable_by leaves them in -- as far as the
+// first `keep` positions of each list go: a segment that lies wholly behind them is dropped (segments never exchange
+// elements, so the kept prefix cannot tell).  Called by all 64 lanes of a wavefront with the same arguments; `lane` =
+// the caller's lane; v and s are LDS.
 template <int MAXP>
-__device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int len0, int start1, int len1,
-                                                    CoopScratch<MAXP> *s, int lane) {
+__device__ __attribute__((noinline)) void coop_sort(elem_t *v_generic, int start0, int len0, int start1, int len1, int keep,
+                                                    CoopScratch<MAXP> *s_generic, int lane) {
     using namespace coop_detail;
     constexpr int kPos = 64 * MAXP;
     static_assert(sizeof(Scratch) * 2 <= sizeof(uint16_t) * 2 * kPos || kPos < kCoopMaxLen,
                   "the serial fall-back borrows the position tables as its scratch");
+    typedef FCD_LDS_AS elem_t *vptr;
+    const vptr v = (vptr)v_generic;
+    FCD_LDS_AS CoopScratch<MAXP> *const s = (FCD_LDS_AS CoopScratch<MAXP> *)s_generic;
 
     // ---- boundaries known from the start; lists that are leaves or too long for one-round partitions ----
     for (int p = lane; p < kPos + 8; p += 64) s->cut[p] = 0;
@@ -124,7 +132,7 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
             s->cut[st] = 1;
             s->cut[st + ln] = 1;
             if (ln > 20 && ln <= kCoopMaxLen) {
-                int16_t *f = s->seg[0][nseg++];
+                FCD_LDS_AS int16_t *f = s->seg[nseg++];
                 int limit = 0;  // usize::BITS - len.leading_zeros()
                 for (uint32_t m = (uint32_t)ln; m; m >>= 1) ++limit;
                 f[0] = (int16_t)st;
@@ -136,27 +144,29 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
     }
     nseg = __builtin_amdgcn_readfirstlane(nseg);
     if (kPos >= kCoopMaxLen && (len0 > kCoopMaxLen || len1 > kCoopMaxLen)) {
-        Scratch *ser = reinterpret_cast<Scratch *>(s->pos_a);
-        if (lane == 0 && len0 > kCoopMaxLen) sort_desc(v + start0, len0, ser);
-        if (lane == 32 && len1 > kCoopMaxLen) sort_desc(v + start1, len1, ser + 1);
+        Scratch *ser = reinterpret_cast<Scratch *>(s_generic->pos_a);
+        if (lane == 0 && len0 > kCoopMaxLen) sort_desc(v_generic + start0, len0, ser);
+        if (lane == 32 && len1 > kCoopMaxLen) sort_desc(v_generic + start1, len1, ser + 1);
     }
     sync();
 
-    int cur = 0;
     while (nseg > 0) {
         // ---- A: every segment's leader picks the pivot (and does what only ever touches a few elements) ----
         int base = 0, len = 0, pred = -1, limit = 0;
         bool wbal = true, wpar = true;
         int act = kActDone;
+        uint32_t pk = 0;
+        elem_t piv = 0;
         if (lane < nseg) {
-            const int16_t *f = s->seg[cur][lane];
+            FCD_LDS_AS const int16_t *f = s->seg[lane];
             base = f[0];
             len = f[1];
             pred = f[2];
-            limit = f[3] & 255;
-            wbal = (f[3] & 256) != 0;
-            wpar = (f[3] & 512) != 0;
-            elem_t *w = v + base;
+            const int fl = f[3];
+            limit = fl & 255;
+            wbal = (fl & 256) != 0;
+            wpar = (fl & 512) != 0;
+            const vptr w = v + base;
             if (limit == 0) {
                 heapsort(w, len);
             } else {
@@ -164,20 +174,75 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
                     break_patterns(w, len);
                     --limit;
                 }
-                bool likely_sorted = false;
-                const int pivot = choose_pivot(w, len, likely_sorted);
-                if (wbal && wpar && likely_sorted && partial_insertion_sort(w, len)) {
-                    act = kActDone;
-                } else {
-                    act = (pred >= 0 && !less(v[pred], w[pivot])) ? kActEqual : kActNormal;
-                    swp(w, 0, pivot);
+                // choose_pivot with its samples loaded up front: the adjacent triples around len/4, len/2, 3 len/4 (from
+                // 50 elements: Tukey's ninther), the predecessor, the first element -- one LDS round trip
+                const bool ninther = len >= 50;
+                const int ia = len / 4, ib = len / 4 * 2, ic = len / 4 * 3;
+                elem_t e[9];
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int c = t == 0 ? ia : (t == 1 ? ib : ic);
+                    e[3 * t + 1] = w[c];
+                    e[3 * t] = ninther ? w[c - 1] : 0;
+                    e[3 * t + 2] = ninther ? w[c + 1] : 0;
+                }
+                const elem_t first = w[0];
+                const elem_t pe = pred >= 0 ? v[pred] : 0;
+                int swaps = 0;
+                int ix[3];
+                elem_t ev[3];
+                auto srt2 = [&](int &a, elem_t &ea, int &b, elem_t &eb) {  // sort2: the smaller (in sort order) index first
+                    if (less(eb, ea)) {
+                        const int ti = a;
+                        a = b;
+                        b = ti;
+                        const elem_t te = ea;
+                        ea = eb;
+                        eb = te;
+                        ++swaps;
+                    }
+                };
+#pragma unroll
+                for (int t = 0; t < 3; ++t) {
+                    const int c = t == 0 ? ia : (t == 1 ? ib : ic);
+                    int lo = c - 1, mi = c, hi = c + 1;
+                    elem_t elo = e[3 * t], emi = e[3 * t + 1], ehi = e[3 * t + 2];
+                    if (ninther) {  // sort_adjacent: the median of (c - 1, c, c + 1) replaces c
+                        srt2(lo, elo, mi, emi);
+                        srt2(mi, emi, hi, ehi);
+                        srt2(lo, elo, mi, emi);
+                    }
+                    ix[t] = mi;
+                    ev[t] = emi;
+                }
+                srt2(ix[0], ev[0], ix[1], ev[1]);
+                srt2(ix[1], ev[1], ix[2], ev[2]);
+                srt2(ix[0], ev[0], ix[1], ev[1]);
+                int pivot = ix[1];
+                elem_t pval = ev[1];
+                bool likely_sorted = swaps == 0;
+                bool moved = false;  // the samples above no longer describe the segment
+                if (swaps >= 12) {
+                    for (int i = 0; i < len / 2; ++i) swp(w, i, len - 1 - i);  // v.reverse()
+                    pivot = len - 1 - pivot;
+                    likely_sorted = true;
+                    moved = true;
+                }
+                bool done = false;
+                if (wbal && wpar && likely_sorted) {
+                    done = partial_insertion_sort(w, len);
+                    moved = moved || len >= 50;  // (a shorter segment is only inspected)
+                }
+                if (!done) {
+                    if (moved) pval = w[pivot];
+                    act = (pred >= 0 && !less(pe, pval)) ? kActEqual : kActNormal;
+                    const elem_t f0 = moved ? w[0] : first;   // swap(0, pivot)
+                    w[pivot] = f0;
+                    w[0] = pval;
+                    piv = pval;
+                    pk = (uint32_t)(pval >> 32);
                 }
             }
-            int16_t *r = s->rt[lane];
-            r[R_ACT] = (int16_t)act;
-            s->key[lane] = (uint32_t)(w[0] >> 32);
-            r[R_WB] = (int16_t)(base + 1);
-            r[R_WE] = (int16_t)(base + len);
         }
         sync();
 
@@ -192,10 +257,10 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
             bit[j] = false;
         }
         for (int sg = 0; sg < nseg; ++sg) {
-            const int16_t *r = s->rt[sg];
-            const int a = r[R_ACT], wb = r[R_WB], we = r[R_WE];
-            const uint32_t pk = s->key[sg];
+            const int a = __builtin_amdgcn_readlane(act, sg);
             if (a == kActDone) continue;
+            const int wb = __builtin_amdgcn_readlane(base, sg) + 1, we = wb - 1 + __builtin_amdgcn_readlane(len, sg);
+            const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)pk, sg);
 #pragma unroll
             for (int j = 0; j < MAXP; ++j) {
                 const int p = 64 * j + lane;
@@ -203,7 +268,7 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
                     myseg[j] = sg;
                     const uint32_t k = (uint32_t)(val[j] >> 32);
                     // NORMAL: less(e, pivot) -- the element belongs left.  EQUAL: less(pivot, e) -- it belongs right.
-                    bit[j] = a == kActNormal ? k > pk : pk > k;
+                    bit[j] = a == kActNormal ? k > k0 : k0 > k;
                 }
             }
         }
@@ -212,73 +277,70 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
         for (int j = 0; j < MAXP; ++j) mk.m[j] = __builtin_amdgcn_ballot_w64(bit[j]);
 
         // ---- C: leaders: the scans of `partition`, the block split of partition_in_blocks, the counts ----
+        int a0 = 0, a1 = 0, a2 = 0, p0 = 0, p2 = 0, count = 0, cL = 0, cR = 0;
         if (lane < nseg && act != kActDone) {
-            int16_t *r = s->rt[lane];
             const int wb = base + 1, we = base + len;
             if (act == kActNormal) {
-                const int l_abs = mk.first_zero(wb, we);            // while l < r && is_less(v[l], pivot)
-                const int last1 = mk.last_one(l_abs, we);
-                const int r_abs = last1 + 1 > l_abs ? last1 + 1 : l_abs;  // while l < r && !is_less(v[r - 1], pivot)
-                const int rem = r_abs - l_abs;                      // <= 2 * BLOCK: one round, is_done at once
-                const int s_abs = l_abs + rem / 2;                  // block_l = rem / 2, block_r = rem - block_l
-                const int p0 = mk.prefix1(l_abs), p1 = mk.prefix1(s_abs), p2 = mk.prefix1(r_abs);
-                const int cL = (s_abs - l_abs) - (p1 - p0);         // left block: elements that are NOT less than the pivot
-                const int cR = p2 - p1;                             // right block: elements that are
-                r[R_A0] = (int16_t)(l_abs);
-                r[R_A1] = (int16_t)(s_abs);
-                r[R_A2] = (int16_t)(r_abs);
-                r[R_P0] = (int16_t)(p0);
-                r[R_P1] = (int16_t)(p1);
-                r[R_P2] = (int16_t)(p2);
-                r[R_CL] = (int16_t)(cL);
-                r[R_CR] = (int16_t)(cR);
-                r[R_COUNT] = (int16_t)(cL < cR ? cL : cR);
+                a0 = mk.first_zero(wb, we);                        // while l < r && is_less(v[l], pivot)
+                const int last1 = mk.last_one(a0, we);
+                a2 = last1 + 1 > a0 ? last1 + 1 : a0;              // while l < r && !is_less(v[r - 1], pivot)
+                const int rem = a2 - a0;                           // <= 2 * BLOCK: one round, is_done at once
+                a1 = a0 + rem / 2;                                 // block_l = rem / 2, block_r = rem - block_l
+                p0 = mk.prefix1(a0);
+                const int p1 = mk.prefix1(a1);
+                p2 = mk.prefix1(a2);
+                cL = (a1 - a0) - (p1 - p0);                        // left block: elements that are NOT less than the pivot
+                cR = p2 - p1;                                      // right block: elements that are
+                count = cL < cR ? cL : cR;
             } else {
-                const int p0 = mk.prefix1(wb), p2 = mk.prefix1(we);
-                const int nE = (we - wb) - (p2 - p0);               // elements equal to the pivot: they end up on the left
-                const int z_abs = wb + nE;
-                const int p1 = mk.prefix1(z_abs);
-                r[R_A0] = (int16_t)(wb);
-                r[R_A1] = (int16_t)(z_abs);
-                r[R_A2] = (int16_t)(we);
-                r[R_P0] = (int16_t)(p0);
-                r[R_P1] = (int16_t)(p1);
-                r[R_P2] = (int16_t)(p2);
-                r[R_COUNT] = (int16_t)(p1 - p0);                               // greater ones inside the left zone == equal ones outside it
+                p0 = mk.prefix1(wb);
+                p2 = mk.prefix1(we);
+                const int nE = (we - wb) - (p2 - p0);              // elements equal to the pivot: they end up on the left
+                a0 = wb;
+                a1 = wb + nE;
+                a2 = we;
+                count = mk.prefix1(a1) - p0;                       // greater ones inside the left zone == equal ones outside it
             }
         }
-        sync();
+        // what an element needs to know about its segment, two 16-bit fields to a word, fetched from the leader's lane
+        const int w_a01 = a0 | (a1 << 16), w_a2b = a2 | ((base + 1) << 16), w_p02 = p0 | (p2 << 16), w_cnt = count | (act << 16);
 
         // ---- D: every misplaced element's index among the misplaced ones of its side -> position tables ----
-        int role[MAXP], kk[MAXP];
+        int role[MAXP], kk[MAXP], s_cnt[MAXP], s_wb[MAXP];
+        bool s_normal[MAXP];
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
+            const int src = (myseg[j] < 0 ? 0 : myseg[j]) << 2;
+            const int g_a01 = __builtin_amdgcn_ds_bpermute(src, w_a01), g_a2b = __builtin_amdgcn_ds_bpermute(src, w_a2b);
+            const int g_p02 = __builtin_amdgcn_ds_bpermute(src, w_p02), g_cnt = __builtin_amdgcn_ds_bpermute(src, w_cnt);
             role[j] = 0;
             kk[j] = 0;
+            s_cnt[j] = g_cnt & 0xFFFF;
+            s_wb[j] = g_a2b >> 16;
+            s_normal[j] = (g_cnt >> 16) == kActNormal;
             if (myseg[j] < 0) continue;
             const int p = 64 * j + lane;
-            const int16_t *r = s->rt[myseg[j]];
-            const int a0 = r[R_A0], a1 = r[R_A1], a2 = r[R_A2], wb = r[R_WB];
+            const int e0 = g_a01 & 0xFFFF, e1 = g_a01 >> 16, e2 = g_a2b & 0xFFFF, q0 = g_p02 & 0xFFFF, q2 = g_p02 >> 16;
             const int ones_before = mk.prefix1(p);
-            if (r[R_ACT] == kActNormal) {
-                if (p >= a0 && p < a1 && !bit[j]) {         // offsets_l, in tracing order (left to right)
+            if (s_normal[j]) {
+                if (p >= e0 && p < e1 && !bit[j]) {         // offsets_l, in tracing order (left to right)
                     role[j] = 1;
-                    kk[j] = (p - a0) - (ones_before - r[R_P0]);
-                    s->pos_a[wb + kk[j]] = (uint16_t)p;
-                } else if (p >= a1 && p < a2 && bit[j]) {   // offsets_r, in tracing order (right to left)
+                    kk[j] = (p - e0) - (ones_before - q0);
+                    s->pos_a[s_wb[j] + kk[j]] = (uint16_t)p;
+                } else if (p >= e1 && p < e2 && bit[j]) {   // offsets_r, in tracing order (right to left)
                     role[j] = 2;
-                    kk[j] = r[R_P2] - ones_before - 1;
-                    s->pos_b[wb + kk[j]] = (uint16_t)p;
+                    kk[j] = q2 - ones_before - 1;
+                    s->pos_b[s_wb[j] + kk[j]] = (uint16_t)p;
                 }
             } else {
-                if (p < a1 && bit[j]) {                     // a greater element inside the left zone, from the left
+                if (p < e1 && bit[j]) {                     // a greater element inside the left zone, from the left
                     role[j] = 1;
-                    kk[j] = ones_before - r[R_P0];
-                    s->pos_a[wb + kk[j]] = (uint16_t)p;
-                } else if (p >= a1 && !bit[j]) {            // an equal element outside it, from the right
+                    kk[j] = ones_before - q0;
+                    s->pos_a[s_wb[j] + kk[j]] = (uint16_t)p;
+                } else if (p >= e1 && !bit[j]) {            // an equal element outside it, from the right
                     role[j] = 2;
-                    kk[j] = (a2 - p - 1) - (r[R_P2] - ones_before);
-                    s->pos_b[wb + kk[j]] = (uint16_t)p;
+                    kk[j] = (e2 - p - 1) - (q2 - ones_before);
+                    s->pos_b[s_wb[j] + kk[j]] = (uint16_t)p;
                 }
             }
         }
@@ -289,15 +351,12 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
         // the right.  Every mover still holds its own value in a register. ----
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
-            if (role[j] == 0) continue;
-            const int16_t *r = s->rt[myseg[j]];
-            const int count = r[R_COUNT], wb = r[R_WB];
-            if (kk[j] >= count) continue;
+            if (role[j] == 0 || kk[j] >= s_cnt[j]) continue;
             int dest;
-            if (r[R_ACT] == kActNormal)
-                dest = role[j] == 1 ? s->pos_b[wb + (kk[j] == 0 ? count - 1 : kk[j] - 1)] : s->pos_a[wb + kk[j]];
+            if (s_normal[j])
+                dest = role[j] == 1 ? s->pos_b[s_wb[j] + (kk[j] == 0 ? s_cnt[j] - 1 : kk[j] - 1)] : s->pos_a[s_wb[j] + kk[j]];
             else
-                dest = role[j] == 1 ? s->pos_b[wb + kk[j]] : s->pos_a[wb + kk[j]];
+                dest = role[j] == 1 ? s->pos_b[s_wb[j] + kk[j]] : s->pos_a[s_wb[j] + kk[j]];
             v[dest] = val[j];
         }
         sync();
@@ -305,35 +364,33 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
         // ---- F: leaders: park the left-over misplaced elements, put the pivot in place, queue the children ----
         int c_base[2] = {0, 0}, c_len[2] = {0, 0}, c_pred[2] = {-1, -1}, c_flag[2] = {0, 0};
         if (lane < nseg && act != kActDone) {
-            const int16_t *r = s->rt[lane];
             const int wb = base + 1;
             if (act == kActNormal) {
-                const int count = r[R_COUNT], cL = r[R_CL], cR = r[R_CR];
-                int bound = r[R_A1];
+                int bound = a1;
                 if (cL > cR) {          // while start_l < end_l { end_l -= 1; swap(l + *end_l, r - 1); r -= 1 }
                     for (int j = cL - 1; j >= count; --j) {
                         --bound;
                         const int hole = s->pos_a[wb + j];
-                        const elem_t t = v[hole];
-                        v[hole] = v[bound];
+                        const elem_t t = v[hole], u = v[bound];
+                        v[hole] = u;
                         v[bound] = t;
                     }
                 } else if (cR > cL) {   // while start_r < end_r { end_r -= 1; swap(l, r - *end_r - 1); l += 1 }
                     for (int j = cR - 1; j >= count; --j) {
                         const int hole = s->pos_b[wb + j];
-                        const elem_t t = v[hole];
-                        v[hole] = v[bound];
+                        const elem_t t = v[hole], u = v[bound];
+                        v[hole] = u;
                         v[bound] = t;
                         ++bound;
                     }
                 }
-                const int pm = bound - 1;  // where the pivot belongs
-                const elem_t t = v[base];
-                v[base] = v[pm];
-                v[pm] = t;
+                const int pm = bound - 1;  // where the pivot belongs: swap(0, mid)
+                const elem_t t = v[pm];
+                v[base] = t;
+                v[pm] = piv;
                 const int mid = pm - base;
                 const int smaller = mid < len - mid ? mid : len - mid;
-                const bool nb = smaller >= len / 8, np = r[R_A0] >= r[R_A2];
+                const bool nb = smaller >= len / 8, np = a0 >= a2;
                 const int nl = mid, nr = len - mid - 1;
                 s->cut[pm] = 1;
                 s->cut[pm + 1] = 1;
@@ -348,21 +405,26 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
                 c_pred[1] = pm;
                 c_flag[1] = nl < nr ? cont : fresh;
             } else {
-                const int mid = (r[R_A1] - wb) + 1;  // the elements equal to the pivot (and the pivot) are done
+                const int mid = (a1 - wb) + 1;  // the elements equal to the pivot (and the pivot) are done
                 s->cut[base + mid] = 1;
                 c_base[1] = base + mid;
                 c_len[1] = len - mid;
                 c_pred[1] = pred;
                 c_flag[1] = limit | (wbal ? 256 : 0) | (wpar ? 512 : 0);
             }
+            // a segment wholly behind the kept prefix of its list is nobody's business
+            const int horizon = ((len1 > 0 && base >= start1) ? start1 : start0) + keep;
+            if (c_base[0] >= horizon) c_len[0] = 0;
+            if (c_base[1] >= horizon) c_len[1] = 0;
         }
         const uint64_t q0 = __builtin_amdgcn_ballot_w64(c_len[0] > 20), q1 = __builtin_amdgcn_ballot_w64(c_len[1] > 20);
         const uint64_t below = bits_below(lane);
         int slot = __builtin_popcountll(q0 & below) + __builtin_popcountll(q1 & below);
+        sync();  // (every leader has read its own record: the table can take the next round's)
 #pragma unroll
         for (int c = 0; c < 2; ++c) {
             if (c_len[c] > 20) {
-                int16_t *f = s->seg[cur ^ 1][slot++];
+                FCD_LDS_AS int16_t *f = s->seg[slot++];
                 f[0] = (int16_t)c_base[c];
                 f[1] = (int16_t)c_len[c];
                 f[2] = (int16_t)c_pred[c];
@@ -370,7 +432,6 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int l
             }
         }
         nseg = __builtin_popcountll(q0) + __builtin_popcountll(q1);
-        cur ^= 1;
         sync();
     }
 

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(64) void pdq178_probe_kernel(uint64_t *lists, int64
 // [0, len) and list 2b + 1 right-aligned at the end of the 64 * MAXP positions, like the two reads of a wavefront
 template <int MAXP>
 __global__ __launch_bounds__(64) void pdq178_coop_probe_kernel(uint64_t *lists, int64_t n_lists, int64_t stride,
-                                                               const int32_t *lens) {
+                                                               const int32_t *lens, int keep) {
     __shared__ uint64_t s_v[64 * MAXP];
     __shared__ pdq178::CoopScratch<MAXP> s_scr;
     const int lane = threadIdx.x;
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(64) void pdq178_coop_probe_kernel(uint64_t *lists, 
     for (int j = lane; j < len0; j += kWave) s_v[j] = lists[i0 * stride + j];
     for (int j = lane; j < len1; j += kWave) s_v[start1 + j] = lists[i1 * stride + j];
     __syncthreads();
-    pdq178::coop_sort<MAXP>(s_v, 0, len0, start1, len1, &s_scr, lane);
+    pdq178::coop_sort<MAXP>(s_v, 0, len0, start1, len1, keep, &s_scr, lane);
     __syncthreads();
     for (int j = lane; j < len0; j += kWave) lists[i0 * stride + j] = s_v[j];
     for (int j = lane; j < len1; j += kWave) lists[i1 * stride + j] = s_v[start1 + j];
@@ -52,13 +52,13 @@ __global__ __launch_bounds__(64) void pdq178_coop_probe_kernel(uint64_t *lists, 
 }  // namespace
 
 hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, int planes,
-                                    hipStream_t stream) {
+                                    int keep, hipStream_t stream) {
     if (n_lists <= 0) return hipSuccess;
     const dim3 grid((unsigned)((n_lists + 1) / 2)), block(64);
     switch (planes) {
-        case 1: hipLaunchKernelGGL(pdq178_coop_probe_kernel<1>, grid, block, 0, stream, lists, n_lists, stride, lens); break;
-        case 5: hipLaunchKernelGGL(pdq178_coop_probe_kernel<5>, grid, block, 0, stream, lists, n_lists, stride, lens); break;
-        case 8: hipLaunchKernelGGL(pdq178_coop_probe_kernel<8>, grid, block, 0, stream, lists, n_lists, stride, lens); break;
+        case 1: hipLaunchKernelGGL(pdq178_coop_probe_kernel<1>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
+        case 5: hipLaunchKernelGGL(pdq178_coop_probe_kernel<5>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
+        case 8: hipLaunchKernelGGL(pdq178_coop_probe_kernel<8>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

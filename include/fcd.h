@@ -193,9 +193,11 @@ int fcd_set_default_tie_order(int order);                /* FCD_TIE_PDQ178 or FC
 int fcd_debug_pdq178_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens);
 /* The same lists through the wave-cooperative form of that routine (csrc/pdq178_coop.h: what the wide-beam kernels run,
  * all 64 lanes on up to two lists at once): wavefront b sorts lists 2b and 2b + 1 together.  planes = 1, 5 or 8: the
- * instantiation (64 * planes positions; lens[2b] + lens[2b + 1] must not exceed them).  Must equal the call above. */
+ * instantiation (64 * planes positions; lens[2b] + lens[2b + 1] must not exceed them); keep: only the first `keep`
+ * positions of every list have to come out right (the searches keep beam_size candidates).  Must equal the call
+ * above on those positions. */
 int fcd_debug_pdq178_coop_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens,
-                                   int planes);
+                                   int planes, int keep);
 /* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
  * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
  * it) and decode the reads that outgrow their slab again in worst-case slabs carved from the same arena.  A

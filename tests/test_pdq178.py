@@ -52,12 +52,15 @@ def device_sort(lib, handle, lists, to_dev, from_dev):
     return from_dev(d_buf, buf.shape, np.uint64), lens
 
 
-def check_against_oracle(out, lens, lists):
+def check_against_oracle(out, lens, lists, keep=None):
     differs = 0
     for i, p in enumerate(lists):
         n = int(lens[i])
         got = (out[i, :n] & np.uint64(0xFFFFFFFF)).astype(np.int64)
         _, want = oracle.pdqsort_desc(p, np.arange(n, dtype=np.int32))
+        if keep is not None:  # only a prefix was asked for; the rest must still be the same elements
+            assert np.array_equal(np.sort(got), np.sort(want)), (i, n)
+            got, want = got[:keep], want[:keep]
         assert np.array_equal(got, want), (i, n)
         differs += int(not np.array_equal(got, np.argsort(-p, kind="stable")))
     return differs
@@ -87,7 +90,7 @@ def coop_lists(planes, seed=1):
     return out
 
 
-def device_coop_sort(lib, handle, lists, planes, to_dev, from_dev):
+def device_coop_sort(lib, handle, lists, planes, to_dev, from_dev, keep=1 << 20):
     stride = max(1, max(len(p) for p in lists))
     buf = np.zeros((len(lists), stride), np.uint64)
     lens = np.zeros(len(lists), np.int32)
@@ -95,7 +98,7 @@ def device_coop_sort(lib, handle, lists, planes, to_dev, from_dev):
         buf[i, :len(p)] = (orderable(p) << np.uint64(32)) | np.arange(len(p), dtype=np.uint64)
         lens[i] = len(p)
     d_buf, d_lens = to_dev(buf), to_dev(lens)
-    rc = lib.fcd_debug_pdq178_coop_sort_dev(handle.ptr, d_buf.ptr, len(lists), stride, d_lens.ptr, planes)
+    rc = lib.fcd_debug_pdq178_coop_sort_dev(handle.ptr, d_buf.ptr, len(lists), stride, d_lens.ptr, planes, keep)
     assert rc == 0, lib.fcd_last_error(handle.ptr)
     handle.synchronize()
     return from_dev(d_buf, buf.shape, np.uint64), lens
@@ -129,6 +132,12 @@ def test_cooperative_routine_equals_the_oracle_restatement_emulated(planes):
         h = nat.default_handle(0)
         out, lens = device_coop_sort(lib, h, lists, planes, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
     assert check_against_oracle(out, lens, lists) > (10 if planes == 1 else 100)
+    if planes == 5:  # the searches only need the kept prefix: segments behind it are dropped
+        with emulated_kernels() as lib:
+            h = nat.default_handle(0)
+            for keep in (1, 5, 32):
+                out, lens = device_coop_sort(lib, h, lists, planes, _HostBuf, lambda d, shape, dt: d.a.reshape(shape), keep=keep)
+                check_against_oracle(out, lens, lists, keep=keep)
 
 
 def test_tie_order_api_emulated():

@@ -70,7 +70,18 @@ def main():
             amb = fcd.beam_search_batch_raw(xd, c["beam"], c["thr"], True, count_ambiguous=True).cpu().ambiguous
             amb = np.asarray(amb).astype(np.int64)
             differ = rows_differing(res["stable"][0], res["pdq178"][0])
+            # the same launch without its tied reads (each replaced by an untied one): what the tie bookkeeping costs
+            # every step, apart from what replaying the quicksort costs the reads that need it
+            flagged = np.flatnonzero(amb[:, 0] > 0)
+            clean = np.flatnonzero(amb[:, 0] == 0)
+            xq = xd.clone()
+            xq[torch.from_numpy(flagged).cuda()] = xd[int(clean[0])]
+            res_q = both_orders(lambda: fcd.beam_search_batch_raw(xq, c["beam"], c["thr"], True), 5)
+            del xq
             out = {"config": cfg, "workload": "beam_search beam %d thr %g, %d reads T=4000 N=5" % (c["beam"], c["thr"], c["batch"]),
+                   "tied_steps_per_flagged_read": {"max": int(amb[:, 0].max()), "mean": float(amb[flagged, 0].mean()) if len(flagged) else 0.0,
+                                                   "reads_tied_on_more_than_half_their_steps": int((amb[:, 0] > 2000).sum())},
+                   "kernel_ms_without_the_tied_reads": {o: res_q[o][1] for o in res_q},
                    "reads_with_gt20_candidate_kept_tie": int((amb[:, 0] > 0).sum()),
                    "reads_with_result_changing_tie": int((amb[:, 1] > 0).sum()),
                    "reads_differing_between_orders": len(differ), "differing_reads": differ[:64],
