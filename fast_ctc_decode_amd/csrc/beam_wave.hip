@@ -48,6 +48,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 #endif
+#include <type_traits>
+
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
@@ -306,12 +308,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     };
     float pk_next = 0.0f, ptip_next = 0.0f;
     if (!GATHER) fetch_row(pk_next, ptip_next);
-    for (int t = 0; t < Tmax; ++t) {
-        const bool act = UNI ? alive : (alive && t < T);
-        float pk = GATHER ? rowv : pk_next;
-        const float pr0 = pk;
-        const float ptip = ptip_next;
-        stamp_f(0, pk);  // loop overhead + posterior row
+    // the row FIFO moves on to step t + 1 (the values step t needs were fetched at the end of step t - 1)
+    auto advance_fifo = [&]() __attribute__((always_inline)) {
         gE += E;
         if (!GATHER && ++g == RPR) {
             g = 0;
@@ -325,295 +323,26 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
             ++blk;
             incoming = load_block(blk + kFifo);
         }
-        const bool grp = UNI ? i < B : (act && i < B);
-
-        // ---- child lanes: extension by label l (:200-239) ----
-        const bool pass = !(pk < thr);  // :201 skips only when pr_b < thr
-        const bool rep = collapse && (k << 2) == tipf;  // l == tip
-        const float contrib = rep ? gp * pk : (lp + gp) * pk;
-        const bool exists = child >= 0;
-        const int cid = child & kIdMask;
-        const bool inbeam = exists && (child & kInBeam);
-        const int mslot = (child >> kSlotShift) & kSlotMask;
-        const bool cvalid = grp && is_child && pass && (exists || !rep || gp > 0.0f);  // :212-218
-        const bool merged = cvalid && inbeam;  // the target's own lane 0 absorbs this extension
-        const int dst = merged ? hbase + mslot * GW : dummy;
-        float inc = __int_as_float(perm(dst, __float_as_int(merged ? contrib : 0.0f)));
-        const int incv = perm(dst, merged ? 1 : 0);
-        stamp_f(1, inc);  // extensions + the push into slots that are beam entries
-
-        // ---- self lanes: blank (:191-198) + repeat-stay (:206-211) + incoming extension ----
-        const bool blank = pr0 > thr;
-        const float gpn = (lp + gp) * pr0;
-        const bool stay = collapse && tipf != 0 && !(ptip < thr);
-        const float lpn = lp * ptip;
-        const bool has_inc = is_self && incv != 0;
-        const float slp = (stay ? lpn : 0.0f) + (has_inc ? inc : 0.0f);
-        const float sgp = blank ? gpn : 0.0f;
-        const bool svalid = grp && is_self && (blank || stay || has_inc);
-
-        const bool valid = svalid || (cvalid && !merged);  // svalid / cvalid already carry is_self / is_child
-        const float clp = is_self ? slp : contrib;
-        const float cgp = is_self ? sgp : 0.0f;
-        const float prob = clp + cgp;
-
-        const bool is_new = cvalid && !exists;
-
-        // ---- prune, first half: sort keys out, comparands back (exact rank on (probability desc, node asc)) ----
-        // The key needs a node index only to break probability ties, and only its ORDER matters: a node
-        // created in this step gets (t << KS) + q here -- above every existing index and increasing with the
-        // lane, exactly like the index it is about to receive -- so the key does not wait for the numbering below.
-        // (A NaN key is garbage but non-zero: it only ever ranks when it is the read's lone candidate, :262.)
-        const int idk = is_self ? node : (is_new ? (t << KS) + q : cid);
-        const uint64_t key = (UNI ? valid : (valid && act)) ? make_key(prob, idk) : 0ull;
-        keys[lane] = key;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        constexpr int NC = BCAP * N;  // comparand u = (slot u / N, column u % N)
-        uint64_t kk[NC];
-#pragma unroll
-        for (int u = 0; u < NC; ++u) kk[u] = keys[hbase + (u / N) * GW + (u % N)];
-
-        // ---- tree.rs:125-145 add_node: ids in (beam order, label order) == lane order; runs under the LDS reads ----
-        const uint64_t m_new = ballot(is_new);
-        const uint32_t w_new = RPW == 1 ? 0u : (hbase ? (uint32_t)(m_new >> 32) : (uint32_t)m_new);
-        int pre_new;
-        if (RPW == 1) {
-            pre_new = popc64(m_new & lanemask_lt());
-        } else {
-            pre_new = __builtin_popcount(w_new & ((1u << q) - 1u));
-        }
-        const int newid = (t << KS) + pre_new;  // < cap: the host sizes every slab for (T << KS) ids (capi.hip)
-        if (is_new) {
-            *at32(rec_w, hoff + (uint32_t)newid) = ((node + 1) << 3) | l;
-            // a segment head (depth % 64 == 0) records where the next head up the tree is
-            if ((depth + 1) % kSeg == 0) *at32(jmp_w, hoff + (uint32_t)newid) = (depth % kSeg == 0) ? node : jump;
-            child = newid;
-        }
-        int id = is_self ? node : (is_new ? newid : cid);
-        stamp_i(2, id);  // own candidate, key, node numbering, record stores
-
-        // ---- prune, second half: count the larger keys ----
-        int rank = 0;
-        int n_eq = 0, n_gt = 0;  // AMB: candidates of exactly this probability (itself included) / of a greater one
-        if (AMB) {
-#pragma unroll
-            for (int u = 0; u < NC; ++u) {
-                rank += (kk[u] > key) ? 1 : 0;
-                n_eq += (kk[u] != 0ull && (uint32_t)(kk[u] >> 32) == (uint32_t)(key >> 32)) ? 1 : 0;
-                n_gt += ((uint32_t)(kk[u] >> 32) > (uint32_t)(key >> 32)) ? 1 : 0;
+    };
+    {
+        int t = 0;
+        while (t < Tmax) {
+            bool again = false;
+            for (; t < Tmax; ++t) {
+                advance_fifo();
+#define FCD_STEP_SLOW 0
+#include "beam_wave_step.inc"
+#undef FCD_STEP_SLOW
             }
-        } else {
-            // four independent compare-and-count chains (device_utils.h)
-            int r0, r1, r2, r3;
-            static_assert(NC >= 4, "at least one block of four comparands");
-            FCD_RANK4_FIRST(key, kk[0], kk[1], kk[2], kk[3], r0, r1, r2, r3);
-#pragma unroll
-            for (int u = 4; u + 4 <= NC; u += 4) FCD_RANK4(key, kk[u], kk[u + 1], kk[u + 2], kk[u + 3], r0, r1, r2, r3);
-#pragma unroll
-            for (int u = NC & ~3; u < NC; ++u) r0 += (kk[u] > key) ? 1 : 0;
-            rank = (r0 + r1) + (r2 + r3);
-        }
-        __builtin_amdgcn_wave_barrier();
-        stamp_i(3, rank);  // exact rank
-
-        // ---- search.rs:261-277 ----
-        // (key != 0 <=> valid && act: a vote on a compare costs one instruction, a vote on a derived flag two)
-        const uint64_t m_valid = ballot(key != 0ull);
-        int n_valid = RPW == 1 ? popc64(m_valid)
-                               : __builtin_popcount(hbase ? (uint32_t)(m_valid >> 32) : (uint32_t)m_valid);
-        // Everything that ends a read is rare: one wave-wide test, the bookkeeping behind it.
-        const bool is_nan = valid && prob != prob;
-        if (ballot(act && (n_valid == 0 || is_nan)) != 0ull) {
-            const uint64_t m_nan = ballot(is_nan);
-            const bool any_nan = RPW == 1 ? m_nan != 0ull
-                                          : (hbase ? (uint32_t)(m_nan >> 32) : (uint32_t)m_nan) != 0u;
-            const bool f_nan = act && n_valid >= 2 && any_nan;  // a lone NaN is never compared (:262)
-            const bool f_empty = act && n_valid == 0;
-            if (f_nan || f_empty) {
-                if (q == 0) {
-                    p.out.status[r] = f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE;
-                    p.out.out_len[r] = 0;
-                }
-                alive = false;
-                if (UNI) n_valid = 0;  // the failed read keeps an empty beam from here on
+            if (PDQ && again) {
+                do {  // (a block the step can `break` out of, like the loop above)
+#define FCD_STEP_SLOW 1
+#include "beam_wave_step.inc"
+#undef FCD_STEP_SLOW
+                } while (false);
+                ++t;
             }
         }
-        const bool go = UNI ? true : (act && alive);  // this half completes the step
-
-        const int Bn = n_valid < beam_size ? n_valid : beam_size;
-        // ---- keep the IN-BEAM/slot bits of every child entry current ----
-        // an entry whose node is a beam entry follows that entry's own candidate: where did it go?
-        // selflag = rank | 16 for a kept candidate, 0 otherwise: shifted to kSlotShift it IS the (slot, IN-BEAM)
-        // field of a child entry (kInBeam == 16 << kSlotShift), so following an entry needs no compare
-        static_assert(kInBeam == (16 << kSlotShift) && kSlotMask == 15, "child-entry bit layout");
-        // Survivor table: entry r = the lane whose candidate took rank r.  LDS executes a wavefront's operations
-        // in order, so the store, the read-back and the two look-ups below share ONE round trip (a ds_permute
-        // to the new slot followed by a broadcast to its group were two dependent ones).
-        const int depc = depth + (is_child ? 1 : 0);
-        const int tipfc = is_self ? tipf : (k << 2);
-        const int statec = (CRF && !is_self) ? (GATHER ? ((state * NL) & s_mask) + l : (state * NL) % (S > 0 ? S : 1) + l)
-                                             : state;  // :97
-        const int jumpc = is_self ? jump : ((depth % kSeg == 0) ? node : jump);
-        // 0 self, 1 a child entering the beam for the first time, 2 a child that has been there before (EVER:
-        // its row is in HBM); read off the entry BEFORE it is marked below
-        const int kind = is_child ? 1 + ((child >> 30) & 1) : 0;
-        const int meta = kind | tipfc | (depc << 5);
-        const int child_in = child;  // (PDQ: a tie-flagged step settles twice)
-        bool sel;
-        int n_node, n_meta, n_state, n_jump, n_child;
-        float n_lp, n_gp, top;
-        uint32_t tie0 = 0, tie1 = 1;
-        // Everything that depends on the ranks: survivor table, fate of the child entries, row eviction, the gather of
-        // the survivors into rank order.  PDQ: it runs on the exact ranks first; the tie table comes back with the
-        // same LDS round trip and is looked at only when the gather has landed -- a flagged step (rare) replaces the
-        // ranks and settles again.  (An eviction store of the first pass that the second does not repeat leaves a row
-        // in HBM nobody reads before it is written again: rows are read back only after their node's LAST eviction.)
-        auto settle = [&]() {
-            sel = valid && go && rank < beam_size;
-            const int selflag = sel ? (rank | 16) : 0;
-            if (sel) srcs[rank] = (lane << 2) | (depc << 8);
-            if (PDQ && key != 0ull && rank <= beam_size) tie_tab[rank] = (uint32_t)(key >> 32);
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const int fate = bperm(hbase + mslot * GW, selflag);
-            const int own = bperm(grp0, selflag);  // ... and this group's own candidate?
-            // every lane of new group i learns its source lane (stale beyond the new beam: unused), where the best
-            // candidate sits, and the SMALLEST DEPTH in the new beam: a stale entry can only lower it
-            const int src_a = srcs[i] & 0xFF;  // byte address, as ds_bpermute wants it
-            int e_min = srcs[0];
-            const int top_a = e_min & 0xFF;
-#pragma unroll
-            for (int j = 1; j < BCAP; ++j) e_min = min(e_min, srcs[j]);
-            if (PDQ) {
-                tie0 = tie_tab[i];
-                tie1 = tie_tab[i + 1];
-            }
-            {
-                // a child entry whose node is a beam entry follows it to its new slot (or learns it left);
-                // a child entering the beam is marked EVER: from now on it may own children
-                const int followed = (child_in & kStored) | (fate << kSlotShift);
-                const int entered = id | kEver | (selflag << kSlotShift);
-                const bool upd = go && is_child;
-                child = (upd && inbeam) ? followed : ((upd && sel) ? entered : child_in);
-                // A node's child row only has to exist in HBM while the node is OUT of the beam (it is read back if
-                // the node re-enters, below): write it once, when the node is evicted -- four lanes, 16 contiguous
-                // bytes.  And only if the node can come back at all: a node re-enters the beam as the extension of its
-                // parent, so it needs a proper ancestor in the beam -- none exists once every beam entry is at least as
-                // deep as the node, and then none ever will (its ancestors have left for good, top-down from the
-                // root).  Three evicted rows in four are dead by this test and are never written.
-                const bool dead = (depth << 8) <= e_min;  // e_min = (minimum depth << 8) | a lane address
-                if (upd && grp && own == 0 && !dead)
-                    *at32(rows_w, (hoff + (uint32_t)(node + 1)) * RW + l) = child;  // (beam-position bits and all: stripped when read back)
-            }
-            stamp_i(4, child);  // fate of every child entry, row eviction
-            // ---- gather the survivors into rank order ----
-            n_node = __builtin_amdgcn_ds_bpermute(src_a, id);
-            n_lp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(clp)));
-            n_gp = __int_as_float(__builtin_amdgcn_ds_bpermute(src_a, __float_as_int(cgp)));
-            n_meta = __builtin_amdgcn_ds_bpermute(src_a, meta);
-            n_state = CRF ? __builtin_amdgcn_ds_bpermute(src_a, statec) : 0;
-            n_jump = __builtin_amdgcn_ds_bpermute(src_a, jumpc);
-            n_child = __builtin_amdgcn_ds_bpermute(src_a + (k << 2), child);  // meaningful when the source is a self lane
-            top = __int_as_float(__builtin_amdgcn_ds_bpermute(top_a, __float_as_int(prob)));  // beam[0].probability() :278 = its candidate's label + gap probability
-            stamp_f(5, n_lp);  // survivors gathered into rank order
-        };
-        settle();
-        if (PDQ) {
-            // ranks i and i + 1 hold one probability, rank i is kept and rank i + 1 exists: sort_unstable_by's order
-            // of the two is pdqsort's business once the list is longer than 20 (:262).  tie_lim folds "i < beam_size",
-            // "i + 1 < n_valid" and "n_valid > 20" into one compare; the votes are unconditional (convergent), so the
-            // table reads above cannot be sunk behind a branch and a wait of their own.  (A half that is not running,
-            // or has just failed, has no candidates or loses nothing by re-ranking them.)
-            const uint64_t m_tied = ballot(tie0 == tie1) & ballot(tie_lim < n_valid);
-            if (__builtin_expect(m_tied != 0ull, 0)) {
-                const bool mine = RPW == 1 ? true : (hbase ? (m_tied >> 32) != 0ull : (uint32_t)m_tied != 0u);
-                uint64_t *list = s_list[wave] + hbase;
-                int *newrank = s_heads[wave];  // (free until the traceback)
-                // the list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260)
-                int pos = 0;
-#pragma unroll 1
-                for (int u = 0; u < NC; ++u) {
-                    const uint64_t ku = keys[hbase + (u / N) * GW + (u % N)];
-                    pos += (ku != 0ull && (uint32_t)ku > (uint32_t)key) ? 1 : 0;  // low word: larger = smaller node
-                }
-                if (mine && key != 0ull) list[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)lane;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                {   // the whole wavefront replays the quicksort, on both halves' lists at once (pdq178_coop.h)
-                    const bool f0 = RPW == 1 || (uint32_t)m_tied != 0u, f1 = RPW == 2 && (m_tied >> 32) != 0ull;
-                    const int len0 = f0 ? __builtin_amdgcn_readlane(n_valid, 0) : 0;
-                    const int len1 = f1 ? __builtin_amdgcn_readlane(n_valid, 32) : 0;
-                    pdq178::coop_sort<1>(s_list[wave], 0, len0, 32, len1, beam_size, &s_coop[wave], lane);
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (mine && q < n_valid) newrank[(int)(uint32_t)list[q]] = q;
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (mine && key != 0ull) rank = newrank[lane];
-                settle();
-            }
-        }
-        if (AMB) {
-            // [0] a kept candidate that shares its probability with any other candidate of a > 20-candidate step;
-            // [1] (any candidate count) equal probabilities at ranks 0 / 1 or across the truncation boundary:
-            //     the group of n_eq equal candidates occupies ranks [n_gt, n_gt + n_eq)
-            const bool tie = sel && n_valid > 20 && n_eq >= 2;
-            const bool crit = valid && go && n_eq >= 2 && (n_gt == 0 || (n_gt < beam_size && n_gt + n_eq > beam_size));
-            const uint64_t m_tie = ballot(tie), m_crit = ballot(crit);
-            n_amb += (RPW == 1 ? m_tie : (hbase ? (m_tie >> 32) : (m_tie & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
-            n_crit += (RPW == 1 ? m_crit : (hbase ? (m_crit >> 32) : (m_crit & 0xFFFFFFFFull))) != 0ull ? 1 : 0;
-        }
-        const int n_kind = n_meta & 3;
-        const bool ngrp = go && i < Bn;
-        if (n_kind == 1 || !is_child) n_child = -1;
-        const bool reload = ngrp && n_kind == 2 && is_child;
-        // (the vote is on the bare compare -- one instruction; a kind-2 record in a slot past the new beam only
-        // sends the wavefront through the rare path for nothing)
-        if (ballot(n_kind == 2) != 0ull) {
-            // a node that was in the beam before comes back: its row is in HBM, and which of its
-            // children are beam entries right now has to be looked up (rare path)
-            int e = -1;
-            if (reload) e = load_i32_l2(at32(rows_w, (hoff + (uint32_t)(n_node + 1)) * RW + l));
-#ifdef FCD_HIPEMU  // (lockstep emulation, tests/hipemu: device memory arrives poisoned with 0xA5)
-            if (reload && e == (int)0xA5A5A5A5) {  // a row that was never written: the dead-row test (above) was wrong
-                fprintf(stderr, "beam_wave: node %d re-entered the beam but its child row was never stored\n", n_node);
-                abort();
-            }
-#endif
-            if (e >= 0) e &= kStored;  // the stored entry still carries the beam-position bits it had at eviction
-#pragma unroll
-            for (int j = 0; j < BCAP; ++j) {
-                const int nj = bperm(hbase + j * GW, n_node);
-                if (reload && e >= 0 && j < Bn && (e & kIdMask) == nj)
-                    e = (e & kStored) | kInBeam | (j << kSlotShift);
-            }
-            if (reload) n_child = e;
-        }
-        if (CRF && (UNI || go)) state = n_state;  // < S: (s*4) % 4 + l = l for (N, S) = (5, 4); masked when GATHER
-        if (UNI || go) tipf = n_meta & 0x1C;
-        if (GATHER) rowv = gather_row(t + 1);  // in flight during the divisions below
-        else fetch_row(pk_next, ptip_next);    // (the FIFO was already advanced to step t + 1 above)
-        // Every lane of a group would compute the same two IEEE quotients: lane k = 1 divides the gap
-        // probability, the others the label probability -- one division per lane -- and the group shares them.
-        const float quot = (k == 1 ? n_gp : n_lp) / top;
-        const float q_lp = bpermf(grp0, quot), q_gp = bpermf(grp0 + 1, quot);
-        if (UNI || go) {
-            node = n_node;
-            lp = q_lp;
-            gp = q_gp;
-            depth = n_meta >> 5;
-            jump = n_jump;
-            child = n_child;
-            B = Bn;
-        }
-        stamp_f(6, lp);  // row reload, top, the two divisions, state update
     }
     if (PROF && lane == 0 && p.a.prof) {
         uint32_t *o = p.a.prof + ((int64_t)blockIdx.x * kWavesPerBlock + wave) * 8;

@@ -110,8 +110,8 @@ struct Masks {
 // elements, so the kept prefix cannot tell).  Called by all 64 lanes of a wavefront with the same arguments; `lane` =
 // the caller's lane; v and s are LDS.
 template <int MAXP>
-__device__ __attribute__((noinline)) void coop_sort(elem_t *v_generic, int start0, int len0, int start1, int len1, int keep,
-                                                    CoopScratch<MAXP> *s_generic, int lane) {
+__device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, int len0, int start1, int len1, int keep,
+                                                 CoopScratch<MAXP> *s_generic, int lane) {
     using namespace coop_detail;
     constexpr int kPos = 64 * MAXP;
     static_assert(sizeof(Scratch) * 2 <= sizeof(uint16_t) * 2 * kPos || kPos < kCoopMaxLen,
@@ -483,6 +483,13 @@ __device__ __attribute__((noinline)) void coop_sort(elem_t *v_generic, int start
     for (int j = 0; j < MAXP; ++j)
         if (dest[j] >= 0) v[dest[j]] = val[j];
     sync();
+}
+
+// The same as a call (the wide-beam kernel: its 128-VGPR budget cannot hold the routine next to its own state).
+template <int MAXP>
+__device__ __attribute__((noinline)) void coop_sort(elem_t *v, int start0, int len0, int start1, int len1, int keep,
+                                                    CoopScratch<MAXP> *s, int lane) {
+    coop_sort_inline<MAXP>(v, start0, len0, start1, len1, keep, s, lane);
 }
 
 }  // namespace pdq178

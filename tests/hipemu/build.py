@@ -26,7 +26,7 @@ def _sources():
 
 
 def _deps():
-    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    d = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h", ".inc"))]
     d += [os.path.join(HERE, "hipemu.cpp"), os.path.join(HERE, "hip", "hip_runtime.h"),
           os.path.join(ROOT, "include", "fcd.h"), os.path.abspath(__file__)]
     return d

@@ -1,0 +1,50 @@
+"""developer scratch: latency of one cooperative quicksort replay (pdq178_coop.h) -- one wavefront per SIMD"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
+import numpy as np
+import torch
+from fast_ctc_decode_amd import _native as nat
+from test_pdq178 import orderable
+
+lib = nat.load()
+h = nat.default_handle(0)
+h.set_stream(torch.cuda.current_stream().cuda_stream)
+rng = np.random.default_rng(0)
+
+
+def run(n, planes, keep, pairs=1024, serial=False):
+    lists = []
+    for _ in range(2 * pairs):
+        vals = rng.random(6, dtype=np.float32)
+        p = np.where(rng.random(n) < 0.3, vals[rng.integers(0, 6, n)], rng.random(n, dtype=np.float32)).astype(np.float32)
+        lists.append(p)
+    buf = np.zeros((len(lists), n), np.uint64)
+    for i, p in enumerate(lists):
+        buf[i] = (orderable(p) << np.uint64(32)) | np.arange(n, dtype=np.uint64)
+    lens = np.full(len(lists), n, np.int32)
+    d0 = torch.from_numpy(buf.view(np.int64)).cuda()
+    dl = torch.from_numpy(lens).cuda()
+    best = 1e9
+    for _ in range(5):
+        d = d0.clone()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        if serial:
+            rc = lib.fcd_debug_pdq178_sort_dev(h.ptr, d.data_ptr(), len(lists), n, dl.data_ptr())
+        else:
+            rc = lib.fcd_debug_pdq178_coop_sort_dev(h.ptr, d.data_ptr(), len(lists), n, dl.data_ptr(), planes, keep)
+        e1.record()
+        torch.cuda.synchronize()
+        assert rc == 0
+        best = min(best, e0.elapsed_time(e1))
+    print("n=%d planes=%d keep=%d %s: %.1f us per launch (%d wavefronts, one sort of two lists each)" %
+          (n, planes, keep, "serial" if serial else "coop", best * 1e3, pairs), flush=True)
+
+
+for n, planes in ((25, 1), (128, 5), (64, 5), (160, 5)):
+    for keep in (1 << 20, 32, 5):
+        run(n, planes, keep)
+run(128, 5, 0, serial=True)
+run(25, 1, 0, serial=True)
