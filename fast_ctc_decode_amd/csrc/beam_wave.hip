@@ -145,10 +145,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
     // survivor table, per half: entry r = (byte address of the lane whose candidate took rank r) | that candidate's depth << 8
-    __shared__ int s_srcs[kWavesPerBlock][RPW * 16];
-    // PDQ: probability (orderable bits) of the candidate of rank r, r <= beam_size; the node-ordered candidate list
-    // and the quicksort's scratch of a tie-flagged step
-    __shared__ uint32_t s_tie[PDQ ? kWavesPerBlock : 1][RPW * 16];
+    __shared__ int s_srcs[kWavesPerBlock][RPW * 16 * (PDQ ? 2 : 1)];  // (PDQ: two words per entry, below)
+    // PDQ: the node-ordered candidate list and the quicksort's tables of a tie-flagged step
     __shared__ uint64_t s_list[PDQ ? kWavesPerBlock : 1][64];
     __shared__ pdq178::CoopScratch<1> s_coop[PDQ ? kWavesPerBlock : 1];
     static_assert(!PDQ || BCAP * N > 20, "the tie order only matters above 20 candidates");
@@ -187,12 +185,18 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const bool collapse = !CRF && p.a.collapse != 0;
     const float thr = p.a.thr;
     uint64_t *keys = s_keys[wave];
-    int *srcs = s_srcs[wave] + (hbase ? 16 : 0);
-    uint32_t *tie_tab = s_tie[PDQ ? wave : 0] + (hbase ? 16 : 0);
+    int *srcs = s_srcs[wave] + (hbase ? 16 * (PDQ ? 2 : 1) : 0);
     // smallest candidate count from which "rank i ties with rank i + 1" is the quicksort's business: more than 20
     // candidates, rank i kept, rank i + 1 present (never, for a lane outside the beam's groups)
     const int tie_lim = (!idle && i < p.a.beam_size) ? (i + 1 > 20 ? i + 1 : 20) : 0x7FFFFFFF;
-    if (lane < RPW * 16) s_srcs[wave][lane] = 0x7FFFFF00;  // never the minimum depth; points at lane 0
+    if (PDQ) {  // second words: pairwise different, bit 31 clear -- no candidate's probability word looks like that
+        if (lane < RPW * 16) {
+            s_srcs[wave][2 * lane] = 0x7FFFFF00;
+            s_srcs[wave][2 * lane + 1] = lane;
+        }
+    } else if (lane < RPW * 16) {
+        s_srcs[wave][lane] = 0x7FFFFF00;  // never the minimum depth; points at lane 0
+    }
 
     const int64_t local = ((int64_t)blockIdx.x * kWavesPerBlock + wave) * RPW + (lane / HALF);
     const bool has_read = local < p.in.n_reads;  // n_reads here = reads in this launch
