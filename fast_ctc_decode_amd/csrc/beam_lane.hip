@@ -297,45 +297,522 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         rowv[c] = (CRF && T > 0) ? load_post(post, (int64_t)state * st_s + c * st_n, dt) : 0.0f;
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): see beam_wave.hip
 
-    {
-        // Two copies of the step at two loop depths (beam_lane_step.inc): the time loop proper holds no cold path.
-        int t = 0;
-        bool act = false;
+    for (int t = 0; t < Tmax; ++t) {
+        const bool act = alive && t < T;
+        // ---- the posterior row: uniform over the read's lanes ----
         float pr[N];
-        int g_row = 0;
-        float win_row = 0.0f;
-        while (t < Tmax) {
-            bool again = false;
-            for (; t < Tmax; ++t) {
-                act = alive && t < T;
-                // ---- the posterior row: uniform over the read's lanes ----
 #pragma unroll
-                for (int c = 0; c < N; ++c)
-                    pr[c] = CRF ? rowv[c] : (RPW == 1 ? rdlanef(win[0], g * N + c) : bpermf(hbase + g * N + c, win[0]));
-                g_row = g;            // (the FIFO may rotate below: the tip's column is fetched from this row later)
-                win_row = win[0];
-                if (!CRF && ++g == RPR) {
-                    g = 0;
+        for (int c = 0; c < N; ++c)
+            pr[c] = CRF ? rowv[c] : (RPW == 1 ? rdlanef(win[0], g * N + c) : bpermf(hbase + g * N + c, win[0]));
+        const int g_row = g;            // (the FIFO may rotate below: the tip's column is fetched from this row later)
+        const float win_row = win[0];
+        if (!CRF && ++g == RPR) {
+            g = 0;
 #pragma unroll
-                    for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
-                    __builtin_amdgcn_s_waitcnt(0x0F70);
-                    win[kFifo - 1] = incoming;
-                    ++blk;
-                    incoming = load_block(blk + kFifo);
-                }
-#define FCD_STEP_SLOW 0
-#include "beam_lane_step.inc"
-#undef FCD_STEP_SLOW
+            for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            win[kFifo - 1] = incoming;
+            ++blk;
+            incoming = load_block(blk + kFifo);
+        }
+        const bool ent = act && q < B;
+
+        // ---- extensions by label l (:200-239); targets that are beam entries get the push ----
+        s_inc[lane] = 0ull;
+        wave_sync();
+        float contrib[NL];
+        bool cvalid[NL], merged[NL];
+        int ccand[NL];  // candidate id of extension l (existing child or the new node)
+        int n_new = 0;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const float pk = pr[l + 1];
+            const bool pass = !(pk < thr);  // :201 skips only when pr_b < thr
+            const bool rep = collapse && l == tip;
+            contrib[l] = rep ? gp * pk : (lp + gp) * pk;
+            const int ch = child[l];
+            const bool exists = ch >= 0;
+            cvalid[l] = ent && pass && (exists || !rep || gp > 0.0f);  // :212-218
+            merged[l] = cvalid[l] && exists && (ch & kInBeam);
+            if (merged[l])
+                s_inc[hbase + ((ch >> kSlotShift) & kSlotMask)] = (1ull << 32) | (uint32_t)__float_as_int(contrib[l]);
+            n_new += (cvalid[l] && !exists) ? 1 : 0;
+        }
+        wave_sync();
+
+        // ---- the entry's own node: blank (:191-198) + repeat-stay (:206-211) + incoming extension ----
+        const uint64_t iv = s_inc[lane];
+        const bool has_inc = ent && (iv >> 32) != 0ull;
+        const float inc = __int_as_float((int)(uint32_t)iv);
+        // the tip label's column of the row: one more cross-lane fetch instead of a compare-and-select per label
+        // (CRF: no repeat-stay, unused)
+        float ptip = 0.0f;
+        if (!CRF) ptip = bpermf(hbase + g_row * N + tip + 1, win_row);
+        const float pr0 = pr[0];
+        const bool blank = pr0 > thr;
+        const float gpn = (lp + gp) * pr0;
+        const bool stay = collapse && tip >= 0 && !(ptip < thr);
+        const float lpn = lp * ptip;
+        const float slp = (stay ? lpn : 0.0f) + (has_inc ? inc : 0.0f);
+        const float sgp = blank ? gpn : 0.0f;
+        const bool svalid = ent && (blank || stay || has_inc);
+
+        // ---- tree.rs:125-145 add_node: ids in (beam order, label order) ----
+        const int incl = half_prefix_add<RPW>(n_new);
+        const int nn0 = nn;  // ids from here on are this step's new nodes
+        if (q == 0 && act) *first_at(t) = nn;
+        int next_id = nn + incl - n_new;
+        nn += RPW == 1 ? rdlane(incl, 63) : bperm(hbase + HALF - 1, incl);
+        const bool f_cap = act && nn > cap;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const bool is_new = cvalid[l] && child[l] < 0;
+            if (is_new && !f_cap) {
+                const int id = next_id++;
+                *rec_at(id) = ((node + 1) << 3) | l;
+                if ((depth + 1) % kSeg == 0) *jmp_at(id) = (depth % kSeg == 0) ? node : jump;
+                child[l] = id;
             }
-            if (PDQ && again) {  // (act, pr[], g_row, win_row: still this step's)
-                do {
-#define FCD_STEP_SLOW 1
-#include "beam_lane_step.inc"
-#undef FCD_STEP_SLOW
-                } while (false);
-                ++t;
+            ccand[l] = child[l] & kIdMask;
+        }
+
+        // ---- search.rs:261-277 ----
+        uint64_t key[N];
+        bool cand_valid[N];
+        cand_valid[0] = svalid;
+        int n_valid = hcount(svalid);
+        bool lane_nan = svalid && (slp + sgp) != (slp + sgp);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            cand_valid[l + 1] = cvalid[l] && !merged[l];
+            n_valid += hcount(cand_valid[l + 1]);
+            lane_nan = lane_nan || (cand_valid[l + 1] && contrib[l] != contrib[l]);
+        }
+        const bool any_nan = hcount(lane_nan) != 0;
+        const bool f_nan = act && n_valid >= 2 && any_nan;
+        const bool f_empty = act && n_valid == 0;
+        if (f_nan || f_empty || f_cap) {
+            if (q == 0) {
+                p.out.status[r] = f_cap ? FCD_ST_INTERNAL : (f_empty ? FCD_ST_RAN_OUT_OF_BEAM : FCD_ST_INCOMPARABLE);
+                p.out.out_len[r] = 0;
+            }
+            alive = false;
+        }
+        const bool go = act && alive;  // this read completes the step
+        // (a NaN that gets this far is the lone candidate of the read: any non-zero key ranks it first)
+        key[0] = (svalid && go) ? make_key(slp + sgp, node) : 0ull;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) key[l + 1] = (cand_valid[l + 1] && go) ? make_key(contrib[l], ccand[l]) : 0ull;
+
+        // ---- prune: the top beam_size candidates in exact key order ----
+        const int Bn = go ? (n_valid < beam_size ? n_valid : beam_size) : 0;
+        int rank[N];
+#pragma unroll
+        for (int k = 0; k < N; ++k) rank[k] = -1;
+        const bool need_sel = go && n_valid > beam_size;
+        int bstar = KB - 1;
+        int Lc = go ? n_valid : 0;
+        uint32_t mx = 0;
+        bool tie = false, crit = false;  // AMB: the two tie conditions of include/fcd.h (fcd_result.ambiguous)
+        if (ballot(need_sel) != 0ull) {
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                const uint32_t hi = (uint32_t)(key[k] >> 32);
+                mx = hi > mx ? hi : mx;
+            }
+            // maximum over the half: the DPP reduction of half_min_in_last_lane on the complement (keys are unsigned)
+            mx = ~(uint32_t)bperm(hbase + HALF - 1, half_umin_in_last_lane<RPW>((int)~mx));
+            *reinterpret_cast<int4 *>(hist + 4 * lane) = make_int4(0, 0, 0, 0);
+            wave_sync();
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                if (need_sel && key[k] != 0ull) {
+                    const uint32_t d = (mx - (uint32_t)(key[k] >> 32)) >> kBucketShift;
+                    atomicAdd(&hist[4 * hbase + (d < (uint32_t)(KB - 1) ? d : (uint32_t)(KB - 1))], 1);
+                }
+            wave_sync();
+            const int4 h = *reinterpret_cast<const int4 *>(hist + 4 * lane);
+            const int s0 = h.x, s1 = s0 + h.y, s2 = s1 + h.z, s3 = s2 + h.w;
+            const int hin = half_prefix_add<RPW>(s3);
+            const int hex = hin - s3;
+            // exactly one lane of a selecting half owns the bucket where the running count reaches beam_size
+            const bool cross = need_sel && hex < beam_size && hin >= beam_size;
+            const int kk = (hex + s0 >= beam_size) ? 0 : (hex + s1 >= beam_size) ? 1 : (hex + s2 >= beam_size) ? 2 : 3;
+            const int cum = hex + (kk == 0 ? s0 : kk == 1 ? s1 : kk == 2 ? s2 : s3);
+            const uint64_t m_cross = hmask(ballot(cross));
+            const int owner = hbase + (m_cross ? __builtin_ctzll(m_cross) : 0);
+            const int b_sel = bperm(owner, 4 * q + kk);
+            const int l_sel = bperm(owner, cum);
+            if (need_sel) {
+                bstar = b_sel;
+                Lc = l_sel;
+            }
+            wave_sync();
+        }
+        const bool listed = ballot(Lc > LCAP) == 0ull;
+        if (listed) {
+            // "bucket <= bstar" as one compare per candidate: bucket = min((mx - hi) >> shift, KB - 1) <= bstar  <=>
+            // mx - hi < (bstar + 1) << shift (everything qualifies when bstar is the catch-all bucket)  <=>  hi >= lim
+            const uint32_t span = (uint32_t)(bstar + 1) << kBucketShift;
+            const uint32_t lim = (!need_sel || bstar >= KB - 1 || mx < span) ? 0u : mx - span + 1u;
+            // the list in lane order (its order does not matter to the ranking): one prefix sum over the lanes'
+            // counts instead of a vote and two population counts per candidate
+            bool in[N];
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                in[k] = key[k] != 0ull && (uint32_t)(key[k] >> 32) >= lim;
+                cnt += in[k] ? 1 : 0;
+            }
+            int pos = half_prefix_add<RPW>(cnt) - cnt;
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                if (in[k]) {
+                    l_key[pos] = key[k];
+                    l_src[pos] = lane * 8 + k;
+                }
+                pos += in[k] ? 1 : 0;
+            }
+            // the ranking loop runs to a wave-uniform bound, eight keys at a time: pad this read's list with zero keys
+            int lmax = Lc;
+            if (RPW == 2) lmax = max(lmax, __shfl_xor(lmax, 32));
+            lmax = (__builtin_amdgcn_readfirstlane(lmax) + 7) & ~7;
+            for (int z = Lc + q; z < lmax; z += HALF) l_key[z] = 0ull;
+            *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
+            wave_sync();
+            for (int e0 = 0; e0 < lmax; e0 += HALF) {
+                if (!AMB && e0 > 0 && lmax - e0 <= HALF / 4) {
+                    // The list is usually a handful of entries longer than the half has lanes (beam_size survivors
+                    // plus whatever shares the last bucket): a second pass of every lane over the whole list for
+                    // their sake would double the ranking work.  Four lanes share each of them instead, each
+                    // counting a quarter of the list, and add their counts up across the quad.
+                    const int e = e0 + (q >> 2), sub = q & 3;
+                    const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
+                    const int per = lmax >> 2;  // keys per lane: a quarter of the list (lmax is a multiple of 8)
+                    int rk = 0, rk2 = 0;
+                    for (int jj = 0; jj < per; jj += 2) {
+                        const int j = sub * per + jj;
+                        ulonglong2 kk2;
+                        kk2.x = 0ull;
+                        kk2.y = 0ull;
+                        if (j < lmax) kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
+                        rk += (kk2.x > ke) ? 1 : 0;
+                        rk2 += (kk2.y > ke) ? 1 : 0;
+                    }
+                    rk += rk2;
+                    rk += __builtin_amdgcn_update_dpp(0, rk, 0xB1, 0xf, 0xf, false);  // quad_perm [1,0,3,2]
+                    rk += __builtin_amdgcn_update_dpp(0, rk, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+                    if (sub == 0 && e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                    if (PDQ && sub == 0 && e < Lc && rk <= beam_size) tie_tab[rk] = (uint32_t)(ke >> 32);
+                    break;
+                }
+                const int e = e0 + q;
+                const uint64_t ke = e < Lc ? l_key[e] : ~0ull;
+                int rk = 0, rk2 = 0, n_eq = 0, n_gt = 0;
+                if (!AMB) {
+                    // eight keys per trip: four 16-byte LDS reads in flight, four independent compare-and-count chains
+                    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+                    for (int j = 0; j < lmax; j += 8) {
+                        const ulonglong2 ka = *reinterpret_cast<const ulonglong2 *>(l_key + j);
+                        const ulonglong2 kb = *reinterpret_cast<const ulonglong2 *>(l_key + j + 2);
+                        const ulonglong2 kc = *reinterpret_cast<const ulonglong2 *>(l_key + j + 4);
+                        const ulonglong2 kd = *reinterpret_cast<const ulonglong2 *>(l_key + j + 6);
+                        FCD_RANK4(ke, ka.x, ka.y, kb.x, kb.y, r0, r1, r2, r3);
+                        FCD_RANK4(ke, kc.x, kc.y, kd.x, kd.y, r0, r1, r2, r3);
+                    }
+                    rk = (r0 + r1) + (r2 + r3);
+                }
+                for (int j = 0; AMB && j < lmax; j += 2) {  // two keys per 16-byte LDS read
+                    const ulonglong2 kk2 = *reinterpret_cast<const ulonglong2 *>(l_key + j);
+                    rk += (kk2.x > ke) ? 1 : 0;
+                    rk2 += (kk2.y > ke) ? 1 : 0;
+                    if (AMB) {  // equal probabilities share a bucket: every candidate tied with a kept one is listed
+                        n_eq += (kk2.x != 0ull && (uint32_t)(kk2.x >> 32) == (uint32_t)(ke >> 32)) ? 1 : 0;
+                        n_eq += (kk2.y != 0ull && (uint32_t)(kk2.y >> 32) == (uint32_t)(ke >> 32)) ? 1 : 0;
+                        n_gt += ((uint32_t)(kk2.x >> 32) > (uint32_t)(ke >> 32)) ? 1 : 0;
+                        n_gt += ((uint32_t)(kk2.y >> 32) > (uint32_t)(ke >> 32)) ? 1 : 0;
+                    }
+                }
+                rk += rk2;
+                if (e < Lc && rk < beam_size) s_rank[l_src[e]] = (int8_t)rk;
+                if (PDQ && e < Lc && rk <= beam_size) tie_tab[rk] = (uint32_t)(ke >> 32);
+                if (AMB && e < Lc) {
+                    tie = tie || (rk < beam_size && n_valid > 20 && n_eq >= 2);
+                    crit = crit || (n_eq >= 2 && (n_gt == 0 || (n_gt < beam_size && n_gt + n_eq > beam_size)));
+                }
+            }
+            wave_sync();
+            const uint64_t mine = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
+#pragma unroll
+            for (int k = 0; k < N; ++k) rank[k] = (int)(int8_t)(uint8_t)(mine >> (8 * k));
+        } else {
+            // heavily tied (or extremely spread) probabilities: rank every candidate against all of its read's
+#pragma unroll
+            for (int k = 0; k < N; ++k) c_key[lane * N + k] = key[k];
+            wave_sync();
+            int rk[N], n_eq[N], n_gt[N];
+#pragma unroll
+            for (int k = 0; k < N; ++k) rk[k] = n_eq[k] = n_gt[k] = 0;
+            for (int j = 0; j < HALF * N; ++j) {
+                const uint64_t kj = c_key[hbase * N + j];
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    rk[k] += (kj > key[k]) ? 1 : 0;
+                    if (AMB) {
+                        n_eq[k] += (kj != 0ull && (uint32_t)(kj >> 32) == (uint32_t)(key[k] >> 32)) ? 1 : 0;
+                        n_gt[k] += ((uint32_t)(kj >> 32) > (uint32_t)(key[k] >> 32)) ? 1 : 0;
+                    }
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < N; ++k) {
+                rank[k] = (key[k] != 0ull && rk[k] < beam_size) ? rk[k] : -1;
+                if (PDQ && key[k] != 0ull && rk[k] <= beam_size) tie_tab[rk[k]] = (uint32_t)(key[k] >> 32);
+                if (AMB && key[k] != 0ull) {
+                    tie = tie || (rank[k] >= 0 && n_valid > 20 && n_eq[k] >= 2);
+                    crit = crit || (n_eq[k] >= 2 && (n_gt[k] == 0 || (n_gt[k] < beam_size && n_gt[k] + n_eq[k] > beam_size)));
+                }
+            }
+            wave_sync();
+        }
+
+        if (AMB) {
+            n_amb += hcount(tie) != 0 ? 1 : 0;
+            n_crit += hcount(crit) != 0 ? 1 : 0;
+        }
+        if (PDQ) {
+            // ranks q and q + 1 hold one probability, rank q is kept and rank q + 1 was ranked in this step (a
+            // candidate outside the list shares no probability with a listed one): sort_unstable_by's order of the
+            // two is pdqsort's business once the list is longer than 20 (:262)
+            const int n_ranked = listed ? Lc : n_valid;
+            const bool tied = go && n_valid > 20 && q < beam_size && q + 1 < n_ranked && tie_tab[q] == tie_tab[q + 1];
+            const uint64_t m_tied = ballot(tied);
+            if (__builtin_expect(m_tied != 0ull, 0)) {
+                const bool mine_h = hmask(m_tied) != 0ull;
+                // The list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260).  This
+                // step's new nodes are numbered in candidate order and follow every older node, so only the candidates
+                // on OLDER nodes need ranking -- against each other, four to a 16-byte LDS read.
+                pdq178::CoopScratch<N> *cs = reinterpret_cast<pdq178::CoopScratch<N> *>(&s_coop);
+                // (both position tables, 64 * N words, and the first bytes of the table behind them: each half's ids
+                // are followed by four words of padding OF ITS OWN -- the lanes run in lockstep, a padding store that
+                // reached into the other half's region would land after that half's ids)
+                uint32_t *eid = reinterpret_cast<uint32_t *>(cs->pos_a) + hh * (HALF * N + 4);
+                bool older[N];
+                int n_older = 0;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    older[k] = mine_h && key[k] != 0ull && (k == 0 || ccand[k > 0 ? k - 1 : 0] < nn0);
+                    n_older += older[k] ? 1 : 0;
+                }
+                const int o_incl = half_prefix_add<RPW>(n_older);
+                int o_pos = o_incl - n_older;
+                const int n_old = RPW == 1 ? rdlane(o_incl, 63) : bperm(hbase + HALF - 1, o_incl);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (older[k]) eid[o_pos++] = (uint32_t)key[k];  // low word: larger = smaller node
+                if (q < 4) eid[n_old + q] = 0u;                     // (padding of the last 16-byte read: never "smaller")
+                wave_sync();
+                int n_old_max = n_old;
+                if (RPW == 2) n_old_max = max(n_old_max, __shfl_xor(n_old_max, 32));
+                n_old_max = __builtin_amdgcn_readfirstlane(n_old_max);
+                int pos[N];
+#pragma unroll
+                for (int k = 0; k < N; ++k) pos[k] = 0;
+#pragma unroll 1
+                for (int j = 0; j < n_old_max; j += 4) {
+                    uint4 e = make_uint4(0u, 0u, 0u, 0u);
+                    if (j < n_old) e = *reinterpret_cast<const uint4 *>(eid + j);
+#pragma unroll
+                    for (int k = 0; k < N; ++k) {
+                        const uint32_t me = (uint32_t)key[k];
+                        pos[k] += ((e.x > me) ? 1 : 0) + ((e.y > me) ? 1 : 0) + ((e.z > me) ? 1 : 0) + ((e.w > me) ? 1 : 0);
+                    }
+                }
+                wave_sync();  // (the table the ids sat in is the sort's scratch from here on)
+                uint64_t *list = c_key + hbase * N;
+#pragma unroll
+                for (int k = 0; k < N; ++k) {
+                    if (!mine_h || key[k] == 0ull) continue;
+                    const int at = older[k] ? pos[k] : n_old + (ccand[k > 0 ? k - 1 : 0] - nn0);
+                    list[at] = (key[k] & 0xFFFFFFFF00000000ull) | (uint32_t)(lane * 8 + k);
+                }
+                if (mine_h) *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
+                wave_sync();
+                // both reads of the wavefront at once, all 64 lanes (pdq178_coop.h)
+                const bool f0 = (m_tied & 0xFFFFFFFFull) != 0ull || (RPW == 1 && m_tied != 0ull), f1 = RPW == 2 && (m_tied >> 32) != 0ull;
+                const int len0 = f0 ? rdlane(n_valid, 0) : 0, len1 = f1 ? rdlane(n_valid, 32) : 0;
+                pdq178::coop_sort<N>(c_key, 0, len0, HALF * N, len1, beam_size, cs, lane);
+                for (int j = q; mine_h && j < Bn; j += HALF) s_rank[(int)(uint32_t)list[j]] = (int8_t)j;
+                wave_sync();
+                const uint64_t again = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (mine_h) rank[k] = (int)(int8_t)(uint8_t)(again >> (8 * k));
+                wave_sync();
             }
         }
+
+        // ---- survivors publish their records in rank order; old slot i says where its own candidate went ----
+        // kInBeam == 64 << kSlotShift: the published value, shifted, IS the (slot, IN-BEAM) field of a child entry
+        static_assert(kInBeam == (64 << kSlotShift) && kSlotMask == 63, "child-entry bit layout");
+        s_fate[lane] = rank[0] >= 0 ? (rank[0] | 64) : 0;
+        // a record is {label prob, gap prob, node, meta | jump, source lane, -, CRF state}: written dword by dword
+        // behind an offset the compiler cannot see through, so that the stores pair up from whatever registers hold
+        // the values (ds_write2_b32) instead of being moved into four consecutive ones for a 16-byte store
+        int *const recw = reinterpret_cast<int *>(s_rec);
+        auto publish = [&](int slot, int a, int b, int c, int d, int e, int f) {
+            int off = 8 * slot;
+            FCD_OPAQUE_V(off);
+            recw[off + 0] = a;
+            recw[off + 1] = b;
+            recw[off + 2] = c;
+            recw[off + 3] = d;
+            recw[off + 4] = e;
+            recw[off + 5] = lane;
+            if (CRF) recw[off + 7] = f;
+        };
+        if (rank[0] >= 0) {  // the entry's own node stays in the beam
+            const int meta = 0 | ((tip + 1) << 2) | (depth << 5);
+            publish(hbase + rank[0], __float_as_int(slp), __float_as_int(sgp), node, meta, jump, state);
+        }
+        const int jumpc = (depth % kSeg == 0) ? node : jump;  // a child's nearest segment head
+        const int metac = 1 | ((depth + 1) << 5);
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            const int rk = rank[l + 1];
+            if (rk >= 0) {  // the child by label l enters the beam
+                // kind 1, or 2 when it has been there before (EVER: its row is in HBM)
+                const int ever = (int)(((uint32_t)child[l] >> 30) & 1u);
+                const int meta = (metac + ever) | ((l + 1) << 2);
+                publish(hbase + rk, __float_as_int(contrib[l]), 0, ccand[l], meta, jumpc,
+                        CRF ? ((state * NL) & s_mask) + l : 0);  // :97
+            }
+        }
+        wave_sync();
+
+        // ---- child entries: follow a beam entry to its new slot, mark entering children, evict rows ----
+#pragma unroll
+        for (int l = 0; l < NL; ++l) {
+            int ch = child[l];
+            if (ent && go && ch >= 0) {
+                if (ch & kInBeam) {
+                    int *const fp = &s_fate[hbase + ((ch >> kSlotShift) & kSlotMask)];
+                    const int fate = *fp;
+                    ch = (ch & kStored) | (fate << kSlotShift);
+                    // the child leaves the beam while this entry -- its parent, the only reader of that slot --
+                    // stays: tell the child's lane (see the row eviction below)
+                    if (fate == 0 && rank[0] >= 0) *fp = kParentStays;
+                } else if (rank[l + 1] >= 0) {
+                    ch = (ch & kIdMask) | kEver | kInBeam | (rank[l + 1] << kSlotShift);
+                }
+            }
+            child[l] = ch;
+        }
+        // word l of this entry's child row as it is stored: the entry as it is (its beam-position bits are stale by
+        // the time the row is read back and are stripped THERE, on the rare path), or -1
+        int row_word[RW];
+#pragma unroll
+        for (int l = 0; l < RW; ++l) row_word[l] = -1;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) row_word[l] = child[l];
+#pragma unroll
+        for (int l = 0; l < RW; ++l) s_child[lane * RW + l] = -1;
+#pragma unroll
+        for (int l = 0; l < NL; ++l) s_child[lane * RW + l] = child[l];
+        wave_sync();
+
+        // ---- the new beam: lane r of the half takes record r ----
+        const int me = hbase + (q < Bn ? q : 0);
+        const int4 ra = s_rec[2 * me], rb = s_rec[2 * me + 1];
+        const int2 r0 = *reinterpret_cast<const int2 *>(&s_rec[2 * hbase]);
+        const int n_node = ra.z;
+        const int n_meta = ra.w;
+        const int n_kind = n_meta & 3;
+        const int src = rb.y & 63;
+        int n_child[NL];
+#pragma unroll
+        for (int l = 0; l < NL; ++l) n_child[l] = n_kind == 0 ? s_child[src * RW + l] : -1;
+        const bool reload = q < Bn && n_kind == 2;
+        const uint64_t m_reload = ballot(reload);
+        // A node re-enters the beam only as the extension of its parent, so it needs a proper ancestor in the beam:
+        // once every beam entry is at least as deep as the node none is one, and none ever will be (the minimum
+        // depth of the beam never decreases).  Such a node's row is dead and is not written -- most evicted rows.
+        int mind = 0x7FFFFFFF;  // smallest depth among the survivors this entry contributes ...
+        if (rank[0] >= 0) mind = depth;
+#pragma unroll
+        for (int l = 0; l < NL; ++l)
+            if (rank[l + 1] >= 0) mind = min(mind, depth + 1);
+        mind = bperm(hbase + HALF - 1, half_min_in_last_lane<RPW>(mind));  // ... and in the whole new beam
+        // One level further the test is still exact: a node exactly one deeper than the shallowest beam entry can
+        // only come back through its PARENT (any other ancestor is shallower than every beam entry).  A parent that
+        // stays in the beam has just said so (above); a parent that is only now coming back itself has not, so a
+        // step in which any node re-enters the beam keeps the plain depth test.
+        const bool any_reent = hmask(m_reload) != 0ull;
+        const bool parent_stays = s_fate[lane] == kParentStays;
+        const bool dead = depth <= mind || (depth == mind + 1 && !parent_stays && !any_reent);
+        if (ent && go && rank[0] < 0 && node >= 0 && !dead) {
+            // this node leaves the beam and may come back: its child row has to exist in HBM from now on
+            int4 *row = reinterpret_cast<int4 *>(row_at(node));
+            row[0] = make_int4(row_word[0], row_word[1], row_word[2], row_word[3]);
+            if (RW == 8) row[1] = make_int4(row_word[RW - 4], row_word[RW - 3], row_word[RW - 2], row_word[RW - 1]);
+        }
+        if (m_reload != 0ull) {
+            // a node that was in the beam before comes back: its row is in HBM, and which of its
+            // children are beam entries right now has to be looked up
+            int e[NL], eid[NL], eslot[NL];
+#pragma unroll
+            for (int l = 0; l < NL; ++l) {
+                e[l] = reload ? load_i32_l2(reinterpret_cast<int32_t *>(row_at(n_node)) + l) : -1;
+                if (e[l] >= 0) e[l] &= kStored;  // (written with whatever beam-position bits the entry had at eviction)
+#ifdef FCD_HIPEMU  // (lockstep emulation: device memory arrives poisoned with 0xA5)
+                if (reload && e[l] == (int)0xA5A5A5A5) {  // never written: the dead-row test was wrong
+                    fprintf(stderr, "beam_lane: node %d re-entered the beam but its child row was never stored\n", n_node);
+                    abort();
+                }
+#endif
+                // only a child that has been a beam entry (EVER) can be one now
+                eid[l] = (e[l] >= 0 && (e[l] & kEver)) ? (e[l] & kIdMask) : -2;
+                eslot[l] = -1;
+            }
+            // few lanes reload in a step: take them one at a time and let their read's lanes look for each
+            // of their children among the new beam's nodes (one compare + ballot per child)
+            for (uint64_t m_rel = ballot(reload); m_rel != 0ull; m_rel &= m_rel - 1ull) {
+                const int L = __builtin_ctzll(m_rel);
+                const int Lb = L & ~(HALF - 1);
+#pragma unroll
+                for (int l = 0; l < NL; ++l) {
+                    const int id = rdlane(eid[l], L);
+                    if (id >= 0) {
+                        uint64_t m_hit = ballot(q < Bn && n_node == id);
+                        if (RPW == 2) m_hit = Lb ? (m_hit >> 32) : (m_hit & 0xFFFFFFFFull);
+                        if (m_hit != 0ull && lane == L) eslot[l] = __builtin_ctzll(m_hit);
+                    }
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NL; ++l)
+                if (reload)
+                    n_child[l] = eslot[l] >= 0 ? ((e[l] & kStored) | kInBeam | (eslot[l] << kSlotShift)) : e[l];
+        }
+        if (CRF) {
+            if (q < Bn) state = rb.w;
+#pragma unroll
+            for (int c = 0; c < N; ++c)   // in flight during the divisions below
+                rowv[c] = t + 1 < T ? load_post(post, (int64_t)(t + 1) * st_t + (int64_t)state * st_s + c * st_n, dt) : 0.0f;
+        }
+        const float top = __int_as_float(r0.x) + __int_as_float(r0.y);  // beam[0].probability() :278
+        if (q < Bn) {
+            node = n_node;
+            lp = __int_as_float(ra.x) / top;
+            gp = __int_as_float(ra.y) / top;
+            tip = ((n_meta >> 2) & 7) - 1;
+            depth = n_meta >> 5;
+            jump = rb.x;
+#pragma unroll
+            for (int l = 0; l < NL; ++l) child[l] = n_child[l];
+        }
+        if (go) B = Bn;
+        wave_sync();
     }
 
     // ---- walk the best labelling leaf -> root (:285-300), segment-parallel (see beam_wave.hip) ----

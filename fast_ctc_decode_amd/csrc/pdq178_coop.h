@@ -263,6 +263,7 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             const uint32_t k0 = (uint32_t)__builtin_amdgcn_readlane((int)pk, sg);
 #pragma unroll
             for (int j = 0; j < MAXP; ++j) {
+                if (wb >= 64 * (j + 1) || we <= 64 * j) continue;  // (wave-uniform: the segment does not reach this plane)
                 const int p = 64 * j + lane;
                 if (p >= wb && p < we) {
                     myseg[j] = sg;
@@ -273,8 +274,18 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             }
         }
         Masks<MAXP> mk;
+        int ones_upto[MAXP];     // ones in the planes below plane j
+        bool plane_busy[MAXP];   // some element of plane j belongs to a segment of this round
+        {
+            int run = 0;
 #pragma unroll
-        for (int j = 0; j < MAXP; ++j) mk.m[j] = __builtin_amdgcn_ballot_w64(bit[j]);
+            for (int j = 0; j < MAXP; ++j) {
+                mk.m[j] = __builtin_amdgcn_ballot_w64(bit[j]);
+                plane_busy[j] = __builtin_amdgcn_ballot_w64(myseg[j] >= 0) != 0ull;
+                ones_upto[j] = run;
+                run += __builtin_popcountll(mk.m[j]);
+            }
+        }
 
         // ---- C: leaders: the scans of `partition`, the block split of partition_in_blocks, the counts ----
         int a0 = 0, a1 = 0, a2 = 0, p0 = 0, p2 = 0, count = 0, cL = 0, cR = 0;
@@ -310,6 +321,12 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
         bool s_normal[MAXP];
 #pragma unroll
         for (int j = 0; j < MAXP; ++j) {
+            role[j] = 0;
+            kk[j] = 0;
+            s_cnt[j] = 0;
+            s_wb[j] = 0;
+            s_normal[j] = false;
+            if (!plane_busy[j]) continue;  // (wave-uniform)
             const int src = (myseg[j] < 0 ? 0 : myseg[j]) << 2;
             const int g_a01 = __builtin_amdgcn_ds_bpermute(src, w_a01), g_a2b = __builtin_amdgcn_ds_bpermute(src, w_a2b);
             const int g_p02 = __builtin_amdgcn_ds_bpermute(src, w_p02), g_cnt = __builtin_amdgcn_ds_bpermute(src, w_cnt);
@@ -321,7 +338,7 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             if (myseg[j] < 0) continue;
             const int p = 64 * j + lane;
             const int e0 = g_a01 & 0xFFFF, e1 = g_a01 >> 16, e2 = g_a2b & 0xFFFF, q0 = g_p02 & 0xFFFF, q2 = g_p02 >> 16;
-            const int ones_before = mk.prefix1(p);
+            const int ones_before = ones_upto[j] + __builtin_popcountll(mk.m[j] & bits_below(lane));
             if (s_normal[j]) {
                 if (p >= e0 && p < e1 && !bit[j]) {         // offsets_l, in tracing order (left to right)
                     role[j] = 1;
