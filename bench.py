@@ -327,6 +327,78 @@ def viterbi_roofline(fcd, torch, dev, n_reads=16384, reps=20, half=False):
     }
 
 
+def free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N ...` without a launcher around it: start N ranks of this script through
+    torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1) and pass their exit code on.  Fewer than N
+    devices: say so and fail (rc 2) -- never a silent smaller run."""
+    import subprocess
+    if not args.stub:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            sys.stderr.write("bench.py: --gpus %d but this node shows %d GPU(s); nothing was run\n" % (args.gpus, have))
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL across processes needs it on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def stub_main(args):
+    """The distributed skeleton of main() with nothing to decode (TEST ONLY, --stub): gloo on the CPU."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher and the flag must agree)" % (args.gpus, world))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    B = args.batch or CONFIGS[args.config]["batch"]
+
+    def step():
+        time.sleep(0.002 * (1 + rank))  # ranks of different speed: the clock must be the slowest one's
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    mine = time.perf_counter() - t0
+    t = torch.tensor([mine], dtype=torch.float64)
+    allr = [torch.zeros_like(t) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(allr, t)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    else:
+        allr = [t.clone()]
+    elapsed = float(t.item())
+    if rank == 0:
+        print(json.dumps({"metric": "reads/s (T=4000, N=5, beam=%d)" % CONFIGS[args.config]["beam"], "stub": True,
+                          "value": world * B * args.steps / elapsed, "unit": "reads/s", "n_gpus": world, "steps": args.steps,
+                          "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+                          "scaling": "weak", "ranks": {"world_size": dist.get_world_size() if world > 1 else 1, "backend": "gloo",
+                                                       "per_rank_ms_per_step": [float(a.item()) / args.steps * 1e3 for a in allr]},
+                          "config": {"baseline_config": args.config, "reads_per_gpu": B}}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -353,7 +425,15 @@ def main():
                          "with the next step's search on a second HIP stream")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise RCCL and run the gather even with one rank (path check on a 1-GPU box)")
+    ap.add_argument("--stub", action="store_true",
+                    help="TEST ONLY (tests/test_bench_launcher.py): no GPU, no search -- the launcher, the rendezvous "
+                         "(gloo), the barriers and the max-over-ranks clock with a sleeping stand-in for the step")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher of N ranks (one per GPU) of this very script
+        raise SystemExit(self_launch(args))
+    if args.stub:
+        return stub_main(args)
     cfg = CONFIGS[args.config]
     beam, thr = cfg["beam"], cfg["thr"]
 
@@ -366,8 +446,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (the launcher and the flag must agree)" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -466,6 +545,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    my_elapsed = elapsed
 
     # kernel duration: the C ABI brackets every launch of the timed region with a HIP event pair
     # on the launch stream (torch's current stream); read them back after the final sync.
@@ -474,8 +554,14 @@ def main():
     k_ms = sum(ms * n for ms, n in tm) / max(k_calls, 1)
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    per_rank = [None]
     if distributed:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+        # every rank's own clock and search-kernel time, for the record (rank 0 prints them)
+        mine = torch.tensor([my_elapsed / args.steps * 1e3, k_ms], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank[0] = [[float(v) for v in t.cpu()] for t in allr]
     elapsed = float(t_max.item())
 
     if rank == 0:
@@ -522,6 +608,12 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
             "scaling": "weak",
+            "ranks": {"world_size": dist.get_world_size() if distributed else 1, "backend": "rccl" if distributed else None,
+                      "per_rank_ms_per_step": [p[0] for p in per_rank[0]] if per_rank[0] else None,
+                      "per_rank_search_kernel_ms": [p[1] for p in per_rank[0]] if per_rank[0] else None,
+                      # what a step costs beyond its search kernel: the result gather (pack, RCCL, unpack on rank 0)
+                      # and launch gaps, on the slowest rank
+                      "step_ms_beyond_the_search_kernel": elapsed / args.steps * 1e3 - k_ms},
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
