@@ -356,6 +356,10 @@ int fcd_create(int device, fcd_handle **out) {
 
 int fcd_destroy(fcd_handle *h) {
     if (!h) return FCD_OK;
+    if (h->job_active) {  // its lane threads still write buffers this call would free: fcd_job_end comes first
+        h->err = "a host job is running on this handle (fcd_job_end it first)";
+        return FCD_E_INVALID;
+    }
     DeviceGuard dev_guard(h->device);
     host_job_release_lanes(h, true);
     (void)hipStreamSynchronize(h->stream);
@@ -419,6 +423,7 @@ int fcd_set_workspace_limit(fcd_handle *h, int64_t bytes) {
 int fcd_release_workspace(fcd_handle *h) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (h->job_active) return fail(h, FCD_E_INVALID, "a host job is running on this handle (fcd_job_end it first)");
     FCD_DEVICE(h);
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->own_stream != h->stream) FCD_HIP(h, hipStreamSynchronize(h->own_stream));

@@ -228,7 +228,6 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
     } restore{prev, h->device};
     hipStream_t st = h->stream;
     const int W = (int)std::min<int64_t>(res->out_stride, 1 << 30);
-    const int pb = res->out_stride <= 65535 ? 2 : 4;  // time indices are < out_stride (csrc/pack.hip)
     // meta: offsets of this shard [n_reads + 1] | unpack offsets [n_total + world] (destination)
     const size_t o_uoffs = ((size_t)(n_reads + 1) * 8 + 15) & ~(size_t)15;
     int rc = need(c, c->meta, o_uoffs + (is_dst ? (size_t)(n_total + c->world) * 8 : 0) + 16);
@@ -244,26 +243,43 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
     char *meta = reinterpret_cast<char *>(c->meta.p);
     char *fixed = reinterpret_cast<char *>(c->fixed.p);
     uint64_t *d_offs = reinterpret_cast<uint64_t *>(meta);
+    // fixed: [0, 16) the agreed {largest label total, largest out_stride} | [16, 20) header flag | [32, 48) this rank's
+    // {label total, out_stride} | [64, ...) prefix sums of the read counts
     uint64_t *d_max = reinterpret_cast<uint64_t *>(fixed);
-    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 8);
+    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 16);
+    uint64_t *d_mine = reinterpret_cast<uint64_t *>(fixed + 32);
     int64_t *d_first = reinterpret_cast<int64_t *>(fixed + 64);
     FCD_HIP(h, launch_result_offsets(res->out_len, n_reads, W, d_offs, st));
-    // one count for every rank: the largest label total decides the buffer size (with the largest shard)
+    // Every rank must hand ncclGather the SAME byte count, and that depends on two things: the largest label total
+    // and the width of the time indices (2 bytes below 65536 rows) -- i.e. on the largest out_stride.  Both are agreed
+    // on with one 16-byte all-reduce (a rank whose shard is padded differently would otherwise send another size
+    // and hang or corrupt the collective).
+    uint64_t *pin64 = reinterpret_cast<uint64_t *>(c->pin);
+    pin64[4] = (uint64_t)res->out_stride;
+    FCD_HIP(h, hipMemcpyAsync(d_mine, d_offs + n_reads, 8, hipMemcpyDeviceToDevice, st));
+    FCD_HIP(h, hipMemcpyAsync(d_mine + 1, pin64 + 4, 8, hipMemcpyHostToDevice, st));
     if (c->comm) {
-        rc = nccl_check(c, rccl().AllReduce(d_offs + n_reads, d_max, 1, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
+        rc = nccl_check(c, rccl().AllReduce(d_mine, d_max, 2, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
         if (rc) return rc;
     } else {
-        FCD_HIP(h, hipMemcpyAsync(d_max, d_offs + n_reads, 8, hipMemcpyDeviceToDevice, st));
+        FCD_HIP(h, hipMemcpyAsync(d_max, d_mine, 16, hipMemcpyDeviceToDevice, st));
     }
-    // (the flag next to it is the PREVIOUS gather's header check: reported one call late, or by fcd_comm_synchronize)
-    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 16, hipMemcpyDeviceToHost, st));
+    // (the flag behind them is the PREVIOUS gather's header check: reported one call late, or by fcd_comm_synchronize)
+    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 24, hipMemcpyDeviceToHost, st));
     FCD_HIP(h, hipStreamSynchronize(st));  // the one host wait of the gather
-    const uint64_t max_total = *reinterpret_cast<const uint64_t *>(c->pin);
-    if (reinterpret_cast<const int32_t *>(c->pin)[2] != 0) {
+    const uint64_t max_total = pin64[0], max_stride = pin64[1];
+    // From here to the ncclGather nothing may return early on one rank only: the other ranks are about to enqueue
+    // theirs.  What this rank has to complain about is remembered and reported once its own gather is in the stream.
+    const char *late_error = nullptr;
+    if (reinterpret_cast<const int32_t *>(c->pin)[4] != 0) {
         FCD_HIP(h, hipMemsetAsync(d_bad, 0, 4, st));
-        return comm_fail(c, FCD_E_INVALID, "gather: a shard's header contradicted the read counts (earlier call)");
+        late_error = "gather: a shard's header contradicted the read counts (earlier call)";
     }
-    if (max_total > (uint64_t)n_max * (uint64_t)W) return comm_fail(c, FCD_E_HIP, "gather: impossible label total");
+    const int Wmax = (int)std::min<uint64_t>(max_stride, 1u << 30);
+    if (max_total > (uint64_t)n_max * (uint64_t)Wmax) return comm_fail(c, FCD_E_HIP, "gather: impossible label total");  // (the same on every rank)
+    if (is_dst && n_total > 0 && (uint64_t)out->out_stride < max_stride)
+        late_error = "gather: the destination's out_stride is narrower than a shard's (out_stride must match across ranks)";
+    const int pb = max_stride <= 65535 ? 2 : 4;  // time indices are < out_stride (csrc/pack.hip)
     const int64_t nbytes = fcd_packed_result_bytes(n_max, (int64_t)max_total, pb);
     rc = need(c, c->send, (size_t)nbytes);
     if (rc) return rc;
@@ -281,6 +297,7 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
         if (rc) return rc;
         gathered = reinterpret_cast<const uint8_t *>(c->recv.p);
     }
+    if (late_error) return comm_fail(c, FCD_E_INVALID, late_error);
     if (!is_dst || n_total == 0) return FCD_OK;
     // shard s owns rows [first[s], first[s + 1]) of the destination; the prefix sums live on the device and
     // are refreshed only when the counts change
@@ -309,9 +326,9 @@ int fcd_comm_synchronize(fcd_comm *c) {
     int32_t bad = 0;
     if (hipStreamSynchronize(h->stream) != hipSuccess) rc = FCD_E_HIP;
     if (rc == FCD_OK && c->fixed.p) {
-        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 8, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
+        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 16, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
         if (bad) {
-            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 8, 0, 4);
+            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 16, 0, 4);
             rc = comm_fail(c, FCD_E_INVALID, "gather: the header of shard " + std::to_string(bad - 1) +
                                                  " contradicts the read counts / buffer size");
         }

@@ -246,6 +246,21 @@ int64_t chunk_default(const fcd_handle *h, int64_t B, int n_lanes) {
     return (c + 63) & ~63ll;
 }
 
+// A chunk is uploaded as ONE copy of the span its reads cover.  In read-major storage that span is the chunk; in
+// time-major storage -- the (T, B, N) tensor seen as a batch: stride_read = S * N, stride_t = B * S * N -- it is nearly
+// the whole tensor, for every chunk: the pipeline would move the input over PCIe n_chunks times.  Such a batch goes
+// up once (one chunk; fcd_*_host: the single-shot path).
+bool chunk_span_wasteful(const fcd_batch *in, int64_t chunk, bool crf) {
+    const int64_t n = std::min<int64_t>(chunk, in->n_reads);
+    if (n <= 0 || in->T <= 0 || n >= in->n_reads) return false;
+    const double S = crf ? (double)in->S : 1.0;
+    const double dense = (double)n * (double)in->T * S * (double)in->N;
+    double span = 1.0 + (double)(n - 1) * (double)in->stride_read + (double)(in->T - 1) * (double)in->stride_t +
+                  (double)(in->N - 1) * (double)in->stride_n;
+    if (crf) span += (double)(in->S - 1) * (double)in->stride_s;
+    return span > 2.0 * dense;
+}
+
 int job_begin(fcd_handle *h, const fcd_batch *in, const HostCall &call, int want, fcd_job **out) {
     if (!h || !out) return FCD_E_INVALID;
     *out = nullptr;
@@ -278,6 +293,7 @@ int job_begin(fcd_handle *h, const fcd_batch *in, const HostCall &call, int want
     const int64_t B = in->n_reads;
     j->n_lanes = lanes_default(h);
     j->chunk = chunk_default(h, B, j->n_lanes);
+    if (chunk_span_wasteful(in, j->chunk, call.op == HostOp::CrfBeam || call.op == HostOp::CrfGreedy)) j->chunk = std::max<int64_t>(B, 1);
     j->n_chunks = (int)((B + j->chunk - 1) / j->chunk);
     j->n_lanes = std::max(1, std::min(j->n_lanes, j->n_chunks));
     j->state.assign((size_t)j->n_chunks, 0);
@@ -309,6 +325,7 @@ bool host_job_wanted(fcd_handle *h, const fcd_batch *in, const HostCall &c) {
     const bool crf = c.op == HostOp::CrfBeam || c.op == HostOp::CrfGreedy;
     const double bytes = (double)in->n_reads * (double)in->T * (double)(crf ? in->S : 1) * (double)in->N *
                          (in->dtype == FCD_DTYPE_F32 ? 4.0 : 2.0);
+    if (chunk_span_wasteful(in, chunk_default(h, in->n_reads, lanes_default(h)), crf)) return false;  // e.g. time-major storage
     if (h->pipe_min_bytes >= 0) return in->n_reads >= 2 && bytes >= (double)h->pipe_min_bytes;
     return in->n_reads >= 128 && bytes >= (double)(16 << 20);
 }

@@ -183,8 +183,9 @@ __global__ __launch_bounds__(kScanThreads) void gathered_offsets_kernel(GatherUn
     const uint32_t *hdr = reinterpret_cast<const uint32_t *>(buf);
     uint64_t *offs = p.offsets + p.first[s] + s;
     bool ok = true;
+    uint64_t total = 0;
     if (n > 0) {
-        const uint64_t total = (uint64_t)hdr[0] | ((uint64_t)hdr[1] << 32);
+        total = (uint64_t)hdr[0] | ((uint64_t)hdr[1] << 32);
         const uint32_t pb = hdr[3] & 0xffu;
         ok = (int64_t)hdr[2] == n && (pb == 2 || pb == 4) &&
              16 + 8 * (uint64_t)n + ((total + 3) & ~(uint64_t)3) + total * pb <= (uint64_t)p.stride;
@@ -216,7 +217,15 @@ __global__ __launch_bounds__(kScanThreads) void gathered_offsets_kernel(GatherUn
         if (tid == kScanThreads - 1) s_carry = before + incl;
         __syncthreads();
     }
-    if (tid == 0) offs[n] = s_carry;
+    // the lengths must add up to the header's total: a shard whose lengths promise more than it holds would send
+    // the unpack past its end (and, for the last shard, past the gathered buffer) -- its rows are left empty instead
+    __syncthreads();
+    if (ok && n > 0 && s_carry != total) {
+        if (tid == 0) atomicMax(p.bad, 1 + s);
+        for (int64_t i = tid; i <= n; i += kScanThreads) offs[i] = 0;
+    } else if (tid == 0) {
+        offs[n] = s_carry;
+    }
 }
 
 __global__ __launch_bounds__(256) void gathered_unpack_kernel(GatherUnpack p) {

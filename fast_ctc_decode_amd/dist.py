@@ -258,7 +258,11 @@ def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
 
     r       this rank's BatchResult (numpy or torch)
     counts  reads per rank (len == world size), e.g. from shard_bounds
-    scratch optional dict reused across calls to avoid re-allocating the buffers
+    scratch optional dict reused across calls to avoid re-allocating the buffers.  WITH a scratch dict the BatchResult
+            returned on dst LIVES IN IT: the next call with the same dict overwrites its labels / path / out_len /
+            status arrays -- copy what must outlive the next step (or pass a fresh dict per result you keep) -- and
+            a shard header that contradicts `counts` is reported by the NEXT call, or by check_gather(scratch):
+            call check_gather(scratch) after the last step.
     Returns the concatenated BatchResult on dst, None elsewhere."""
     import torch
     import torch.distributed as dist
@@ -297,7 +301,9 @@ def gather_batch_result(r, counts, dst=0, group=None, scratch=None):
 
 
 def decode_sharded(x_local, decode_fn, counts, dst=0, group=None, scratch=None):
-    """Decode this rank's shard with `decode_fn(x_local) -> BatchResult`, then one gather to dst."""
+    """Decode this rank's shard with `decode_fn(x_local) -> BatchResult`, then one gather to dst.  (With `scratch`
+    the result on dst is valid until the next call with the same dict -- see gather_batch_result; call
+    check_gather(scratch) after the last step.)"""
     r = decode_fn(x_local)
     return gather_batch_result(r, counts, dst=dst, group=group, scratch=scratch)
 

@@ -171,7 +171,7 @@ typedef struct fcd_result {
 int fcd_version(void);                                   /* major*1000 + minor */
 int fcd_device_count(void);                              /* number of visible HIP devices, 0 if none */
 int fcd_create(int device, fcd_handle **out);            /* binds to a device, creates its own stream */
-int fcd_destroy(fcd_handle *h);
+int fcd_destroy(fcd_handle *h);                         /* FCD_E_INVALID while a host job (fcd_*_host_begin) is open */
 int fcd_set_stream(fcd_handle *h, void *hip_stream);     /* launch on this hipStream_t; NULL = the HIP null (legacy default) stream */
 int fcd_reset_stream(fcd_handle *h);                     /* back to the handle's own non-blocking stream */
 int fcd_synchronize(fcd_handle *h);
@@ -362,9 +362,11 @@ int fcd_unpack_results_dev(fcd_handle *h, const uint8_t *buf, int64_t n_reads, u
  *                        fcd_beam_search_dev wrote) -> on rank `dst`, `out` receives all ranks' rows in global read
  *                        order (counts[k] = reads of rank k; out->out_stride >= res->out_stride).  Steps, all on
  *                        the handle's stream: prefix sums + pack of the used prefixes (u16 times below 65536 rows),
- *                        an 8-byte ncclAllReduce(MAX) so that all ranks send one size, ONE ncclGather, and on `dst`
+ *                        a 16-byte ncclAllReduce(MAX) of {label total, out_stride} so that all ranks send one size (the
+ *                        ranks' out_stride should be equal; the destination's must not be narrower), ONE ncclGather, and on `dst`
  *                        the unpack of every shard with one pair of launches.  The call waits for the device once
- *                        (the agreed size: 8 bytes); the gather and the unpack are left in flight on the stream.
+ *                        (the agreed size: 16 bytes); the gather and the unpack are left in flight on the stream.  An error a
+ *                        rank finds after the all-reduce is reported once its own ncclGather is enqueued: no rank is left hanging.
  *   fcd_comm_synchronize waits for the stream and reports a shard whose header contradicted `counts`
  *                        (FCD_E_INVALID; such a shard's rows are left empty, never read out of bounds). */
 #define FCD_COMM_ID_BYTES 128
