@@ -101,7 +101,7 @@ int check_result(fcd_handle *h, const fcd_batch *in, const fcd_result *out, bool
 
 BatchDesc to_desc(const fcd_batch *in, bool crf) {
     BatchDesc d;
-    d.post = in->post;
+    d.post = static_cast<const float *>(in->post);  // (typed by `dtype`; the kernels convert on load)
     d.lengths = in->lengths;
     d.n_reads = in->n_reads;
     d.T = in->T;
@@ -660,9 +660,9 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     float *ln2 = ln1 + n1;
     int *d_width = reinterpret_cast<int *>(ln2 + n2);
     Timer tm(h);
-    FCD_HIP(h, launch_ln_convert(in1->post, in1->dtype, B, in1->T, S, N, in1->stride_read, in1->stride_t,
+    FCD_HIP(h, launch_ln_convert(static_cast<const float *>(in1->post), in1->dtype, B, in1->T, S, N, in1->stride_read, in1->stride_t,
                                  is_crf ? in1->stride_s : 0, in1->stride_n, ln1, h->stream));
-    FCD_HIP(h, launch_ln_convert(in2->post, in2->dtype, B, in2->T, S, N, in2->stride_read, in2->stride_t,
+    FCD_HIP(h, launch_ln_convert(static_cast<const float *>(in2->post), in2->dtype, B, in2->T, S, N, in2->stride_read, in2->stride_t,
                                  is_crf ? in2->stride_s : 0, in2->stride_n, ln2, h->stream));
     FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), h->stream));
     FCD_HIP(h, launch_env_width(envelope, B, env_stride, in1->T, in2->T, in1->lengths,

@@ -150,12 +150,13 @@ void run_batch_once(Lane &L, std::vector<Req *> &batch) {
         for (int64_t i = 0; i < n; ++i) {
             const fcd_batch *b = batch[i]->in;
             float *dst = x + i * Tmax * N;
+            const float *src = static_cast<const float *>(b->post);  // (the coalescer takes float32 reads only)
             lengths[i] = b->T;
             if (b->stride_n == 1 && b->stride_t == N) {
-                std::memcpy(dst, b->post, (size_t)(b->T * N) * sizeof(float));
+                std::memcpy(dst, src, (size_t)(b->T * N) * sizeof(float));
             } else {
                 for (int64_t t = 0; t < b->T; ++t)
-                    for (int64_t j = 0; j < N; ++j) dst[t * N + j] = b->post[t * b->stride_t + j * b->stride_n];
+                    for (int64_t j = 0; j < N; ++j) dst[t * N + j] = src[t * b->stride_t + j * b->stride_n];
             }
         }
         fcd_batch in{};

@@ -119,7 +119,7 @@ typedef struct fcd_handle fcd_handle;
 enum { FCD_DTYPE_F32 = 0, FCD_DTYPE_F16 = 1, FCD_DTYPE_BF16 = 2 };
 
 typedef struct fcd_batch {
-    const float *post;  /* element type `dtype`: cast a uint16_t pointer for the 16-bit types */
+    const void *post;   /* elements of type `dtype`: float (FCD_DTYPE_F32) or 16-bit words (F16 / BF16) */
     int64_t n_reads;
     int64_t T;          /* rows allocated per read */
     int64_t S;          /* CRF states; 1 for the plain searches */
