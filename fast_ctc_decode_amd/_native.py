@@ -24,7 +24,7 @@ TIE_DEFAULT, TIE_PDQ178, TIE_STABLE = -1, 0, 1
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
-    "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev", "fcd_debug_pdq178_coop_sort_dev",
+    "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev", "fcd_debug_pdq178_coop_sort_dev", "fcd_debug_pdq178_coop_profile",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
@@ -126,6 +126,7 @@ def bind(lib):
     lib.fcd_set_default_tie_order.argtypes = [i32]
     lib.fcd_debug_pdq178_sort_dev.argtypes = [P, P, i64, i64, P]
     lib.fcd_debug_pdq178_coop_sort_dev.argtypes = [P, P, i64, i64, P, i32, i32]
+    lib.fcd_debug_pdq178_coop_profile.argtypes = [P, P, i32]
     lib.fcd_debug_set_first_pass_divisor.argtypes = [P, i32]
     lib.fcd_debug_set_duplex_profile.argtypes = [P, P]
     lib.fcd_last_kernel_ms.argtypes = [P]

@@ -473,6 +473,15 @@ int fcd_debug_pdq178_coop_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lis
     return FCD_OK;
 }
 
+int fcd_debug_pdq178_coop_profile(fcd_handle *h, uint64_t cycles[16], int reset) {
+    if (!h || !cycles) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    FCD_DEVICE(h);
+    FCD_HIP(h, hipStreamSynchronize(h->stream));
+    FCD_HIP(h, coop_prof_read(reinterpret_cast<unsigned long long *>(cycles), reset != 0));
+    return FCD_OK;
+}
+
 int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor) {
     if (!h || divisor < 0) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);

@@ -180,6 +180,7 @@ hipError_t launch_logadd_sweep(int which, uint32_t first, uint32_t last, unsigne
 hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, hipStream_t stream);
 hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, int planes,
                                     int keep, hipStream_t stream);
+hipError_t coop_prof_read(unsigned long long *out16, bool reset);  // developer instrument of the probe kernels
 // the tie order searches on this handle use (capi.hip)
 int effective_tie_order(const fcd_handle *h);
 

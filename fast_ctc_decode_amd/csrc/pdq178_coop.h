@@ -47,6 +47,31 @@ enum { kActDone = 0, kActNormal = 1, kActEqual = 2 };
 #define FCD_LDS_AS __attribute__((address_space(3)))  // ds_* instructions instead of flat_* ones: a third of the latency
 #endif
 
+#if defined(FCD_COOP_PROF) && !defined(FCD_HIPEMU)
+// developer instrument (tools/dev/time_coop.py): shader cycles per phase, summed over the calls of lane 0's wavefronts
+__device__ unsigned long long g_coop_prof[16];
+#define FCD_COOP_STAMP(slot)                                                             \
+    do {                                                                                 \
+        const unsigned long long now__ = __builtin_amdgcn_s_memtime();                   \
+        prof_acc__[slot] += (unsigned)(now__ - prof_last__);                             \
+        prof_last__ = now__;                                                             \
+    } while (0)
+#define FCD_COOP_STAMP_INIT                                         \
+    unsigned prof_acc__[11] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};    \
+    unsigned long long prof_last__ = __builtin_amdgcn_s_memtime()
+#define FCD_COOP_COUNT_ROUND ++prof_acc__[9]
+#define FCD_COOP_COUNT_CALL                                                                   \
+    do {                                                                                      \
+        prof_acc__[10] = 1;                                                                   \
+        for (int i__ = 0; i__ < 11; ++i__) atomicAdd(&g_coop_prof[i__], (unsigned long long)prof_acc__[i__]); \
+    } while (0)
+#else
+#define FCD_COOP_COUNT_CALL ((void)0)
+#define FCD_COOP_COUNT_ROUND ((void)0)
+#define FCD_COOP_STAMP(slot) ((void)0)
+#define FCD_COOP_STAMP_INIT ((void)0)
+#endif
+
 namespace coop_detail {
 
 __device__ __forceinline__ void sync() {
@@ -120,8 +145,12 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
     const vptr v = (vptr)v_generic;
     FCD_LDS_AS CoopScratch<MAXP> *const s = (FCD_LDS_AS CoopScratch<MAXP> *)s_generic;
 
+    FCD_COOP_STAMP_INIT;
     // ---- boundaries known from the start; lists that are leaves or too long for one-round partitions ----
-    for (int p = lane; p < kPos + 8; p += 64) s->cut[p] = 0;
+    {
+        FCD_LDS_AS uint64_t *c8 = reinterpret_cast<FCD_LDS_AS uint64_t *>(s->cut);  // (the struct is 16-byte aligned, kPos even)
+        for (int p = lane; p < (kPos + 8) / 8; p += 64) c8[p] = 0ull;
+    }
     sync();
     int nseg = 0;
     if (lane == 0) {
@@ -150,7 +179,9 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
     }
     sync();
 
+    FCD_COOP_STAMP(0);
     while (nseg > 0) {
+        FCD_COOP_STAMP(7);
         // ---- A: every segment's leader picks the pivot (and does what only ever touches a few elements) ----
         int base = 0, len = 0, pred = -1, limit = 0;
         bool wbal = true, wpar = true;
@@ -245,6 +276,7 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             }
         }
         sync();
+        FCD_COOP_STAMP(1);
 
         // ---- B: one lane per element: which side of its segment's pivot does it belong to? ----
         elem_t val[MAXP];
@@ -287,8 +319,18 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             }
         }
 
+        FCD_COOP_STAMP(2);
         // ---- C: leaders: the scans of `partition`, the block split of partition_in_blocks, the counts ----
         int a0 = 0, a1 = 0, a2 = 0, p0 = 0, p2 = 0, count = 0, cL = 0, cR = 0;
+        auto ones_below = [&](int x) -> int {  // ones at positions < x: the plane's running count + one masked popcount
+            int c = 0;
+#pragma unroll
+            for (int j = 0; j < MAXP; ++j) {
+                const int lo = x - 64 * j;
+                if (lo > 0 && lo <= 64) c = ones_upto[j] + __builtin_popcountll(mk.m[j] & bits_below(lo));
+            }
+            return c;  // (x = 0: no plane qualifies, 0)
+        };
         if (lane < nseg && act != kActDone) {
             const int wb = base + 1, we = base + len;
             if (act == kActNormal) {
@@ -297,25 +339,26 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
                 a2 = last1 + 1 > a0 ? last1 + 1 : a0;              // while l < r && !is_less(v[r - 1], pivot)
                 const int rem = a2 - a0;                           // <= 2 * BLOCK: one round, is_done at once
                 a1 = a0 + rem / 2;                                 // block_l = rem / 2, block_r = rem - block_l
-                p0 = mk.prefix1(a0);
-                const int p1 = mk.prefix1(a1);
-                p2 = mk.prefix1(a2);
+                p0 = ones_below(a0);
+                const int p1 = ones_below(a1);
+                p2 = ones_below(a2);
                 cL = (a1 - a0) - (p1 - p0);                        // left block: elements that are NOT less than the pivot
                 cR = p2 - p1;                                      // right block: elements that are
                 count = cL < cR ? cL : cR;
             } else {
-                p0 = mk.prefix1(wb);
-                p2 = mk.prefix1(we);
+                p0 = ones_below(wb);
+                p2 = ones_below(we);
                 const int nE = (we - wb) - (p2 - p0);              // elements equal to the pivot: they end up on the left
                 a0 = wb;
                 a1 = wb + nE;
                 a2 = we;
-                count = mk.prefix1(a1) - p0;                       // greater ones inside the left zone == equal ones outside it
+                count = ones_below(a1) - p0;                       // greater ones inside the left zone == equal ones outside it
             }
         }
         // what an element needs to know about its segment, two 16-bit fields to a word, fetched from the leader's lane
         const int w_a01 = a0 | (a1 << 16), w_a2b = a2 | ((base + 1) << 16), w_p02 = p0 | (p2 << 16), w_cnt = count | (act << 16);
 
+        FCD_COOP_STAMP(3);
         // ---- D: every misplaced element's index among the misplaced ones of its side -> position tables ----
         int role[MAXP], kk[MAXP], s_cnt[MAXP], s_wb[MAXP];
         bool s_normal[MAXP];
@@ -363,6 +406,7 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
         }
         sync();
 
+        FCD_COOP_STAMP(4);
         // ---- E: the moves.  NORMAL: the cyclic permutation L0 <- R0 <- L1 <- R1 ... <- R(count-1) <- L0 of the first
         // `count` misplaced pairs; EQUAL: the k-th greater element from the left swaps with the k-th equal one from
         // the right.  Every mover still holds its own value in a register. ----
@@ -378,6 +422,7 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
         }
         sync();
 
+        FCD_COOP_STAMP(5);
         // ---- F: leaders: park the left-over misplaced elements, put the pivot in place, queue the children ----
         int c_base[2] = {0, 0}, c_len[2] = {0, 0}, c_pred[2] = {-1, -1}, c_flag[2] = {0, 0};
         if (lane < nseg && act != kActDone) {
@@ -450,7 +495,10 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
         }
         nseg = __builtin_popcountll(q0) + __builtin_popcountll(q1);
         sync();
+        FCD_COOP_STAMP(6);
+        if (lane == 0) FCD_COOP_COUNT_ROUND;
     }
+    FCD_COOP_STAMP(7);
 
     // ---- leaves: what is left between two boundaries and holds 20 elements or fewer ends in pdqsort's insertion
     // sort -- a stable sort: every element ranks itself inside its leaf.  (Longer stretches are finished regions:
@@ -466,7 +514,13 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
         const int p = 64 * j + lane;
         dest[j] = -1;
         val[j] = 0;
-        const bool in_list = (len0 > 0 && p >= start0 && p < start0 + len0) || (len1 > 0 && p >= start1 && p < start1 + len1);
+        // (a leaf that starts behind the kept prefix of its list is nobody's business: 20 positions of slack cover
+        // every leaf that reaches into it)
+        const int reach = keep < kPos ? keep + 20 : kPos;
+        const bool in1 = len1 > 0 && p >= start1 && p < start1 + len1, in0 = len0 > 0 && p >= start0 && p < start0 + len0;
+        const int list_start = in1 ? start1 : start0;
+        const bool in_list = in0 || in1;
+        if (__builtin_amdgcn_ballot_w64(in_list && p < list_start + reach) == 0ull) continue;  // (wave-uniform: nothing of this plane matters)
         if (!in_list) continue;
         // nearest boundary at or below p, nearest one above it (every list starts and ends with one)
         int lo = -1, hi = -1;
@@ -485,13 +539,17 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             if (lo < 0 && dn) lo = 64 * jj + 63 - __builtin_clzll(dn);
         }
         const int n = hi - lo;
-        if (lo < 0 || hi < 0 || n < 2 || n > 20) continue;
+        if (lo < 0 || hi < 0 || n < 2 || n > 20 || lo >= list_start + keep) continue;  // (whole leaves: in or out)
         val[j] = v[p];
         const uint32_t key = (uint32_t)(val[j] >> 32);
         int rank = 0;
-        for (int q = lo; q < hi; ++q) {
-            const uint32_t kq = (uint32_t)(v[q] >> 32);
-            rank += (kq > key || (kq == key && q < p)) ? 1 : 0;
+        for (int q = lo; q < hi; q += 4) {  // four keys per trip: their loads travel together
+            uint32_t kq[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) kq[u] = (uint32_t)(v[q + u < kPos ? q + u : kPos - 1] >> 32);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                rank += (q + u < hi && (kq[u] > key || (kq[u] == key && q + u < p))) ? 1 : 0;
         }
         dest[j] = lo + rank;
     }
@@ -500,6 +558,8 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
     for (int j = 0; j < MAXP; ++j)
         if (dest[j] >= 0) v[dest[j]] = val[j];
     sync();
+    FCD_COOP_STAMP(8);
+    if (lane == 0) FCD_COOP_COUNT_CALL;
 }
 
 // The same as a call (the wide-beam kernel: its 128-VGPR budget cannot hold the routine next to its own state).

@@ -4,6 +4,7 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
+#define FCD_COOP_PROF 1  // (this translation unit only: the probe kernels; the search kernels carry no stamps)
 #include "pdq178_coop.h"
 
 namespace fcd {
@@ -62,6 +63,21 @@ hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t st
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
+}
+
+hipError_t coop_prof_read(unsigned long long *out16, bool reset) {
+#ifndef FCD_HIPEMU
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(pdq178::g_coop_prof), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(pdq178::g_coop_prof), zero, sizeof(zero));
+    }
+    return hipSuccess;
+#else
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    return hipSuccess;
+#endif
 }
 
 hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens,

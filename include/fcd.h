@@ -198,6 +198,10 @@ int fcd_debug_pdq178_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, i
  * above on those positions. */
 int fcd_debug_pdq178_coop_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens,
                                    int planes, int keep);
+/* Developer instrument: shader cycles the wavefronts of the call above spent per phase of the routine, summed since the
+ * last reset (HOST array): [0] set-up, [1..6] phases A-F of the partition rounds, [7] loop overhead, [8] leaves,
+ * [9] rounds, [10] calls.  (The search kernels carry no stamps.) */
+int fcd_debug_pdq178_coop_profile(fcd_handle *h, uint64_t cycles[16], int reset);
 /* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
  * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
  * it) and decode the reads that outgrow their slab again in worst-case slabs carved from the same arena.  A

@@ -41,6 +41,14 @@ def run(n, planes, keep, pairs=1024, serial=False):
         best = min(best, e0.elapsed_time(e1))
     print("n=%d planes=%d keep=%d %s: %.1f us per launch (%d wavefronts, one sort of two lists each)" %
           (n, planes, keep, "serial" if serial else "coop", best * 1e3, pairs), flush=True)
+    if not serial:
+        import ctypes as C
+        cyc = (C.c_uint64 * 16)()
+        lib.fcd_debug_pdq178_coop_profile(h.ptr, cyc, 1)
+        calls = max(int(cyc[10]), 1)
+        names = ["setup", "A pivot", "B classify", "C scans", "D tables", "E moves", "F leftovers+queue", "loop", "leaves"]
+        print("    cycles per call: " + ", ".join("%s %.0f" % (nm, cyc[i] / calls) for i, nm in enumerate(names)) +
+              "; rounds per call %.2f; total %.0f" % (cyc[9] / calls, sum(cyc[:9]) / calls), flush=True)
 
 
 for n, planes in ((25, 1), (128, 5), (64, 5), (160, 5)):
