@@ -643,10 +643,19 @@ struct BatchCall {
 // reference counts are then settled in ONE pass over the table (T additions instead of one increment per entry: eight
 // million at config 2).  Nothing in between can raise or touch a Python object.
 struct ListFill {
-    PyObject **items;
+    PyObject *list;
     uint64_t off;
     size_t len;
 };
+
+// The bulk path below writes PyListObject::ob_item from threads that do not hold the GIL and settles reference counts
+// with Py_SET_REFCNT -- fine on a GIL build of CPython (tested: test_list_paths_reference_counts), wrong wherever a
+// reference count is not a plain field one thread may add to: free-threaded CPython (Py_GIL_DISABLED: biased counts,
+// per-object locks), the limited API, other interpreters.  There every entry is stored the documented way, under the
+// GIL, with its own Py_INCREF.  -DFCD_PORTABLE_LISTS=1 forces that path (tests/test_host_layers.py builds it so).
+#if !defined(FCD_PORTABLE_LISTS) && (defined(Py_GIL_DISABLED) || defined(Py_LIMITED_API) || defined(PYPY_VERSION) || defined(GRAALVM_PYTHON))
+#define FCD_PORTABLE_LISTS 1
+#endif
 
 void fill_list_paths(const fcd_chunk &ch, const std::vector<ListFill> &fills, IntTable &ints, int64_t T) {
     if (fills.empty()) return;
@@ -662,6 +671,17 @@ void fill_list_paths(const fcd_chunk &ch, const std::vector<ListFill> &fills, In
     }
     ints.fill_below(n_idx);
     PyObject *const *tab = ints.v.data();
+#ifdef FCD_PORTABLE_LISTS
+    for (const ListFill &f : fills)
+        for (size_t k = 0; k < f.len; ++k) {
+            size_t v = ch.path_bytes == 2 ? static_cast<const uint16_t *>(ch.path)[f.off + k]
+                                          : static_cast<const uint32_t *>(ch.path)[f.off + k];
+            if (v >= n_idx) v = 0;
+            Py_INCREF(tab[v]);
+            PyList_SET_ITEM(f.list, (Py_ssize_t)k, tab[v]);
+        }
+    return;
+#else
     size_t total = 0;
     for (const ListFill &f : fills) total += f.len;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
@@ -671,18 +691,19 @@ void fill_list_paths(const fcd_chunk &ch, const std::vector<ListFill> &fills, In
         uint32_t *cnt = counts[t].data();
         for (size_t i = t; i < fills.size(); i += nt) {
             const ListFill &f = fills[i];
+            PyObject **items = reinterpret_cast<PyListObject *>(f.list)->ob_item;
             if (ch.path_bytes == 2) {
                 const uint16_t *src = static_cast<const uint16_t *>(ch.path) + f.off;
                 for (size_t k = 0; k < f.len; ++k) {
                     const uint32_t v = src[k] < n_idx ? src[k] : 0u;
-                    f.items[k] = tab[v];
+                    items[k] = tab[v];
                     ++cnt[v];
                 }
             } else {
                 const uint32_t *src = static_cast<const uint32_t *>(ch.path) + f.off;
                 for (size_t k = 0; k < f.len; ++k) {
                     const uint32_t v = src[k] < n_idx ? src[k] : 0u;
-                    f.items[k] = tab[v];
+                    items[k] = tab[v];
                     ++cnt[v];
                 }
             }
@@ -705,6 +726,7 @@ void fill_list_paths(const fcd_chunk &ch, const std::vector<ListFill> &fills, In
 #endif
         Py_SET_REFCNT(tab[i], Py_REFCNT(tab[i]) + add);
     }
+#endif
 }
 
 // Turns one result chunk into Python objects and stores them in result[read_begin ..].
@@ -779,7 +801,7 @@ void emit_chunk(const fcd_chunk &ch, const std::vector<std::string> &alpha, cons
                 Py_DECREF(seq);
                 throw py::error_already_set();
             }
-            if (len) fills.push_back(ListFill{reinterpret_cast<PyListObject *>(pth)->ob_item, off, len});
+            if (len) fills.push_back(ListFill{pth, off, len});
         }
         PyObject *tup = PyTuple_New(2);
         if (!tup) {
@@ -1159,6 +1181,11 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
         "set_tie_order(order): how the beam searches order EQUAL probabilities among more than 20 candidates -- "
         "'pdq178' (default: the order Rust 1.78's sort_unstable_by, i.e. the reference wheels, leaves them in) or "
         "'stable' (ascending node index).  Process-wide (include/fcd.h, FCD_TIE_*).");
+#ifdef FCD_PORTABLE_LISTS
+    m.attr("_portable_lists") = true;
+#else
+    m.attr("_portable_lists") = false;
+#endif
     m.def("tie_order", []() { return std::string(fcd_get_tie_order(nullptr) == FCD_TIE_STABLE ? "stable" : "pdq178"); });
     m.def(
         "set_coalescing",

@@ -68,27 +68,31 @@ def build(force=False, opt="-O1"):
     return LIB
 
 
-def pymodule_path():
+def pymodule_path(portable=False):
     import sysconfig
-    return os.path.join(OUT, "fast_ctc_decode" + sysconfig.get_config_var("EXT_SUFFIX"))
+    d = os.path.join(OUT, "portable") if portable else OUT
+    return os.path.join(d, "fast_ctc_decode" + sysconfig.get_config_var("EXT_SUFFIX"))
 
 
-def build_pymodule(force=False):
+def build_pymodule(force=False, portable=False):
     """The product's csrc/pymodule.cpp (the compiled host layer) linked against libfcd_emu.so instead of
-    libfcd_hip.so, so that its batch functions can be exercised without a GPU.  Test infrastructure only."""
+    libfcd_hip.so, so that its batch functions can be exercised without a GPU.  Test infrastructure only.
+    portable: with -DFCD_PORTABLE_LISTS=1 -- the list[int] path of interpreters without a plain reference count."""
     import sysconfig
 
     import pybind11
 
     lib = build(force=False)
-    out = pymodule_path()
+    out = pymodule_path(portable)
+    os.makedirs(os.path.dirname(out), exist_ok=True)
     src = os.path.join(CSRC, "pymodule.cpp")
     deps = [src, os.path.join(ROOT, "include", "fcd.h"), lib]
     if not force and os.path.exists(out) and all(os.path.getmtime(d) <= os.path.getmtime(out) for d in deps):
         return out
     subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-shared", "-fPIC", "-fvisibility=hidden",
                            "-ffp-contract=off", "-I", pybind11.get_include(), "-I", sysconfig.get_paths()["include"],
-                           src, "-o", out, "-L", OUT, "-lfcd_emu", "-Wl,-rpath,$ORIGIN"])
+                           src, "-o", out, "-L", OUT, "-lfcd_emu", "-Wl,-rpath," + OUT] +
+                          (["-DFCD_PORTABLE_LISTS=1"] if portable else []))
     return out
 
 

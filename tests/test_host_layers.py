@@ -90,3 +90,38 @@ def test_reference_messages():
             m.viterbi_search(X, "")
         with pytest.raises(ValueError, match="alphabet size does not match probability matrix dimensions"):
             m.viterbi_search(X, "NACG")
+
+
+def test_portable_list_path_gives_identical_objects():
+    """csrc/pymodule.cpp fills list[int] paths from worker threads with bulk reference counts -- CPython-with-a-GIL
+    internals.  Built with -DFCD_PORTABLE_LISTS=1 (what Py_GIL_DISABLED / the limited API / other interpreters select)
+    every entry is stored under the GIL with its own Py_INCREF: the objects must be the same, and so must the counts
+    (the shared ints return to their baseline when the results are dropped).  On the emulated kernels."""
+    import gc
+    import importlib.util
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "hipemu"))
+    import build as emu_build
+    from emu_util import emu_compiled_module
+    spec = importlib.util.spec_from_file_location("fcd_hipemu_portable.fast_ctc_decode", emu_build.build_pymodule(portable=True))
+    portable = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(portable)
+    fast = emu_compiled_module()
+    assert portable._portable_lists is True and fast._portable_lists is False
+    rng = np.random.default_rng(1)
+    x = rng.random((9, 600, 5), dtype=np.float32)
+    x /= np.linalg.norm(x, axis=-1, keepdims=True)
+    a = portable.beam_search_batch(x, "NACGT", 5, 0.1, paths="list")
+    b = fast.beam_search_batch(x, "NACGT", 5, 0.1, paths="list")
+    assert a == b and all(type(p) is list and all(type(v) is int for v in p) for _, p in a)
+    big = [v for _, p in a for v in p if v > 256]
+    some = big[len(big) // 2]
+    uses = sum(1 for _, p in a for v in p if v is some)
+    held = sum(1 for v in big if v is some)
+    before = sys.getrefcount(some)
+    del big, a
+    gc.collect()
+    assert before - sys.getrefcount(some) == uses + held
