@@ -37,6 +37,6 @@ from .api import (  # noqa: F401
     viterbi_search_batch_raw,
 )
 from ._native import (  # noqa: F401
-    KERNEL_AUTO, KERNEL_GENERIC, KERNEL_LANE, KERNEL_WAVE, KERNEL_WAVE1, LOGADD_LOGSUMEXP, LOGADD_MAX,
+    KERNEL_AUTO, KERNEL_GENERIC, KERNEL_LANE, KERNEL_WAVE, KERNEL_WAVE1, LOGADD_LOGSUMEXP, LOGADD_LOGSUMEXP_GLIBC235, LOGADD_MAX,
     TIE_DEFAULT, TIE_PDQ178, TIE_STABLE, default_tie_order, set_default_tie_order,
 )

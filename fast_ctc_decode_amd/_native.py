@@ -15,7 +15,7 @@ OK = 0
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_NODEVICE = -1, -2, -3, -4, -5
 ST_OK, ST_RAN_OUT_OF_BEAM, ST_INCOMPARABLE, ST_INVALID_ENVELOPE, ST_BAD_STATE, ST_INTERNAL = range(6)
 KERNEL_AUTO, KERNEL_GENERIC, KERNEL_WAVE, KERNEL_WAVE1, KERNEL_LANE = 0, 1, 2, 3, 4
-LOGADD_LOGSUMEXP, LOGADD_MAX = 0, 1
+LOGADD_LOGSUMEXP, LOGADD_MAX, LOGADD_LOGSUMEXP_GLIBC235 = 0, 1, 2
 DTYPE_F32, DTYPE_F16, DTYPE_BF16 = 0, 1, 2
 TIE_DEFAULT, TIE_PDQ178, TIE_STABLE = -1, 0, 1
 
@@ -34,7 +34,7 @@ SYMBOLS = [
     "fcd_beam_search_duplex_dev", "fcd_beam_search_duplex_host",
     "fcd_crf_beam_search_duplex_dev", "fcd_crf_beam_search_duplex_host",
     "fcd_duplex_envelope_dev", "fcd_duplex_envelope_host",
-    "fcd_logspace_probe_dev", "fcd_logadd_latency_probe_dev", "fcd_logadd_sweep_dev", "fcd_phred",
+    "fcd_logspace_probe_dev", "fcd_debug_glibc235_dev", "fcd_logadd_latency_probe_dev", "fcd_logadd_sweep_dev", "fcd_phred",
     "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
     "fcd_coalescer_create", "fcd_coalescer_destroy", "fcd_coalescer_beam_search", "fcd_coalescer_viterbi_search",
     "fcd_coalescer_stats", "fcd_coalescer_last_error",
@@ -151,6 +151,7 @@ def bind(lib):
         getattr(lib, "fcd_duplex_envelope_" + sfx).argtypes = [
             P, i64, P, P, P, i64, P, i64, P, P, P, i64, P, i64, i64, P, i64]
     lib.fcd_logspace_probe_dev.argtypes = [P, P, P, P, P, i64, i32]
+    lib.fcd_debug_glibc235_dev.argtypes = [P, i32, P, P, i64]
     lib.fcd_logadd_latency_probe_dev.argtypes = [P, i32, i32, P, P]
     lib.fcd_logadd_sweep_dev.argtypes = [P, i32, C.c_uint32, C.c_uint32, P]
     lib.fcd_packed_result_bytes.argtypes = [i64, i64, i32]

@@ -342,17 +342,18 @@ def crf_greedy_search_batch(network_outputs, init_states, alphabet, qstring=Fals
 _DEFAULT_LOGADD = [nat.LOGADD_LOGSUMEXP]
 
 
-_MODE_CODES = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX,
-               nat.LOGADD_LOGSUMEXP: nat.LOGADD_LOGSUMEXP, nat.LOGADD_MAX: nat.LOGADD_MAX}
+_MODE_CODES = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX, "logsumexp_glibc235": nat.LOGADD_LOGSUMEXP_GLIBC235,
+               nat.LOGADD_LOGSUMEXP: nat.LOGADD_LOGSUMEXP, nat.LOGADD_MAX: nat.LOGADD_MAX,
+               nat.LOGADD_LOGSUMEXP_GLIBC235: nat.LOGADD_LOGSUMEXP_GLIBC235}
 
 
 def set_duplex_logadd_mode(mode):
     """Select the duplex log-space addition: "logsumexp" (the reference built with
-    --no-default-features; BASELINE.json's north star) or "max" (the reference's default `fastexp`
-    feature, whose exp() is identically 0.0 -- what the PyPI wheels compute; SURVEY.md finding 3)."""
-    _DEFAULT_LOGADD[0] = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX,
-                          nat.LOGADD_LOGSUMEXP: nat.LOGADD_LOGSUMEXP,
-                          nat.LOGADD_MAX: nat.LOGADD_MAX}[mode]
+    --no-default-features; BASELINE.json's north star; ln / exp / ln_1p correctly rounded), "max" (the reference's
+    default `fastexp` feature, whose exp() is identically 0.0 -- what the PyPI wheels compute; SURVEY.md finding 3) or
+    "logsumexp_glibc235" (logsumexp on glibc 2.35's expf / logf / log1pf, bit for bit: what the reference computes on
+    such a host -- csrc/glibc235_math.h)."""
+    _DEFAULT_LOGADD[0] = _MODE_CODES[mode]
 
 
 def set_tie_order(order):

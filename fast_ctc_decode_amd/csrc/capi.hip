@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "fcd_internal.h"
+#include "glibc235_math.h"
 
 using namespace fcd;
 
@@ -646,7 +647,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     if (in1->N != in2->N) return fail(h, FCD_E_INVALID, "inner axes of the network outputs do not match");
     if (in1->N < 2) return fail(h, FCD_E_UNSUPPORTED, "alphabet needs at least one label besides the blank");
     if (beam_size < 1) return fail(h, FCD_E_INVALID, "beam_size cannot be 0");
-    if (logadd_mode != FCD_LOGADD_LOGSUMEXP && logadd_mode != FCD_LOGADD_MAX)
+    if (logadd_mode != FCD_LOGADD_LOGSUMEXP && logadd_mode != FCD_LOGADD_MAX && logadd_mode != FCD_LOGADD_LOGSUMEXP_GLIBC235)
         return fail(h, FCD_E_INVALID, "unknown logadd_mode");
     if (!out) return fail(h, FCD_E_INVALID, "null result");
     const int64_t B = in1->n_reads;
@@ -670,9 +671,9 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     int *d_width = reinterpret_cast<int *>(ln2 + n2);
     Timer tm(h);
     FCD_HIP(h, launch_ln_convert(static_cast<const float *>(in1->post), in1->dtype, B, in1->T, S, N, in1->stride_read, in1->stride_t,
-                                 is_crf ? in1->stride_s : 0, in1->stride_n, ln1, h->stream));
+                                 is_crf ? in1->stride_s : 0, in1->stride_n, ln1, logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235, h->stream));
     FCD_HIP(h, launch_ln_convert(static_cast<const float *>(in2->post), in2->dtype, B, in2->T, S, N, in2->stride_read, in2->stride_t,
-                                 is_crf ? in2->stride_s : 0, in2->stride_n, ln2, h->stream));
+                                 is_crf ? in2->stride_s : 0, in2->stride_n, ln2, logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235, h->stream));
     FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), h->stream));
     FCD_HIP(h, launch_env_width(envelope, B, env_stride, in1->T, in2->T, in1->lengths,
                                 in2->lengths, d_width, h->stream));
@@ -696,7 +697,8 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.len1 = in1->lengths; a.len2 = in2->lengths; a.env = envelope; a.env_stride = env_stride;
     a.N = N; a.beam_size = (int)beam_size;
     // ln(threshold) with the kernels' definition of ln: correctly rounded f32 (duplex.rs:454)
-    a.thr_ln = (float)log((double)beam_cut_threshold);
+    a.thr_ln = logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235 ? g235::logf235(beam_cut_threshold)
+                                                           : (float)log((double)beam_cut_threshold);
     a.collapse = collapse_repeats ? 1 : 0; a.mode = logadd_mode;
     a.S = S; a.crf = is_crf ? 1 : 0;
     a.init1 = is_crf ? crf->init1 : nullptr; a.init2 = is_crf ? crf->init2 : nullptr;
@@ -973,6 +975,15 @@ int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float 
     if (n < 0 || (n > 0 && (!a || !b || !out_add || !out_ln))) return fail(h, FCD_E_INVALID, "null array");
     FCD_DEVICE(h);
     FCD_HIP(h, launch_logspace_probe(a, b, out_add, out_ln, n, logadd_mode, h->stream));
+    return FCD_OK;
+}
+
+int fcd_debug_glibc235_dev(fcd_handle *h, int which, const float *x, float *y, int64_t n) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (which < 0 || which > 2 || n < 0 || (n > 0 && (!x || !y))) return fail(h, FCD_E_INVALID, "bad argument");
+    FCD_DEVICE(h);
+    FCD_HIP(h, launch_glibc235_apply(which, x, y, n, h->stream));
     return FCD_OK;
 }
 

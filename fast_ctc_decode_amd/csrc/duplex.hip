@@ -37,6 +37,7 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
+#include "glibc235_math.h"
 #include "logadd_fast.h"
 
 namespace fcd {
@@ -97,6 +98,8 @@ __device__ __forceinline__ float ladd(float a, float b, const LogAddCoef &K) {
     }
     if (small == kNegInf) return big;
     if (MODE == FCD_LOGADD_MAX) return big + 0.0f;
+    // FCD_LOGADD_LOGSUMEXP_GLIBC235: the same expression on glibc 2.35's expf / log1pf, bit for bit (glibc235_math.h)
+    if (MODE == FCD_LOGADD_LOGSUMEXP_GLIBC235) return big + g235::log1pf235(g235::expf235(small - big));
     // big + ln_1p(exp(small - big)), exp and ln_1p each correctly rounded to f32.  Fast binary64
     // evaluations (logadd_fast.h, verified exhaustively on the host) with Ziv's rounding test; the
     // general-purpose library routines only run for the ~1e-6 of arguments that test rejects and
@@ -128,6 +131,8 @@ __device__ __forceinline__ float ladd_lockstep(float a, float b, const LogAddCoe
     const bool ab = a <= b;
     const float big = ab ? b : a, small = ab ? a : b;  // a NaN ends up in `big` or makes x NaN
     if (MODE == FCD_LOGADD_MAX) return small == kNegInf ? big : big + 0.0f;
+    if (MODE == FCD_LOGADD_LOGSUMEXP_GLIBC235)  // (a parity mode: no fast paths, no votes)
+        return small == kNegInf ? big : big + g235::log1pf235(g235::expf235(small - big));
     const float x = small - big;  // <= 0, or NaN
     // ladd()'s shortcuts, folded: the transcendental part is needed unless x < -86 -- and then it is still needed when
     // `big` is so small (below 2^-90) that exp(x) could show in the sum, which the slow exponential handles down to
@@ -1530,19 +1535,20 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
 
 // ---- prepass: ln of the posteriors into contiguous log-space copies (:452-453) ----
 __global__ void ln_convert_kernel(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N,
-                                  int64_t s_read, int64_t s_t, int64_t s_s, int64_t s_n, float *out) {
+                                  int64_t s_read, int64_t s_t, int64_t s_s, int64_t s_n, float *out, int glibc235) {
     const int64_t total = n_reads * T * S * N;
     for (int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int64_t j = idx % N, st = (idx / N) % S, t = (idx / ((int64_t)N * S)) % T,
                       r = idx / ((int64_t)N * S * T);
-        out[idx] = ln_cr(load_post(x, r * s_read + t * s_t + st * s_s + j * s_n, dtype));
+        const float v = load_post(x, r * s_read + t * s_t + st * s_s + j * s_n, dtype);
+        out[idx] = glibc235 ? g235::logf235(v) : ln_cr(v);  // LogSpace::new (:24-26)
     }
 }
 
 // test hook: out[i] = LogSpace::add(a[i], b[i]) and ln(a[i]) exactly as the duplex kernels compute them.  mode: the
-// log-add flavour, + 2 for the form the window-building loop uses (ladd_lockstep: every lane of the wavefront in step,
-// shortcuts folded into selects) instead of the general one.
+// log-add flavour (FCD_LOGADD_*), + 4 for the form the window-building loop uses (ladd_lockstep: every lane of the
+// wavefront in step, shortcuts folded into selects) instead of the general one.
 __global__ void logspace_probe_kernel(const float *a, const float *b, float *out_add, float *out_ln,
                                       int64_t n, int mode) {
     const LogAddCoef K = logadd_coef();
@@ -1553,11 +1559,16 @@ __global__ void logspace_probe_kernel(const float *a, const float *b, float *out
         const bool valid = i < n;
         const float x = valid ? a[i] : -1.0f, y = valid ? b[i] : -2.0f;
         float r;
-        if (mode & 2) r = (mode & 1) ? ladd_lockstep<FCD_LOGADD_MAX>(x, y, K) : ladd_lockstep<FCD_LOGADD_LOGSUMEXP>(x, y, K);
-        else r = (mode & 1) ? ladd<FCD_LOGADD_MAX>(x, y) : ladd<FCD_LOGADD_LOGSUMEXP>(x, y);
+        const int flavour = mode & 3;
+        if (flavour == FCD_LOGADD_LOGSUMEXP_GLIBC235)
+            r = (mode & 4) ? ladd_lockstep<FCD_LOGADD_LOGSUMEXP_GLIBC235>(x, y, K) : ladd<FCD_LOGADD_LOGSUMEXP_GLIBC235>(x, y);
+        else if (mode & 4)
+            r = flavour == FCD_LOGADD_MAX ? ladd_lockstep<FCD_LOGADD_MAX>(x, y, K) : ladd_lockstep<FCD_LOGADD_LOGSUMEXP>(x, y, K);
+        else
+            r = flavour == FCD_LOGADD_MAX ? ladd<FCD_LOGADD_MAX>(x, y) : ladd<FCD_LOGADD_LOGSUMEXP>(x, y);
         if (valid) {
             out_add[i] = r;
-            out_ln[i] = ln_cr(x);
+            out_ln[i] = flavour == FCD_LOGADD_LOGSUMEXP_GLIBC235 ? g235::logf235(x) : ln_cr(x);
         }
     }
 }
@@ -1638,12 +1649,12 @@ size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S) {
 }
 
 hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
-                             int64_t s_t, int64_t s_s, int64_t s_n, float *out, hipStream_t stream) {
+                             int64_t s_t, int64_t s_s, int64_t s_n, float *out, int glibc235, hipStream_t stream) {
     const int64_t total = n_reads * T * S * N;
     if (total <= 0) return hipSuccess;
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 16);
     hipLaunchKernelGGL(ln_convert_kernel, dim3(blocks), dim3(256), 0, stream, x, dtype, n_reads, T, S, N,
-                       s_read, s_t, s_s, s_n, out);
+                       s_read, s_t, s_s, s_n, out, glibc235);
     return hipGetLastError();
 }
 
@@ -1655,6 +1666,20 @@ hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_st
     const unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(env_width_kernel, dim3(blocks), dim3(256), 0, stream, env, n_pairs,
                        env_stride, T1cap, T2cap, len1, len2, out);
+    return hipGetLastError();
+}
+
+namespace {
+__global__ void glibc235_apply_kernel(int which, const float *x, float *y, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        y[i] = which == 0 ? g235::expf235(x[i]) : (which == 1 ? g235::logf235(x[i]) : g235::log1pf235(x[i]));
+}
+}  // namespace
+
+hipError_t launch_glibc235_apply(int which, const float *x, float *y, int64_t n, hipStream_t stream) {
+    if (n <= 0) return hipSuccess;
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 8192);
+    hipLaunchKernelGGL(glibc235_apply_kernel, dim3(blocks), dim3(256), 0, stream, which, x, y, n);
     return hipGetLastError();
 }
 
@@ -1698,7 +1723,10 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S);
     // up to two wavefronts per SIMD (2048 pairs on the 256 CUs): the coefficient-pinning instantiation
     const bool pin = a.staged && n_pairs <= 2048;
-    if (a.mode == FCD_LOGADD_MAX)
+    if (a.mode == FCD_LOGADD_LOGSUMEXP_GLIBC235)
+        hipLaunchKernelGGL((duplex_kernel<FCD_LOGADD_LOGSUMEXP_GLIBC235, false>), dim3((unsigned)n_pairs), dim3(64), lds,
+                           stream, p);
+    else if (a.mode == FCD_LOGADD_MAX)
         hipLaunchKernelGGL((duplex_kernel<FCD_LOGADD_MAX, false>), dim3((unsigned)n_pairs), dim3(64), lds,
                            stream, p);
     else if (pin)

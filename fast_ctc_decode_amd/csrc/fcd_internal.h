@@ -133,7 +133,7 @@ struct DuplexArgs {
 
 size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S);
 hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
-                             int64_t s_t, int64_t s_s, int64_t s_n, float *out, hipStream_t stream);
+                             int64_t s_t, int64_t s_s, int64_t s_n, float *out, int glibc235, hipStream_t stream);
 hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,
                             int64_t T2cap, const int64_t *len1, const int64_t *len2, int *out,
                             hipStream_t stream);
@@ -175,6 +175,7 @@ hipError_t launch_unpack_gathered(const uint8_t *gathered, int64_t stride, int w
 
 hipError_t launch_logspace_probe(const float *a, const float *b, float *out_add, float *out_ln,
                                  int64_t n, int mode, hipStream_t stream);
+hipError_t launch_glibc235_apply(int which, const float *x, float *y, int64_t n, hipStream_t stream);
 hipError_t launch_logadd_chain(int n_chain, int mode, uint64_t *cycles, float *sink, hipStream_t stream);
 hipError_t launch_logadd_sweep(int which, uint32_t first, uint32_t last, unsigned long long *counts, hipStream_t stream);
 hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, hipStream_t stream);

@@ -1162,11 +1162,13 @@ PYBIND11_MODULE(fast_ctc_decode, m) {
     auto set_mode = [](const std::string &mode) {
         if (mode == "logsumexp") g_logadd_mode = FCD_LOGADD_LOGSUMEXP;
         else if (mode == "max") g_logadd_mode = FCD_LOGADD_MAX;
-        else throw py::value_error("mode must be 'logsumexp' or 'max'");
+        else if (mode == "logsumexp_glibc235") g_logadd_mode = FCD_LOGADD_LOGSUMEXP_GLIBC235;
+        else throw py::value_error("mode must be 'logsumexp', 'max' or 'logsumexp_glibc235'");
     };
     m.def("set_duplex_logadd_mode", set_mode, "mode"_a,
           "set_duplex_logadd_mode(mode): 'logsumexp' (default; the reference built with --no-default-features) or "
-          "'max' (the reference's default `fastexp` feature, i.e. what the PyPI wheels compute)");
+          "'max' (the reference's default `fastexp` feature, i.e. what the PyPI wheels compute) or 'logsumexp_glibc235' "
+          "(logsumexp on glibc 2.35's expf / logf / log1pf, bit for bit)");
     m.def("_set_duplex_logadd_mode", set_mode);  // earlier name, kept for the tests
     m.def(
         "set_tie_order",

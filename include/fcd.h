@@ -70,7 +70,13 @@ enum {
 /* duplex log-add flavour (SURVEY.md section 0 finding 3) */
 enum {
     FCD_LOGADD_LOGSUMEXP = 0, /* reference built with --no-default-features */
-    FCD_LOGADD_MAX = 1        /* reference's default `fastexp` feature (exp() == 0.0) */
+    FCD_LOGADD_MAX = 1,       /* reference's default `fastexp` feature (exp() == 0.0) */
+    /* FCD_LOGADD_LOGSUMEXP computes ln / exp / ln_1p correctly rounded -- a platform-independent definition.  The
+     * reference computes them with whatever expf / logf / log1pf its process links (src/duplex.rs:17,25,50); this
+     * flavour reproduces ONE such library bit for bit: glibc 2.35 on x86-64 with FMA (csrc/glibc235_math.h; verified
+     * against that libm on every binary32 argument).  Strings then equal the reference's on such a host, not only on
+     * >= 90 % of the pairs.  Slower: no fast paths. */
+    FCD_LOGADD_LOGSUMEXP_GLIBC235 = 2
 };
 
 /* kernel selection for fcd_beam_search_* (0 = pick the fastest that supports the shape) */
@@ -325,9 +331,13 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
 /* Test hook (device pointers, n elements): out_add[i] = LogSpace::add(a[i], b[i]) (src/duplex.rs:42-63)
  * and out_ln[i] = LogSpace::new(a[i]) = ln(a[i]) (:24-26), computed by the very device functions the
  * duplex kernel uses, so the log-space arithmetic can be checked bit for bit against the oracle.
- * logadd_mode: FCD_LOGADD_*, + 2 for the lockstep form of the window-building loop instead of the general one. */
+ * logadd_mode: FCD_LOGADD_*, + 4 for the lockstep form of the window-building loop instead of the general one. */
 int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
                            float *out_ln, int64_t n, int logadd_mode);
+
+/* Test hook: y[i] = f(x[i]) (device pointers) with the device build of csrc/glibc235_math.h -- which = 0 expf, 1 logf,
+ * 2 log1pf -- to be compared with the host's libm (glibc 2.35: identical on every argument). */
+int fcd_debug_glibc235_dev(fcd_handle *h, int which, const float *x, float *y, int64_t n);
 
 /* Developer instrument: one wavefront folds n_chain values into an accumulator with the duplex kernel's
  * LogSpace::add, each add waiting for the previous one; cycles[lane] (DEVICE u64[64]) = shader cycles of the chain,

@@ -1088,6 +1088,12 @@ float fcdo_logspace_add(float a, float b, int mode) {
     if ((mode & 3) == FCDO_LOGADD_MAX) return big + 0.0f; /* big + ln_1p(+-0.0) */
     return big + log1p_m(exp_m(small - big, mode), mode);
 }
+/* (test hook) out[i] = f(x[i]) with the C library's binary32 routine: 0 expf, 1 logf, 2 log1pf -- what the reference's
+ * f32::exp / ln / ln_1p call (src/duplex.rs:17,25,50) on the machine this runs on */
+void fcdo_libm_apply(int which, const float *x, float *out, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) out[i] = which == 0 ? expf(x[i]) : (which == 1 ? logf(x[i]) : log1pf(x[i]));
+}
+
 void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int mode) {
     for (int64_t i = 0; i < n; ++i) out[i] = fcdo_logspace_add(a[i], b[i], mode);
 }

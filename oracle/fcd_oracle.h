@@ -191,6 +191,7 @@ void fcdo_duplex_tie_steps(int64_t out[4], int reset);
 void fcdo_duplex_last_ambiguous(int64_t out[2]);
 /* out[i] = fcdo_logspace_add(a[i], b[i], logadd_mode) -- lets tests compare millions of operands */
 void fcdo_logspace_add_batch(const float *a, const float *b, float *out, int64_t n, int logadd_mode);
+void fcdo_libm_apply(int which, const float *x, float *out, int64_t n); /* 0 expf, 1 logf, 2 log1pf of the host's libm */
 
 /* Order of EQUAL probabilities in the prune of the beam searches (src/search.rs:122,262, src/duplex.rs:620,807:
  * sort_unstable_by).  0 (default): the stable rule -- what Rust's insertion sort does up to 20 candidates, and

@@ -76,6 +76,8 @@ def _load():
     lib.fcdo_logspace_add.restype = f32
     lib.fcdo_logspace_add_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, i32]
     lib.fcdo_logspace_add_batch.restype = None
+    lib.fcdo_libm_apply.argtypes = [i32, C.c_void_p, C.c_void_p, C.c_int64]
+    lib.fcdo_libm_apply.restype = None
     lib.fcdo_logadd_calls.argtypes = [i32]
     lib.fcdo_duplex_tie_steps.argtypes = [C.POINTER(i64), i32]
     lib.fcdo_duplex_tie_steps.restype = None

@@ -105,6 +105,13 @@ def test_duplex(fcd):
         assert fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, logadd_mode=mode) == want
 
 
+def test_duplex_glibc235_flavour(fcd):
+    """FCD_LOGADD_LOGSUMEXP_GLIBC235 == the oracle on the host's libm (this image: glibc 2.35), every pair"""
+    if __import__("platform").libc_ver() != ("glibc", "2.35"):
+        pytest.skip("the host links another libm")
+    D.test_duplex_glibc235_mode_equals_the_oracle_on_the_hosts_libm(fcd)
+
+
 def test_envelope(fcd):
     E.test_envelope_equals_model(fcd, 3)
 

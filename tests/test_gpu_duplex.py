@@ -313,8 +313,10 @@ def test_logspace_arithmetic_bits(fcd):
         oracle.lib.fcdo_logspace_add_batch(x.ctypes.data, y.ctypes.data, out.ctypes.data, x.size, omode)
         return out
 
-    # (modes 2 / 3: the same two flavours in the form the window-building loop evaluates them)
-    for mode, omode in ((0, LSE | CR), (1, MAX | CR), (2, LSE | CR), (3, MAX | CR)):
+    # (+ 4: the same flavours in the form the window-building loop evaluates them; 2 / 6: on glibc 2.35's expf and
+    # log1pf, bit for bit -- compared with the oracle on the HOST'S libm, which in the build image is that library)
+    glibc235 = __import__("platform").libc_ver() == ("glibc", "2.35")
+    for mode, omode in ((0, LSE | CR), (1, MAX | CR), (4, LSE | CR), (5, MAX | CR)) + (((2, LSE), (6, LSE)) if glibc235 else ()):
         h.check(h.lib.fcd_logspace_probe_dev(h.ptr, ad.data_ptr(), bd.data_ptr(), out_add.data_ptr(),
                                              out_ln.data_ptr(), n, mode))
         torch.cuda.synchronize()
@@ -593,3 +595,71 @@ def test_logadd_fast_paths_exhaustive_on_device(fcd):
         assert n == hi - lo + 1 and bad == 0, (which, n, slow, bad)
         assert slow < n * 1e-5          # the slow path stays rare (r01 host sweep: 517 / 397 arguments)
         print("device sweep", "exp" if which == 0 else "ln_1p", n, "arguments,", slow, "to the slow path, 0 wrong")
+
+
+def _libm():
+    import ctypes as C
+    m = C.CDLL("libm.so.6")
+    for f in ("expf", "logf", "log1pf"):
+        getattr(m, f).restype = C.c_float
+        getattr(m, f).argtypes = [C.c_float]
+    return m
+
+
+def _libm_apply(name, x):
+    """f(x) with the C library's binary32 routine, element by element through the oracle's helper (a C loop)"""
+    x = np.ascontiguousarray(x, np.float32)
+    out = np.empty_like(x)
+    oracle.lib.fcdo_libm_apply({"expf": 0, "logf": 1, "log1pf": 2}[name], x.ctypes.data, out.ctypes.data, x.size)
+    return out
+
+
+needs_glibc235 = pytest.mark.skipif(__import__("platform").libc_ver() != ("glibc", "2.35"),
+                                    reason="FCD_LOGADD_LOGSUMEXP_GLIBC235 reproduces glibc 2.35; this host links another libm")
+
+
+@needs_glibc235
+def test_glibc235_device_functions_equal_the_hosts_libm(fcd):
+    """csrc/glibc235_math.h as compiled for gfx950 (v_fma_f64, IEEE division) against the libm of this host -- glibc 2.35
+    on the build image and the GPU box -- on 12.6 M arguments per function: every 1021st binary32 pattern, and dense
+    stretches where the routines change branch.  (All 2^32 arguments: tools/verify/verify_glibc235.c on the host,
+    tools/verify/verify_glibc235_gpu.py on the device; profiles/r04_glibc235_verify.txt.)"""
+    torch = pytest.importorskip("torch")
+    from fast_ctc_decode_amd import _native as nat
+    h = nat.default_handle()
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    pats = np.arange(0, 1 << 32, 1021, dtype=np.uint64).astype(np.uint32)
+    dense = [np.arange(c - (1 << 20), c + (1 << 20), dtype=np.int64).astype(np.uint32) for c in
+             (0x3f800000, 0x3ed413d7, 0xc2b00000, 0x42b00000, 0x00800000, 0xc2cff1b4)]
+    x = np.concatenate([pats] + dense).view(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    yd = torch.empty_like(xd)
+    try:
+        for which, name in enumerate(("expf", "logf", "log1pf")):
+            h.check(h.lib.fcd_debug_glibc235_dev(h.ptr, which, xd.data_ptr(), yd.data_ptr(), x.size))
+            torch.cuda.synchronize()
+            got = yd.cpu().numpy()
+            with np.errstate(all="ignore"):
+                want = _libm_apply(name, x)
+            same = (got.view(np.uint32) == want.view(np.uint32)) | (np.isnan(got) & np.isnan(want))
+            assert same.all(), (name, int((~same).sum()), x[~same][:4], got[~same][:4], want[~same][:4])
+    finally:
+        h.reset_stream()
+
+
+@needs_glibc235
+def test_duplex_glibc235_mode_equals_the_oracle_on_the_hosts_libm(fcd):
+    """FCD_LOGADD_LOGSUMEXP_GLIBC235: strings IDENTICAL to the oracle on the host's libm -- the arithmetic the reference
+    computes on this machine -- on every pair (the correctly-rounded default flavour is held to >= 90 % against it:
+    test_duplex_vs_host_libm_many_pairs), plain and CRF, banded and default envelopes."""
+    x1, x2 = pairs(8100, 48, 140, 130)
+    envs = np.stack([band(140, 130, 20)] * 48)
+    got = gpu_strings(fcd, x1, x2, "NACGT", envs, 5, 0.1, True, "logsumexp_glibc235")
+    assert got == oracle_strings(x1, x2, "NACGT", envs, 5, 0.1, True, LSE)
+    y1, y2 = pairs(8101, 6, 50, 60)
+    got = gpu_strings(fcd, y1, y2, "NACGT", None, 5, 0.0, False, "logsumexp_glibc235")
+    assert got == oracle_strings(y1, y2, "NACGT", None, 5, 0.0, False, LSE)
+    cx1, ci1, cx2, ci2 = crf_pairs(8102, 90, 84)
+    cenv = band(90, 84, 16)
+    assert fcd.crf_beam_search_duplex(cx1, ci1, cx2, ci2, "NACGT", cenv, 5, 0.0, logadd_mode="logsumexp_glibc235") == \
+        oracle.crf_beam_search_duplex(cx1, ci1, cx2, ci2, "NACGT", cenv, 5, 0.0, LSE)
