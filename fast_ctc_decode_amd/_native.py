@@ -41,7 +41,7 @@ SYMBOLS = [
     "fcd_comm_unique_id", "fcd_comm_create", "fcd_comm_wrap", "fcd_comm_destroy", "fcd_gather_results_dev",
     "fcd_comm_synchronize", "fcd_unpack_gathered_dev",
     "fcd_viterbi_search_host_begin", "fcd_beam_search_host_begin", "fcd_crf_beam_search_host_begin",
-    "fcd_crf_greedy_search_host_begin", "fcd_set_host_pipeline", "fcd_job_chunks", "fcd_job_next", "fcd_job_end",
+    "fcd_crf_greedy_search_host_begin", "fcd_viterbi_search_host_ptrs_begin", "fcd_beam_search_host_ptrs_begin", "fcd_set_host_pipeline", "fcd_job_chunks", "fcd_job_next", "fcd_job_end",
 ]
 JOB_PATH, JOB_QUAL, JOB_AMBIGUOUS, JOB_DONE = 1, 2, 4, 1
 
@@ -179,6 +179,8 @@ def bind(lib):
     lib.fcd_beam_search_host_begin.argtypes = [P, BP, i64, f32, i32, i32, i32, PP]
     lib.fcd_crf_beam_search_host_begin.argtypes = [P, BP, P, i64, i64, i64, f32, i32, i32, PP]
     lib.fcd_crf_greedy_search_host_begin.argtypes = [P, BP, P, i64, i64, i32, PP]
+    lib.fcd_viterbi_search_host_ptrs_begin.argtypes = [P, P, P, i64, i64, i32, i32, i32, PP]
+    lib.fcd_beam_search_host_ptrs_begin.argtypes = [P, P, P, i64, i64, i32, i64, f32, i32, i32, i32, PP]
     lib.fcd_set_host_pipeline.argtypes = [P, i32, i64, i64]
     lib.fcd_job_chunks.argtypes = [P, C.POINTER(i64), C.POINTER(i32)]
     lib.fcd_job_next.argtypes = [P, C.POINTER(Chunk)]

@@ -40,12 +40,16 @@ struct fcd_host_lane {
     size_t pack_dev_bytes = 0;
     void *pack_pin = nullptr;  // page-locked mirror the views point into
     size_t pack_pin_bytes = 0;
+    void *in_pin = nullptr;    // page-locked gather buffer of a chunk whose reads arrive as separate arrays (fcd_*_host_ptrs_begin)
+    size_t in_pin_bytes = 0;
 };
 
 struct fcd_job {
     fcd_handle *h = nullptr;
     fcd_batch in{};
     HostCall call{HostOp::Viterbi};
+    const void *const *read_ptrs = nullptr;  // one base pointer per read instead of in.post (contiguous (T_r, N) matrices)
+    const int64_t *read_rows = nullptr;      // their row counts (host array, as long as the job lives)
     int want = 0;
     int64_t chunk = 0;
     int n_chunks = 0, n_lanes = 0;
@@ -101,10 +105,33 @@ int issue_chunk(fcd_job *j, int c) {
     const bool has_path = (j->want & FCD_JOB_PATH) != 0, has_qual = (j->want & FCD_JOB_QUAL) != 0;
     const bool has_amb = (j->want & FCD_JOB_AMBIGUOUS) != 0;
     fcd_batch sub = j->in;
-    sub.post = reinterpret_cast<const float *>(reinterpret_cast<const char *>(j->in.post) +
-                                               b0 * j->in.stride_read * (j->in.dtype == FCD_DTYPE_F32 ? 4 : 2));
+    const size_t esz = j->in.dtype == FCD_DTYPE_F32 ? 4 : 2;
     sub.n_reads = n;
     sub.lengths = j->in.lengths ? j->in.lengths + b0 : nullptr;
+    if (j->read_ptrs) {
+        // Reads that live in separate host arrays (a Python list of ragged matrices: what the reference's callers hold,
+        // src/lib.rs:325,352 take them one by one) are gathered into the lane's page-locked buffer, every lane its own
+        // chunk at the same time, and leave as ONE DMA -- no padded copy of the batch on the caller's side.
+        const size_t row_bytes = (size_t)j->in.N * esz, slot = (size_t)j->in.T * row_bytes;
+        const size_t need = std::max<size_t>((size_t)n * slot, 16);
+        if (L->in_pin_bytes < need) {
+            if (L->in_pin) (void)hipHostFree(L->in_pin);
+            L->in_pin = nullptr;
+            L->in_pin_bytes = 0;
+            if (hipHostMalloc(&L->in_pin, need, hipHostMallocDefault) != hipSuccess)
+                return lane_fail(j, FCD_E_NOMEM, "hipHostMalloc failed (gather buffer)");
+            L->in_pin_bytes = need;
+        }
+        char *dst = reinterpret_cast<char *>(L->in_pin);
+        for (int64_t i = 0; i < n; ++i) {
+            const int64_t rows = std::min<int64_t>(std::max<int64_t>(j->read_rows[b0 + i], 0), j->in.T);
+            if (rows > 0) memcpy(dst + (size_t)i * slot, j->read_ptrs[b0 + i], (size_t)rows * row_bytes);
+        }
+        sub.post = L->in_pin;
+        sub.lengths = j->read_rows + b0;
+    } else {
+        sub.post = reinterpret_cast<const char *>(j->in.post) + b0 * j->in.stride_read * (int64_t)esz;
+    }
     HostCall call = j->call;
     if (crf) call.init = j->call.init + b0 * j->call.init_stride;
     const int64_t W = std::max<int64_t>(j->in.T, 1);
@@ -261,7 +288,8 @@ bool chunk_span_wasteful(const fcd_batch *in, int64_t chunk, bool crf) {
     return span > 2.0 * dense;
 }
 
-int job_begin(fcd_handle *h, const fcd_batch *in, const HostCall &call, int want, fcd_job **out) {
+int job_begin(fcd_handle *h, const fcd_batch *in, const HostCall &call, int want, fcd_job **out,
+              const void *const *read_ptrs = nullptr, const int64_t *read_rows = nullptr) {
     if (!h || !out) return FCD_E_INVALID;
     *out = nullptr;
     std::lock_guard<std::recursive_mutex> g(h->mu);
@@ -288,6 +316,8 @@ int job_begin(fcd_handle *h, const fcd_batch *in, const HostCall &call, int want
     j->h = h;
     j->in = *in;
     j->call = call;
+    j->read_ptrs = read_ptrs;
+    j->read_rows = read_rows;
     j->want = want;
     j->path_bytes = in->T <= 65535 ? 2 : 4;
     const int64_t B = in->n_reads;
@@ -371,8 +401,9 @@ void host_job_release_lanes(fcd_handle *h, bool destroy) {
         (void)hipStreamSynchronize(L->copy_stream);
         if (L->pack_dev) (void)hipFree(L->pack_dev);
         if (L->pack_pin) (void)hipHostFree(L->pack_pin);
-        L->pack_dev = L->pack_pin = nullptr;
-        L->pack_dev_bytes = L->pack_pin_bytes = 0;
+        if (L->in_pin) (void)hipHostFree(L->in_pin);
+        L->pack_dev = L->pack_pin = L->in_pin = nullptr;
+        L->pack_dev_bytes = L->pack_pin_bytes = L->in_pin_bytes = 0;
         if (destroy) {
             (void)hipStreamDestroy(L->copy_stream);
             (void)hipEventDestroy(L->ev_header);
@@ -403,6 +434,64 @@ int fcd_beam_search_host_begin(fcd_handle *h, const fcd_batch *in, int64_t beam_
     c.thr = beam_cut_threshold;
     c.kernel = kernel;
     return job_begin(h, in, c, want, job);
+}
+
+namespace {
+// a batch whose reads are separate contiguous (rows[r], N) host matrices: described as the dense batch they are
+// gathered into (T = the longest read)
+int ptrs_batch(fcd_handle *h, const void *const *reads, const int64_t *rows, int64_t n_reads, int64_t N, int dtype,
+               fcd_batch *b) {
+    if (!h) return FCD_E_INVALID;
+    if (n_reads < 0 || N < 1 || (n_reads > 0 && (!reads || !rows))) {
+        h->err = "reads / rows missing";
+        return FCD_E_INVALID;
+    }
+    int64_t T = 0;
+    for (int64_t r = 0; r < n_reads; ++r) {
+        if (rows[r] < 0 || (rows[r] > 0 && !reads[r])) {
+            h->err = "a read is missing (null pointer or negative row count)";
+            return FCD_E_INVALID;
+        }
+        T = std::max(T, rows[r]);
+    }
+    memset(b, 0, sizeof *b);
+    static const float dummy = 0.0f;
+    b->post = &dummy;  // (never read: every chunk is gathered from `reads`)
+    b->n_reads = n_reads;
+    b->T = T;
+    b->S = 1;
+    b->N = N;
+    b->stride_read = T * N;
+    b->stride_t = N;
+    b->stride_n = 1;
+    b->lengths = rows;
+    b->dtype = dtype;
+    return FCD_OK;
+}
+}  // namespace
+
+int fcd_viterbi_search_host_ptrs_begin(fcd_handle *h, const void *const *reads, const int64_t *rows, int64_t n_reads,
+                                       int64_t N, int dtype, int collapse_repeats, int want, fcd_job **job) {
+    fcd_batch b;
+    const int rc = ptrs_batch(h, reads, rows, n_reads, N, dtype, &b);
+    if (rc) return rc;
+    HostCall c{HostOp::Viterbi};
+    c.collapse = collapse_repeats;
+    return job_begin(h, &b, c, want, job, reads, rows);
+}
+
+int fcd_beam_search_host_ptrs_begin(fcd_handle *h, const void *const *reads, const int64_t *rows, int64_t n_reads,
+                                    int64_t N, int dtype, int64_t beam_size, float beam_cut_threshold,
+                                    int collapse_repeats, int kernel, int want, fcd_job **job) {
+    fcd_batch b;
+    const int rc = ptrs_batch(h, reads, rows, n_reads, N, dtype, &b);
+    if (rc) return rc;
+    HostCall c{HostOp::Beam};
+    c.collapse = collapse_repeats;
+    c.beam_size = beam_size;
+    c.thr = beam_cut_threshold;
+    c.kernel = kernel;
+    return job_begin(h, &b, c, want, job, reads, rows);
 }
 
 int fcd_crf_beam_search_host_begin(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,

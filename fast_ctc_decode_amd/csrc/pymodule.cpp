@@ -494,12 +494,17 @@ struct BatchInput {
     std::unique_ptr<float[]> padded;  // or a padded copy of a sequence of per-read arrays
     std::vector<int64_t> lengths;
     py::ssize_t inner = 0;
+    // ... or (the 1D searches' host jobs) the per-read arrays as they are: fcd_*_host_ptrs_begin gathers them chunk by
+    // chunk on its lanes, no padded copy here
+    std::vector<py::array> reads;
+    std::vector<const void *> ptrs;
+    bool use_ptrs = false;
 };
 
 // network_outputs: ONE float32 array of rank `ndim` ((B,T,N) or (B,T,S,N), any non-negative strides: not copied),
 // or a sequence of per-read float32 arrays of rank ndim-1 with equal inner shapes (copied into a padded batch;
 // their row counts become the lengths).
-void make_batch(BatchInput &in, const py::object &x, int ndim, const py::object &lengths_o) {
+void make_batch(BatchInput &in, const py::object &x, int ndim, const py::object &lengths_o, bool allow_ptrs = false) {
     if (py::isinstance<py::array>(x)) {
         int dtype = FCD_DTYPE_F32;
         py::ssize_t esz = 4;
@@ -547,6 +552,23 @@ void make_batch(BatchInput &in, const py::object &x, int ndim, const py::object 
             reads.push_back(a);
         }
         if (!lengths_o.is_none()) throw py::value_error("lengths cannot be given with a sequence of per-read arrays");
+        if (allow_ptrs && ndim == 3 && B > 0) {
+            in.lengths.resize((size_t)B);
+            in.ptrs.resize((size_t)B);
+            for (py::ssize_t i = 0; i < B; ++i) {
+                in.reads.push_back(py::array::ensure(reads[(size_t)i], py::array::c_style));  // a no-op for contiguous reads
+                in.lengths[(size_t)i] = in.reads.back().shape(0);
+                in.ptrs[(size_t)i] = in.reads.back().data();
+            }
+            in.use_ptrs = true;
+            in.b.n_reads = B;
+            in.b.T = Tmax;
+            in.b.S = 1;
+            in.b.N = N;
+            in.b.dtype = FCD_DTYPE_F32;
+            in.inner = N;
+            return;
+        }
         const size_t row = (size_t)S * (size_t)N;
         in.padded.reset(new float[std::max<size_t>((size_t)B * (size_t)Tmax * row, 1)]);
         in.lengths.resize((size_t)B);
@@ -860,7 +882,7 @@ py::list beam_search_batch(const py::object &network_outputs, const py::object &
                            const py::object &beam_size_o, float beam_cut_threshold, bool collapse_repeats,
                            const py::object &lengths, const py::object &paths_o, int kernel, bool raise_on_error) {
     BatchInput in;
-    make_batch(in, network_outputs, 3, lengths);
+    make_batch(in, network_outputs, 3, lengths, true);
     auto alpha = seq_to_vec(alphabet);
     const size_t beam_size = to_usize(beam_size_o, "beam_size");
     check_beam_args(alpha.size(), in.inner, (py::ssize_t)beam_size, beam_cut_threshold);
@@ -870,8 +892,13 @@ py::list beam_search_batch(const py::object &network_outputs, const py::object &
     int rc;
     {
         py::gil_scoped_release nogil;
-        rc = fcd_beam_search_host_begin(h, &in.b, (int64_t)beam_size, beam_cut_threshold, collapse_repeats ? 1 : 0,
-                                        kernel, want_flags(paths, false), &jg.job);
+        if (in.use_ptrs)
+            rc = fcd_beam_search_host_ptrs_begin(h, in.ptrs.data(), in.lengths.data(), in.b.n_reads, in.b.N, in.b.dtype,
+                                                 (int64_t)beam_size, beam_cut_threshold, collapse_repeats ? 1 : 0, kernel,
+                                                 want_flags(paths, false), &jg.job);
+        else
+            rc = fcd_beam_search_host_begin(h, &in.b, (int64_t)beam_size, beam_cut_threshold, collapse_repeats ? 1 : 0,
+                                            kernel, want_flags(paths, false), &jg.job);
     }
     check_rc(h, rc);
     BatchCall call{BatchCall::Beam};
@@ -883,7 +910,7 @@ py::list viterbi_search_batch(const py::object &network_outputs, const py::objec
                               float qbias, bool collapse_repeats, const py::object &lengths, const py::object &paths_o,
                               bool raise_on_error) {
     BatchInput in;
-    make_batch(in, network_outputs, 3, lengths);
+    make_batch(in, network_outputs, 3, lengths, true);
     auto alpha = seq_to_vec(alphabet);
     check_greedy_alphabet(alpha.size(), in.inner);
     if (in.b.T == 0 && in.b.n_reads > 0)
@@ -894,7 +921,11 @@ py::list viterbi_search_batch(const py::object &network_outputs, const py::objec
     int rc;
     {
         py::gil_scoped_release nogil;
-        rc = fcd_viterbi_search_host_begin(h, &in.b, collapse_repeats ? 1 : 0, want_flags(paths, qstring), &jg.job);
+        if (in.use_ptrs)
+            rc = fcd_viterbi_search_host_ptrs_begin(h, in.ptrs.data(), in.lengths.data(), in.b.n_reads, in.b.N, in.b.dtype,
+                                                    collapse_repeats ? 1 : 0, want_flags(paths, qstring), &jg.job);
+        else
+            rc = fcd_viterbi_search_host_begin(h, &in.b, collapse_repeats ? 1 : 0, want_flags(paths, qstring), &jg.job);
     }
     check_rc(h, rc);
     BatchCall call{BatchCall::Viterbi};

@@ -463,6 +463,16 @@ int fcd_crf_beam_search_host_begin(fcd_handle *h, const fcd_batch *in, const flo
                                    int want, fcd_job **job);
 int fcd_crf_greedy_search_host_begin(fcd_handle *h, const fcd_batch *in, const float *init, int64_t n_init,
                                      int64_t init_stride, int want, fcd_job **job);
+/* The same jobs for a batch whose reads are SEPARATE host arrays -- a Python list of ragged matrices, which is how the
+ * reference's callers hold them (src/lib.rs:325,352 take one read per call): reads[r] points at read r's contiguous
+ * (rows[r], N) matrix of element type `dtype`.  Every chunk is gathered into page-locked memory by its lane (the lanes
+ * gather side by side) and leaves as one DMA: no padded copy of the batch on the caller's side.  reads / rows must stay
+ * valid until fcd_job_end.  Chunk views are the same (out_stride = the longest read). */
+int fcd_viterbi_search_host_ptrs_begin(fcd_handle *h, const void *const *reads, const int64_t *rows, int64_t n_reads,
+                                       int64_t N, int dtype, int collapse_repeats, int want, fcd_job **job);
+int fcd_beam_search_host_ptrs_begin(fcd_handle *h, const void *const *reads, const int64_t *rows, int64_t n_reads,
+                                    int64_t N, int dtype, int64_t beam_size, float beam_cut_threshold,
+                                    int collapse_repeats, int kernel, int want, fcd_job **job);
 /* Tuning / tests: lanes (0 = default 3 or FCD_HOST_LANES; 1 = never pipeline), reads per chunk (0 = automatic),
  * and the input size from which fcd_*_host takes the pipeline (-1 = default: >= 128 reads and >= 16 MB). */
 int fcd_set_host_pipeline(fcd_handle *h, int lanes, int64_t chunk_reads, int64_t min_bytes);

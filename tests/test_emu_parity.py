@@ -143,6 +143,7 @@ def test_chunked_host_path(fcd):
     H.test_compiled_duplex_batch_functions_equal_per_read_calls(fcd)
     H.test_list_paths_reference_counts(fcd)
     H.test_time_major_host_views_through_the_batch_functions(fcd)
+    H.test_list_of_ragged_reads_without_a_padded_copy(fcd, 3, 3)
 
 
 def test_half_precision_inputs(fcd):

@@ -352,3 +352,39 @@ def test_time_major_host_views_through_the_batch_functions(fcd):
         assert cm.beam_search_batch(view, "NACGT", 5, 0.1) == want
         assert fcd.beam_search_batch(view, "NACGT", 5, 0.1) == want
         assert cm.viterbi_search_batch(view, "NACGT") == cm.viterbi_search_batch(np.ascontiguousarray(view), "NACGT")
+
+
+@pytest.mark.parametrize("lanes,chunk", [(3, 3), (1, 0)])
+def test_list_of_ragged_reads_without_a_padded_copy(fcd, lanes, chunk):
+    """A Python list of per-read (T_r, N) arrays -- how the reference's callers hold their reads (src/lib.rs:325,352) --
+    goes through fcd_*_host_ptrs_begin: each chunk is gathered from the reads' own memory by its lane, nothing is
+    padded on the Python side.  Element i == the per-read call on read i: ragged lengths incl. an empty read, a
+    non-contiguous read (copied once, by numpy), several chunks per lane, list / array / no paths, viterbi qualities."""
+    cm = _compiled_layer()
+    cm._set_host_pipeline(lanes, chunk, 0)
+    try:
+        x = gen_batch(21, 17, 150, 5)
+        rows = [150, 1, 77, 0, 149, 64, 65, 3, 150, 10, 99, 128, 127, 150, 2, 31, 150]
+        reads = [np.ascontiguousarray(x[i, :rows[i]]) for i in range(17)]
+        reads[4] = x[4, :rows[4] * 1][::1]                       # a view
+        reads[6] = np.asfortranarray(x[6, :rows[6]])              # not C-contiguous
+        for paths in ("list", "array", None):
+            res = cm.beam_search_batch(reads, "NACGT", 5, 0.1, paths=paths)
+            assert len(res) == 17
+            for i, r in enumerate(reads):
+                want = fcd.beam_search(np.ascontiguousarray(r), "NACGT", 5, 0.1) if rows[i] > 0 else ("", [])
+                s, p = res[i]
+                assert s == want[0], i
+                if paths == "list":
+                    assert p == want[1]
+                elif paths == "array":
+                    assert p.tolist() == want[1]
+        nonempty = [r for r in reads if r.shape[0] > 0]
+        assert cm.viterbi_search_batch(nonempty, "NACGT", qstring=True) == \
+            [fcd.viterbi_search(np.ascontiguousarray(r), "NACGT", qstring=True) for r in nonempty]
+        with pytest.raises(TypeError):
+            cm.beam_search_batch([reads[0], x[1, :, :4]], "NACGT", 5, 0.1)   # inner shapes differ
+        with pytest.raises(ValueError, match="alphabet size 4 does not match"):
+            cm.beam_search_batch(reads, "NACG", 5, 0.1)
+    finally:
+        cm._set_host_pipeline(0, 0, -1)
