@@ -76,6 +76,22 @@ def main():
         report(tag)
     h.set_host_pipeline(0, 0, -1)
     cm._set_host_pipeline(0, 0, -1)
+    # a ragged batch as a Python LIST of per-read arrays (rows uniform in 2000..4000): the list goes through
+    # fcd_beam_search_host_ptrs_begin -- chunks gathered by the lanes, no padded copy -- against padding it by hand
+    rows = rng.integers(2000, 4001, B)
+    reads = [np.ascontiguousarray(x[i, :rows[i]]) for i in range(B)]
+    ms_rag, res_r = best(lambda: cm.beam_search_batch(reads, "NACGT", 5, 0.1, paths="array"), 3)
+
+    def padded_by_hand():
+        pad = np.zeros((B, 4000, 5), np.float32)
+        for i, r in enumerate(reads):
+            pad[i, :r.shape[0]] = r
+        return cm.beam_search_batch(pad, "NACGT", 5, 0.1, lengths=rows, paths="array")
+    ms_pad, res_p = best(padded_by_hand, 2)
+    same = all(a[0] == b[0] and np.array_equal(a[1], b[1]) for a, b in zip(res_r, res_p))
+    print("ragged list of %d reads (rows 2000..4000, %.0f MB): beam_search_batch(list, array paths) %.2f ms = %.0fk reads/s | "
+          "padded by hand + lengths %.2f ms = %.0fk reads/s | identical %s"
+          % (B, sum(r.nbytes for r in reads) / 1e6, ms_rag, B / ms_rag, ms_pad, B / ms_pad, same), flush=True)
     # the per-read surface for scale: one call per read, one thread
     t0 = time.perf_counter()
     for i in range(64):
