@@ -123,9 +123,22 @@ int issue_chunk(fcd_job *j, int c) {
             L->in_pin_bytes = need;
         }
         char *dst = reinterpret_cast<char *>(L->in_pin);
-        for (int64_t i = 0; i < n; ++i) {
-            const int64_t rows = std::min<int64_t>(std::max<int64_t>(j->read_rows[b0 + i], 0), j->in.T);
-            if (rows > 0) memcpy(dst + (size_t)i * slot, j->read_ptrs[b0 + i], (size_t)rows * row_bytes);
+        auto gather = [&](int64_t i0, int64_t i1) {
+            for (int64_t i = i0; i < i1; ++i) {
+                const int64_t rows = std::min<int64_t>(std::max<int64_t>(j->read_rows[b0 + i], 0), j->in.T);
+                if (rows > 0) memcpy(dst + (size_t)i * slot, j->read_ptrs[b0 + i], (size_t)rows * row_bytes);
+            }
+        };
+        // one core copies ~8 GB/s, PCIe takes 55: a large chunk is gathered by a few threads (FCD_HOST_GATHER_THREADS)
+        const int kmax = std::max(1, std::min(env_int("FCD_HOST_GATHER_THREADS", 4), 16));
+        const int k = (int)std::min<int64_t>(kmax, std::max<int64_t>(1, (int64_t)((size_t)n * slot >> 23)));  // >= 8 MB each
+        if (k <= 1) {
+            gather(0, n);
+        } else {
+            std::vector<std::thread> helpers;
+            for (int t = 1; t < k; ++t) helpers.emplace_back(gather, n * t / k, n * (t + 1) / k);
+            gather(0, n / k);
+            for (std::thread &t : helpers) t.join();
         }
         sub.post = L->in_pin;
         sub.lengths = j->read_rows + b0;
