@@ -145,7 +145,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     __shared__ uint64_t s_keys[kWavesPerBlock][64];
     __shared__ int s_heads[kWavesPerBlock][64];
     // survivor table, per half: entry r = (byte address of the lane whose candidate took rank r) | that candidate's depth << 8
-    __shared__ int s_srcs[kWavesPerBlock][RPW * 16 * (PDQ ? 2 : 1)];  // (PDQ: two words per entry, below)
+    // (PDQ: one entry per candidate rank, and as many tie words behind them -- per half)
+    __shared__ int s_srcs[kWavesPerBlock][PDQ ? 128 : RPW * 16];
+    constexpr int kTie = HALF;
     // PDQ: the node-ordered candidate list and the quicksort's tables of a tie-flagged step
     __shared__ uint64_t s_list[PDQ ? kWavesPerBlock : 1][64];
     __shared__ pdq178::CoopScratch<1> s_coop[PDQ ? kWavesPerBlock : 1];
@@ -185,15 +187,13 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     const bool collapse = !CRF && p.a.collapse != 0;
     const float thr = p.a.thr;
     uint64_t *keys = s_keys[wave];
-    int *srcs = s_srcs[wave] + (hbase ? 16 * (PDQ ? 2 : 1) : 0);
+    int *srcs = s_srcs[wave] + (hbase ? (PDQ ? 2 * HALF : 16) : 0);
     // smallest candidate count from which "rank i ties with rank i + 1" is the quicksort's business: more than 20
     // candidates, rank i kept, rank i + 1 present (never, for a lane outside the beam's groups)
     const int tie_lim = (!idle && i < p.a.beam_size) ? (i + 1 > 20 ? i + 1 : 20) : 0x7FFFFFFF;
-    if (PDQ) {  // second words: pairwise different, bit 31 clear -- no candidate's probability word looks like that
-        if (lane < RPW * 16) {
-            s_srcs[wave][2 * lane] = 0x7FFFFF00;
-            s_srcs[wave][2 * lane + 1] = lane;
-        }
+    if (PDQ) {  // tie words: pairwise different, bit 31 clear -- no candidate's probability word looks like that
+#pragma unroll
+        for (int w = lane; w < 128; w += 64) s_srcs[wave][w] = ((w / HALF) & 1) ? (w % HALF) : 0x7FFFFF00;
     } else if (lane < RPW * 16) {
         s_srcs[wave][lane] = 0x7FFFFF00;  // never the minimum depth; points at lane 0
     }
@@ -329,23 +329,9 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
         }
     };
     {
-        int t = 0;
-        while (t < Tmax) {
-            bool again = false;
-            for (; t < Tmax; ++t) {
-                advance_fifo();
-#define FCD_STEP_SLOW 0
+        for (int t = 0; t < Tmax; ++t) {
+            advance_fifo();
 #include "beam_wave_step.inc"
-#undef FCD_STEP_SLOW
-            }
-            if (PDQ && again) {
-                do {  // (a block the step can `break` out of, like the loop above)
-#define FCD_STEP_SLOW 1
-#include "beam_wave_step.inc"
-#undef FCD_STEP_SLOW
-                } while (false);
-                ++t;
-            }
         }
     }
     if (PROF && lane == 0 && p.a.prof) {
