@@ -312,7 +312,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             for (int j = 0; j + 1 < kFifo; ++j) win[j] = win[j + 1];
             __builtin_amdgcn_s_waitcnt(0x0F70);
             win[kFifo - 1] = incoming;
-            ++blk;
+            blk = (t + 1) / RPR;  // (from the step counter: no count carried through the loop)
             incoming = load_block(blk + kFifo);
         }
         const bool ent = act && q < B;
@@ -422,7 +422,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             }
             // maximum over the half: the DPP reduction of half_min_in_last_lane on the complement (keys are unsigned)
             mx = ~(uint32_t)bperm(hbase + HALF - 1, half_umin_in_last_lane<RPW>((int)~mx));
-            *reinterpret_cast<int4 *>(hist + 4 * lane) = make_int4(0, 0, 0, 0);
+            {   // (zeros made HERE: hoisted out of the time loop, the four registers of a zero vector are the first thing
+                // the PDQ instantiation spills at its 128-register budget -- and a scratch load per step is a memory wait)
+                int z0 = 0;
+                if (PDQ) FCD_OPAQUE_V(z0);
+                *reinterpret_cast<int4 *>(hist + 4 * lane) = make_int4(z0, z0, z0, z0);
+            }
             wave_sync();
 #pragma unroll
             for (int k = 0; k < N; ++k)
@@ -465,11 +470,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 cnt += in[k] ? 1 : 0;
             }
             int pos = half_prefix_add<RPW>(cnt) - cnt;
+            int src0 = lane * 8;
+            if (PDQ) FCD_OPAQUE_V(src0);  // (made here, not kept in five registers across the loop: see the zeros above)
 #pragma unroll
             for (int k = 0; k < N; ++k) {
                 if (in[k]) {
                     l_key[pos] = key[k];
-                    l_src[pos] = lane * 8 + k;
+                    l_src[pos] = src0 + k;
                 }
                 pos += in[k] ? 1 : 0;
             }
@@ -478,7 +485,11 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             if (RPW == 2) lmax = max(lmax, __shfl_xor(lmax, 32));
             lmax = (__builtin_amdgcn_readfirstlane(lmax) + 7) & ~7;
             for (int z = Lc + q; z < lmax; z += HALF) l_key[z] = 0ull;
-            *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
+            {
+                uint32_t m1 = ~0u;  // (same remark)
+                if (PDQ) FCD_OPAQUE_V(m1);
+                *reinterpret_cast<uint2 *>(s_rank + 8 * lane) = make_uint2(m1, m1);
+            }
             wave_sync();
             for (int e0 = 0; e0 < lmax; e0 += HALF) {
                 if (!AMB && e0 > 0 && lmax - e0 <= HALF / 4) {
@@ -593,6 +604,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 // step's new nodes are numbered in candidate order and follow every older node, so only the candidates
                 // on OLDER nodes need ranking -- against each other, four to a 16-byte LDS read.
                 pdq178::CoopScratch<N> *cs = reinterpret_cast<pdq178::CoopScratch<N> *>(&s_coop);
+                // (the keys, made again from what the step still holds: kept alive from the ranking to this rare block
+                // they would cost the step's hot path ten registers -- and at the 128-register budget, spills)
+                uint64_t key[N];
+                key[0] = (svalid && go) ? make_key(slp + sgp, node) : 0ull;
+#pragma unroll
+                for (int l = 0; l < NL; ++l) key[l + 1] = (cand_valid[l + 1] && go) ? make_key(contrib[l], ccand[l]) : 0ull;
                 // (both position tables, 64 * N words, and the first bytes of the table behind them: each half's ids
                 // are followed by four words of padding OF ITS OWN -- the lanes run in lockstep, a padding store that
                 // reached into the other half's region would land after that half's ids)
