@@ -190,7 +190,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     int *srcs = s_srcs[wave] + (hbase ? (PDQ ? 2 * HALF : 16) : 0);
     // smallest candidate count from which "rank i ties with rank i + 1" is the quicksort's business: more than 20
     // candidates, rank i kept, rank i + 1 present (never, for a lane outside the beam's groups)
-    const int tie_lim = (!idle && i < p.a.beam_size) ? (i + 1 > 20 ? i + 1 : 20) : 0x7FFFFFFF;
+    int tie_lim = (!idle && i < p.a.beam_size) ? (i + 1 > 20 ? i + 1 : 20) : 0x7FFFFFFF;
+    if (PDQ) FCD_OPAQUE_V(tie_lim);  // (ONE compare per step: the optimiser would take the folded limit apart again)
+    // where a lane looks its group's source up: groups past the beam read an entry nobody ever writes (lane 0, kind 0)
+    // -- the entries behind the kept ranks belong to dropped candidates, and a dropped candidate is often a node that
+    // has been in the beam before: read as a source it would vote "re-entering" in every step
+    const int i_src = (!idle && i < p.a.beam_size) ? i : HALF - 2;
     if (PDQ) {  // tie words: pairwise different, bit 31 clear -- no candidate's probability word looks like that
 #pragma unroll
         for (int w = lane; w < 128; w += 64) s_srcs[wave][w] = ((w / HALF) & 1) ? (w % HALF) : 0x7FFFFF00;

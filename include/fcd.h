@@ -102,8 +102,8 @@ enum {
  *                  of an unstable sort, but not the one Rust 1.78 gives on about 0.05 % of BASELINE config-2 reads.
  * A handle follows the process default until fcd_set_tie_order names an order for it (FCD_TIE_DEFAULT: follow
  * again); the process default is FCD_TIE_PDQ178, or what the environment variable FCD_TIE_ORDER (pdq178 | stable)
- * says at load time, or what fcd_set_default_tie_order set last.  Coalescer and host-pipeline handles follow
- * their creator. */
+ * says at load time, or what fcd_set_default_tie_order set last.  The lanes of a host job follow the handle the job
+ * was begun on; a coalescer's own handles follow the process default. */
 enum { FCD_TIE_DEFAULT = -1, FCD_TIE_PDQ178 = 0, FCD_TIE_STABLE = 1 };
 
 typedef struct fcd_handle fcd_handle;

@@ -38,3 +38,13 @@ def test_bench_refuses_more_gpus_than_the_node_has():
     """(this container has none: the real path must say so and fail, not run something smaller)"""
     r = run("--gpus", "2", "--steps", "2", "--warmup", "1")
     assert r.returncode == 2 and "GPU(s)" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
+def test_viterbi_clock_note_reads_the_committed_summary():
+    """bench.py quotes both clocks of the viterbi kernel from profiles/*_viterbi_clock_summary.json (a helper that runs
+    inside the timed script on the GPU box: it must not be able to take the bench line down)"""
+    import bench
+    note = bench.viterbi_clock_note()
+    assert note is not None and "error" not in note, note
+    assert 0.9 < note["events_over_rocprofv3"] < 1.1
+    assert os.path.exists(os.path.join(bench.ROOT, note["source"]))

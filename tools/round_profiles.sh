@@ -24,4 +24,12 @@ python tools/duplex_account.py > $O/${TAG}_duplex_account.jsonl 2> $O/${TAG}_dup
 python tools/cycle_account.py > $O/${TAG}_cycle_account.jsonl 2> $O/${TAG}_cycle_account.err
 python tools/bench_configs.py 1 3 4 5 64 1024 --check > $O/${TAG}_configs.jsonl 2> $O/${TAG}_configs.err
 python tools/probe_latency.py > $O/${TAG}_latency.txt 2>&1
+# what the tie order changes and costs, the viterbi kernel by both clocks, the bench variants
+python tools/tie_order_delta.py 2 3 4 5 --oracle 8 > $O/${TAG}_tie_order_delta.jsonl 2> $O/${TAG}_tie_order_delta.err
+bash tools/viterbi_clock.sh $TAG > $O/${TAG}_viterbi_clock.log 2>&1
+cp $O/viterbi_clock_$TAG/summary.json $O/${TAG}_viterbi_clock_summary.json
+cp $(find $O/viterbi_clock_$TAG -name '*kernel_stats.csv' | head -n 1) $O/${TAG}_viterbi_clock_kernel_stats.csv
+FCD_TIE_ORDER=stable python bench.py --no-viterbi --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_line_stable_order.json 2> $O/${TAG}_bench_stable.err
+FCD_TIE_ORDER=stable python bench.py --config 3 --no-viterbi --steps 5 --cpu-seconds 1 > $O/${TAG}_bench_config3_stable_order.json 2>> $O/${TAG}_bench_stable.err
+( python bench.py --streams 2 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --batch 16384 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --data peaky --no-viterbi --no-e2e --cpu-seconds 1 ) > $O/${TAG}_bench_variants.txt 2> $O/${TAG}_bench_variants.err
 for f in $O/${TAG}_bench_line.json $O/${TAG}_bench_config3.json $O/${TAG}_duplex_account.jsonl $O/${TAG}_e2e_probe.txt $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt; do tail -n 2 $f | cut -c1-300; done
