@@ -178,7 +178,8 @@ _coalescer = None
 
 
 def set_coalescing(max_batch=256, max_wait_us=0, device=0):
-    """Route the per-read `viterbi_search` / `beam_search` calls of ALL threads through one coalescer
+    """Route the per-read `viterbi_search` / `beam_search` / `crf_beam_search` / `crf_greedy_search` calls of ALL threads
+    through one coalescer
     (include/fcd.h, csrc/coalesce.hip): calls that are in flight at the same time are decoded by one batched
     launch instead of one single-wavefront launch each.  Results do not change.  `max_batch=0` switches it
     off again.  Not in the reference (which has no batch notion); meant for callers that keep its per-read,
@@ -264,12 +265,18 @@ def crf_beam_search(network_output, init_state, alphabet, beam_size=5, beam_cut_
         raise RuntimeError(nat.status_string(nat.ST_RAN_OUT_OF_BEAM))  # truncate(0) -> empty beam
     x = _dense(x)
     init = np.ascontiguousarray(init)
-    h = nat.default_handle()
     out = _HostOut(1, x.shape[0])
     b = _host_batch(x[None], True)
-    h.check(h.lib.fcd_crf_beam_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[0],
-                                           init.shape[0], int(beam_size), float(beam_cut_threshold),
-                                           C.byref(out.res)))
+    co = _coalescer
+    if co is not None:
+        with co:
+            co.check(co.lib.fcd_coalescer_crf_beam_search(co.ptr, C.byref(b), init.ctypes.data, init.shape[0],
+                                                          int(beam_size), float(beam_cut_threshold), C.byref(out.res)))
+    else:
+        h = nat.default_handle()
+        h.check(h.lib.fcd_crf_beam_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[0],
+                                               init.shape[0], int(beam_size), float(beam_cut_threshold),
+                                               C.byref(out.res)))
     _raise_status(int(out.status[0]))
     n = int(out.out_len[0])
     labels = out.labels[0, :n]
@@ -288,11 +295,17 @@ def crf_greedy_search(network_output, init_state, alphabet, qstring=False, qscal
         raise RuntimeError("network_output/init_state is empty (the reference asserts and aborts here)")
     x = _dense(x)
     init = np.ascontiguousarray(init)
-    h = nat.default_handle()
     out = _HostOut(1, x.shape[0], want_qual=bool(qstring))
     b = _host_batch(x[None], True)
-    h.check(h.lib.fcd_crf_greedy_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[0],
-                                             init.shape[0], C.byref(out.res)))
+    co = _coalescer
+    if co is not None:
+        with co:
+            co.check(co.lib.fcd_coalescer_crf_greedy_search(co.ptr, C.byref(b), init.ctypes.data, init.shape[0],
+                                                            C.byref(out.res)))
+    else:
+        h = nat.default_handle()
+        h.check(h.lib.fcd_crf_greedy_search_host(h.ptr, C.byref(b), init.ctypes.data, init.shape[0],
+                                                 init.shape[0], C.byref(out.res)))
     _raise_status(int(out.status[0]))
     n = int(out.out_len[0])
     seq = "".join(alpha[l] for l in out.labels[0, :n])

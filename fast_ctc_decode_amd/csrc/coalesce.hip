@@ -35,7 +35,7 @@
 
 namespace {
 
-enum Kind { kBeam = 0, kViterbi = 1 };
+enum Kind { kBeam = 0, kViterbi = 1, kCrfBeam = 2, kCrfGreedy = 3 };
 
 struct Req {
     int kind;
@@ -44,6 +44,8 @@ struct Req {
     float thr;
     int collapse;
     const fcd_result *out;
+    const float *init = nullptr;  // CRF searches: the read's init_state (n_init entries, contiguous)
+    int64_t n_init = 0;
     int rc = FCD_OK;
     bool done = false;
     std::string err;
@@ -51,8 +53,8 @@ struct Req {
 };
 
 bool compatible(const Req &a, const Req &b) {
-    return a.kind == b.kind && a.in->N == b.in->N && a.beam == b.beam && a.collapse == b.collapse &&
-           std::memcmp(&a.thr, &b.thr, sizeof(float)) == 0;
+    return a.kind == b.kind && a.in->N == b.in->N && a.in->S == b.in->S && a.n_init == b.n_init && a.beam == b.beam &&
+           a.collapse == b.collapse && std::memcmp(&a.thr, &b.thr, sizeof(float)) == 0;
 }
 
 thread_local std::string t_error;
@@ -86,7 +88,7 @@ struct Pinned {
 struct Lane {
     fcd_handle *h = nullptr;
     bool busy = false;
-    Pinned x, qual, labels, path, out_len, status, lengths;
+    Pinned x, qual, labels, path, out_len, status, lengths, init;
 };
 
 }  // namespace
@@ -126,6 +128,8 @@ void run_batch_once(Lane &L, std::vector<Req *> &batch) {
     const int64_t n = (int64_t)batch.size();
     const Req &first = *batch[0];
     const int64_t N = first.in->N;
+    const bool crf = first.kind == kCrfBeam || first.kind == kCrfGreedy;
+    const int64_t S = crf ? first.in->S : 1, row = S * N, n_init = first.n_init;
     int64_t Tmax = 1;
     bool want_path = false, want_qual = false;
     for (Req *r : batch) {
@@ -133,40 +137,46 @@ void run_batch_once(Lane &L, std::vector<Req *> &batch) {
         want_path = want_path || r->out->path;
         want_qual = want_qual || r->out->qual;
     }
-    float *x = static_cast<float *>(L.x.need((size_t)(n * Tmax * N) * sizeof(float)));
+    float *x = static_cast<float *>(L.x.need((size_t)(n * Tmax * row) * sizeof(float)));
     uint8_t *labels = static_cast<uint8_t *>(L.labels.need((size_t)(n * Tmax)));
     uint32_t *out_len = static_cast<uint32_t *>(L.out_len.need((size_t)n * sizeof(uint32_t)));
     int32_t *status = static_cast<int32_t *>(L.status.need((size_t)n * sizeof(int32_t)));
     int64_t *lengths = static_cast<int64_t *>(L.lengths.need((size_t)n * sizeof(int64_t)));
     uint32_t *path = want_path ? static_cast<uint32_t *>(L.path.need((size_t)(n * Tmax) * sizeof(uint32_t))) : nullptr;
     float *qual = want_qual ? static_cast<float *>(L.qual.need((size_t)(n * Tmax) * sizeof(float))) : nullptr;
+    float *init = crf ? static_cast<float *>(L.init.need((size_t)(n * n_init) * sizeof(float))) : nullptr;
     int rc = FCD_OK;
     std::string err;
-    if (!x || !labels || !out_len || !status || !lengths || (want_path && !path) || (want_qual && !qual)) {
+    if (!x || !labels || !out_len || !status || !lengths || (want_path && !path) || (want_qual && !qual) || (crf && !init)) {
         rc = FCD_E_NOMEM;
         err = "coalescer: cannot allocate pinned staging memory";
     }
     if (rc == FCD_OK) {
         for (int64_t i = 0; i < n; ++i) {
             const fcd_batch *b = batch[i]->in;
-            float *dst = x + i * Tmax * N;
+            float *dst = x + i * Tmax * row;
             const float *src = static_cast<const float *>(b->post);  // (the coalescer takes float32 reads only)
             lengths[i] = b->T;
-            if (b->stride_n == 1 && b->stride_t == N) {
-                std::memcpy(dst, src, (size_t)(b->T * N) * sizeof(float));
+            const bool dense = b->stride_n == 1 && (crf ? (b->stride_s == N && b->stride_t == row) : b->stride_t == N);
+            if (dense) {
+                std::memcpy(dst, src, (size_t)(b->T * row) * sizeof(float));
             } else {
                 for (int64_t t = 0; t < b->T; ++t)
-                    for (int64_t j = 0; j < N; ++j) dst[t * N + j] = src[t * b->stride_t + j * b->stride_n];
+                    for (int64_t sidx = 0; sidx < S; ++sidx)
+                        for (int64_t j = 0; j < N; ++j)
+                            dst[(t * S + sidx) * N + j] = src[t * b->stride_t + (crf ? sidx * b->stride_s : 0) + j * b->stride_n];
             }
+            if (crf) std::memcpy(init + i * n_init, batch[i]->init, (size_t)n_init * sizeof(float));
         }
         fcd_batch in{};
         in.post = x;
         in.n_reads = n;
         in.T = Tmax;
-        in.S = 1;
+        in.S = S;
         in.N = N;
-        in.stride_read = Tmax * N;
-        in.stride_t = N;
+        in.stride_read = Tmax * row;
+        in.stride_t = row;
+        in.stride_s = crf ? N : 0;
         in.stride_n = 1;
         in.lengths = lengths;
         fcd_result out{};
@@ -178,8 +188,12 @@ void run_batch_once(Lane &L, std::vector<Req *> &batch) {
         out.out_stride = Tmax;
         if (first.kind == kBeam)
             rc = fcd_beam_search_host(L.h, &in, first.beam, first.thr, first.collapse, FCD_KERNEL_AUTO, &out);
-        else
+        else if (first.kind == kViterbi)
             rc = fcd_viterbi_search_host(L.h, &in, first.collapse, &out);
+        else if (first.kind == kCrfBeam)
+            rc = fcd_crf_beam_search_host(L.h, &in, init, n_init, n_init, first.beam, first.thr, &out);
+        else
+            rc = fcd_crf_greedy_search_host(L.h, &in, init, n_init, n_init, &out);
         if (rc != FCD_OK) err = fcd_last_error(L.h);
     }
     for (int64_t i = 0; i < n; ++i) {
@@ -202,17 +216,20 @@ int submit(fcd_coalescer *c, Req &req) {
         t_error = "coalescer: null argument";
         return FCD_E_INVALID;
     }
-    if (req.kind == kBeam && !req.out->status) {  // a per-read FCD_ST_* outcome must have somewhere to go
-        t_error = "coalescer: beam_search needs out->status";
+    const bool crf = req.kind == kCrfBeam || req.kind == kCrfGreedy;
+    if (req.kind != kViterbi && !req.out->status) {  // a per-read FCD_ST_* outcome must have somewhere to go
+        t_error = "coalescer: the beam and CRF searches need out->status";
         return FCD_E_INVALID;
     }
     if (req.in->dtype != FCD_DTYPE_F32) {
         t_error = "coalescer: float32 reads only (the per-read surface is the reference's, which takes float32)";
         return FCD_E_UNSUPPORTED;
     }
-    if (req.in->n_reads != 1 || req.in->S > 1 || req.in->T < 0 || req.in->N < 1 || req.in->stride_t < 0 ||
-        req.in->stride_n < 0 || req.out->out_stride < req.in->T || req.in->lengths) {
-        t_error = "coalescer: expects exactly one (T, N) read with non-negative strides and out_stride >= T";
+    if (req.in->n_reads != 1 || req.in->T < 0 || req.in->N < 1 || req.in->stride_t < 0 || req.in->stride_n < 0 ||
+        req.out->out_stride < req.in->T || req.in->lengths ||
+        (crf ? (req.in->S < 1 || req.in->stride_s < 0 || !req.init || req.n_init < 1) : req.in->S > 1)) {
+        t_error = crf ? "coalescer: expects exactly one (T, S, N) read with non-negative strides, an init_state and out_stride >= T"
+                      : "coalescer: expects exactly one (T, N) read with non-negative strides and out_stride >= T";
         return FCD_E_INVALID;
     }
     req.arrived = std::chrono::steady_clock::now();
@@ -329,6 +346,22 @@ int fcd_coalescer_beam_search(fcd_coalescer *c, const fcd_batch *read, int64_t b
 
 int fcd_coalescer_viterbi_search(fcd_coalescer *c, const fcd_batch *read, int collapse_repeats, const fcd_result *out) {
     Req r{kViterbi, read, 0, 0.0f, collapse_repeats ? 1 : 0, out};
+    return submit(c, r);
+}
+
+int fcd_coalescer_crf_beam_search(fcd_coalescer *c, const fcd_batch *read, const float *init, int64_t n_init,
+                                  int64_t beam_size, float beam_cut_threshold, const fcd_result *out) {
+    Req r{kCrfBeam, read, beam_size, beam_cut_threshold, 0, out};
+    r.init = init;
+    r.n_init = n_init;
+    return submit(c, r);
+}
+
+int fcd_coalescer_crf_greedy_search(fcd_coalescer *c, const fcd_batch *read, const float *init, int64_t n_init,
+                                    const fcd_result *out) {
+    Req r{kCrfGreedy, read, 0, 0.0f, 0, out};
+    r.init = init;
+    r.n_init = n_init;
     return submit(c, r);
 }
 

@@ -129,8 +129,10 @@ int issue_chunk(fcd_job *j, int c) {
                 if (rows > 0) memcpy(dst + (size_t)i * slot, j->read_ptrs[b0 + i], (size_t)rows * row_bytes);
             }
         };
-        // one core copies ~8 GB/s, PCIe takes 55: a large chunk is gathered by a few threads (FCD_HOST_GATHER_THREADS)
-        const int kmax = std::max(1, std::min(env_int("FCD_HOST_GATHER_THREADS", 4), 16));
+        // one core copies ~8 GB/s, PCIe takes 55: a large chunk is gathered by a few threads (FCD_HOST_GATHER_THREADS;
+        // measured on 4096 ragged reads, three lanes: 2 -> 14.6 ms, 4 -> 15.2, 6..12 -> 17-18: the lanes gather at the
+        // same time, and the boxes this runs on sustain about a dozen busy cores)
+        const int kmax = std::max(1, std::min(env_int("FCD_HOST_GATHER_THREADS", 2), 16));
         const int k = (int)std::min<int64_t>(kmax, std::max<int64_t>(1, (int64_t)((size_t)n * slot >> 23)));  // >= 8 MB each
         if (k <= 1) {
             gather(0, n);

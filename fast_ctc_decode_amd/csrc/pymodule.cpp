@@ -49,7 +49,8 @@ fcd_handle *thread_handle() {
     return th.h;
 }
 
-// set_coalescing(): when set, per-read viterbi_search / beam_search calls of every thread go through it
+// set_coalescing(): when set, per-read viterbi_search / beam_search / crf_beam_search / crf_greedy_search calls of
+// every thread go through it
 // (include/fcd.h: concurrent calls share batched launches).  Every call holds a reference to the coalescer that
 // was current when it started; a replaced coalescer is destroyed when its LAST call returns -- nobody waits for
 // a global count to reach zero, so set_coalescing() cannot starve under a steady stream of calls.
@@ -308,13 +309,23 @@ py::tuple crf_beam_search(const py::object &network_output, const py::object &in
     Out o(x.shape(0), true, false);
     fcd_batch b = batch3(x);
     int rc;
-    fcd_handle *h = thread_handle();
-    {
-        py::gil_scoped_release nogil;
-        rc = fcd_crf_beam_search_host(h, &b, static_cast<const float *>(init.data()), init.shape(0),
-                                      init.shape(0), (int64_t)beam_size, beam_cut_threshold, &o.res);
+    CoalescerUse use;
+    if (fcd_coalescer *co = use.co) {
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_coalescer_crf_beam_search(co, &b, static_cast<const float *>(init.data()), init.shape(0),
+                                               (int64_t)beam_size, beam_cut_threshold, &o.res);
+        }
+        check_rc_coalescer(rc);
+    } else {
+        fcd_handle *h = thread_handle();
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_crf_beam_search_host(h, &b, static_cast<const float *>(init.data()), init.shape(0),
+                                          init.shape(0), (int64_t)beam_size, beam_cut_threshold, &o.res);
+        }
+        check_rc(h, rc);
     }
-    check_rc(h, rc);
     raise_status(o.status);
     // search.rs:146-156: labels appended leaf -> root, then the CHARACTERS are reversed
     std::string rev;
@@ -334,13 +345,22 @@ py::tuple crf_greedy_search(const py::object &network_output, const py::object &
     Out o(x.shape(0), true, true);
     fcd_batch b = batch3(x);
     int rc;
-    fcd_handle *h = thread_handle();
-    {
-        py::gil_scoped_release nogil;
-        rc = fcd_crf_greedy_search_host(h, &b, static_cast<const float *>(init.data()), init.shape(0),
-                                        init.shape(0), &o.res);
+    CoalescerUse use;
+    if (fcd_coalescer *co = use.co) {
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_coalescer_crf_greedy_search(co, &b, static_cast<const float *>(init.data()), init.shape(0), &o.res);
+        }
+        check_rc_coalescer(rc);
+    } else {
+        fcd_handle *h = thread_handle();
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_crf_greedy_search_host(h, &b, static_cast<const float *>(init.data()), init.shape(0),
+                                            init.shape(0), &o.res);
+        }
+        check_rc(h, rc);
     }
-    check_rc(h, rc);
     raise_status(o.status);
     std::string seq;
     for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];

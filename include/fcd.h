@@ -421,6 +421,12 @@ int fcd_coalescer_beam_search(fcd_coalescer *c, const fcd_batch *read, int64_t b
                               float beam_cut_threshold, int collapse_repeats, const fcd_result *out);
 int fcd_coalescer_viterbi_search(fcd_coalescer *c, const fcd_batch *read, int collapse_repeats,
                                  const fcd_result *out);
+/* r04: the CRF searches (src/search.rs:38-157, :385-423) through the same door: one (T, S, N) read and its init_state
+ * (n_init contiguous floats) per call; calls with the same S, N, n_init, beam and threshold share a launch. */
+int fcd_coalescer_crf_beam_search(fcd_coalescer *c, const fcd_batch *read, const float *init, int64_t n_init,
+                                  int64_t beam_size, float beam_cut_threshold, const fcd_result *out);
+int fcd_coalescer_crf_greedy_search(fcd_coalescer *c, const fcd_batch *read, const float *init, int64_t n_init,
+                                    const fcd_result *out);
 int fcd_coalescer_stats(fcd_coalescer *c, int64_t *n_calls, int64_t *n_launches, int64_t *largest_batch);
 const char *fcd_coalescer_last_error(void);
 

@@ -86,13 +86,67 @@ def _check(mod, reads, n_threads, max_wait_us):
     return stats
 
 
+def _crf_reads(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        T = int(rng.integers(1, 120))
+        S = 4 if i % 3 else 16
+        x = rng.random((T, S, 5), dtype=np.float32)
+        if i % 4 == 1:
+            x = np.ascontiguousarray(x.transpose(1, 0, 2)).transpose(1, 0, 2)  # strided (T, S, N) view
+        init = rng.random(S, dtype=np.float32)
+        out.append((x, init))
+    return out
+
+
+def _check_crf(mod, reads, n_threads, max_wait_us):
+    """crf_beam_search / crf_greedy_search through the coalescer == the same calls without it"""
+    def call(i):
+        x, init = reads[i]
+        beam, thr = [(5, 0.0), (3, 0.01), (32, 0.0)][i % 3]
+        try:
+            a = tuple(mod.crf_beam_search(x, init, ALPHA, beam, thr))
+        except RuntimeError as e:
+            a = ("error", str(e))
+        return a, tuple(mod.crf_greedy_search(x, init, ALPHA, qstring=(i % 2 == 0)))
+
+    want = [call(i) for i in range(len(reads))]
+    got, errors = {}, []
+
+    def work(tid):
+        try:
+            for i in range(tid, len(reads), n_threads):
+                got[i] = call(i)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    mod.set_coalescing(16, max_wait_us)
+    try:
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        stats = mod.coalescing_stats()
+    finally:
+        mod.set_coalescing(0)
+    assert not errors, errors
+    for i in range(len(reads)):
+        assert got[i] == want[i], i
+    assert stats["calls"] == 2 * len(reads)
+    return stats
+
+
 def test_coalescer_emulated():
     import fast_ctc_decode_amd as fcd
     from emu_util import emulated_kernels
     with emulated_kernels():
         stats = _check(fcd, _reads(24, 5), 6, 20000)
+        crf_stats = _check_crf(fcd, _crf_reads(12, 7), 4, 20000)
     # six threads start together and the leader waits 20 ms for company: launches are shared
     assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
+    assert crf_stats["launches"] < crf_stats["calls"], crf_stats
 
 
 @pytest.mark.gpu
@@ -106,6 +160,8 @@ def test_coalescer_gpu(layer):
     stats = _check(mod, reads, 16, 0)         # no timer: batches form from whatever arrives during a launch
     assert stats["launches"] <= stats["calls"], stats
     stats = _check(mod, reads, 16, 2000)
+    assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
+    stats = _check_crf(mod, _crf_reads(60, 8), 12, 2000)
     assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
 
 
