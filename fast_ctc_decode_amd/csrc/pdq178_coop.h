@@ -331,45 +331,28 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             }
             return c;  // (x = 0: no plane qualifies, 0)
         };
-        // (segment by segment on the SCALAR unit: the masks and running counts are wave-uniform, a round has two or
-        // three segments, and 64-bit shifts, population counts and bit scans are single scalar instructions -- as
-        // vector code for all leaders at once this block was a quarter of a round)
-        for (int sg = 0; sg < nseg; ++sg) {
-            const int s_act = __builtin_amdgcn_readlane(act, sg);
-            if (s_act == kActDone) continue;
-            const int s_base = __builtin_amdgcn_readlane(base, sg), s_len = __builtin_amdgcn_readlane(len, sg);
-            const int wb = s_base + 1, we = s_base + s_len;
-            int r_a0, r_a1, r_a2, r_p0, r_p2, r_count, r_cL = 0, r_cR = 0;
-            if (s_act == kActNormal) {
-                r_a0 = mk.first_zero(wb, we);                      // while l < r && is_less(v[l], pivot)
-                const int last1 = mk.last_one(r_a0, we);
-                r_a2 = last1 + 1 > r_a0 ? last1 + 1 : r_a0;        // while l < r && !is_less(v[r - 1], pivot)
-                const int rem = r_a2 - r_a0;                       // <= 2 * BLOCK: one round, is_done at once
-                r_a1 = r_a0 + rem / 2;                             // block_l = rem / 2, block_r = rem - block_l
-                r_p0 = ones_below(r_a0);
-                const int p1 = ones_below(r_a1);
-                r_p2 = ones_below(r_a2);
-                r_cL = (r_a1 - r_a0) - (p1 - r_p0);                // left block: elements that are NOT less than the pivot
-                r_cR = r_p2 - p1;                                  // right block: elements that are
-                r_count = r_cL < r_cR ? r_cL : r_cR;
+        if (lane < nseg && act != kActDone) {
+            const int wb = base + 1, we = base + len;
+            if (act == kActNormal) {
+                a0 = mk.first_zero(wb, we);                        // while l < r && is_less(v[l], pivot)
+                const int last1 = mk.last_one(a0, we);
+                a2 = last1 + 1 > a0 ? last1 + 1 : a0;              // while l < r && !is_less(v[r - 1], pivot)
+                const int rem = a2 - a0;                           // <= 2 * BLOCK: one round, is_done at once
+                a1 = a0 + rem / 2;                                 // block_l = rem / 2, block_r = rem - block_l
+                p0 = ones_below(a0);
+                const int p1 = ones_below(a1);
+                p2 = ones_below(a2);
+                cL = (a1 - a0) - (p1 - p0);                        // left block: elements that are NOT less than the pivot
+                cR = p2 - p1;                                      // right block: elements that are
+                count = cL < cR ? cL : cR;
             } else {
-                r_p0 = ones_below(wb);
-                r_p2 = ones_below(we);
-                const int nE = (we - wb) - (r_p2 - r_p0);          // elements equal to the pivot: they end up on the left
-                r_a0 = wb;
-                r_a1 = wb + nE;
-                r_a2 = we;
-                r_count = ones_below(r_a1) - r_p0;                 // greater ones inside the left zone == equal ones outside it
-            }
-            if (lane == sg) {
-                a0 = r_a0;
-                a1 = r_a1;
-                a2 = r_a2;
-                p0 = r_p0;
-                p2 = r_p2;
-                count = r_count;
-                cL = r_cL;
-                cR = r_cR;
+                p0 = ones_below(wb);
+                p2 = ones_below(we);
+                const int nE = (we - wb) - (p2 - p0);              // elements equal to the pivot: they end up on the left
+                a0 = wb;
+                a1 = wb + nE;
+                a2 = we;
+                count = ones_below(a1) - p0;                       // greater ones inside the left zone == equal ones outside it
             }
         }
         // what an element needs to know about its segment, two 16-bit fields to a word, fetched from the leader's lane
@@ -446,22 +429,17 @@ __device__ __forceinline__ void coop_sort_inline(elem_t *v_generic, int start0, 
             const int wb = base + 1;
             if (act == kActNormal) {
                 int bound = a1;
-                // (the next swap's position is fetched with this swap's elements: one LDS round trip per swap, not two)
                 if (cL > cR) {          // while start_l < end_l { end_l -= 1; swap(l + *end_l, r - 1); r -= 1 }
-                    int next = s->pos_a[wb + cL - 1];
                     for (int j = cL - 1; j >= count; --j) {
                         --bound;
-                        const int hole = next;
-                        if (j > count) next = s->pos_a[wb + j - 1];
+                        const int hole = s->pos_a[wb + j];
                         const elem_t t = v[hole], u = v[bound];
                         v[hole] = u;
                         v[bound] = t;
                     }
                 } else if (cR > cL) {   // while start_r < end_r { end_r -= 1; swap(l, r - *end_r - 1); l += 1 }
-                    int next = s->pos_b[wb + cR - 1];
                     for (int j = cR - 1; j >= count; --j) {
-                        const int hole = next;
-                        if (j > count) next = s->pos_b[wb + j - 1];
+                        const int hole = s->pos_b[wb + j];
                         const elem_t t = v[hole], u = v[bound];
                         v[hole] = u;
                         v[bound] = t;
