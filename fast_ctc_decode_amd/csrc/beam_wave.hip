@@ -152,6 +152,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     __shared__ uint64_t s_list[PDQ ? kWavesPerBlock : 1][64];
     __shared__ pdq178::CoopScratch<1> s_coop[PDQ ? kWavesPerBlock : 1];
     static_assert(!PDQ || BCAP * N > 20, "the tie order only matters above 20 candidates");
+    static_assert(!PDQ || BCAP * N <= HALF - 2, "the last two entries of a half's table are never written (i_src below)");
     int n_amb = 0, n_crit = 0;
     uint32_t cyc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint32_t cyc_last = 0;

@@ -16,6 +16,21 @@ import fast_ctc_decode_amd as fcd
 import test_gpu_parity as P
 
 
+
+def budgeted(first, n):
+    """seeds first .. first + n - 1, or as many as FCD_SOAK_SECONDS of wall clock allow (the summary line names the last one)"""
+    import time
+    budget = float(os.environ.get("FCD_SOAK_SECONDS", "0"))
+    t0 = time.time()
+    for seed in range(first, first + n):
+        if budget and time.time() - t0 > budget:
+            break
+        budgeted.last = seed
+        yield seed
+
+
+budgeted.last = -1
+
 def inject(rng, x):
     n = int(rng.integers(0, 5))
     for _ in range(n):
@@ -29,7 +44,7 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     cases = bad = 0
-    for seed in range(first, first + n):
+    for seed in budgeted(first, n):
         x, beam, thr, collapse, lengths = P._fuzz_case(seed)
         rng = np.random.default_rng(seed + 7)
         x = inject(rng, x)
@@ -176,7 +191,7 @@ def main():
             except AssertionError as e:
                 bad += 1
                 print("MISMATCH crf_greedy", name, seed, Bg, Tg, Sg, Ng, str(e)[:160], flush=True)
-    print("beam soak: seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
+    print("beam soak: seeds %d..%d, %d cases, %d mismatches" % (first, budgeted.last, cases, bad))
     return 1 if bad else 0
 
 

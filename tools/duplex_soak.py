@@ -16,6 +16,21 @@ import fast_ctc_decode_amd as fcd
 import test_gpu_duplex as D
 
 
+
+def budgeted(first, n):
+    """seeds first .. first + n - 1, or as many as FCD_SOAK_SECONDS of wall clock allow (the summary line names the last one)"""
+    import time
+    budget = float(os.environ.get("FCD_SOAK_SECONDS", "0"))
+    t0 = time.time()
+    for seed in range(first, first + n):
+        if budget and time.time() - t0 > budget:
+            break
+        budgeted.last = seed
+        yield seed
+
+
+budgeted.last = -1
+
 def long_case(seed, mode):
     """Long reads inside a band (stale windows re-entering the beam, catch-up of several rows, discards, wobble)."""
     rng = np.random.default_rng(seed)
@@ -49,18 +64,18 @@ def main():
         first = int(sys.argv[1]) if len(sys.argv) > 1 else 900000
         n = int(sys.argv[2]) if len(sys.argv) > 2 else 100
         cases = bad = 0
-        for seed in range(first, first + n):
+        for seed in budgeted(first, n):
             for mode in (D.LSE, D.MAX):
                 cases += 1
                 if not long_case(seed, mode):
                     bad += 1
                     print("MISMATCH long", seed, mode, flush=True)
-        print("duplex soak (long reads): seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
+        print("duplex soak (long reads): seeds %d..%d, %d cases, %d mismatches" % (first, budgeted.last, cases, bad))
         return 1 if bad else 0
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 100000
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     cases = bad = 0
-    for seed in range(first, first + n):
+    for seed in budgeted(first, n):
         for mode in (D.LSE, D.MAX):
             for name, fn in (("fuzz", lambda: D.duplex_fuzz_seed(fcd, seed, mode)),
                              ("crf", lambda: D.crf_duplex_fuzz_seed(fcd, seed, mode))):
@@ -74,7 +89,7 @@ def main():
             if not D.special_values_case(fcd, seed, mode):
                 bad += 1
                 print("MISMATCH special", seed, mode, flush=True)
-    print("duplex soak: seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
+    print("duplex soak: seeds %d..%d, %d cases, %d mismatches" % (first, budgeted.last, cases, bad))
     return 1 if bad else 0
 
 

@@ -13,11 +13,26 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
 
+
+def budgeted(first, n):
+    """seeds first .. first + n - 1, or as many as FCD_SOAK_SECONDS of wall clock allow (the summary line names the last one)"""
+    import time
+    budget = float(os.environ.get("FCD_SOAK_SECONDS", "0"))
+    t0 = time.time()
+    for seed in range(first, first + n):
+        if budget and time.time() - t0 > budget:
+            break
+        budgeted.last = seed
+        yield seed
+
+
+budgeted.last = -1
+
 def run(fcd, first, n):
     from fast_ctc_decode_amd import api
     cm = api._compiled()
     cases = bad = 0
-    for seed in range(first, first + n):
+    for seed in budgeted(first, n):
         rng = np.random.default_rng(seed)
         B, T, N = int(rng.integers(1, 40)), int(rng.integers(1, 120)), int(rng.integers(2, 7))
         lanes, chunk = int(rng.integers(1, 5)), int(rng.integers(1, 9))
@@ -61,7 +76,7 @@ def run(fcd, first, n):
             bad += 1
             print("MISMATCH", seed, B, T, N, lanes, chunk, paths, str(e)[:160], flush=True)
     cm._set_host_pipeline(0, 0, -1)
-    print("host batch soak: seeds %d..%d, %d cases, %d mismatches" % (first, first + n - 1, cases, bad))
+    print("host batch soak: seeds %d..%d, %d cases, %d mismatches" % (first, budgeted.last, cases, bad))
     return 1 if bad else 0
 
 
