@@ -616,6 +616,29 @@ def main():
                 "note": "a read with either counter at 0 decodes the same under any order of equal probabilities; on "
                         "the others the kernels follow the restated order of Rust 1.78's sort_unstable_by "
                         "(FCD_TIE_PDQ178, csrc/pdq178.h; tests/test_gpu_fullsize.py::test_config2_tie_instrument)"}
+        # outside the timed region (N = 1): the same launches under the OTHER selectable order of equal probabilities,
+        # so that one line from one box shows what the default order (Rust 1.78's) costs against the stable one
+        other_order = None
+        if world == 1:
+            mine_order = fcd.tie_order()
+            try:
+                alt = "stable" if mine_order == "pdq178" else "pdq178"
+                fcd.set_tie_order(alt)
+                for _ in range(2):
+                    search(0)
+                torch.cuda.synchronize()
+                handles[0].timing_reset()
+                for _ in range(args.steps):
+                    search(0)
+                torch.cuda.synchronize()
+                alt_ms, alt_calls = handles[0].timing_mean_ms()
+                other_order = {"tie_order": alt, "kernel_ms": alt_ms, "launches_timed": alt_calls,
+                               "reads_per_s_by_kernel_time": B / (alt_ms * 1e-3),
+                               "this_order_reads_per_s_by_kernel_time": B / (k_ms * 1e-3)}
+            except Exception as e:  # never at the price of the bench line
+                other_order = {"error": str(e)}
+            finally:
+                fcd.set_tie_order(mine_order)
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
         vit16 = viterbi_roofline(fcd, torch, dev, half=True) if not args.no_viterbi else None
         valu = valu_issue_roofline(prefix, k_ms, simds) if default_shape else None
@@ -660,6 +683,7 @@ def main():
                 "reads_ok": ok, "mean_labels_per_read": mean_L, "streams": n_streams,
                 "tie_instrument": ties,
                 "tie_order": fcd.tie_order(),  # include/fcd.h FCD_TIE_*: pdq178 = Rust 1.78's sort_unstable_by (default)
+                "other_tie_order": other_order,
             },
             "roofline": {
                 "bound": "hbm",
