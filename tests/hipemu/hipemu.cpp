@@ -2,6 +2,8 @@
 // runtime calls csrc/capi.hip makes.  See hip/hip_runtime.h in this directory.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
 #include <time.h>
 
 #include <mutex>
@@ -130,6 +132,8 @@ void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *),
     }
     g_tramp = tramp;
     g_closure = closure;
+    int lane_order = 0;
+    if (const char *e = getenv("FCD_EMU_LANE_ORDER")) lane_order = !strcmp(e, "reverse") ? 1 : (!strcmp(e, "swap-halves") ? 2 : 0);
     g_lds.assign(lds_bytes + 64, 0);
     while ((int)g_stacks.size() < nthreads) {
         void *p = nullptr;
@@ -161,7 +165,14 @@ void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *),
         int n_done = 0;
         while (n_done < nthreads) {
             bool progressed = false;
-            for (int t = 0; t < nthreads; ++t) {
+            for (int t0 = 0; t0 < nthreads; ++t0) {
+                // A fibre runs until its next cross-lane operation, so between two such operations the lanes' plain
+                // stores land in SCHEDULING order, not in the per-instruction order of true lockstep: a store of lane 3
+                // that the GPU performs after an earlier store of lane 40 lands before it here.  Code that is correct in
+                // lockstep but sensitive to that (r04: half 0's padding stores over half 1's ids) shows up as a result
+                // that depends on the order the fibres are taken in: FCD_EMU_LANE_ORDER=reverse takes them from the
+                // last lane down, =swap-halves exchanges the two halves of every wavefront.
+                const int t = lane_order == 1 ? nthreads - 1 - t0 : (lane_order == 2 ? (t0 ^ 32) : t0);
                 Fiber &f = fibers[t];
                 if (f.state != READY) continue;
                 progressed = true;

@@ -153,6 +153,21 @@ def test_half_precision_inputs(fcd):
     HP.test_half_precision_crf_and_duplex(fcd)
 
 
+@pytest.mark.parametrize("order", ["reverse", "swap-halves"])
+def test_results_do_not_depend_on_the_order_the_fibres_run_in(fcd, order, monkeypatch):
+    """The emulator runs a lane until its next cross-lane operation, so plain stores between two such operations land
+    in scheduling order -- not in lockstep's per-instruction order.  Taking the fibres in another order (hipemu.cpp,
+    FCD_EMU_LANE_ORDER) makes code that leans on one order fail here instead of only on the GPU: round 4's lane kernel
+    wrote half 0's padding over half 1's ids, invisibly with ascending lanes."""
+    import test_gpu_tieorder as TO
+    monkeypatch.setenv("FCD_EMU_LANE_ORDER", order)
+    TO.test_both_tie_orders_every_kernel(fcd, 5, 5, (0, 1, 2, 3, 4))
+    TO.test_both_tie_orders_every_kernel(fcd, 5, 32, (1, 4))
+    TO.test_both_tie_orders_every_kernel(fcd, 7, 8, (0, 1, 3, 4))
+    P.test_beam_fuzz(fcd, 3)
+    P.test_crf_fuzz(fcd, 2)
+
+
 def test_tie_orders(fcd):
     """FCD_TIE_PDQ178 / FCD_TIE_STABLE (tests/test_gpu_tieorder.py) under the emulator: every kernel family under both
     orders on inputs built to tie, the CRF and duplex searches, and the BASELINE reads whose result depends on it."""
