@@ -6,6 +6,7 @@
 #include <string.h>
 #include <time.h>
 
+#include <algorithm>
 #include <mutex>
 #include <vector>
 
@@ -133,7 +134,15 @@ void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *),
     g_tramp = tramp;
     g_closure = closure;
     int lane_order = 0;
-    if (const char *e = getenv("FCD_EMU_LANE_ORDER")) lane_order = !strcmp(e, "reverse") ? 1 : (!strcmp(e, "swap-halves") ? 2 : 0);
+    uint64_t shuffle_state = 0;
+    if (const char *e = getenv("FCD_EMU_LANE_ORDER")) {
+        lane_order = !strcmp(e, "reverse") ? 1 : (!strcmp(e, "swap-halves") ? 2 : 0);
+        if (!strncmp(e, "random:", 7)) {  // a fresh pseudo-random order for every sweep over the fibres
+            lane_order = 3;
+            shuffle_state = strtoull(e + 7, nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+        }
+    }
+    std::vector<int> perm;
     g_lds.assign(lds_bytes + 64, 0);
     while ((int)g_stacks.size() < nthreads) {
         void *p = nullptr;
@@ -165,14 +174,24 @@ void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *),
         int n_done = 0;
         while (n_done < nthreads) {
             bool progressed = false;
+            if (lane_order == 3) {
+                perm.resize(nthreads);
+                for (int i = 0; i < nthreads; ++i) perm[i] = i;
+                for (int i = nthreads - 1; i > 0; --i) {  // Fisher-Yates on an xorshift stream
+                    shuffle_state ^= shuffle_state << 13;
+                    shuffle_state ^= shuffle_state >> 7;
+                    shuffle_state ^= shuffle_state << 17;
+                    std::swap(perm[i], perm[(int)(shuffle_state % (uint64_t)(i + 1))]);
+                }
+            }
             for (int t0 = 0; t0 < nthreads; ++t0) {
                 // A fibre runs until its next cross-lane operation, so between two such operations the lanes' plain
                 // stores land in SCHEDULING order, not in the per-instruction order of true lockstep: a store of lane 3
                 // that the GPU performs after an earlier store of lane 40 lands before it here.  Code that is correct in
                 // lockstep but sensitive to that (r04: half 0's padding stores over half 1's ids) shows up as a result
                 // that depends on the order the fibres are taken in: FCD_EMU_LANE_ORDER=reverse takes them from the
-                // last lane down, =swap-halves exchanges the two halves of every wavefront.
-                const int t = lane_order == 1 ? nthreads - 1 - t0 : (lane_order == 2 ? (t0 ^ 32) : t0);
+                // last lane down, =swap-halves exchanges the two halves of every wavefront, =random:SEED shuffles every sweep.
+                const int t = lane_order == 1 ? nthreads - 1 - t0 : (lane_order == 2 ? (t0 ^ 32) : (lane_order == 3 ? perm[t0] : t0));
                 Fiber &f = fibers[t];
                 if (f.state != READY) continue;
                 progressed = true;

@@ -153,7 +153,7 @@ def test_half_precision_inputs(fcd):
     HP.test_half_precision_crf_and_duplex(fcd)
 
 
-@pytest.mark.parametrize("order", ["reverse", "swap-halves"])
+@pytest.mark.parametrize("order", ["reverse", "swap-halves", "random:7"])
 def test_results_do_not_depend_on_the_order_the_fibres_run_in(fcd, order, monkeypatch):
     """The emulator runs a lane until its next cross-lane operation, so plain stores between two such operations land
     in scheduling order -- not in lockstep's per-instruction order.  Taking the fibres in another order (hipemu.cpp,
