@@ -142,8 +142,8 @@ def cpu_baseline(cfg, x_host, init_host, gpu_labels, gpu_path, gpu_len, budget_s
 
 
 KERNEL_SOURCES = {  # the files a kernel's instruction stream and memory traffic depend on
-    "beam_wave_kernel": ("beam_wave.hip", "beam_wave_step.inc", "pdq178.h", "pdq178_coop.h", "device_utils.h"),
-    "beam_lane_kernel": ("beam_lane.hip", "pdq178.h", "pdq178_coop.h", "device_utils.h"),
+    "beam_wave_kernel": ("beam_wave.hip", "beam_wave_step.inc", "pdq178.h", "pdq178_wave.h", "device_utils.h"),
+    "beam_lane_kernel": ("beam_lane.hip", "pdq178.h", "pdq178_wave.h", "device_utils.h"),
     "beam_generic_kernel": ("beam_generic.hip", "pdq178.h", "device_utils.h"),
     "viterbi": ("viterbi.hip", "device_utils.h"),
     "crf_greedy": ("viterbi.hip", "device_utils.h"),

@@ -31,7 +31,7 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
-#include "pdq178_coop.h"
+#include "pdq178_wave.h"
 
 namespace fcd {
 
@@ -132,8 +132,8 @@ __device__ __forceinline__ float rdlanef(float v, int l) {
 // moves to state (state * 4) & (S - 1) + label (:97), which cannot leave the table.
 // PDQ: FCD_TIE_PDQ178 (include/fcd.h; see beam_wave.hip) -- the candidates of rank <= beam_size leave their probability
 // in a table by rank; when a kept candidate ties with its successor among more than 20 candidates, the half builds
-// the node-ordered list of ALL its candidates in LDS, one lane replays Rust 1.78's quicksort on it (pdq178.h) and the
-// ranks it produces replace the exact ones.
+// the node-ordered list of ALL its candidates in LDS, the wavefront replays Rust 1.78's quicksort on it (pdq178_wave.h)
+// and the ranks it produces replace the exact ones.
 template <int N, int RPW, bool AMB, bool CRF, bool PDQ>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void beam_lane_kernel(LaneParams p) {
     constexpr int NL = N - 1;
@@ -152,9 +152,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     __shared__ __attribute__((aligned(16))) int s_child[64 * RW];   // child entries of old slot i
     __shared__ int s_heads[64];
     __shared__ uint32_t s_tie[PDQ ? 2 * 66 : 2];  // probability (orderable bits) of the candidate of rank r <= beam_size
-    // the wave-cooperative quicksort's tables (pdq178_coop.h); with them the N = 5 instantiation holds 10 KB of LDS:
-    // sixteen wavefronts per CU still fit
-    __shared__ pdq178::CoopScratch<PDQ ? N : 1> s_coop;
+    // the wave-cooperative quicksort's position tables (pdq178_wave.h: a list of HALF * N candidates spans PL planes of
+    // 64 positions), which first hold the ids of the candidates on older nodes while the list is put in node order
+    constexpr int PL = PDQ ? (HALF * N + 63) / 64 : 1;
+    union TieScratch {
+        pdq178::WaveScratch<PL> ws;
+        uint32_t eid[PDQ ? RPW * (HALF * N + 4) : 1];
+    };
+    __shared__ TieScratch s_tie_scr;
 
 #ifdef FCD_HIPEMU  // (lockstep emulation: LDS arrives zeroed there, as garbage on the GPU -- make it garbage here too)
     if (threadIdx.x == 0) {
@@ -165,7 +170,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         memset(s_fate, 0xA5, sizeof(s_fate));
         memset(s_child, 0xA5, sizeof(s_child));
         memset(s_tie, 0xA5, sizeof(s_tie));
-        memset(&s_coop, 0xA5, sizeof(s_coop));
+        memset(&s_tie_scr, 0xA5, sizeof(s_tie_scr));
     }
     __syncthreads();
 #endif
@@ -600,20 +605,34 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const uint64_t m_tied = ballot(tied);
             if (__builtin_expect(m_tied != 0ull, 0)) {
                 const bool mine_h = hmask(m_tied) != 0ull;
+                // Fourteen registers of loop-carried state sit the rare block out in LDS that is dead until the survivors
+                // publish their records (s_rec, s_child, s_inc): the quicksort is inlined, and at the 128-register budget it
+                // would otherwise push them to scratch memory.
+                int *const park = reinterpret_cast<int *>(s_rec) + lane;
+                int *const park2 = s_child + lane;
+#pragma unroll
+                for (int j = 0; j < kFifo; ++j) park[64 * j] = __float_as_int(win[j]);
+                park[64 * 4] = __float_as_int(incoming);
+                park[64 * 5] = jump;
+                park[64 * 6] = __float_as_int(lp);
+                park[64 * 7] = __float_as_int(gp);
+#pragma unroll
+                for (int l = 0; l < NL && l < RW; ++l) park2[64 * l] = child[l];
+                int *const park3 = reinterpret_cast<int *>(s_inc) + lane;  // (dead until the next step's pushes)
+                park3[0] = depth;
+                park3[64] = tip;
                 // The list sort_unstable_by is handed: the merged candidates in ascending node order (:245-260).  This
                 // step's new nodes are numbered in candidate order and follow every older node, so only the candidates
                 // on OLDER nodes need ranking -- against each other, four to a 16-byte LDS read.
-                pdq178::CoopScratch<N> *cs = reinterpret_cast<pdq178::CoopScratch<N> *>(&s_coop);
                 // (the keys, made again from what the step still holds: kept alive from the ranking to this rare block
                 // they would cost the step's hot path ten registers -- and at the 128-register budget, spills)
                 uint64_t key[N];
                 key[0] = (svalid && go) ? make_key(slp + sgp, node) : 0ull;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) key[l + 1] = (cand_valid[l + 1] && go) ? make_key(contrib[l], ccand[l]) : 0ull;
-                // (both position tables, 64 * N words, and the first bytes of the table behind them: each half's ids
-                // are followed by four words of padding OF ITS OWN -- the lanes run in lockstep, a padding store that
-                // reached into the other half's region would land after that half's ids)
-                uint32_t *eid = reinterpret_cast<uint32_t *>(cs->pos_a) + hh * (HALF * N + 4);
+                // (each half's ids are followed by four words of padding OF ITS OWN -- the lanes run in lockstep, a
+                // padding store that reached into the other half's region would land after that half's ids)
+                uint32_t *eid = s_tie_scr.eid + hh * (HALF * N + 4);
                 bool older[N];
                 int n_older = 0;
 #pragma unroll
@@ -655,16 +674,30 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 }
                 if (mine_h) *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
                 wave_sync();
-                // both reads of the wavefront at once, all 64 lanes (pdq178_coop.h)
-                const bool f0 = (m_tied & 0xFFFFFFFFull) != 0ull || (RPW == 1 && m_tied != 0ull), f1 = RPW == 2 && (m_tied >> 32) != 0ull;
-                const int len0 = f0 ? rdlane(n_valid, 0) : 0, len1 = f1 ? rdlane(n_valid, 32) : 0;
-                pdq178::coop_sort<N>(c_key, 0, len0, HALF * N, len1, beam_size, cs, lane);
+                // all 64 lanes replay the quicksort on a flagged read's list, one read after the other (pdq178_wave.h:
+                // at the tail of a launch a wavefront has ONE chronically tied read)
+#pragma unroll 1
+                for (int hs = 0; hs < RPW; ++hs) {
+                    const bool flagged = RPW == 1 || (hs ? (m_tied >> 32) != 0ull : (m_tied & 0xFFFFFFFFull) != 0ull);
+                    if (!flagged) continue;
+                    pdq178::wave_sort_inline<PL>(c_key + hs * HALF * N, rdlane(n_valid, hs * HALF), beam_size, &s_tie_scr.ws, lane);
+                }
                 for (int j = q; mine_h && j < Bn; j += HALF) s_rank[(int)(uint32_t)list[j]] = (int8_t)j;
                 wave_sync();
                 const uint64_t again = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
 #pragma unroll
                 for (int k = 0; k < N; ++k)
                     if (mine_h) rank[k] = (int)(int8_t)(uint8_t)(again >> (8 * k));
+#pragma unroll
+                for (int j = 0; j < kFifo; ++j) win[j] = __int_as_float(park[64 * j]);
+                incoming = __int_as_float(park[64 * 4]);
+                jump = park[64 * 5];
+                lp = __int_as_float(park[64 * 6]);
+                gp = __int_as_float(park[64 * 7]);
+#pragma unroll
+                for (int l = 0; l < NL && l < RW; ++l) child[l] = park2[64 * l];
+                depth = park3[0];
+                tip = park3[64];
                 wave_sync();
             }
         }

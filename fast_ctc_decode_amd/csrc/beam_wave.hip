@@ -53,7 +53,7 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
-#include "pdq178_coop.h"
+#include "pdq178_wave.h"
 
 namespace fcd {
 
@@ -121,10 +121,10 @@ constexpr int kSeg = 64;  // nodes per traceback segment (jump-pointer spacing)
 // desc, node asc); the candidates of rank <= beam_size also leave their probability in a small table by rank, so
 // one compare per slot says whether a KEPT candidate ties with its successor.  Only then (a few steps per thousand
 // reads on the BASELINE generator) the half builds the node-ordered candidate list in LDS, the wavefront replays the
-// quicksort on it (pdq178_coop.h) and the ranks it produces replace the exact ones.  Instantiated only for shapes
+// quicksort on it (pdq178_wave.h) and the ranks it produces replace the exact ones.  Instantiated only for shapes
 // that can hold more than 20 candidates.
 template <int N, int GW, int RPW, int S, bool AMB, bool PROF = false, bool UNI = false, bool H16 = false, bool PDQ = false>
-__global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WaveParams p) {
+__global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu((RPW == 2 && !AMB) ? 4 : 1))) void beam_wave_kernel(WaveParams p) {
     constexpr bool CRF = S != 0;
     constexpr bool GATHER = S == kCrfGather;
     constexpr int NL = N - 1;
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) void beam_wave_kernel(WavePara
     constexpr int kTie = HALF;
     // PDQ: the node-ordered candidate list and the quicksort's tables of a tie-flagged step
     __shared__ uint64_t s_list[PDQ ? kWavesPerBlock : 1][64];
-    __shared__ pdq178::CoopScratch<1> s_coop[PDQ ? kWavesPerBlock : 1];
+    __shared__ pdq178::WaveScratch<1> s_ws[PDQ ? kWavesPerBlock : 1];
     static_assert(!PDQ || BCAP * N > 20, "the tie order only matters above 20 candidates");
     static_assert(!PDQ || BCAP * N <= HALF - 2, "the last two entries of a half's table are never written (i_src below)");
     int n_amb = 0, n_crit = 0;

@@ -467,7 +467,7 @@ int fcd_debug_pdq178_coop_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lis
                                    int planes, int keep) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);
-    if (n_lists < 0 || stride < 0 || (n_lists > 0 && (!lists || !lens)) || (planes != 1 && planes != 5 && planes != 8) || keep < 1)
+    if (n_lists < 0 || stride < 0 || (n_lists > 0 && (!lists || !lens)) || (planes != 1 && planes != 3 && planes != 5 && planes != 8) || keep < 1)
         return fail(h, FCD_E_INVALID, "bad argument");
     FCD_DEVICE(h);
     FCD_HIP(h, launch_pdq178_coop_probe(lists, n_lists, stride, lens, planes, keep, h->stream));

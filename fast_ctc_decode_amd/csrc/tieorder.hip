@@ -4,8 +4,8 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
-#define FCD_COOP_PROF 1  // (this translation unit only: the probe kernels; the search kernels carry no stamps)
-#include "pdq178_coop.h"
+#define FCD_WAVE_PROF 1  // (this translation unit only: the probe kernels; the search kernels carry no stamps)
+#include "pdq178_wave.h"
 
 namespace fcd {
 
@@ -30,24 +30,22 @@ __global__ __launch_bounds__(64) void pdq178_probe_kernel(uint64_t *lists, int64
     }
 }
 
-// the wave-cooperative routine (pdq178_coop.h): block b sorts lists 2b and 2b + 1 TOGETHER, list 2b at positions
-// [0, len) and list 2b + 1 right-aligned at the end of the 64 * MAXP positions, like the two reads of a wavefront
-template <int MAXP>
-__global__ __launch_bounds__(64) void pdq178_coop_probe_kernel(uint64_t *lists, int64_t n_lists, int64_t stride,
+// the wave-cooperative routine (pdq178_wave.h): block b sorts list b, living in LDS at an offset that is not a
+// multiple of 64 (like the second read's list of a wavefront in the wide-beam kernel)
+template <int P>
+__global__ __launch_bounds__(64) void pdq178_wave_probe_kernel(uint64_t *lists, int64_t n_lists, int64_t stride,
                                                                const int32_t *lens, int keep) {
-    __shared__ uint64_t s_v[64 * MAXP];
-    __shared__ pdq178::CoopScratch<MAXP> s_scr;
+    __shared__ uint64_t s_v[64 * P + 40];
+    __shared__ pdq178::WaveScratch<P> s_scr;
     const int lane = threadIdx.x;
-    const int64_t i0 = 2 * (int64_t)blockIdx.x, i1 = i0 + 1;
-    const int len0 = lens[i0], len1 = i1 < n_lists ? lens[i1] : 0;
-    const int start1 = 64 * MAXP - len1;
-    for (int j = lane; j < len0; j += kWave) s_v[j] = lists[i0 * stride + j];
-    for (int j = lane; j < len1; j += kWave) s_v[start1 + j] = lists[i1 * stride + j];
+    const int64_t i0 = blockIdx.x;
+    const int len0 = lens[i0];
+    uint64_t *v = s_v + (blockIdx.x % 3) * 20;
+    for (int j = lane; j < len0; j += kWave) v[j] = lists[i0 * stride + j];
     __syncthreads();
-    pdq178::coop_sort<MAXP>(s_v, 0, len0, start1, len1, keep, &s_scr, lane);
+    pdq178::wave_sort<P>(v, len0, keep, &s_scr, lane);
     __syncthreads();
-    for (int j = lane; j < len0; j += kWave) lists[i0 * stride + j] = s_v[j];
-    for (int j = lane; j < len1; j += kWave) lists[i1 * stride + j] = s_v[start1 + j];
+    for (int j = lane; j < len0; j += kWave) lists[i0 * stride + j] = v[j];
 }
 
 }  // namespace
@@ -55,11 +53,12 @@ __global__ __launch_bounds__(64) void pdq178_coop_probe_kernel(uint64_t *lists, 
 hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, int planes,
                                     int keep, hipStream_t stream) {
     if (n_lists <= 0) return hipSuccess;
-    const dim3 grid((unsigned)((n_lists + 1) / 2)), block(64);
+    const dim3 grid((unsigned)n_lists), block(64);
     switch (planes) {
-        case 1: hipLaunchKernelGGL(pdq178_coop_probe_kernel<1>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
-        case 5: hipLaunchKernelGGL(pdq178_coop_probe_kernel<5>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
-        case 8: hipLaunchKernelGGL(pdq178_coop_probe_kernel<8>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
+        case 1: hipLaunchKernelGGL(pdq178_wave_probe_kernel<1>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
+        case 3: hipLaunchKernelGGL(pdq178_wave_probe_kernel<3>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
+        case 5: hipLaunchKernelGGL(pdq178_wave_probe_kernel<5>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
+        case 8: hipLaunchKernelGGL(pdq178_wave_probe_kernel<8>, grid, block, 0, stream, lists, n_lists, stride, lens, keep); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -67,11 +66,11 @@ hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t st
 
 hipError_t coop_prof_read(unsigned long long *out16, bool reset) {
 #ifndef FCD_HIPEMU
-    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(pdq178::g_coop_prof), 16 * sizeof(unsigned long long));
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(pdq178::g_wave_prof), 16 * sizeof(unsigned long long));
     if (e != hipSuccess) return e;
     if (reset) {
         unsigned long long zero[16] = {0};
-        return hipMemcpyToSymbol(HIP_SYMBOL(pdq178::g_coop_prof), zero, sizeof(zero));
+        return hipMemcpyToSymbol(HIP_SYMBOL(pdq178::g_wave_prof), zero, sizeof(zero));
     }
     return hipSuccess;
 #else

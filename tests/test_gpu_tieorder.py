@@ -47,9 +47,9 @@ def test_device_routine_equals_the_oracle_restatement(fcd):
     assert check_against_oracle(out, lens, lists) > 100
 
 
-@pytest.mark.parametrize("planes", [1, 5, 8])
+@pytest.mark.parametrize("planes", [1, 3, 5, 8])
 def test_cooperative_routine_equals_the_oracle_restatement(fcd, planes):
-    """csrc/pdq178_coop.h as compiled for gfx950: the whole wavefront on two lists at once"""
+    """csrc/pdq178_wave.h as compiled for gfx950: the whole wavefront replaying the quicksort on one list"""
     torch = pytest.importorskip("torch")
     from fast_ctc_decode_amd import _native as nat
 
@@ -67,6 +67,15 @@ def test_cooperative_routine_equals_the_oracle_restatement(fcd, planes):
     finally:
         h.reset_stream()
     assert check_against_oracle(out, lens, lists) > (10 if planes == 1 else 100)
+    if planes in (3, 5):  # the searches only need the kept prefix: segments behind it are dropped
+        h.set_stream(torch.cuda.current_stream().cuda_stream)
+        try:
+            for keep in (1, 5, 32):
+                out, lens = device_coop_sort(nat.load(), h, lists, planes, Dev,
+                                             lambda d, shape, dt: d.t.cpu().numpy().view(dt).reshape(shape), keep=keep)
+                check_against_oracle(out, lens, lists, keep=keep)
+        finally:
+            h.reset_stream()
 
 
 def results(fcd, x, beam, thr, collapse, kernel, lengths=None):

@@ -67,8 +67,8 @@ def check_against_oracle(out, lens, lists, keep=None):
 
 
 def coop_lists(planes, seed=1):
-    """lists for the wave-cooperative routine: consecutive pairs share a wavefront (their lengths add up to at most
-    64 * planes positions); every regime of the serial routine, plus pairs of beam-like lists with few distinct values"""
+    """lists for the wave-cooperative routine (at most 64 * planes positions each): every regime of the serial routine,
+    plus beam-like lists with few distinct values"""
     cap = 64 * planes
     rng = np.random.default_rng(seed)
     out = []
@@ -121,10 +121,10 @@ def test_device_routine_equals_the_oracle_restatement_emulated():
     assert check_against_oracle(out, lens, lists) > 100  # and it really is another order than the stable one
 
 
-@pytest.mark.parametrize("planes", [1, 5, 8])
+@pytest.mark.parametrize("planes", [1, 3, 5, 8])
 def test_cooperative_routine_equals_the_oracle_restatement_emulated(planes):
-    """csrc/pdq178_coop.h -- the whole wavefront replaying the quicksort on two lists at once (level by level, ballots
-    for partition_in_blocks' offsets, leaves ranked in parallel) -- must produce the serial routine's permutation"""
+    """csrc/pdq178_wave.h -- the whole wavefront replaying the quicksort on a list (one wave-uniform segment at a time,
+    ballots for partition_in_blocks' offsets, leaves ranked in parallel) -- must produce the serial routine's permutation"""
     from emu_util import emulated_kernels
     from fast_ctc_decode_amd import _native as nat
     lists = coop_lists(planes)
@@ -132,7 +132,7 @@ def test_cooperative_routine_equals_the_oracle_restatement_emulated(planes):
         h = nat.default_handle(0)
         out, lens = device_coop_sort(lib, h, lists, planes, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
     assert check_against_oracle(out, lens, lists) > (10 if planes == 1 else 100)
-    if planes == 5:  # the searches only need the kept prefix: segments behind it are dropped
+    if planes in (3, 5):  # the searches only need the kept prefix: segments behind it are dropped
         with emulated_kernels() as lib:
             h = nat.default_handle(0)
             for keep in (1, 5, 32):

@@ -1,4 +1,4 @@
-"""developer scratch: latency of one cooperative quicksort replay (pdq178_coop.h) -- one wavefront per SIMD"""
+"""developer scratch: latency of one cooperative quicksort replay (pdq178_wave.h) -- one wavefront per SIMD"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
@@ -39,20 +39,20 @@ def run(n, planes, keep, pairs=1024, serial=False):
         torch.cuda.synchronize()
         assert rc == 0
         best = min(best, e0.elapsed_time(e1))
-    print("n=%d planes=%d keep=%d %s: %.1f us per launch (%d wavefronts, one sort of two lists each)" %
+    print("n=%d planes=%d keep=%d %s: %.1f us per launch (%d lists, one wavefront each)" %
           (n, planes, keep, "serial" if serial else "coop", best * 1e3, pairs), flush=True)
     if not serial:
         import ctypes as C
         cyc = (C.c_uint64 * 16)()
         lib.fcd_debug_pdq178_coop_profile(h.ptr, cyc, 1)
-        calls = max(int(cyc[10]), 1)
-        names = ["setup", "A pivot", "B classify", "C scans", "D tables", "E moves", "F leftovers+queue", "loop", "leaves"]
+        calls = max(int(cyc[11]), 1)
+        names = ["setup", "pivot", "swap+mode", "classify", "scans+tables", "moves", "leftovers+children", "next", "exit", "leaves"]
         print("    cycles per call: " + ", ".join("%s %.0f" % (nm, cyc[i] / calls) for i, nm in enumerate(names)) +
-              "; rounds per call %.2f; total %.0f" % (cyc[9] / calls, sum(cyc[:9]) / calls), flush=True)
+              "; segments per call %.2f; total %.0f" % (cyc[10] / calls, sum(cyc[:10]) / calls), flush=True)
 
 
-for n, planes in ((25, 1), (128, 5), (64, 5), (160, 5)):
+for n, planes in ((25, 1), (128, 3), (64, 3), (160, 3), (130, 5)):
     for keep in (1 << 20, 32, 5):
         run(n, planes, keep)
-run(128, 5, 0, serial=True)
+run(128, 3, 0, serial=True)
 run(25, 1, 0, serial=True)
