@@ -31,6 +31,9 @@
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
+#ifdef FCD_LANE_TIE_PROF  // developer build (tools/dev/lane_tie_prof.sh): shader-clock stamps inside the tie-flagged step
+#define FCD_WAVE_PROF 1
+#endif
 #include "pdq178_wave.h"
 
 namespace fcd {
@@ -605,6 +608,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const uint64_t m_tied = ballot(tied);
             if (__builtin_expect(m_tied != 0ull, 0)) {
                 const bool mine_h = hmask(m_tied) != 0ull;
+#ifdef FCD_LANE_TIE_PROF
+                const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
+#endif
                 // Fourteen registers of loop-carried state sit the rare block out in LDS that is dead until the survivors
                 // publish their records (s_rec, s_child, s_inc): the quicksort is inlined, and at the 128-register budget it
                 // would otherwise push them to scratch memory.
@@ -674,6 +680,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 }
                 if (mine_h) *reinterpret_cast<uint64_t *>(s_rank + 8 * lane) = ~0ull;
                 wave_sync();
+#ifdef FCD_LANE_TIE_PROF
+                const unsigned long long tp1 = __builtin_amdgcn_s_memtime();
+#endif
                 // all 64 lanes replay the quicksort on a flagged read's list, one read after the other (pdq178_wave.h:
                 // at the tail of a launch a wavefront has ONE chronically tied read)
 #pragma unroll 1
@@ -682,6 +691,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                     if (!flagged) continue;
                     pdq178::wave_sort_inline<PL>(c_key + hs * HALF * N, rdlane(n_valid, hs * HALF), beam_size, &s_tie_scr.ws, lane);
                 }
+#ifdef FCD_LANE_TIE_PROF
+                const unsigned long long tp2 = __builtin_amdgcn_s_memtime();
+#endif
                 for (int j = q; mine_h && j < Bn; j += HALF) s_rank[(int)(uint32_t)list[j]] = (int8_t)j;
                 wave_sync();
                 const uint64_t again = *reinterpret_cast<const uint64_t *>(s_rank + 8 * lane);
@@ -699,6 +711,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 depth = park3[0];
                 tip = park3[64];
                 wave_sync();
+#ifdef FCD_LANE_TIE_PROF
+                if (lane == 0) {
+                    const unsigned long long tp3 = __builtin_amdgcn_s_memtime();
+                    atomicAdd(&pdq178::g_wave_prof[12], tp1 - tp0);  // the node-ordered list
+                    atomicAdd(&pdq178::g_wave_prof[13], tp2 - tp1);  // the replay
+                    atomicAdd(&pdq178::g_wave_prof[14], tp3 - tp2);  // ranks handed back
+                    atomicAdd(&pdq178::g_wave_prof[15], 1ull);       // tied steps
+                }
+#endif
             }
         }
 
@@ -970,6 +991,22 @@ hipError_t launch_n(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
 }
 
 }  // namespace
+
+// developer instrument: the cycle counters of a -DFCD_LANE_TIE_PROF build (zeros otherwise)
+hipError_t lane_tie_prof_read(unsigned long long *out16, bool reset) {
+#if defined(FCD_LANE_TIE_PROF) && !defined(FCD_HIPEMU)
+    hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(pdq178::g_wave_prof), 16 * sizeof(unsigned long long));
+    if (e != hipSuccess) return e;
+    if (reset) {
+        unsigned long long zero[16] = {0};
+        return hipMemcpyToSymbol(HIP_SYMBOL(pdq178::g_wave_prof), zero, sizeof(zero));
+    }
+    return hipSuccess;
+#else
+    for (int i = 0; i < 16; ++i) out16[i] = 0;
+    return hipSuccess;
+#endif
+}
 
 bool beam_lane_supported(int beam_size, int N, int crf, int S) {
     if (beam_size < 1 || beam_size > 64) return false;

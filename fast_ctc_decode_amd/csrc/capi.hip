@@ -1,5 +1,6 @@
 // capi.hip -- the C ABI of libfcd_hip.so (include/fcd.h): argument checking, workspace and
 // chunking, stream/event plumbing, host staging for the *_host entry points.
+#include <stdio.h>
 #include <math.h>
 #include <string.h>
 
@@ -20,10 +21,16 @@ namespace {
 // fcd_set_default_tie_order
 int tie_order_from_env() {
     const char *e = getenv("FCD_TIE_ORDER");
-    if (e && (!strcmp(e, "stable") || !strcmp(e, "STABLE") || !strcmp(e, "1"))) return FCD_TIE_STABLE;
+    if (!e || !*e) return FCD_TIE_PDQ178;
+    if (!strcmp(e, "stable") || !strcmp(e, "STABLE") || !strcmp(e, "1")) return FCD_TIE_STABLE;
+    if (!strcmp(e, "pdq178") || !strcmp(e, "PDQ178") || !strcmp(e, "2")) return FCD_TIE_PDQ178;
+    // a typo must not silently select the other order
+    fprintf(stderr, "fast_ctc_decode (fcd): FCD_TIE_ORDER=\"%s\" is neither \"pdq178\" nor \"stable\"; using pdq178\n", e);
     return FCD_TIE_PDQ178;
 }
 std::atomic<int> g_tie_order{tie_order_from_env()};
+
+constexpr int64_t kMaxRetryRounds = 4;  // lane kernel, two-pass sizing: retry rounds enqueued without asking (beam_dev)
 
 #define FCD_HIP(h, expr)                                                          \
     do {                                                                          \
@@ -219,10 +226,10 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     // would reserve 117 GB for BASELINE config 3's 8192 reads.  The lane kernel therefore runs in slabs of HALF
     // the worst case; a read that outgrows its slab is stopped (FCD_ST_INTERNAL) and decoded again by a retry
     // pass in worst-case slabs carved out of the SAME arena (stream order: the first pass has finished with it,
-    // results are already traced back).  The retry loop reads a 4-byte counter back -- the one place this entry
-    // point waits for the device -- so it is used only when the worst-case arena would exceed 8 GiB (or the
-    // workspace limit).  A job in which more than a quarter of the reads overflow (dense posteriors: nearly
-    // every extension passes the cut) makes this handle size later jobs for the worst case straight away.
+    // results are already traced back).  The retry rounds are enqueued unconditionally (see below): the entry point
+    // never waits for the device.  Used only when the worst-case arena would exceed 8 GiB (or the workspace limit).
+    // A job in which more than a quarter of the reads overflow (dense posteriors: nearly every extension passes
+    // the cut) makes this handle size later jobs for the worst case straight away -- one job late.
     // both register kernels keep 4-byte records (parent, label); the creation time is the upper part of the id
     // (wave kernel) or comes from the lane kernel's per-step table of first ids: T + 1 more words per slab
     const size_t rec_bytes = 4;
@@ -234,6 +241,13 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     const bool two_pass = use_lane && (worst_total > ((size_t)8 << 30) || (int64_t)worst_total > budget);
     const int64_t cap_worst = cap_nodes;
     const size_t worst_read = (size_t)cap_worst * node_bytes + first_bytes;
+    if (two_pass && h->retry_pending && hipEventQuery(h->retry_ev) == hipSuccess) {
+        // the overflow count of an earlier job has arrived: a job in which more than a quarter of the reads outgrew
+        // their first-pass slabs makes this handle size later jobs for the worst case straight away
+        const int64_t overflowed = *reinterpret_cast<volatile int32_t *>(h->retry_host);
+        if (!h->first_pass_div_pinned && overflowed * 4 > h->retry_n) h->first_pass_div = 1;
+        h->retry_pending = false;
+    }
     if (two_pass) {
         cap_nodes = (cap_worst / std::max(h->first_pass_div, 1) + 63) & ~63ll;
         per_read = (size_t)cap_nodes * node_bytes + first_bytes;
@@ -249,10 +263,17 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     if (rc) return rc;
     const int retry_slots = retry_needed ? (int)std::min<size_t>(h->arena_bytes / worst_read, 1u << 30) : 0;
     int32_t *d_counter = nullptr;
-    if (retry_needed) {  // the overflow counter of the retry rounds has its own small allocation
+    if (retry_needed) {  // the overflow counters of the retry rounds have their own small allocation
         rc = ensure(h, &h->retry_counter, &h->retry_counter_bytes, 256);
         if (rc) return rc;
         d_counter = reinterpret_cast<int32_t *>(h->retry_counter);
+        if (!h->retry_host) {  // (page-locked: the copy back is a DMA nobody waits for)
+            if (hipHostMalloc(&h->retry_host, 64, hipHostMallocDefault) != hipSuccess) h->retry_host = nullptr;
+            if (h->retry_host && hipEventCreateWithFlags(&h->retry_ev, hipEventDisableTiming) != hipSuccess) {
+                (void)hipHostFree(h->retry_host);
+                h->retry_host = nullptr;
+            }
+        }
     }
 
     auto wave_arena = [&](char *base, int64_t slabs, int64_t cap) {
@@ -278,16 +299,38 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
             FCD_HIP(h, e);
             if (retry_needed) {
                 WaveArena rr = wave_arena(reinterpret_cast<char *>(h->arena), retry_slots, cap_worst);
-                rr.retry_counter = d_counter;
                 rr.retry_slots = retry_slots;
-                for (;;) {  // every round decodes up to retry_slots of the reads that overflowed
-                    int32_t overflowed = 0;
-                    FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t), h->stream));
-                    FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
-                    FCD_HIP(h, hipMemcpyAsync(&overflowed, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                    FCD_HIP(h, hipStreamSynchronize(h->stream));
-                    if (!h->first_pass_div_pinned && (int64_t)overflowed * 4 > n) h->first_pass_div = 1;
-                    if (overflowed <= retry_slots) break;
+                // Every round decodes up to retry_slots of the reads that overflowed, and a read decoded in a worst-case
+                // slab cannot overflow again: ceil(n / retry_slots) rounds finish the chunk whatever happened in the first
+                // pass (two rounds with the default sizing -- a round with nothing to do is 8192 wavefronts that read one
+                // status word and leave).  So the rounds are ENQUEUED, each with a counter of its own, and nobody waits:
+                // this entry point stays enqueue-only, and launches on other streams slide under a chunk's stragglers.
+                const int64_t rounds = (n + retry_slots - 1) / retry_slots;
+                if (rounds <= kMaxRetryRounds) {
+                    FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t) * (size_t)rounds, h->stream));
+                    for (int64_t k = 0; k < rounds; ++k) {
+                        rr.retry_counter = d_counter + k;
+                        FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
+                    }
+                    // how many reads overflowed (round 0 counts them all) is read back ONE CALL LATE: it only steers
+                    // the sizing of later jobs
+                    if (h->retry_host && !h->retry_pending) {
+                        FCD_HIP(h, hipMemcpyAsync(h->retry_host, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                        FCD_HIP(h, hipEventRecord(h->retry_ev, h->stream));
+                        h->retry_pending = true;
+                        h->retry_n = n;
+                    }
+                } else {  // (a workspace limit that leaves fewer than n / 4 worst-case slabs: count and repeat)
+                    rr.retry_counter = d_counter;
+                    for (;;) {
+                        int32_t overflowed = 0;
+                        FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t), h->stream));
+                        FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
+                        FCD_HIP(h, hipMemcpyAsync(&overflowed, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
+                        FCD_HIP(h, hipStreamSynchronize(h->stream));
+                        if (!h->first_pass_div_pinned && (int64_t)overflowed * 4 > n) h->first_pass_div = 1;
+                        if (overflowed <= retry_slots) break;
+                    }
                 }
             }
             continue;
@@ -357,9 +400,12 @@ int fcd_create(int device, fcd_handle **out) {
 
 int fcd_destroy(fcd_handle *h) {
     if (!h) return FCD_OK;
-    if (h->job_active) {  // its lane threads still write buffers this call would free: fcd_job_end comes first
-        h->err = "a host job is running on this handle (fcd_job_end it first)";
-        return FCD_E_INVALID;
+    {
+        std::lock_guard<std::recursive_mutex> g(h->mu);
+        if (h->job_active) {  // its lane threads still write buffers this call would free: fcd_job_end comes first
+            h->err = "a host job is running on this handle (fcd_job_end it first)";
+            return FCD_E_INVALID;
+        }
     }
     DeviceGuard dev_guard(h->device);
     host_job_release_lanes(h, true);
@@ -369,6 +415,12 @@ int fcd_destroy(fcd_handle *h) {
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->lnbuf) (void)hipFree(h->lnbuf);
     if (h->retry_counter) (void)hipFree(h->retry_counter);
+    if (h->retry_host) {
+        (void)hipEventDestroy(h->retry_ev);
+        (void)hipHostFree(h->retry_host);
+        h->retry_host = nullptr;
+        h->retry_pending = false;
+    }
     for (hipEvent_t e : h->ev0) (void)hipEventDestroy(e);
     for (hipEvent_t e : h->ev1) (void)hipEventDestroy(e);
     if (h->own_stream) (void)hipStreamDestroy(h->own_stream);
@@ -434,6 +486,12 @@ int fcd_release_workspace(fcd_handle *h) {
     if (h->lnbuf) (void)hipFree(h->lnbuf);
     if (h->pin) (void)hipHostFree(h->pin);
     if (h->retry_counter) (void)hipFree(h->retry_counter);
+    if (h->retry_host) {
+        (void)hipEventDestroy(h->retry_ev);
+        (void)hipHostFree(h->retry_host);
+        h->retry_host = nullptr;
+        h->retry_pending = false;
+    }
     h->arena = h->stage = h->lnbuf = h->pin = h->retry_counter = nullptr;
     h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = h->retry_counter_bytes = 0;
     return FCD_OK;
@@ -479,7 +537,9 @@ int fcd_debug_pdq178_coop_profile(fcd_handle *h, uint64_t cycles[16], int reset)
     std::lock_guard<std::recursive_mutex> g(h->mu);
     FCD_DEVICE(h);
     FCD_HIP(h, hipStreamSynchronize(h->stream));
-    FCD_HIP(h, coop_prof_read(reinterpret_cast<unsigned long long *>(cycles), reset != 0));
+    // bit 0: reset afterwards; bit 1: the wide-beam kernel's in-place counters (a -DFCD_LANE_TIE_PROF build) instead of the probe kernels'
+    if (reset & 2) FCD_HIP(h, lane_tie_prof_read(reinterpret_cast<unsigned long long *>(cycles), (reset & 1) != 0));
+    else FCD_HIP(h, coop_prof_read(reinterpret_cast<unsigned long long *>(cycles), (reset & 1) != 0));
     return FCD_OK;
 }
 

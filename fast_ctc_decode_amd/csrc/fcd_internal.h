@@ -182,6 +182,7 @@ hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride,
 hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, int planes,
                                     int keep, hipStream_t stream);
 hipError_t coop_prof_read(unsigned long long *out16, bool reset);  // developer instrument of the probe kernels
+hipError_t lane_tie_prof_read(unsigned long long *out16, bool reset);  // ... of a -DFCD_LANE_TIE_PROF build of beam_lane.hip
 // the tie order searches on this handle use (capi.hip)
 int effective_tie_order(const fcd_handle *h);
 
@@ -242,6 +243,10 @@ struct fcd_handle {
     size_t lnbuf_bytes = 0;
     void *retry_counter = nullptr;  // lane kernel, two-pass sizing: overflow counter of the retry rounds
     size_t retry_counter_bytes = 0;
+    void *retry_host = nullptr;     // page-locked word the first retry round's overflow count is copied to, read one call late
+    hipEvent_t retry_ev = nullptr;  // ... recorded behind that copy
+    bool retry_pending = false;
+    int64_t retry_n = 0;            // reads of the chunk the pending count belongs to
     // chunk lanes of the pipelined host path (hostjob.hip): sub-handles with their own stream and workspace
     std::vector<fcd_host_lane *> lanes;
     bool job_active = false;  // a host job owns the lanes from begin to end

@@ -458,12 +458,14 @@ int ptrs_batch(fcd_handle *h, const void *const *reads, const int64_t *rows, int
                fcd_batch *b) {
     if (!h) return FCD_E_INVALID;
     if (n_reads < 0 || N < 1 || (n_reads > 0 && (!reads || !rows))) {
+        std::lock_guard<std::recursive_mutex> g(h->mu);
         h->err = "reads / rows missing";
         return FCD_E_INVALID;
     }
     int64_t T = 0;
     for (int64_t r = 0; r < n_reads; ++r) {
         if (rows[r] < 0 || (rows[r] > 0 && !reads[r])) {
+            std::lock_guard<std::recursive_mutex> g(h->mu);
             h->err = "a read is missing (null pointer or negative row count)";
             return FCD_E_INVALID;
         }

@@ -55,7 +55,7 @@ struct alignas(16) WaveScratch {
 
 #if defined(FCD_WAVE_PROF) && !defined(FCD_HIPEMU)
 // developer instrument (tools/dev/time_coop.py): shader cycles per phase, summed over the calls of lane 0's wavefronts
-__device__ unsigned long long g_wave_prof[16];
+static __device__ unsigned long long g_wave_prof[16];  // (one per translation unit that asks for the stamps)
 #define FCD_WAVE_STAMP(slot)                                                             \
     do {                                                                                 \
         const unsigned long long now__ = __builtin_amdgcn_s_memtime();                   \
