@@ -160,7 +160,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     constexpr int PL = PDQ ? (HALF * N + 63) / 64 : 1;
     union TieScratch {
         pdq178::WaveScratch<PL> ws;
-        uint32_t eid[PDQ ? RPW * (HALF * N + 4) : 1];
+        uint32_t eid[PDQ ? RPW * (HALF * N + 16) : 1];
     };
     __shared__ TieScratch s_tie_scr;
 
@@ -636,9 +636,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 key[0] = (svalid && go) ? make_key(slp + sgp, node) : 0ull;
 #pragma unroll
                 for (int l = 0; l < NL; ++l) key[l + 1] = (cand_valid[l + 1] && go) ? make_key(contrib[l], ccand[l]) : 0ull;
-                // (each half's ids are followed by four words of padding OF ITS OWN -- the lanes run in lockstep, a
+                // (each half's ids are followed by sixteen words of padding OF ITS OWN -- the lanes run in lockstep, a
                 // padding store that reached into the other half's region would land after that half's ids)
-                uint32_t *eid = s_tie_scr.eid + hh * (HALF * N + 4);
+                uint32_t *eid = s_tie_scr.eid + hh * (HALF * N + 16);
                 bool older[N];
                 int n_older = 0;
 #pragma unroll
@@ -652,7 +652,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
                 for (int k = 0; k < N; ++k)
                     if (older[k]) eid[o_pos++] = (uint32_t)key[k];  // low word: larger = smaller node
-                if (q < 4) eid[n_old + q] = 0u;                     // (padding of the last 16-byte read: never "smaller")
+                if (q < 16) eid[n_old + q] = 0u;                    // (padding of the last block of reads: never "smaller")
                 wave_sync();
                 int n_old_max = n_old;
                 if (RPW == 2) n_old_max = max(n_old_max, __shfl_xor(n_old_max, 32));
@@ -660,14 +660,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 int pos[N];
 #pragma unroll
                 for (int k = 0; k < N; ++k) pos[k] = 0;
+                // sixteen ids per trip: four 16-byte LDS reads in flight together (a straggler's wavefront runs alone on
+                // its SIMD: one read per trip was one exposed LDS round trip per four ids)
 #pragma unroll 1
-                for (int j = 0; j < n_old_max; j += 4) {
-                    uint4 e = make_uint4(0u, 0u, 0u, 0u);
-                    if (j < n_old) e = *reinterpret_cast<const uint4 *>(eid + j);
+                for (int j = 0; j < n_old_max; j += 16) {
+                    uint4 e[4];
 #pragma unroll
-                    for (int k = 0; k < N; ++k) {
-                        const uint32_t me = (uint32_t)key[k];
-                        pos[k] += ((e.x > me) ? 1 : 0) + ((e.y > me) ? 1 : 0) + ((e.z > me) ? 1 : 0) + ((e.w > me) ? 1 : 0);
+                    for (int u = 0; u < 4; ++u) {
+                        e[u] = make_uint4(0u, 0u, 0u, 0u);
+                        if (j + 4 * u < n_old) e[u] = *reinterpret_cast<const uint4 *>(eid + j + 4 * u);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                        for (int k = 0; k < N; ++k) {
+                            const uint32_t me = (uint32_t)key[k];
+                            pos[k] += ((e[u].x > me) ? 1 : 0) + ((e[u].y > me) ? 1 : 0) + ((e[u].z > me) ? 1 : 0) + ((e[u].w > me) ? 1 : 0);
+                        }
                     }
                 }
                 wave_sync();  // (the table the ids sat in is the sort's scratch from here on)

@@ -13,6 +13,11 @@
 // then checked against the image's own libm on EVERY binary32 argument: tools/verify/verify_glibc235.c -- expf, logf and
 // log1pf each 4 294 967 296 arguments, 0 differences (profiles/r04_glibc235_verify.txt).  Without the fused r, expf
 // differs on exactly two arguments (0x1.04845ep+5, -0x1.f8cbb2p+5): what a CPU without FMA would compute.
+// Attribution: the algorithms and table constants are those of the GNU C Library 2.35 (LGPL-2.1-or-later).  expf and
+// logf there are Arm's optimized routines by Szabolcs Nagy (Copyright (c) 2017-2018 Arm Ltd; MIT OR Apache-2.0 WITH
+// LLVM-exception upstream, github.com/ARM-software/optimized-routines); log1pf descends from fdlibm's s_log1pf.c
+// (Copyright (C) 1993 Sun Microsystems, Inc.: "Permission to use, copy, modify, and distribute this software is freely
+// granted, provided that this notice is preserved").  No file was copied; what is restated is the arithmetic.
 // Plain IEEE binary64 / binary32 arithmetic and fma(): the same code runs on the host (the verification, the threshold's
 // logarithm in capi.hip) and on gfx950 (v_fma_f64, IEEE division).
 #pragma once

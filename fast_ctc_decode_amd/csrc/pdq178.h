@@ -8,8 +8,9 @@
 // toolchain (Rust 1.78.0: .github/workflows/test.yml:16, build-wheels.sh:6) -- a pattern-defeating quicksort whose
 // permutation of equal keys is a deterministic function of the whole list.  The kernels rank candidates exactly
 // on (probability desc, node asc) without sorting; on the rare steps where a KEPT candidate ties with another one
-// among more than 20 candidates, ONE lane replays that quicksort on the node-ordered list and the wavefront adopts
-// the ranks it produces (FCD_TIE_PDQ178, include/fcd.h).
+// among more than 20 candidates, the quicksort is replayed on the node-ordered list -- by one lane with this file's
+// routine (generic and duplex kernels), by the whole wavefront with pdq178_wave.h's (register kernels) -- and the
+// wavefront adopts the ranks it produces (FCD_TIE_PDQ178, include/fcd.h).
 //
 // The routine follows library/core/src/slice/sort.rs as of 1.78 (recurse / choose_pivot / partial_insertion_sort /
 // partition_equal / partition + partition_in_blocks with BLOCK = 128 / break_patterns / heapsort).  Neither the Rust
@@ -17,6 +18,13 @@
 // oracle/fcd_oracle.c, DEFINE_PDQSORT), and the two are compared element for element on adversarial lists
 // (tests/test_pdq178.py, also on the GPU through fcd_debug_pdq178_sort_dev).  Recursion is an explicit stack:
 // the quicksort recurses into the SHORTER side, so 24 frames cover any list below 2^24 elements.
+//
+// Attribution: the algorithm is core::slice::sort of the Rust standard library, version 1.78.0 (The Rust Project
+// Developers; MIT OR Apache-2.0), itself after Orson Peters' pattern-defeating quicksort (zlib licence) with
+// BlockQuicksort's partitioning (Edelkamp & Weiss).  No file was copied; what is restated is the sequence of
+// comparisons and moves.  PINNING: tools/verify/pdq178_vectors.json holds 1731 lists with the permutation this
+// restatement produces and tools/verify/pdq178_check.rs sorts them with rustc's own sort_unstable_by -- one command
+// for whoever has the 1.78.0 toolchain; until somebody runs it the claim "follows Rust 1.78" rests on recollection.
 //
 // An element is a u64: the sort key is the upper word (the orderable bits of the probability, larger = earlier;
 // is_less(a, b) = a.key > b.key, i.e. descending probability; keys never are NaNs -- a NaN among two or more
@@ -40,7 +48,7 @@ struct Scratch {
 };
 
 #define FCD_PDQ_FN static __device__ inline
-// The list may sit behind a generic pointer (elem_t *) or an LDS one (pdq178_coop.h: ds_* instructions instead of
+// The list may sit behind a generic pointer (elem_t *) or an LDS one (pdq178_wave.h: ds_* instructions instead of
 // flat_* ones -- a third of the latency): the helpers take either.
 
 FCD_PDQ_FN bool less(elem_t a, elem_t b) { return (uint32_t)(a >> 32) > (uint32_t)(b >> 32); }

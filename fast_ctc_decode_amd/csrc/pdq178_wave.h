@@ -198,28 +198,29 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
                 sync();
             }
             // ---- choose_pivot: the adjacent triples around len/4, len/2, 3 len/4 (from 50 elements: Tukey's ninther),
-            // every lane reading the same addresses; the network runs on (index, key) pairs ----
+            // every lane reading the same addresses -- all nine loads in flight together (below 50 elements the outer
+            // two of a triple are read and ignored: c - 1 >= base + 4 and c + 1 < base + len either way); the network
+            // runs on (index, key) pairs ----
             const bool ninther = len >= 50;
             const int ia = len / 4, ib = ia * 2, ic = ia * 3;
             uint32_t e[9];
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const int c = base + (t == 0 ? ia : (t == 1 ? ib : ic));
+                e[3 * t] = key_at(c - 1);
                 e[3 * t + 1] = key_at(c);
-                e[3 * t] = ninther ? key_at(c - 1) : 0u;
-                e[3 * t + 2] = ninther ? key_at(c + 1) : 0u;
+                e[3 * t + 2] = key_at(c + 1);
             }
             int swaps = 0;
             auto srt2 = [&](int &a, uint32_t &ea, int &b, uint32_t &eb) {  // sort2: the smaller (in sort order) index first
-                if (eb > ea) {  // less(v[b], v[a])
-                    const int ti = a;
-                    a = b;
-                    b = ti;
-                    const uint32_t te = ea;
-                    ea = eb;
-                    eb = te;
-                    ++swaps;
-                }
+                const bool sw = eb > ea;  // less(v[b], v[a])
+                const int ta = a, tb = b;
+                const uint32_t tea = ea, teb = eb;
+                a = sw ? tb : ta;
+                b = sw ? ta : tb;
+                ea = sw ? teb : tea;
+                eb = sw ? tea : teb;
+                swaps += sw ? 1 : 0;
             };
             int ix[3];
             uint32_t ev[3];
@@ -282,21 +283,32 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
                 }
             }
             if (!finished) {
-                // ---- swap(0, pivot); which partition: the pivot equals the predecessor -> partition_equal ----
+                // ---- ONE round of loads: every element of the segment (a lane per element and plane), the pivot, the
+                // first element (it changes places with the pivot: swap(0, pivot)) and the predecessor.  The swap
+                // happens in registers: the lane of the pivot's position takes the first element, position `base` is
+                // not classified, and what LDS holds at the two positions is put right by the scatter below. ----
+                const int wb = base + 1, we = base + len;
+                const int ppos = base + pivot;
+                elem_t val[P];
+                bool in[P];
+#pragma unroll
+                for (int j = 0; j < P; ++j) {
+                    const int p = 64 * j + lane;
+                    val[j] = 0;
+                    in[j] = false;
+                    if (wb < 64 * (j + 1) && we > 64 * j) {  // (wave-uniform: the segment reaches this plane)
+                        in[j] = p >= wb && p < we;
+                        if (in[j]) val[j] = v[p];
+                    }
+                }
                 const elem_t pval = w[pivot], first = w[0];
                 const uint32_t pe = pred >= 0 ? key_at(pred) : 0u;
-                const uint32_t pk = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(pval >> 32));
+                const uint32_t pk = (uint32_t)uni((int)(uint32_t)(pval >> 32));
+                // which partition: the pivot equals the predecessor (nothing in the segment is "less" than it) -> partition_equal
                 const bool equal = pred >= 0 && !((uint32_t)uni((int)pe) > pk);  // !less(v[pred], v[pivot])
-                if (lane == 0) {
-                    w[pivot] = first;
-                    w[0] = pval;
-                }
-                sync();
                 FCD_WAVE_STAMP(2);
                 // ---- one lane per element: which side of the pivot does it belong to? ----
-                const int wb = base + 1, we = base + len;
-                elem_t val[P];
-                bool bit[P], in[P];
+                bool bit[P];
                 Bits<P> mk;
                 int ones_upto[P];  // ones in the planes below plane j
                 {
@@ -304,16 +316,10 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
 #pragma unroll
                     for (int j = 0; j < P; ++j) {
                         const int p = 64 * j + lane;
-                        val[j] = 0;
-                        bit[j] = false;
-                        in[j] = false;
-                        if (wb < 64 * (j + 1) && we > 64 * j) {  // (wave-uniform: the segment reaches this plane)
-                            in[j] = p >= wb && p < we;
-                            if (in[j]) val[j] = v[p];
-                            const uint32_t k = (uint32_t)(val[j] >> 32);
-                            // NORMAL: less(e, pivot) -- the element belongs left.  EQUAL: less(pivot, e) -- it belongs right.
-                            bit[j] = in[j] && (equal ? pk > k : k > pk);
-                        }
+                        if (in[j] && p == ppos) val[j] = first;
+                        const uint32_t k = (uint32_t)(val[j] >> 32);
+                        // NORMAL: less(e, pivot) -- the element belongs left.  EQUAL: less(pivot, e) -- it belongs right.
+                        bit[j] = in[j] && (equal ? pk > k : k > pk);
                         mk.m[j] = __builtin_amdgcn_ballot_w64(bit[j]);
                         ones_upto[j] = run;
                         run += __builtin_popcountll(mk.m[j]);
@@ -376,48 +382,54 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
                 }
                 sync();
                 FCD_WAVE_STAMP(4);
-                // ---- the moves.  NORMAL: the cyclic permutation L0 <- R0 <- L1 <- R1 ... <- R(count-1) <- L0 of the
-                // first `count` misplaced pairs; EQUAL: the k-th greater element from the left swaps with the k-th equal
-                // one from the right.  Every mover still holds its own value in a register. ----
+                // ---- where every element ends up, in ONE scatter: every mover still holds its value in a register.
+                // NORMAL, as partition_in_blocks and `partition` do it:
+                //  1. the cyclic permutation L0 <- R0 <- L1 <- R1 ... <- R(count-1) <- L0 of the first `count` misplaced pairs;
+                //  2. the left-over misplaced elements of the longer side are parked against the block boundary by
+                //     swaps taken from the far end: left-over hole j of the left block ends at a1 - cL + j (of the right
+                //     block: a1 + cR - 1 - j), and the well-placed element the swap met at that spot goes to the hole --
+                //     which may itself be a spot a later swap visits, and so on: it follows the chain of holes until one
+                //     lies outside the parking zone (each hop moves strictly away from the boundary);
+                //  3. swap(0, mid): whoever ends at the last position of the left part goes to `base`, the pivot there.
+                // EQUAL: the k-th greater element from the left swaps with the k-th equal one from the right; the pivot
+                // stays in front. ----
+                const int m_left = equal ? 0 : cL - count, m_right = equal ? 0 : cR - count;  // (one of them is 0)
+                const int pm = a1 - m_left + m_right - 1;  // NORMAL: where the pivot belongs
+                const int zlo = m_left > 0 ? a1 - m_left : a1, zhi = m_left > 0 ? a1 : a1 + m_right;  // the parking zone
+                const int org_l = a1 - cL, org_r = a1 + cR - 1;  // left-over hole j parks at org_l + j / org_r - j
 #pragma unroll
                 for (int j = 0; j < P; ++j) {
-                    if (role[j] == 0 || kk[j] >= count) continue;
-                    int dest;
-                    if (!equal)
-                        dest = role[j] == 1 ? s->pos_r[kk[j] == 0 ? count - 1 : kk[j] - 1] : s->pos_l[kk[j]];
-                    else
-                        dest = role[j] == 1 ? s->pos_r[kk[j]] : s->pos_l[kk[j]];
-                    v[dest] = val[j];
+                    if (!in[j]) continue;
+                    const int p = 64 * j + lane;
+                    int z = p;             // where the element sits after step 1
+                    bool parked = false;   // a left-over misplaced element: its spot is known outright
+                    if (role[j] != 0) {
+                        if (kk[j] < count) {
+                            if (!equal) z = role[j] == 1 ? s->pos_r[kk[j] == 0 ? count - 1 : kk[j] - 1] : s->pos_l[kk[j]];
+                            else z = role[j] == 1 ? s->pos_r[kk[j]] : s->pos_l[kk[j]];
+                        } else {
+                            z = role[j] == 1 ? org_l + kk[j] : org_r - kk[j];
+                            parked = true;
+                        }
+                    }
+                    if (!parked && z >= zlo && z < zhi) {  // met by a parking swap: on to that swap's hole, and again
+                        if (m_left > 0) {
+                            do z = s->pos_l[z - org_l]; while (z >= zlo);
+                        } else {
+                            do z = s->pos_r[org_r - z]; while (z < zhi);
+                        }
+                    }
+                    if (!equal && z == pm) z = base;
+                    // (the pivot's old position still holds the pivot in LDS: whoever sits there writes even if it stays)
+                    if (z != p || p == ppos) v[z] = val[j];
+                }
+                if (lane == 0) {
+                    if (equal || pm == base) w[0] = pval;
+                    else v[pm] = pval;
                 }
                 sync();
                 FCD_WAVE_STAMP(5);
                 if (!equal) {
-                    // ---- park the left-over misplaced elements, put the pivot in place, name the children ----
-                    const int m_left = cL - count, m_right = cR - count;  // (one of them is 0)
-                    const int pm = a1 - m_left + m_right - 1;             // where the pivot belongs: swap(0, mid)
-                    if (lane == 0) {
-                        int bound = a1;
-                        // while start_l < end_l { end_l -= 1; swap(l + *end_l, r - 1); r -= 1 }
-                        for (int j = cL - 1; j >= count; --j) {
-                            --bound;
-                            const int hole = s->pos_l[j];
-                            const elem_t t = v[hole], u = v[bound];
-                            v[hole] = u;
-                            v[bound] = t;
-                        }
-                        // while start_r < end_r { end_r -= 1; swap(l, r - *end_r - 1); l += 1 }
-                        for (int j = cR - 1; j >= count; --j) {
-                            const int hole = s->pos_r[j];
-                            const elem_t t = v[hole], u = v[bound];
-                            v[hole] = u;
-                            v[bound] = t;
-                            ++bound;
-                        }
-                        const elem_t t = v[pm];
-                        v[base] = t;
-                        v[pm] = pval;
-                    }
-                    sync();
                     const int mid = pm - base;
                     const int smaller = mid < len - mid ? mid : len - mid;
                     const bool nb = smaller >= len / 8, np = a0 >= a2;
@@ -492,24 +504,29 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
         dest[j] = -1;
         lval[j] = 0;
         if (64 * j >= n || 64 * j >= reach) continue;  // (wave-uniform: nothing of this plane matters)
-        if (p >= n) continue;
-        // nearest boundary at or below p, nearest one above it (the list starts and ends with one)
-        const int hi = cut.first(p + 1, n + 1, true);
-        const int lo = cut.last_one(0, p + 1);
+        // nearest boundary at or below p and nearest one above it, as far as 63 positions away: two 64-bit windows of the
+        // boundary bits around p (the list starts and ends with a boundary; a leaf spans at most 20 positions)
+        const uint64_t below_w = (cut.m[j] << (63 - lane)) | (j > 0 ? ((cut.m[j > 0 ? j - 1 : 0] >> 1) >> lane) : 0ull);  // bit 63 = position p
+        const uint64_t above_w = ((cut.m[j] >> 1) >> lane) | (cut.m[j + 1] << (63 - lane));                          // bit 0 = position p + 1
+        const int lo = p - (below_w ? __builtin_clzll(below_w) : 64);
+        const int hi = p + 1 + (above_w ? __builtin_ctzll(above_w) : 64);
         const int ln = hi - lo;
-        if (ln < 2 || ln > 20 || lo >= keep) continue;  // (whole leaves: in or out)
-        lval[j] = v[p];
+        const bool mine = p < n && ln >= 2 && ln <= 20 && lo < keep;  // (whole leaves: in or out)
+        if (__builtin_amdgcn_ballot_w64(mine) == 0ull) continue;      // (wave-uniform)
+        if (mine) lval[j] = v[p];
         const uint32_t key = (uint32_t)(lval[j] >> 32);
+        // the leaf's keys, ten loads in flight together
         int rank = 0;
-        for (int q = lo; q < hi; q += 4) {  // four keys per trip: their loads travel together
-            uint32_t kq[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) kq[u] = key_at(q + u < n ? q + u : n - 1);
+        for (int u0 = 0; u0 < 20; u0 += 10) {
+            uint32_t kq[10];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-                rank += (q + u < hi && (kq[u] > key || (kq[u] == key && q + u < p))) ? 1 : 0;
+            for (int u = 0; u < 10; ++u) kq[u] = mine ? key_at(lo + u0 + u < n ? lo + u0 + u : n - 1) : 0u;
+#pragma unroll
+            for (int u = 0; u < 10; ++u)
+                rank += (lo + u0 + u < hi && (kq[u] > key || (kq[u] == key && lo + u0 + u < p))) ? 1 : 0;
         }
-        dest[j] = lo + rank;
+        if (mine) dest[j] = lo + rank;
     }
     sync();
 #pragma unroll

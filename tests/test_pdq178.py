@@ -152,3 +152,29 @@ def test_tie_order_api_emulated():
         assert lib.fcd_set_default_tie_order(nat.TIE_STABLE) == 0 and h.tie_order() == nat.TIE_STABLE
         assert lib.fcd_set_default_tie_order(nat.TIE_PDQ178) == 0 and h.tie_order() == nat.TIE_PDQ178
         assert lib.fcd_set_default_tie_order(7) != 0 and lib.fcd_set_tie_order(h.ptr, 7) != 0
+
+
+def test_committed_vectors_match_every_restatement_emulated():
+    """tools/verify/pdq178_vectors.json is what a holder of rustc 1.78.0 checks with tools/verify/pdq178_check.rs: it has
+    to say what the oracle, csrc/pdq178.h and csrc/pdq178_wave.h really do -- all three, on every list it holds."""
+    import json
+    import os
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify", "pdq178_vectors.json")
+    doc = json.load(open(path))
+    assert doc["meta"]["cases"] == len(doc["cases"]) >= 1500
+    lists = [np.array(c["bits"], np.uint32).view(np.float32) for c in doc["cases"]]
+    perms = [np.array(c["perm"], np.int64) for c in doc["cases"]]
+    assert min(len(p) for p in lists) >= 21 and max(len(p) for p in lists) <= 512
+    for p, perm in zip(lists, perms):
+        _, want = oracle.pdqsort_desc(p, np.arange(len(p), dtype=np.int32))
+        assert np.array_equal(want, perm)
+    with emulated_kernels() as lib:
+        h = nat.default_handle(0)
+        out, lens = device_sort(lib, h, lists, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
+        for i, perm in enumerate(perms):
+            assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), i
+        out, lens = device_coop_sort(lib, h, lists, 8, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
+        for i, perm in enumerate(perms):
+            assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), i
