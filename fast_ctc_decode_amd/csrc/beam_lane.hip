@@ -608,6 +608,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
             const uint64_t m_tied = ballot(tied);
             if (__builtin_expect(m_tied != 0ull, 0)) {
                 const bool mine_h = hmask(m_tied) != 0ull;
+                // A read that ties once usually ties at most of its later steps, and each such step costs several plain
+                // ones: its wavefront is one of the launch's stragglers.  Alone on its SIMD it runs an instruction per
+                // ~4 cycles; sharing the SIMD with three wavefronts of the NEXT launch (another stream) it would get a
+                // quarter of that and stretch its launch fourfold -- so from its first tied step on it keeps the
+                // issue priority (a few dozen wavefronts per launch: nobody else notices).
+                __builtin_amdgcn_s_setprio(3);
 #ifdef FCD_LANE_TIE_PROF
                 const unsigned long long tp0 = __builtin_amdgcn_s_memtime();
 #endif

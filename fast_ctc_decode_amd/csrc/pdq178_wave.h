@@ -24,6 +24,8 @@
 //     boundary, in scalar registers) and every element of every such leaf ranks itself inside its leaf in one last
 //     pass; a segment that lies wholly behind the first `keep` positions is dropped (segments never exchange
 //     elements, so the kept prefix cannot tell).
+// From 64 elements down a segment is handed, with its recursion state, to pdq178_reg.h: one element per lane, every
+// partition a handful of cross-lane operations, nothing in memory.
 // The stack lives in two vector registers (frame k in lane k): a push is a masked move, a pop two v_readlane.
 // A list longer than kWaveMaxLen (its first partition could need more than one round of 128-element blocks) is
 // sorted by pdq178::sort_desc on one lane instead.  tests/test_pdq178.py compares this routine with sort_desc --
@@ -34,6 +36,7 @@
 #pragma once
 
 #include "pdq178.h"
+#include "pdq178_reg.h"
 
 namespace fcd {
 namespace pdq178 {
@@ -187,7 +190,21 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
         bool finished = false;  // this segment needs nothing more
         // what is left of the segment after this round, if anything (NORMAL: two children, EQUAL: one)
         int c_base[2] = {0, 0}, c_len[2] = {0, 0}, c_pred[2] = {-1, -1}, c_flag[2] = {0, 0};
-        if (limit == 0) {
+        if (P == 1 || len <= 64) {
+            // the segment fits the lanes of the wavefront: the rest of ITS quicksort -- every partition down to the leaves --
+            // runs in registers (pdq178_reg.h) and comes back sorted as far as the kept prefix reaches
+            uint32_t rk = 0, rt = 0;
+            if (lane < len) {
+                const elem_t e = w[lane];
+                rk = (uint32_t)(e >> 32);
+                rt = (uint32_t)e;
+            }
+            const uint32_t ppk = (uint32_t)uni((int)(pred >= 0 ? key_at(pred) : 0u));
+            reg_sort(rk, rt, len, keep - base, pred >= 0, ppk, limit, wbal, wpar, v_generic + base, lane);
+            if (lane < len) w[lane] = ((elem_t)rk << 32) | rt;
+            sync();
+            finished = true;
+        } else if (limit == 0) {
             if (lane == 0) heapsort(w, len);
             sync();
             finished = true;
