@@ -45,6 +45,15 @@ __device__ __forceinline__ int uni(int x) { return __builtin_amdgcn_readfirstlan
 __device__ __forceinline__ uint64_t below(int n) {  // bits 0 .. n-1, n in [0, 64]
     return n >= 64 ? ~0ull : ((1ull << n) - 1ull);
 }
+// ones of `m` at positions below this lane (v_mbcnt_lo / v_mbcnt_hi; tests/hipemu has no such builtin)
+__device__ __forceinline__ int ones_below_lane(uint64_t m, int lane) {
+#ifdef FCD_HIPEMU
+    return __builtin_popcountll(m & below(lane));
+#else
+    (void)lane;
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#endif
+}
 __device__ __forceinline__ uint32_t rdl(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, l); }
 __device__ __forceinline__ int bperm(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
 __device__ __forceinline__ int perm(int dst_lane, int v) { return __builtin_amdgcn_ds_permute(dst_lane << 2, v); }
@@ -186,14 +195,11 @@ __device__ __forceinline__ void reg_sort(uint32_t &key, uint32_t &tag, const int
                 const uint32_t kp = rdl(key, ppos), tp = rdl(tag, ppos), kf = rdl(key, base), tf = rdl(tag, base);
                 const uint32_t pe = pred >= 0 ? rdl(key, pred) : pred_key;
                 const bool equal = pred != -1 && !(pe > kp);  // !less(v[pred], v[pivot])
-                if (lane == ppos) {
-                    key = kf;
-                    tag = tf;
-                }
-                if (lane == base) {
-                    key = kp;
-                    tag = tp;
-                }
+                // (selects, not branches: a divergent `if` costs four scalar instructions of mask bookkeeping)
+                key = lane == ppos ? kf : key;
+                tag = lane == ppos ? tf : tag;
+                key = lane == base ? kp : key;
+                tag = lane == base ? tp : tag;
                 const int wb = base + 1, we = base + len;
                 const bool in = lane >= wb && lane < we;
                 // NORMAL: less(e, pivot) -- the element belongs left.  EQUAL: less(pivot, e) -- it belongs right.
@@ -224,27 +230,22 @@ __device__ __forceinline__ void reg_sort(uint32_t &key, uint32_t &tag, const int
                     a2 = we;
                     count = __builtin_popcountll(m & below(a1));        // greater ones inside the left zone == equal ones outside it
                 }
-                const int ones_before = __builtin_popcountll(m & below(lane));
-                int role = 0, kk = 0;
-                if (in) {
-                    if (!equal) {
-                        if (lane >= a0 && lane < a1 && !bit) {          // offsets_l, in tracing order
-                            role = 1;
-                            kk = (lane - a0) - (ones_before - p0);
-                        } else if (lane >= a1 && lane < a2 && bit) {    // offsets_r, in tracing order (from the right)
-                            role = 2;
-                            kk = p2 - ones_before - 1;
-                        }
-                    } else {
-                        if (lane < a1 && bit) {
-                            role = 1;
-                            kk = ones_before;
-                        } else if (lane >= a1 && !bit) {
-                            role = 2;
-                            kk = (a2 - lane - 1) - (p2 - ones_before);
-                        }
-                    }
+                const int ones_before = ones_below_lane(m, lane);
+                bool is_l, is_r;
+                int kk_l, kk_r;
+                if (!equal) {
+                    is_l = in && lane >= a0 && lane < a1 && !bit;   // offsets_l, in tracing order
+                    is_r = in && lane >= a1 && lane < a2 && bit;    // offsets_r, in tracing order (from the right)
+                    kk_l = (lane - a0) - (ones_before - p0);
+                    kk_r = p2 - ones_before - 1;
+                } else {
+                    is_l = in && lane < a1 && bit;                  // a greater element inside the left zone, from the left
+                    is_r = in && lane >= a1 && !bit;                // an equal element outside it, from the right
+                    kk_l = ones_before;
+                    kk_r = (a2 - lane - 1) - (p2 - ones_before);
                 }
+                const int role = is_l ? 1 : (is_r ? 2 : 0);
+                const int kk = is_l ? kk_l : kk_r;
                 // position of the k-th misplaced element of either side: lane k of two registers (at most 31 pairs: lane
                 // 63 takes what has nothing to say)
                 const int tab_l = perm(role == 1 ? kk : 63, lane), tab_r = perm(role == 2 ? kk : 63, lane);
@@ -256,16 +257,10 @@ __device__ __forceinline__ void reg_sort(uint32_t &key, uint32_t &tag, const int
                 const int idx_r = equal ? kk : (kk == 0 ? count - 1 : kk - 1);
                 const int from_r = bperm((role == 1 && kk < count) ? idx_r : 63, tab_r);
                 const int from_l = bperm((role == 2 && kk < count) ? kk : 63, tab_l);
-                int z = lane;
-                bool parked = false;
-                if (role != 0) {
-                    if (kk < count) {
-                        z = role == 1 ? from_r : from_l;
-                    } else {  // a left-over misplaced element: parked against the block boundary
-                        z = role == 1 ? org_l + kk : org_r - kk;
-                        parked = true;
-                    }
-                }
+                // a left-over misplaced element is parked against the block boundary
+                const bool parked = role != 0 && kk >= count;
+                const int z_pair = role == 1 ? from_r : from_l, z_park = role == 1 ? org_l + kk : org_r - kk;
+                int z = role == 0 ? lane : (parked ? z_park : z_pair);
                 // a well-placed element a parking swap met goes to that swap's hole -- and on, while the hole is a spot a
                 // later swap visits (pdq178_wave.h)
                 bool hop = in && !parked && z >= zlo && z < zhi;
@@ -275,8 +270,8 @@ __device__ __forceinline__ void reg_sort(uint32_t &key, uint32_t &tag, const int
                     if (hop) z = h;
                     hop = hop && z >= zlo && z < zhi;
                 }
-                if (in && !equal && z == pm) z = base;       // swap(0, mid): the last element of the left part ...
-                if (lane == base) z = equal ? base : pm;     // ... changes places with the pivot
+                z = (in && !equal && z == pm) ? base : z;          // swap(0, mid): the last element of the left part ...
+                z = lane == base ? (equal ? base : pm) : z;        // ... changes places with the pivot
                 key = (uint32_t)perm(z, (int)key);
                 tag = (uint32_t)perm(z, (int)tag);
                 if (!equal) {

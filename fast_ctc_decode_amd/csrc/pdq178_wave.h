@@ -374,7 +374,7 @@ __device__ __forceinline__ void wave_sort_inline(elem_t *v_generic, int n_in, in
                     kk[j] = 0;
                     if (!(wb < 64 * (j + 1) && we > 64 * j) || !in[j]) continue;
                     const int p = 64 * j + lane;
-                    const int ones_before = ones_upto[j] + __builtin_popcountll(mk.m[j] & bits_below(lane));
+                    const int ones_before = ones_upto[j] + reg_detail::ones_below_lane(mk.m[j], lane);
                     if (!equal) {
                         if (p >= a0 && p < a1 && !bit[j]) {         // offsets_l, in tracing order (left to right)
                             role[j] = 1;
