@@ -15,6 +15,7 @@
 // so libfcd_hip.so has no link-time dependency on it and single-GPU users never load it.  An fcd_comm can also
 // wrap a communicator the host already owns (fcd_comm_wrap), or none at all for world = 1.
 #include <dlfcn.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -56,8 +57,12 @@ Rccl &rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, [] {
+        // FCD_RCCL_LIBRARY names the library outright (a site's own build; tests/stubs' shared-memory stand-in)
+        if (const char *named = getenv("FCD_RCCL_LIBRARY"))
+            if (*named) r.lib = dlopen(named, RTLD_NOW | RTLD_LOCAL);
         // a copy already in the process (PyTorch's) first: two RCCLs in one process would not share state
         for (const char *name : {"librccl.so", "librccl.so.1"}) {
+            if (r.lib) break;
             r.lib = dlopen(name, RTLD_NOW | RTLD_NOLOAD | RTLD_LOCAL);
             if (r.lib) break;
         }
@@ -100,6 +105,14 @@ namespace {
 int comm_fail(fcd_comm *c, int code, const std::string &msg) {
     c->h->err = msg;
     return code;
+}
+
+// test hook (tests/capi/comm_world.c): FCD_DEBUG_FAIL_GATHER_ALLOC=<rank> makes that rank's gather buffers
+// "unallocatable", once they have to grow -- the failure every rank must then learn of before any of them enqueues its
+// ncclGather
+bool injected_alloc_failure(const fcd_comm *c) {
+    const char *e = getenv("FCD_DEBUG_FAIL_GATHER_ALLOC");
+    return e && *e && atoi(e) == c->rank;
 }
 
 int need(fcd_comm *c, Buf &b, size_t bytes) {
@@ -243,10 +256,10 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
     char *meta = reinterpret_cast<char *>(c->meta.p);
     char *fixed = reinterpret_cast<char *>(c->fixed.p);
     uint64_t *d_offs = reinterpret_cast<uint64_t *>(meta);
-    // fixed: [0, 16) the agreed {largest label total, largest out_stride} | [16, 20) header flag | [32, 48) this rank's
-    // {label total, out_stride} | [64, ...) prefix sums of the read counts
+    // fixed: [0, 24) the agreed {largest label total, largest out_stride, ~smallest capacity} | [24, 28) header flag |
+    // [32, 56) this rank's three words | [64, ...) prefix sums of the read counts
     uint64_t *d_max = reinterpret_cast<uint64_t *>(fixed);
-    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 16);
+    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 24);
     uint64_t *d_mine = reinterpret_cast<uint64_t *>(fixed + 32);
     int64_t *d_first = reinterpret_cast<int64_t *>(fixed + 64);
     FCD_HIP(h, launch_result_offsets(res->out_len, n_reads, W, d_offs, st));
@@ -254,24 +267,28 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
     // and the width of the time indices (2 bytes below 65536 rows) -- i.e. on the largest out_stride.  Both are agreed
     // on with one 16-byte all-reduce (a rank whose shard is padded differently would otherwise send another size
     // and hang or corrupt the collective).
+    // The third word is the complement of what this rank's buffers hold already (send; the destination: receive / world),
+    // so the same reduction also says whether ANY rank will have to allocate: only then a second, 8-byte all-reduce
+    // follows, in which the ranks tell each other whether they could (below).
     uint64_t *pin64 = reinterpret_cast<uint64_t *>(c->pin);
     pin64[4] = (uint64_t)res->out_stride;
+    pin64[5] = ~(uint64_t)std::min<size_t>(c->send.cap, is_dst ? c->recv.cap / (size_t)c->world : ~(size_t)0);
     FCD_HIP(h, hipMemcpyAsync(d_mine, d_offs + n_reads, 8, hipMemcpyDeviceToDevice, st));
-    FCD_HIP(h, hipMemcpyAsync(d_mine + 1, pin64 + 4, 8, hipMemcpyHostToDevice, st));
+    FCD_HIP(h, hipMemcpyAsync(d_mine + 1, pin64 + 4, 16, hipMemcpyHostToDevice, st));
     if (c->comm) {
-        rc = nccl_check(c, rccl().AllReduce(d_mine, d_max, 2, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
+        rc = nccl_check(c, rccl().AllReduce(d_mine, d_max, 3, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
         if (rc) return rc;
     } else {
-        FCD_HIP(h, hipMemcpyAsync(d_max, d_mine, 16, hipMemcpyDeviceToDevice, st));
+        FCD_HIP(h, hipMemcpyAsync(d_max, d_mine, 24, hipMemcpyDeviceToDevice, st));
     }
     // (the flag behind them is the PREVIOUS gather's header check: reported one call late, or by fcd_comm_synchronize)
-    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 24, hipMemcpyDeviceToHost, st));
+    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 32, hipMemcpyDeviceToHost, st));
     FCD_HIP(h, hipStreamSynchronize(st));  // the one host wait of the gather
-    const uint64_t max_total = pin64[0], max_stride = pin64[1];
+    const uint64_t max_total = pin64[0], max_stride = pin64[1], min_cap = ~pin64[2];
     // From here to the ncclGather nothing may return early on one rank only: the other ranks are about to enqueue
     // theirs.  What this rank has to complain about is remembered and reported once its own gather is in the stream.
     const char *late_error = nullptr;
-    if (reinterpret_cast<const int32_t *>(c->pin)[4] != 0) {
+    if (reinterpret_cast<const int32_t *>(c->pin)[6] != 0) {
         FCD_HIP(h, hipMemsetAsync(d_bad, 0, 4, st));
         late_error = "gather: a shard's header contradicted the read counts (earlier call)";
     }
@@ -281,15 +298,32 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
         late_error = "gather: the destination's out_stride is narrower than a shard's (out_stride must match across ranks)";
     const int pb = max_stride <= 65535 ? 2 : 4;  // time indices are < out_stride (csrc/pack.hip)
     const int64_t nbytes = fcd_packed_result_bytes(n_max, (int64_t)max_total, pb);
-    rc = need(c, c->send, (size_t)nbytes);
-    if (rc) return rc;
-    if (is_dst) {
-        rc = need(c, c->recv, (size_t)nbytes * (size_t)c->world);
-        if (rc) return rc;
+    if (min_cap < (uint64_t)nbytes) {
+        // Some rank's buffers have to grow (every rank knows: the capacities rode along in the reduction).  An
+        // allocation can fail on one rank only -- and that rank must not walk away while the others enqueue a gather
+        // it will never join.  So the ranks tell each other how it went before anybody enqueues anything: one more
+        // 8-byte all-reduce, on growth rounds only (the buffers keep a quarter of slack: a steady workload has none).
+        int grow_rc = injected_alloc_failure(c) ? comm_fail(c, FCD_E_NOMEM, "hipMalloc failed (gather buffers; injected)") : need(c, c->send, (size_t)nbytes);
+        if (!grow_rc && is_dst) grow_rc = need(c, c->recv, (size_t)nbytes * (size_t)c->world);
+        pin64[4] = grow_rc ? 1u : 0u;
+        FCD_HIP(h, hipMemcpyAsync(d_mine, pin64 + 4, 8, hipMemcpyHostToDevice, st));
+        if (c->comm) {
+            rc = nccl_check(c, rccl().AllReduce(d_mine, d_max, 1, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
+            if (rc) return rc;
+        } else {
+            FCD_HIP(h, hipMemcpyAsync(d_max, d_mine, 8, hipMemcpyDeviceToDevice, st));
+        }
+        FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 8, hipMemcpyDeviceToHost, st));
+        FCD_HIP(h, hipStreamSynchronize(st));
+        if (pin64[0] != 0)  // (the same verdict on every rank: nobody is left waiting in a collective)
+            return grow_rc ? grow_rc : comm_fail(c, FCD_E_NOMEM, "gather: another rank could not allocate its buffers");
     }
     ResultDesc wire{res->labels, res->path, nullptr, res->out_len, res->status, res->out_stride, nullptr};
-    if (n_reads > 0) FCD_HIP(h, launch_pack(wire, n_reads, pb, d_offs, reinterpret_cast<uint8_t *>(c->send.p), st));
-    else FCD_HIP(h, hipMemsetAsync(c->send.p, 0, 16, st));
+    {   // (a launch that fails here is reported AFTER this rank's gather is in the stream, like the header check)
+        const hipError_t pe = n_reads > 0 ? launch_pack(wire, n_reads, pb, d_offs, reinterpret_cast<uint8_t *>(c->send.p), st)
+                                          : hipMemsetAsync(c->send.p, 0, 16, st);
+        if (pe != hipSuccess && !late_error) late_error = "gather: packing this rank's shard failed";
+    }
     const uint8_t *gathered = reinterpret_cast<const uint8_t *>(c->send.p);
     if (c->comm) {
         rc = nccl_check(c, rccl().Gather(c->send.p, is_dst ? c->recv.p : nullptr, (size_t)nbytes, kNcclUint8, dst,
@@ -326,9 +360,9 @@ int fcd_comm_synchronize(fcd_comm *c) {
     int32_t bad = 0;
     if (hipStreamSynchronize(h->stream) != hipSuccess) rc = FCD_E_HIP;
     if (rc == FCD_OK && c->fixed.p) {
-        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 16, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
+        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 24, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
         if (bad) {
-            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 16, 0, 4);
+            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 24, 0, 4);
             rc = comm_fail(c, FCD_E_INVALID, "gather: the header of shard " + std::to_string(bad - 1) +
                                                  " contradicts the read counts / buffer size");
         }
