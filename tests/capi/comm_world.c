@@ -196,7 +196,11 @@ int main(int argc, char **argv) {
         if (pids[k] < 0) return 4;
         if (pids[k] == 0) {
             alarm(120); /* a rank left waiting in a collective dies here instead of hanging the suite */
-            _exit(run_rank(world, k, id, argv[2]));
+            {
+                const int rc = run_rank(world, k, id, argv[2]);
+                fflush(NULL);
+                _exit(rc);
+            }
         }
     }
     for (k = 0; k < world; ++k) {

@@ -41,6 +41,8 @@ def test_gather_between_processes(world_exe, world, scenario):
     r = subprocess.run([exe, str(world), scenario], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr)
     assert ("scenario %s at world size %d ok" % (scenario, world)) in r.stdout
+    if scenario in ("uneven", "wide", "mixed"):  # rank 0 really compared every gathered read with its own decode
+        assert ("comm_world: %d ranks" % world) in r.stdout and "gathered == decoded in one process" in r.stdout
 
 
 def test_world_one_needs_no_stub(world_exe):
