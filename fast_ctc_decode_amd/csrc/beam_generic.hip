@@ -83,7 +83,9 @@ __host__ __device__ inline size_t shared_region_words(int BC, int N) {
     return (w + 3) & ~(size_t)3;
 }
 
-__host__ __device__ inline size_t lds_words(int BC, int N) {
+// pdq: the tie order is FCD_TIE_PDQ178 and a step can hold more than 20 candidates -- only then the node-ordered list and
+// the quicksort's scratch exist (reserved unconditionally they cost the stable order a sixth of its largest beam)
+__host__ __device__ inline size_t lds_words(int BC, int N, bool pdq) {
     int NL = N - 1;
     size_t C = (size_t)BC * N;
     size_t w = 0;
@@ -97,7 +99,7 @@ __host__ __device__ inline size_t lds_words(int BC, int N) {
     w += 2;      // top + pad
     w += shared_region_words(BC, N) + 3;  // m_flag / hist / l_key, 16-byte aligned
     w += (size_t)list_cap(BC);            // l_c
-    w += 2 * C + 2 + (sizeof(pdq178::Scratch) + 3) / 4;  // pq_list (u64, 8-byte aligned) + pq_scr
+    if (pdq) w += 2 * C + 2 + (sizeof(pdq178::Scratch) + 3) / 4;  // pq_list (u64, 8-byte aligned) + pq_scr
     return w;
 }
 
@@ -580,14 +582,20 @@ __global__ __launch_bounds__(64) void beam_generic_kernel(GenericParams p) {
 
 }  // namespace
 
-size_t beam_generic_lds_bytes(int beam_size, int N) { return lds_words(beam_size, N) * 4 + 16; }
+bool beam_generic_replays_ties(int beam_size, int N, int tie_order) {
+    return tie_order == FCD_TIE_PDQ178 && (int64_t)beam_size * N > 20;
+}
+
+size_t beam_generic_lds_bytes(int beam_size, int N, int tie_order) {
+    return lds_words(beam_size, N, beam_generic_replays_ties(beam_size, N, tie_order)) * 4 + 16;
+}
 
 hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
                                const BeamArgs &a, const GenericArena &arena, const ResultDesc &out,
                                hipStream_t stream) {
     if (n_reads <= 0) return hipSuccess;
     GenericParams p{in, a, arena, out, read_begin};
-    const size_t lds = beam_generic_lds_bytes(a.beam_size, in.N);
+    const size_t lds = beam_generic_lds_bytes(a.beam_size, in.N, a.tie_order);
     hipLaunchKernelGGL(beam_generic_kernel, dim3((unsigned)n_reads), dim3(64), lds, stream, p);
     return hipGetLastError();
 }

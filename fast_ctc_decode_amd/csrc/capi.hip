@@ -213,8 +213,11 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         per_read = (size_t)cap_nodes * (4 + 4 + row_words * 4);
     } else {
         if (beam > (1 << 16)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 65536");
-        if (beam_generic_lds_bytes((int)beam, N) > 64 * 1024)
-            return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
+        if (beam_generic_lds_bytes((int)beam, N, args.tie_order) > 64 * 1024)
+            return fail(h, FCD_E_UNSUPPORTED, beam_generic_lds_bytes((int)beam, N, FCD_TIE_STABLE) > 64 * 1024
+                                                  ? "beam_size * alphabet too large for the LDS-resident kernel"
+                                                  : "beam_size * alphabet too large for the LDS-resident kernel under FCD_TIE_PDQ178 (the "
+                                                    "quicksort's list needs LDS too: it fits under FCD_TIE_STABLE)");
         cap_nodes = T * beam * NL + 8;
         if (cap_nodes >= (1ll << 30)) return fail(h, FCD_E_UNSUPPORTED, "tree arena above 2^30 nodes per read");
         per_read = (size_t)cap_nodes * (sizeof(int4) + (size_t)NL * 4);
@@ -717,7 +720,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     if (!envelope || env_stride < in1->T) return fail(h, FCD_E_INVALID, "envelope missing or shorter than read 1");
     if (beam_size > (1 << 12)) return fail(h, FCD_E_UNSUPPORTED, "beam_size above 4096");
     const int N = (int)in1->N, NL = N - 1;
-    if (duplex_lds_bytes((int)beam_size, N, 0, S) > 64 * 1024)
+    if (duplex_lds_bytes((int)beam_size, N, 0, S, effective_tie_order(h)) > 64 * 1024)
         return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
     FCD_DEVICE(h);
 
@@ -774,7 +777,7 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.cap_nodes = cap_nodes; a.Wcap = Wcap;
     // tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
     // (and keep the beam entries' windows resident there: one LDS buffer per beam slot, handed over by lane votes)
-    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S) <= 48 * 1024 && beam_size <= 64 ? 1 : 0;
+    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S, effective_tie_order(h)) <= 48 * 1024 && beam_size <= 64 ? 1 : 0;
     a.out = to_desc(out);
     a.prof = h->duplex_prof;
     a.tie_order = effective_tie_order(h);

@@ -239,21 +239,24 @@ struct DLds {
     float *bw;           // BC*(Wmax+2)*3: the beam entries' resident rings {label, gap, label(+)gap}, slot = row mod Wcap
 };
 
-__host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax, int S) {
+// pdq: FCD_TIE_PDQ178 with more than 20 candidates possible -- only then the quicksort's list and scratch exist
+__host__ __device__ inline size_t dlds_words(int BC, int N, int Wmax, int S, bool pdq) {
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
-    return 2 * (size_t)BC * (11 + NL) + 2 * C + 2 * C + (sizeof(pdq178::Scratch) + 3) / 4 + 5 * C + 3 * (size_t)BC + 4 + 64 +
+    return 2 * (size_t)BC * (11 + NL) + 2 * C + (pdq ? 2 * C + (sizeof(pdq178::Scratch) + 3) / 4 : 0) + 5 * C + 3 * (size_t)BC + 4 + 64 +
            (size_t)Wmax * S * N + (Wmax > 0 ? (size_t)BC * (Wmax + 2) * 3 : 0);
 }
 
-__device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S) {
+__device__ inline DLds dcarve(int *smem, int BC, int N, int Wmax, int S, bool pdq) {
     DLds L;
     const int NL = N - 1;
     const size_t C = (size_t)BC * N;
     L.c_key = reinterpret_cast<uint64_t *>(smem);
     int *p = smem + 2 * C;
-    L.pq_list = reinterpret_cast<uint64_t *>(p); p += 2 * C;
-    L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p); p += (sizeof(pdq178::Scratch) + 3) / 4;
+    L.pq_list = reinterpret_cast<uint64_t *>(p);
+    if (pdq) p += 2 * C;
+    L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p);
+    if (pdq) p += (sizeof(pdq178::Scratch) + 3) / 4;
     L.c_lp = reinterpret_cast<float *>(p); p += C;
     L.c_gp = reinterpret_cast<float *>(p); p += C;
     L.c_p2 = reinterpret_cast<float *>(p); p += C;
@@ -412,7 +415,7 @@ __global__ __launch_bounds__(64, PIN ? 2 : 3) void duplex_kernel(DuplexParams p)
     const float thr = p.thr_ln;
     const bool staged = p.staged != 0;
     const int Wmax = staged ? Wcap - 2 : 0;
-    DLds L = dcarve(smem, BC, N, Wmax, S);
+    DLds L = dcarve(smem, BC, N, Wmax, S, p.tie_order == FCD_TIE_PDQ178 && (int64_t)BC * N > 20);
 
     int64_t T1 = p.T1cap, T2 = p.T2cap;
     if (p.len1) { int64_t t = p.len1[r]; T1 = t < 0 ? 0 : (t < T1 ? t : T1); }
@@ -1644,8 +1647,8 @@ __global__ void env_width_kernel(const uint64_t *env, int64_t n_pairs, int64_t e
 
 }  // namespace
 
-size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S) {
-    return dlds_words(beam_size, N, Wmax, S) * 4 + 16;
+size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S, int tie_order) {
+    return dlds_words(beam_size, N, Wmax, S, tie_order == FCD_TIE_PDQ178 && (int64_t)beam_size * N > 20) * 4 + 16;
 }
 
 hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
@@ -1720,7 +1723,7 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     p.pair_begin = pair_begin;
     p.prof = a.prof;
     p.tie_order = a.tie_order;
-    const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S);
+    const size_t lds = duplex_lds_bytes(a.beam_size, a.N, a.staged ? a.Wcap - 2 : 0, a.S, a.tie_order);
     // up to two wavefronts per SIMD (2048 pairs on the 256 CUs): the coefficient-pinning instantiation
     const bool pin = a.staged && n_pairs <= 2048;
     if (a.mode == FCD_LOGADD_LOGSUMEXP_GLIBC235)

@@ -80,7 +80,7 @@ struct WaveArena {
     int retry_slots;
 };
 
-size_t beam_generic_lds_bytes(int beam_size, int N);
+size_t beam_generic_lds_bytes(int beam_size, int N, int tie_order);  // (the quicksort's list and scratch only under FCD_TIE_PDQ178 above 20 candidates)
 hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t n_reads,
                                const BeamArgs &a, const GenericArena &arena, const ResultDesc &out,
                                hipStream_t stream);
@@ -131,7 +131,7 @@ struct DuplexArgs {
     int tie_order;   // FCD_TIE_PDQ178 / FCD_TIE_STABLE
 };
 
-size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S);
+size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S, int tie_order);
 hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
                              int64_t s_t, int64_t s_s, int64_t s_n, float *out, int glibc235, hipStream_t stream);
 hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,

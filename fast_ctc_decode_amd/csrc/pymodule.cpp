@@ -574,8 +574,13 @@ void make_batch(BatchInput &in, const py::object &x, int ndim, const py::object 
                 }
                 auto *pa = py::detail::array_proxy(it);
                 const int tn = py::detail::array_descriptor_proxy(pa->descr)->type_num;
-                if (tn != py::detail::npy_api::NPY_FLOAT_ || pa->nd != 2 ||
-                    !(pa->flags & py::detail::npy_api::NPY_ARRAY_C_CONTIGUOUS_) || (N0 >= 0 && pa->dimensions[1] != N0)) {
+                // native byte order ('=' or '|'; a '>f4' array has the same type number and other bytes) and aligned
+                // data: anything else takes the converting path below.  The arrays are read by the lane threads with
+                // the GIL released: they must not be written to until the batch call returns (README).
+                const char bo = py::detail::array_descriptor_proxy(pa->descr)->byteorder;
+                if (tn != py::detail::npy_api::NPY_FLOAT_ || pa->nd != 2 || (bo != '=' && bo != '|') ||
+                    !(pa->flags & py::detail::npy_api::NPY_ARRAY_C_CONTIGUOUS_) ||
+                    !(pa->flags & py::detail::npy_api::NPY_ARRAY_ALIGNED_) || (N0 >= 0 && pa->dimensions[1] != N0)) {
                     ok = false;
                     break;
                 }

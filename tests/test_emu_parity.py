@@ -59,6 +59,10 @@ def test_lane_two_pass_retry(fcd):
     P.test_lane_two_pass_retry(fcd)
 
 
+def test_largest_beam_of_the_lds_kernel(fcd):
+    P.test_largest_beam_of_the_lds_kernel(fcd)
+
+
 def test_ambiguity_counter(fcd):
     P.test_ambiguity_counter(fcd)
 

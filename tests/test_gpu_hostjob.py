@@ -379,6 +379,10 @@ def test_list_of_ragged_reads_without_a_padded_copy(fcd, lanes, chunk):
                     assert p == want[1]
                 elif paths == "array":
                     assert p.tolist() == want[1]
+        # big-endian float32 has float32's type number and other bytes: it must not be read as native floats (ADVICE
+        # r4) -- it is not a float32 array in the reference's sense either (PyO3's &PyArray2<f32>): TypeError
+        with pytest.raises(TypeError):
+            cm.beam_search_batch([r.astype(">f4") for r in reads], "NACGT", 5, 0.1)
         nonempty = [r for r in reads if r.shape[0] > 0]
         assert cm.viterbi_search_batch(nonempty, "NACGT", qstring=True) == \
             [fcd.viterbi_search(np.ascontiguousarray(r), "NACGT", qstring=True) for r in nonempty]

@@ -50,6 +50,34 @@ def test_beam_generic_random(fcd, N, beam):
 KERNELS = [1, 2, 3]  # generic (LDS), wave (two reads per wavefront where possible), wave1
 
 
+def test_largest_beam_of_the_lds_kernel(fcd):
+    """README: beams up to ~295 at N = 5 on the LDS-resident kernel.  The quicksort's node-ordered list and scratch
+    (FCD_TIE_PDQ178, more than 20 candidates) need LDS of their own, so that order stops earlier (247) and says so;
+    the stable order keeps the whole 64 KiB (the space used to be reserved whatever the order)."""
+    from tie_util import tie_order
+    x = gen_batch(77, 2, 12, 5)
+
+    def largest(lo, hi):  # largest beam_size in [lo, hi) that is accepted
+        while hi - lo > 1:
+            mid = (lo + hi) // 2
+            try:
+                fcd.beam_search_batch_raw(x, mid, 0.0, True, kernel=fcd.KERNEL_GENERIC)
+                lo = mid
+            except RuntimeError as e:
+                assert "LDS" in str(e)
+                hi = mid
+        return lo
+
+    with tie_order(fcd, "stable"):
+        assert largest(64, 600) == 295
+        check_beam(fcd, x, 295, 0.0, kernel=fcd.KERNEL_GENERIC)
+    with tie_order(fcd, "pdq178"):
+        assert largest(64, 600) == 247
+        check_beam(fcd, x, 247, 0.0, kernel=fcd.KERNEL_GENERIC)
+        with pytest.raises(RuntimeError, match="FCD_TIE_STABLE"):
+            fcd.beam_search_batch_raw(x, 280, 0.0, True, kernel=fcd.KERNEL_GENERIC)
+
+
 @pytest.mark.parametrize("kernel", [2, 3])
 @pytest.mark.parametrize("N", [3, 4, 5, 6, 7])
 @pytest.mark.parametrize("beam", [1, 2, 5, 8])
