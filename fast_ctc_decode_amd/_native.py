@@ -38,6 +38,7 @@ SYMBOLS = [
     "fcd_packed_result_bytes", "fcd_result_offsets_dev", "fcd_pack_results_dev", "fcd_unpack_results_dev",
     "fcd_coalescer_create", "fcd_coalescer_destroy", "fcd_coalescer_beam_search", "fcd_coalescer_viterbi_search",
     "fcd_coalescer_crf_beam_search", "fcd_coalescer_crf_greedy_search",
+    "fcd_coalescer_beam_search_duplex", "fcd_coalescer_crf_beam_search_duplex",
     "fcd_coalescer_stats", "fcd_coalescer_last_error",
     "fcd_comm_unique_id", "fcd_comm_create", "fcd_comm_wrap", "fcd_comm_destroy", "fcd_gather_results_dev",
     "fcd_comm_synchronize", "fcd_unpack_gathered_dev",
@@ -168,6 +169,8 @@ def bind(lib):
     lib.fcd_coalescer_viterbi_search.argtypes = [P, BP, i32, RP]
     lib.fcd_coalescer_crf_beam_search.argtypes = [P, BP, P, i64, i64, f32, RP]
     lib.fcd_coalescer_crf_greedy_search.argtypes = [P, BP, P, i64, RP]
+    lib.fcd_coalescer_beam_search_duplex.argtypes = [P, BP, BP, P, i64, f32, i32, i32, RP]
+    lib.fcd_coalescer_crf_beam_search_duplex.argtypes = [P, BP, P, i64, BP, P, i64, P, i64, f32, i32, RP]
     lib.fcd_coalescer_stats.argtypes = [P, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)]
     lib.fcd_coalescer_last_error.restype = C.c_char_p
     PP = C.POINTER(P)

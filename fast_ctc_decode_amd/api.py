@@ -491,9 +491,22 @@ def beam_search_duplex(network_output_1, network_output_2, alphabet, envelope=No
     _check_envelope(envelope, x1.shape[0])
     if x1.shape[0] == 0:
         raise RuntimeError("network_output_1 is empty (the reference indexes envelope[(0,1)] and aborts)")
-    env = None if envelope is None else np.ascontiguousarray(envelope)[None]
-    r = beam_search_duplex_batch_raw(_dense(x1)[None], _dense(x2)[None], env, beam_size,
-                                     beam_cut_threshold, collapse_repeats, logadd_mode=logadd_mode)
+    co = _coalescer
+    if co is not None:  # concurrent per-pair calls share a launch (set_coalescing; csrc/coalesce.hip)
+        mode = _DEFAULT_LOGADD[0] if logadd_mode is None else _MODE_CODES[logadd_mode]
+        x1, x2 = _dense(x1), _dense(x2)
+        env = (_default_envelope(1, x1.shape[0], x2.shape[0])[0] if envelope is None
+               else np.ascontiguousarray(envelope, np.uint64))
+        r = _HostOut(1, x1.shape[0], want_path=False)
+        b1, b2 = _host_batch(x1[None], False), _host_batch(x2[None], False)
+        with co:
+            co.check(co.lib.fcd_coalescer_beam_search_duplex(
+                co.ptr, C.byref(b1), C.byref(b2), env.ctypes.data, int(beam_size), float(beam_cut_threshold),
+                int(bool(collapse_repeats)), int(mode), C.byref(r.res)))
+    else:
+        env = None if envelope is None else np.ascontiguousarray(envelope)[None]
+        r = beam_search_duplex_batch_raw(_dense(x1)[None], _dense(x2)[None], env, beam_size,
+                                         beam_cut_threshold, collapse_repeats, logadd_mode=logadd_mode)
     _raise_status(int(r.status[0]))
     n = int(r.out_len[0])
     return "".join(alpha[l] for l in r.labels[0, :n])
@@ -693,10 +706,23 @@ def crf_beam_search_duplex(network_output_1, init_state_1, network_output_2, ini
         raise RuntimeError("state axes of the network outputs do not match (the reference asserts and aborts)")
     if x1.shape[0] == 0 or i1.size == 0 or i2.size == 0:
         raise RuntimeError("empty network_output_1 / init_state (the reference aborts here)")
-    env = None if envelope is None else np.ascontiguousarray(envelope)[None]
-    r = crf_beam_search_duplex_batch_raw(_dense(x1)[None], np.ascontiguousarray(i1)[None],
-                                         _dense(x2)[None], np.ascontiguousarray(i2)[None], env,
-                                         beam_size, beam_cut_threshold, logadd_mode=logadd_mode)
+    co = _coalescer
+    if co is not None:
+        mode = _DEFAULT_LOGADD[0] if logadd_mode is None else _MODE_CODES[logadd_mode]
+        x1, x2, i1, i2 = _dense(x1), _dense(x2), np.ascontiguousarray(i1), np.ascontiguousarray(i2)
+        env = (_default_envelope(1, x1.shape[0], x2.shape[0])[0] if envelope is None
+               else np.ascontiguousarray(envelope, np.uint64))
+        r = _HostOut(1, x1.shape[0], want_path=False)
+        b1, b2 = _host_batch(x1[None], True), _host_batch(x2[None], True)
+        with co:
+            co.check(co.lib.fcd_coalescer_crf_beam_search_duplex(
+                co.ptr, C.byref(b1), i1.ctypes.data, i1.shape[0], C.byref(b2), i2.ctypes.data, i2.shape[0],
+                env.ctypes.data, int(beam_size), float(beam_cut_threshold), int(mode), C.byref(r.res)))
+    else:
+        env = None if envelope is None else np.ascontiguousarray(envelope)[None]
+        r = crf_beam_search_duplex_batch_raw(_dense(x1)[None], np.ascontiguousarray(i1)[None],
+                                             _dense(x2)[None], np.ascontiguousarray(i2)[None], env,
+                                             beam_size, beam_cut_threshold, logadd_mode=logadd_mode)
     _raise_status(int(r.status[0]))
     n = int(r.out_len[0])
     # src/duplex.rs:825-833: labels appended leaf -> root, then the CHARACTERS reversed

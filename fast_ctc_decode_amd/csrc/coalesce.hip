@@ -8,7 +8,7 @@
 //
 // A coalescer turns concurrent calls into batches without changing the callers: the first thread to arrive
 // becomes the LEADER, takes every compatible request that is pending (same search, alphabet size, beam size,
-// threshold, collapse flag), decodes them with ONE batched launch (ragged lengths) on the coalescer's own
+// threshold, collapse flag; the pair searches of src/duplex.rs too: one PAIR per call, same log-add flavour), decodes them with ONE batched launch (ragged lengths) on the coalescer's own
 // handle and hands each caller its own result; the callers that arrive while a launch is in flight form the
 // next batch.  A launch takes about as long for one read as for a thousand (a read is one wavefront), so the
 // policy is "batch first": a leader takes everything that is pending, and before launching it waits briefly
@@ -35,7 +35,7 @@
 
 namespace {
 
-enum Kind { kBeam = 0, kViterbi = 1, kCrfBeam = 2, kCrfGreedy = 3 };
+enum Kind { kBeam = 0, kViterbi = 1, kCrfBeam = 2, kCrfGreedy = 3, kDuplex = 4, kCrfDuplex = 5 };
 
 struct Req {
     int kind;
@@ -46,6 +46,13 @@ struct Req {
     const fcd_result *out;
     const float *init = nullptr;  // CRF searches: the read's init_state (n_init entries, contiguous)
     int64_t n_init = 0;
+    // the pair searches (duplex::beam_search, duplex::crf_beam_search): the second read, its init_state, the pair's
+    // envelope (in->T rows of {lo, hi}), the LogSpace::add flavour
+    const fcd_batch *in2 = nullptr;
+    const float *init2 = nullptr;
+    int64_t n_init2 = 0;
+    const uint64_t *env = nullptr;
+    int mode = 0;
     int rc = FCD_OK;
     bool done = false;
     std::string err;
@@ -54,7 +61,8 @@ struct Req {
 
 bool compatible(const Req &a, const Req &b) {
     return a.kind == b.kind && a.in->N == b.in->N && a.in->S == b.in->S && a.n_init == b.n_init && a.beam == b.beam &&
-           a.collapse == b.collapse && std::memcmp(&a.thr, &b.thr, sizeof(float)) == 0;
+           a.collapse == b.collapse && std::memcmp(&a.thr, &b.thr, sizeof(float)) == 0 && a.n_init2 == b.n_init2 &&
+           a.mode == b.mode;
 }
 
 thread_local std::string t_error;
@@ -89,6 +97,7 @@ struct Lane {
     fcd_handle *h = nullptr;
     bool busy = false;
     Pinned x, qual, labels, path, out_len, status, lengths, init;
+    Pinned x2, lengths2, init2, env;  // the pair searches' second read and envelopes
 };
 
 }  // namespace
@@ -124,7 +133,110 @@ void run_batch(Lane &L, std::vector<Req *> &batch) {
     }
 }
 
+// one read into its padded slot: dense rows are one copy, anything else goes element by element
+void stage_read(const fcd_batch *b, bool crf, int64_t S, int64_t N, float *dst) {
+    const int64_t row = S * N;
+    const float *src = static_cast<const float *>(b->post);  // (the coalescer takes float32 reads only)
+    const bool dense = b->stride_n == 1 && (crf ? (b->stride_s == N && b->stride_t == row) : b->stride_t == N);
+    if (dense) {
+        std::memcpy(dst, src, (size_t)(b->T * row) * sizeof(float));
+        return;
+    }
+    for (int64_t t = 0; t < b->T; ++t)
+        for (int64_t sidx = 0; sidx < S; ++sidx)
+            for (int64_t j = 0; j < N; ++j)
+                dst[(t * S + sidx) * N + j] = src[t * b->stride_t + (crf ? sidx * b->stride_s : 0) + j * b->stride_n];
+}
+
+// the pair searches: every request is one pair (two reads, an envelope of in->T rows); the batch is the ragged batch
+// fcd_beam_search_duplex_host / fcd_crf_beam_search_duplex_host take
+void run_pair_batch_once(Lane &L, std::vector<Req *> &batch) {
+    const int64_t n = (int64_t)batch.size();
+    const Req &first = *batch[0];
+    const int64_t N = first.in->N;
+    const bool crf = first.kind == kCrfDuplex;
+    const int64_t S = crf ? first.in->S : 1, row = S * N;
+    int64_t T1 = 1, T2 = 1;
+    for (Req *r : batch) {
+        T1 = std::max<int64_t>(T1, r->in->T);
+        T2 = std::max<int64_t>(T2, r->in2->T);
+    }
+    float *x1 = static_cast<float *>(L.x.need((size_t)(n * T1 * row) * sizeof(float)));
+    float *x2 = static_cast<float *>(L.x2.need((size_t)(n * T2 * row) * sizeof(float)));
+    uint64_t *env = static_cast<uint64_t *>(L.env.need((size_t)(n * T1 * 2) * sizeof(uint64_t)));
+    uint8_t *labels = static_cast<uint8_t *>(L.labels.need((size_t)(n * T1)));
+    uint32_t *out_len = static_cast<uint32_t *>(L.out_len.need((size_t)n * sizeof(uint32_t)));
+    int32_t *status = static_cast<int32_t *>(L.status.need((size_t)n * sizeof(int32_t)));
+    int64_t *len1 = static_cast<int64_t *>(L.lengths.need((size_t)n * sizeof(int64_t)));
+    int64_t *len2 = static_cast<int64_t *>(L.lengths2.need((size_t)n * sizeof(int64_t)));
+    float *init1 = crf ? static_cast<float *>(L.init.need((size_t)(n * first.n_init) * sizeof(float))) : nullptr;
+    float *init2 = crf ? static_cast<float *>(L.init2.need((size_t)(n * first.n_init2) * sizeof(float))) : nullptr;
+    int rc = FCD_OK;
+    std::string err;
+    if (!x1 || !x2 || !env || !labels || !out_len || !status || !len1 || !len2 || (crf && (!init1 || !init2))) {
+        rc = FCD_E_NOMEM;
+        err = "coalescer: cannot allocate pinned staging memory";
+    }
+    if (rc == FCD_OK) {
+        std::memset(env, 0, (size_t)(n * T1 * 2) * sizeof(uint64_t));
+        for (int64_t i = 0; i < n; ++i) {
+            const Req *r = batch[i];
+            stage_read(r->in, crf, S, N, x1 + i * T1 * row);
+            stage_read(r->in2, crf, S, N, x2 + i * T2 * row);
+            len1[i] = r->in->T;
+            len2[i] = r->in2->T;
+            std::memcpy(env + i * T1 * 2, r->env, (size_t)(r->in->T * 2) * sizeof(uint64_t));
+            if (crf) {
+                std::memcpy(init1 + i * first.n_init, r->init, (size_t)first.n_init * sizeof(float));
+                std::memcpy(init2 + i * first.n_init2, r->init2, (size_t)first.n_init2 * sizeof(float));
+            }
+        }
+        fcd_batch a{}, b{};
+        a.post = x1;
+        a.n_reads = n;
+        a.T = T1;
+        a.S = S;
+        a.N = N;
+        a.stride_read = T1 * row;
+        a.stride_t = row;
+        a.stride_s = crf ? N : 0;
+        a.stride_n = 1;
+        a.lengths = len1;
+        b = a;
+        b.post = x2;
+        b.T = T2;
+        b.stride_read = T2 * row;
+        b.lengths = len2;
+        fcd_result out{};
+        out.labels = labels;
+        out.out_len = out_len;
+        out.status = status;
+        out.out_stride = T1;
+        if (crf)
+            rc = fcd_crf_beam_search_duplex_host(L.h, &a, init1, first.n_init, first.n_init, &b, init2, first.n_init2,
+                                                 first.n_init2, env, T1, first.beam, first.thr, first.mode, &out);
+        else
+            rc = fcd_beam_search_duplex_host(L.h, &a, &b, env, T1, first.beam, first.thr, first.collapse, first.mode, &out);
+        if (rc != FCD_OK) err = fcd_last_error(L.h);
+    }
+    for (int64_t i = 0; i < n; ++i) {
+        Req *r = batch[i];
+        r->rc = rc;
+        r->err = err;
+        if (rc != FCD_OK) continue;
+        const fcd_result *o = r->out;
+        const size_t len = std::min<size_t>(out_len[i], (size_t)std::max<int64_t>(o->out_stride, 0));
+        if (o->out_len) *o->out_len = out_len[i];
+        *o->status = status[i];
+        std::memcpy(o->labels, labels + i * T1, len);
+    }
+}
+
 void run_batch_once(Lane &L, std::vector<Req *> &batch) {
+    if (batch[0]->kind == kDuplex || batch[0]->kind == kCrfDuplex) {
+        run_pair_batch_once(L, batch);
+        return;
+    }
     const int64_t n = (int64_t)batch.size();
     const Req &first = *batch[0];
     const int64_t N = first.in->N;
@@ -154,18 +266,8 @@ void run_batch_once(Lane &L, std::vector<Req *> &batch) {
     if (rc == FCD_OK) {
         for (int64_t i = 0; i < n; ++i) {
             const fcd_batch *b = batch[i]->in;
-            float *dst = x + i * Tmax * row;
-            const float *src = static_cast<const float *>(b->post);  // (the coalescer takes float32 reads only)
             lengths[i] = b->T;
-            const bool dense = b->stride_n == 1 && (crf ? (b->stride_s == N && b->stride_t == row) : b->stride_t == N);
-            if (dense) {
-                std::memcpy(dst, src, (size_t)(b->T * row) * sizeof(float));
-            } else {
-                for (int64_t t = 0; t < b->T; ++t)
-                    for (int64_t sidx = 0; sidx < S; ++sidx)
-                        for (int64_t j = 0; j < N; ++j)
-                            dst[(t * S + sidx) * N + j] = src[t * b->stride_t + (crf ? sidx * b->stride_s : 0) + j * b->stride_n];
-            }
+            stage_read(b, crf, S, N, x + i * Tmax * row);
             if (crf) std::memcpy(init + i * n_init, batch[i]->init, (size_t)n_init * sizeof(float));
         }
         fcd_batch in{};
@@ -216,7 +318,24 @@ int submit(fcd_coalescer *c, Req &req) {
         t_error = "coalescer: null argument";
         return FCD_E_INVALID;
     }
-    const bool crf = req.kind == kCrfBeam || req.kind == kCrfGreedy;
+    const bool pair = req.kind == kDuplex || req.kind == kCrfDuplex;
+    const bool crf = req.kind == kCrfBeam || req.kind == kCrfGreedy || req.kind == kCrfDuplex;
+    if (pair) {
+        const fcd_batch *b = req.in2;
+        if (!b || !b->post || !req.env || (crf && (!req.init2 || req.n_init2 < 1))) {
+            t_error = "coalescer: a pair search needs both reads and the pair's envelope (CRF: both init_states)";
+            return FCD_E_INVALID;
+        }
+        if (b->dtype != FCD_DTYPE_F32) {
+            t_error = "coalescer: float32 reads only (the per-read surface is the reference's, which takes float32)";
+            return FCD_E_UNSUPPORTED;
+        }
+        if (b->n_reads != 1 || b->T < 0 || b->N != req.in->N || b->stride_t < 0 || b->stride_n < 0 || b->lengths ||
+            (crf ? (b->S != req.in->S || b->stride_s < 0) : b->S > 1)) {
+            t_error = "coalescer: the second read must be one matrix of the first read's inner shape, with non-negative strides";
+            return FCD_E_INVALID;
+        }
+    }
     if (req.kind != kViterbi && !req.out->status) {  // a per-read FCD_ST_* outcome must have somewhere to go
         t_error = "coalescer: the beam and CRF searches need out->status";
         return FCD_E_INVALID;
@@ -362,6 +481,31 @@ int fcd_coalescer_crf_greedy_search(fcd_coalescer *c, const fcd_batch *read, con
     Req r{kCrfGreedy, read, 0, 0.0f, 0, out};
     r.init = init;
     r.n_init = n_init;
+    return submit(c, r);
+}
+
+int fcd_coalescer_beam_search_duplex(fcd_coalescer *c, const fcd_batch *read1, const fcd_batch *read2,
+                                     const uint64_t *envelope, int64_t beam_size, float beam_cut_threshold,
+                                     int collapse_repeats, int logadd_mode, const fcd_result *out) {
+    Req r{kDuplex, read1, beam_size, beam_cut_threshold, collapse_repeats ? 1 : 0, out};
+    r.in2 = read2;
+    r.env = envelope;
+    r.mode = logadd_mode;
+    return submit(c, r);
+}
+
+int fcd_coalescer_crf_beam_search_duplex(fcd_coalescer *c, const fcd_batch *read1, const float *init1, int64_t n_init1,
+                                         const fcd_batch *read2, const float *init2, int64_t n_init2,
+                                         const uint64_t *envelope, int64_t beam_size, float beam_cut_threshold,
+                                         int logadd_mode, const fcd_result *out) {
+    Req r{kCrfDuplex, read1, beam_size, beam_cut_threshold, 0, out};
+    r.init = init1;
+    r.n_init = n_init1;
+    r.in2 = read2;
+    r.init2 = init2;
+    r.n_init2 = n_init2;
+    r.env = envelope;
+    r.mode = logadd_mode;
     return submit(c, r);
 }
 

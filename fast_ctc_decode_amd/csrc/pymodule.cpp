@@ -49,7 +49,8 @@ fcd_handle *thread_handle() {
     return th.h;
 }
 
-// set_coalescing(): when set, per-read viterbi_search / beam_search / crf_beam_search / crf_greedy_search calls of
+// set_coalescing(): when set, per-read viterbi_search / beam_search / crf_beam_search / crf_greedy_search calls (and
+// the per-PAIR beam_search_duplex / crf_beam_search_duplex calls) of
 // every thread go through it
 // (include/fcd.h: concurrent calls share batched launches).  Every call holds a reference to the coalescer that
 // was current when it started; a replaced coalescer is destroyed when its LAST call returns -- nobody waits for
@@ -409,13 +410,23 @@ py::str beam_search_duplex(const py::object &network_output_1, const py::object 
     Out o(T1, false, false);
     fcd_batch b1 = batch2(x1), b2 = batch2(x2);
     int rc;
-    fcd_handle *h = thread_handle();
-    {
-        py::gil_scoped_release nogil;
-        rc = fcd_beam_search_duplex_host(h, &b1, &b2, env, T1, (int64_t)beam_size, beam_cut_threshold,
-                                         collapse_repeats ? 1 : 0, g_logadd_mode, &o.res);
+    CoalescerUse use;
+    if (fcd_coalescer *co = use.co) {  // concurrent per-pair calls share a launch (set_coalescing)
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_coalescer_beam_search_duplex(co, &b1, &b2, env, (int64_t)beam_size, beam_cut_threshold,
+                                                  collapse_repeats ? 1 : 0, g_logadd_mode, &o.res);
+        }
+        check_rc_coalescer(rc);
+    } else {
+        fcd_handle *h = thread_handle();
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_beam_search_duplex_host(h, &b1, &b2, env, T1, (int64_t)beam_size, beam_cut_threshold,
+                                             collapse_repeats ? 1 : 0, g_logadd_mode, &o.res);
+        }
+        check_rc(h, rc);
     }
-    check_rc(h, rc);
     raise_status(o.status);
     std::string seq;
     for (uint32_t i = 0; i < o.len; ++i) seq += alpha[o.labels[i]];
@@ -468,15 +479,26 @@ py::str crf_beam_search_duplex(const py::object &network_output_1, const py::obj
     Out o(T1, false, false);
     fcd_batch b1 = batch3(x1), b2 = batch3(x2);
     int rc;
-    fcd_handle *h = thread_handle();
-    {
-        py::gil_scoped_release nogil;
-        rc = fcd_crf_beam_search_duplex_host(h, &b1, static_cast<const float *>(i1.data()), i1.shape(0),
-                                             i1.shape(0), &b2, static_cast<const float *>(i2.data()),
-                                             i2.shape(0), i2.shape(0), env, T1, (int64_t)beam_size,
-                                             beam_cut_threshold, g_logadd_mode, &o.res);
+    CoalescerUse use;
+    if (fcd_coalescer *co = use.co) {
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_coalescer_crf_beam_search_duplex(co, &b1, static_cast<const float *>(i1.data()), i1.shape(0), &b2,
+                                                      static_cast<const float *>(i2.data()), i2.shape(0), env,
+                                                      (int64_t)beam_size, beam_cut_threshold, g_logadd_mode, &o.res);
+        }
+        check_rc_coalescer(rc);
+    } else {
+        fcd_handle *h = thread_handle();
+        {
+            py::gil_scoped_release nogil;
+            rc = fcd_crf_beam_search_duplex_host(h, &b1, static_cast<const float *>(i1.data()), i1.shape(0),
+                                                 i1.shape(0), &b2, static_cast<const float *>(i2.data()),
+                                                 i2.shape(0), i2.shape(0), env, T1, (int64_t)beam_size,
+                                                 beam_cut_threshold, g_logadd_mode, &o.res);
+        }
+        check_rc(h, rc);
     }
-    check_rc(h, rc);
     raise_status(o.status);
     std::string rev;  // duplex.rs:825-833: appended leaf -> root, characters reversed
     for (uint32_t i = o.len; i > 0; --i) rev += alpha[o.labels[i - 1]];

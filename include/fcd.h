@@ -427,6 +427,18 @@ int fcd_coalescer_crf_beam_search(fcd_coalescer *c, const fcd_batch *read, const
                                   int64_t beam_size, float beam_cut_threshold, const fcd_result *out);
 int fcd_coalescer_crf_greedy_search(fcd_coalescer *c, const fcd_batch *read, const float *init, int64_t n_init,
                                     const fcd_result *out);
+/* r05: the pair searches (src/duplex.rs:443-650, :652-834; the reference's beam_search_duplex /
+ * crf_beam_search_duplex, src/lib.rs:401-578, decode ONE pair per call with the GIL released): read1 / read2 as above,
+ * `envelope` = read1->T rows of {lo, hi} (u64), logadd_mode = FCD_LOGADD_*.  A lone pair is one wavefront walking a
+ * 2000-step chain: per-pair callers get the latency of a whole batch per call -- through this door concurrent calls
+ * with the same N (S, init sizes), beam, threshold, collapse flag and log-add flavour share ONE launch. */
+int fcd_coalescer_beam_search_duplex(fcd_coalescer *c, const fcd_batch *read1, const fcd_batch *read2,
+                                     const uint64_t *envelope, int64_t beam_size, float beam_cut_threshold,
+                                     int collapse_repeats, int logadd_mode, const fcd_result *out);
+int fcd_coalescer_crf_beam_search_duplex(fcd_coalescer *c, const fcd_batch *read1, const float *init1, int64_t n_init1,
+                                         const fcd_batch *read2, const float *init2, int64_t n_init2,
+                                         const uint64_t *envelope, int64_t beam_size, float beam_cut_threshold,
+                                         int logadd_mode, const fcd_result *out);
 int fcd_coalescer_stats(fcd_coalescer *c, int64_t *n_calls, int64_t *n_launches, int64_t *largest_batch);
 const char *fcd_coalescer_last_error(void);
 

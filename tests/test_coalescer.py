@@ -138,6 +138,83 @@ def _check_crf(mod, reads, n_threads, max_wait_us):
     return stats
 
 
+def _pairs(n, seed):
+    """pairs of reads with a banded envelope each (ragged lengths; a few with the default envelope), and CRF pairs"""
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        T1, T2 = int(rng.integers(8, 60)), int(rng.integers(8, 60))
+        x1 = reference_style_rows(rng, T1, 5).reshape(T1, 5)
+        x2 = reference_style_rows(rng, T2, 5).reshape(T2, 5)
+        if i % 4 == 1:
+            x2 = np.asfortranarray(x2)
+        if i % 3 == 0:
+            env = None
+        else:
+            c = np.arange(T1) * T2 // T1
+            lo = np.maximum(c - 6, 0)
+            hi = np.minimum(c + 7, T2)
+            lo[0], hi[-1] = 0, T2
+            env = np.stack([lo, hi], 1).astype(np.uint64)
+        out.append((x1, x2, env))
+    return out
+
+
+def _crf_pairs(n, seed):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        T1, T2, S = int(rng.integers(6, 40)), int(rng.integers(6, 40)), 4
+        out.append((rng.random((T1, S, 5), dtype=np.float32), rng.random(S, dtype=np.float32),
+                    rng.random((T2, S, 5), dtype=np.float32), rng.random(S, dtype=np.float32)))
+    return out
+
+
+def _check_pairs(mod, pairs, crf_pairs, n_threads, max_wait_us):
+    """beam_search_duplex / crf_beam_search_duplex through the coalescer == the same calls without it"""
+    def call(i):
+        if i < len(pairs):
+            x1, x2, env = pairs[i]
+            beam, thr = [(5, 0.1), (3, 0.0)][i % 2]
+            try:
+                return mod.beam_search_duplex(x1, x2, ALPHA, env, beam, thr)
+            except RuntimeError as e:
+                return ("error", str(e))
+        x1, i1, x2, i2 = crf_pairs[i - len(pairs)]
+        try:
+            return mod.crf_beam_search_duplex(x1, i1, x2, i2, ALPHA, None, 5, 0.0)
+        except RuntimeError as e:
+            return ("error", str(e))
+
+    n = len(pairs) + len(crf_pairs)
+    want = [call(i) for i in range(n)]
+    assert sum(isinstance(w, str) and len(w) > 0 for w in want) > n // 2  # real sequences, not a wall of errors
+    got, errors = {}, []
+
+    def work(tid):
+        try:
+            for i in range(tid, n, n_threads):
+                got[i] = call(i)
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    mod.set_coalescing(16, max_wait_us)
+    try:
+        threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        stats = mod.coalescing_stats()
+    finally:
+        mod.set_coalescing(0)
+    assert not errors, errors
+    for i in range(n):
+        assert got[i] == want[i], i
+    assert stats["calls"] == n
+    return stats
+
+
 def test_coalescer_emulated():
     import fast_ctc_decode_amd as fcd
     from emu_util import emulated_kernels
@@ -147,6 +224,17 @@ def test_coalescer_emulated():
     # six threads start together and the leader waits 20 ms for company: launches are shared
     assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
     assert crf_stats["launches"] < crf_stats["calls"], crf_stats
+
+
+def test_coalescer_pair_searches_emulated():
+    """r05: the per-PAIR searches (src/lib.rs:401-578) through the same door, both host layers"""
+    import fast_ctc_decode_amd as fcd
+    from emu_util import emu_compiled_module, emulated_kernels
+    with emulated_kernels():
+        stats = _check_pairs(fcd, _pairs(10, 11), _crf_pairs(4, 12), 5, 20000)
+        assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
+        stats = _check_pairs(emu_compiled_module(), _pairs(8, 13), _crf_pairs(4, 14), 4, 20000)
+        assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
 
 
 @pytest.mark.gpu
@@ -162,6 +250,8 @@ def test_coalescer_gpu(layer):
     stats = _check(mod, reads, 16, 2000)
     assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
     stats = _check_crf(mod, _crf_reads(60, 8), 12, 2000)
+    assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
+    stats = _check_pairs(mod, _pairs(40, 9), _crf_pairs(12, 10), 12, 2000)
     assert stats["launches"] < stats["calls"] and stats["largest_batch"] >= 2, stats
 
 
