@@ -142,8 +142,8 @@ def cpu_baseline(cfg, x_host, init_host, gpu_labels, gpu_path, gpu_len, budget_s
 
 
 KERNEL_SOURCES = {  # the files a kernel's instruction stream and memory traffic depend on
-    "beam_wave_kernel": ("beam_wave.hip", "beam_wave_step.inc", "pdq178.h", "pdq178_wave.h", "device_utils.h"),
-    "beam_lane_kernel": ("beam_lane.hip", "pdq178.h", "pdq178_wave.h", "device_utils.h"),
+    "beam_wave_kernel": ("beam_wave.hip", "beam_wave_step.inc", "pdq178.h", "pdq178_wave.h", "pdq178_reg.h", "device_utils.h"),
+    "beam_lane_kernel": ("beam_lane.hip", "pdq178.h", "pdq178_wave.h", "pdq178_reg.h", "device_utils.h"),
     "beam_generic_kernel": ("beam_generic.hip", "pdq178.h", "device_utils.h"),
     "viterbi": ("viterbi.hip", "device_utils.h"),
     "crf_greedy": ("viterbi.hip", "device_utils.h"),
@@ -169,6 +169,55 @@ def kernel_source_digest(kernel_prefix=None):
         with open(os.path.join(csrc, name), "rb") as f:
             out[name] = hashlib.md5(f.read()).hexdigest()
     return out
+
+
+def kernel_occupancy(mangled_substring):
+    """What the dispatched instantiation reserves, read off the gfx950 code object inside libfcd_hip.so (so that an
+    occupancy regression shows in the driver's own bench line): VGPRs, scratch and LDS bytes per
+    wavefront / workgroup, and the wavefronts per SIMD they allow (512 VGPRs per SIMD lane in granules of 8, at most 8
+    wavefronts; 160 KiB of LDS per CU over 4 SIMDs).  None when the LLVM tools are missing -- never an exception."""
+    import re
+    import shutil
+    import subprocess
+    import tempfile
+    try:
+        from fast_ctc_decode_amd import _native as nat
+        llvm = "/opt/rocm/lib/llvm/bin"
+        tmp = tempfile.mkdtemp(prefix="fcd_occ_")
+        try:
+            subprocess.check_call(["objcopy", "-O", "binary", "--only-section=.hip_fatbin", nat.LIB_PATH, tmp + "/fat.bin"],
+                                  stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            # the section holds one offload bundle per translation unit, back to back
+            blob = open(tmp + "/fat.bin", "rb").read()
+            magic = b"__CLANG_OFFLOAD_BUNDLE__"
+            starts = [m.start() for m in re.finditer(re.escape(magic), blob)] + [len(blob)]
+            notes = ""
+            for i in range(len(starts) - 1):
+                with open(tmp + "/one.bin", "wb") as f:
+                    f.write(blob[starts[i]:starts[i + 1]])
+                rc = subprocess.call([llvm + "/clang-offload-bundler", "--type=o", "--targets=hipv4-amdgcn-amd-amdhsa--gfx950",
+                                      "--input=" + tmp + "/one.bin", "--output=" + tmp + "/dev.co", "--unbundle"],
+                                     stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                if rc == 0 and mangled_substring.split("ILi")[0].encode() in blob[starts[i]:starts[i + 1]]:
+                    notes += subprocess.check_output([llvm + "/llvm-readelf", "--notes", tmp + "/dev.co"],
+                                                     stderr=subprocess.DEVNULL).decode()
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+        for blk in re.split(r"\n\s*- \.agpr_count", notes)[1:]:
+            name = re.search(r"\.name:\s+(\S+)", blk)
+            if not name or mangled_substring not in name.group(1):
+                continue
+            g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
+            vgpr, lds, scratch, wg = g("vgpr_count"), g("group_segment_fixed_size"), g("private_segment_fixed_size"), g("max_flat_workgroup_size")
+            by_vgpr = min(8, 512 // max(8, (vgpr + 7) // 8 * 8))
+            waves_per_wg = max(1, wg // 64)
+            by_lds = (160 * 1024 // lds) * waves_per_wg // 4 if lds else 8
+            return {"kernel_symbol": name.group(1)[:96], "vgpr": vgpr, "scratch_bytes": scratch, "lds_bytes_per_workgroup": lds,
+                    "wavefronts_per_workgroup": waves_per_wg, "wavefronts_per_simd_by_vgpr": by_vgpr,
+                    "wavefronts_per_simd_by_lds": min(8, by_lds), "wavefronts_per_simd": min(by_vgpr, 8, by_lds)}
+    except Exception:  # noqa: BLE001  (nothing in the timed script may fail for want of a tool)
+        return None
+    return None
 
 
 def digest_matches(recorded, kernel_prefix):
@@ -639,6 +688,12 @@ def main():
                 other_order = {"error": str(e)}
             finally:
                 fcd.set_tie_order(mine_order)
+        pdq = "1" if fcd.tie_order() == "pdq178" else "0"
+        uni = "1"  # (bench batches have one length: the UNI instantiation)
+        symbol = {2: "beam_wave_kernelILi5ELi6ELi2ELi0ELb0ELb0ELb%sELb0ELb%sE" % (uni, pdq),
+                  3: "beam_lane_kernelILi5ELi2ELb0ELb0ELb%sE" % pdq,
+                  4: "beam_wave_kernelILi5ELi6ELi2ELi4ELb0ELb0ELb%sELb0ELb%sE" % (uni, pdq)}.get(args.config)
+        occupancy = kernel_occupancy(symbol) if (symbol and args.kernel == 0) else None
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
         vit16 = viterbi_roofline(fcd, torch, dev, half=True) if not args.no_viterbi else None
         valu = valu_issue_roofline(prefix, k_ms, simds) if default_shape else None
@@ -702,6 +757,8 @@ def main():
                     "bound": "valu_issue", "achieved": None, "peak": simds * 2.4e9 / 2.0,
                     "note": "no SQ counter summary of this kernel / shape on the current kernel sources under profiles/"},
                 "wavefronts_per_simd": B / rpw / simds,
+                # (what the instantiation RESERVES: registers, LDS and the resident wavefronts per SIMD they allow)
+                "occupancy": occupancy,
                 "step_latency_us": k_ms * 1e3 / T,
             },
             "cpu_baseline": cpu,

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "../../include/fcd.h"
+#include "../../include/fcd_debug.h"
 
 namespace fcd {
 

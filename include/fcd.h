@@ -94,9 +94,11 @@ enum {
  * sort and ties keep node order; above 20 it is the pattern-defeating quicksort of the pinned toolchain (Rust
  * 1.78.0, .github/workflows/test.yml:16), whose permutation of equal keys is a deterministic function of the list.
  *   FCD_TIE_PDQ178 (default)  on a step with more than 20 candidates in which a candidate that survives the
- *                  truncation ties with another one, one lane replays that quicksort (csrc/pdq178.h, restated from
- *                  memory of library/core/src/slice/sort.rs -- no Rust source or toolchain in the build image; the
- *                  same restatement, written independently, is the oracle's) and the search adopts its order;
+ *                  truncation ties with another one, that quicksort is replayed on the node-ordered list -- by the
+ *                  whole wavefront in the register kernels (csrc/pdq178_wave.h, pdq178_reg.h), by one lane in the
+ *                  LDS-resident ones (csrc/pdq178.h); restated from memory of library/core/src/slice/sort.rs, as is
+ *                  the oracle's: no Rust source or toolchain in the build image, see tools/verify/pdq178_check.rs
+ *                  for the one-command check a holder of rustc 1.78.0 can run -- and the search adopts its order;
  *                  every other step is ranked exactly on (probability desc, node asc), which is the same thing.
  *   FCD_TIE_STABLE ties always keep ascending node order (what rounds 1-3 shipped): one of the admissible answers
  *                  of an unstable sort, but not the one Rust 1.78 gives on about 0.05 % of BASELINE config-2 reads.
@@ -193,35 +195,8 @@ int fcd_release_workspace(fcd_handle *h);
 int fcd_set_tie_order(fcd_handle *h, int order);         /* FCD_TIE_DEFAULT: follow the process default again */
 int fcd_get_tie_order(const fcd_handle *h);              /* the order searches on this handle use right now */
 int fcd_set_default_tie_order(int order);                /* FCD_TIE_PDQ178 or FCD_TIE_STABLE; process-wide */
-/* Test hook: lists (DEVICE u64 [n_lists][stride], lens DEVICE i32 [n_lists]) are sorted in place by the device
- * function the kernels run on tie-flagged steps: descending by the UPPER 32 bits of each element, equal keys in
- * the order Rust 1.78's sort_unstable_by leaves them in; the lower 32 bits ride along. */
-int fcd_debug_pdq178_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens);
-/* The same lists through the wave-cooperative form of that routine (csrc/pdq178_coop.h: what the wide-beam kernels run,
- * all 64 lanes on up to two lists at once): wavefront b sorts lists 2b and 2b + 1 together.  planes = 1, 5 or 8: the
- * instantiation (64 * planes positions; lens[2b] + lens[2b + 1] must not exceed them); keep: only the first `keep`
- * positions of every list have to come out right (the searches keep beam_size candidates).  Must equal the call
- * above on those positions. */
-int fcd_debug_pdq178_coop_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens,
-                                   int planes, int keep);
-/* Developer instrument: shader cycles the wavefronts of the call above spent per phase of the routine, summed since the
- * last reset (HOST array): [0] set-up, [1..6] phases A-F of the partition rounds, [7] loop overhead, [8] leaves,
- * [9] rounds, [10] calls.  (The search kernels carry no stamps.) */
-int fcd_debug_pdq178_coop_profile(fcd_handle *h, uint64_t cycles[16], int reset);
-/* Developer instrument: wide-beam searches whose worst-case tree arena would exceed 8 GiB (or the workspace
- * limit) run a first pass in slabs of 1/divisor of the worst case (default 2; trees usually reach a third of
- * it) and decode the reads that outgrow their slab again in worst-case slabs carved from the same arena.  A
- * job in which more than a quarter of the reads overflow switches the handle to worst-case slabs for later
- * jobs.  A larger divisor makes the retry path run on small inputs (tests) and pins it; 0 restores the
- * adaptive default. */
-int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor);
-/* Developer instrument: while `cycles` (DEVICE array [n_pairs][16] u32, indexed by the pair's position in the batch)
- * is set, the duplex searches on this handle record a cycle account per pair: shader cycles / 64 spent in
- * [0] envelope + forward-vector extension, [1] LDS tiles, [2] expansion without the window builds, [3] window
- * builds of the new nodes, [4] rank + next beam; [5] window-build loop iterations, [6] new nodes, [7] steps, [8] steps
- * whose extension took the sequential path, [9] nodes that entered the beam, [10] steps with a growing upper bound.
- * NULL switches it off.  The stamps wait for each phase's results (tools/duplex_account.py). */
-int fcd_debug_set_duplex_profile(fcd_handle *h, uint32_t *cycles);
+/* (test hooks and developer instruments -- fcd_debug_*, the probes and sweeps -- are declared in fcd_debug.h: the
+ * library exports them, but they are no part of the surface a binding generator should consume) */
 /* duration (ms) of the decode kernel(s) of the last call on this handle, measured with HIP
  * events on the stream the kernels were launched on; <0 if unavailable */
 double fcd_last_kernel_ms(fcd_handle *h);
@@ -244,16 +219,6 @@ int fcd_beam_search_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
 int fcd_beam_search_host(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
                          float beam_cut_threshold, int collapse_repeats, int kernel,
                          const fcd_result *out);
-
-/* Developer instrument, not part of the drop-in surface: the headline instantiation of the register kernel
- * (beam_size <= 5, N = 5, two reads per wavefront) with a shader-clock stamp after each block of the time
- * step.  cycles: device array [ceil(n_reads / 2)][8] u32 -- per wavefront, cycles summed over the read in
- * blocks 0..6 (row fetch, extensions + push, numbering + stores, key + rank, child-entry upkeep, gather,
- * top + divisions + state) and the step count in [7].  Results in `out` are the search's.  The stamps
- * serialise the blocks, so this measures their dependent latencies (tools/cycle_account.py, profiles/). */
-int fcd_beam_search_profile_dev(fcd_handle *h, const fcd_batch *in, int64_t beam_size,
-                                float beam_cut_threshold, int collapse_repeats, const fcd_result *out,
-                                uint32_t *cycles);
 
 /* ---- search::crf_beam_search (src/search.rs:38-157) ----
  * init: [n_reads * init_stride] f32, n_init entries used per read (src/search.rs:54-59). */
@@ -328,26 +293,6 @@ int fcd_duplex_envelope_host(fcd_handle *h, int64_t n_pairs,
                              int64_t stride2, const int64_t *T2, int64_t T2cap,
                              int64_t band, uint64_t *envelope, int64_t env_stride);
 
-/* Test hook (device pointers, n elements): out_add[i] = LogSpace::add(a[i], b[i]) (src/duplex.rs:42-63)
- * and out_ln[i] = LogSpace::new(a[i]) = ln(a[i]) (:24-26), computed by the very device functions the
- * duplex kernel uses, so the log-space arithmetic can be checked bit for bit against the oracle.
- * logadd_mode: FCD_LOGADD_*, + 4 for the lockstep form of the window-building loop instead of the general one. */
-int fcd_logspace_probe_dev(fcd_handle *h, const float *a, const float *b, float *out_add,
-                           float *out_ln, int64_t n, int logadd_mode);
-
-/* Test hook: y[i] = f(x[i]) (device pointers) with the device build of csrc/glibc235_math.h -- which = 0 expf, 1 logf,
- * 2 log1pf -- to be compared with the host's libm (glibc 2.35: identical on every argument). */
-int fcd_debug_glibc235_dev(fcd_handle *h, int which, const float *x, float *y, int64_t n);
-
-/* Developer instrument: one wavefront folds n_chain values into an accumulator with the duplex kernel's
- * LogSpace::add, each add waiting for the previous one; cycles[lane] (DEVICE u64[64]) = shader cycles of the chain,
- * sink (DEVICE f32[64]) keeps the result alive.  cycles / n_chain is the dependent latency that bounds the duplex
- * searches (tools/duplex_account.py: the dependent-chain roofline). */
-int fcd_logadd_latency_probe_dev(fcd_handle *h, int n_chain, int logadd_mode, uint64_t *cycles, float *sink);
-/* Test hook: exhaustive sweep of one fast path of LogSpace::add on the device -- which = 0: exp, 1: ln_1p -- over
- * every f32 bit pattern in [first_bits, last_bits]; counts (DEVICE u64[3]) = arguments, arguments Ziv's test sends
- * to the slow path, arguments whose trusted fast result differs from the library routine's (must be 0). */
-int fcd_logadd_sweep_dev(fcd_handle *h, int which, uint32_t first_bits, uint32_t last_bits, uint64_t *counts);
 
 /* ---- compact wire format of a shard's results, for the ONE gather of the multi-GPU path ----
  * The searches write fixed-stride rows; only out_len[r] entries of row r are meaningful (~48 % at BASELINE

@@ -1,5 +1,6 @@
 """CPU-only: the C-ABI library builds (hipcc cross-compiles gfx950), loads, and exports every
-symbol include/fcd.h declares.  No compute calls."""
+symbol include/fcd.h (the drop-in boundary) and include/fcd_debug.h (test hooks, developer instruments) declare.
+No compute calls."""
 import ctypes
 import os
 import re
@@ -16,10 +17,20 @@ def lib():
     return _native.load()
 
 
-def header_functions():
-    text = open(os.path.join(ROOT, "include", "fcd.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fcd_[a-z_0-9]+)\s*\(", text)))
+def header_functions(headers=("fcd.h", "fcd_debug.h")):
+    names = set()
+    for h in headers:
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\b(fcd_[a-z_0-9]+)\s*\(", text))
+    return sorted(names)
+
+
+def test_the_boundary_header_holds_no_test_hooks():
+    """what a binding generator consumes: no fcd_debug_*, probes or sweeps in fcd.h"""
+    for n in header_functions(("fcd.h",)):
+        assert not re.search(r"debug|_probe|_sweep|_profile", n), n
+    assert len(header_functions(("fcd_debug.h",))) >= 9
 
 
 def test_header_symbols_exported(lib):

@@ -53,5 +53,32 @@ def main():
                   % (T, name, n, plain, co, st["calls"], st["launches"], st["largest_batch"]), flush=True)
 
 
+def main_pairs():
+    """python tools/probe_threads.py pairs [T] [calls_per_thread] [threads ...]: per-PAIR callers of beam_search_duplex
+    (src/lib.rs:401-488: one pair per call), banded envelope of +-64 rows as in BASELINE config 5"""
+    T = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
+    calls = int(sys.argv[3]) if len(sys.argv) > 3 else 4
+    threads = [int(a) for a in sys.argv[4:]] or [1, 16, 64]
+    i = np.arange(T)
+    env = np.stack([np.maximum(i - 64, 0), np.minimum(i + 64, T)], 1).astype(np.uint64)
+    pairs = [(rows(T, 2 * s), rows(T, 2 * s + 1)) for s in range(64)]
+    fn = lambda p: ext.beam_search_duplex(p[0], p[1], "NACGT", env, 5, 0.1)
+    for n in threads:
+        ext.set_coalescing(0)
+        run(n, 1, pairs, fn)
+        plain = run(n, calls, pairs, fn)
+        ext.set_coalescing(256, 0)
+        run(n, 1, pairs, fn)
+        co = run(n, calls, pairs, fn)
+        st = ext.coalescing_stats()
+        ext.set_coalescing(0)
+        print("T=%d beam_search_duplex(5, 0.1, band 64) %3d threads: %7.1f pairs/s per-pair launches, %7.1f pairs/s coalesced "
+              "(%d calls in %d launches, largest batch %d)"
+              % (T, n, plain, co, st["calls"], st["launches"], st["largest_batch"]), flush=True)
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "pairs":
+        main_pairs()
+    else:
+        main()
