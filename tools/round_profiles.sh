@@ -32,4 +32,16 @@ cp $(find $O/viterbi_clock_$TAG -name '*kernel_stats.csv' | head -n 1) $O/${TAG}
 FCD_TIE_ORDER=stable python bench.py --no-viterbi --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_line_stable_order.json 2> $O/${TAG}_bench_stable.err
 FCD_TIE_ORDER=stable python bench.py --config 3 --no-viterbi --steps 5 --cpu-seconds 1 > $O/${TAG}_bench_config3_stable_order.json 2>> $O/${TAG}_bench_stable.err
 ( python bench.py --streams 2 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --batch 16384 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --data peaky --no-viterbi --no-e2e --cpu-seconds 1 ) > $O/${TAG}_bench_variants.txt 2> $O/${TAG}_bench_variants.err
+# ---- round 5: the tie order's cost by beam (both orders, reference-style and peaky rows), its cycle account in place
+# (a -DFCD_LANE_TIE_PROF build: tools/dev/lane_tie_prof.sh, made before the call), the replay's dynamic instruction
+# counts, config 3 on 1 / 2 / 3 streams, the lane kernel's SQ counters, per-pair duplex callers through the coalescer
+( for b in 5 8 12; do BEAM=$b REPS=5 python tools/dev/time_variant.py; done; BEAM=32 BATCH=8192 REPS=3 python tools/dev/time_variant.py ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_tie_order_by_beam.txt
+python tools/dev/lane_tie_prof.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lane_tie_prof.txt
+python tools/dev/time_coop.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_replay_probe.txt
+bash tools/dev/probe_sort_sq.sh 2>&1 | grep "per wavefront" > $O/${TAG}_replay_instruction_counts.txt
+for s in 1 2 3; do python bench.py --config 3 --streams $s --no-viterbi --steps 12 --warmup 6 --cpu-seconds 0.5 2>> $O/${TAG}_bench_config3_streams.err; done > $O/${TAG}_bench_config3_streams.txt
+FCD_TIE_ORDER=stable bash tools/profile_sq.sh ${TAG}_lane_stable beam32 > $O/${TAG}_sq_lane_stable.log 2>&1
+bash tools/profile_sq.sh ${TAG}_lane beam32 > $O/${TAG}_sq_lane.log 2>&1
+python tools/probe_threads.py pairs 2000 3 1 16 64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_pair_callers.txt
+python tools/probe_threads.py 4000 10 64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_read_callers.txt
 for f in $O/${TAG}_bench_line.json $O/${TAG}_bench_config3.json $O/${TAG}_duplex_account.jsonl $O/${TAG}_e2e_probe.txt $O/${TAG}_cycle_account.jsonl $O/${TAG}_latency.txt; do tail -n 2 $f | cut -c1-300; done
