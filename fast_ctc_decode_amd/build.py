@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfcd_hip.so")
 SOURCES = ["capi.hip", "beam_generic.hip", "beam_wave.hip", "viterbi.hip", "duplex.hip", "envelope.hip", "beam_lane.hip", "pack.hip", "coalesce.hip", "hostjob.hip", "comm.hip", "tieorder.hip"]
-HEADERS = ["fcd_internal.h", "device_utils.h", "logadd_fast.h", "pdq178.h", "pdq178_coop.h", "pdq178_wave.h", "glibc235_math.h", "beam_wave_step.inc", os.path.join("..", "..", "include", "fcd.h"), os.path.join("..", "..", "include", "fcd_debug.h")]
+HEADERS = ["fcd_internal.h", "device_utils.h", "logadd_fast.h", "pdq178.h", "pdq178_wave.h", "glibc235_math.h", "beam_wave_step.inc", os.path.join("..", "..", "include", "fcd.h"), os.path.join("..", "..", "include", "fcd_debug.h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
