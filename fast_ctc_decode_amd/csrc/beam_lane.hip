@@ -653,35 +653,97 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                     n_older += older[k] ? 1 : 0;
                 }
                 const int o_incl = half_prefix_add<RPW>(n_older);
-                int o_pos = o_incl - n_older;
                 const int n_old = RPW == 1 ? rdlane(o_incl, 63) : bperm(hbase + HALF - 1, o_incl);
-#pragma unroll
-                for (int k = 0; k < N; ++k)
-                    if (older[k]) eid[o_pos++] = (uint32_t)key[k];  // low word: larger = smaller node
-                if (q < 16) eid[n_old + q] = 0u;                    // (padding of the last block of reads: never "smaller")
-                wave_sync();
-                int n_old_max = n_old;
-                if (RPW == 2) n_old_max = max(n_old_max, __shfl_xor(n_old_max, 32));
-                n_old_max = __builtin_amdgcn_readfirstlane(n_old_max);
                 int pos[N];
 #pragma unroll
                 for (int k = 0; k < N; ++k) pos[k] = 0;
-                // sixteen ids per trip: four 16-byte LDS reads in flight together (a straggler's wavefront runs alone on
-                // its SIMD: one read per trip was one exposed LDS round trip per four ids)
-#pragma unroll 1
-                for (int j = 0; j < n_old_max; j += 16) {
-                    uint4 e[4];
+                // Rank of an older candidate's node among the older candidates' nodes.  Node ids are dense creation-order
+                // integers and the candidates of a step sit on RECENT nodes (a beam entry is rarely more than a few dozen
+                // steps old), so the ids span a small range: every older candidate sets ITS bit of a bitmap over that range
+                // (ids are unique: one candidate per node), and a node's rank is the number of bits below its own -- a
+                // per-word prefix count plus one masked population count.  ~100 instructions where comparing every
+                // candidate with every older id took ~1000 (round 4; a straggler's wavefront pays per instruction).  A
+                // range the table cannot hold (an entry that has sat in the beam for ~60 steps) takes the all-pairs path.
+                constexpr int CAPW = (HALF * N + 16) / 2;  // words per table: the bitmap, and the per-word prefix counts behind it
+                uint32_t idv[N];                            // node + 1: the root (-1) counts as 0
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        e[u] = make_uint4(0u, 0u, 0u, 0u);
-                        if (j + 4 * u < n_old) e[u] = *reinterpret_cast<const uint4 *>(eid + j + 4 * u);
+                for (int k = 0; k < N; ++k) idv[k] = (uint32_t)((k == 0 ? node : ccand[k > 0 ? k - 1 : 0]) + 1);
+                uint32_t id_lo = ~0u, id_hi_c = ~0u;  // smallest id; complement of the largest (both by an unsigned minimum)
+#pragma unroll
+                for (int k = 0; k < N; ++k)
+                    if (older[k]) {
+                        id_lo = idv[k] < id_lo ? idv[k] : id_lo;
+                        id_hi_c = ~idv[k] < id_hi_c ? ~idv[k] : id_hi_c;
                     }
+                id_lo = (uint32_t)bperm(hbase + HALF - 1, half_umin_in_last_lane<RPW>((int)id_lo));
+                const uint32_t id_hi = ~(uint32_t)bperm(hbase + HALF - 1, half_umin_in_last_lane<RPW>((int)id_hi_c));
+                const int W32 = n_old > 0 ? (int)((id_hi - id_lo) >> 5) + 1 : 0;  // bitmap words this read needs
+                bool by_bitmap = ballot(mine_h && W32 > CAPW) == 0ull;   // (wave-uniform: both reads take the same path)
+#ifdef FCD_HIPEMU  // (tests/test_emu_parity.py runs the tie-order tests once more on the all-pairs path)
+                if (getenv("FCD_EMU_LANE_ALLPAIRS")) by_bitmap = false;
+#endif
+                if (by_bitmap) {
+                    uint32_t *bm = eid, *pf = eid + CAPW;
+                    for (int w = q; mine_h && w < W32; w += HALF) bm[w] = 0u;
+                    wave_sync();
 #pragma unroll
-                    for (int u = 0; u < 4; ++u) {
+                    for (int k = 0; k < N; ++k)
+                        if (older[k]) {
+                            const uint32_t d = idv[k] - id_lo;
+                            atomicOr(&bm[d >> 5], 1u << (d & 31u));
+                        }
+                    wave_sync();
+                    {   // exclusive count of the bits in the words below each word: lane q takes words [q * WPL, (q + 1) * WPL)
+                        constexpr int WPL = (CAPW + HALF - 1) / HALF;
+                        uint32_t wv[WPL];
+                        int c = 0;
 #pragma unroll
-                        for (int k = 0; k < N; ++k) {
-                            const uint32_t me = (uint32_t)key[k];
-                            pos[k] += ((e[u].x > me) ? 1 : 0) + ((e[u].y > me) ? 1 : 0) + ((e[u].z > me) ? 1 : 0) + ((e[u].w > me) ? 1 : 0);
+                        for (int u = 0; u < WPL; ++u) {
+                            const int w = q * WPL + u;
+                            wv[u] = (mine_h && w < W32) ? bm[w] : 0u;
+                            c += __builtin_popcount(wv[u]);
+                        }
+                        int run = half_prefix_add<RPW>(c) - c;
+#pragma unroll
+                        for (int u = 0; u < WPL; ++u) {
+                            const int w = q * WPL + u;
+                            if (mine_h && w < W32) pf[w] = (uint32_t)run;
+                            run += __builtin_popcount(wv[u]);
+                        }
+                    }
+                    wave_sync();
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        if (older[k]) {
+                            const uint32_t d = idv[k] - id_lo;
+                            pos[k] = (int)pf[d >> 5] + __builtin_popcount(bm[d >> 5] & ((1u << (d & 31u)) - 1u));
+                        }
+                } else {
+                    int o_pos = o_incl - n_older;
+#pragma unroll
+                    for (int k = 0; k < N; ++k)
+                        if (older[k]) eid[o_pos++] = (uint32_t)key[k];  // low word: larger = smaller node
+                    if (q < 16) eid[n_old + q] = 0u;                    // (padding of the last block of reads: never "smaller")
+                    wave_sync();
+                    int n_old_max = n_old;
+                    if (RPW == 2) n_old_max = max(n_old_max, __shfl_xor(n_old_max, 32));
+                    n_old_max = __builtin_amdgcn_readfirstlane(n_old_max);
+                    // sixteen ids per trip: four 16-byte LDS reads in flight together
+#pragma unroll 1
+                    for (int j = 0; j < n_old_max; j += 16) {
+                        uint4 e[4];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+                            e[u] = make_uint4(0u, 0u, 0u, 0u);
+                            if (j + 4 * u < n_old) e[u] = *reinterpret_cast<const uint4 *>(eid + j + 4 * u);
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                            for (int k = 0; k < N; ++k) {
+                                const uint32_t me = (uint32_t)key[k];
+                                pos[k] += ((e[u].x > me) ? 1 : 0) + ((e[u].y > me) ? 1 : 0) + ((e[u].z > me) ? 1 : 0) + ((e[u].w > me) ? 1 : 0);
+                            }
                         }
                     }
                 }

@@ -172,6 +172,17 @@ def test_results_do_not_depend_on_the_order_the_fibres_run_in(fcd, order, monkey
     P.test_crf_fuzz(fcd, 2)
 
 
+def test_lane_kernel_node_order_by_all_pairs_too(fcd, monkeypatch):
+    """The lane kernel puts a tie-flagged step's candidates in node order with a bitmap over the ids' range (r05) and
+    falls back to comparing all pairs when the range does not fit its table: the emulator build can force that path."""
+    import test_gpu_tieorder as TO
+    monkeypatch.setenv("FCD_EMU_LANE_ALLPAIRS", "1")
+    TO.test_both_tie_orders_every_kernel(fcd, 5, 32, (1, 4))
+    TO.test_both_tie_orders_every_kernel(fcd, 8, 64, (4,))
+    TO.test_both_tie_orders_every_kernel(fcd, 7, 8, (4,))
+    TO.test_both_tie_orders_every_kernel(fcd, 5, 12, (4,))
+
+
 def test_tie_orders(fcd):
     """FCD_TIE_PDQ178 / FCD_TIE_STABLE (tests/test_gpu_tieorder.py) under the emulator: every kernel family under both
     orders on inputs built to tie, the CRF and duplex searches, and the BASELINE reads whose result depends on it."""

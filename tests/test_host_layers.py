@@ -125,3 +125,19 @@ def test_portable_list_path_gives_identical_objects():
     del big, a
     gc.collect()
     assert before - sys.getrefcount(some) == uses + held
+
+
+def test_unknown_tie_order_in_the_environment_is_reported():
+    """a typo in FCD_TIE_ORDER must not silently select the other order (csrc/capi.hip)"""
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from fast_ctc_decode_amd import _native as nat; print(nat.default_tie_order())"
+    env = dict(os.environ, FCD_TIE_ORDER="stabel")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "FCD_TIE_ORDER" in r.stderr and "stabel" in r.stderr and r.stdout.strip() == "pdq178"
+    env["FCD_TIE_ORDER"] = "stable"
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == "stable" and "FCD_TIE_ORDER" not in r.stderr
