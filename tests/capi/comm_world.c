@@ -118,7 +118,8 @@ static int run_rank(int world, int rank, const uint8_t *id, const char *scenario
     if (badheader && rank == 0) view[1] = counts[1] + 1 <= 4 ? counts[1] + 1 : counts[1] - 1; /* (the largest count stays the largest) */
     for (k = 0; k < rank; ++k) first += counts[k];
     for (k = 0; k < world; ++k) total += view[k];
-    CHECK(fcd_create(0, &g_h));
+    /* one process per GPU: with FCD_EMU_DEVICES=N (the emulator's device count) rank k takes device k */
+    CHECK(fcd_create(fcd_device_count() > 1 ? rank % fcd_device_count() : 0, &g_h));
     CHECK(fcd_comm_create(g_h, world, rank, id, &c));
     if (alloc_result(&mine, counts[rank], stride)) return 11;
     CHECK(decode(g_h, first, counts[rank], &mine));

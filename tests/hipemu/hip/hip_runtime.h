@@ -149,6 +149,7 @@ void block_barrier();
 int lane_id();
 
 void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *), void *closure);
+void check_launch_stream(hipStream_t s);  // aborts when the stream belongs to another device than the current one
 
 template <class F>
 void launch(dim3 grid, dim3 block, size_t lds_bytes, F f) {
@@ -164,7 +165,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, F f) {
 #define warpSize 64
 
 #define hipLaunchKernelGGL(kern, grid, block, lds, stream, ...) \
-    hipemu::launch((grid), (block), (size_t)(lds), [=]() { kern(__VA_ARGS__); })
+    (hipemu::check_launch_stream(stream), hipemu::launch((grid), (block), (size_t)(lds), [=]() { kern(__VA_ARGS__); }))
 
 // ---- device intrinsics ----------------------------------------------------------------------------
 static inline int __float_as_int(float f) { int i; memcpy(&i, &f, 4); return i; }

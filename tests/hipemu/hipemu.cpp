@@ -7,6 +7,7 @@
 #include <time.h>
 
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -231,8 +232,43 @@ void launch_impl(dim3 grid, dim3 block, size_t lds_bytes, void (*tramp)(void *),
 }  // namespace hipemu
 
 // ---- host runtime stand-ins -------------------------------------------------------------------
-struct hipemu_stream { int dummy; };
+// Devices: FCD_EMU_DEVICES (default 1) emulated devices.  The current device is per host thread, as in HIP; streams
+// and allocations remember the device they were made on, and an operation on them under ANOTHER current device aborts
+// with a message -- on the GPU that is a wrong-context launch or an invalid-device-pointer error, the class of defect a
+// one-GPU box can never show (device index > 0 had never executed).
+struct hipemu_stream { int device; };
 struct hipemu_event { double t_ms; };
+
+static thread_local int t_device = 0;
+static int emu_devices() {
+    const char *e = getenv("FCD_EMU_DEVICES");
+    const int n = e ? atoi(e) : 1;
+    return n >= 1 && n <= 16 ? n : 1;
+}
+extern "C" int hipemu_current_device() { return t_device; }  // (for the tests: "the caller's device is put back")
+static std::mutex g_alloc_mu;
+static std::map<uintptr_t, std::pair<size_t, int>> g_allocs;  // device allocations: start -> (bytes, device)
+static void check_device_ptr(const void *p, const char *what) {
+    if (emu_devices() < 2 || !p) return;
+    std::lock_guard<std::mutex> g(g_alloc_mu);
+    auto it = g_allocs.upper_bound((uintptr_t)p);
+    if (it == g_allocs.begin()) return;  // host memory
+    --it;
+    if ((uintptr_t)p >= it->first + it->second.first) return;
+    if (it->second.second != t_device) {
+        fprintf(stderr, "hipemu: %s touches memory of device %d while device %d is current\n", what, it->second.second, t_device);
+        abort();
+    }
+}
+static void check_stream(hipStream_t s, const char *what) {
+    if (s && s->device != t_device) {
+        fprintf(stderr, "hipemu: %s on a stream of device %d while device %d is current\n", what, s->device, t_device);
+        abort();
+    }
+}
+namespace hipemu {
+void check_launch_stream(hipStream_t s) { check_stream(s, "kernel launch"); }
+}
 
 static double now_ms() {
     timespec ts;
@@ -240,17 +276,32 @@ static double now_ms() {
     return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6;
 }
 
-hipError_t hipGetDeviceCount(int *n) { *n = 1; return hipSuccess; }
-hipError_t hipSetDevice(int) { return hipSuccess; }
-hipError_t hipGetDevice(int *d) { *d = 0; return hipSuccess; }
+hipError_t hipGetDeviceCount(int *n) { *n = emu_devices(); return hipSuccess; }
+hipError_t hipSetDevice(int d) {
+    if (d < 0 || d >= emu_devices()) return hipErrorInvalidValue;
+    t_device = d;
+    return hipSuccess;
+}
+hipError_t hipGetDevice(int *d) { *d = t_device; return hipSuccess; }
 hipError_t hipMalloc(void **p, size_t n) {
     void *q = nullptr;
     if (posix_memalign(&q, 256, n ? n : 1)) { *p = nullptr; return hipErrorOutOfMemory; }
     memset(q, 0xA5, n);  // device memory arrives uninitialised: make reliance on zeros visible
     *p = q;
+    if (emu_devices() > 1) {
+        std::lock_guard<std::mutex> g(g_alloc_mu);
+        g_allocs[(uintptr_t)q] = std::make_pair(n ? n : (size_t)1, t_device);
+    }
     return hipSuccess;
 }
-hipError_t hipFree(void *p) { free(p); return hipSuccess; }
+hipError_t hipFree(void *p) {
+    if (emu_devices() > 1 && p) {
+        std::lock_guard<std::mutex> g(g_alloc_mu);
+        g_allocs.erase((uintptr_t)p);
+    }
+    free(p);
+    return hipSuccess;
+}
 hipError_t hipHostMalloc(void **p, size_t n, unsigned) {
     *p = malloc(n ? n : 1);
     return *p ? hipSuccess : hipErrorOutOfMemory;
@@ -261,18 +312,29 @@ hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b) {
     *total_b = (size_t)2 << 30;
     return hipSuccess;
 }
-hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t) { memcpy(dst, src, n); return hipSuccess; }
+hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind, hipStream_t st) {
+    check_stream(st, "hipMemcpyAsync");
+    check_device_ptr(dst, "hipMemcpyAsync");
+    check_device_ptr(src, "hipMemcpyAsync");
+    memcpy(dst, src, n);
+    return hipSuccess;
+}
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind) { memcpy(dst, src, n); return hipSuccess; }
-hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t) { memset(dst, v, n); return hipSuccess; }
+hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t st) {
+    check_stream(st, "hipMemsetAsync");
+    check_device_ptr(dst, "hipMemsetAsync");
+    memset(dst, v, n);
+    return hipSuccess;
+}
 hipError_t hipMemset(void *dst, int v, size_t n) { memset(dst, v, n); return hipSuccess; }
-hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemu_stream{0}; return hipSuccess; }
+hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemu_stream{t_device}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
-hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+hipError_t hipStreamSynchronize(hipStream_t st) { check_stream(st, "hipStreamSynchronize"); return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event{0.0}; return hipSuccess; }
 hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCreate(e); }
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
-hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t_ms = now_ms(); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) { check_stream(st, "hipEventRecord"); e->t_ms = now_ms(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }  // (launches run to completion: whatever was recorded has happened)
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }

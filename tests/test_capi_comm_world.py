@@ -31,6 +31,7 @@ def world_exe(tmp_path_factory):
                            "-Wl,-rpath," + libdir])
     env = dict(os.environ)
     env["FCD_RCCL_LIBRARY"] = stub
+    env["FCD_EMU_DEVICES"] = "8"  # one process per (emulated) GPU: rank k creates its handle and communicator on device k
     return exe, env
 
 

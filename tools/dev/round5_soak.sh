@@ -2,11 +2,11 @@
 # differential soaks of the round's final kernels against the oracle, default tie order on both sides, side by side
 set -u
 O=gpurun_out; mkdir -p $O
-FCD_SOAK_SECONDS=${1:-420} python tools/beam_soak.py 8000000 100000000 > $O/r05f_soak_beam.log 2>&1 &
-FCD_SOAK_SECONDS=${1:-420} python tools/duplex_soak.py 8100000 100000000 > $O/r05f_soak_duplex.log 2>&1 &
-FCD_SOAK_SECONDS=${2:-200} python tools/hostjob_soak.py 8700000 100000000 > $O/r05f_soak_hostjob.log 2>&1 &
+FCD_SOAK_SECONDS=${1:-420} python tools/beam_soak.py 8500000 100000000 > $O/r05i_soak_beam.log 2>&1 &
+FCD_SOAK_SECONDS=${1:-420} python tools/duplex_soak.py 8600000 100000000 > $O/r05i_soak_duplex.log 2>&1 &
+FCD_SOAK_SECONDS=${2:-200} python tools/hostjob_soak.py 8800000 100000000 > $O/r05i_soak_hostjob.log 2>&1 &
 # the tie-order tests once more, and the replay against the committed vectors ON THE GPU
-python - > $O/r05f_vectors_gpu.log 2>&1 <<'PY'
+python - > $O/r05i_vectors_gpu.log 2>&1 <<'PY'
 import json, os, sys
 sys.path.insert(0, "tests")
 import numpy as np, torch
@@ -28,4 +28,4 @@ bad += sum(not np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(
 print("tools/verify/pdq178_vectors.json on the GPU: %d lists through pdq178.h (serial) and pdq178_wave.h + pdq178_reg.h: %d differ from the file" % (len(lists), bad))
 PY
 wait
-tail -n 2 $O/r05f_soak_beam.log $O/r05f_soak_duplex.log $O/r05f_soak_hostjob.log $O/r05f_vectors_gpu.log
+tail -n 2 $O/r05i_soak_beam.log $O/r05i_soak_duplex.log $O/r05i_soak_hostjob.log $O/r05i_vectors_gpu.log
