@@ -22,8 +22,10 @@
 //     follow through a second table, a re-entering node re-reads its row from HBM.
 // Tree arena and the segment-parallel leaf -> root walk are beam_wave.hip's, with dense node ids: a record is
 // (parent, label) and the creation time of a node -- what `path` reports -- is looked up in first[t], the read's
-// node count when step t began (one 4-byte store per step).  A leaving node's child row is written only if the
-// node can ever re-enter the beam (some beam entry is shallower; see beam_wave.hip).
+// node count when step t began (one 4-byte store per step).  A node's record is written when the node FIRST ENTERS
+// THE BEAM, not when it is created (the traceback only ever walks through nodes that were beam entries).  A leaving
+// node's child row is written only if the node can ever re-enter the beam (some beam entry is shallower; see
+// beam_wave.hip).
 #ifdef FCD_HIPEMU
 #include <stdio.h>
 #include <stdlib.h>
@@ -375,12 +377,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
 #pragma unroll
         for (int l = 0; l < NL; ++l) {
             const bool is_new = cvalid[l] && child[l] < 0;
-            if (is_new && !f_cap) {
-                const int id = next_id++;
-                *rec_at(id) = ((node + 1) << 3) | l;
-                if ((depth + 1) % kSeg == 0) *jmp_at(id) = (depth % kSeg == 0) ? node : jump;
-                child[l] = id;
-            }
+            // (the node's record -- parent, label -- is not written here: only a node that becomes a beam entry is ever
+            // walked through by the traceback, and most of a step's new nodes never do; see the publish loop below)
+            if (is_new && !f_cap) child[l] = next_id++;
             ccand[l] = child[l] & kIdMask;
         }
 
@@ -832,6 +831,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
                 // kind 1, or 2 when it has been there before (EVER: its row is in HBM)
                 const int ever = (int)(((uint32_t)child[l] >> 30) & 1u);
                 const int meta = (metac + ever) | ((l + 1) << 2);
+                if (!ever) {
+                    // first time in the beam: NOW its record exists in the arena -- (parent, label), and for a segment
+                    // head where the next head up the tree is.  The best labelling is a beam entry, every node was
+                    // created as the child of one, so every node on the way to the root has been through here; the
+                    // 5 new nodes in 6 that are pruned at once cost the arena no write (43 -> 7 records per step at
+                    // beam 32).  (Under the default tie order a tied step publishes once, after its ranks are final.)
+                    *rec_at(ccand[l]) = ((node + 1) << 3) | l;
+                    if ((depth + 1) % kSeg == 0) *jmp_at(ccand[l]) = jumpc;
+                }
                 publish(hbase + rk, __float_as_int(contrib[l]), 0, ccand[l], meta, jumpc,
                         CRF ? ((state * NL) & s_mask) + l : 0);  // :97
             }
