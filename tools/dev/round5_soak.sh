@@ -2,9 +2,9 @@
 # differential soaks of the round's final kernels against the oracle, default tie order on both sides, side by side
 set -u
 O=gpurun_out; mkdir -p $O
-FCD_SOAK_SECONDS=${1:-420} python tools/beam_soak.py 8500000 100000000 > $O/r05i_soak_beam.log 2>&1 &
-FCD_SOAK_SECONDS=${1:-420} python tools/duplex_soak.py 8600000 100000000 > $O/r05i_soak_duplex.log 2>&1 &
-FCD_SOAK_SECONDS=${2:-200} python tools/hostjob_soak.py 8800000 100000000 > $O/r05i_soak_hostjob.log 2>&1 &
+FCD_SOAK_SECONDS=${1:-420} python tools/beam_soak.py ${3:-8500000} 100000000 > $O/r05i_soak_beam.log 2>&1 &
+FCD_SOAK_SECONDS=${1:-420} python tools/duplex_soak.py ${4:-8600000} 100000000 > $O/r05i_soak_duplex.log 2>&1 &
+FCD_SOAK_SECONDS=${2:-200} python tools/hostjob_soak.py ${5:-8800000} 100000000 > $O/r05i_soak_hostjob.log 2>&1 &
 # the tie-order tests once more, and the replay against the committed vectors ON THE GPU
 python - > $O/r05i_vectors_gpu.log 2>&1 <<'PY'
 import json, os, sys
