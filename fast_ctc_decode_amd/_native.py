@@ -25,6 +25,7 @@ SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
     "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev", "fcd_debug_pdq178_coop_sort_dev", "fcd_debug_pdq178_coop_profile",
+    "fcd_debug_set_pdq178_std_form", "fcd_debug_get_pdq178_std_form",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
@@ -126,6 +127,8 @@ def bind(lib):
     lib.fcd_set_tie_order.argtypes = [P, i32]
     lib.fcd_get_tie_order.argtypes = [P]
     lib.fcd_set_default_tie_order.argtypes = [i32]
+    lib.fcd_debug_set_pdq178_std_form.argtypes = [P, i32]
+    lib.fcd_debug_get_pdq178_std_form.argtypes = []
     lib.fcd_debug_pdq178_sort_dev.argtypes = [P, P, i64, i64, P]
     lib.fcd_debug_pdq178_coop_sort_dev.argtypes = [P, P, i64, i64, P, i32, i32]
     lib.fcd_debug_pdq178_coop_profile.argtypes = [P, P, i32]
@@ -247,6 +250,11 @@ class Handle:
 
     def tie_order(self):
         return int(self.lib.fcd_get_tie_order(self.ptr))
+
+    def set_pdq178_std_form(self, bits):
+        """(include/fcd_debug.h) which form of the two routines std changed in 2023 the quicksort replay follows:
+        process-wide, written to this handle's device at once; 0 = Rust 1.78 as recalled (default), 3 = rustc 1.65"""
+        self.check(self.lib.fcd_debug_set_pdq178_std_form(self.ptr, int(bits)))
 
     def release_workspace(self):
         """Give the tree arena / staging memory back to the device (the next call allocates afresh)."""

@@ -600,4 +600,7 @@ hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t 
     return hipGetLastError();
 }
 
+// this translation unit's copy of the replay's std-form word (pdq178.h), on the current device
+FCD_PDQ178_DEFINE_STD_FORM_SETTER(beam_generic_set_pdq178_std_form)
+
 }  // namespace fcd

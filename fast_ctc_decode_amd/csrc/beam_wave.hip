@@ -516,4 +516,7 @@ hipError_t launch_beam_wave(const BatchDesc &in, int64_t read_begin, int64_t n_r
     return hipErrorInvalidValue;
 }
 
+// this translation unit's copy of the replay's std-form word (pdq178.h), on the current device
+FCD_PDQ178_DEFINE_STD_FORM_SETTER(beam_wave_set_pdq178_std_form)
+
 }  // namespace fcd

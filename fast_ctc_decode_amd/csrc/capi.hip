@@ -30,6 +30,27 @@ int tie_order_from_env() {
 }
 std::atomic<int> g_tie_order{tie_order_from_env()};
 
+// FCD_PDQ178_STD_FORM (include/fcd.h): which form of the two routines std changed in 2023 the quicksort replay follows --
+// a process-wide word, copied to every device a handle is created on (csrc/pdq178.h g_std_form)
+int pdq178_std_form_from_env() {
+    const char *e = getenv("FCD_PDQ178_STD_FORM");
+    if (!e || !*e) return 0;
+    if (e[0] >= '0' && e[0] <= '3' && !e[1]) return e[0] - '0';
+    fprintf(stderr, "fast_ctc_decode (fcd): FCD_PDQ178_STD_FORM=\"%s\" is not 0, 1, 2 or 3; using 0\n", e);
+    return 0;
+}
+std::atomic<int> g_pdq178_std_form{pdq178_std_form_from_env()};
+
+// (on the current device)
+hipError_t apply_pdq178_std_form(int bits) {
+    hipError_t e = beam_wave_set_pdq178_std_form(bits);
+    if (e == hipSuccess) e = beam_lane_set_pdq178_std_form(bits);
+    if (e == hipSuccess) e = beam_generic_set_pdq178_std_form(bits);
+    if (e == hipSuccess) e = duplex_set_pdq178_std_form(bits);
+    if (e == hipSuccess) e = tieorder_set_pdq178_std_form(bits);
+    return e;
+}
+
 constexpr int64_t kMaxRetryRounds = 4;  // lane kernel, two-pass sizing: retry rounds enqueued without asking (beam_dev)
 
 #define FCD_HIP(h, expr)                                                          \
@@ -397,6 +418,12 @@ int fcd_create(int device, fcd_handle **out) {
         return FCD_E_HIP;
     }
     h->stream = h->own_stream;
+    // the replay's std-form word lives on the device: every device a handle is created on gets the process's value
+    if (apply_pdq178_std_form(g_pdq178_std_form.load()) != hipSuccess) {
+        (void)hipStreamDestroy(h->own_stream);
+        delete h;
+        return FCD_E_HIP;
+    }
     *out = h;
     return FCD_OK;
 }
@@ -514,6 +541,19 @@ int fcd_set_default_tie_order(int order) {
     g_tie_order.store(order);
     return FCD_OK;
 }
+
+int fcd_debug_set_pdq178_std_form(fcd_handle *h, int bits) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (bits < 0 || bits > 3) return fail(h, FCD_E_INVALID, "the std form is 0, 1, 2 or 3");
+    FCD_DEVICE(h);
+    FCD_HIP(h, hipStreamSynchronize(h->stream));  // (no launch of this handle reads the word while it changes)
+    FCD_HIP(h, apply_pdq178_std_form(bits));
+    g_pdq178_std_form.store(bits);
+    return FCD_OK;
+}
+
+int fcd_debug_get_pdq178_std_form(void) { return g_pdq178_std_form.load(); }
 
 int fcd_debug_pdq178_sort_dev(fcd_handle *h, uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens) {
     if (!h) return FCD_E_INVALID;

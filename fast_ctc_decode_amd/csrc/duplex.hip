@@ -1741,4 +1741,7 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
     return hipGetLastError();
 }
 
+// this translation unit's copy of the replay's std-form word (pdq178.h), on the current device
+FCD_PDQ178_DEFINE_STD_FORM_SETTER(duplex_set_pdq178_std_form)
+
 }  // namespace fcd

@@ -183,6 +183,12 @@ hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride,
 hipError_t launch_pdq178_coop_probe(uint64_t *lists, int64_t n_lists, int64_t stride, const int32_t *lens, int planes,
                                     int keep, hipStream_t stream);
 hipError_t coop_prof_read(unsigned long long *out16, bool reset);  // developer instrument of the probe kernels
+// the replay's std-form word (pdq178.h g_std_form) of each translation unit that holds a replay, on the current device
+hipError_t beam_wave_set_pdq178_std_form(int bits);
+hipError_t beam_lane_set_pdq178_std_form(int bits);
+hipError_t beam_generic_set_pdq178_std_form(int bits);
+hipError_t duplex_set_pdq178_std_form(int bits);
+hipError_t tieorder_set_pdq178_std_form(int bits);
 hipError_t lane_tie_prof_read(unsigned long long *out16, bool reset);  // ... of a -DFCD_LANE_TIE_PROF build of beam_lane.hip
 // the tie order searches on this handle use (capi.hip)
 int effective_tie_order(const fcd_handle *h);

@@ -48,6 +48,25 @@ struct Scratch {
 };
 
 #define FCD_PDQ_FN static __device__ inline
+
+// Which FORM of the two routines std changed in 2023 the replay follows -- one word per translation unit and device, 0
+// unless somebody sets it (FCD_PDQ178_STD_FORM in the environment, read when the library is loaded and applied by
+// fcd_create; fcd_debug_set_pdq178_std_form).  A rustc-1.65 build of std found compiled in the image this was written
+// in agrees element for element with this restatement under form 3 (oracle/fcd_oracle.c fcdo_set_pdq_std_form,
+// tools/verify/rust165_pdqsort.py); form 0 -- the later forms -- is Rust 1.78 as recalled, and
+// tools/verify/pdq178_check.rs tells whoever has that toolchain which form its std carries.
+//   bit 0: break_patterns draws a usize as two 32-bit xorshift numbers (13, 17, 5) -- std 1.20 .. 2022 -- instead of
+//          one usize-wide xorshift (64-bit: 13, 7, 17; seed = len);
+//   bit 1: partial_insertion_sort, having swapped the pair, calls shift_tail(&mut v[..i]) and shift_head(&mut v[i..])
+//          -- std .. 2022 -- instead of insertion_sort_shift_left(&mut v[..i], i - 1) and
+//          insertion_sort_shift_right(&mut v[..i], 1).
+// Both routines run on rare paths of a rare step: the word is read there, nowhere else.
+static __device__ int g_std_form = 0;
+#define FCD_PDQ178_DEFINE_STD_FORM_SETTER(NAME)                                                     \
+    hipError_t NAME(int bits) {                                                                     \
+        const int v = bits & 3;                                                                     \
+        return hipMemcpyToSymbol(HIP_SYMBOL(pdq178::g_std_form), &v, sizeof(v));                    \
+    }
 // The list may sit behind a generic pointer (elem_t *) or an LDS one (pdq178_wave.h: ds_* instructions instead of
 // flat_* ones -- a third of the latency): the helpers take either.
 
@@ -105,7 +124,10 @@ FCD_PDQ_FN bool partial_insertion_sort(V v, int len) {
         if (i == len) return true;
         if (len < kShortestShifting) return false;
         swp(v, i - 1, i);
-        if (i >= 2) {
+        if (g_std_form & 2) {  // (std .. 2022)
+            insert_tail(v, i);               // shift_tail(&mut v[..i])
+            insert_head(v + i, len - i);     // shift_head(&mut v[i..])
+        } else if (i >= 2) {
             shift_left(v, i, i - 1);
             shift_right(v, i, 1);  // (1.78 hands v[..i] to both)
         }
@@ -141,10 +163,23 @@ FCD_PDQ_FN void break_patterns(V v, int len) {
     uint64_t modulus = 1;
     while (modulus < (uint64_t)len) modulus <<= 1;  // len.next_power_of_two()
     const int pos = len / 4 * 2;
+    const bool two_draws = (g_std_form & 1) != 0;  // (std 1.20 .. 2022: ((gen_u32() as u64) << 32) | (gen_u32() as u64))
+    uint32_t r32 = (uint32_t)len;
     for (int i = 0; i < 3; ++i) {
-        seed ^= seed << 13;
-        seed ^= seed >> 7;
-        seed ^= seed << 17;
+        if (two_draws) {
+            r32 ^= r32 << 13;
+            r32 ^= r32 >> 17;
+            r32 ^= r32 << 5;
+            seed = (uint64_t)r32 << 32;
+            r32 ^= r32 << 13;
+            r32 ^= r32 >> 17;
+            r32 ^= r32 << 5;
+            seed |= (uint64_t)r32;
+        } else {
+            seed ^= seed << 13;
+            seed ^= seed >> 7;
+            seed ^= seed << 17;
+        }
         uint64_t other = seed & (modulus - 1);
         if (other >= (uint64_t)len) other -= (uint64_t)len;
         swp(v, pos - 1 + i, (int)other);

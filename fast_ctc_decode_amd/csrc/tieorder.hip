@@ -86,4 +86,7 @@ hipError_t launch_pdq178_probe(uint64_t *lists, int64_t n_lists, int64_t stride,
     return hipGetLastError();
 }
 
+// this translation unit's copy of the replay's std-form word (pdq178.h), on the current device
+FCD_PDQ178_DEFINE_STD_FORM_SETTER(tieorder_set_pdq178_std_form)
+
 }  // namespace fcd

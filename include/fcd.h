@@ -96,10 +96,15 @@ enum {
  *   FCD_TIE_PDQ178 (default)  on a step with more than 20 candidates in which a candidate that survives the
  *                  truncation ties with another one, that quicksort is replayed on the node-ordered list -- by the
  *                  whole wavefront in the register kernels (csrc/pdq178_wave.h, pdq178_reg.h), by one lane in the
- *                  LDS-resident ones (csrc/pdq178.h); restated from memory of library/core/src/slice/sort.rs, as is
- *                  the oracle's: no Rust source or toolchain in the build image, see tools/verify/pdq178_check.rs
- *                  for the one-command check a holder of rustc 1.78.0 can run -- and the search adopts its order;
- *                  every other step is ranked exactly on (probability desc, node asc), which is the same thing.
+ *                  LDS-resident ones (csrc/pdq178.h) -- and the search adopts its order; every other step is ranked
+ *                  exactly on (probability desc, node asc), which is the same thing.  The quicksort was restated
+ *                  from memory of library/core/src/slice/sort.rs (no Rust source or toolchain in the build image)
+ *                  and then pinned, element for element, against a rustc-1.65 build of std found compiled in that
+ *                  image (tools/verify/rust165_pdqsort.py) -- all of it but the two routines std changed in 2023,
+ *                  whose LATER forms (Rust 1.78 as recalled) are the default.  The environment variable
+ *                  FCD_PDQ178_STD_FORM (0 .. 3, read at load time; bit 0: break_patterns' generator as until 2022,
+ *                  bit 1: partial_insertion_sort's shifting as until 2022) selects the earlier ones process-wide;
+ *                  tools/verify/pdq178_check.rs tells a holder of rustc 1.78.0 in one command which form it carries.
  *   FCD_TIE_STABLE ties always keep ascending node order (what rounds 1-3 shipped): one of the admissible answers
  *                  of an unstable sort, but not the one Rust 1.78 gives on about 0.05 % of BASELINE config-2 reads.
  * A handle follows the process default until fcd_set_tie_order names an order for it (FCD_TIE_DEFAULT: follow

@@ -13,6 +13,14 @@
 extern "C" {
 #endif
 
+/* Which FORM of the two routines Rust's std changed in 2023 the quicksort replay of FCD_TIE_PDQ178 follows (csrc/pdq178.h
+ * g_std_form; fcd.h, FCD_PDQ178_STD_FORM): bit 0 = break_patterns' generator as until 2022, bit 1 =
+ * partial_insertion_sort's shifting as until 2022; 0 = Rust 1.78 as recalled (the default), 3 = what a compiled
+ * rustc-1.65 std does (tools/verify/rust165_pdqsort.py).  The word is process-wide: this call stores it for handles
+ * created later and writes it to THIS handle's device at once (other devices that already hold handles keep theirs).
+ * For tests and for whoever has just learnt from tools/verify/pdq178_check.rs which form their toolchain carries. */
+int fcd_debug_set_pdq178_std_form(fcd_handle *h, int bits);
+int fcd_debug_get_pdq178_std_form(void);
 /* Test hook: lists (DEVICE u64 [n_lists][stride], lens DEVICE i32 [n_lists]) are sorted in place by the device
  * function the kernels run on tie-flagged steps: descending by the UPPER 32 bits of each element, equal keys in
  * the order Rust 1.78's sort_unstable_by leaves them in; the lower 32 bits ride along. */

@@ -256,10 +256,16 @@ DEFINE_STABLE_SORT(sp1_sort_prob, sp1, SP1_PROB_GREATER)
  * and slice reversal at 12 swaps, partial_insertion_sort on likely-sorted slices, partition_equal against the
  * predecessor pivot, BlockQuicksort partition_in_blocks with BLOCK = 128 and its cyclic block swaps,
  * break_patterns with the xorshift generator seeded by the length, heapsort once the imbalance budget
- * floor(log2 n) + 1 is spent).  UNVERIFIED: neither the Rust source nor a Rust toolchain exists in this
- * environment, so this cannot be checked against the real thing; every sort it performs is a correct
- * descending sort, only the order of EQUAL keys is at stake.  It exists to MEASURE how much that order could
- * matter (fcdo_set_unstable_sort, tools/pdqsort_ties.py).  Round 3 measured with it; since
+ * floor(log2 n) + 1 is spent).  Neither the Rust source nor a Rust toolchain exists in this environment; what does
+ * exist (found in round 5) is a rustc-1.65 build of std, compiled into libcst's native module with its symbols:
+ * tools/verify/rust165_pdqsort.py calls its core::slice::sort::recurse on (key, node) records.  With the EARLIER
+ * forms of the two routines std changed in 2023 (fcdo_set_pdq_std_form below) this restatement equals that binary
+ * element for element on every committed vector and on 1.7 million random lists of 2 .. 5000 elements (half of them
+ * reaching break_patterns, a fifth shifting in partial_insertion_sort, heapsort included): pivot choice, both
+ * partitions, the recursion with its limit and flags, the insertion sorts, heapsort and the reversal are PINNED to a
+ * compiled std.  The default forms of those two routines are Rust 1.78 as recalled -- the part that is still only
+ * recollection, and what tools/verify/pdq178_check.rs asks a 1.78 toolchain.  Every sort is a correct descending
+ * sort either way; only the order of EQUAL keys is at stake (tools/pdqsort_ties.py).  Since
  * round 4 it is the oracle's default and the kernels follow the same order (FCD_TIE_PDQ178, csrc/pdq178.h: a second
  * restatement, written separately, compared with this one element for element in tests/test_pdq178.py); "ties keep
  * ascending node order" (FCD_TIE_STABLE) remains selectable on both sides.
@@ -269,6 +275,32 @@ static int g_unstable_sort_mode = 1; /* 1 = the pdqsort restatement above (defau
                                       * 0 = the stable rule (FCD_TIE_STABLE) */
 void fcdo_set_unstable_sort(int mode) { g_unstable_sort_mode = mode ? 1 : 0; }
 int fcdo_get_unstable_sort(void) { return g_unstable_sort_mode; }
+/* The two routines of std's pdqsort that CHANGED between the toolchain a binary in this image was built with (rustc
+ * 1.65: libcst's native module, whose compiled core::slice::sort::recurse tools/verify/rust165_pdqsort.py calls) and
+ * the reference's 1.78, as far as the authors recall -- selectable so that the REST of the restatement can be checked
+ * against that binary (with both bits set it agrees with it on every committed vector, element for element):
+ *   bit 0  break_patterns' random numbers: 0 = `seed = len`, ONE usize-wide xorshift per number (64-bit: 13, 7, 17),
+ *          std 2023 .. 1.80; 1 = two 32-bit xorshift draws (13, 17, 5) glued into a usize, std 1.20 .. 2022;
+ *   bit 1  partial_insertion_sort after swapping the out-of-order pair: 0 = insertion_sort_shift_left(&mut v[..i], i - 1)
+ *          then insertion_sort_shift_right(&mut v[..i], 1) under `if i >= 2` (the 2023 refactor of the insertion sorts:
+ *          BOTH on v[..i]); 1 = shift_tail(&mut v[..i]) then shift_head(&mut v[i..]), std .. 2022.
+ * Default 0 = Rust 1.78 as recalled; the kernels restate form 0 only (csrc/pdq178.h says where the two spots are).
+ * Test hook. */
+static int g_pdq_std_form = 0;
+static _Thread_local int64_t g_pdq_break_calls = 0, g_pdq_shift_calls = 0;
+void fcdo_set_pdq_std_form(int bits) { g_pdq_std_form = bits & 3; }
+int fcdo_get_pdq_std_form(void) { return g_pdq_std_form; }
+/* how often this thread's quicksorts reached break_patterns / shifted elements in partial_insertion_sort */
+int64_t fcdo_pdq_break_patterns_calls(int reset) {
+    const int64_t n = g_pdq_break_calls;
+    if (reset) g_pdq_break_calls = 0;
+    return n;
+}
+int64_t fcdo_pdq_partial_shift_calls(int reset) {
+    const int64_t n = g_pdq_shift_calls;
+    if (reset) g_pdq_shift_calls = 0;
+    return n;
+}
 
 #define DEFINE_PDQSORT(NAME, TYPE, LESS)                                                                      \
     static void NAME##_swap(TYPE *a, TYPE *b) {                                                               \
@@ -318,7 +350,11 @@ int fcdo_get_unstable_sort(void) { return g_unstable_sort_mode; }
             if (i == len) return 1;                                                                           \
             if (len < SHORTEST_SHIFTING) return 0;                                                            \
             NAME##_swap(&v[i - 1], &v[i]);                                                                    \
-            if (i >= 2) {                                                                                     \
+            ++g_pdq_shift_calls;                                                                              \
+            if (g_pdq_std_form & 2) { /* std until the insertion-sort refactor of 2023 (bit 1, above) */      \
+                NAME##_insert_tail(v, i);            /* shift_tail(&mut v[..i]) */                            \
+                NAME##_insert_head(v + i, len - i);  /* shift_head(&mut v[i..]) */                            \
+            } else if (i >= 2) {                                                                              \
                 NAME##_shift_left(v, i, i - 1);  /* the smaller element to the left */                        \
                 NAME##_shift_right(v, i, 1);     /* (1.78 passes v[..i] here too) */                          \
             }                                                                                                 \
@@ -343,15 +379,28 @@ int fcdo_get_unstable_sort(void) { return g_unstable_sort_mode; }
         }                                                                                                     \
     }                                                                                                         \
     static void NAME##_break_patterns(TYPE *v, int64_t len) {                                                 \
+        ++g_pdq_break_calls;                                                                                  \
         if (len < 8) return;                                                                                  \
         uint64_t seed = (uint64_t)len;                                                                        \
+        uint32_t r32 = (uint32_t)len;                                                                         \
         uint64_t modulus = 1;                                                                                 \
         while (modulus < (uint64_t)len) modulus <<= 1; /* next_power_of_two */                                \
         int64_t pos = len / 4 * 2;                                                                            \
         for (int64_t i = 0; i < 3; ++i) {                                                                     \
-            seed ^= seed << 13;                                                                               \
-            seed ^= seed >> 7;                                                                                \
-            seed ^= seed << 17;                                                                               \
+            if (!(g_pdq_std_form & 1)) {                                                                      \
+                seed ^= seed << 13;                                                                           \
+                seed ^= seed >> 7;                                                                            \
+                seed ^= seed << 17;                                                                           \
+            } else { /* ((gen_u32() as u64) << 32) | (gen_u32() as u64) */                                    \
+                r32 ^= r32 << 13;                                                                             \
+                r32 ^= r32 >> 17;                                                                             \
+                r32 ^= r32 << 5;                                                                              \
+                seed = (uint64_t)r32 << 32;                                                                   \
+                r32 ^= r32 << 13;                                                                             \
+                r32 ^= r32 >> 17;                                                                             \
+                r32 ^= r32 << 5;                                                                              \
+                seed |= (uint64_t)r32;                                                                        \
+            }                                                                                                 \
             uint64_t other = seed & (modulus - 1);                                                            \
             if (other >= (uint64_t)len) other -= (uint64_t)len;                                               \
             NAME##_swap(&v[pos - 1 + i], &v[other]);                                                          \

@@ -13,10 +13,13 @@
  *
  * Parity status:
  *   - viterbi / beam_search / crf_beam_search / crf_greedy: pinned by KATs K1-K13, K16.
- *   - tie order of Rust's sort_unstable_by for > 20 candidates (pdqsort): PARITY UNPINNED;
- *     this restatement orders ties by ascending node index (what the <= 20 element
- *     insertion-sort path of Rust 1.78's sort_unstable does, because the list is first
- *     stably sorted by node).
+ *   - tie order of Rust's sort_unstable_by for > 20 candidates (pdqsort): restated (fcd_oracle.c,
+ *     DEFINE_PDQSORT; the default since round 4) and, since round 5, pinned against a rustc-1.65 build
+ *     of std found compiled in this image (tools/verify/rust165_pdqsort.py) -- all of it except the
+ *     later (2023) forms of break_patterns' generator and partial_insertion_sort's shifting, which are
+ *     Rust 1.78 AS RECALLED (tools/verify/pdq178_check.rs asks a 1.78 toolchain).  Up to 20 candidates
+ *     the sort is an insertion sort: ties keep ascending node order (the list is first stably sorted
+ *     by node); that rule for every length stays selectable (fcdo_set_unstable_sort(0)).
  *   - duplex: pinned by K14, K15, K16, K18; libm bit-level results (logf/expf/log1pf)
  *     are PARITY UNPINNED beyond those KATs.
  *
@@ -195,11 +198,19 @@ void fcdo_libm_apply(int which, const float *x, float *out, int64_t n); /* 0 exp
 
 /* Order of EQUAL probabilities in the prune of the beam searches (src/search.rs:122,262, src/duplex.rs:620,807:
  * sort_unstable_by).  0 (default): the stable rule -- what Rust's insertion sort does up to 20 candidates, and
- * what the kernels implement.  1: above 20 candidates, the order left by a restatement of Rust 1.78's pdqsort
- * written from memory (UNVERIFIED: no Rust source or toolchain here; see fcd_oracle.c).  Process-wide switch for
- * measurements (tools/pdqsort_ties.py); the tie counters are taken on the stably sorted list in both modes. */
+ * what FCD_TIE_STABLE selects in the kernels.  1: above 20 candidates, the order left by a restatement of Rust 1.78's
+ * pdqsort (written from memory; pinned in round 5 against a compiled rustc-1.65 std except for two routines std
+ * changed in 2023: see fcd_oracle.c) -- the default since round 4, like the kernels' FCD_TIE_PDQ178.  Process-wide
+ * switch; the tie counters are taken on the stably sorted list in both modes. */
 void fcdo_set_unstable_sort(int mode);
 int fcdo_get_unstable_sort(void);
+/* the two routines of std's pdqsort that changed between rustc 1.65 and 1.78 (fcd_oracle.c): bit 0 = break_patterns'
+ * generator as until 2022, bit 1 = partial_insertion_sort's shifting as until 2022; 0 = Rust 1.78 as recalled (default).
+ * And how often this thread's quicksorts reached either.  Test hooks: tools/verify/rust165_pdqsort.py */
+void fcdo_set_pdq_std_form(int bits);
+int fcdo_get_pdq_std_form(void);
+int64_t fcdo_pdq_break_patterns_calls(int reset);
+int64_t fcdo_pdq_partial_shift_calls(int reset);
 void fcdo_test_pdqsort(float *prob, int32_t *node, int64_t n);
 
 #ifdef __cplusplus

@@ -87,6 +87,13 @@ def _load():
     lib.fcdo_set_unstable_sort.argtypes = [i32]
     lib.fcdo_set_unstable_sort.restype = None
     lib.fcdo_get_unstable_sort.restype = i32
+    lib.fcdo_set_pdq_std_form.argtypes = [i32]
+    lib.fcdo_set_pdq_std_form.restype = None
+    lib.fcdo_get_pdq_std_form.restype = i32
+    lib.fcdo_pdq_break_patterns_calls.argtypes = [i32]
+    lib.fcdo_pdq_break_patterns_calls.restype = i64
+    lib.fcdo_pdq_partial_shift_calls.argtypes = [i32]
+    lib.fcdo_pdq_partial_shift_calls.restype = i64
     lib.fcdo_test_pdqsort.argtypes = [P, P, i64]
     lib.fcdo_test_pdqsort.restype = None
     return lib
@@ -408,7 +415,8 @@ def duplex_tie_steps(reset=False):
 
 class unstable_sort:
     """with unstable_sort("pdqsort"): the beam searches order EQUAL probabilities above 20 candidates the way the
-    oracle's restatement of Rust 1.78's pdqsort leaves them (UNVERIFIED, fcd_oracle.c) -- the default since round 4,
+    oracle's restatement of Rust 1.78's pdqsort leaves them (fcd_oracle.c: pinned against a compiled rustc-1.65 std
+    except for two routines std changed in 2023, tools/verify/rust165_pdqsort.py) -- the default since round 4,
     like the product's FCD_TIE_PDQ178; with unstable_sort("stable"): ties keep ascending node order (FCD_TIE_STABLE)."""
 
     def __init__(self, mode):
@@ -421,6 +429,30 @@ class unstable_sort:
     def __exit__(self, *exc):
         lib.fcdo_set_unstable_sort(self.prev)
         return False
+
+
+class pdq_std_form:
+    """with pdq_std_form(bits): the two routines of std's pdqsort that changed between rustc 1.65 and 1.78 take their
+    EARLIER form (bit 0: break_patterns' generator, bit 1: partial_insertion_sort's shifting; fcd_oracle.c) -- with
+    both, the restatement equals the compiled 1.65 routine tools/verify/rust165_pdqsort.py finds in this image.
+    0 = Rust 1.78 as recalled: the default, and the kernels' only form."""
+
+    def __init__(self, bits):
+        self.bits = int(bits)
+
+    def __enter__(self):
+        self.prev = lib.fcdo_get_pdq_std_form()
+        lib.fcdo_set_pdq_std_form(self.bits)
+
+    def __exit__(self, *exc):
+        lib.fcdo_set_pdq_std_form(self.prev)
+        return False
+
+
+def pdq_path_counts(reset=False):
+    """(break_patterns calls, partial_insertion_sort shifts) of this thread's quicksorts since the last reset"""
+    r = 1 if reset else 0
+    return int(lib.fcdo_pdq_break_patterns_calls(r)), int(lib.fcdo_pdq_partial_shift_calls(r))
 
 
 def pdqsort_desc(prob, node):

@@ -103,6 +103,16 @@ hipError_t hipMemGetInfo(size_t *free_b, size_t *total_b);
 hipError_t hipMemcpyAsync(void *dst, const void *src, size_t n, hipMemcpyKind k, hipStream_t s);
 hipError_t hipMemcpy(void *dst, const void *src, size_t n, hipMemcpyKind k);
 hipError_t hipMemset(void *dst, int v, size_t n);
+// `__device__` variables are plain globals here (shared by every emulated device)
+#define HIP_SYMBOL(x) (&(x))
+inline hipError_t hipMemcpyToSymbol(void *symbol, const void *src, size_t n) {
+    memcpy(symbol, src, n);
+    return hipSuccess;
+}
+inline hipError_t hipMemcpyFromSymbol(void *dst, const void *symbol, size_t n) {
+    memcpy(dst, symbol, n);
+    return hipSuccess;
+}
 hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t s);
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned flags);
 hipError_t hipStreamDestroy(hipStream_t s);

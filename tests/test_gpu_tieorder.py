@@ -190,3 +190,47 @@ def test_baseline_reads_that_depend_on_the_order(fcd):
                 got[order] = results(fcd, x, beam, 0.1, True, 0)
         differ = [reads[i] for i in range(len(reads)) if got["pdq178"][i] != got["stable"][i]]
         assert differ == [r for r in reads if r in (1198, 3588, 173, 257, 914)], differ
+
+
+def test_std_forms_of_the_replay_on_the_gpu(fcd):
+    """FCD_PDQ178_STD_FORM / fcd_debug_set_pdq178_std_form on the MI355X: under form 3 (the earlier forms of the two
+    routines std changed in 2023 -- what a compiled rustc-1.65 std does, tests/test_rust165_pdqsort.py) the serial and the
+    wave / register routines give the permutations the vector file lists for it, and whole searches equal the oracle
+    under the same form; back at form 0 everything is as before."""
+    import json
+    import os
+    torch = pytest.importorskip("torch")
+    from fast_ctc_decode_amd import _native as nat
+
+    class Dev:
+        def __init__(self, a):
+            self.t = torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).cuda()
+            self.ptr = self.t.data_ptr()
+
+    back = lambda d, shape, dt: d.t.cpu().numpy().view(dt).reshape(shape)  # noqa: E731
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify", "pdq178_vectors.json")
+    cases = [c for c in json.load(open(path))["cases"] if "perm_gp" in c]
+    lists = [np.array(c["bits"], np.uint32).view(np.float32) for c in cases]
+    rng = np.random.default_rng(31)
+    x = (rng.integers(0, 4, size=(6, 200, 5)) / 4.0).astype(np.float32)
+    x[:, :, 0] = np.maximum(x[:, :, 0], 0.25)
+    lib = nat.load()
+    h = nat.default_handle(0)
+    h.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        for form, key in ((3, "perm_gp"), (1, "perm_g"), (0, "perm")):
+            h.set_pdq178_std_form(form)
+            perms = [np.array(c.get(key, c["perm"]), np.int64) for c in cases]
+            out, lens = device_sort(lib, h, lists, Dev, back)
+            for i, perm in enumerate(perms):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), (form, i)
+            out, lens = device_coop_sort(lib, h, lists, 8, Dev, back)
+            for i, perm in enumerate(perms):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), (form, i)
+            with oracle.pdq_std_form(form):
+                for beam, kernels in ((12, (0, 1, 3)), (32, (1, 4))):
+                    for k in kernels:
+                        P.check_beam(fcd, x, beam, 0.0, kernel=k)
+    finally:
+        h.set_pdq178_std_form(0)
+        h.reset_stream()

@@ -141,3 +141,37 @@ def test_unknown_tie_order_in_the_environment_is_reported():
     env["FCD_TIE_ORDER"] = "stable"
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert r.returncode == 0 and r.stdout.strip() == "stable" and "FCD_TIE_ORDER" not in r.stderr
+
+
+def test_std_form_of_the_quicksort_replay_comes_from_the_environment():
+    """FCD_PDQ178_STD_FORM (include/fcd.h): read once at load time, applied to the device when a handle is created --
+    here on the emulated library: a list of the vector file whose permutation depends on the form comes out accordingly"""
+    import json
+    import os
+    import subprocess
+    import sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    doc = json.load(open(os.path.join(ROOT, "tools", "verify", "pdq178_vectors.json")))
+    idx = next(i for i, c in enumerate(doc["cases"]) if "perm_gp" in c and "perm_g" in c and "perm_p" in c)
+    code = (
+        "import sys, json, numpy as np\n"
+        "sys.path.insert(0, 'tests')\n"
+        "from emu_util import emulated_kernels\n"
+        "from fast_ctc_decode_amd import _native as nat\n"
+        "from test_pdq178 import device_sort, _HostBuf\n"
+        "c = json.load(open('tools/verify/pdq178_vectors.json'))['cases'][%d]\n"
+        "p = np.array(c['bits'], np.uint32).view(np.float32)\n"
+        "with emulated_kernels() as lib:\n"
+        "    h = nat.default_handle(0)\n"
+        "    out, lens = device_sort(lib, h, [p], _HostBuf, lambda d, shape, dt: d.a.reshape(shape))\n"
+        "    got = (out[0, :lens[0]] & np.uint64(0xFFFFFFFF)).astype(np.int64).tolist()\n"
+        "    print(lib.fcd_debug_get_pdq178_std_form(), [k for k in ('perm', 'perm_g', 'perm_p', 'perm_gp') if c[k] == got])\n" % idx)
+    for value, want in (("", "0 ['perm']"), ("1", "1 ['perm_g']"), ("2", "2 ['perm_p']"), ("3", "3 ['perm_gp']")):
+        env = dict(os.environ, FCD_PDQ178_STD_FORM=value)
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+        assert r.returncode == 0, r.stderr
+        assert r.stdout.strip().splitlines()[-1] == want, (value, r.stdout, r.stderr)
+        assert "FCD_PDQ178_STD_FORM" not in r.stderr
+    env = dict(os.environ, FCD_PDQ178_STD_FORM="7")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=600)
+    assert r.returncode == 0 and "FCD_PDQ178_STD_FORM" in r.stderr and r.stdout.strip().splitlines()[-1] == "0 ['perm']"

@@ -12,7 +12,7 @@ from oracle import oracle
 @pytest.fixture(autouse=True, params=["stable", "pdqsort"])
 def _tie_order_of_the_unstable_sort(request):
     """Every KAT must hold under both orders of EQUAL probabilities the oracle can impose above 20 candidates:
-    the stable rule and its (unverified) restatement of Rust 1.78's pdqsort -- the reference's vectors do not
+    the stable rule and its restatement of Rust 1.78's pdqsort -- the reference's vectors do not
     depend on that order."""
     with oracle.unstable_sort(request.param):
         yield

@@ -178,3 +178,77 @@ def test_committed_vectors_match_every_restatement_emulated():
         out, lens = device_coop_sort(lib, h, lists, 8, _HostBuf, lambda d, shape, dt: d.a.reshape(shape))
         for i, perm in enumerate(perms):
             assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), i
+
+
+@pytest.mark.parametrize("form,key", [(1, "perm_g"), (2, "perm_p"), (3, "perm_gp")])
+def test_std_forms_of_the_device_routines_emulated(form, key):
+    """FCD_PDQ178_STD_FORM / fcd_debug_set_pdq178_std_form: the EARLIER forms of the two routines std changed in 2023
+    (csrc/pdq178.h g_std_form) -- the serial routine and the wave / register ones must give the permutations the vector
+    file lists for that form (form 3 is what a compiled rustc-1.65 std produces: tests/test_rust165_pdqsort.py)"""
+    import json
+    import os
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify", "pdq178_vectors.json")
+    cases = [c for c in json.load(open(path))["cases"] if key in c or len(c["bits"]) in (50, 130, 257)]
+    assert sum(key in c for c in cases) > 50
+    lists = [np.array(c["bits"], np.uint32).view(np.float32) for c in cases]
+    perms = [np.array(c.get(key, c["perm"]), np.int64) for c in cases]
+    back = lambda d, shape, dt: d.a.reshape(shape)  # noqa: E731
+    with emulated_kernels() as lib:
+        h = nat.default_handle(0)
+        assert lib.fcd_debug_get_pdq178_std_form() == 0
+        h.set_pdq178_std_form(form)
+        try:
+            assert lib.fcd_debug_get_pdq178_std_form() == form
+            out, lens = device_sort(lib, h, lists, _HostBuf, back)
+            for i, perm in enumerate(perms):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), i
+            out, lens = device_coop_sort(lib, h, lists, 8, _HostBuf, back)
+            for i, perm in enumerate(perms):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), i
+            short = [(p, perm) for p, perm in zip(lists, perms) if len(p) <= 64]
+            out, lens = device_coop_sort(lib, h, [p for p, _ in short], 1, _HostBuf, back)  # (registers only)
+            for i, (_, perm) in enumerate(short):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), perm), i
+            assert lib.fcd_debug_set_pdq178_std_form(h.ptr, 4) != 0
+        finally:
+            h.set_pdq178_std_form(0)
+        out, lens = device_sort(lib, h, lists[:40], _HostBuf, back)  # back to the default form
+        for i, c in enumerate(cases[:40]):
+            assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), np.array(c["perm"], np.int64)), i
+
+
+def test_searches_follow_the_std_form_emulated():
+    """a whole search under std form 3 equals the oracle under the same form, on every kernel family (reads built to tie)"""
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    import fast_ctc_decode_amd as fcd
+    import test_gpu_parity as P
+    rng = np.random.default_rng(31)
+    sets = []
+    for N, beam, kernels in ((5, 12, (0, 1, 3)), (5, 32, (1, 4)), (7, 8, (3,))):
+        x = (rng.integers(0, 4, size=(3, 120, N)) / 4.0).astype(np.float32)
+        x[:, :, 0] = np.maximum(x[:, :, 0], 0.25)
+        sets.append((x, beam, kernels))
+
+    def decoded(x, beam):
+        out = oracle.batch_outputs(x.shape[0], x.shape[1])
+        lab, path, lens, st = oracle.beam_search_batch(x, beam, 0.0, True, 1, out=out)
+        return [(int(st[i]), lab[i, :lens[i]].tolist(), path[i, :lens[i]].tolist()) for i in range(x.shape[0])]
+
+    # (the reads really depend on the form: else the test below would say nothing)
+    plain = [decoded(x, beam) for x, beam, _ in sets]
+    with oracle.pdq_std_form(3):
+        earlier = [decoded(x, beam) for x, beam, _ in sets]
+    assert sum(a != b for u, v in zip(plain, earlier) for a, b in zip(u, v)) >= 3
+    with emulated_kernels():
+        h = nat.default_handle(0)
+        h.set_pdq178_std_form(3)
+        try:
+            with oracle.pdq_std_form(3):
+                for x, beam, kernels in sets:
+                    for k in kernels:
+                        P.check_beam(fcd, x, beam, 0.0, kernel=k)
+        finally:
+            h.set_pdq178_std_form(0)

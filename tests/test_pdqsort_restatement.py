@@ -1,5 +1,6 @@
-"""The oracle's restatement of Rust 1.78's pdqsort (oracle/fcd_oracle.c, DEFINE_PDQSORT; written from memory,
-UNVERIFIED against the real thing -- no Rust source or toolchain here).  What CAN be checked: every sort it
+"""The oracle's restatement of Rust 1.78's pdqsort (oracle/fcd_oracle.c, DEFINE_PDQSORT; written from memory; no
+Rust source or toolchain here -- tests/test_rust165_pdqsort.py pins it against a COMPILED rustc-1.65 std found in the
+image, except for the 2023 forms of two routines).  What can be checked without that binary: every sort it
 performs is a correct descending sort and a permutation on adversarial patterns (sorted, reversed, constant,
 few distinct keys, organ pipes: the inputs that reach partition_equal, break_patterns, the reversal in
 choose_pivot, partial_insertion_sort and heapsort); distinct keys give the unique answer; it is deterministic;

@@ -4,7 +4,8 @@
 
 Runs the oracle on BASELINE config 2 (beam 5) and on a config-3 shard (beam 32) twice -- with the stable tie
 rule (the oracle's default and the kernels' rule) and with the order its restatement of Rust 1.78's
-sort_unstable_by leaves above 20 candidates (oracle/fcd_oracle.c, written from memory, UNVERIFIED) -- and counts
+sort_unstable_by leaves above 20 candidates (oracle/fcd_oracle.c: written from memory, pinned since round 5 against a
+compiled rustc-1.65 std except for two routines std changed in 2023) -- and counts
 the reads whose (labels, path) differ, next to the tie counters that say which reads COULD differ."""
 import json
 import os
@@ -50,7 +51,7 @@ def compare(name, x, beam, thr, threads):
         "differing_reads_all_flagged_by_both_counters": bool(all(amb[i, 0] > 0 and amb[i, 1] > 0 for i in differ)),
         "counters_identical_in_both_modes": bool(np.array_equal(amb, b[4])),
         "seconds": round(time.perf_counter() - t0, 1),
-        "note": "pdqsort restatement written from memory of Rust 1.78 library/core/src/slice/sort.rs: UNVERIFIED",
+        "note": "pdqsort restatement written from memory of Rust 1.78 library/core/src/slice/sort.rs; pinned against a compiled rustc-1.65 std except for two routines std changed in 2023 (tools/verify/rust165_pdqsort.py)",
     }
     print(json.dumps(rec), flush=True)
     return rec

@@ -3,14 +3,17 @@
 of Rust 1.78's pattern-defeating quicksort produces (oracle/fcd_oracle.c, DEFINE_PDQSORT; the kernels' csrc/pdq178.h and
 csrc/pdq178_wave.h are tested element for element against it).
 
-Nobody in this image could run rustc, so the restatement is UNPINNED.  This file and
-pdq178_check.rs turn that into one command for whoever has the reference's toolchain:
+Nobody in this image could run rustc; a rustc-1.65 build of std found compiled in it pins everything but the 2023 forms
+of two routines (tools/verify/rust165_pdqsort.py).  This file and pdq178_check.rs turn the rest into
+one command for whoever has the reference's toolchain:
 
     rustc +1.78.0 -O tools/verify/pdq178_check.rs -o /tmp/pdq178_check && /tmp/pdq178_check tools/verify/pdq178_vectors.json
 
     python tools/verify/make_pdq178_vectors.py          # regenerates the file (deterministic)
 
-Format: {"meta": {...}, "cases": [{"bits": [u32 ...], "perm": [int ...]}, ...]}; the list handed to the sort is
+Format: {"meta": {...}, "cases": [{"bits": [u32 ...], "perm": [int ...] (, "perm_g" / "perm_p" / "perm_gp": [int ...])}, ...]}
+(the optional ones: the same list under the earlier forms of the two routines std changed in 2023, see meta.alternatives
+and tools/verify/rust165_pdqsort.py); the list handed to the sort is
 [(f32::from_bits(bits[i]), node = i) for i in 0..n] -- already in ascending node order, like the reference's list after
 its stable sort by node (src/search.rs:245) -- and perm[j] = the node the sorted list holds at position j."""
 import json
@@ -69,6 +72,7 @@ def lists():
 def main():
     cases = []
     differs = 0
+    alts = {"perm_g": 0, "perm_p": 0, "perm_gp": 0}
     for p in lists():
         n = len(p)
         with oracle.unstable_sort("pdqsort"):
@@ -77,7 +81,16 @@ def main():
         sp = p[perm]
         assert np.all(sp[:-1] >= sp[1:])
         differs += int(not np.array_equal(perm, np.argsort(-p, kind="stable")))
-        cases.append({"bits": p.view(np.uint32).tolist(), "perm": perm.tolist()})
+        case = {"bits": p.view(np.uint32).tolist(), "perm": perm.tolist()}
+        # the same list under the EARLIER forms of the two routines std changed in 2023 (fcd_oracle.c,
+        # fcdo_set_pdq_std_form): given only where the permutation differs
+        for key, form in (("perm_g", 1), ("perm_p", 2), ("perm_gp", 3)):
+            with oracle.unstable_sort("pdqsort"), oracle.pdq_std_form(form):
+                _, alt = oracle.pdqsort_desc(p, np.arange(n, dtype=np.int32))
+            if not np.array_equal(alt, perm):
+                case[key] = alt.tolist()
+                alts[key] += 1
+        cases.append(case)
     meta = {
         "what": "lists handed to sort_unstable_by(|a, b| b.probability().partial_cmp(&a.probability())...) and the permutation "
                 "this repository's restatement of Rust 1.78.0's core::slice::sort::quicksort produces",
@@ -86,13 +99,22 @@ def main():
         "cases": len(cases),
         "cases_where_the_order_differs_from_a_stable_sort": differs,
         "generator": "tools/verify/make_pdq178_vectors.py (numpy default_rng(178); oracle/fcd_oracle.c DEFINE_PDQSORT)",
+        "alternatives": "perm = Rust 1.78 as recalled (the kernels' order).  Two routines of std's pdqsort changed in 2023; where "
+                        "their EARLIER forms give another permutation it is listed too: perm_g = break_patterns drawing two "
+                        "32-bit xorshift numbers (13, 17, 5) per usize, perm_p = partial_insertion_sort calling shift_tail(&mut "
+                        "v[..i]) and shift_head(&mut v[i..]), perm_gp = both -- which is what the compiled rustc-1.65 std in this "
+                        "image produces on every list (tools/verify/rust165_pdqsort.py).  pdq178_check.rs says which one "
+                        "your toolchain agrees with",
+        "cases_with_alternatives": alts,
     }
     out = os.path.join(os.path.dirname(os.path.abspath(__file__)), "pdq178_vectors.json")
     with open(out, "w") as f:
         f.write('{"meta": %s,\n "cases": [\n' % json.dumps(meta))
         for i, c in enumerate(cases):
-            f.write('  {"bits": %s, "perm": %s}%s\n' % (json.dumps(c["bits"], separators=(",", ":")),
-                                                      json.dumps(c["perm"], separators=(",", ":")), "," if i + 1 < len(cases) else ""))
+            extra = "".join(', "%s": %s' % (k, json.dumps(c[k], separators=(",", ":"))) for k in ("perm_g", "perm_p", "perm_gp") if k in c)
+            f.write('  {"bits": %s, "perm": %s%s}%s\n' % (json.dumps(c["bits"], separators=(",", ":")),
+                                                        json.dumps(c["perm"], separators=(",", ":")), extra,
+                                                        "," if i + 1 < len(cases) else ""))
         f.write(" ]}\n")
     print(out, len(cases), "cases,", differs, "differ from the stable order,", os.path.getsize(out), "bytes")
 
