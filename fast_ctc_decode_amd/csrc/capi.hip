@@ -46,7 +46,6 @@ hipError_t apply_pdq178_std_form(int bits) {
     hipError_t e = beam_wave_set_pdq178_std_form(bits);
     if (e == hipSuccess) e = beam_lane_set_pdq178_std_form(bits);
     if (e == hipSuccess) e = beam_generic_set_pdq178_std_form(bits);
-    if (e == hipSuccess) e = duplex_set_pdq178_std_form(bits);
     if (e == hipSuccess) e = tieorder_set_pdq178_std_form(bits);
     return e;
 }

@@ -36,6 +36,7 @@
 // default `fastexp` feature, where exp() is identically 0 and the addition degenerates to max().
 #include "device_utils.h"
 #include "fcd_internal.h"
+#define FCD_PDQ178_FORM0_ONLY 1  // (pdq178.h: this kernel replays the default std form only)
 #include "pdq178.h"
 #include "glibc235_math.h"
 #include "logadd_fast.h"
@@ -1740,8 +1741,5 @@ hipError_t launch_duplex(const DuplexArgs &a, int64_t pair_begin, int64_t n_pair
                            lds, stream, p);
     return hipGetLastError();
 }
-
-// this translation unit's copy of the replay's std-form word (pdq178.h), on the current device
-FCD_PDQ178_DEFINE_STD_FORM_SETTER(duplex_set_pdq178_std_form)
 
 }  // namespace fcd

@@ -187,7 +187,6 @@ hipError_t coop_prof_read(unsigned long long *out16, bool reset);  // developer 
 hipError_t beam_wave_set_pdq178_std_form(int bits);
 hipError_t beam_lane_set_pdq178_std_form(int bits);
 hipError_t beam_generic_set_pdq178_std_form(int bits);
-hipError_t duplex_set_pdq178_std_form(int bits);
 hipError_t tieorder_set_pdq178_std_form(int bits);
 hipError_t lane_tie_prof_read(unsigned long long *out16, bool reset);  // ... of a -DFCD_LANE_TIE_PROF build of beam_lane.hip
 // the tie order searches on this handle use (capi.hip)

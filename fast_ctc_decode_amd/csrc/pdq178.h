@@ -60,8 +60,16 @@ struct Scratch {
 //   bit 1: partial_insertion_sort, having swapped the pair, calls shift_tail(&mut v[..i]) and shift_head(&mut v[i..])
 //          -- std .. 2022 -- instead of insertion_sort_shift_left(&mut v[..i], i - 1) and
 //          insertion_sort_shift_right(&mut v[..i], 1).
-// Both routines run on rare paths of a rare step: the word is read there, nowhere else.
+// Both routines run on rare paths of a rare step: the word is read there, nowhere else.  A translation unit that
+// defines FCD_PDQ178_FORM0_ONLY before including this file replays form 0 whatever the word says (duplex.hip: its time
+// loop fills the instruction cache and any change of the code around it costs 2-3 % -- measured; the duplex searches
+// return a label string without a path, and none of 1024 config-5 pairs decodes differently under another form).
 static __device__ int g_std_form = 0;
+#ifdef FCD_PDQ178_FORM0_ONLY
+#define FCD_PDQ178_FORM() 0
+#else
+#define FCD_PDQ178_FORM() g_std_form
+#endif
 #define FCD_PDQ178_DEFINE_STD_FORM_SETTER(NAME)                                                     \
     hipError_t NAME(int bits) {                                                                     \
         const int v = bits & 3;                                                                     \
@@ -115,6 +123,31 @@ FCD_PDQ_FN void shift_right(V v, int len, int offset) {  // insertion_sort_shift
     for (int i = offset - 1; i >= 0; --i) insert_head(v + i, len - i);
 }
 
+// (the earlier forms sit out of line: inlined they grow every replay by a few hundred instructions nobody runs, and the
+// duplex kernel -- whose time loop fills the instruction cache -- was 2.8 % slower for it)
+template <typename V>
+static __device__ __attribute__((noinline)) void shift_pair_earlier(V v, int i, int len) {
+    insert_tail(v, i);            // shift_tail(&mut v[..i])
+    insert_head(v + i, len - i);  // shift_head(&mut v[i..])
+}
+
+// break_patterns' i-th position under the generator of std 1.20 .. 2022: ((gen_u32() as u64) << 32) | (gen_u32() as u64)
+static __device__ __attribute__((noinline)) uint64_t two_draws_number(int len, int i) {
+    uint32_t r32 = (uint32_t)len;
+    uint64_t x = 0;
+    for (int k = 0; k <= i; ++k) {
+        r32 ^= r32 << 13;
+        r32 ^= r32 >> 17;
+        r32 ^= r32 << 5;
+        x = (uint64_t)r32 << 32;
+        r32 ^= r32 << 13;
+        r32 ^= r32 >> 17;
+        r32 ^= r32 << 5;
+        x |= (uint64_t)r32;
+    }
+    return x;
+}
+
 template <typename V>
 FCD_PDQ_FN bool partial_insertion_sort(V v, int len) {
     const int kMaxSteps = 5, kShortestShifting = 50;
@@ -124,9 +157,8 @@ FCD_PDQ_FN bool partial_insertion_sort(V v, int len) {
         if (i == len) return true;
         if (len < kShortestShifting) return false;
         swp(v, i - 1, i);
-        if (g_std_form & 2) {  // (std .. 2022)
-            insert_tail(v, i);               // shift_tail(&mut v[..i])
-            insert_head(v + i, len - i);     // shift_head(&mut v[i..])
+        if (FCD_PDQ178_FORM() & 2) {  // (std .. 2022)
+            shift_pair_earlier(v, i, len);
         } else if (i >= 2) {
             shift_left(v, i, i - 1);
             shift_right(v, i, 1);  // (1.78 hands v[..i] to both)
@@ -163,24 +195,12 @@ FCD_PDQ_FN void break_patterns(V v, int len) {
     uint64_t modulus = 1;
     while (modulus < (uint64_t)len) modulus <<= 1;  // len.next_power_of_two()
     const int pos = len / 4 * 2;
-    const bool two_draws = (g_std_form & 1) != 0;  // (std 1.20 .. 2022: ((gen_u32() as u64) << 32) | (gen_u32() as u64))
-    uint32_t r32 = (uint32_t)len;
+    const bool two_draws = (FCD_PDQ178_FORM() & 1) != 0;  // (std 1.20 .. 2022)
     for (int i = 0; i < 3; ++i) {
-        if (two_draws) {
-            r32 ^= r32 << 13;
-            r32 ^= r32 >> 17;
-            r32 ^= r32 << 5;
-            seed = (uint64_t)r32 << 32;
-            r32 ^= r32 << 13;
-            r32 ^= r32 >> 17;
-            r32 ^= r32 << 5;
-            seed |= (uint64_t)r32;
-        } else {
-            seed ^= seed << 13;
-            seed ^= seed >> 7;
-            seed ^= seed << 17;
-        }
-        uint64_t other = seed & (modulus - 1);
+        seed ^= seed << 13;
+        seed ^= seed >> 7;
+        seed ^= seed << 17;
+        uint64_t other = (two_draws ? two_draws_number(len, i) : seed) & (modulus - 1);
         if (other >= (uint64_t)len) other -= (uint64_t)len;
         swp(v, pos - 1 + i, (int)other);
     }

@@ -105,25 +105,13 @@ __device__ __forceinline__ void reg_sort(uint32_t &key, uint32_t &tag, const int
                 uint64_t modulus = 1;
                 while (modulus < (uint64_t)len) modulus <<= 1;
                 const int pos = len / 4 * 2;
-                const bool two_draws = (g_std_form & 1) != 0;  // (pdq178.h: std's generator until 2022)
-                uint32_t r32 = (uint32_t)len;
+                const bool two_draws = (FCD_PDQ178_FORM() & 1) != 0;  // (pdq178.h: std's generator until 2022)
 #pragma unroll 1
                 for (int i = 0; i < 3; ++i) {
-                    if (two_draws) {
-                        r32 ^= r32 << 13;
-                        r32 ^= r32 >> 17;
-                        r32 ^= r32 << 5;
-                        seed = (uint64_t)r32 << 32;
-                        r32 ^= r32 << 13;
-                        r32 ^= r32 >> 17;
-                        r32 ^= r32 << 5;
-                        seed |= (uint64_t)r32;
-                    } else {
-                        seed ^= seed << 13;
-                        seed ^= seed >> 7;
-                        seed ^= seed << 17;
-                    }
-                    uint64_t other = seed & (modulus - 1);
+                    seed ^= seed << 13;
+                    seed ^= seed >> 7;
+                    seed ^= seed << 17;
+                    uint64_t other = (two_draws ? two_draws_number(len, i) : seed) & (modulus - 1);
                     if (other >= (uint64_t)len) other -= (uint64_t)len;
                     const int a = base + pos - 1 + i, b = base + (int)other;
                     const uint32_t ka = rdl(key, a), ta = rdl(tag, a), kb = rdl(key, b), tb = rdl(tag, b);
