@@ -103,7 +103,9 @@ enum {
  *                  image (tools/verify/rust165_pdqsort.py) -- all of it but the two routines std changed in 2023,
  *                  whose LATER forms (Rust 1.78 as recalled) are the default.  The environment variable
  *                  FCD_PDQ178_STD_FORM (0 .. 3, read at load time; bit 0: break_patterns' generator as until 2022,
- *                  bit 1: partial_insertion_sort's shifting as until 2022) selects the earlier ones process-wide;
+ *                  bit 1: partial_insertion_sort's shifting as until 2022) selects the earlier ones process-wide
+ *                  for the 1-D searches (the duplex searches replay the default form only: csrc/pdq178.h says why;
+ *                  none of 1024 BASELINE config-5 pairs decodes differently under another form);
  *                  tools/verify/pdq178_check.rs tells a holder of rustc 1.78.0 in one command which form it carries.
  *   FCD_TIE_STABLE ties always keep ascending node order (what rounds 1-3 shipped): one of the admissible answers
  *                  of an unstable sort, but not the one Rust 1.78 gives on about 0.05 % of BASELINE config-2 reads.
