@@ -30,6 +30,18 @@ def compiled():
     return s
 
 
+def test_the_second_compiled_instance_agrees_too():
+    """libcst carries two monomorphisations (24-byte elements ascending by their first word, 16-byte ones DESCENDING by
+    their second): two separately compiled copies of the routine, one answer"""
+    s = R.Rust165Sort()
+    if not s.path or "897e37553bba" not in R.rustc_commit(s.path) or not s.select(1):
+        pytest.skip("no second callable core::slice::sort::recurse")
+    first = R.Rust165Sort()
+    assert first.select(0) and first.symbol != s.symbol
+    rep = R.compare(s)
+    assert rep["ok"] and rep["differ"][3] == [], rep["lines"]
+
+
 def test_committed_vectors_pin_the_restatement_to_a_compiled_std(compiled):
     rep = R.compare(compiled)
     assert rep["ok"], rep["lines"]

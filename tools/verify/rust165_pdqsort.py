@@ -8,7 +8,8 @@ with their local symbols -- the body of `sort_unstable_by_key`:
 
     recurse<T, F>(v: &mut [T], is_less: &mut F, pred: Option<&T>, limit: u32)      (rdi, rsi | rdx | rcx | r8d)
 
-one over 24-byte elements ordered by their first u64, one over 16-byte elements ordered by their second u64 (read off
+one over 24-byte elements in ascending order of their first u64, one over 16-byte elements in DESCENDING order of their
+second u64 (read off
 the disassembly: `cmp $0x15,%rsi` -- insertion sort up to 20 elements; `cmp $0x31` -- the ninther from 50; the compares
 themselves).  The comparator is inlined and the rest of an element is payload, so calling the routine on (key, node)
 records whose keys order like the reference's comparator (src/search.rs:262-269: greater probability first, equal
@@ -87,7 +88,8 @@ def load_base(path):
 class Rust165Sort:
     """sort(keys: uint64[n], payload: int64[n]) -> payload in the order the compiled routine leaves it (ascending keys)"""
 
-    LAYOUTS = ((24, 0, 8), (16, 8, 0))  # (element bytes, key offset, payload offset)
+    # (element bytes, key offset, payload offset, the comparator is `a.key > b.key`: the instance sorts DESCENDING)
+    LAYOUTS = ((24, 0, 8, False), (16, 8, 0, True))
 
     def __init__(self):
         self.path = native_path()
@@ -107,8 +109,11 @@ class Rust165Sort:
         self.candidates = [(name, proto(base + off)) for name, off in syms]
 
     def call(self, fn, layout, keys, payload):
-        size, koff, poff = layout
+        size, koff, poff, descending = layout
         n = len(keys)
+        keys = np.ascontiguousarray(keys, np.uint64)
+        if descending:  # the same comparison outcomes from the complemented keys
+            keys = ~keys
         buf = np.zeros(n * size + 64, np.uint8)
         rec = buf[:n * size].reshape(n, size)
         rec[:, koff:koff + 8] = np.ascontiguousarray(keys, np.uint64).view(np.uint8).reshape(n, 8)
@@ -117,6 +122,8 @@ class Rust165Sort:
         limit = int(n).bit_length()  # usize::BITS - len.leading_zeros()
         fn(buf.ctypes.data, n, ctypes.addressof(dummy), None, limit)
         out_k = rec[:, koff:koff + 8].copy().view(np.uint64).reshape(n)
+        if descending:
+            out_k = ~out_k
         out_p = rec[:, poff:poff + 8].copy().view(np.int64).reshape(n)
         return out_k, out_p
 
@@ -132,8 +139,8 @@ class Rust165Sort:
                 return False
         return True
 
-    def select(self):
-        """finds a (routine, layout) pair that behaves; each attempt runs in a child process first"""
+    def select(self, skip=0):
+        """finds a (routine, layout) pair that behaves -- the (skip + 1)-th one; each attempt runs in a child process first"""
         if not getattr(self, "candidates", None):
             return False
         for ci in range(len(self.candidates)):
@@ -141,6 +148,9 @@ class Rust165Sort:
                 r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe", str(ci), str(li)],
                                    capture_output=True, text=True, timeout=120)
                 if r.returncode == 0 and r.stdout.strip().endswith("ok"):
+                    if skip > 0:
+                        skip -= 1
+                        break  # (the next routine: a second layout of this one is not a second instance)
                     self.symbol, self.fn = self.candidates[ci]
                     self.layout = self.LAYOUTS[li]
                     return True
@@ -173,11 +183,19 @@ def main(argv):
     if not s.select():
         print("%s: no core::slice::sort::recurse that takes (key, payload) records found" % s.path)
         return 2
-    print("%s\n  rustc commit %s, %s, %d-byte elements" % (s.path, rustc_commit(s.path), s.symbol, s.layout[0]))
-    rep = compare(s, path)
-    for line in rep["lines"]:
-        print(line)
-    return 0 if rep["ok"] else 1
+    print("%s\n  rustc commit %s" % (s.path, rustc_commit(s.path)))
+    ok, skip = True, 0
+    while True:  # every compiled instance of the routine that takes (key, payload) records
+        print("%s, %d-byte elements, %s order of the key" % (s.symbol, s.layout[0], "descending" if s.layout[3] else "ascending"))
+        rep = compare(s, path)
+        for line in rep["lines"]:
+            print("  " + line)
+        ok = ok and rep["ok"]
+        skip += 1
+        s = Rust165Sort()
+        if not s.select(skip):
+            break
+    return 0 if ok else 1
 
 
 FORMS = ((3, "both routines as until 2022 (= what rustc 1.65 compiled)"), (1, "the generator as until 2022 only"),
