@@ -302,6 +302,15 @@ int64_t fcdo_pdq_partial_shift_calls(int reset) {
     return n;
 }
 
+/* Test hook (tools/verify/rust165_pdqsort.py, tests/test_rust165_pdqsort.py): an EXTERNAL routine with the signature of
+ * core::slice::sort::recurse<T, F> over 24-byte records ordered by their first u64 -- the one a rustc-1.65 build of std
+ * carries inside libcst's native module -- sorts in place of the restatement: the searches of this file then run on
+ * Rust's own quicksort.  The records' keys are the elements' ranks under the comparator (equal elements, equal keys), the
+ * second word says which element it is. */
+typedef void (*fcdo_external_recurse)(void *v, size_t len, void *is_less, const void *pred, uint32_t limit);
+static fcdo_external_recurse g_external_recurse = NULL;
+void fcdo_set_external_recurse(void *fn) { g_external_recurse = (fcdo_external_recurse)fn; }
+
 #define DEFINE_PDQSORT(NAME, TYPE, LESS)                                                                      \
     static void NAME##_swap(TYPE *a, TYPE *b) {                                                               \
         TYPE t = *a;                                                                                          \
@@ -592,6 +601,24 @@ int64_t fcdo_pdq_partial_shift_calls(int reset) {
     static void NAME(TYPE *v, int64_t len) {                                                                  \
         uint32_t limit = 0; /* usize::BITS - len.leading_zeros() = floor(log2 len) + 1 */                     \
         for (uint64_t n = (uint64_t)len; n; n >>= 1) ++limit;                                                 \
+        if (g_external_recurse && len >= 2) {                                                                 \
+            uint64_t *rec = (uint64_t *)malloc(sizeof(uint64_t) * 3 * (size_t)len);                           \
+            TYPE *copy = (TYPE *)malloc(sizeof(TYPE) * (size_t)len);                                          \
+            uint64_t dummy[8] = {0};                                                                          \
+            for (int64_t i = 0; i < len; ++i) {                                                               \
+                uint64_t key = 0; /* how many elements come strictly before this one */                       \
+                for (int64_t j = 0; j < len; ++j) key += LESS(&v[j], &v[i]) ? 1 : 0;                          \
+                rec[3 * i] = key;                                                                             \
+                rec[3 * i + 1] = (uint64_t)i;                                                                 \
+                rec[3 * i + 2] = 0;                                                                           \
+                copy[i] = v[i];                                                                               \
+            }                                                                                                 \
+            g_external_recurse(rec, (size_t)len, dummy, NULL, limit);                                         \
+            for (int64_t i = 0; i < len; ++i) v[i] = copy[rec[3 * i + 1]];                                    \
+            free(copy);                                                                                       \
+            free(rec);                                                                                        \
+            return;                                                                                           \
+        }                                                                                                     \
         NAME##_recurse(v, len, NULL, limit);                                                                  \
     }
 

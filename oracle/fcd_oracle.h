@@ -211,6 +211,8 @@ void fcdo_set_pdq_std_form(int bits);
 int fcdo_get_pdq_std_form(void);
 int64_t fcdo_pdq_break_patterns_calls(int reset);
 int64_t fcdo_pdq_partial_shift_calls(int reset);
+/* test hook: an external core::slice::sort::recurse over 24-byte (key, index, -) records replaces the restatement (NULL: off) */
+void fcdo_set_external_recurse(void *fn);
 void fcdo_test_pdqsort(float *prob, int32_t *node, int64_t n);
 
 #ifdef __cplusplus

@@ -94,6 +94,8 @@ def _load():
     lib.fcdo_pdq_break_patterns_calls.restype = i64
     lib.fcdo_pdq_partial_shift_calls.argtypes = [i32]
     lib.fcdo_pdq_partial_shift_calls.restype = i64
+    lib.fcdo_set_external_recurse.argtypes = [P]
+    lib.fcdo_set_external_recurse.restype = None
     lib.fcdo_test_pdqsort.argtypes = [P, P, i64]
     lib.fcdo_test_pdqsort.restype = None
     return lib
@@ -446,6 +448,22 @@ class pdq_std_form:
 
     def __exit__(self, *exc):
         lib.fcdo_set_pdq_std_form(self.prev)
+        return False
+
+
+class external_recurse:
+    """with external_recurse(address): the quicksort above 20 candidates is run by the routine at `address` -- a compiled
+    core::slice::sort::recurse over 24-byte records ordered by their first u64 (tools/verify/rust165_pdqsort.py) --
+    instead of the restatement.  Process-wide test hook."""
+
+    def __init__(self, address):
+        self.address = address
+
+    def __enter__(self):
+        lib.fcdo_set_external_recurse(C.c_void_p(self.address))
+
+    def __exit__(self, *exc):
+        lib.fcdo_set_external_recurse(None)
         return False
 
 

@@ -95,3 +95,47 @@ def test_random_lists_against_the_compiled_std(compiled):
             n_lists += 1
             assert np.array_equal(real, perm), (n, kind)
     assert reached > 200
+
+
+def test_whole_searches_on_the_compiled_quicksort(compiled):
+    """The oracle's beam searches with RUST'S OWN quicksort in place of the restatement (fcdo_set_external_recurse: the
+    compiled rustc-1.65 routine sorts every list above 20 candidates) decode every read exactly as the oracle does under
+    the earlier std forms -- plain, CRF-free 1-D searches at three beams and the duplex search -- and not as it does under
+    the later forms on some of them (the inputs are built to tie)."""
+    addr = compiled.address_of_ascending_24()
+    if addr is None:
+        pytest.skip("no instance over 24-byte ascending records")
+    rng = np.random.default_rng(165)
+
+    def decoded(x, beam):
+        out = oracle.batch_outputs(x.shape[0], x.shape[1])
+        lab, path, lens, st = oracle.beam_search_batch(x, beam, 0.0, True, 1, out=out)
+        return [(int(st[i]), lab[i, :lens[i]].tolist(), path[i, :lens[i]].tolist()) for i in range(x.shape[0])]
+
+    changed = 0
+    for N, beam, B, T in ((5, 12, 6, 150), (5, 32, 6, 150), (7, 8, 6, 150), (8, 64, 2, 100)):
+        x = (rng.integers(0, 4, size=(B, T, N)) / 4.0).astype(np.float32)
+        x[:, :, 0] = np.maximum(x[:, :, 0], 0.25)
+        with oracle.unstable_sort("pdqsort"):
+            with oracle.external_recurse(addr):
+                real = decoded(x, beam)
+            with oracle.pdq_std_form(3):
+                earlier = decoded(x, beam)
+            later = decoded(x, beam)
+        assert real == earlier, (N, beam)
+        changed += sum(a != b for a, b in zip(real, later))
+    assert changed >= 3
+    # the duplex search (its own element type and comparator through the same routine)
+    T = 300
+    x1 = rng.random((T, 5), dtype=np.float32)
+    x2 = (np.round(rng.random((T, 5)) * 4) / 4).astype(np.float32) + np.float32(0.01)
+    x1 /= np.linalg.norm(x1, axis=-1, keepdims=True)
+    x2 /= np.linalg.norm(x2, axis=-1, keepdims=True)
+    i = np.arange(T)
+    env = np.stack([np.maximum(0, i - 20), np.minimum(T, i + 20)], 1).astype(np.uint64)
+    with oracle.unstable_sort("pdqsort"):
+        with oracle.external_recurse(addr):
+            real = oracle.beam_search_duplex(x1, x2, "NACGT", env, 8, 0.0, True)
+        with oracle.pdq_std_form(3):
+            earlier = oracle.beam_search_duplex(x1, x2, "NACGT", env, 8, 0.0, True)
+    assert real == earlier

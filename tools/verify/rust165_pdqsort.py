@@ -30,6 +30,10 @@ insertion sorts and the earlier forms themselves to a rustc-compiled std -- and 
 difference must be on a list that reaches one of the two changed routines.  What remains for pdq178_check.rs (rustc 1.78
 proper) is whether 1.78 carries the later forms; the vectors say per list which form gives which permutation.
 
+The oracle can also run its SEARCHES on the compiled routine (fcdo_set_external_recurse: every list above 20 candidates
+is sorted by Rust's own code): `--searches` decodes the BASELINE configurations that way and compares with the oracle on
+its restatement under both forms.
+
 Test infrastructure only (tests/test_rust165_pdqsort.py runs it when the module is there); nothing in the product or in
 the oracle depends on libcst."""
 import ctypes
@@ -107,6 +111,7 @@ class Rust165Sort:
             return
         proto = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32)
         self.candidates = [(name, proto(base + off)) for name, off in syms]
+        self.addresses = {name: base + off for name, off in syms}
 
     def call(self, fn, layout, keys, payload):
         size, koff, poff, descending = layout
@@ -159,6 +164,18 @@ class Rust165Sort:
     def sort(self, keys, payload):
         return self.call(self.fn, self.layout, keys, payload)[1]
 
+    def address_of_ascending_24(self):
+        """the address of the instance over 24-byte records in ascending order of their first word (what the oracle's
+        fcdo_set_external_recurse expects), or None"""
+        for skip in (0, 1, 2):
+            t = Rust165Sort()
+            if not t.select(skip):
+                return None
+            if t.layout == self.LAYOUTS[0]:
+                self._keep = t  # (its mapping of the module stays)
+                return t.addresses[t.symbol]
+        return None
+
 
 def keys_of(p):
     """u64 keys that order like src/search.rs:262-269: a is `less` than b when its probability is GREATER; equal
@@ -175,6 +192,8 @@ def main(argv):
         ok = bool(getattr(s, "candidates", None)) and s.probe(int(argv[2]), int(argv[3]))
         print("ok" if ok else "no")
         return 0 if ok else 1
+    if len(argv) >= 2 and argv[1] == "--searches":
+        return searches(int(argv[2]) if len(argv) > 2 else 1024)
     path = argv[1] if len(argv) > 1 else os.path.join(ROOT, "tools", "verify", "pdq178_vectors.json")
     s = Rust165Sort()
     if not s.path:
@@ -196,6 +215,48 @@ def main(argv):
         if not s.select(skip):
             break
     return 0 if ok else 1
+
+
+def searches(n_config3):
+    """BASELINE config 2 (all 4096 reads), its rows at beam 12, and n_config3 reads of config 3 (beam 32): the oracle with
+    the compiled rustc-1.65 quicksort in place of its restatement, against the oracle under the earlier / later std forms"""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    from oracle import oracle
+    s = Rust165Sort()
+    if not s.path or not s.select():
+        print("no compiled core::slice::sort::recurse here")
+        return 2
+    addr = s.address_of_ascending_24()
+    if addr is None:
+        print("no instance over 24-byte ascending records")
+        return 2
+
+    def run(x, beam):
+        n, T = x.shape[0], x.shape[1]
+        out = oracle.batch_outputs(n, T)
+        lab, path, lens, st = oracle.beam_search_batch(x, beam, 0.1, True, os.cpu_count() or 1, out=out)
+        return [(int(st[i]), lab[i, :lens[i]].tobytes(), path[i, :lens[i]].tobytes()) for i in range(n)]
+
+    bad = 0
+    for name, x, beam in (("BASELINE config 2 (4096 reads, beam 5)", bench.make_batch(1, 4096), 5),
+                          ("config 2's rows at beam 12 (1024 reads)", bench.make_batch(1, 1024), 12),
+                          ("BASELINE config 3 (%d reads, beam 32)" % n_config3, bench.make_batch(1, n_config3), 32)):
+        t0 = time.time()
+        with oracle.unstable_sort("pdqsort"):
+            with oracle.external_recurse(addr):
+                real = run(x, beam)
+            with oracle.pdq_std_form(3):
+                earlier = run(x, beam)
+            later = run(x, beam)
+        d_e = sum(a != b for a, b in zip(real, earlier))
+        d_l = sum(a != b for a, b in zip(real, later))
+        bad += d_e
+        print("%s: the oracle ON THE COMPILED rustc-1.65 quicksort vs the oracle on its restatement -- earlier std forms: %d reads "
+              "differ; later forms (the default, Rust 1.78 as recalled): %d reads differ  (%.0f s)" % (name, d_e, d_l, time.time() - t0),
+              flush=True)
+    return 0 if bad == 0 else 1
 
 
 FORMS = ((3, "both routines as until 2022 (= what rustc 1.65 compiled)"), (1, "the generator as until 2022 only"),
