@@ -139,3 +139,17 @@ def test_whole_searches_on_the_compiled_quicksort(compiled):
         with oracle.pdq_std_form(3):
             earlier = oracle.beam_search_duplex(x1, x2, "NACGT", env, 8, 0.0, True)
     assert real == earlier
+
+
+def test_a_second_toolchain_version_agrees_where_the_image_has_one():
+    """cryptography's Rust binding in the image's conda environment was built in 2021 (rustc commit a178d0322ce2): an
+    older std still, the same pdqsort -- its compiled routine (comparator closure zero-sized: another call shape) must
+    agree with the restatement under the earlier forms as well"""
+    mods = R.other_modules()
+    if not mods:
+        pytest.skip("no other Rust-built module with a pre-2023 core::slice::sort::recurse here")
+    s = R.Rust165Sort(mods[0])
+    if not s.select():
+        pytest.skip("no callable core::slice::sort::recurse in %s" % mods[0])
+    rep = R.compare(s)
+    assert rep["ok"] and rep["differ"][3] == [], rep["lines"]

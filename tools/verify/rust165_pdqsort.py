@@ -89,14 +89,22 @@ def load_base(path):
     return None
 
 
+def other_modules():
+    """other Rust-built extension modules of this image known to carry a pre-2023 core::slice::sort::recurse with its
+    symbols (a second toolchain version for the same question): cryptography's binding in the image's conda environment
+    (rustc commit a178d0322ce2, 2021: its comparator closure is zero-sized and not passed at all)"""
+    import glob
+    return sorted(glob.glob("/opt/conda/lib/python3*/site-packages/cryptography/hazmat/bindings/_rust.abi3.so"))
+
+
 class Rust165Sort:
     """sort(keys: uint64[n], payload: int64[n]) -> payload in the order the compiled routine leaves it (ascending keys)"""
 
     # (element bytes, key offset, payload offset, the comparator is `a.key > b.key`: the instance sorts DESCENDING)
     LAYOUTS = ((24, 0, 8, False), (16, 8, 0, True))
 
-    def __init__(self):
-        self.path = native_path()
+    def __init__(self, path=None):
+        self.path = path or native_path()
         self.fn = None
         self.layout = None
         self.symbol = None
@@ -109,8 +117,12 @@ class Rust165Sort:
         base = load_base(self.path)
         if base is None:
             return
+        # two shapes of the call: (v.ptr, v.len, &mut is_less, pred, limit), or without the closure when it is zero-sized
         proto = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32)
+        proto_nc = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_uint32)
         self.candidates = [(name, proto(base + off)) for name, off in syms]
+        self.candidates_nc = [(name, proto_nc(base + off)) for name, off in syms]
+        self.no_closure = False
         self.addresses = {name: base + off for name, off in syms}
 
     def call(self, fn, layout, keys, payload):
@@ -125,7 +137,10 @@ class Rust165Sort:
         rec[:, poff:poff + 8] = np.ascontiguousarray(payload, np.int64).view(np.uint8).reshape(n, 8)
         dummy = ctypes.create_string_buffer(64)  # is_less: the comparator is inlined, its environment is never read
         limit = int(n).bit_length()  # usize::BITS - len.leading_zeros()
-        fn(buf.ctypes.data, n, ctypes.addressof(dummy), None, limit)
+        if self.no_closure:
+            fn(buf.ctypes.data, n, None, limit)
+        else:
+            fn(buf.ctypes.data, n, ctypes.addressof(dummy), None, limit)
         out_k = rec[:, koff:koff + 8].copy().view(np.uint64).reshape(n)
         if descending:
             out_k = ~out_k
@@ -134,7 +149,7 @@ class Rust165Sort:
 
     def probe(self, index, layout_index):
         """(in a child process: a wrong guess may crash) does candidate `index` sort records of this layout?"""
-        name, fn = self.candidates[index]
+        name, fn = (self.candidates_nc if self.no_closure else self.candidates)[index]
         rng = np.random.default_rng(5)
         for n in (30, 77, 300):
             keys = rng.permutation(n).astype(np.uint64) * 3 + 1
@@ -142,23 +157,35 @@ class Rust165Sort:
             k, p = self.call(fn, self.LAYOUTS[layout_index], keys, pay)
             if not (np.all(k[:-1] <= k[1:]) and np.array_equal(keys[p - 1000], k)):
                 return False
-        return True
+        # a call of the wrong shape may still sort -- by heapsort, with the limit read as 0: it must be the quicksort
+        keys = np.array([3, 3, 0, 3, 2, 1, 2, 0, 0, 1, 2, 2, 2, 0, 0, 1, 3, 0, 3, 3, 2], np.uint64)
+        want = [8, 17, 2, 14, 13, 7, 15, 5, 9, 6, 10, 11, 12, 4, 20, 1, 0, 16, 3, 18, 19]
+        _, p = self.call(fn, self.LAYOUTS[layout_index], keys, np.arange(21, dtype=np.int64))
+        if self.LAYOUTS[layout_index][3]:
+            return True  # (the descending instance orders equal keys its own way: checked against the restatement later)
+        return p.tolist() == want
 
     def select(self, skip=0):
         """finds a (routine, layout) pair that behaves -- the (skip + 1)-th one; each attempt runs in a child process first"""
         if not getattr(self, "candidates", None):
             return False
         for ci in range(len(self.candidates)):
+            found = False
             for li in range(len(self.LAYOUTS)):
-                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe", str(ci), str(li)],
-                                   capture_output=True, text=True, timeout=120)
-                if r.returncode == 0 and r.stdout.strip().endswith("ok"):
-                    if skip > 0:
-                        skip -= 1
-                        break  # (the next routine: a second layout of this one is not a second instance)
-                    self.symbol, self.fn = self.candidates[ci]
-                    self.layout = self.LAYOUTS[li]
-                    return True
+                for nc in (0, 1):
+                    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe", str(ci), str(li), str(nc), self.path],
+                                       capture_output=True, text=True, timeout=120)
+                    if r.returncode == 0 and r.stdout.strip().endswith("ok"):
+                        found = True
+                        if skip > 0:
+                            skip -= 1
+                            break  # (the next routine: a second layout of this one is not a second instance)
+                        self.no_closure = bool(nc)
+                        self.symbol, self.fn = (self.candidates_nc if nc else self.candidates)[ci]
+                        self.layout = self.LAYOUTS[li]
+                        return True
+                if found:
+                    break
         return False
 
     def sort(self, keys, payload):
@@ -168,10 +195,10 @@ class Rust165Sort:
         """the address of the instance over 24-byte records in ascending order of their first word (what the oracle's
         fcdo_set_external_recurse expects), or None"""
         for skip in (0, 1, 2):
-            t = Rust165Sort()
+            t = Rust165Sort(self.path)
             if not t.select(skip):
                 return None
-            if t.layout == self.LAYOUTS[0]:
+            if t.layout == self.LAYOUTS[0] and not t.no_closure:
                 self._keep = t  # (its mapping of the module stays)
                 return t.addresses[t.symbol]
         return None
@@ -188,7 +215,8 @@ def keys_of(p):
 
 def main(argv):
     if len(argv) >= 4 and argv[1] == "--probe":
-        s = Rust165Sort()
+        s = Rust165Sort(argv[5] if len(argv) > 5 else None)
+        s.no_closure = len(argv) > 4 and argv[4] == "1"
         ok = bool(getattr(s, "candidates", None)) and s.probe(int(argv[2]), int(argv[3]))
         print("ok" if ok else "no")
         return 0 if ok else 1
@@ -214,6 +242,15 @@ def main(argv):
         s = Rust165Sort()
         if not s.select(skip):
             break
+    for extra in other_modules():  # a second toolchain version, if the image has one
+        s = Rust165Sort(extra)
+        if s.select():
+            print("%s\n  rustc commit %s\n%s, %d-byte elements, %s order of the key" % (extra, rustc_commit(extra), s.symbol, s.layout[0],
+                  "descending" if s.layout[3] else "ascending"))
+            rep = compare(s, path)
+            for line in rep["lines"]:
+                print("  " + line)
+            ok = ok and rep["ok"]
     return 0 if ok else 1
 
 
@@ -294,7 +331,7 @@ def compare(s, path=None):
     only_shift = [i for i in differ[2] if not reach[2][i][0]]    # shifting old, generator new: ... needs break_patterns
     lines.append("differences under the default forms on lists that reach NEITHER changed routine: %d" % len(unexplained))
     ok = not differ[3] and not unexplained and not only_gen and not only_shift
-    lines.append("PINNED to the compiled rustc-1.65 std except for the two routines std changed in 2023" if ok
+    lines.append("PINNED to this compiled std except for the two routines std changed in 2023" if ok
                  else "NOT pinned: see the counts above")
     return {"ok": ok, "lines": lines, "differ": differ}
 
