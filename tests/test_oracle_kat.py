@@ -9,11 +9,36 @@ import kat_cases
 from oracle import oracle
 
 
-@pytest.fixture(autouse=True, params=["stable", "pdqsort"])
+_COMPILED = {}
+
+
+def _compiled_recurse():
+    """address of the rustc-1.65 core::slice::sort::recurse libcst's native module carries (tools/verify/rust165_pdqsort.py),
+    or None"""
+    if "addr" not in _COMPILED:
+        import os
+        import sys
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "verify"))
+        import rust165_pdqsort as R
+        s = R.Rust165Sort()
+        ok = bool(s.path) and "897e37553bba" in R.rustc_commit(s.path) and s.select()
+        _COMPILED["addr"] = s.address_of_ascending_24() if ok else None
+        _COMPILED["keep"] = s
+    return _COMPILED["addr"]
+
+
+@pytest.fixture(autouse=True, params=["stable", "pdqsort", "rustc165"])
 def _tie_order_of_the_unstable_sort(request):
-    """Every KAT must hold under both orders of EQUAL probabilities the oracle can impose above 20 candidates:
-    the stable rule and its restatement of Rust 1.78's pdqsort -- the reference's vectors do not
-    depend on that order."""
+    """Every KAT must hold under every order of EQUAL probabilities the oracle can impose above 20 candidates: the stable
+    rule, its restatement of Rust 1.78's pdqsort, and -- where the image has it -- Rust's OWN quicksort, compiled by rustc
+    1.65, sorting in the restatement's place.  The reference's vectors do not depend on that order."""
+    if request.param == "rustc165":
+        addr = _compiled_recurse()
+        if addr is None:
+            pytest.skip("no compiled core::slice::sort::recurse here")
+        with oracle.unstable_sort("pdqsort"), oracle.external_recurse(addr):
+            yield
+        return
     with oracle.unstable_sort(request.param):
         yield
 
