@@ -153,3 +153,50 @@ def test_a_second_toolchain_version_agrees_where_the_image_has_one():
         pytest.skip("no callable core::slice::sort::recurse in %s" % mods[0])
     rep = R.compare(s)
     assert rep["ok"] and rep["differ"][3] == [], rep["lines"]
+
+
+def test_the_kernels_routines_against_the_compiled_std_directly_emulated(compiled):
+    """csrc/pdq178.h (serial) and csrc/pdq178_wave.h + pdq178_reg.h (the whole wavefront; registers only up to 64
+    elements) -- the code the GPU kernels replay ties with, here on the lockstep emulator under std form 3 -- against
+    the compiled rustc-1.65 routine itself, without the oracle in between"""
+    from emu_util import emulated_kernels
+    from fast_ctc_decode_amd import _native as nat
+    from test_pdq178 import _HostBuf, device_coop_sort, device_sort
+    rng = np.random.default_rng(1650)
+    lists = []
+    for _ in range(260):
+        n = int(rng.integers(21, 400))
+        kind = int(rng.integers(0, 4))
+        if kind == 0:
+            p = rng.random(n, dtype=np.float32)
+        elif kind == 1:
+            k = int(rng.integers(1, 9))
+            p = rng.random(k, dtype=np.float32)[rng.integers(0, k, n)]
+        elif kind == 2:
+            p = np.sort(rng.random(n, dtype=np.float32))[::-1].copy()
+            p = (np.round(p * 16) / 16).astype(np.float32)
+            for _ in range(int(rng.integers(0, 5))):
+                i, j = rng.integers(0, n, 2)
+                p[i], p[j] = p[j], p[i]
+        else:
+            h = rng.random((n + 1) // 2, dtype=np.float32)
+            p = np.repeat(h, 2)[:n][rng.permutation(n)]
+        lists.append(np.ascontiguousarray(p, np.float32))
+    want = [compiled.sort(R.keys_of(p), np.arange(len(p), dtype=np.int64)) for p in lists]
+    back = lambda d, shape, dt: d.a.reshape(shape)  # noqa: E731
+    with emulated_kernels() as lib:
+        h = nat.default_handle(0)
+        h.set_pdq178_std_form(3)
+        try:
+            out, lens = device_sort(lib, h, lists, _HostBuf, back)
+            for i, w in enumerate(want):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), w), i
+            out, lens = device_coop_sort(lib, h, lists, 8, _HostBuf, back)
+            for i, w in enumerate(want):
+                assert np.array_equal((out[i, :lens[i]] & np.uint64(0xFFFFFFFF)).astype(np.int64), w), i
+            short = [i for i, p in enumerate(lists) if len(p) <= 64]
+            out, lens = device_coop_sort(lib, h, [lists[i] for i in short], 1, _HostBuf, back)
+            for j, i in enumerate(short):
+                assert np.array_equal((out[j, :lens[j]] & np.uint64(0xFFFFFFFF)).astype(np.int64), want[i]), i
+        finally:
+            h.set_pdq178_std_form(0)
