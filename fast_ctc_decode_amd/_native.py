@@ -26,7 +26,7 @@ SYMBOLS = [
     "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
     "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev", "fcd_debug_pdq178_coop_sort_dev", "fcd_debug_pdq178_coop_profile",
     "fcd_debug_set_pdq178_std_form", "fcd_debug_get_pdq178_std_form",
-    "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile",
+    "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile", "fcd_debug_set_duplex_kernel",
     "fcd_viterbi_search_dev", "fcd_viterbi_search_host",
     "fcd_beam_search_dev", "fcd_beam_search_host", "fcd_beam_search_profile_dev",
     "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k", "fcd_crf_beam_search_host",
@@ -134,6 +134,7 @@ def bind(lib):
     lib.fcd_debug_pdq178_coop_profile.argtypes = [P, P, i32]
     lib.fcd_debug_set_first_pass_divisor.argtypes = [P, i32]
     lib.fcd_debug_set_duplex_profile.argtypes = [P, P]
+    lib.fcd_debug_set_duplex_kernel.argtypes = [P, C.c_int]
     lib.fcd_last_kernel_ms.argtypes = [P]
     lib.fcd_last_kernel_ms.restype = C.c_double
     lib.fcd_timing_reset.argtypes = [P]

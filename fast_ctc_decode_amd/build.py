@@ -14,8 +14,11 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libfcd_hip.so")
-SOURCES = ["capi.hip", "beam_generic.hip", "beam_wave.hip", "viterbi.hip", "duplex.hip", "envelope.hip", "beam_lane.hip", "pack.hip", "coalesce.hip", "hostjob.hip", "comm.hip", "tieorder.hip"]
-HEADERS = ["fcd_internal.h", "device_utils.h", "logadd_fast.h", "pdq178.h", "pdq178_wave.h", "glibc235_math.h", "beam_wave_step.inc", os.path.join("..", "..", "include", "fcd.h"), os.path.join("..", "..", "include", "fcd_debug.h")]
+# every translation unit and every header / include file under csrc/ (listed by glob, so that a new file can never be
+# missing from the staleness test of needs_build(): a forgotten header once meant a stale libfcd_hip.so loaded silently)
+SOURCES = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+HEADERS = sorted(f for f in os.listdir(CSRC) if f.endswith((".h", ".inc"))) + [
+    os.path.join("..", "..", "include", f) for f in sorted(os.listdir(os.path.join(HERE, "..", "include"))) if f.endswith(".h")]
 FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",

@@ -600,6 +600,13 @@ int fcd_debug_set_duplex_profile(fcd_handle *h, uint32_t *cycles) {
     return FCD_OK;
 }
 
+int fcd_debug_set_duplex_kernel(fcd_handle *h, int which) {
+    if (!h || which < 0 || which > 2) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    h->duplex_kernel = which;
+    return FCD_OK;
+}
+
 double fcd_last_kernel_ms(fcd_handle *h) {
     if (!h) return -1.0;
     std::lock_guard<std::recursive_mutex> g(h->mu);
@@ -782,12 +789,25 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     int width = 0;
     FCD_HIP(h, hipMemcpyAsync(&width, d_width, sizeof(int), hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipStreamSynchronize(h->stream));  // ring capacity is needed to size the arena
-    const int Wcap = std::max(width, 1) + 2;
+    // Which kernel: the slot-resident one (duplex_slots.hip) wherever it fits -- beam_size * N <= 64 and the live nodes'
+    // rings next to the read-2 tile in 64 KiB of LDS -- the any-shape one (duplex.hip) otherwise.
+    const int tie = effective_tie_order(h);
+    static const int env_kernel = [] {
+        const char *e = getenv("FCD_DUPLEX_KERNEL");  // "legacy" / "slots": A/B and test aid
+        return e ? (!strcmp(e, "legacy") ? 1 : (!strcmp(e, "slots") ? 2 : 0)) : 0;
+    }();
+    const int want = h->duplex_kernel ? h->duplex_kernel : env_kernel;
+    const bool fits = duplex_slots_supported((int)beam_size, N, S, std::max(width, 1), tie);
+    if (want == 2 && !fits) return fail(h, FCD_E_UNSUPPORTED, "duplex kernel: the slot-resident kernel does not cover this shape");
+    const bool slots = fits && want != 1;
+    const int Wcap = slots ? duplex_slots_ring_rows(std::max(width, 1)) : std::max(width, 1) + 2;
+    const int NLp = (NL + 3) & ~3;
 
     const int64_t cap_nodes = (std::max<int64_t>(in1->T, 1) * beam_size * NL + 8 + 3) & ~3ll;
     if (cap_nodes >= (1ll << 30)) return fail(h, FCD_E_UNSUPPORTED, "tree arena above 2^30 nodes per pair");
-    const size_t per_pair = (size_t)cap_nodes * (sizeof(int4) + 8 + (size_t)NL * 4 + (size_t)Wcap * 12) +
-                            (size_t)(in2->T + 1) * 4 + 64;
+    const size_t per_node = slots ? 2 * sizeof(int4) + (size_t)NLp * 4 + (size_t)Wcap * 4
+                                  : sizeof(int4) + 8 + (size_t)NL * 4 + (size_t)Wcap * 12;
+    const size_t per_pair = (size_t)cap_nodes * per_node + (((size_t)(in2->T + 1) * 4 + 64 + 15) & ~(size_t)15);
     const int64_t budget = workspace_budget(h);
     int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_pair);
     chunk = std::min<int64_t>(chunk, B);
@@ -808,21 +828,28 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.init1_stride = is_crf ? crf->s1 : 0; a.init2_stride = is_crf ? crf->s2 : 0;
     char *base = reinterpret_cast<char *>(h->arena);
     a.meta = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
-    a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
-    a.rlo = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * 4;
-    a.rows = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * NL * 4;
-    a.vec = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * (size_t)Wcap * 12;
+    a.aux = nullptr; a.nmax = nullptr; a.rlo = nullptr; a.NLp = NLp;
+    if (slots) {
+        a.aux = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
+        a.vec = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * (size_t)Wcap * 4;  // (16-byte aligned rings)
+        a.rows = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * NLp * 4;
+    } else {
+        a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
+        a.rlo = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * 4;
+        a.rows = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * NL * 4;
+        a.vec = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * (size_t)Wcap * 12;
+    }
     a.rootgap = reinterpret_cast<float *>(base);
     a.cap_nodes = cap_nodes; a.Wcap = Wcap;
-    // tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
+    // any-shape kernel: tile the envelope window through LDS when it fits next to the beam (48 KiB budget)
     // (and keep the beam entries' windows resident there: one LDS buffer per beam slot, handed over by lane votes)
-    a.staged = duplex_lds_bytes((int)beam_size, N, Wcap - 2, S, effective_tie_order(h)) <= 48 * 1024 && beam_size <= 64 ? 1 : 0;
+    a.staged = !slots && duplex_lds_bytes((int)beam_size, N, Wcap - 2, S, tie) <= 48 * 1024 && beam_size <= 64 ? 1 : 0;
     a.out = to_desc(out);
     a.prof = h->duplex_prof;
-    a.tie_order = effective_tie_order(h);
+    a.tie_order = tie;
     for (int64_t begin = 0; begin < B; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, B - begin);
-        FCD_HIP(h, launch_duplex(a, begin, n, h->stream));
+        FCD_HIP(h, slots ? launch_duplex_slots(a, begin, n, h->stream) : launch_duplex(a, begin, n, h->stream));
     }
     tm.stop();
     return FCD_OK;

@@ -1,0 +1,1138 @@
+// duplex_slots.hip -- 2D pair-consensus beam search, duplex::beam_search / duplex::crf_beam_search
+// (/root/reference/src/duplex.rs:443-650, :652-834), one read PAIR per wavefront: the SLOT-RESIDENT kernel (r06).
+//
+// Same search, same arithmetic and the same results as duplex.hip's kernel (which stays the any-shape fallback); what
+// changed is where things live, so that a time step costs its window builds and little else:
+//
+//  * SLOTS.  beam_size * N <= 64.  Every tree node that is "live" in a step -- the beam entries and the nodes the step
+//    creates -- owns one of P = beam_size * N slots for as long as it stays live: an LDS ring with its forward window
+//    over read 2 and one word per field (node, label, parent, bounds, running maximum, children ...) in LDS arrays
+//    indexed by slot.  Re-ranking the beam moves three words per entry (slot, label / gap probability); a new node
+//    that survives the prune keeps the slot it was built in; nothing is copied when the beam changes.
+//  * WINDOWS ARE ONE FLOAT PER ROW.  A window row of the reference is (label, gap) (ProbPair, :82-150).  Children read a
+//    parent's label (+) gap, or -- the repeated label -- its gap alone (:234-240); a node's own continuation needs the
+//    last row's label only.  gap_t = (label_{t-1} (+) gap_{t-1}) (x) blank_t (:232) is recomputed from the stored sum
+//    of row t - 1 where it is needed (bit-identical: the same f32 addition on the same operands), so a ring holds
+//    label (+) gap per row, the last label is one field, and `vfrom` remembers the row whose predecessor was "zero".
+//    Rings hold Wcap4 >= widest envelope + 4 rows, slot = row mod Wcap4; the reference's discard_until (:181-191) is an
+//    offset update.
+//  * HBM IS WRITTEN ON EVICTION ONLY.  A node's ring and record go to its arena entry when it stops being live (a
+//    new node the prune drops at once, a beam entry that falls out) -- it may come back as the child of a beam entry
+//    (:546-566), and then ring and record are read back into a free slot.  12 bytes per window row written through at
+//    build time became 4 bytes written once: config 5's 23 GB of writes -> ~7 GB.
+//  * READ 2 IS A RING TOO.  The rows of read 2 inside the envelope live in LDS transposed ([state * N + label][row mod
+//    Wcap4]); a step loads the rows the envelope gained (asked for one step ahead), not the window.
+//  * The per-step bookkeeping is wave-scope: no __syncthreads(), cross-lane traffic by ds_bpermute / v_readlane,
+//    exact rank by counting 64-bit keys, ties looked for in the ranked probability words.
+//  * Window builds.  logsumexp: a pair of lanes per new node (label chain / sum chain, as before) on a BRANCH-FREE
+//    log-add: the two "Ziv test failed, take the library routine" exits of LogSpace::add (1e-6 of the arguments) are
+//    accumulated in a flag and the whole pass is redone on the exact routine when any lane raised it -- the dependent
+//    chain no longer carries two divergent branches per row.  max: one lane per node, four rows per trip (16-byte LDS
+//    reads of coefficients and parent rows, one 16-byte store), LogSpace::add's max flavour as v_max_f32 -- which
+//    differs from it only when the label chain holds a NaN (the FIRST operand of (+); duplex.rs:57-61): detected per
+//    row, and such a pass is redone on the exact routine.
+//
+// Everything else follows duplex.hip line for line in meaning: envelope check (:485-488), sort by node + extension
+// (:490-522, :338-387) with the reference's quirks (stale windows of re-entering nodes, the extension's repeat test
+// without collapse_repeats :512, assert!(current_end < upper_bound) -> FCD_ST_BAD_STATE), expansion (:526-593), merge in
+// the reference's order (max mode's (+) is not commutative once a NaN takes part), prob_2_max refresh (:613-618), NaN
+// check, sort_unstable_by's order of equal probabilities above 20 candidates (pdq178.h), truncate.
+#include "device_utils.h"
+#include "fcd_internal.h"
+#define FCD_PDQ178_FORM0_ONLY 1  // (pdq178.h: the duplex kernels replay the default std form only)
+#include "pdq178.h"
+#include "duplex_math.h"
+
+namespace fcd {
+
+namespace {
+
+constexpr int kSlots = 64;   // slot-indexed LDS arrays have 64 entries whatever P is: field offsets are immediates
+constexpr int kNLMax = 7;    // N <= 8
+constexpr int kBeamMax = 32; // beam_size * N <= 64 with N >= 2
+
+// slot fields (one 64-word array each)
+enum {
+    F_NODE = 0, F_TIP, F_PAR, F_STATE, F_OFF, F_END, F_VFROM, F_MX, F_LLAB, F_XREP, F_DEPTH,
+    F_POFF, F_PEND, F_PVFROM,  // the parent's window bounds as they were when it left the beam (valid while it is out)
+    F_CHILD0,                  // kNLMax arrays
+    F_COUNT = F_CHILD0 + kNLMax
+};
+
+struct SlotParams {
+    const float *ln1, *ln2;   // log-space posteriors, [pair][Tcap][S][N] contiguous
+    int64_t T1cap, T2cap;
+    const int64_t *len1, *len2;
+    const uint64_t *env;
+    int64_t env_stride;
+    int N, beam_size;
+    float thr_ln;
+    int collapse, S, crf;
+    const float *init1, *init2;
+    int64_t n_init1, n_init2, init1_stride, init2_stride;
+    // arena (per pair slabs)
+    int4 *meta;      // {parent, label, off, end}
+    int4 *aux;       // {running maximum, vfrom, last label, 0}
+    int32_t *rows;   // NLp child ids per node
+    float *ring;     // Wcap4 floats per node: label (+) gap of row t at [t mod Wcap4]
+    float *rootgap;  // T2cap + 1 per pair
+    int64_t cap_nodes;
+    int Wcap4, NLp;
+    ResultDesc out;
+    int64_t pair_begin;
+    uint32_t *prof;
+    int tie_order;
+};
+
+struct SLds {
+    int *F;          // F_COUNT x 64
+    uint64_t *keys;  // 64 (+ 4 zero words of padding for the four-at-a-time rank loop)
+    int *pw;         // 66: probability words by rank, then new ranks of the quicksort replay
+    int *bt;         // 64: candidate lane that owns the m-th new node
+    int *flist;      // 64: free slots, ascending
+    float *f1;       // S * N: the current row of read 1
+    uint64_t *pq_list;
+    pdq178::Scratch *pq_scr;
+    float *tile;     // S * N x Wcap4
+    float *rings;    // P x Wcap4
+};
+
+__host__ __device__ inline size_t slds_words(int BC, int N, int S, int WC, bool pdq) {
+    const size_t P = (size_t)BC * N;
+    size_t w = (size_t)F_COUNT * kSlots + 2 * (kSlots + 4) + 68 + 64 + 64;
+    w += ((size_t)S * N + 3) & ~(size_t)3;
+    if (pdq) w += 2 * kSlots + (sizeof(pdq178::Scratch) + 15) / 16 * 4;
+    w += (size_t)S * N * WC + P * WC;
+    return w;
+}
+
+__device__ inline SLds scarve(int *smem, int BC, int N, int S, int WC, bool pdq) {
+    SLds L;
+    int *p = smem;
+    L.keys = reinterpret_cast<uint64_t *>(p); p += 2 * (kSlots + 4);
+    L.F = p; p += F_COUNT * kSlots;
+    L.pw = p; p += 68;
+    L.bt = p; p += 64;
+    L.flist = p; p += 64;
+    L.f1 = reinterpret_cast<float *>(p); p += (S * N + 3) & ~3;
+    L.pq_list = reinterpret_cast<uint64_t *>(p);
+    if (pdq) p += 2 * kSlots;
+    L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p);
+    if (pdq) p += (sizeof(pdq178::Scratch) + 15) / 16 * 4;
+    L.tile = reinterpret_cast<float *>(p); p += (size_t)S * N * WC;
+    L.rings = reinterpret_cast<float *>(p);
+    return L;
+}
+
+__device__ __forceinline__ void wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ __forceinline__ int bperm_i(int src_lane, int v) { return __builtin_amdgcn_ds_bpermute(src_lane << 2, v); }
+__device__ __forceinline__ float bperm_f(int src_lane, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(src_lane << 2, __float_as_int(v)));
+}
+__device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
+__device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+__device__ __forceinline__ int4 load_int4_l2(const int4 *p) {
+    const int32_t *q = reinterpret_cast<const int32_t *>(p);
+    return make_int4(load_i32_l2(q), load_i32_l2(q + 1), load_i32_l2(q + 2), load_i32_l2(q + 3));
+}
+
+// LogSpace::add for the window-building loop WITHOUT its two rare exits: where ladd_lockstep() leaves the chain for the
+// library routine (exp's Ziv test failed, exp's result subnormal or the argument outside [-86, 0] with a `big` so small
+// that it could show, ln_1p's Ziv test failed) this one raises `redo` and carries on with a meaningless value; the
+// caller runs the whole pass again on ladd_lockstep() when any lane raised it.  Where `redo` stays clear the value is
+// ladd()'s, operation for operation.
+__device__ __forceinline__ float ladd_spec(float a, float b, const LogAddCoef &K, bool &redo) {
+    const bool ab = a <= b;
+    const float big = ab ? b : a, small = ab ? a : b;
+    const float x = small - big;
+    const bool sc_inf = small == kNegInf;
+    const bool full = (!(x < kExpFastMin) | (__builtin_fabsf(big) < 8.0779356694631609e-28f)) & !sc_inf;
+    float res = big;
+    if (ballot(full) != 0ull) {
+        const float xs = full ? x : -1.0f;
+        const double ye = exp_fast((double)xs, K);
+        const double ed = round_to_f32_as_f64(ye);
+        const double yl = log1p_fast(ed, K);
+        const float l = (float)yl;
+        const int unsafe = (int)!(xs >= kExpFastMin) | (int)round_to_f32_unsafe(ye) |
+                           (int)((uint32_t)(bits_of(ed) >> 32) < 0x38100000u) | (int)round_to_f32_unsafe(yl);
+        redo = redo | (full & (unsafe != 0));
+        res = full ? big + l : res;
+    }
+    return res;
+}
+
+template <int MODE, bool PROF>
+__global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
+    extern __shared__ __attribute__((aligned(16))) int smem[];
+    const int lane = threadIdx.x;
+    const int64_t local = blockIdx.x;
+    const int64_t r = p.pair_begin + local;
+    const int N = p.N, NL = N - 1, BC = p.beam_size, S = p.S, SN = S * N, WC = p.Wcap4, NLp = p.NLp;
+    const int P = BC * N;
+    const bool crf = p.crf != 0;
+    const bool collapse = !crf && p.collapse != 0;
+    const float thr = p.thr_ln;
+    const bool pdq = p.tie_order == FCD_TIE_PDQ178;
+    SLds L = scarve(smem, BC, N, S, WC, pdq && P > 20);
+    int *F = L.F;
+    auto fi = [&](int f, int slot) -> int & { return F[f * kSlots + slot]; };
+    auto ff = [&](int f, int slot) -> float & { return reinterpret_cast<float *>(F)[f * kSlots + slot]; };
+    auto ring = [&](int slot) { return L.rings + (size_t)slot * WC; };
+
+    int64_t T1 = p.T1cap, T2 = p.T2cap;
+    if (p.len1) { int64_t t = p.len1[r]; T1 = t < 0 ? 0 : (t < T1 ? t : T1); }
+    if (p.len2) { int64_t t = p.len2[r]; T2 = t < 0 ? 0 : (t < T2 ? t : T2); }
+    const float *ln1 = p.ln1 + r * p.T1cap * SN;
+    const float *ln2 = p.ln2 + r * p.T2cap * SN;
+    const uint64_t *env = p.env + r * p.env_stride * 2;
+    int4 *meta = p.meta + local * p.cap_nodes;
+    int4 *aux = p.aux + local * p.cap_nodes;
+    int32_t *rows = p.rows + local * p.cap_nodes * NLp;
+    float *aring = p.ring + local * p.cap_nodes * (int64_t)WC;
+    float *rootgap = p.rootgap + local * (p.T2cap + 1);
+    uint8_t *lab_out = p.out.labels + r * p.out.out_stride;
+
+    const bool count_amb = p.out.ambiguous != nullptr;
+    int n_amb = 0, n_crit = 0;
+    auto fail = [&](int code) {
+        if (lane == 0) {
+            p.out.status[r] = code;
+            p.out.out_len[r] = 0;
+            if (count_amb) {
+                p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+                p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+            }
+        }
+    };
+
+    // ---- root_probs (:389-409): needs envelope[(0,1)], so an empty read 1 panics in the reference
+    if (T1 <= 0) return fail(FCD_ST_BAD_STATE);
+    const uint64_t ub_u = env[1];
+    if (ub_u > (uint64_t)T2) return fail(FCD_ST_BAD_STATE);  // slice(s![..upper_bound]) panics
+    const int root_end = (int)ub_u;                            // root rows are [-1, ub)
+    int st1 = 0, st2 = 0;
+    if (crf) {  // init_state.argmax() (:679,:691; first maximum, NaN panics in the reference)
+        bool bad = false;
+        for (int which = 0; which < 2; ++which) {
+            const float *init = which ? p.init2 + r * p.init2_stride : p.init1 + r * p.init1_stride;
+            const int64_t n_init = which ? p.n_init2 : p.n_init1;
+            int arg = 0;
+            float m = init[0];
+            bad = bad || (m != m);
+            for (int64_t j = 1; j < n_init; ++j) {
+                const float e = init[j];
+                bad = bad || (e != e);
+                if (e > m) { m = e; arg = (int)j; }
+            }
+            bad = bad || arg >= S;
+            if (which) st2 = arg; else st1 = arg;
+        }
+        if (bad) return fail(FCD_ST_BAD_STATE);
+    }
+    if (lane == 0) {
+        // root_probs (:389-409) / crf_root_probs (:411-441): cumulative blank product, sequential as the reference's
+        float cur = 0.0f;
+        rootgap[0] = cur;
+        int st = st2;
+        for (int t = 0; t < root_end; ++t) {
+            cur = cur + ln2[((int64_t)t * S + st) * N];
+            rootgap[t + 1] = cur;
+            if (crf) st = (int)(((int64_t)st * NL) % S);  // :437
+        }
+        // slot 0: the root
+        fi(F_NODE, 0) = -1;
+        fi(F_TIP, 0) = -1;
+        fi(F_PAR, 0) = -2;
+        fi(F_STATE, 0) = st1;
+        fi(F_OFF, 0) = -1;
+        fi(F_END, 0) = root_end;
+        fi(F_VFROM, 0) = -1;
+        ff(F_MX, 0) = 0.0f;
+        ff(F_LLAB, 0) = kNegInf;
+        fi(F_XREP, 0) = 0;
+        fi(F_DEPTH, 0) = 0;
+    }
+    for (int j = lane; j < kNLMax; j += kWave) fi(F_CHILD0 + j, 0) = -1;
+    if (lane < 4) L.keys[kSlots + lane] = 0ull;  // padding of the four-at-a-time rank loop
+    L.flist[lane] = lane + 1;                    // free: every slot but 0
+    // lane c is candidate (ci, ck) of every step
+    const int ci = lane / N, ck = lane - ci * N;
+    // ... and element (l_rw, l_sn) of a block of read-2 rows taken one element per lane
+    const int l_rw = lane / SN, l_sn = lane - l_rw * SN;
+    // rank lanes: lane e < B holds entry e of the beam
+    int slotE = 0, nodeE = -1;
+    float lpE = kNegInf, gpE = 0.0f;  // root: label zero, gap one
+    int B = 1, nn = 0, last_hi = 0;
+    // read-2 tile: rows [tl_lo, tl_hi) are in the LDS ring
+    int tl_lo = 0, tl_hi = 0;
+    // the slot of the current lower bound (lo mod Wcap4), kept incrementally
+    int cur_lo = 0, cur_lo_s = 0;
+    // rows of read 2 asked for one step ahead: element (pf_row, pf_sn) in pf_val for lanes below pf_n
+    float pf_val = 0.0f;
+    int pf_lo = 0, pf_hi = 0;
+    // the row of read 1 the coming step expands with
+    if (lane < SN) L.f1[lane] = ln1[lane];
+    float f1_next = 0.0f;
+
+    const bool prof = PROF && p.prof != nullptr;
+    uint64_t acc[5] = {0, 0, 0, 0, 0}, t_prev = 0, t_now = 0;
+    uint32_t n_iter = 0, n_newnodes = 0, n_slow = 0, n_enter = 0, n_ext = 0, n_redo = 0;
+    uint64_t sub[5] = {0, 0, 0, 0, 0}, t_sub = 0, t_sub2 = 0;
+    int stamp_dep = 0;
+#define FCD_S_SUB_BEGIN() if (PROF && prof) FCD_STAMP(t_sub, stamp_dep);
+#define FCD_S_SUB(k) if (PROF && prof) { FCD_STAMP(t_sub2, stamp_dep); sub[k] += t_sub2 - t_sub; t_sub = t_sub2; }
+#define FCD_S_PHASE(k) if (PROF && prof) { FCD_STAMP(t_now, stamp_dep); acc[k] += t_now - t_prev; t_prev = t_now; }
+    if (PROF && prof) FCD_STAMP(t_prev, stamp_dep);
+    wave_sync();
+
+    uint64_t env_lo_next = env[0], env_hi_next = env[1];
+    for (int64_t t1 = 0; t1 < T1; ++t1) {
+        // ---- envelope (:485-488) ----
+        const uint64_t lo_u = env_lo_next, hi_u = env_hi_next;
+        const bool more = t1 + 1 < T1;
+        if (more) {
+            env_lo_next = env[2 * (t1 + 1)];
+            env_hi_next = env[2 * (t1 + 1) + 1];
+            if (lane < SN) f1_next = ln1[(t1 + 1) * SN + lane];
+        }
+        const int hi = (int)(hi_u > (uint64_t)T2 ? (uint64_t)T2 : hi_u);
+        if (lo_u >= (uint64_t)hi || lo_u > (uint64_t)last_hi) return fail(FCD_ST_INVALID_ENVELOPE);
+        const int lo = (int)lo_u;
+        const int W = hi - lo;
+        {
+            const int d = lo - cur_lo;
+            int s = cur_lo_s + d;
+            if (d < -WC || d > WC) s = lo % WC;
+            else {
+                s = s < 0 ? s + WC : s;
+                s = s >= WC ? s - WC : s;
+            }
+            cur_lo = lo;
+            cur_lo_s = s;
+        }
+        const int lo_s = cur_lo_s;
+        // slot of row t, |t - lo| < Wcap4
+        auto slotn = [&](int t) {
+            int s = lo_s + (t - lo);
+            s = s < 0 ? s + WC : s;
+            return s >= WC ? s - WC : s;
+        };
+
+        // ---- read-2 tile: rows [max(lo - 1, 0), hi) ----
+        FCD_S_SUB_BEGIN()
+        {
+            const int need_lo = lo > 0 ? lo - 1 : 0;
+            int from;
+            if (tl_hi > tl_lo && need_lo >= tl_lo && need_lo <= tl_hi) {
+                from = tl_hi;  // rows the envelope gained (none when hi <= tl_hi)
+            } else {
+                from = need_lo;
+                tl_lo = need_lo;
+                tl_hi = need_lo;
+            }
+            if (hi > from) {
+                if (from == pf_lo && hi == pf_hi) {  // asked for during the previous step: one element per lane
+                    const int n = (hi - from) * SN;
+                    if (lane < n) L.tile[(size_t)l_sn * WC + slotn(from + l_rw)] = pf_val;
+                } else {
+                    const int n = (hi - from) * SN;
+                    for (int x = lane; x < n; x += kWave) {
+                        const int rw = x / SN, sn = x - rw * SN;
+                        const int row = from + rw;
+                        L.tile[(size_t)sn * WC + (row % WC)] = ln2[(int64_t)row * SN + sn];
+                    }
+                }
+                tl_hi = hi;
+                if (tl_hi - tl_lo > WC) tl_lo = tl_hi - WC;
+            }
+            // ask for the rows the NEXT step will gain
+            pf_lo = pf_hi = 0;
+            if (more) {
+                const int hi_n = (int)(env_hi_next > (uint64_t)T2 ? (uint64_t)T2 : env_hi_next);
+                const int n = (hi_n - tl_hi) * SN;
+                if (hi_n > tl_hi && n <= kWave) {
+                    pf_lo = tl_hi;
+                    pf_hi = hi_n;
+                    if (lane < n) pf_val = ln2[(int64_t)tl_hi * SN + lane];  // (row-major: element `lane` of the block of rows)
+                }
+            }
+        }
+        FCD_S_SUB(0)
+
+        const bool grew = hi > last_hi;
+        if (grew) {
+            FCD_S_SUB_BEGIN()
+            // ---- :493 beam.sort_by_key(node): parents before children ----
+            {
+                int rk = 0;
+                for (int j = 0; j < B; ++j) {
+                    const int nj = rl_i(nodeE, j);
+                    rk += nj < nodeE ? 1 : 0;
+                }
+                const int dst = lane < B ? rk : 63;  // (B <= 32: lane 63 is never a rank lane)
+                const int s2 = __builtin_amdgcn_ds_permute(dst << 2, slotE);
+                const int n2 = __builtin_amdgcn_ds_permute(dst << 2, nodeE);
+                const int l2 = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(lpE));
+                const int g2 = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(gpE));
+                slotE = s2; nodeE = n2; lpE = __int_as_float(l2); gpE = __int_as_float(g2);
+            }
+        }
+        // which rank holds my parent (rank lanes) -- also used by the expansion below
+        const bool mineE = lane < B;
+        int parE = -2, pslotE = -1, prankE = -1;
+        if (mineE) parE = fi(F_PAR, slotE);
+        for (int j = 0; j < B; ++j) {
+            const int nj = rl_i(nodeE, j), sj = rl_i(slotE, j);
+            const bool hit = mineE && nodeE >= 0 && parE == nj;
+            pslotE = hit ? sj : pslotE;
+            prankE = hit ? j : prankE;
+        }
+        if (grew) {
+            // ---- extend_secondary_probs (:338-387) for every beam node, one per lane ----
+            // An entry appends rows [end, hi).  Row idx reads the parent's row idx - 1 <= hi - 2, which exists BEFORE this
+            // step whenever the parent's window reaches hi - 1 -- then nothing depends on a row written in this step and
+            // the reference's parents-first order (:493) is immaterial.  Only a parent that is itself behind takes the
+            // one-entry-at-a-time path (entries are in node order: parents first).
+            const bool mine = mineE && nodeE >= 0;
+            int off = 0, end = 0, vfrom = 0, lab = 0, tst = 0, p_off = 0, p_end = 0, p_vfrom = 0, xrep = 0;
+            float mx = kNegInf, llab = kNegInf;
+            bool rescan = false, panic = false, behind = false;
+            if (mine) {
+                off = fi(F_OFF, slotE); end = fi(F_END, slotE); vfrom = fi(F_VFROM, slotE);
+                mx = ff(F_MX, slotE); llab = ff(F_LLAB, slotE);
+                lab = fi(F_TIP, slotE); tst = fi(F_STATE, slotE); xrep = fi(F_XREP, slotE);
+                if (lo > off) {  // :351-359
+                    const int keep = lo - 1;
+                    if (keep > off) {
+                        if (keep < end) off = keep;
+                        else { off = keep; end = keep; }
+                    }
+                    if (end == off) { off = lo; end = lo; vfrom = lo; llab = kNegInf; }
+                    rescan = true;  // update_max(lo, hi)
+                }
+                panic = end >= hi;  // assert!(current_end < upper_bound) :363-366
+                if (parE >= 0) {
+                    if (pslotE >= 0) {
+                        p_off = fi(F_OFF, pslotE); p_end = fi(F_END, pslotE); p_vfrom = fi(F_VFROM, pslotE);
+                        behind = p_end < hi - 1;
+                    } else {
+                        p_off = fi(F_POFF, slotE); p_end = fi(F_PEND, slotE); p_vfrom = fi(F_PVFROM, slotE);
+                    }
+                } else {  // the root's window
+                    p_off = -1; p_end = root_end; p_vfrom = -1;
+                }
+            }
+            FCD_S_SUB(4)
+            if (ballot(panic) != 0ull) return fail(FCD_ST_BAD_STATE);
+            // update_max over the rows that stay, [max(lo, off), end), for every entry that discarded rows: 64 lanes
+            // per entry (NaN rows never replace the maximum)
+            for (uint64_t m = ballot(rescan); m != 0ull; m &= m - 1) {
+                const int e2 = (int)__builtin_ctzll(m);
+                const int o2 = rl_i(off, e2), n2 = rl_i(end, e2);
+                const float *rg = ring(rl_i(slotE, e2));
+                float part = kNegInf;
+                for (int t0 = (lo > o2 ? lo : o2) + lane; t0 < n2; t0 += kWave) part = lmax(part, rg[slotn(t0)]);
+                part = wave_lmax(part);
+                if (lane == e2) mx = part;
+            }
+            FCD_S_SUB(2)
+            const bool seq = ballot(behind) != 0ull;
+            // the recurrence (:361-386) for one entry on its own lane
+            auto extend = [&]() {
+                float *mw = ring(slotE);
+                const float *prg = pslotE >= 0 ? ring(pslotE) : (parE < 0 ? ring(0) : nullptr);
+                const float *parena = aring + (int64_t)(parE < 0 ? 0 : parE) * WC;
+                const bool rootpar = parE < 0;
+                float l_lab = llab, l_sum = kNegInf;
+                if (end > off) l_sum = mw[slotn(end - 1)];
+                const float *tb = L.tile + (size_t)(tst * N) * WC;        // blank of the entry's state (:725-728)
+                const float *tl = L.tile + (size_t)(tst * N + lab + 1) * WC;
+                for (int idx = end; idx < hi; ++idx) {
+                    const int sl = slotn(idx);
+                    const int at = idx - 1;
+                    // the parent's row idx - 1: label (+) gap, or -- repeated label -- the gap alone, recomputed from
+                    // its stored sum of row idx - 2 and the blank of row idx - 1
+                    float x = kNegInf;
+                    if (at >= p_off && at < p_end) {
+                        if (rootpar) {
+                            x = load_f32_l2(rootgap + (at + 1));
+                        } else if (!xrep) {
+                            x = prg ? prg[slotn(at)] : load_f32_l2(parena + (at % WC));
+                        } else {
+                            float ps = kNegInf;
+                            if (at != p_vfrom) ps = prg ? prg[slotn(at - 1)] : load_f32_l2(parena + ((at - 1) % WC));
+                            // (xrep only without transition states: the blank column of row `at` is state 0's)
+                            const float bl = (at >= tl_lo && at < tl_hi) ? L.tile[slotn(at)] : ln2[(int64_t)at * SN];
+                            x = ps + bl;
+                        }
+                    }
+                    const float g = l_sum + tb[sl];
+                    const float lb = tl[sl] + ladd<MODE>(l_lab, x);
+                    const float sm = ladd<MODE>(lb, g);
+                    mw[sl] = sm;
+                    mx = lmax(mx, sm);
+                    l_lab = lb;
+                    l_sum = sm;
+                }
+                fi(F_OFF, slotE) = off;
+                fi(F_END, slotE) = hi;
+                fi(F_VFROM, slotE) = vfrom;
+                ff(F_MX, slotE) = mx;
+                ff(F_LLAB, slotE) = l_lab;
+            };
+            if (!seq) {
+                if (mine) extend();
+            } else {
+                for (int e = 0; e < B; ++e) {
+                    if (mine && lane == e) {
+                        // the parent may have moved in an earlier trip
+                        if (pslotE >= 0) { p_off = fi(F_OFF, pslotE); p_end = fi(F_END, pslotE); p_vfrom = fi(F_VFROM, pslotE); }
+                        extend();
+                    }
+                    wave_sync();
+                }
+            }
+            if (PROF && prof) {
+                ++n_ext;
+                n_slow += seq ? 1u : 0u;
+            }
+        }
+        last_hi = hi;
+        wave_sync();
+        FCD_S_PHASE(0)
+
+        // the root (in the beam for the first few rows only) has no ring of its own: the rows its children's builds
+        // and its children's extensions will ask for, [lo - 1, hi - 1), are staged into slot 0's ring from the
+        // cumulative blank products
+        const bool root_in = ballot(mineE && nodeE < 0) != 0ull;
+        if (root_in) {
+            float *rg = ring(0);
+            for (int j = lane; j < W; j += kWave) {
+                const int at = lo - 1 + j;
+                if (at < -1 || at >= root_end) continue;
+                rg[slotn(at)] = load_f32_l2(rootgap + (at + 1));
+            }
+            wave_sync();
+        }
+        FCD_S_PHASE(1)
+
+        // ---- expansion (:526-593): lane c = candidate (ci, ck) ----
+        const bool act = ci < B;
+        const int slot_i = bperm_i(ci, slotE);
+        const int node = bperm_i(ci, nodeE);
+        const float lp = bperm_f(ci, lpE), gp = bperm_f(ci, gpE);
+        const int prank_i = bperm_i(ci, prankE);
+        int tip = -1, state = 0, ch = -1, depth = 0;
+        if (act) {
+            tip = fi(F_TIP, slot_i);
+            state = fi(F_STATE, slot_i);
+            depth = fi(F_DEPTH, slot_i);
+            if (ck > 0) ch = fi(F_CHILD0 + ck - 1, slot_i);
+        }
+        // is the child a beam entry already?  (then the extension is folded into that entry's own candidate)
+        bool ch_inbeam = false;
+        for (int j = 0; j < B; ++j) {
+            const int nj = rl_i(nodeE, j);
+            ch_inbeam = ch_inbeam | (ch >= 0 && ch == nj);
+        }
+        // the entry of my parent, if it is in the beam (own candidates)
+        const int pj = (act && ck == 0 && node >= 0) ? prank_i : -1;
+        const int pjc = pj >= 0 ? pj : 0;
+        const int slot_j = bperm_i(pjc, slotE);
+        const float lpj = bperm_f(pjc, lpE), gpj = bperm_f(pjc, gpE);
+        // running maximum of an existing child that is outside the beam: in its arena record (asked for here, used
+        // after the window builds)
+        float p2_stale = 0.0f;
+        const bool stale_c = act && ck > 0 && ch >= 0 && !ch_inbeam;
+        if (stale_c) p2_stale = __int_as_float(load_i32_l2(reinterpret_cast<const int32_t *>(&aux[ch])));
+        const float *row1 = L.f1 + state * N;  // crf: probs[state, :] (:749)
+        bool valid = false, is_new = false, rep = false;
+        float clp = kNegInf, cgp = kNegInf, p2 = 0.0f;
+        int cid = -2;
+        if (act) {
+            if (ck == 0) {
+                // The node's own candidate is the MERGE (:596-611) of up to three items that share the node -- the blank
+                // extension {zero, gap}, the repeat-stay {label, zero} and the extension that arrives from the parent's
+                // entry {label, zero} -- folded with LogSpace::add in the order the reference appends them: tips in
+                // beam order, and within a tip blank first, labels after (max mode's add keeps a NaN only as its
+                // FIRST operand).
+                const float pr0 = row1[0];
+                const bool blank = pr0 > thr;  // :529
+                const float g_item = blank ? ladd<MODE>(lp, gp) + pr0 : kNegInf;
+                bool stay = collapse && tip >= 0;
+                float s_item = kNegInf;
+                if (stay) {
+                    const float pt = row1[tip + 1];
+                    stay = !(pt < thr);
+                    if (stay) s_item = lp + pt;  // :541-544
+                }
+                bool inc = false, inc_first = false;
+                float c_item = kNegInf;
+                if (pj >= 0) {
+                    const float pl = L.f1[fi(F_STATE, slot_j) * N + tip + 1];  // the PARENT's row
+                    if (!(pl < thr)) {
+                        const bool rj = collapse && fi(F_TIP, slot_j) == tip;
+                        // (the parent's own test `gap > zero` (:546) only guards the CREATION of this node: it exists)
+                        c_item = rj ? gpj + pl : ladd<MODE>(lpj, gpj) + pl;
+                        inc = true;
+                        inc_first = pj < ci;  // the parent's entry comes earlier in the beam: its item was appended first
+                    }
+                }
+                bool have = false;
+                auto push = [&](float l_it, float g_it) {
+                    if (!have) {
+                        clp = l_it;
+                        cgp = g_it;
+                        have = true;
+                    } else {
+                        clp = ladd<MODE>(clp, l_it);
+                        cgp = ladd<MODE>(cgp, g_it);
+                    }
+                };
+                if (inc && inc_first) push(c_item, kNegInf);
+                if (blank) push(kNegInf, g_item);
+                if (stay) push(s_item, kNegInf);
+                if (inc && !inc_first) push(c_item, kNegInf);
+                valid = blank || stay || inc;
+                cid = node;
+                if (node >= 0) p2 = ff(F_MX, slot_i);  // :613-618 (the root keeps one)
+            } else {
+                const int l = ck - 1;
+                const float pk = row1[ck];
+                const bool pass = !(pk < thr);  // :537
+                rep = collapse && l == tip;
+                const float contrib = rep ? gp + pk : ladd<MODE>(lp, gp) + pk;
+                const bool exists = ch >= 0;
+                valid = pass && (exists || !rep || gp > kNegInf) && !ch_inbeam;  // :546
+                is_new = valid && !exists;
+                clp = contrib;
+                cid = ch;
+                if (stale_c) p2 = p2_stale;
+            }
+        }
+        const uint64_t m_new = ballot(is_new);
+        const int n_new = popc64(m_new);
+        const int pre = popc64(m_new & lanemask_lt());
+        int nbuf = 0;
+        if (is_new) {
+            cid = nn + pre;
+            L.bt[pre] = lane;
+            nbuf = L.flist[pre];
+        }
+        const bool can = is_new && cid < p.cap_nodes;
+        if (can) {  // add_node (tree.rs:125-145): the new node's slot
+            const int l = ck - 1;
+            fi(F_NODE, nbuf) = cid;
+            fi(F_TIP, nbuf) = l;
+            fi(F_PAR, nbuf) = node;
+            fi(F_STATE, nbuf) = crf ? (int)(((int64_t)state * NL) % S) + l : 0;  // :782
+            fi(F_OFF, nbuf) = lo;
+            fi(F_END, nbuf) = hi;
+            fi(F_VFROM, nbuf) = lo;
+            fi(F_XREP, nbuf) = (!crf && node >= 0 && tip == l) ? 1 : 0;  // :512 (no collapse_repeats test there)
+            fi(F_DEPTH, nbuf) = depth + 1;
+            for (int j = 0; j < NL; ++j) fi(F_CHILD0 + j, nbuf) = -1;
+            fi(F_CHILD0 + l, slot_i) = cid;
+        }
+        FCD_S_PHASE(2)
+        if (PROF && prof) {
+            n_newnodes += (uint32_t)n_new;
+            n_iter += (uint32_t)(W + 1) * (uint32_t)((n_new + 31) / 32);
+        }
+        wave_sync();
+
+        // ---- new nodes: build_secondary_probs (:212-249), whole window [lo, hi) ----
+        // One lane per node, both chains, every test per row: the exact form (glibc 2.35 flavour always; the other
+        // flavours when a fast pass asked for it).  W + 1 trips.
+        auto build_exact = [&](int m0) {
+            const int m = m0 + lane;
+            const bool have = m < n_new;
+            const int owner = have ? L.bt[m] : 0;
+            const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
+            const bool work = have && (o_flags & 1);
+            const bool q_rep = (o_flags & 2) != 0;
+            const int q_buf = bperm_i(owner, nbuf), q_ps = bperm_i(owner, slot_i), q_l = bperm_i(owner, ck - 1);
+            const int q_state = bperm_i(owner, state), q_node = bperm_i(owner, node);
+            float lb = kNegInf, sm = kNegInf, mx = kNegInf;
+            if (work) {
+                float *my = ring(q_buf);
+                const float *prg = ring(q_ps);
+                const int p_off = q_node < 0 ? -1 : fi(F_OFF, q_ps), p_end = q_node < 0 ? root_end : fi(F_END, q_ps);
+                const int p_vfrom = q_node < 0 ? -1 : fi(F_VFROM, q_ps);
+                const float *tb = L.tile + (size_t)(q_state * N) * WC;  // crf: tip.state (:772)
+                const float *tl = L.tile + (size_t)(q_state * N + q_l + 1) * WC;
+                for (int idx = lo; idx < hi; ++idx) {
+                    const int sl = slotn(idx), at = idx - 1;
+                    float x = kNegInf;
+                    if (at >= p_off && at < p_end) {
+                        if (!q_rep) x = prg[slotn(at)];
+                        else {
+                            float ps = kNegInf;
+                            if (at != p_vfrom) ps = prg[slotn(at - 1)];
+                            const float bl = (at >= tl_lo && at < tl_hi) ? L.tile[slotn(at)] : ln2[(int64_t)at * SN];
+                            x = ps + bl;
+                        }
+                    }
+                    const float g = sm + tb[sl];
+                    lb = tl[sl] + ladd<MODE>(lb, x);
+                    sm = ladd<MODE>(lb, g);
+                    my[sl] = sm;
+                    mx = lmax(mx, sm);
+                }
+                ff(F_MX, q_buf) = mx;
+                ff(F_LLAB, q_buf) = lb;
+            }
+        };
+        if (n_new > 0) {
+            bool redo_pass = MODE == FCD_LOGADD_LOGSUMEXP_GLIBC235;
+            if (MODE == FCD_LOGADD_LOGSUMEXP) {
+                // The recurrence of one node is two interleaved serial chains:
+                //   label_t = p_t[label] (x) (label_{t-1} (+) X_{t-1})            (needs only the label chain)
+                //   sum_t   = label_t (+) (sum_{t-1} (x) p_t[blank])   [gap_t = sum_{t-1} (x) p_t[blank]]
+                // so every new node gets a PAIR of lanes: the even lane runs the label chain, the odd lane runs the sum
+                // chain one row behind it -- same operations in the same order as the reference, one log-add per trip.
+                LogAddCoef K = logadd_coef();
+                FCD_OPAQUE_V(K.log2e); FCD_OPAQUE_V(K.ln2hi); FCD_OPAQUE_V(K.ln2lo); FCD_OPAQUE_V(K.two);
+#pragma unroll
+                for (int u = 0; u < 12; ++u) FCD_OPAQUE_V(K.e[u]);
+#pragma unroll
+                for (int u = 0; u < 15; ++u) FCD_OPAQUE_V(K.a[u]);
+                bool redo = false;
+                for (int rd = 0; rd * 32 < n_new; ++rd) {
+                    const int m = rd * 32 + (lane >> 1);
+                    const bool have = m < n_new;
+                    const int owner = have ? L.bt[m] : 0;
+                    const bool isA = (lane & 1) == 0;
+                    const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
+                    const bool work = have && (o_flags & 1);
+                    const bool q_rep = (o_flags & 2) != 0;
+                    const int o_buf = bperm_i(owner, nbuf), o_ps = bperm_i(owner, slot_i), o_l = bperm_i(owner, ck - 1);
+                    const int o_state = bperm_i(owner, state), o_node = bperm_i(owner, node);
+                    // (idle lanes run the loop too, on slot 0's tables: every address they form is a real one)
+                    const int q_buf = work ? o_buf : 0, q_ps = work ? o_ps : 0, q_l = work ? o_l : 0;
+                    const int q_state = work ? o_state : 0;
+                    const bool q_root = !work || o_node < 0;
+                    const int p_off = q_root ? -1 : fi(F_OFF, q_ps), p_end = q_root ? root_end : fi(F_END, q_ps);
+                    const int p_vfrom = q_root ? -1 : fi(F_VFROM, q_ps);
+                    float *my = ring(q_buf);
+                    const float *prg = ring(q_ps);
+                    // per-lane coefficient column: even lane the label's, odd lane the blank's
+                    const float *tc = L.tile + (size_t)(q_state * N + (isA ? q_l + 1 : 0)) * WC;
+                    const float *tb0 = L.tile;  // blank column of state 0 (repeat children exist without states only)
+                    float lb = kNegInf;   // A: label_{t-1};  B: label_{t'} received from A
+                    float sm = kNegInf;   // B: sum_{t'-1}
+                    float mx = kNegInf;
+                    float lkeep = kNegInf;  // B: label of the last row it has combined
+                    // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
+                    int jn = isA ? 0 : -1;      // the row (relative to lo) this lane handles in the coming trip
+                    int s_cur = slotn(lo + jn); // its slot
+                    int s_m1 = slotn(lo + jn - 1), s_m2 = slotn(lo + jn - 2);
+                    const unsigned wlim = work ? (unsigned)W : 0u;
+                    // X of row lo + j is the parent's row lo + j - 1: present iff p_off <= lo + j - 1 < p_end
+                    const int jv0 = p_off + 1 - lo;
+                    const unsigned jspan = isA && p_end > p_off ? (unsigned)(p_end - p_off) : 0u;
+                    const int jvf = p_vfrom + 1 - lo;  // the row whose X has no predecessor sum (repeat children)
+                    auto fetch_x = [&](int j, int sm1, int sm2) {
+                        float xr = prg[sm1];
+                        if (q_rep) {
+                            const float ps = j == jvf ? kNegInf : prg[sm2];
+                            xr = ps + tb0[sm1];
+                        }
+                        return (unsigned)(j - jv0) < jspan ? xr : kNegInf;
+                    };
+                    float c_cur = tc[s_cur];
+                    float x_cur = isA ? fetch_x(jn, s_m1, s_m2) : kNegInf;
+                    for (int sidx = 0; sidx <= W; ++sidx) {
+                        const bool on = (unsigned)jn < wlim;
+                        // next row's operands (one row past the window at the very end: inside the ring, value unused)
+                        const int s_nx = s_cur + 1 == WC ? 0 : s_cur + 1;
+                        const float c_nxt = tc[s_nx];
+                        const float x_nxt = fetch_x(jn + 1, s_cur, s_m1);
+                        const float bb = isA ? x_cur : sm + c_cur;                    // A: X_{t-1};  B: gap_{t'}
+                        const float v = ladd_spec(lb, bb, K, redo);
+                        if (on && !isA) my[s_cur] = v;  // sum_{t'}
+                        lkeep = on ? lb : lkeep;
+                        // No selects on `on`: the odd lane's idle first row yields -inf (-inf (+) -inf), which changes
+                        // neither sum nor maximum; the even lane never reads sum / maximum; and what the odd lane puts
+                        // into label_t is overwritten by the even lane's through the DPP move below.
+                        sm = v;
+                        mx = lmax(mx, v);
+                        const float lb_out = c_cur + v;  // label_t (even lane)
+                        // hand label_t to the odd lane for the next trip; the even lane keeps it
+                        lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
+                                                                        0xf, 0xf, false));
+                        c_cur = c_nxt;
+                        x_cur = x_nxt;
+                        ++jn;
+                        s_m2 = s_m1;
+                        s_m1 = s_cur;
+                        s_cur = s_nx;
+                    }
+                    if (work && !isA) {
+                        ff(F_MX, q_buf) = mx;
+                        ff(F_LLAB, q_buf) = lkeep;  // label_{hi-1}: what the even lane handed over before its idle last trip
+                    }
+                    redo = redo & work;  // (idle lanes compute on whatever slot 0 holds)
+                }
+                redo_pass = ballot(redo) != 0ull;
+                if (PROF && prof) n_redo += redo_pass ? 1u : 0u;
+            } else if (MODE == FCD_LOGADD_MAX) {
+                // Max-product mode has no transcendental in the recurrence, so a row costs its instructions: one lane
+                // per node, four rows per trip.  LogSpace::add's max flavour is v_max_f32 unless its FIRST operand is a
+                // NaN (the label chain): watched per row, and a pass that met one is redone on the exact form.
+                const int m = lane;
+                const bool have = m < n_new;
+                const int owner = have ? L.bt[m] : 0;
+                const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
+                const bool work = have && (o_flags & 1);
+                const bool q_rep = (o_flags & 2) != 0;
+                const int o_buf = bperm_i(owner, nbuf), o_ps = bperm_i(owner, slot_i), o_l = bperm_i(owner, ck - 1);
+                const int o_state = bperm_i(owner, state), o_node = bperm_i(owner, node);
+                const int q_buf = work ? o_buf : 0, q_ps = work ? o_ps : 0, q_l = work ? o_l : 0;
+                const int q_state = work ? o_state : 0;
+                const bool q_root = !work || o_node < 0;
+                const int p_off = q_root ? -1 : fi(F_OFF, q_ps), p_end = q_root ? root_end : fi(F_END, q_ps);
+                const int p_vfrom = q_root ? -1 : fi(F_VFROM, q_ps);
+                const float4 *my4 = reinterpret_cast<const float4 *>(ring(q_buf));
+                const float4 *pr4 = reinterpret_cast<const float4 *>(ring(q_ps));
+                const float4 *tb4 = reinterpret_cast<const float4 *>(L.tile + (size_t)(q_state * N) * WC);
+                const float4 *tl4 = reinterpret_cast<const float4 *>(L.tile + (size_t)(q_state * N + q_l + 1) * WC);
+                const float4 *t04 = reinterpret_cast<const float4 *>(L.tile);  // blank column of state 0
+                const int G = WC >> 2;
+                // X of row t is the parent's row t - 1: present iff t in [xa, xb)
+                const int xa = p_off + 1, xb = p_end + 1, xvf = p_vfrom + 1;
+                // all X of [lo, hi) present and no repeat child whose zero-predecessor row falls inside?  (the usual case)
+                const bool plain = ballot(work && (xa > lo || xb < hi || (q_rep && xvf >= lo))) == 0ull;
+                float lab = kNegInf, sum = kNegInf, mx = kNegInf;
+                uint64_t nanm = 0ull;
+                int g = lo >> 2;
+                int sg = lo_s >> 2;
+                const int g_last = (hi - 1) >> 2;
+                // carries from the group before the first one: the parent's rows 4g - 1, 4g - 2 and the blank of 4g - 1
+                float4 pprev, bprev;
+                {
+                    const int sgm = sg == 0 ? G - 1 : sg - 1;
+                    pprev = pr4[sgm];
+                    bprev = t04[sgm];
+                }
+                for (; g <= g_last; ++g) {
+                    const float4 cb = tb4[sg], cl = tl4[sg], px = pr4[sg], b0 = q_rep ? t04[sg] : cb;
+                    const int t0 = g << 2;
+                    // X of the group's four rows
+                    float x0, x1, x2, x3;
+                    if (plain) {
+                        x0 = q_rep ? pprev.z + bprev.w : pprev.w;
+                        x1 = q_rep ? pprev.w + b0.x : px.x;
+                        x2 = q_rep ? px.x + b0.y : px.y;
+                        x3 = q_rep ? px.y + b0.z : px.z;
+                    } else {
+                        auto xj = [&](int t, float s1, float s2, float bl) {
+                            float xr = s1;
+                            if (q_rep) xr = (t == xvf ? kNegInf : s2) + bl;
+                            return (t >= xa && t < xb) ? xr : kNegInf;
+                        };
+                        x0 = xj(t0, pprev.w, pprev.z, bprev.w);
+                        x1 = xj(t0 + 1, px.x, pprev.w, b0.x);
+                        x2 = xj(t0 + 2, px.y, px.x, b0.y);
+                        x3 = xj(t0 + 3, px.z, px.y, b0.z);
+                    }
+                    float s0, s1, s2, s3;
+                    const bool whole = t0 >= lo && t0 + 4 <= hi;  // (wave-uniform)
+                    if (whole) {
+                        lab = cl.x + vmax_raw(lab, x0); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.x); s0 = sum;
+                        lab = cl.y + vmax_raw(lab, x1); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.y); s1 = sum;
+                        lab = cl.z + vmax_raw(lab, x2); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.z); s2 = sum;
+                        lab = cl.w + vmax_raw(lab, x3); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.w); s3 = sum;
+                        mx = vmax_raw(vmax_raw(mx, vmax_raw(s0, s1)), vmax_raw(s2, s3));
+                    } else {
+                        s0 = s1 = s2 = s3 = kNegInf;
+                        if (t0 >= lo && t0 < hi) {
+                            lab = cl.x + vmax_raw(lab, x0); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.x); s0 = sum;
+                        }
+                        if (t0 + 1 >= lo && t0 + 1 < hi) {
+                            lab = cl.y + vmax_raw(lab, x1); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.y); s1 = sum;
+                        }
+                        if (t0 + 2 >= lo && t0 + 2 < hi) {
+                            lab = cl.z + vmax_raw(lab, x2); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.z); s2 = sum;
+                        }
+                        if (t0 + 3 >= lo && t0 + 3 < hi) {
+                            lab = cl.w + vmax_raw(lab, x3); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.w); s3 = sum;
+                        }
+                        mx = vmax_raw(vmax_raw(mx, vmax_raw(s0, s1)), vmax_raw(s2, s3));
+                    }
+                    if (work) const_cast<float4 *>(my4)[sg] = make_float4(s0, s1, s2, s3);
+                    pprev = px;
+                    bprev = b0;
+                    sg = sg + 1 == G ? 0 : sg + 1;
+                }
+                if (work) {
+                    ff(F_MX, q_buf) = mx;
+                    ff(F_LLAB, q_buf) = lab;
+                }
+                redo_pass = (nanm & ballot(work)) != 0ull;
+                if (PROF && prof) n_redo += redo_pass ? 1u : 0u;
+            }
+            if (redo_pass) {
+                wave_sync();
+                for (int m0 = 0; m0 < n_new; m0 += kWave) build_exact(m0);
+            }
+            wave_sync();
+        }
+        if (is_new && can) p2 = ff(F_MX, nbuf);
+        nn += n_new;
+        FCD_S_PHASE(3)
+        if (nn > p.cap_nodes) return fail(FCD_ST_INTERNAL);
+
+        // ---- merge is done (own candidates folded the three items); probability (:146-148), keys, exact rank ----
+        const float prob = ladd<MODE>(clp, cgp) + p2;
+        const uint64_t key = valid ? (prob == prob ? make_key(prob, cid) : 1ull) : 0ull;
+        L.keys[lane] = key;
+        const uint64_t m_valid = ballot(valid);
+        const int n_valid = popc64(m_valid);
+        const bool any_nan = ballot(valid && prob != prob) != 0ull;
+        if (n_valid >= 2 && any_nan) return fail(FCD_ST_INCOMPARABLE);  // :619-631
+        if (n_valid == 0) return fail(FCD_ST_RAN_OUT_OF_BEAM);          // :633-636
+        wave_sync();
+        int rank;
+        {
+            int r0, r1, r2, r3;
+            FCD_RANK4_FIRST(key, L.keys[0], L.keys[1], L.keys[2], L.keys[3], r0, r1, r2, r3);
+            for (int u = 4; u < P; u += 4) FCD_RANK4(key, L.keys[u], L.keys[u + 1], L.keys[u + 2], L.keys[u + 3], r0, r1, r2, r3);
+            rank = (r0 + r1) + (r2 + r3);
+        }
+        const int Bn = n_valid < BC ? n_valid : BC;
+        // equal probabilities: candidates with one probability occupy consecutive ranks, so a KEPT candidate is tied
+        // when ranks i and i + 1 hold one probability word for some i < beam_size; the tie can change the kept set or
+        // the best entry when it sits at ranks 0 / 1 or across the truncation boundary
+        bool any_kept_tie = false;
+        if (count_amb || (pdq && n_valid > 20)) {
+            if (valid) L.pw[rank] = (int)(uint32_t)(key >> 32);
+            wave_sync();
+            const bool pair_eq = lane + 1 < n_valid && L.pw[lane] == L.pw[lane + 1];
+            const uint64_t m_eq = ballot(pair_eq);
+            const uint64_t keptm = BC >= 64 ? ~0ull : ((1ull << BC) - 1ull);
+            any_kept_tie = n_valid > 20 && (m_eq & keptm) != 0ull;
+            if (count_amb) {
+                if (any_kept_tie) ++n_amb;
+                if ((m_eq & 1ull) != 0ull || (BC < 64 && ((m_eq >> (BC - 1)) & 1ull) != 0ull)) ++n_crit;
+            }
+            wave_sync();
+        }
+        if (pdq && any_kept_tie) {
+            // sort_unstable_by's own order (src/duplex.rs:620,807): the merged candidates in ascending node order go
+            // through the restated quicksort (one lane); the position of a candidate in its result is its rank
+            int pos = 0;
+            for (int j = 0; j < P; ++j) {
+                const uint64_t kj = L.keys[j];
+                pos += (kj != 0ull && (uint32_t)kj > (uint32_t)key) ? 1 : 0;  // low word: larger = smaller node
+            }
+            if (valid) L.pq_list[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)lane;
+            wave_sync();
+            if (lane == 0) pdq178::sort_desc(L.pq_list, n_valid, L.pq_scr);
+            wave_sync();
+            if (lane < n_valid) L.pw[(int)(uint32_t)L.pq_list[lane]] = lane;
+            wave_sync();
+            if (valid) rank = L.pw[lane];
+            wave_sync();
+        }
+        FCD_S_SUB_BEGIN()
+
+        // ---- the next beam: survivors keep (or get) a slot, everything else that was live leaves ----
+        const bool surv = valid && rank < Bn;
+        const bool stale_in = surv && ck > 0 && !is_new;  // an existing child comes (back) into the beam
+        const uint64_t m_stale = ballot(stale_in);
+        int myslot = ck == 0 ? slot_i : nbuf;
+        if (stale_in) myslot = L.flist[n_new + popc64(m_stale & lanemask_lt())];
+        // its record: asked for now, used after the evictions below
+        int4 s_meta = make_int4(0, 0, 0, 0), s_aux = make_int4(0, 0, 0, 0);
+        if (stale_in) {
+            s_meta = load_int4_l2(&meta[cid]);
+            s_aux = load_int4_l2(&aux[cid]);
+            const int l = ck - 1;
+            fi(F_NODE, myslot) = cid;
+            fi(F_TIP, myslot) = l;
+            fi(F_PAR, myslot) = node;
+            fi(F_STATE, myslot) = crf ? (int)(((int64_t)state * NL) % S) + l : 0;  // :782
+            fi(F_XREP, myslot) = (!crf && node >= 0 && tip == l) ? 1 : 0;
+            fi(F_DEPTH, myslot) = depth + 1;
+            for (int j = 0; j < NL; ++j) fi(F_CHILD0 + j, myslot) = load_i32_l2(&rows[(int64_t)cid * NLp + j]);
+        }
+        if (PROF && prof) n_enter += (uint32_t)popc64(m_stale);
+        // rank lanes of the next beam
+        {
+            const int dst = surv ? rank : 63;
+            const int s2 = __builtin_amdgcn_ds_permute(dst << 2, myslot);
+            const int n2 = __builtin_amdgcn_ds_permute(dst << 2, cid);
+            const int l2 = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(clp));
+            const int g2 = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(cgp));
+            slotE = s2; nodeE = n2; lpE = __int_as_float(l2); gpE = __int_as_float(g2);
+        }
+        // a state outside [0, S) is an ndarray index panic in the reference when the entry is next expanded (:749) --
+        // which never happens for the entries the last row leaves behind
+        wave_sync();
+        if (crf && more) {
+            const bool bs = lane < Bn && fi(F_STATE, slotE) >= S;
+            if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
+        }
+        // ---- evictions: a live slot whose node is not in the next beam goes to the arena ----
+        {
+            const bool ev = (act && ck == 0 && !surv) || (is_new && can && !surv);
+            // slot-lane view for the parents'-bounds cache: lane b looks after slot b
+            const int par_b = fi(F_PAR, lane);
+            bool live_next = false;
+            for (int j = 0; j < Bn; ++j) {
+                const int sj = rl_i(slotE, j);
+                live_next = live_next | (sj == lane);
+            }
+            for (uint64_t m = ballot(ev); m != 0ull; m &= m - 1) {
+                const int src = (int)__builtin_ctzll(m);
+                const int s = rl_i(myslot, src);
+                const int nd = fi(F_NODE, s);  // (wave-uniform address: a broadcast read)
+                if (nd < 0) continue;          // the root has no arena entry
+                const int e_off = fi(F_OFF, s), e_end = fi(F_END, s), e_vf = fi(F_VFROM, s);
+                // ring: Wcap4 floats, 16 bytes per lane
+                for (int x = lane; x < (WC >> 2); x += kWave) {
+                    const float4 v = reinterpret_cast<const float4 *>(ring(s))[x];
+                    reinterpret_cast<float4 *>(aring + (int64_t)nd * WC)[x] = v;
+                }
+                if (lane == 0) {
+                    meta[nd] = make_int4(fi(F_PAR, s), fi(F_TIP, s), e_off, e_end);
+                    aux[nd] = make_int4(fi(F_MX, s), e_vf, fi(F_LLAB, s), 0);
+                }
+                if (lane < NL) rows[(int64_t)nd * NLp + lane] = fi(F_CHILD0 + lane, s);
+                // entries of the next beam whose parent this is remember its bounds
+                if (live_next && par_b == nd) {
+                    fi(F_POFF, lane) = e_off;
+                    fi(F_PEND, lane) = e_end;
+                    fi(F_PVFROM, lane) = e_vf;
+                }
+            }
+        }
+        // ---- nodes coming back: ring and record from the arena into their slot ----
+        for (uint64_t m = m_stale; m != 0ull; m &= m - 1) {
+            const int src = (int)__builtin_ctzll(m);
+            const int s = rl_i(myslot, src), nd = rl_i(cid, src);
+            float *dst = ring(s);
+            const float *a = aring + (int64_t)nd * WC;
+            for (int x0 = 0; x0 < WC; x0 += 4 * kWave) {  // four loads in flight per lane
+                float v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + u * kWave + lane;
+                    v[u] = x < WC ? load_f32_l2(a + x) : 0.0f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int x = x0 + u * kWave + lane;
+                    if (x < WC) dst[x] = v[u];
+                }
+            }
+        }
+        if (stale_in) {
+            fi(F_OFF, myslot) = s_meta.z;
+            fi(F_END, myslot) = s_meta.w;
+            fi(F_MX, myslot) = s_aux.x;
+            fi(F_VFROM, myslot) = s_aux.y;
+            fi(F_LLAB, myslot) = s_aux.z;
+        }
+        FCD_S_SUB(1)
+        // ---- free list of the coming step: the slots no entry of the next beam sits in ----
+        {
+            bool used = false;
+            for (int j = 0; j < Bn; ++j) {
+                const int sj = rl_i(slotE, j);
+                used = used | (sj == lane);
+            }
+            const bool is_free = lane < P && !used;
+            const uint64_t fm = ballot(is_free);
+            if (is_free) L.flist[popc64(fm & lanemask_lt())] = lane;
+        }
+        if (more && lane < SN) L.f1[lane] = f1_next;
+        B = Bn;
+        wave_sync();
+        FCD_S_PHASE(4)
+    }
+    if (PROF && prof && lane == 0) {
+        uint32_t *o = p.prof + 16 * r;
+        for (int k = 0; k < 5; ++k) o[k] = (uint32_t)(acc[k] >> 6);  // units of 64 cycles
+        o[5] = n_iter;
+        o[6] = n_newnodes;
+        o[7] = (uint32_t)T1;
+        o[8] = n_slow;
+        o[9] = n_enter;
+        o[10] = n_ext;
+        for (int k = 0; k < 5; ++k) o[11 + k] = (uint32_t)(sub[k] >> 6);
+    }
+    (void)n_redo;
+
+    // ---- labels leaf -> root (:638-649), written in sequence order ----
+    // entries still in the beam have no arena record yet: the walk needs (parent, label) of the best node's ancestors
+    if (lane < B && nodeE >= 0) meta[nodeE] = make_int4(fi(F_PAR, slotE), fi(F_TIP, slotE), fi(F_OFF, slotE), fi(F_END, slotE));
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
+    {
+        const int s0 = rl_i(slotE, 0);
+        const int n = fi(F_DEPTH, s0);
+        if (lane == 0) {
+            int q = rl_i(nodeE, 0);
+            for (int j = n - 1; j >= 0; --j) {
+                const int4 mq = load_int4_l2(&meta[q]);
+                lab_out[j] = (uint8_t)(mq.y + 1);
+                q = mq.x;
+            }
+            p.out.out_len[r] = (uint32_t)n;
+            p.out.status[r] = FCD_ST_OK;
+            if (count_amb) {
+                p.out.ambiguous[2 * r] = (uint32_t)n_amb;
+                p.out.ambiguous[2 * r + 1] = (uint32_t)n_crit;
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool duplex_slots_supported(int beam_size, int N, int S, int width, int tie_order) {
+    if (beam_size < 1 || N < 2 || N > 8 || beam_size > kBeamMax || (int64_t)beam_size * N > kSlots) return false;
+    const int WC = duplex_slots_ring_rows(width);
+    return duplex_slots_lds_bytes(beam_size, N, S, WC, tie_order) <= 64 * 1024;
+}
+
+int duplex_slots_ring_rows(int width) { return ((width > 1 ? width : 1) + 4 + 3) & ~3; }
+
+size_t duplex_slots_lds_bytes(int beam_size, int N, int S, int WC, int tie_order) {
+    return slds_words(beam_size, N, S, WC, tie_order == FCD_TIE_PDQ178 && (int64_t)beam_size * N > 20) * 4 + 16;
+}
+
+hipError_t launch_duplex_slots(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream) {
+    if (n_pairs <= 0) return hipSuccess;
+    SlotParams p;
+    p.ln1 = a.ln1; p.ln2 = a.ln2; p.T1cap = a.T1cap; p.T2cap = a.T2cap;
+    p.len1 = a.len1; p.len2 = a.len2; p.env = a.env; p.env_stride = a.env_stride;
+    p.N = a.N; p.beam_size = a.beam_size; p.thr_ln = a.thr_ln; p.collapse = a.collapse;
+    p.S = a.S; p.crf = a.crf; p.init1 = a.init1; p.init2 = a.init2; p.n_init1 = a.n_init1;
+    p.n_init2 = a.n_init2; p.init1_stride = a.init1_stride; p.init2_stride = a.init2_stride;
+    p.meta = a.meta; p.aux = a.aux; p.rows = a.rows; p.ring = a.vec; p.rootgap = a.rootgap;
+    p.cap_nodes = a.cap_nodes; p.Wcap4 = a.Wcap; p.NLp = a.NLp;
+    p.out = a.out; p.pair_begin = pair_begin; p.prof = a.prof; p.tie_order = a.tie_order;
+    const size_t lds = duplex_slots_lds_bytes(a.beam_size, a.N, a.S, a.Wcap, a.tie_order);
+    const dim3 grid((unsigned)n_pairs), block(64);
+#define FCD_SLOTS_LAUNCH(MODE)                                                                                     \
+    do {                                                                                                           \
+        if (a.prof) hipLaunchKernelGGL((duplex_slots_kernel<MODE, true>), grid, block, lds, stream, p);            \
+        else hipLaunchKernelGGL((duplex_slots_kernel<MODE, false>), grid, block, lds, stream, p);                  \
+    } while (0)
+    if (a.mode == FCD_LOGADD_LOGSUMEXP_GLIBC235) FCD_SLOTS_LAUNCH(FCD_LOGADD_LOGSUMEXP_GLIBC235);
+    else if (a.mode == FCD_LOGADD_MAX) FCD_SLOTS_LAUNCH(FCD_LOGADD_MAX);
+    else FCD_SLOTS_LAUNCH(FCD_LOGADD_LOGSUMEXP);
+#undef FCD_SLOTS_LAUNCH
+    return hipGetLastError();
+}
+
+}  // namespace fcd

@@ -130,9 +130,18 @@ struct DuplexArgs {
     ResultDesc out;
     uint32_t *prof;  // developer instrument: [pair][8] cycle account, nullable
     int tie_order;   // FCD_TIE_PDQ178 / FCD_TIE_STABLE
+    // slot-resident kernel (duplex_slots.hip): `vec` holds Wcap (= ring rows, a multiple of 4) floats per node -- label (+)
+    // gap per row -- `aux` {running maximum, vfrom, last label, 0} per node, `rows` NLp child ids per node
+    int4 *aux;
+    int NLp;
 };
 
 size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S, int tie_order);
+// duplex_slots.hip: beam_size * N <= 64, N <= 8, and the rings of every live node + the read-2 tile fit 64 KiB of LDS
+bool duplex_slots_supported(int beam_size, int N, int S, int width, int tie_order);
+int duplex_slots_ring_rows(int width);  // ring capacity for a widest envelope row of `width`
+size_t duplex_slots_lds_bytes(int beam_size, int N, int S, int ring_rows, int tie_order);
+hipError_t launch_duplex_slots(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream);
 hipError_t launch_ln_convert(const float *x, int dtype, int64_t n_reads, int64_t T, int S, int N, int64_t s_read,
                              int64_t s_t, int64_t s_s, int64_t s_n, float *out, int glibc235, hipStream_t stream);
 hipError_t launch_env_width(const uint64_t *env, int64_t n_pairs, int64_t env_stride, int64_t T1cap,
@@ -258,6 +267,7 @@ struct fcd_handle {
     bool job_active = false;  // a host job owns the lanes from begin to end
     bool is_lane = false;
     uint32_t *duplex_prof = nullptr;  // fcd_debug_set_duplex_profile
+    int duplex_kernel = 0;            // fcd_debug_set_duplex_kernel: 0 automatic, 1 the any-shape kernel (duplex.hip), 2 the slot-resident one
     int tie_order = FCD_TIE_DEFAULT;  // fcd_set_tie_order; FCD_TIE_DEFAULT = follow the process default
     int pipe_lanes = 0;          // fcd_set_host_pipeline: 0 = default (FCD_HOST_LANES or 4)
     int64_t pipe_chunk = 0;      // reads per chunk, 0 = automatic

@@ -54,6 +54,13 @@ int fcd_debug_set_first_pass_divisor(fcd_handle *h, int divisor);
  * NULL switches it off.  The stamps wait for each phase's results (tools/duplex_account.py). */
 int fcd_debug_set_duplex_profile(fcd_handle *h, uint32_t *cycles);
 
+/* Test hook: which kernel the duplex searches on this handle run -- 0 automatic (the slot-resident kernel,
+ * csrc/duplex_slots.hip, wherever beam_size * N <= 64 and its rings fit the LDS; the any-shape kernel, csrc/duplex.hip,
+ * otherwise), 1 the any-shape kernel always, 2 the slot-resident kernel (FCD_E_UNSUPPORTED where it does not fit).  The
+ * process default comes from FCD_DUPLEX_KERNEL = "legacy" / "slots".  Results are identical by construction; the
+ * tests run both. */
+int fcd_debug_set_duplex_kernel(fcd_handle *h, int which);
+
 /* Developer instrument, not part of the drop-in surface: the headline instantiation of the register kernel
  * (beam_size <= 5, N = 5, two reads per wavefront) with a shader-clock stamp after each block of the time
  * step.  cycles: device array [ceil(n_reads / 2)][8] u32 -- per wavefront, cycles summed over the read in
