@@ -95,7 +95,8 @@ struct fcd_comm {
     bool owns_comm = false;
     int world = 1, rank = 0;
     Buf send, recv, meta;  // grow-only device buffers: packed shard | world packed shards | offsets
-    Buf fixed;             // [0, 8) the agreed label total, [8, 12) bad-header flag, [64, ...) first[world + 1]
+    Buf fixed;             // [0, 32) the agreed {label total, out_stride, ~capacity, error}, [32, 36) bad-header flag,
+                           // [64, 96) this rank's four words, [128, ...) first[world + 1]; allocated with the communicator
     std::vector<int64_t> counts;  // the counts `first` on the device was computed from
     void *pin = nullptr;   // page-locked bytes for the size / flag read-back
 };
@@ -107,13 +108,20 @@ int comm_fail(fcd_comm *c, int code, const std::string &msg) {
     return code;
 }
 
-// test hook (tests/capi/comm_world.c): FCD_DEBUG_FAIL_GATHER_ALLOC=<rank> makes that rank's gather buffers
-// "unallocatable", once they have to grow -- the failure every rank must then learn of before any of them enqueues its
-// ncclGather
-bool injected_alloc_failure(const fcd_comm *c) {
-    const char *e = getenv("FCD_DEBUG_FAIL_GATHER_ALLOC");
-    return e && *e && atoi(e) == c->rank;
+// test hooks (tests/capi/comm_world.c): FCD_DEBUG_FAIL_GATHER_ALLOC=<rank> makes that rank's gather buffers
+// "unallocatable" once they have to grow -- the failure every rank must learn of before any of them enqueues its
+// ncclGather; FCD_DEBUG_FAIL_GATHER_PREP=<rank> fails that rank's preparation (offsets workspace) BEFORE the size
+// agreement -- the rank must still join the all-reduce and every rank must come back with the error.  A value that is
+// not a plain rank number switches nothing on.
+bool debug_rank_env(const char *name, int rank) {
+    const char *e = getenv(name);
+    if (!e || !*e) return false;
+    char *end = nullptr;
+    const long v = strtol(e, &end, 10);
+    return end && *end == 0 && v >= 0 && v == (long)rank;
 }
+bool injected_alloc_failure(const fcd_comm *c) { return debug_rank_env("FCD_DEBUG_FAIL_GATHER_ALLOC", c->rank); }
+bool injected_prep_failure(const fcd_comm *c) { return debug_rank_env("FCD_DEBUG_FAIL_GATHER_PREP", c->rank); }
 
 int need(fcd_comm *c, Buf &b, size_t bytes) {
     if (b.cap >= bytes) return FCD_OK;
@@ -135,11 +143,24 @@ int nccl_check(fcd_comm *c, int rc, const char *what) {
     return comm_fail(c, FCD_E_HIP, std::string(what) + ": " + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error"));
 }
 
+constexpr size_t kFixedBytes = 128 + 65 * 8;
+
+// The communicator's fixed-size pieces -- the words of the size agreement and the page-locked read-back -- exist from
+// creation on (the handle's device current): nothing a gather needs BEFORE its first collective can then fail on one
+// rank only, except the per-batch offsets workspace, whose failure travels through that collective (below).
 fcd_comm *new_comm(fcd_handle *h, int world, int rank) {
     fcd_comm *c = new fcd_comm();
     c->h = h;
     c->world = world;
     c->rank = rank;
+    if (hipMalloc(&c->fixed.p, kFixedBytes) != hipSuccess || hipMemset(c->fixed.p, 0, kFixedBytes) != hipSuccess ||
+        hipHostMalloc(&c->pin, 64, hipHostMallocDefault) != hipSuccess) {
+        if (c->fixed.p) (void)hipFree(c->fixed.p);
+        h->err = "allocation failed (communicator)";
+        delete c;
+        return nullptr;
+    }
+    c->fixed.cap = kFixedBytes;
     return c;
 }
 
@@ -169,15 +190,24 @@ int fcd_comm_create(fcd_handle *h, int world, int rank, const uint8_t id[FCD_COM
     }
     int prev = -1;
     if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (world > 64) {
+        h->err = "more than 64 ranks";
+        return FCD_E_UNSUPPORTED;
+    }
     if (prev != h->device && hipSetDevice(h->device) != hipSuccess) return FCD_E_HIP;
-    fcd_comm *c = new_comm(h, world, rank);
+    fcd_comm *c = new_comm(h, world, rank);  // (before ncclCommInitRank: a rank that cannot allocate never joins)
+    if (!c) {
+        if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
+        return FCD_E_NOMEM;
+    }
     NcclId nid;
     memcpy(nid.internal, id, FCD_COMM_ID_BYTES);
     const int rc = r.CommInitRank(&c->comm, world, nid, rank);  // one process per GPU: the handle's device
     if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
     if (rc != 0) {
         h->err = std::string("ncclCommInitRank: ") + (r.GetErrorString ? r.GetErrorString(rc) : "RCCL error");
-        delete c;
+        c->owns_comm = false;
+        (void)fcd_comm_destroy(c);
         return FCD_E_HIP;
     }
     c->owns_comm = true;
@@ -190,7 +220,14 @@ int fcd_comm_wrap(fcd_handle *h, void *nccl_comm, int world, int rank, fcd_comm 
     *out = nullptr;
     if (!nccl_comm && world != 1) return FCD_E_INVALID;  // no communicator: a single rank only
     if (nccl_comm && !rccl().ok) return FCD_E_UNSUPPORTED;
+    if (world > 64) return FCD_E_UNSUPPORTED;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    int prev = -1;
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    if (prev != h->device && hipSetDevice(h->device) != hipSuccess) return FCD_E_HIP;
     fcd_comm *c = new_comm(h, world, rank);
+    if (prev >= 0 && prev != h->device) (void)hipSetDevice(prev);
+    if (!c) return FCD_E_NOMEM;
     c->comm = nccl_comm;
     *out = c;
     return FCD_OK;
@@ -241,55 +278,80 @@ int fcd_gather_results_dev(fcd_comm *c, const fcd_result *res, int64_t n_reads, 
     } restore{prev, h->device};
     hipStream_t st = h->stream;
     const int W = (int)std::min<int64_t>(res->out_stride, 1 << 30);
+    int rc = FCD_OK;
+    // Nothing between here and the first collective may return on ONE rank only -- the others are about to enter the
+    // all-reduce and would wait for this one for ever.  What fails here (the per-batch offsets workspace, a launch) is
+    // remembered, the rank joins the reduction with its error word set, and EVERY rank returns an error after it.
+    int pre_rc = FCD_OK;
+    std::string pre_msg;
+    auto pre_fail = [&](int code, const char *what) {
+        if (pre_rc == FCD_OK) {
+            pre_rc = code;
+            pre_msg = what;
+        }
+    };
+#define FCD_PRE(call)                                                            \
+    do {                                                                         \
+        const hipError_t e_ = (call);                                            \
+        if (e_ != hipSuccess) pre_fail(FCD_E_HIP, hipGetErrorString(e_));        \
+    } while (0)
     // meta: offsets of this shard [n_reads + 1] | unpack offsets [n_total + world] (destination)
     const size_t o_uoffs = ((size_t)(n_reads + 1) * 8 + 15) & ~(size_t)15;
-    int rc = need(c, c->meta, o_uoffs + (is_dst ? (size_t)(n_total + c->world) * 8 : 0) + 16);
-    if (rc) return rc;
-    if (c->world > 64) return comm_fail(c, FCD_E_UNSUPPORTED, "more than 64 ranks");
-    if (!c->fixed.p) {
-        rc = need(c, c->fixed, 64 + 65 * 8);
-        if (rc) return rc;
-        FCD_HIP(h, hipMemsetAsync(c->fixed.p, 0, 64 + 65 * 8, st));
-    }
-    if (!c->pin && hipHostMalloc(&c->pin, 64, hipHostMallocDefault) != hipSuccess)
-        return comm_fail(c, FCD_E_NOMEM, "hipHostMalloc failed (gather)");
+    if (injected_prep_failure(c)) pre_fail(FCD_E_NOMEM, "hipMalloc failed (gather offsets; injected)");
+    else if (need(c, c->meta, o_uoffs + (is_dst ? (size_t)(n_total + c->world) * 8 : 0) + 16) != FCD_OK)
+        pre_fail(FCD_E_NOMEM, "hipMalloc failed (gather offsets)");
     char *meta = reinterpret_cast<char *>(c->meta.p);
     char *fixed = reinterpret_cast<char *>(c->fixed.p);
     uint64_t *d_offs = reinterpret_cast<uint64_t *>(meta);
-    // fixed: [0, 24) the agreed {largest label total, largest out_stride, ~smallest capacity} | [24, 28) header flag |
-    // [32, 56) this rank's three words | [64, ...) prefix sums of the read counts
+    // fixed: [0, 32) the agreed {largest label total, largest out_stride, ~smallest capacity, any error} | [32, 36)
+    // header flag | [64, 96) this rank's four words | [128, ...) prefix sums of the read counts
     uint64_t *d_max = reinterpret_cast<uint64_t *>(fixed);
-    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 24);
-    uint64_t *d_mine = reinterpret_cast<uint64_t *>(fixed + 32);
-    int64_t *d_first = reinterpret_cast<int64_t *>(fixed + 64);
-    FCD_HIP(h, launch_result_offsets(res->out_len, n_reads, W, d_offs, st));
+    int32_t *d_bad = reinterpret_cast<int32_t *>(fixed + 32);
+    uint64_t *d_mine = reinterpret_cast<uint64_t *>(fixed + 64);
+    int64_t *d_first = reinterpret_cast<int64_t *>(fixed + 128);
+    if (pre_rc == FCD_OK) FCD_PRE(launch_result_offsets(res->out_len, n_reads, W, d_offs, st));
     // Every rank must hand ncclGather the SAME byte count, and that depends on two things: the largest label total
     // and the width of the time indices (2 bytes below 65536 rows) -- i.e. on the largest out_stride.  Both are agreed
-    // on with one 16-byte all-reduce (a rank whose shard is padded differently would otherwise send another size
+    // on with one 32-byte all-reduce (a rank whose shard is padded differently would otherwise send another size
     // and hang or corrupt the collective).
     // The third word is the complement of what this rank's buffers hold already (send; the destination: receive / world),
     // so the same reduction also says whether ANY rank will have to allocate: only then a second, 8-byte all-reduce
-    // follows, in which the ranks tell each other whether they could (below).
+    // follows, in which the ranks tell each other whether they could (below).  The fourth word is 1 on a rank whose
+    // preparation failed.
     uint64_t *pin64 = reinterpret_cast<uint64_t *>(c->pin);
-    pin64[4] = (uint64_t)res->out_stride;
-    pin64[5] = ~(uint64_t)std::min<size_t>(c->send.cap, is_dst ? c->recv.cap / (size_t)c->world : ~(size_t)0);
-    FCD_HIP(h, hipMemcpyAsync(d_mine, d_offs + n_reads, 8, hipMemcpyDeviceToDevice, st));
-    FCD_HIP(h, hipMemcpyAsync(d_mine + 1, pin64 + 4, 16, hipMemcpyHostToDevice, st));
+    pin64[4] = 0;  // (label total: copied device to device below when there is one)
+    pin64[5] = (uint64_t)res->out_stride;
+    pin64[6] = ~(uint64_t)std::min<size_t>(c->send.cap, is_dst ? c->recv.cap / (size_t)c->world : ~(size_t)0);
+    pin64[7] = pre_rc != FCD_OK ? 1u : 0u;
+    FCD_PRE(hipMemcpyAsync(d_mine, pin64 + 4, 32, hipMemcpyHostToDevice, st));
+    if (pre_rc == FCD_OK) {
+        FCD_PRE(hipMemcpyAsync(d_mine, d_offs + n_reads, 8, hipMemcpyDeviceToDevice, st));
+        if (pre_rc != FCD_OK) {  // (the error word has to say so: once more, synchronously)
+            pin64[7] = 1u;
+            (void)hipMemcpyAsync(d_mine, pin64 + 4, 32, hipMemcpyHostToDevice, st);
+        }
+    }
+#undef FCD_PRE
     if (c->comm) {
-        rc = nccl_check(c, rccl().AllReduce(d_mine, d_max, 3, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
+        rc = nccl_check(c, rccl().AllReduce(d_mine, d_max, 4, kNcclUint64, kNcclMax, c->comm, st), "ncclAllReduce");
         if (rc) return rc;
     } else {
-        FCD_HIP(h, hipMemcpyAsync(d_max, d_mine, 24, hipMemcpyDeviceToDevice, st));
+        FCD_HIP(h, hipMemcpyAsync(d_max, d_mine, 32, hipMemcpyDeviceToDevice, st));
     }
     // (the flag behind them is the PREVIOUS gather's header check: reported one call late, or by fcd_comm_synchronize)
-    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 32, hipMemcpyDeviceToHost, st));
+    // (a failing copy or wait here is a lost device: this rank cannot learn the agreed sizes and returns; the other
+    // ranks' collectives end with RCCL's own error)
+    FCD_HIP(h, hipMemcpyAsync(c->pin, d_max, 40, hipMemcpyDeviceToHost, st));
     FCD_HIP(h, hipStreamSynchronize(st));  // the one host wait of the gather
     const uint64_t max_total = pin64[0], max_stride = pin64[1], min_cap = ~pin64[2];
+    if (pin64[3] != 0)  // (the same verdict on every rank: nobody goes on to the gather)
+        return pre_rc != FCD_OK ? comm_fail(c, pre_rc, "gather: " + pre_msg)
+                                : comm_fail(c, FCD_E_HIP, "gather: another rank failed before the size agreement");
     // From here to the ncclGather nothing may return early on one rank only: the other ranks are about to enqueue
     // theirs.  What this rank has to complain about is remembered and reported once its own gather is in the stream.
     const char *late_error = nullptr;
-    if (reinterpret_cast<const int32_t *>(c->pin)[6] != 0) {
-        FCD_HIP(h, hipMemsetAsync(d_bad, 0, 4, st));
+    if (reinterpret_cast<const int32_t *>(c->pin)[8] != 0) {
+        (void)hipMemsetAsync(d_bad, 0, 4, st);
         late_error = "gather: a shard's header contradicted the read counts (earlier call)";
     }
     const int Wmax = (int)std::min<uint64_t>(max_stride, 1u << 30);
@@ -360,9 +422,9 @@ int fcd_comm_synchronize(fcd_comm *c) {
     int32_t bad = 0;
     if (hipStreamSynchronize(h->stream) != hipSuccess) rc = FCD_E_HIP;
     if (rc == FCD_OK && c->fixed.p) {
-        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 24, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
+        if (hipMemcpy(&bad, reinterpret_cast<char *>(c->fixed.p) + 32, 4, hipMemcpyDeviceToHost) != hipSuccess) rc = FCD_E_HIP;
         if (bad) {
-            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 24, 0, 4);
+            (void)hipMemset(reinterpret_cast<char *>(c->fixed.p) + 32, 0, 4);
             rc = comm_fail(c, FCD_E_INVALID, "gather: the header of shard " + std::to_string(bad - 1) +
                                                  " contradicts the read counts / buffer size");
         }

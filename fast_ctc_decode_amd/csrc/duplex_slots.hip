@@ -91,18 +91,19 @@ struct SLds {
     int *bt;         // 64: candidate lane that owns the m-th new node
     int *flist;      // 64: free slots, ascending
     float *f1;       // S * N: the current row of read 1
+    float *zero;     // one word of 0.0f (a "column" whose every row is zero, for pointer-driven loops)
     uint64_t *pq_list;
     pdq178::Scratch *pq_scr;
     float *tile;     // S * N x Wcap4
-    float *rings;    // P x Wcap4
+    float *rings;    // (P + 1) x Wcap4: the slots' rings and a trash ring idle lanes may scribble on
 };
 
 __host__ __device__ inline size_t slds_words(int BC, int N, int S, int WC, bool pdq) {
     const size_t P = (size_t)BC * N;
-    size_t w = (size_t)F_COUNT * kSlots + 2 * (kSlots + 4) + 68 + 64 + 64;
+    size_t w = (size_t)F_COUNT * kSlots + 2 * (kSlots + 4) + 68 + 64 + 64 + 4;
     w += ((size_t)S * N + 3) & ~(size_t)3;
     if (pdq) w += 2 * kSlots + (sizeof(pdq178::Scratch) + 15) / 16 * 4;
-    w += (size_t)S * N * WC + P * WC;
+    w += (size_t)S * N * WC + (P + 1) * WC;
     return w;
 }
 
@@ -115,6 +116,7 @@ __device__ inline SLds scarve(int *smem, int BC, int N, int S, int WC, bool pdq)
     L.bt = p; p += 64;
     L.flist = p; p += 64;
     L.f1 = reinterpret_cast<float *>(p); p += (S * N + 3) & ~3;
+    L.zero = reinterpret_cast<float *>(p); p += 4;
     L.pq_list = reinterpret_cast<uint64_t *>(p);
     if (pdq) p += 2 * kSlots;
     L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p);
@@ -136,6 +138,18 @@ __device__ __forceinline__ float bperm_f(int src_lane, float v) {
 }
 __device__ __forceinline__ int rl_i(int v, int l) { return __builtin_amdgcn_readlane(v, l); }
 __device__ __forceinline__ float rl_f(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
+
+// min(a, |b|) in one instruction (a NaN operand is dropped, as v_min_f32 does)
+__device__ __forceinline__ float vmin_abs_raw(float a, float b) {
+#ifdef FCD_HIPEMU
+    const float c = __builtin_fabsf(b);
+    return a != a ? c : (c != c ? a : (c < a ? c : a));
+#else
+    float r;
+    asm("v_min_f32 %0, %1, |%2|" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+#endif
+}
 
 __device__ __forceinline__ int4 load_int4_l2(const int4 *p) {
     const int32_t *q = reinterpret_cast<const int32_t *>(p);
@@ -167,6 +181,10 @@ __device__ __forceinline__ float ladd_spec(float a, float b, const LogAddCoef &K
     }
     return res;
 }
+
+#ifdef FCD_HIPEMU
+static long g_emu_passes = 0, g_emu_exact = 0;
+#endif
 
 template <int MODE, bool PROF>
 __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
@@ -261,9 +279,18 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
     }
     for (int j = lane; j < kNLMax; j += kWave) fi(F_CHILD0 + j, 0) = -1;
     if (lane < 4) L.keys[kSlots + lane] = 0ull;  // padding of the four-at-a-time rank loop
+    if (lane < 4) L.zero[lane] = 0.0f;
+    // (rows of read 2 that were never loaded read as a finite number: "zero (x) p" stays zero in the guard rows' sums)
+    for (int x = lane; x < SN * WC; x += kWave) L.tile[x] = 0.0f;
+    for (int x = lane; x < WC; x += kWave) ring(P)[x] = kNegInf;
+    // a NaN or +inf among the posteriors of read 2 loaded so far: the window builds take their exact form from then on
+    bool unclean = false;
     L.flist[lane] = lane + 1;                    // free: every slot but 0
     // lane c is candidate (ci, ck) of every step
     const int ci = lane / N, ck = lane - ci * N;
+    // ... item `lane` of a batch of rings copied 16 bytes at a time is piece g_c0 of ring g_q0; 64 items on: + (g_dq, g_dc)
+    const int g_q0 = lane / (WC >> 2), g_c0 = lane - g_q0 * (WC >> 2);
+    const int g_dq = kWave / (WC >> 2), g_dc = kWave - g_dq * (WC >> 2);
     // ... and element (l_rw, l_sn) of a block of read-2 rows taken one element per lane
     const int l_rw = lane / SN, l_sn = lane - l_rw * SN;
     // rank lanes: lane e < B holds entry e of the beam
@@ -341,13 +368,18 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 if (from == pf_lo && hi == pf_hi) {  // asked for during the previous step: one element per lane
                     const int n = (hi - from) * SN;
                     if (lane < n) L.tile[(size_t)l_sn * WC + slotn(from + l_rw)] = pf_val;
+                    unclean = unclean || ballot(lane < n && !(pf_val < __builtin_huge_valf())) != 0ull;
                 } else {
                     const int n = (hi - from) * SN;
+                    bool bad_v = false;
                     for (int x = lane; x < n; x += kWave) {
                         const int rw = x / SN, sn = x - rw * SN;
                         const int row = from + rw;
-                        L.tile[(size_t)sn * WC + (row % WC)] = ln2[(int64_t)row * SN + sn];
+                        const float v = ln2[(int64_t)row * SN + sn];
+                        L.tile[(size_t)sn * WC + (row % WC)] = v;
+                        bad_v = bad_v || !(v < __builtin_huge_valf());
                     }
+                    unclean = unclean || ballot(bad_v) != 0ull;
                 }
                 tl_hi = hi;
                 if (tl_hi - tl_lo > WC) tl_lo = tl_hi - WC;
@@ -414,7 +446,12 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                         if (keep < end) off = keep;
                         else { off = keep; end = keep; }
                     }
-                    if (end == off) { off = lo; end = lo; vfrom = lo; llab = kNegInf; }
+                    if (end == off) {  // emptied: a new run of rows starts at lo, below it two guard rows of "zero"
+                        off = lo; end = lo; vfrom = lo; llab = kNegInf;
+                        float *mw0 = ring(slotE);
+                        mw0[slotn(lo - 1)] = kNegInf;
+                        mw0[slotn(lo - 2)] = kNegInf;
+                    }
                     rescan = true;  // update_max(lo, hi)
                 }
                 panic = end >= hi;  // assert!(current_end < upper_bound) :363-366
@@ -516,8 +553,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             float *rg = ring(0);
             for (int j = lane; j < W; j += kWave) {
                 const int at = lo - 1 + j;
-                if (at < -1 || at >= root_end) continue;
-                rg[slotn(at)] = load_f32_l2(rootgap + (at + 1));
+                if (at < -1) continue;
+                rg[slotn(at)] = at < root_end ? load_f32_l2(rootgap + (at + 1)) : kNegInf;
             }
             wave_sync();
         }
@@ -688,197 +725,230 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 }
                 ff(F_MX, q_buf) = mx;
                 ff(F_LLAB, q_buf) = lb;
+                my[slotn(lo - 1)] = kNegInf;  // the guard rows
+                my[slotn(lo - 2)] = kNegInf;
             }
         };
         if (n_new > 0) {
-            bool redo_pass = MODE == FCD_LOGADD_LOGSUMEXP_GLIBC235;
-            if (MODE == FCD_LOGADD_LOGSUMEXP) {
+            // Who builds what: the m-th new node's parameters come from its candidate lane (L.bt).  Shared by the passes below.
+            struct NodeParams {
+                bool work, rep;
+                int buf, ps, l, state;
+                int p_off, p_end, p_vfrom;
+            };
+            auto node_params = [&](int m) {
+                NodeParams q;
+                const bool have = m < n_new;
+                const int owner = have ? L.bt[m] : 0;
+                const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
+                q.work = have && (o_flags & 1);
+                q.rep = q.work && (o_flags & 2) != 0;
+                const int o_buf = bperm_i(owner, nbuf), o_ps = bperm_i(owner, slot_i), o_l = bperm_i(owner, ck - 1);
+                const int o_state = bperm_i(owner, state), o_node = bperm_i(owner, node);
+                // (idle lanes run the loops too, on the trash ring / slot 0's tables: every address they form is a real one)
+                q.buf = q.work ? o_buf : P;
+                q.ps = q.work ? o_ps : P;
+                q.l = q.work ? o_l : 0;
+                q.state = q.work ? o_state : 0;
+                const bool root = !q.work || o_node < 0;
+                q.p_off = root ? -1 : fi(F_OFF, q.ps);
+                q.p_end = root ? root_end : fi(F_END, q.ps);
+                q.p_vfrom = root ? -1 : fi(F_VFROM, q.ps);
+                return q;
+            };
+            // The lean passes read a parent's row t - 1 (t - 2 for a repeated label) for every t in [lo, hi) straight
+            // out of its ring, without asking whether the row is inside the parent's window: true when the window reaches
+            // hi - 1 and starts at or before lo - 1 -- or starts where the parent's run of rows began (vfrom), below which
+            // every ring holds two rows of "zero" (the guard rows; root: staged).  Receding envelopes, and special
+            // posteriors whose "zero (x) p" is not zero, take the general form.
+            auto lean_ok = [&](const NodeParams &q) {
+                return !q.work || (q.p_end >= hi - 1 && (q.p_off <= lo - 1 || q.p_off == q.p_vfrom) && q.p_vfrom <= lo);
+            };
+            bool redo_pass = MODE == FCD_LOGADD_LOGSUMEXP_GLIBC235 || unclean;
+            if (MODE == FCD_LOGADD_LOGSUMEXP && !redo_pass) {
                 // The recurrence of one node is two interleaved serial chains:
                 //   label_t = p_t[label] (x) (label_{t-1} (+) X_{t-1})            (needs only the label chain)
                 //   sum_t   = label_t (+) (sum_{t-1} (x) p_t[blank])   [gap_t = sum_{t-1} (x) p_t[blank]]
                 // so every new node gets a PAIR of lanes: the even lane runs the label chain, the odd lane runs the sum
                 // chain one row behind it -- same operations in the same order as the reference, one log-add per trip.
+                // A lone wavefront pays ~6 cycles per instruction whatever the instruction is, so the trip is kept to
+                // the log-add and a dozen instructions: every operand comes through a pointer that advances by one row
+                // (the three trips in which some pointer wraps round its ring are fix-up points BETWEEN runs of trips,
+                // not tests inside them), the rare exits of LogSpace::add are folded into two accumulators (the smallest
+                // distance of a binary64 result from an f32 rounding boundary; the largest `big`), and nothing is masked:
+                // idle trips and idle lanes compute on "zero" or on the trash ring.
                 LogAddCoef K = logadd_coef();
                 FCD_OPAQUE_V(K.log2e); FCD_OPAQUE_V(K.ln2hi); FCD_OPAQUE_V(K.ln2lo); FCD_OPAQUE_V(K.two);
 #pragma unroll
                 for (int u = 0; u < 12; ++u) FCD_OPAQUE_V(K.e[u]);
 #pragma unroll
                 for (int u = 0; u < 15; ++u) FCD_OPAQUE_V(K.a[u]);
-                bool redo = false;
-                for (int rd = 0; rd * 32 < n_new; ++rd) {
-                    const int m = rd * 32 + (lane >> 1);
-                    const bool have = m < n_new;
-                    const int owner = have ? L.bt[m] : 0;
-                    const bool isA = (lane & 1) == 0;
-                    const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
-                    const bool work = have && (o_flags & 1);
-                    const bool q_rep = (o_flags & 2) != 0;
-                    const int o_buf = bperm_i(owner, nbuf), o_ps = bperm_i(owner, slot_i), o_l = bperm_i(owner, ck - 1);
-                    const int o_state = bperm_i(owner, state), o_node = bperm_i(owner, node);
-                    // (idle lanes run the loop too, on slot 0's tables: every address they form is a real one)
-                    const int q_buf = work ? o_buf : 0, q_ps = work ? o_ps : 0, q_l = work ? o_l : 0;
-                    const int q_state = work ? o_state : 0;
-                    const bool q_root = !work || o_node < 0;
-                    const int p_off = q_root ? -1 : fi(F_OFF, q_ps), p_end = q_root ? root_end : fi(F_END, q_ps);
-                    const int p_vfrom = q_root ? -1 : fi(F_VFROM, q_ps);
-                    float *my = ring(q_buf);
-                    const float *prg = ring(q_ps);
-                    // per-lane coefficient column: even lane the label's, odd lane the blank's
-                    const float *tc = L.tile + (size_t)(q_state * N + (isA ? q_l + 1 : 0)) * WC;
-                    const float *tb0 = L.tile;  // blank column of state 0 (repeat children exist without states only)
-                    float lb = kNegInf;   // A: label_{t-1};  B: label_{t'} received from A
-                    float sm = kNegInf;   // B: sum_{t'-1}
-                    float mx = kNegInf;
-                    float lkeep = kNegInf;  // B: label of the last row it has combined
-                    // A works on row t = lo + sidx (if sidx < W); B on row t' = lo + sidx - 1 (if sidx >= 1)
-                    int jn = isA ? 0 : -1;      // the row (relative to lo) this lane handles in the coming trip
-                    int s_cur = slotn(lo + jn); // its slot
-                    int s_m1 = slotn(lo + jn - 1), s_m2 = slotn(lo + jn - 2);
-                    const unsigned wlim = work ? (unsigned)W : 0u;
-                    // X of row lo + j is the parent's row lo + j - 1: present iff p_off <= lo + j - 1 < p_end
-                    const int jv0 = p_off + 1 - lo;
-                    const unsigned jspan = isA && p_end > p_off ? (unsigned)(p_end - p_off) : 0u;
-                    const int jvf = p_vfrom + 1 - lo;  // the row whose X has no predecessor sum (repeat children)
-                    auto fetch_x = [&](int j, int sm1, int sm2) {
-                        float xr = prg[sm1];
-                        if (q_rep) {
-                            const float ps = j == jvf ? kNegInf : prg[sm2];
-                            xr = ps + tb0[sm1];
+                const bool isA = (lane & 1) == 0;
+                // slots of rows lo - 2 .. lo + 1 and the first trip in which a pointer wraps (wave-uniform)
+                const int s_m2 = slotn(lo - 2), s_m1 = slotn(lo - 1), s_p1 = slotn(lo + 1);
+                const int first_wrap = WC - (s_m1 > lo_s ? s_m1 : (s_p1 > lo_s ? s_p1 : lo_s));  // (the largest of three consecutive slots mod WC wraps first)
+                const int n_trips = W + 1;
+                for (int rd = 0; rd * 32 < n_new && !redo_pass; ++rd) {
+                    const NodeParams q = node_params(rd * 32 + (lane >> 1));
+                    if (ballot(!lean_ok(q)) != 0ull) { redo_pass = true; break; }
+                    float *trash = ring(P);
+                    const float *col = L.tile + (size_t)(q.state * N + (isA ? q.l + 1 : 0)) * WC;  // even: the label's column, odd: the blank's
+                    const float *prg = ring(q.ps);
+                    // pa: this lane's coefficient of the NEXT trip's row; pb (+ pz): X of the next trip's row -- the
+                    // parent's sum one row up, or (repeated label) its sum two rows up plus the blank one row up; pw: where
+                    // the odd lane stores.  Even lane: rows lo, lo + 1, ...; odd lane: one row behind.
+                    const float *pa = col + (isA ? s_p1 : lo_s);
+                    const float *pb = isA ? prg + (q.rep ? s_m1 : lo_s) : trash + lo_s;
+                    const float *pz = q.rep && isA ? L.tile + lo_s : L.zero;
+                    const int zstep = q.rep && isA ? 1 : 0;
+                    float *pw = (isA ? trash : ring(q.buf)) + (isA ? lo_s : s_m1);
+                    int wa = WC - (isA ? s_p1 : lo_s), wb = WC - (isA && q.rep ? s_m1 : lo_s), wz = zstep ? WC - lo_s : 0x7FFFFFFF,
+                        ww = WC - (isA ? lo_s : s_m1);
+                    float c_cur = isA ? col[lo_s] : 0.0f;
+                    float x_cur = kNegInf;
+                    if (isA) x_cur = q.rep ? prg[s_m2] + L.tile[s_m1] : prg[s_m1] + 0.0f;
+                    float lb = kNegInf;     // A: label_{t-1};  B: label_{t'} received from A
+                    float sm = kNegInf;     // B: sum_{t'-1}
+                    float mx = kNegInf, lkeep = kNegInf;
+                    uint32_t zacc = 0xFFFFFFFFu;  // min over the trips of (dropped bits - (2^28 - 512)) mod 2^32: < 1024 = a Ziv test failed
+                    float bmin = __builtin_huge_valf();  // min over the trips of |big|: below 2^-90 = exp(x) under -86 could show in big + ln_1p(exp(x))
+                    int i = 0;
+                    for (int seg = 0; seg < 4; ++seg) {
+                        const int stop_raw = seg < 3 ? first_wrap + seg : n_trips;
+                        const int stop = stop_raw < n_trips ? stop_raw : n_trips;
+                        // fix-ups due before trip i (no pointer wraps before trip 1)
+                        pa -= i == wa ? WC : 0;
+                        pb -= i == wb ? WC : 0;
+                        pz -= i == wz ? WC : 0;
+                        pw -= i == ww ? WC : 0;
+                        for (; i < stop; ++i) {
+                            const float c_nxt = *pa;
+                            const float x_nxt = *pb + *pz;
+                            const float b = isA ? x_cur : sm + c_cur;  // A: X_{t-1};  B: gap_{t'}
+                            // ---- LogSpace::add(lb, b), exits folded ----
+                            const bool ab = lb <= b;
+                            const float big = ab ? b : lb, small = ab ? lb : b;
+                            const float x = small - big;
+                            const bool full = !(x < kExpFastMin) & !(small == kNegInf);
+                            float v = big;
+                            if (ballot(full) != 0ull) {
+                                const float xs = full ? x : -1.0f;
+                                const double ye = exp_fast((double)xs, K);
+                                const double ed = round_to_f32_as_f64(ye);
+                                const double yl = log1p_fast(ed, K);
+                                const uint32_t d1 = ((uint32_t)bits_of(ye) & 0x1FFFFFFFu) + 0xF0000200u;
+                                const uint32_t d2 = ((uint32_t)bits_of(yl) & 0x1FFFFFFFu) + 0xF0000200u;
+                                zacc = zacc < d1 ? zacc : d1;
+                                zacc = zacc < d2 ? zacc : d2;
+                                const float r = big + (float)yl;
+                                v = full ? r : big;
+                            }
+                            bmin = vmin_abs_raw(bmin, big);
+                            *pw = v;  // (odd lane: sum_{t'}; even lane: the trash ring)
+                            sm = v;
+                            mx = vmax_raw(mx, v);  // (LogSpace::max keeps the accumulator against a NaN, as v_max_f32 does)
+                            lkeep = lb;
+                            const float lb_out = c_cur + v;  // label_t (even lane)
+                            // hand label_t to the odd lane for the next trip; the even lane keeps it
+                            lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
+                                                                            0xf, 0xf, false));
+                            c_cur = c_nxt;
+                            x_cur = x_nxt;
+                            ++pa; ++pb; pz += zstep; ++pw;
                         }
-                        return (unsigned)(j - jv0) < jspan ? xr : kNegInf;
-                    };
-                    float c_cur = tc[s_cur];
-                    float x_cur = isA ? fetch_x(jn, s_m1, s_m2) : kNegInf;
-                    for (int sidx = 0; sidx <= W; ++sidx) {
-                        const bool on = (unsigned)jn < wlim;
-                        // next row's operands (one row past the window at the very end: inside the ring, value unused)
-                        const int s_nx = s_cur + 1 == WC ? 0 : s_cur + 1;
-                        const float c_nxt = tc[s_nx];
-                        const float x_nxt = fetch_x(jn + 1, s_cur, s_m1);
-                        const float bb = isA ? x_cur : sm + c_cur;                    // A: X_{t-1};  B: gap_{t'}
-                        const float v = ladd_spec(lb, bb, K, redo);
-                        if (on && !isA) my[s_cur] = v;  // sum_{t'}
-                        lkeep = on ? lb : lkeep;
-                        // No selects on `on`: the odd lane's idle first row yields -inf (-inf (+) -inf), which changes
-                        // neither sum nor maximum; the even lane never reads sum / maximum; and what the odd lane puts
-                        // into label_t is overwritten by the even lane's through the DPP move below.
-                        sm = v;
-                        mx = lmax(mx, v);
-                        const float lb_out = c_cur + v;  // label_t (even lane)
-                        // hand label_t to the odd lane for the next trip; the even lane keeps it
-                        lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
-                                                                        0xf, 0xf, false));
-                        c_cur = c_nxt;
-                        x_cur = x_nxt;
-                        ++jn;
-                        s_m2 = s_m1;
-                        s_m1 = s_cur;
-                        s_cur = s_nx;
                     }
-                    if (work && !isA) {
-                        ff(F_MX, q_buf) = mx;
-                        ff(F_LLAB, q_buf) = lkeep;  // label_{hi-1}: what the even lane handed over before its idle last trip
+                    if (q.work && !isA) {
+                        float *my = ring(q.buf);
+                        ff(F_MX, q.buf) = mx;
+                        ff(F_LLAB, q.buf) = lkeep;  // label_{hi-1}: what the odd lane combined in its last trip
+                        my[s_m1] = kNegInf;         // the guard rows
+                        my[s_m2] = kNegInf;
                     }
-                    redo = redo & work;  // (idle lanes compute on whatever slot 0 holds)
+                    if (ballot(q.work && (zacc < 1024u || bmin < 8.0779356694631609e-28f)) != 0ull) redo_pass = true;
                 }
-                redo_pass = ballot(redo) != 0ull;
                 if (PROF && prof) n_redo += redo_pass ? 1u : 0u;
-            } else if (MODE == FCD_LOGADD_MAX) {
-                // Max-product mode has no transcendental in the recurrence, so a row costs its instructions: one lane
-                // per node, four rows per trip.  LogSpace::add's max flavour is v_max_f32 unless its FIRST operand is a
-                // NaN (the label chain): watched per row, and a pass that met one is redone on the exact form.
-                const int m = lane;
-                const bool have = m < n_new;
-                const int owner = have ? L.bt[m] : 0;
-                const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
-                const bool work = have && (o_flags & 1);
-                const bool q_rep = (o_flags & 2) != 0;
-                const int o_buf = bperm_i(owner, nbuf), o_ps = bperm_i(owner, slot_i), o_l = bperm_i(owner, ck - 1);
-                const int o_state = bperm_i(owner, state), o_node = bperm_i(owner, node);
-                const int q_buf = work ? o_buf : 0, q_ps = work ? o_ps : 0, q_l = work ? o_l : 0;
-                const int q_state = work ? o_state : 0;
-                const bool q_root = !work || o_node < 0;
-                const int p_off = q_root ? -1 : fi(F_OFF, q_ps), p_end = q_root ? root_end : fi(F_END, q_ps);
-                const int p_vfrom = q_root ? -1 : fi(F_VFROM, q_ps);
-                const float4 *my4 = reinterpret_cast<const float4 *>(ring(q_buf));
-                const float4 *pr4 = reinterpret_cast<const float4 *>(ring(q_ps));
-                const float4 *tb4 = reinterpret_cast<const float4 *>(L.tile + (size_t)(q_state * N) * WC);
-                const float4 *tl4 = reinterpret_cast<const float4 *>(L.tile + (size_t)(q_state * N + q_l + 1) * WC);
-                const float4 *t04 = reinterpret_cast<const float4 *>(L.tile);  // blank column of state 0
-                const int G = WC >> 2;
-                // X of row t is the parent's row t - 1: present iff t in [xa, xb)
-                const int xa = p_off + 1, xb = p_end + 1, xvf = p_vfrom + 1;
-                // all X of [lo, hi) present and no repeat child whose zero-predecessor row falls inside?  (the usual case)
-                const bool plain = ballot(work && (xa > lo || xb < hi || (q_rep && xvf >= lo))) == 0ull;
-                float lab = kNegInf, sum = kNegInf, mx = kNegInf;
-                uint64_t nanm = 0ull;
-                int g = lo >> 2;
-                int sg = lo_s >> 2;
-                const int g_last = (hi - 1) >> 2;
-                // carries from the group before the first one: the parent's rows 4g - 1, 4g - 2 and the blank of 4g - 1
-                float4 pprev, bprev;
-                {
-                    const int sgm = sg == 0 ? G - 1 : sg - 1;
-                    pprev = pr4[sgm];
-                    bprev = t04[sgm];
-                }
-                for (; g <= g_last; ++g) {
-                    const float4 cb = tb4[sg], cl = tl4[sg], px = pr4[sg], b0 = q_rep ? t04[sg] : cb;
-                    const int t0 = g << 2;
-                    // X of the group's four rows
-                    float x0, x1, x2, x3;
-                    if (plain) {
-                        x0 = q_rep ? pprev.z + bprev.w : pprev.w;
-                        x1 = q_rep ? pprev.w + b0.x : px.x;
-                        x2 = q_rep ? px.x + b0.y : px.y;
-                        x3 = q_rep ? px.y + b0.z : px.z;
-                    } else {
-                        auto xj = [&](int t, float s1, float s2, float bl) {
-                            float xr = s1;
-                            if (q_rep) xr = (t == xvf ? kNegInf : s2) + bl;
-                            return (t >= xa && t < xb) ? xr : kNegInf;
-                        };
-                        x0 = xj(t0, pprev.w, pprev.z, bprev.w);
-                        x1 = xj(t0 + 1, px.x, pprev.w, b0.x);
-                        x2 = xj(t0 + 2, px.y, px.x, b0.y);
-                        x3 = xj(t0 + 3, px.z, px.y, b0.z);
+            } else if (MODE == FCD_LOGADD_MAX && !redo_pass) {
+                // Max-product mode has no transcendental in the recurrence, so a row costs its instructions: one lane per
+                // node, four rows per trip -- 16-byte LDS reads of the coefficients and of the parent's rows, one 16-byte
+                // store.  LogSpace::add's max flavour is v_max_f32 unless its FIRST operand is a NaN (the label chain,
+                // duplex.rs:57-61), which takes a NaN or a +inf among the posteriors of read 2 seen so far: such pairs
+                // (`unclean`) build on the exact form from then on.
+                const NodeParams q = node_params(lane);
+                if (ballot(!lean_ok(q)) != 0ull) {
+                    redo_pass = true;
+                } else {
+                    const bool anyrep = ballot(q.rep) != 0ull;
+                    const int G = WC >> 2;
+                    const float4 *pcb = reinterpret_cast<const float4 *>(L.tile + (size_t)(q.state * N) * WC);
+                    const float4 *pcl = reinterpret_cast<const float4 *>(L.tile + (size_t)(q.state * N + q.l + 1) * WC);
+                    const float4 *ppx = reinterpret_cast<const float4 *>(ring(q.ps));
+                    const float4 *pb0 = reinterpret_cast<const float4 *>(L.tile);  // blank column of state 0 (repeat children)
+                    float4 *pmy = reinterpret_cast<float4 *>(ring(q.buf));
+                    const int g0 = lo >> 2, g1 = (hi - 1) >> 2;
+                    int sg = lo_s >> 2;
+                    float lab = kNegInf, sum = kNegInf, mx = kNegInf;
+                    float4 pprev, bprev;  // the group before: the parent's rows 4g - 1, 4g - 2 and the blank of 4g - 1
+                    {
+                        const int sgm = sg == 0 ? G - 1 : sg - 1;
+                        pprev = ppx[sgm];
+                        bprev = pb0[sgm];
                     }
-                    float s0, s1, s2, s3;
-                    const bool whole = t0 >= lo && t0 + 4 <= hi;  // (wave-uniform)
-                    if (whole) {
-                        lab = cl.x + vmax_raw(lab, x0); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.x); s0 = sum;
-                        lab = cl.y + vmax_raw(lab, x1); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.y); s1 = sum;
-                        lab = cl.z + vmax_raw(lab, x2); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.z); s2 = sum;
-                        lab = cl.w + vmax_raw(lab, x3); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.w); s3 = sum;
+                    // one group of four rows at ring group `sgx`; masked: rows outside [lo, hi) are skipped (first / last group)
+                    auto group = [&](int gx, int sgx, bool masked, bool with_rep) __attribute__((always_inline)) {
+                        const float4 cb = pcb[sgx], cl = pcl[sgx], px = ppx[sgx];
+                        float x0 = pprev.w, x1 = px.x, x2 = px.y, x3 = px.z;
+                        if (with_rep) {
+                            const float4 b0 = pb0[sgx];
+                            x0 = q.rep ? pprev.z + bprev.w : x0;
+                            x1 = q.rep ? pprev.w + b0.x : x1;
+                            x2 = q.rep ? px.x + b0.y : x2;
+                            x3 = q.rep ? px.y + b0.z : x3;
+                            bprev = b0;
+                        }
+                        float s0 = kNegInf, s1 = kNegInf, s2 = kNegInf, s3 = kNegInf;
+                        const int t0 = gx << 2;
+                        if (!masked || (t0 >= lo && t0 < hi)) { lab = cl.x + vmax_raw(lab, x0); sum = vmax_raw(lab, sum + cb.x); s0 = sum; }
+                        if (!masked || (t0 + 1 >= lo && t0 + 1 < hi)) { lab = cl.y + vmax_raw(lab, x1); sum = vmax_raw(lab, sum + cb.y); s1 = sum; }
+                        if (!masked || (t0 + 2 >= lo && t0 + 2 < hi)) { lab = cl.z + vmax_raw(lab, x2); sum = vmax_raw(lab, sum + cb.z); s2 = sum; }
+                        if (!masked || (t0 + 3 >= lo && t0 + 3 < hi)) { lab = cl.w + vmax_raw(lab, x3); sum = vmax_raw(lab, sum + cb.w); s3 = sum; }
                         mx = vmax_raw(vmax_raw(mx, vmax_raw(s0, s1)), vmax_raw(s2, s3));
-                    } else {
-                        s0 = s1 = s2 = s3 = kNegInf;
-                        if (t0 >= lo && t0 < hi) {
-                            lab = cl.x + vmax_raw(lab, x0); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.x); s0 = sum;
+                        pmy[sgx] = make_float4(s0, s1, s2, s3);
+                        pprev = px;
+                    };
+                    auto run = [&](bool with_rep) __attribute__((always_inline)) {
+                        int g = g0;
+                        const bool head = (lo & 3) != 0 || g0 == g1;
+                        if (head) {
+                            group(g, sg, true, with_rep);
+                            ++g;
+                            sg = sg + 1 == G ? 0 : sg + 1;
                         }
-                        if (t0 + 1 >= lo && t0 + 1 < hi) {
-                            lab = cl.y + vmax_raw(lab, x1); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.y); s1 = sum;
+                        const int g_full_end = (hi & 3) != 0 ? g1 : g1 + 1;  // groups [g, g_full_end) are whole
+                        while (g < g_full_end) {
+                            // a run of groups up to the end of the ring or of the window
+                            int n = g_full_end - g;
+                            n = n < G - sg ? n : G - sg;
+                            for (int u = 0; u < n; ++u) group(g + u, sg + u, false, with_rep);
+                            g += n;
+                            sg = sg + n == G ? 0 : sg + n;
                         }
-                        if (t0 + 2 >= lo && t0 + 2 < hi) {
-                            lab = cl.z + vmax_raw(lab, x2); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.z); s2 = sum;
-                        }
-                        if (t0 + 3 >= lo && t0 + 3 < hi) {
-                            lab = cl.w + vmax_raw(lab, x3); nanm |= ballot(lab != lab); sum = vmax_raw(lab, sum + cb.w); s3 = sum;
-                        }
-                        mx = vmax_raw(vmax_raw(mx, vmax_raw(s0, s1)), vmax_raw(s2, s3));
+                        if (g <= g1) group(g, sg, true, with_rep);
+                    };
+                    if (anyrep) run(true);
+                    else run(false);
+                    if (q.work) {
+                        ff(F_MX, q.buf) = mx;
+                        ff(F_LLAB, q.buf) = lab;
+                        float *my = ring(q.buf);
+                        my[slotn(lo - 1)] = kNegInf;  // the guard rows (the first group's store may have covered them)
+                        my[slotn(lo - 2)] = kNegInf;
                     }
-                    if (work) const_cast<float4 *>(my4)[sg] = make_float4(s0, s1, s2, s3);
-                    pprev = px;
-                    bprev = b0;
-                    sg = sg + 1 == G ? 0 : sg + 1;
                 }
-                if (work) {
-                    ff(F_MX, q_buf) = mx;
-                    ff(F_LLAB, q_buf) = lab;
-                }
-                redo_pass = (nanm & ballot(work)) != 0ull;
                 if (PROF && prof) n_redo += redo_pass ? 1u : 0u;
             }
+#ifdef FCD_HIPEMU  // (developer aid under the emulator: FCD_EMU_SLOTS_STATS=1 counts how the passes were built)
+            if (lane == 0) { ++g_emu_passes; g_emu_exact += redo_pass ? 1 : 0; }
+#endif
             if (redo_pass) {
                 wave_sync();
                 for (int m0 = 0; m0 < n_new; m0 += kWave) build_exact(m0);
@@ -945,26 +1015,81 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         FCD_S_SUB_BEGIN()
 
         // ---- the next beam: survivors keep (or get) a slot, everything else that was live leaves ----
+        // All of it batched: a step evicts ~7 nodes and the wavefront is alone on its SIMD, so a loop over the evicted
+        // slots (an LDS round trip, a wait and a few dozen instructions each) was 12-15 k cycles of a 20 k step (r06).
         const bool surv = valid && rank < Bn;
         const bool stale_in = surv && ck > 0 && !is_new;  // an existing child comes (back) into the beam
         const uint64_t m_stale = ballot(stale_in);
+        const int n_stale = popc64(m_stale);
         int myslot = ck == 0 ? slot_i : nbuf;
         if (stale_in) myslot = L.flist[n_new + popc64(m_stale & lanemask_lt())];
-        // its record: asked for now, used after the evictions below
+        // records of the nodes coming back: asked for now, looked at after the evictions have been issued
         int4 s_meta = make_int4(0, 0, 0, 0), s_aux = make_int4(0, 0, 0, 0);
+        int s_rows[kNLMax];
+#pragma unroll
+        for (int j = 0; j < kNLMax; ++j) s_rows[j] = -1;
         if (stale_in) {
             s_meta = load_int4_l2(&meta[cid]);
             s_aux = load_int4_l2(&aux[cid]);
-            const int l = ck - 1;
-            fi(F_NODE, myslot) = cid;
-            fi(F_TIP, myslot) = l;
-            fi(F_PAR, myslot) = node;
-            fi(F_STATE, myslot) = crf ? (int)(((int64_t)state * NL) % S) + l : 0;  // :782
-            fi(F_XREP, myslot) = (!crf && node >= 0 && tip == l) ? 1 : 0;
-            fi(F_DEPTH, myslot) = depth + 1;
-            for (int j = 0; j < NL; ++j) fi(F_CHILD0 + j, myslot) = load_i32_l2(&rows[(int64_t)cid * NLp + j]);
+#pragma unroll
+            for (int j = 0; j < kNLMax; ++j)
+                if (j < NL) s_rows[j] = load_i32_l2(&rows[(int64_t)cid * NLp + j]);
         }
-        if (PROF && prof) n_enter += (uint32_t)popc64(m_stale);
+        // ... and their rings, the first two of them (a third one and later: after the evictions)
+        float sr0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sr1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+        const int st_a = n_stale > 0 ? (int)__builtin_ctzll(m_stale) : 0;
+        const uint64_t m_stale2 = m_stale & (m_stale - 1);
+        const int st_b = n_stale > 1 ? (int)__builtin_ctzll(m_stale2) : 0;
+        const bool small_ring = WC <= 4 * kWave;
+        if (n_stale > 0 && small_ring) {
+            const float *aa = aring + (int64_t)rl_i(cid, st_a) * WC;
+            const float *ab_ = aring + (int64_t)rl_i(cid, st_b) * WC;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = u * kWave + lane;
+                if (x < WC) {
+                    sr0[u] = load_f32_l2(aa + x);
+                    if (n_stale > 1) sr1[u] = load_f32_l2(ab_ + x);
+                }
+            }
+        }
+        if (PROF && prof) n_enter += (uint32_t)n_stale;
+        // what leaves: the beam entries that did not survive and the new nodes that did not make it
+        const bool ev = (act && ck == 0 && !surv && node >= 0) || (is_new && can && !surv);  // (the root has no arena entry)
+        const uint64_t m_ev = ballot(ev);
+        const int n_ev = popc64(m_ev);
+        if (ev) {
+            const int qi = popc64(m_ev & lanemask_lt());
+            L.bt[qi] = myslot;
+            L.pw[qi] = cid;  // (ck == 0: cid is the entry's node)
+        }
+        // a survivor whose parent sat in this step's beam and is not in the next one remembers the parent's bounds
+        {
+            const int pr = ck == 0 ? prank_i : ci;  // rank of my parent in this step's beam (own candidates: if it is there)
+            const int prc = (surv && pr >= 0) ? pr : 0;
+            const int p_surv = bperm_i(prc * N, surv ? 1 : 0);
+            const int p_slot = bperm_i(prc * N, slot_i);
+            const int p_node = bperm_i(prc * N, node);
+            if (surv && pr >= 0 && !p_surv && p_node >= 0 && !stale_in) {
+                fi(F_POFF, myslot) = fi(F_OFF, p_slot);
+                fi(F_PEND, myslot) = fi(F_END, p_slot);
+                fi(F_PVFROM, myslot) = fi(F_VFROM, p_slot);
+            }
+            if (stale_in) {  // (its slot's fields are all new)
+                const int l = ck - 1;
+                fi(F_NODE, myslot) = cid;
+                fi(F_TIP, myslot) = l;
+                fi(F_PAR, myslot) = node;
+                fi(F_STATE, myslot) = crf ? (int)(((int64_t)state * NL) % S) + l : 0;  // :782
+                fi(F_XREP, myslot) = (!crf && node >= 0 && tip == l) ? 1 : 0;
+                fi(F_DEPTH, myslot) = depth + 1;
+                if (!p_surv && p_node >= 0) {
+                    fi(F_POFF, myslot) = fi(F_OFF, p_slot);
+                    fi(F_PEND, myslot) = fi(F_END, p_slot);
+                    fi(F_PVFROM, myslot) = fi(F_VFROM, p_slot);
+                }
+            }
+        }
         // rank lanes of the next beam
         {
             const int dst = surv ? rank : 63;
@@ -974,59 +1099,63 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             const int g2 = __builtin_amdgcn_ds_permute(dst << 2, __float_as_int(cgp));
             slotE = s2; nodeE = n2; lpE = __int_as_float(l2); gpE = __int_as_float(g2);
         }
+        wave_sync();
         // a state outside [0, S) is an ndarray index panic in the reference when the entry is next expanded (:749) --
         // which never happens for the entries the last row leaves behind
-        wave_sync();
         if (crf && more) {
             const bool bs = lane < Bn && fi(F_STATE, slotE) >= S;
             if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
         }
-        // ---- evictions: a live slot whose node is not in the next beam goes to the arena ----
-        {
-            const bool ev = (act && ck == 0 && !surv) || (is_new && can && !surv);
-            // slot-lane view for the parents'-bounds cache: lane b looks after slot b
-            const int par_b = fi(F_PAR, lane);
-            bool live_next = false;
-            for (int j = 0; j < Bn; ++j) {
-                const int sj = rl_i(slotE, j);
-                live_next = live_next | (sj == lane);
+        // ---- evictions: records, one evicted node per lane ----
+        if (lane < n_ev) {
+            const int s_ = L.bt[lane], nd = L.pw[lane];
+            meta[nd] = make_int4(fi(F_PAR, s_), fi(F_TIP, s_), fi(F_OFF, s_), fi(F_END, s_));
+            aux[nd] = make_int4(fi(F_MX, s_), fi(F_VFROM, s_), fi(F_LLAB, s_), 0);
+            int32_t *rw = rows + (int64_t)nd * NLp;
+            if (NLp == 4) {
+                *reinterpret_cast<int4 *>(rw) = make_int4(fi(F_CHILD0, s_), NL > 1 ? fi(F_CHILD0 + 1, s_) : -1,
+                                                          NL > 2 ? fi(F_CHILD0 + 2, s_) : -1, NL > 3 ? fi(F_CHILD0 + 3, s_) : -1);
+            } else {
+                for (int j = 0; j < NL; ++j) rw[j] = fi(F_CHILD0 + j, s_);
             }
-            for (uint64_t m = ballot(ev); m != 0ull; m &= m - 1) {
-                const int src = (int)__builtin_ctzll(m);
-                const int s = rl_i(myslot, src);
-                const int nd = fi(F_NODE, s);  // (wave-uniform address: a broadcast read)
-                if (nd < 0) continue;          // the root has no arena entry
-                const int e_off = fi(F_OFF, s), e_end = fi(F_END, s), e_vf = fi(F_VFROM, s);
-                // ring: Wcap4 floats, 16 bytes per lane
-                for (int x = lane; x < (WC >> 2); x += kWave) {
-                    const float4 v = reinterpret_cast<const float4 *>(ring(s))[x];
-                    reinterpret_cast<float4 *>(aring + (int64_t)nd * WC)[x] = v;
-                }
-                if (lane == 0) {
-                    meta[nd] = make_int4(fi(F_PAR, s), fi(F_TIP, s), e_off, e_end);
-                    aux[nd] = make_int4(fi(F_MX, s), e_vf, fi(F_LLAB, s), 0);
-                }
-                if (lane < NL) rows[(int64_t)nd * NLp + lane] = fi(F_CHILD0 + lane, s);
-                // entries of the next beam whose parent this is remember its bounds
-                if (live_next && par_b == nd) {
-                    fi(F_POFF, lane) = e_off;
-                    fi(F_PEND, lane) = e_end;
-                    fi(F_PVFROM, lane) = e_vf;
-                }
+        }
+        // ---- evictions: rings, 16 bytes per lane and trip over all of them at once ----
+        {
+            const int G = WC >> 2;
+            const int total = n_ev * G;
+            int q = g_q0, c = g_c0;  // ring and 16-byte piece of item `lane`
+            for (int x = lane; x < total; x += kWave) {
+                const int s_ = L.bt[q], nd = L.pw[q];
+                const float4 v = reinterpret_cast<const float4 *>(ring(s_))[c];
+                reinterpret_cast<float4 *>(aring + (int64_t)nd * WC)[c] = v;
+                q += g_dq;
+                c += g_dc;
+                if (c >= G) { c -= G; ++q; }
             }
         }
         // ---- nodes coming back: ring and record from the arena into their slot ----
-        for (uint64_t m = m_stale; m != 0ull; m &= m - 1) {
+        if (n_stale > 0 && small_ring) {
+            float *da = ring(rl_i(myslot, st_a)), *db = ring(rl_i(myslot, st_b));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int x = u * kWave + lane;
+                if (x < WC) {
+                    da[x] = sr0[u];
+                    if (n_stale > 1) db[x] = sr1[u];
+                }
+            }
+        }
+        for (uint64_t m = small_ring ? (m_stale2 & (m_stale2 - 1)) : m_stale; m != 0ull; m &= m - 1) {
             const int src = (int)__builtin_ctzll(m);
-            const int s = rl_i(myslot, src), nd = rl_i(cid, src);
-            float *dst = ring(s);
-            const float *a = aring + (int64_t)nd * WC;
+            const int s_ = rl_i(myslot, src), nd = rl_i(cid, src);
+            float *dst = ring(s_);
+            const float *a_ = aring + (int64_t)nd * WC;
             for (int x0 = 0; x0 < WC; x0 += 4 * kWave) {  // four loads in flight per lane
                 float v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
                     const int x = x0 + u * kWave + lane;
-                    v[u] = x < WC ? load_f32_l2(a + x) : 0.0f;
+                    v[u] = x < WC ? load_f32_l2(a_ + x) : 0.0f;
                 }
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -1041,6 +1170,9 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             fi(F_MX, myslot) = s_aux.x;
             fi(F_VFROM, myslot) = s_aux.y;
             fi(F_LLAB, myslot) = s_aux.z;
+#pragma unroll
+            for (int j = 0; j < kNLMax; ++j)
+                if (j < NL) fi(F_CHILD0 + j, myslot) = s_rows[j];
         }
         FCD_S_SUB(1)
         // ---- free list of the coming step: the slots no entry of the next beam sits in ----
@@ -1132,6 +1264,9 @@ hipError_t launch_duplex_slots(const DuplexArgs &a, int64_t pair_begin, int64_t 
     else if (a.mode == FCD_LOGADD_MAX) FCD_SLOTS_LAUNCH(FCD_LOGADD_MAX);
     else FCD_SLOTS_LAUNCH(FCD_LOGADD_LOGSUMEXP);
 #undef FCD_SLOTS_LAUNCH
+#ifdef FCD_HIPEMU
+    if (getenv("FCD_EMU_SLOTS_STATS")) fprintf(stderr, "duplex_slots: %ld build passes so far, %ld on the exact form\n", g_emu_passes, g_emu_exact);
+#endif
     return hipGetLastError();
 }
 

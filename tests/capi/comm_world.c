@@ -12,6 +12,9 @@
  *     badheader   rank 1 and rank 0 disagree about rank 1's read count: the destination must report the shard
  *     allocfail   rank WORLD-1 cannot allocate its gather buffers (FCD_DEBUG_FAIL_GATHER_ALLOC): EVERY rank must come
  *                 back with FCD_E_NOMEM, nobody may hang in a collective
+ *     prepfail    rank WORLD-1 fails BEFORE the size agreement (its offsets workspace: FCD_DEBUG_FAIL_GATHER_PREP): it
+ *                 must still join the all-reduce, and every rank comes back with an error (the failing one with
+ *                 FCD_E_NOMEM, the others with FCD_E_HIP "another rank failed")
  * exit status 0 = the scenario behaved; a watchdog (alarm) turns a hang into a failure. */
 #include <signal.h>
 #include <stdint.h>
@@ -102,6 +105,7 @@ static int run_rank(int world, int rank, const uint8_t *id, const char *scenario
     struct result_mem mine, all, want;
     fcd_comm *c = NULL;
     int k, rc, expect_nomem = !strcmp(scenario, "allocfail"), badheader = !strcmp(scenario, "badheader");
+    const int prepfail = !strcmp(scenario, "prepfail");
     g_rank = rank;
     for (k = 0; k < world; ++k) counts[k] = 1 + (k * 5 + 2) % 4;
     if (!strcmp(scenario, "uneven") && world >= 2) {
@@ -125,6 +129,17 @@ static int run_rank(int world, int rank, const uint8_t *id, const char *scenario
     CHECK(decode(g_h, first, counts[rank], &mine));
     if (alloc_result(&all, total, dst_stride)) return 11;
     rc = fcd_gather_results_dev(c, &mine.r, counts[rank], view, 0, rank == 0 ? &all.r : NULL);
+    if (prepfail) {
+        const int want_rc = rank == world - 1 ? FCD_E_NOMEM : (world > 1 ? FCD_E_HIP : FCD_E_NOMEM);
+        if (rc != want_rc) {
+            fprintf(stderr, "rank %d: a rank failed before the size agreement, this one got %d, not %d (%s)\n", rank, rc, want_rc,
+                    fcd_last_error(g_h));
+            return 19;
+        }
+        (void)fcd_comm_destroy(c);
+        (void)fcd_destroy(g_h);
+        return 0;
+    }
     if (expect_nomem) {
         if (rc != FCD_E_NOMEM) {
             fprintf(stderr, "rank %d: an allocation failed on one rank, this one got %d (%s)\n", rank, rc, fcd_last_error(g_h));
@@ -179,7 +194,7 @@ int main(int argc, char **argv) {
     pid_t pids[64];
     int world, k, bad = 0;
     if (argc < 3 || (world = atoi(argv[1])) < 1 || world > 64) {
-        fprintf(stderr, "usage: comm_world WORLD uneven|wide|mixed|badheader|allocfail\n");
+        fprintf(stderr, "usage: comm_world WORLD uneven|wide|mixed|badheader|allocfail|prepfail\n");
         return 2;
     }
     if (fcd_comm_unique_id(id) != FCD_OK) {
@@ -190,6 +205,11 @@ int main(int argc, char **argv) {
         char v[16];
         snprintf(v, sizeof v, "%d", world - 1);
         setenv("FCD_DEBUG_FAIL_GATHER_ALLOC", v, 1);
+    }
+    if (!strcmp(argv[2], "prepfail")) {
+        char v[16];
+        snprintf(v, sizeof v, "%d", world - 1);
+        setenv("FCD_DEBUG_FAIL_GATHER_PREP", v, 1);
     }
     fflush(NULL);
     for (k = 0; k < world; ++k) {

@@ -2,8 +2,8 @@
 the emulator build of the library and tests/stubs/librccl_stub.c (five RCCL entry points over POSIX shared memory) in
 place of RCCL -- fcd_comm_create, a beam search per rank, ONE fcd_gather_results_dev, rank 0 compares with a
 single-process decode.  Covers uneven and empty shards, out_stride across the 65535-row boundary, a shard whose header
-contradicts the read counts, and an allocation failure on one rank between the size agreement and the gather: every
-rank must come back with the error, nobody may hang.  No GPU: two ranks cannot share one under RCCL, and no scaling
+contradicts the read counts, an allocation failure on one rank between the size agreement and the gather, and (r06) a
+failure on one rank BEFORE the size agreement: every rank must come back with the error, nobody may hang.  No GPU: two ranks cannot share one under RCCL, and no scaling
 curve is claimed from this -- it tests the PROTOCOL (comm.hip), the only part of the multi-GPU path with an exchange."""
 import os
 import subprocess
@@ -36,7 +36,7 @@ def world_exe(tmp_path_factory):
 
 
 @pytest.mark.parametrize("world", [2, 8])
-@pytest.mark.parametrize("scenario", ["uneven", "wide", "mixed", "badheader", "allocfail"])
+@pytest.mark.parametrize("scenario", ["uneven", "wide", "mixed", "badheader", "allocfail", "prepfail"])
 def test_gather_between_processes(world_exe, world, scenario):
     exe, env = world_exe
     r = subprocess.run([exe, str(world), scenario], capture_output=True, text=True, timeout=300, env=env)
