@@ -23,6 +23,11 @@ FLAGS = [
     "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
     "-fhip-fp32-correctly-rounded-divide-sqrt", "-fno-fast-math", "-Wall", "-Wno-unused-function",
 ]
+# Per-file additions.  The duplex kernels run ONE wavefront per SIMD, every instruction on the critical path: where the
+# window-building loop happens to land relative to the instruction-fetch lines moved the logsumexp search by 4 % between
+# two builds of the same source (r06: 109.1 vs 104.5 ms on one box, profiles/r06i_duplex_alignment.txt); aligned loop heads
+# take the lottery out.
+EXTRA_FLAGS = {"duplex_slots.hip": ["-falign-loops=64"]}
 
 
 def _hipcc():
@@ -47,7 +52,7 @@ def build(force=False, verbose=False):
     procs = []
     for s in SOURCES:
         o = os.path.join(CSRC, s.replace(".hip", ".o"))
-        cmd = [_hipcc()] + FLAGS + ["-c", os.path.join(CSRC, s), "-o", o]
+        cmd = [_hipcc()] + FLAGS + EXTRA_FLAGS.get(s, []) + ["-c", os.path.join(CSRC, s), "-o", o]
         if verbose:
             print(" ".join(cmd))
         procs.append((s, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -799,15 +799,18 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     const int want = h->duplex_kernel ? h->duplex_kernel : env_kernel;
     const bool fits = duplex_slots_supported((int)beam_size, N, S, std::max(width, 1), tie);
     if (want == 2 && !fits) return fail(h, FCD_E_UNSUPPORTED, "duplex kernel: the slot-resident kernel does not cover this shape");
-    const bool slots = fits && want != 1;
-    const int Wcap = slots ? duplex_slots_ring_rows(std::max(width, 1)) : std::max(width, 1) + 2;
     const int NLp = (NL + 3) & ~3;
-
     const int64_t cap_nodes = (std::max<int64_t>(in1->T, 1) * beam_size * NL + 8 + 3) & ~3ll;
     if (cap_nodes >= (1ll << 30)) return fail(h, FCD_E_UNSUPPORTED, "tree arena above 2^30 nodes per pair");
-    const size_t per_node = slots ? 2 * sizeof(int4) + (size_t)NLp * 4 + (size_t)Wcap * 4
-                                  : sizeof(int4) + 8 + (size_t)NL * 4 + (size_t)Wcap * 12;
-    const size_t per_pair = (size_t)cap_nodes * per_node + (((size_t)(in2->T + 1) * 4 + 64 + 15) & ~(size_t)15);
+    // (the slot-resident kernel addresses a pair's slab and its log-space reads with 32-bit byte offsets)
+    const bool small = fits && duplex_slots_pair_bytes(cap_nodes, N, duplex_slots_ring_rows(std::max(width, 1)), in2->T) < (1ull << 32) &&
+                       (uint64_t)std::max(in1->T, in2->T) * S * N * 4 < (1ull << 31);
+    if (want == 2 && fits && !small) return fail(h, FCD_E_UNSUPPORTED, "duplex kernel: a pair's arena above 4 GiB");
+    const bool slots = small && want != 1;
+    const int Wcap = slots ? duplex_slots_ring_rows(std::max(width, 1)) : std::max(width, 1) + 2;
+    const size_t per_pair = slots ? duplex_slots_pair_bytes(cap_nodes, N, Wcap, in2->T)
+                                  : (size_t)cap_nodes * (sizeof(int4) + 8 + (size_t)NL * 4 + (size_t)Wcap * 12) +
+                                        (((size_t)(in2->T + 1) * 4 + 64 + 15) & ~(size_t)15);
     const int64_t budget = workspace_budget(h);
     int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_pair);
     chunk = std::min<int64_t>(chunk, B);
@@ -828,11 +831,10 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.init1_stride = is_crf ? crf->s1 : 0; a.init2_stride = is_crf ? crf->s2 : 0;
     char *base = reinterpret_cast<char *>(h->arena);
     a.meta = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
-    a.aux = nullptr; a.nmax = nullptr; a.rlo = nullptr; a.NLp = NLp;
+    a.aux = nullptr; a.nmax = nullptr; a.rlo = nullptr; a.NLp = NLp; a.pair_stride = (int64_t)per_pair;
     if (slots) {
-        a.aux = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
-        a.vec = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * (size_t)Wcap * 4;  // (16-byte aligned rings)
-        a.rows = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * NLp * 4;
+        a.meta = reinterpret_cast<int4 *>(h->arena);  // (one slab per pair: duplex_slots.hip)
+        a.vec = nullptr; a.rows = nullptr;
     } else {
         a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
         a.rlo = reinterpret_cast<int32_t *>(base); base += (size_t)chunk * cap_nodes * 4;

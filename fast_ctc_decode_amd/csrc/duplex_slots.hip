@@ -37,6 +37,9 @@
 // without collapse_repeats :512, assert!(current_end < upper_bound) -> FCD_ST_BAD_STATE), expansion (:526-593), merge in
 // the reference's order (max mode's (+) is not commutative once a NaN takes part), prob_2_max refresh (:613-618), NaN
 // check, sort_unstable_by's order of equal probabilities above 20 candidates (pdq178.h), truncate.
+#include <stdlib.h>
+#include <string.h>
+
 #include "device_utils.h"
 #include "fcd_internal.h"
 #define FCD_PDQ178_FORM0_ONLY 1  // (pdq178.h: the duplex kernels replay the default std form only)
@@ -70,60 +73,48 @@ struct SlotParams {
     int collapse, S, crf;
     const float *init1, *init2;
     int64_t n_init1, n_init2, init1_stride, init2_stride;
-    // arena (per pair slabs)
-    int4 *meta;      // {parent, label, off, end}
-    int4 *aux;       // {running maximum, vfrom, last label, 0}
-    int32_t *rows;   // NLp child ids per node
-    float *ring;     // Wcap4 floats per node: label (+) gap of row t at [t mod Wcap4]
-    float *rootgap;  // T2cap + 1 per pair
+    // arena: ONE slab per pair, below 4 GiB (32-bit byte offsets: base in scalar registers + one vector register):
+    //   meta  int4 per node {parent, label, off, end}
+    //   aux   int4 per node {running maximum, vfrom, last label, 0}
+    //   ring  Wcap4 floats per node: label (+) gap of row t at [t mod Wcap4]
+    //   rows  NLp child ids per node
+    //   root  T2cap + 1 floats: the root's cumulative blank products
+    char *slab;
+    int64_t pair_stride;
     int64_t cap_nodes;
     int Wcap4, NLp;
     ResultDesc out;
     int64_t pair_begin;
     uint32_t *prof;
     int tie_order;
+    int prefetch;  // 1: existing children that pass the threshold have their arena lines touched ahead of the prune
 };
 
+// LDS layout (words of the dynamic segment, which is the kernel's only LDS: offsets are immediates of the ds_ instructions):
+// fixed-size tables first, then what depends on S, N and the ring capacity.
+constexpr int O_KEYS = 0;                                   // 64 (+ 4 zero words of padding) 64-bit sort keys
+constexpr int O_F = O_KEYS + 2 * (kSlots + 4);              // F_COUNT x 64 slot fields
+constexpr int O_PW = O_F + F_COUNT * kSlots;                // 68: probability words by rank / new ranks / evicted nodes
+constexpr int O_BT = O_PW + 68;                             // 64: candidate lane of the m-th new node / evicted slots
+constexpr int O_FLIST = O_BT + 64;                          // 64: free slots, ascending
+constexpr int O_ZERO = O_FLIST + 64;                        // 4: 0.0f (a "column" whose every row is zero)
+constexpr int O_SINK = O_ZERO + 4;                          // 64: where LDS-DMA prefetches land (never read)
+constexpr int O_PQL = O_SINK + 64;                          // 2 x 64: the quicksort's list
+constexpr int O_PQS = O_PQL + 2 * kSlots;                   // its scratch
+constexpr int O_VAR = O_PQS + (int)((sizeof(pdq178::Scratch) + 15) / 16 * 4);
+// then: f1 | f1n (S * N each, rounded to 4) | tile (S * N x Wcap4) | rings ((P + 1) x Wcap4)
+
 struct SLds {
-    int *F;          // F_COUNT x 64
-    uint64_t *keys;  // 64 (+ 4 zero words of padding for the four-at-a-time rank loop)
-    int *pw;         // 66: probability words by rank, then new ranks of the quicksort replay
-    int *bt;         // 64: candidate lane that owns the m-th new node
-    int *flist;      // 64: free slots, ascending
-    float *f1;       // S * N: the current row of read 1
-    float *zero;     // one word of 0.0f (a "column" whose every row is zero, for pointer-driven loops)
-    uint64_t *pq_list;
-    pdq178::Scratch *pq_scr;
+    float *f1, *f1n; // S * N each: the current row of read 1 and the next one
     float *tile;     // S * N x Wcap4
     float *rings;    // (P + 1) x Wcap4: the slots' rings and a trash ring idle lanes may scribble on
 };
 
-__host__ __device__ inline size_t slds_words(int BC, int N, int S, int WC, bool pdq) {
+__host__ __device__ inline size_t slds_words(int BC, int N, int S, int WC) {
     const size_t P = (size_t)BC * N;
-    size_t w = (size_t)F_COUNT * kSlots + 2 * (kSlots + 4) + 68 + 64 + 64 + 4;
-    w += ((size_t)S * N + 3) & ~(size_t)3;
-    if (pdq) w += 2 * kSlots + (sizeof(pdq178::Scratch) + 15) / 16 * 4;
+    size_t w = (size_t)O_VAR + 2 * (((size_t)S * N + 3) & ~(size_t)3);
     w += (size_t)S * N * WC + (P + 1) * WC;
     return w;
-}
-
-__device__ inline SLds scarve(int *smem, int BC, int N, int S, int WC, bool pdq) {
-    SLds L;
-    int *p = smem;
-    L.keys = reinterpret_cast<uint64_t *>(p); p += 2 * (kSlots + 4);
-    L.F = p; p += F_COUNT * kSlots;
-    L.pw = p; p += 68;
-    L.bt = p; p += 64;
-    L.flist = p; p += 64;
-    L.f1 = reinterpret_cast<float *>(p); p += (S * N + 3) & ~3;
-    L.zero = reinterpret_cast<float *>(p); p += 4;
-    L.pq_list = reinterpret_cast<uint64_t *>(p);
-    if (pdq) p += 2 * kSlots;
-    L.pq_scr = reinterpret_cast<pdq178::Scratch *>(p);
-    if (pdq) p += (sizeof(pdq178::Scratch) + 15) / 16 * 4;
-    L.tile = reinterpret_cast<float *>(p); p += (size_t)S * N * WC;
-    L.rings = reinterpret_cast<float *>(p);
-    return L;
 }
 
 __device__ __forceinline__ void wave_sync() {
@@ -186,6 +177,28 @@ __device__ __forceinline__ float ladd_spec(float a, float b, const LogAddCoef &K
 static long g_emu_passes = 0, g_emu_exact = 0;
 #endif
 
+// LogSpace::add without branches or votes, for the bookkeeping that runs under divergent control flow (one row of an
+// entry's extension, the merge of a candidate's items): the transcendental part is always evaluated -- on a tame argument
+// where it is not needed -- and `bad` is raised where ladd() would have left its fast path; the caller then repeats the
+// block on ladd().  Where `bad` stays clear the value is ladd()'s, operation for operation.  A wavefront alone on its SIMD
+// pays per instruction: ladd() with its exits and the 64-bit literals it re-materialises is ~2.5 times this.
+__device__ __forceinline__ float ladd_bf(float a, float b, const LogAddCoef &K, bool &bad) {
+    const bool ab = a <= b;
+    const float big = ab ? b : a, small = ab ? a : b;
+    const float x = small - big;
+    const bool have = !(small == kNegInf);
+    const bool full = !(x < kExpFastMin) & have;
+    const float xs = full ? x : -1.0f;
+    const double ye = exp_fast((double)xs, K);
+    const double ed = round_to_f32_as_f64(ye);
+    const double yl = log1p_fast(ed, K);
+    const uint32_t d1 = ((uint32_t)bits_of(ye) & 0x1FFFFFFFu) + 0xF0000200u;
+    const uint32_t d2 = ((uint32_t)bits_of(yl) & 0x1FFFFFFFu) + 0xF0000200u;
+    const uint32_t dm = d1 < d2 ? d1 : d2;
+    bad = bad | (full & (dm < 1024u)) | (have & (x < kExpFastMin) & (__builtin_fabsf(big) < 8.0779356694631609e-28f));
+    return full ? big + (float)yl : big;
+}
+
 template <int MODE, bool PROF>
 __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
     extern __shared__ __attribute__((aligned(16))) int smem[];
@@ -198,8 +211,20 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
     const bool collapse = !crf && p.collapse != 0;
     const float thr = p.thr_ln;
     const bool pdq = p.tie_order == FCD_TIE_PDQ178;
-    SLds L = scarve(smem, BC, N, S, WC, pdq && P > 20);
-    int *F = L.F;
+    SLds L;
+    {
+        const int snp = (SN + 3) & ~3;
+        L.f1 = reinterpret_cast<float *>(smem + O_VAR);
+        L.f1n = L.f1 + snp;
+        L.tile = L.f1n + snp;
+        L.rings = L.tile + (size_t)SN * WC;
+    }
+    int *F = smem + O_F;
+    uint64_t *l_keys = reinterpret_cast<uint64_t *>(smem + O_KEYS);
+    int *l_pw = smem + O_PW, *l_bt = smem + O_BT, *l_flist = smem + O_FLIST, *l_sink = smem + O_SINK;
+    float *l_zero = reinterpret_cast<float *>(smem + O_ZERO);
+    uint64_t *l_pql = reinterpret_cast<uint64_t *>(smem + O_PQL);
+    pdq178::Scratch *l_pqs = reinterpret_cast<pdq178::Scratch *>(smem + O_PQS);
     auto fi = [&](int f, int slot) -> int & { return F[f * kSlots + slot]; };
     auto ff = [&](int f, int slot) -> float & { return reinterpret_cast<float *>(F)[f * kSlots + slot]; };
     auto ring = [&](int slot) { return L.rings + (size_t)slot * WC; };
@@ -210,13 +235,32 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
     const float *ln1 = p.ln1 + r * p.T1cap * SN;
     const float *ln2 = p.ln2 + r * p.T2cap * SN;
     const uint64_t *env = p.env + r * p.env_stride * 2;
-    int4 *meta = p.meta + local * p.cap_nodes;
-    int4 *aux = p.aux + local * p.cap_nodes;
-    int32_t *rows = p.rows + local * p.cap_nodes * NLp;
-    float *aring = p.ring + local * p.cap_nodes * (int64_t)WC;
-    float *rootgap = p.rootgap + local * (p.T2cap + 1);
+    char *slab = p.slab + local * p.pair_stride;
+    const uint32_t cap32 = (uint32_t)p.cap_nodes;
+    const uint32_t o_aux = cap32 * 16u, o_ring = cap32 * 32u, o_rows = o_ring + cap32 * (uint32_t)(WC * 4),
+                   o_root = o_rows + cap32 * (uint32_t)(NLp * 4);
+    auto g_meta = [&](uint32_t nd) { return reinterpret_cast<int4 *>(slab + (nd << 4)); };
+    auto g_aux = [&](uint32_t nd) { return reinterpret_cast<int4 *>(slab + (o_aux + (nd << 4))); };
+    auto g_rows = [&](uint32_t nd) { return reinterpret_cast<int32_t *>(slab + (o_rows + nd * (uint32_t)(NLp * 4))); };
+    auto g_ring = [&](uint32_t nd) { return reinterpret_cast<float *>(slab + (o_ring + nd * (uint32_t)(WC * 4))); };
+    float *rootgap = reinterpret_cast<float *>(slab + o_root);
     uint8_t *lab_out = p.out.labels + r * p.out.out_stride;
 
+    // the log-add's coefficient table: in vector registers for the whole kernel (logsumexp flavour)
+    LogAddCoef K = logadd_coef();
+    if (MODE == FCD_LOGADD_LOGSUMEXP) {
+        FCD_OPAQUE_V(K.log2e); FCD_OPAQUE_V(K.ln2hi); FCD_OPAQUE_V(K.ln2lo); FCD_OPAQUE_V(K.two); FCD_OPAQUE_V(K.magic);
+#pragma unroll
+        for (int u = 0; u < 12; ++u) FCD_OPAQUE_V(K.e[u]);
+#pragma unroll
+        for (int u = 0; u < 15; ++u) FCD_OPAQUE_V(K.a[u]);
+    }
+    // the bookkeeping's log-add: the branch-free form first (logsumexp flavour), LogSpace::add itself on a repeat
+    bool bf_bad = false;
+    auto la_fast = [&](float a, float b) __attribute__((always_inline)) {
+        return MODE == FCD_LOGADD_LOGSUMEXP ? ladd_bf(a, b, K, bf_bad) : ladd<MODE>(a, b);
+    };
+    auto la_exact = [&](float a, float b) __attribute__((always_inline)) { return ladd<MODE>(a, b); };
     const bool count_amb = p.out.ambiguous != nullptr;
     int n_amb = 0, n_crit = 0;
     auto fail = [&](int code) {
@@ -260,7 +304,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         rootgap[0] = cur;
         int st = st2;
         for (int t = 0; t < root_end; ++t) {
-            cur = cur + ln2[((int64_t)t * S + st) * N];
+            cur = cur + ln2[(uint32_t)((t * S + st) * N)];
             rootgap[t + 1] = cur;
             if (crf) st = (int)(((int64_t)st * NL) % S);  // :437
         }
@@ -278,14 +322,14 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         fi(F_DEPTH, 0) = 0;
     }
     for (int j = lane; j < kNLMax; j += kWave) fi(F_CHILD0 + j, 0) = -1;
-    if (lane < 4) L.keys[kSlots + lane] = 0ull;  // padding of the four-at-a-time rank loop
-    if (lane < 4) L.zero[lane] = 0.0f;
+    if (lane < 4) l_keys[kSlots + lane] = 0ull;  // padding of the four-at-a-time rank loop
+    if (lane < 4) l_zero[lane] = 0.0f;
     // (rows of read 2 that were never loaded read as a finite number: "zero (x) p" stays zero in the guard rows' sums)
     for (int x = lane; x < SN * WC; x += kWave) L.tile[x] = 0.0f;
     for (int x = lane; x < WC; x += kWave) ring(P)[x] = kNegInf;
     // a NaN or +inf among the posteriors of read 2 loaded so far: the window builds take their exact form from then on
     bool unclean = false;
-    L.flist[lane] = lane + 1;                    // free: every slot but 0
+    l_flist[lane] = lane + 1;                    // free: every slot but 0
     // lane c is candidate (ci, ck) of every step
     const int ci = lane / N, ck = lane - ci * N;
     // ... item `lane` of a batch of rings copied 16 bytes at a time is piece g_c0 of ring g_q0; 64 items on: + (g_dq, g_dc)
@@ -375,7 +419,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     for (int x = lane; x < n; x += kWave) {
                         const int rw = x / SN, sn = x - rw * SN;
                         const int row = from + rw;
-                        const float v = ln2[(int64_t)row * SN + sn];
+                        const float v = ln2[(uint32_t)(row * SN + sn)];
                         L.tile[(size_t)sn * WC + (row % WC)] = v;
                         bad_v = bad_v || !(v < __builtin_huge_valf());
                     }
@@ -392,7 +436,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 if (hi_n > tl_hi && n <= kWave) {
                     pf_lo = tl_hi;
                     pf_hi = hi_n;
-                    if (lane < n) pf_val = ln2[(int64_t)tl_hi * SN + lane];  // (row-major: element `lane` of the block of rows)
+                    if (lane < n) pf_val = ln2[(uint32_t)(tl_hi * SN + lane)];  // (row-major: element `lane` of the block of rows)
                 }
             }
         }
@@ -468,24 +512,58 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
             FCD_S_SUB(4)
             if (ballot(panic) != 0ull) return fail(FCD_ST_BAD_STATE);
-            // update_max over the rows that stay, [max(lo, off), end), for every entry that discarded rows: 64 lanes
-            // per entry (NaN rows never replace the maximum)
-            for (uint64_t m = ballot(rescan); m != 0ull; m &= m - 1) {
-                const int e2 = (int)__builtin_ctzll(m);
-                const int o2 = rl_i(off, e2), n2 = rl_i(end, e2);
-                const float *rg = ring(rl_i(slotE, e2));
-                float part = kNegInf;
-                for (int t0 = (lo > o2 ? lo : o2) + lane; t0 < n2; t0 += kWave) part = lmax(part, rg[slotn(t0)]);
-                part = wave_lmax(part);
-                if (lane == e2) mx = part;
+            // update_max over the rows that stay, [max(lo, off), end), for every entry that discarded rows: eight lanes per
+            // entry, 16-byte reads, all entries at once (NaN rows never replace the maximum).  One LDS round trip where a
+            // loop over the entries (64 lanes each, a wait per trip) was 3.9 k cycles per step.
+            if (ballot(rescan) != 0ull) {
+                const int r8 = lane & 7, G = WC >> 2;
+                for (int e0 = 0; e0 < B; e0 += 8) {
+                    const int e = e0 + (lane >> 3);
+                    const bool on = e < B;
+                    const int ec = on ? e : 0;
+                    const int rs = bperm_i(ec, rescan ? 1 : 0), sl = bperm_i(ec, slotE), o2 = bperm_i(ec, off), n2 = bperm_i(ec, end);
+                    const int a0 = lo > o2 ? lo : o2;
+                    float part = kNegInf;
+                    if (on && rs && a0 < n2) {
+                        const float4 *rg4 = reinterpret_cast<const float4 *>(ring(sl));
+                        const int gb = (n2 - 1) >> 2;
+                        for (int g = (a0 >> 2) + r8; g <= gb; g += 32) {  // four 16-byte reads in flight per lane
+                            float4 v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int gu = g + 8 * u;
+                                int sg = (lo_s >> 2) + (gu - (lo >> 2));
+                                sg = sg < 0 ? sg + G : sg;
+                                sg = sg >= G ? sg - G : sg;
+                                v[u] = rg4[gu <= gb ? sg : 0];
+                            }
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) {
+                                const int t0 = (g + 8 * u) << 2;  // (rows past the window fail `< n2`)
+                                part = lmax(part, (t0 >= a0 && t0 < n2) ? v[u].x : kNegInf);
+                                part = lmax(part, (t0 + 1 >= a0 && t0 + 1 < n2) ? v[u].y : kNegInf);
+                                part = lmax(part, (t0 + 2 >= a0 && t0 + 2 < n2) ? v[u].z : kNegInf);
+                                part = lmax(part, (t0 + 3 >= a0 && t0 + 3 < n2) ? v[u].w : kNegInf);
+                            }
+                        }
+                    }
+                    // the eight partial maxima of an entry: quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror
+                    part = lmax(part, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0xB1, 0xf, 0xf, true)));
+                    part = lmax(part, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0x4E, 0xf, 0xf, true)));
+                    part = lmax(part, __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(part), 0x141, 0xf, 0xf, true)));
+                    const float got = bperm_f(((lane - e0) & 7) << 3, part);
+                    if (rescan && lane >= e0 && lane < e0 + 8) mx = got;
+                }
             }
             FCD_S_SUB(2)
             const bool seq = ballot(behind) != 0ull;
             // the recurrence (:361-386) for one entry on its own lane
-            auto extend = [&]() {
+            const float mx_in = mx;
+            auto extend = [&](auto LA) __attribute__((always_inline)) {
+                mx = mx_in;
                 float *mw = ring(slotE);
                 const float *prg = pslotE >= 0 ? ring(pslotE) : (parE < 0 ? ring(0) : nullptr);
-                const float *parena = aring + (int64_t)(parE < 0 ? 0 : parE) * WC;
+                const float *parena = g_ring((uint32_t)(parE < 0 ? 0 : parE));
                 const bool rootpar = parE < 0;
                 float l_lab = llab, l_sum = kNegInf;
                 if (end > off) l_sum = mw[slotn(end - 1)];
@@ -506,13 +584,13 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                             float ps = kNegInf;
                             if (at != p_vfrom) ps = prg ? prg[slotn(at - 1)] : load_f32_l2(parena + ((at - 1) % WC));
                             // (xrep only without transition states: the blank column of row `at` is state 0's)
-                            const float bl = (at >= tl_lo && at < tl_hi) ? L.tile[slotn(at)] : ln2[(int64_t)at * SN];
+                            const float bl = (at >= tl_lo && at < tl_hi) ? L.tile[slotn(at)] : ln2[(uint32_t)(at * SN)];
                             x = ps + bl;
                         }
                     }
                     const float g = l_sum + tb[sl];
-                    const float lb = tl[sl] + ladd<MODE>(l_lab, x);
-                    const float sm = ladd<MODE>(lb, g);
+                    const float lb = tl[sl] + LA(l_lab, x);
+                    const float sm = LA(lb, g);
                     mw[sl] = sm;
                     mx = lmax(mx, sm);
                     l_lab = lb;
@@ -525,13 +603,17 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 ff(F_LLAB, slotE) = l_lab;
             };
             if (!seq) {
-                if (mine) extend();
+                bf_bad = false;
+                if (mine) extend(la_fast);
+                if (MODE == FCD_LOGADD_LOGSUMEXP && ballot(bf_bad && mine) != 0ull) {  // (1e-6 of the log-adds: once more, on LogSpace::add)
+                    if (mine) extend(la_exact);
+                }
             } else {
                 for (int e = 0; e < B; ++e) {
                     if (mine && lane == e) {
                         // the parent may have moved in an earlier trip
                         if (pslotE >= 0) { p_off = fi(F_OFF, pslotE); p_end = fi(F_END, pslotE); p_vfrom = fi(F_VFROM, pslotE); }
-                        extend();
+                        extend(la_exact);
                     }
                     wave_sync();
                 }
@@ -583,16 +665,19 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         const int pj = (act && ck == 0 && node >= 0) ? prank_i : -1;
         const int pjc = pj >= 0 ? pj : 0;
         const int slot_j = bperm_i(pjc, slotE);
-        const float lpj = bperm_f(pjc, lpE), gpj = bperm_f(pjc, gpE);
+        const float gpj = bperm_f(pjc, gpE);
         // running maximum of an existing child that is outside the beam: in its arena record (asked for here, used
         // after the window builds)
         float p2_stale = 0.0f;
         const bool stale_c = act && ck > 0 && ch >= 0 && !ch_inbeam;
-        if (stale_c) p2_stale = __int_as_float(load_i32_l2(reinterpret_cast<const int32_t *>(&aux[ch])));
+        if (stale_c) p2_stale = __int_as_float(load_i32_l2(reinterpret_cast<const int32_t *>(g_aux((uint32_t)ch))));
         const float *row1 = L.f1 + state * N;  // crf: probs[state, :] (:749)
         bool valid = false, is_new = false, rep = false;
         float clp = kNegInf, cgp = kNegInf, p2 = 0.0f;
         int cid = -2;
+        // Everything about a candidate but its probabilities: which items it has, which node it is.
+        bool blank = false, stay = false, inc = false, inc_first = false, rj = false;
+        float pr0 = kNegInf, pt = kNegInf, pl = kNegInf, pk = kNegInf;
         if (act) {
             if (ck == 0) {
                 // The node's own candidate is the MERGE (:596-611) of up to three items that share the node -- the blank
@@ -600,68 +685,108 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 // entry {label, zero} -- folded with LogSpace::add in the order the reference appends them: tips in
                 // beam order, and within a tip blank first, labels after (max mode's add keeps a NaN only as its
                 // FIRST operand).
-                const float pr0 = row1[0];
-                const bool blank = pr0 > thr;  // :529
-                const float g_item = blank ? ladd<MODE>(lp, gp) + pr0 : kNegInf;
-                bool stay = collapse && tip >= 0;
-                float s_item = kNegInf;
+                pr0 = row1[0];
+                blank = pr0 > thr;  // :529
+                stay = collapse && tip >= 0;
                 if (stay) {
-                    const float pt = row1[tip + 1];
-                    stay = !(pt < thr);
-                    if (stay) s_item = lp + pt;  // :541-544
+                    pt = row1[tip + 1];
+                    stay = !(pt < thr);  // :541-544
                 }
-                bool inc = false, inc_first = false;
-                float c_item = kNegInf;
                 if (pj >= 0) {
-                    const float pl = L.f1[fi(F_STATE, slot_j) * N + tip + 1];  // the PARENT's row
+                    pl = L.f1[fi(F_STATE, slot_j) * N + tip + 1];  // the PARENT's row
                     if (!(pl < thr)) {
-                        const bool rj = collapse && fi(F_TIP, slot_j) == tip;
+                        rj = collapse && fi(F_TIP, slot_j) == tip;
                         // (the parent's own test `gap > zero` (:546) only guards the CREATION of this node: it exists)
-                        c_item = rj ? gpj + pl : ladd<MODE>(lpj, gpj) + pl;
                         inc = true;
                         inc_first = pj < ci;  // the parent's entry comes earlier in the beam: its item was appended first
                     }
                 }
-                bool have = false;
-                auto push = [&](float l_it, float g_it) {
-                    if (!have) {
-                        clp = l_it;
-                        cgp = g_it;
-                        have = true;
-                    } else {
-                        clp = ladd<MODE>(clp, l_it);
-                        cgp = ladd<MODE>(cgp, g_it);
-                    }
-                };
-                if (inc && inc_first) push(c_item, kNegInf);
-                if (blank) push(kNegInf, g_item);
-                if (stay) push(s_item, kNegInf);
-                if (inc && !inc_first) push(c_item, kNegInf);
                 valid = blank || stay || inc;
                 cid = node;
                 if (node >= 0) p2 = ff(F_MX, slot_i);  // :613-618 (the root keeps one)
             } else {
                 const int l = ck - 1;
-                const float pk = row1[ck];
+                pk = row1[ck];
                 const bool pass = !(pk < thr);  // :537
                 rep = collapse && l == tip;
-                const float contrib = rep ? gp + pk : ladd<MODE>(lp, gp) + pk;
                 const bool exists = ch >= 0;
                 valid = pass && (exists || !rep || gp > kNegInf) && !ch_inbeam;  // :546
                 is_new = valid && !exists;
-                clp = contrib;
                 cid = ch;
                 if (stale_c) p2 = p2_stale;
             }
         }
+        // ... and the probabilities.  An entry's label (+) gap is wanted by all of its candidates (the blank extension,
+        // every label's extension) and by the child entry it extends into: ONE log-add per lane, handed to the child's
+        // lane by ds_bpermute.  logsumexp flavour: LogSpace::add with a zero operand returns the other operand whatever
+        // it is (duplex.rs:45-47), so the merge is the labels' items folded in the reference's order and the gap item
+        // alone -- three log-adds per step where the literal fold took nine.  (Max flavour: not commutative once a NaN
+        // takes part, folded literally; it has no transcendental to save.)
+        auto probabilities = [&](auto LA) __attribute__((always_inline)) {
+            const float lg = LA(lp, gp);                  // tip.prob_1.probability()
+            const float lgj = bperm_f(pjc * N, lg);       // ... of the parent's entry (own candidates with an incoming item)
+            if (ck == 0) {
+                const float g_item = blank ? lg + pr0 : kNegInf;
+                const float s_item = stay ? lp + pt : kNegInf;
+                const float c_item = inc ? (rj ? gpj + pl : lgj + pl) : kNegInf;
+                if (MODE == FCD_LOGADD_LOGSUMEXP) {
+                    const bool both = inc && stay;
+                    const float first = inc_first ? c_item : s_item, second = inc_first ? s_item : c_item;
+                    const float m2 = LA(both ? first : kNegInf, both ? second : kNegInf);
+                    clp = both ? m2 : (inc ? c_item : s_item);
+                    cgp = g_item;
+                } else {
+                    bool have = false;
+                    auto push = [&](float l_it, float g_it) {
+                        if (!have) {
+                            clp = l_it;
+                            cgp = g_it;
+                            have = true;
+                        } else {
+                            clp = LA(clp, l_it);
+                            cgp = LA(cgp, g_it);
+                        }
+                    };
+                    clp = kNegInf;
+                    cgp = kNegInf;
+                    if (inc && inc_first) push(c_item, kNegInf);
+                    if (blank) push(kNegInf, g_item);
+                    if (stay) push(s_item, kNegInf);
+                    if (inc && !inc_first) push(c_item, kNegInf);
+                }
+            } else {
+                clp = rep ? gp + pk : lg + pk;
+                cgp = kNegInf;
+            }
+        };
+        bf_bad = false;
+        probabilities(la_fast);
+        if (MODE == FCD_LOGADD_LOGSUMEXP && ballot(bf_bad && act) != 0ull) probabilities(la_exact);
+#ifndef FCD_HIPEMU
+        // An existing child outside the beam that passed the threshold may be in the next beam, and then its ring and
+        // record come back from the arena -- evicted tens of steps ago, i.e. from HBM (2-4 k cycles on the critical path
+        // of the hand-over when asked for after the prune).  Touch their cache lines now, with LDS-DMA loads into a
+        // scratch row nobody reads (no register is held, nothing waits): by the prune they sit in L2.
+        if (p.prefetch && valid && ck > 0 && !is_new) {
+            typedef __attribute__((address_space(1))) const void gptr_t;
+            typedef __attribute__((address_space(3))) void lptr_t;
+            lptr_t *sink = (lptr_t *)l_sink;
+            const char *rb = reinterpret_cast<const char *>(g_ring((uint32_t)ch));
+            const int nb = WC * 4;
+            for (int b = 0; b < nb; b += 64) __builtin_amdgcn_global_load_lds((gptr_t *)(rb + b), sink, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(rb + nb - 4), sink, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)g_meta((uint32_t)ch), sink, 4, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)g_rows((uint32_t)ch), sink, 4, 0, 0);
+        }
+#endif
         const uint64_t m_new = ballot(is_new);
         const int n_new = popc64(m_new);
         const int pre = popc64(m_new & lanemask_lt());
         int nbuf = 0;
         if (is_new) {
             cid = nn + pre;
-            L.bt[pre] = lane;
-            nbuf = L.flist[pre];
+            l_bt[pre] = lane;
+            nbuf = l_flist[pre];
         }
         const bool can = is_new && cid < p.cap_nodes;
         if (can) {  // add_node (tree.rs:125-145): the new node's slot
@@ -691,7 +816,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         auto build_exact = [&](int m0) {
             const int m = m0 + lane;
             const bool have = m < n_new;
-            const int owner = have ? L.bt[m] : 0;
+            const int owner = have ? l_bt[m] : 0;
             const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
             const bool work = have && (o_flags & 1);
             const bool q_rep = (o_flags & 2) != 0;
@@ -713,7 +838,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                         else {
                             float ps = kNegInf;
                             if (at != p_vfrom) ps = prg[slotn(at - 1)];
-                            const float bl = (at >= tl_lo && at < tl_hi) ? L.tile[slotn(at)] : ln2[(int64_t)at * SN];
+                            const float bl = (at >= tl_lo && at < tl_hi) ? L.tile[slotn(at)] : ln2[(uint32_t)(at * SN)];
                             x = ps + bl;
                         }
                     }
@@ -730,7 +855,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
         };
         if (n_new > 0) {
-            // Who builds what: the m-th new node's parameters come from its candidate lane (L.bt).  Shared by the passes below.
+            // Who builds what: the m-th new node's parameters come from its candidate lane (l_bt).  Shared by the passes below.
             struct NodeParams {
                 bool work, rep;
                 int buf, ps, l, state;
@@ -739,7 +864,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             auto node_params = [&](int m) {
                 NodeParams q;
                 const bool have = m < n_new;
-                const int owner = have ? L.bt[m] : 0;
+                const int owner = have ? l_bt[m] : 0;
                 const int o_flags = bperm_i(owner, (can ? 1 : 0) | (rep ? 2 : 0));
                 q.work = have && (o_flags & 1);
                 q.rep = q.work && (o_flags & 2) != 0;
@@ -777,12 +902,6 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 // not tests inside them), the rare exits of LogSpace::add are folded into two accumulators (the smallest
                 // distance of a binary64 result from an f32 rounding boundary; the largest `big`), and nothing is masked:
                 // idle trips and idle lanes compute on "zero" or on the trash ring.
-                LogAddCoef K = logadd_coef();
-                FCD_OPAQUE_V(K.log2e); FCD_OPAQUE_V(K.ln2hi); FCD_OPAQUE_V(K.ln2lo); FCD_OPAQUE_V(K.two);
-#pragma unroll
-                for (int u = 0; u < 12; ++u) FCD_OPAQUE_V(K.e[u]);
-#pragma unroll
-                for (int u = 0; u < 15; ++u) FCD_OPAQUE_V(K.a[u]);
                 const bool isA = (lane & 1) == 0;
                 // slots of rows lo - 2 .. lo + 1 and the first trip in which a pointer wraps (wave-uniform)
                 const int s_m2 = slotn(lo - 2), s_m1 = slotn(lo - 1), s_p1 = slotn(lo + 1);
@@ -799,7 +918,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     // the odd lane stores.  Even lane: rows lo, lo + 1, ...; odd lane: one row behind.
                     const float *pa = col + (isA ? s_p1 : lo_s);
                     const float *pb = isA ? prg + (q.rep ? s_m1 : lo_s) : trash + lo_s;
-                    const float *pz = q.rep && isA ? L.tile + lo_s : L.zero;
+                    const float *pz = q.rep && isA ? L.tile + lo_s : l_zero;
                     const int zstep = q.rep && isA ? 1 : 0;
                     float *pw = (isA ? trash : ring(q.buf)) + (isA ? lo_s : s_m1);
                     int wa = WC - (isA ? s_p1 : lo_s), wb = WC - (isA && q.rep ? s_m1 : lo_s), wz = zstep ? WC - lo_s : 0x7FFFFFFF,
@@ -893,12 +1012,21 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                         pprev = ppx[sgm];
                         bprev = pb0[sgm];
                     }
-                    // one group of four rows at ring group `sgx`; masked: rows outside [lo, hi) are skipped (first / last group)
-                    auto group = [&](int gx, int sgx, bool masked, bool with_rep) __attribute__((always_inline)) {
-                        const float4 cb = pcb[sgx], cl = pcl[sgx], px = ppx[sgx];
+                    // one group of four rows at ring group `sgx`: its operands are asked for one group ahead (a wavefront
+                    // alone on its SIMD waits ~100 cycles on every LDS round trip it does not cover itself);
+                    // masked: rows outside [lo, hi) are skipped (first / last group)
+                    struct Ops { float4 cb, cl, px, b0; };
+                    auto gload = [&](int sgx, bool with_rep, Ops &o) __attribute__((always_inline)) {
+                        o.cb = pcb[sgx];
+                        o.cl = pcl[sgx];
+                        o.px = ppx[sgx];
+                        if (with_rep) o.b0 = pb0[sgx];
+                    };
+                    auto gcomp = [&](int gx, int sgx, bool masked, bool with_rep, const Ops &o) __attribute__((always_inline)) {
+                        const float4 cb = o.cb, cl = o.cl, px = o.px;
                         float x0 = pprev.w, x1 = px.x, x2 = px.y, x3 = px.z;
                         if (with_rep) {
-                            const float4 b0 = pb0[sgx];
+                            const float4 b0 = o.b0;
                             x0 = q.rep ? pprev.z + bprev.w : x0;
                             x1 = q.rep ? pprev.w + b0.x : x1;
                             x2 = q.rep ? px.x + b0.y : x2;
@@ -917,22 +1045,35 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     };
                     auto run = [&](bool with_rep) __attribute__((always_inline)) {
                         int g = g0;
+                        Ops A, B2;
                         const bool head = (lo & 3) != 0 || g0 == g1;
                         if (head) {
-                            group(g, sg, true, with_rep);
+                            gload(sg, with_rep, A);
+                            gcomp(g, sg, true, with_rep, A);
                             ++g;
                             sg = sg + 1 == G ? 0 : sg + 1;
                         }
                         const int g_full_end = (hi & 3) != 0 ? g1 : g1 + 1;  // groups [g, g_full_end) are whole
                         while (g < g_full_end) {
-                            // a run of groups up to the end of the ring or of the window
+                            // a run of groups up to the end of the ring or of the window, two per trip
                             int n = g_full_end - g;
                             n = n < G - sg ? n : G - sg;
-                            for (int u = 0; u < n; ++u) group(g + u, sg + u, false, with_rep);
+                            int u = 0;
+                            gload(sg, with_rep, A);
+                            for (; u + 2 <= n; u += 2) {
+                                gload(sg + u + 1, with_rep, B2);
+                                gcomp(0, sg + u, false, with_rep, A);
+                                if (u + 2 < n) gload(sg + u + 2, with_rep, A);
+                                gcomp(0, sg + u + 1, false, with_rep, B2);
+                            }
+                            if (u < n) gcomp(0, sg + u, false, with_rep, A);
                             g += n;
                             sg = sg + n == G ? 0 : sg + n;
                         }
-                        if (g <= g1) group(g, sg, true, with_rep);
+                        if (g <= g1) {
+                            gload(sg, with_rep, A);
+                            gcomp(g, sg, true, with_rep, A);
+                        }
                     };
                     if (anyrep) run(true);
                     else run(false);
@@ -955,15 +1096,29 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
             wave_sync();
         }
+        // What was asked for at the head of the step -- the rows of read 2 the NEXT step gains, the next row of read 1 --
+        // goes to LDS here, long after it arrived and BEFORE the hand-over's stores are issued: a wait on these loads behind
+        // the stores would wait for the stores' acknowledgements too (the memory counter is in order).
+        if (pf_hi > pf_lo && pf_hi - (lo > 0 ? lo - 1 : 0) <= WC && pf_lo == tl_hi) {
+            const int n = (pf_hi - pf_lo) * SN;
+            if (lane < n) L.tile[(size_t)l_sn * WC + slotn(pf_lo + l_rw)] = pf_val;
+            unclean = unclean || ballot(lane < n && !(pf_val < __builtin_huge_valf())) != 0ull;
+            tl_hi = pf_hi;
+            if (tl_hi - tl_lo > WC) tl_lo = tl_hi - WC;
+            pf_lo = pf_hi = 0;
+        }
+        if (more && lane < SN) L.f1n[lane] = f1_next;
         if (is_new && can) p2 = ff(F_MX, nbuf);
         nn += n_new;
         FCD_S_PHASE(3)
         if (nn > p.cap_nodes) return fail(FCD_ST_INTERNAL);
 
         // ---- merge is done (own candidates folded the three items); probability (:146-148), keys, exact rank ----
-        const float prob = ladd<MODE>(clp, cgp) + p2;
+        bf_bad = false;
+        float prob = la_fast(clp, cgp) + p2;
+        if (MODE == FCD_LOGADD_LOGSUMEXP && ballot(bf_bad && valid) != 0ull) prob = la_exact(clp, cgp) + p2;
         const uint64_t key = valid ? (prob == prob ? make_key(prob, cid) : 1ull) : 0ull;
-        L.keys[lane] = key;
+        l_keys[lane] = key;
         const uint64_t m_valid = ballot(valid);
         const int n_valid = popc64(m_valid);
         const bool any_nan = ballot(valid && prob != prob) != 0ull;
@@ -973,8 +1128,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         int rank;
         {
             int r0, r1, r2, r3;
-            FCD_RANK4_FIRST(key, L.keys[0], L.keys[1], L.keys[2], L.keys[3], r0, r1, r2, r3);
-            for (int u = 4; u < P; u += 4) FCD_RANK4(key, L.keys[u], L.keys[u + 1], L.keys[u + 2], L.keys[u + 3], r0, r1, r2, r3);
+            FCD_RANK4_FIRST(key, l_keys[0], l_keys[1], l_keys[2], l_keys[3], r0, r1, r2, r3);
+            for (int u = 4; u < P; u += 4) FCD_RANK4(key, l_keys[u], l_keys[u + 1], l_keys[u + 2], l_keys[u + 3], r0, r1, r2, r3);
             rank = (r0 + r1) + (r2 + r3);
         }
         const int Bn = n_valid < BC ? n_valid : BC;
@@ -983,9 +1138,9 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         // the best entry when it sits at ranks 0 / 1 or across the truncation boundary
         bool any_kept_tie = false;
         if (count_amb || (pdq && n_valid > 20)) {
-            if (valid) L.pw[rank] = (int)(uint32_t)(key >> 32);
+            if (valid) l_pw[rank] = (int)(uint32_t)(key >> 32);
             wave_sync();
-            const bool pair_eq = lane + 1 < n_valid && L.pw[lane] == L.pw[lane + 1];
+            const bool pair_eq = lane + 1 < n_valid && l_pw[lane] == l_pw[lane + 1];
             const uint64_t m_eq = ballot(pair_eq);
             const uint64_t keptm = BC >= 64 ? ~0ull : ((1ull << BC) - 1ull);
             any_kept_tie = n_valid > 20 && (m_eq & keptm) != 0ull;
@@ -1000,16 +1155,16 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             // through the restated quicksort (one lane); the position of a candidate in its result is its rank
             int pos = 0;
             for (int j = 0; j < P; ++j) {
-                const uint64_t kj = L.keys[j];
+                const uint64_t kj = l_keys[j];
                 pos += (kj != 0ull && (uint32_t)kj > (uint32_t)key) ? 1 : 0;  // low word: larger = smaller node
             }
-            if (valid) L.pq_list[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)lane;
+            if (valid) l_pql[pos] = (key & 0xFFFFFFFF00000000ull) | (uint32_t)lane;
             wave_sync();
-            if (lane == 0) pdq178::sort_desc(L.pq_list, n_valid, L.pq_scr);
+            if (lane == 0) pdq178::sort_desc(l_pql, n_valid, l_pqs);
             wave_sync();
-            if (lane < n_valid) L.pw[(int)(uint32_t)L.pq_list[lane]] = lane;
+            if (lane < n_valid) l_pw[(int)(uint32_t)l_pql[lane]] = lane;
             wave_sync();
-            if (valid) rank = L.pw[lane];
+            if (valid) rank = l_pw[lane];
             wave_sync();
         }
         FCD_S_SUB_BEGIN()
@@ -1022,18 +1177,18 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         const uint64_t m_stale = ballot(stale_in);
         const int n_stale = popc64(m_stale);
         int myslot = ck == 0 ? slot_i : nbuf;
-        if (stale_in) myslot = L.flist[n_new + popc64(m_stale & lanemask_lt())];
+        if (stale_in) myslot = l_flist[n_new + popc64(m_stale & lanemask_lt())];
         // records of the nodes coming back: asked for now, looked at after the evictions have been issued
         int4 s_meta = make_int4(0, 0, 0, 0), s_aux = make_int4(0, 0, 0, 0);
         int s_rows[kNLMax];
 #pragma unroll
         for (int j = 0; j < kNLMax; ++j) s_rows[j] = -1;
         if (stale_in) {
-            s_meta = load_int4_l2(&meta[cid]);
-            s_aux = load_int4_l2(&aux[cid]);
+            s_meta = load_int4_l2(g_meta((uint32_t)cid));
+            s_aux = load_int4_l2(g_aux((uint32_t)cid));
 #pragma unroll
             for (int j = 0; j < kNLMax; ++j)
-                if (j < NL) s_rows[j] = load_i32_l2(&rows[(int64_t)cid * NLp + j]);
+                if (j < NL) s_rows[j] = load_i32_l2(g_rows((uint32_t)cid) + j);
         }
         // ... and their rings, the first two of them (a third one and later: after the evictions)
         float sr0[4] = {0.0f, 0.0f, 0.0f, 0.0f}, sr1[4] = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -1042,8 +1197,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         const int st_b = n_stale > 1 ? (int)__builtin_ctzll(m_stale2) : 0;
         const bool small_ring = WC <= 4 * kWave;
         if (n_stale > 0 && small_ring) {
-            const float *aa = aring + (int64_t)rl_i(cid, st_a) * WC;
-            const float *ab_ = aring + (int64_t)rl_i(cid, st_b) * WC;
+            const float *aa = g_ring((uint32_t)rl_i(cid, st_a));
+            const float *ab_ = g_ring((uint32_t)rl_i(cid, st_b));
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int x = u * kWave + lane;
@@ -1060,8 +1215,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         const int n_ev = popc64(m_ev);
         if (ev) {
             const int qi = popc64(m_ev & lanemask_lt());
-            L.bt[qi] = myslot;
-            L.pw[qi] = cid;  // (ck == 0: cid is the entry's node)
+            l_bt[qi] = myslot;
+            l_pw[qi] = cid;  // (ck == 0: cid is the entry's node)
         }
         // a survivor whose parent sat in this step's beam and is not in the next one remembers the parent's bounds
         {
@@ -1106,34 +1261,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             const bool bs = lane < Bn && fi(F_STATE, slotE) >= S;
             if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
         }
-        // ---- evictions: records, one evicted node per lane ----
-        if (lane < n_ev) {
-            const int s_ = L.bt[lane], nd = L.pw[lane];
-            meta[nd] = make_int4(fi(F_PAR, s_), fi(F_TIP, s_), fi(F_OFF, s_), fi(F_END, s_));
-            aux[nd] = make_int4(fi(F_MX, s_), fi(F_VFROM, s_), fi(F_LLAB, s_), 0);
-            int32_t *rw = rows + (int64_t)nd * NLp;
-            if (NLp == 4) {
-                *reinterpret_cast<int4 *>(rw) = make_int4(fi(F_CHILD0, s_), NL > 1 ? fi(F_CHILD0 + 1, s_) : -1,
-                                                          NL > 2 ? fi(F_CHILD0 + 2, s_) : -1, NL > 3 ? fi(F_CHILD0 + 3, s_) : -1);
-            } else {
-                for (int j = 0; j < NL; ++j) rw[j] = fi(F_CHILD0 + j, s_);
-            }
-        }
-        // ---- evictions: rings, 16 bytes per lane and trip over all of them at once ----
-        {
-            const int G = WC >> 2;
-            const int total = n_ev * G;
-            int q = g_q0, c = g_c0;  // ring and 16-byte piece of item `lane`
-            for (int x = lane; x < total; x += kWave) {
-                const int s_ = L.bt[q], nd = L.pw[q];
-                const float4 v = reinterpret_cast<const float4 *>(ring(s_))[c];
-                reinterpret_cast<float4 *>(aring + (int64_t)nd * WC)[c] = v;
-                q += g_dq;
-                c += g_dc;
-                if (c >= G) { c -= G; ++q; }
-            }
-        }
         // ---- nodes coming back: ring and record from the arena into their slot ----
+        // (BEFORE the evictions' stores are issued: a wait on these loads behind the stores would wait for the stores too)
         if (n_stale > 0 && small_ring) {
             float *da = ring(rl_i(myslot, st_a)), *db = ring(rl_i(myslot, st_b));
 #pragma unroll
@@ -1149,7 +1278,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             const int src = (int)__builtin_ctzll(m);
             const int s_ = rl_i(myslot, src), nd = rl_i(cid, src);
             float *dst = ring(s_);
-            const float *a_ = aring + (int64_t)nd * WC;
+            const float *a_ = g_ring((uint32_t)nd);
             for (int x0 = 0; x0 < WC; x0 += 4 * kWave) {  // four loads in flight per lane
                 float v[4];
 #pragma unroll
@@ -1174,6 +1303,50 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             for (int j = 0; j < kNLMax; ++j)
                 if (j < NL) fi(F_CHILD0 + j, myslot) = s_rows[j];
         }
+        // ---- evictions: records, one evicted node per lane ----
+        if (lane < n_ev) {
+            const int s_ = l_bt[lane], nd = l_pw[lane];
+            *g_meta((uint32_t)nd) = make_int4(fi(F_PAR, s_), fi(F_TIP, s_), fi(F_OFF, s_), fi(F_END, s_));
+            *g_aux((uint32_t)nd) = make_int4(fi(F_MX, s_), fi(F_VFROM, s_), fi(F_LLAB, s_), 0);
+            int32_t *rw = g_rows((uint32_t)nd);
+            if (NLp == 4) {
+                *reinterpret_cast<int4 *>(rw) = make_int4(fi(F_CHILD0, s_), NL > 1 ? fi(F_CHILD0 + 1, s_) : -1,
+                                                          NL > 2 ? fi(F_CHILD0 + 2, s_) : -1, NL > 3 ? fi(F_CHILD0 + 3, s_) : -1);
+            } else {
+                for (int j = 0; j < NL; ++j) rw[j] = fi(F_CHILD0 + j, s_);
+            }
+        }
+        // ---- evictions: rings, 16 bytes per lane and item, four items in flight per lane (one LDS round trip for the
+        // lists, one for the rings, then the stores -- which nothing in this step waits for) ----
+        {
+            const int G = WC >> 2;
+            const int total = n_ev * G;
+            int q = g_q0, c = g_c0;  // ring and 16-byte piece of item `lane`
+            for (int x0 = 0; x0 < total; x0 += 4 * kWave) {
+                int qs[4], cs[4], ss[4], ns[4];
+                bool on[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    qs[u] = q;
+                    cs[u] = c;
+                    on[u] = x0 + u * kWave + lane < total;
+                    q += g_dq;
+                    c += g_dc;
+                    if (c >= G) { c -= G; ++q; }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    ss[u] = on[u] ? l_bt[qs[u]] : P;
+                    ns[u] = on[u] ? l_pw[qs[u]] : 0;
+                }
+                float4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = reinterpret_cast<const float4 *>(ring(ss[u]))[cs[u]];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (on[u]) reinterpret_cast<float4 *>(g_ring((uint32_t)ns[u]))[cs[u]] = v[u];
+            }
+        }
         FCD_S_SUB(1)
         // ---- free list of the coming step: the slots no entry of the next beam sits in ----
         {
@@ -1184,9 +1357,9 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
             const bool is_free = lane < P && !used;
             const uint64_t fm = ballot(is_free);
-            if (is_free) L.flist[popc64(fm & lanemask_lt())] = lane;
+            if (is_free) l_flist[popc64(fm & lanemask_lt())] = lane;
         }
-        if (more && lane < SN) L.f1[lane] = f1_next;
+        { float *t_ = L.f1; L.f1 = L.f1n; L.f1n = t_; }
         B = Bn;
         wave_sync();
         FCD_S_PHASE(4)
@@ -1206,7 +1379,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
 
     // ---- labels leaf -> root (:638-649), written in sequence order ----
     // entries still in the beam have no arena record yet: the walk needs (parent, label) of the best node's ancestors
-    if (lane < B && nodeE >= 0) meta[nodeE] = make_int4(fi(F_PAR, slotE), fi(F_TIP, slotE), fi(F_OFF, slotE), fi(F_END, slotE));
+    if (lane < B && nodeE >= 0) *g_meta((uint32_t)nodeE) = make_int4(fi(F_PAR, slotE), fi(F_TIP, slotE), fi(F_OFF, slotE), fi(F_END, slotE));
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "agent");
     {
         const int s0 = rl_i(slotE, 0);
@@ -1214,7 +1387,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         if (lane == 0) {
             int q = rl_i(nodeE, 0);
             for (int j = n - 1; j >= 0; --j) {
-                const int4 mq = load_int4_l2(&meta[q]);
+                const int4 mq = load_int4_l2(g_meta((uint32_t)q));
                 lab_out[j] = (uint8_t)(mq.y + 1);
                 q = mq.x;
             }
@@ -1236,10 +1409,17 @@ bool duplex_slots_supported(int beam_size, int N, int S, int width, int tie_orde
     return duplex_slots_lds_bytes(beam_size, N, S, WC, tie_order) <= 64 * 1024;
 }
 
+size_t duplex_slots_pair_bytes(int64_t cap_nodes, int N, int ring_rows, int64_t T2cap) {
+    const int NLp = (N - 1 + 3) & ~3;
+    const size_t b = (size_t)cap_nodes * (32 + (size_t)ring_rows * 4 + (size_t)NLp * 4) + (size_t)(T2cap + 1) * 4;
+    return (b + 255) & ~(size_t)255;
+}
+
 int duplex_slots_ring_rows(int width) { return ((width > 1 ? width : 1) + 4 + 3) & ~3; }
 
 size_t duplex_slots_lds_bytes(int beam_size, int N, int S, int WC, int tie_order) {
-    return slds_words(beam_size, N, S, WC, tie_order == FCD_TIE_PDQ178 && (int64_t)beam_size * N > 20) * 4 + 16;
+    (void)tie_order;  // (the quicksort's list and scratch are part of the fixed tables: under 1 KiB)
+    return slds_words(beam_size, N, S, WC) * 4 + 16;
 }
 
 hipError_t launch_duplex_slots(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream) {
@@ -1250,9 +1430,17 @@ hipError_t launch_duplex_slots(const DuplexArgs &a, int64_t pair_begin, int64_t 
     p.N = a.N; p.beam_size = a.beam_size; p.thr_ln = a.thr_ln; p.collapse = a.collapse;
     p.S = a.S; p.crf = a.crf; p.init1 = a.init1; p.init2 = a.init2; p.n_init1 = a.n_init1;
     p.n_init2 = a.n_init2; p.init1_stride = a.init1_stride; p.init2_stride = a.init2_stride;
-    p.meta = a.meta; p.aux = a.aux; p.rows = a.rows; p.ring = a.vec; p.rootgap = a.rootgap;
+    p.slab = reinterpret_cast<char *>(a.meta); p.pair_stride = a.pair_stride;
     p.cap_nodes = a.cap_nodes; p.Wcap4 = a.Wcap; p.NLp = a.NLp;
     p.out = a.out; p.pair_begin = pair_begin; p.prof = a.prof; p.tie_order = a.tie_order;
+    static const int env_prefetch = [] {
+        // "1": on.  Off by default: on BASELINE config 5 the touch costs the expansion 0.7 k cycles per step and saves the
+        // hand-over 0.3 k (profiles/r06g_duplex_account_*.jsonl) -- the arena lines of a node evicted a few steps ago are
+        // still in L2 / MALL more often than not
+        const char *e = getenv("FCD_DUPLEX_PREFETCH");
+        return e && !strcmp(e, "1") ? 1 : 0;
+    }();
+    p.prefetch = env_prefetch;
     const size_t lds = duplex_slots_lds_bytes(a.beam_size, a.N, a.S, a.Wcap, a.tie_order);
     const dim3 grid((unsigned)n_pairs), block(64);
 #define FCD_SLOTS_LAUNCH(MODE)                                                                                     \

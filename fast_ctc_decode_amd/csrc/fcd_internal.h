@@ -130,15 +130,17 @@ struct DuplexArgs {
     ResultDesc out;
     uint32_t *prof;  // developer instrument: [pair][8] cycle account, nullable
     int tie_order;   // FCD_TIE_PDQ178 / FCD_TIE_STABLE
-    // slot-resident kernel (duplex_slots.hip): `vec` holds Wcap (= ring rows, a multiple of 4) floats per node -- label (+)
-    // gap per row -- `aux` {running maximum, vfrom, last label, 0} per node, `rows` NLp child ids per node
+    // slot-resident kernel (duplex_slots.hip): `meta` is the base of the arena, ONE slab of `pair_stride` bytes per pair
+    // (meta | aux | rings of Wcap floats | NLp child ids per node | the root's T2cap + 1 floats), below 4 GiB each
     int4 *aux;
     int NLp;
+    int64_t pair_stride;
 };
 
 size_t duplex_lds_bytes(int beam_size, int N, int Wmax, int S, int tie_order);
 // duplex_slots.hip: beam_size * N <= 64, N <= 8, and the rings of every live node + the read-2 tile fit 64 KiB of LDS
 bool duplex_slots_supported(int beam_size, int N, int S, int width, int tie_order);
+size_t duplex_slots_pair_bytes(int64_t cap_nodes, int N, int ring_rows, int64_t T2cap);  // one pair's slab
 int duplex_slots_ring_rows(int width);  // ring capacity for a widest envelope row of `width`
 size_t duplex_slots_lds_bytes(int beam_size, int N, int S, int ring_rows, int tie_order);
 hipError_t launch_duplex_slots(const DuplexArgs &a, int64_t pair_begin, int64_t n_pairs, hipStream_t stream);

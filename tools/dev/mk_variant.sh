@@ -8,7 +8,7 @@ NAME=$1; shift
 SRCS=${@:-beam_wave.hip}
 C=fast_ctc_decode_amd/csrc
 mkdir -p ab_variants/obj_$NAME
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function"
+FLAGS="$EXTRA --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -Wall -Wno-unused-function"
 OBJS=""
 for o in $C/*.o; do
   b=$(basename $o .o)
