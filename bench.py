@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 CONFIGS = {
     2: dict(beam=5, thr=0.1, batch=4096, seed=1, crf=False, kernel_prefix="beam_wave_kernel<5, 6, 2, 0",
             kernel_name="beam_wave_kernel (two reads per wavefront)", baseline="BASELINE.json configs[1]"),
-    3: dict(beam=32, thr=0.1, batch=8192, seed=2, crf=False, kernel_prefix="beam_lane_kernel<5, 2",
+    3: dict(beam=32, thr=0.1, batch=8192, seed=2, crf=False, compare_all=True, kernel_prefix="beam_lane_kernel<5, 2",
             kernel_name="beam_lane_kernel (one beam entry per lane, two reads per wavefront)",
             baseline="BASELINE.json configs[2]: 64k reads sharded over 8 GPUs = 8192 per rank"),
     4: dict(beam=5, thr=0.0, batch=4096, seed=3, crf=True, kernel_prefix="beam_wave_kernel<5, 6, 2, 4",
@@ -78,6 +78,14 @@ def cpu_baseline(cfg, x_host, init_host, gpu_labels, gpu_path, gpu_len, budget_s
     empirically: short probes at 1, 2, 4, ... threads until throughput stops improving; the timed
     run uses the best count and ~budget_s seconds of wall time."""
     from oracle import oracle
+
+    # The checker follows the product's rule for EQUAL probabilities above 20 candidates (FCD_TIE_ORDER / fcd.tie_order();
+    # FCD_PDQ178_STD_FORM): a correct run reports 0 mismatches under either order (r05: the oracle always sorted its own
+    # default way, and `FCD_TIE_ORDER=stable python bench.py` printed 2 "mismatches" on reads 1198 and 3588).
+    import fast_ctc_decode_amd as fcd
+    from fast_ctc_decode_amd import _native as nat
+    oracle.lib.fcdo_set_unstable_sort(0 if fcd.tie_order() == "stable" else 1)
+    oracle.lib.fcdo_set_pdq_std_form(int(nat.load().fcd_debug_get_pdq178_std_form()) & 3)
 
     beam, thr = cfg["beam"], cfg["thr"]
     n_avail = x_host.shape[0]
@@ -124,20 +132,36 @@ def cpu_baseline(cfg, x_host, init_host, gpu_labels, gpu_path, gpu_len, budget_s
     labels, path, lens, status = oracle.beam_search_batch(x_host[:n], beam, thr, True, best_threads,
                                                           n_passes=passes, out=out)
     dt = time.perf_counter() - t0
-    mism = 0
-    for i in range(n):
-        L = int(lens[i])
-        ok = status[i] == 0 and int(gpu_len[i]) == L \
-            and np.array_equal(gpu_labels[i, :L], labels[i, :L]) \
-            and np.array_equal(gpu_path[i, :L].astype(np.int64), path[i, :L])
-        mism += 0 if ok else 1
+
+    def compare(first, labels, path, lens, status):
+        bad = 0
+        for j in range(len(lens)):
+            i = first + j
+            L = int(lens[j])
+            ok = status[j] == 0 and int(gpu_len[i]) == L \
+                and np.array_equal(gpu_labels[i, :L], labels[j, :L]) \
+                and np.array_equal(gpu_path[i, :L].astype(np.int64), path[j, :L])
+            bad += 0 if ok else 1
+        return bad
+
+    mism = compare(0, labels, path, lens, status)
+    n_compared = n
+    if cfg.get("compare_all") and n < n_avail:
+        # (outside the timed sample: the rest of the batch, so that EVERY timed read is checked -- BASELINE config 3's
+        # shard is 8192 reads at beam 32, ~20 s of oracle time on a 64-thread host)
+        for first in range(n, n_avail, 1024):
+            m = min(1024, n_avail - first)
+            l2, p2, n2, s2 = oracle.beam_search_batch(x_host[first:first + m], beam, thr, True, best_threads)
+            mism += compare(first, l2, p2, n2, s2)
+        n_compared = n_avail
     return {
         "value": n * passes / dt, "unit": "reads/s", "cores": best_threads, "kind": "port",
         "sample": "first %d reads of rank 0's batch x %d passes (T=%d N=%d beam=%d thr=%.1f), oracle C "
                   "restatement of src/search.rs, %d pthreads (best of a 1,2,4,.. probe; os.cpu_count()=%d), "
                   "%.1f s" % (n, passes, T, N, beam, thr, best_threads, max_threads, dt),
         "single_thread_reads_per_s": rate1,
-        "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n,
+        "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": n_compared,
+        "oracle_tie_order": "stable" if oracle.lib.fcdo_get_unstable_sort() == 0 else "pdq178",
     }
 
 
@@ -147,7 +171,8 @@ KERNEL_SOURCES = {  # the files a kernel's instruction stream and memory traffic
     "beam_generic_kernel": ("beam_generic.hip", "pdq178.h", "device_utils.h"),
     "viterbi": ("viterbi.hip", "device_utils.h"),
     "crf_greedy": ("viterbi.hip", "device_utils.h"),
-    "duplex_kernel": ("duplex.hip", "logadd_fast.h", "glibc235_math.h", "pdq178.h", "device_utils.h"),
+    "duplex_kernel": ("duplex.hip", "duplex_math.h", "logadd_fast.h", "glibc235_math.h", "pdq178.h", "device_utils.h"),
+    "duplex_slots_kernel": ("duplex_slots.hip", "duplex_math.h", "logadd_fast.h", "glibc235_math.h", "pdq178.h", "device_utils.h"),
     "envelope_kernel": ("envelope.hip", "device_utils.h"),
 }
 

@@ -109,6 +109,11 @@ def test_duplex(fcd):
         assert fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, logadd_mode=mode) == want
 
 
+def test_duplex_any_shape_kernel_forced(fcd):
+    """csrc/duplex.hip is the fallback since r06 (AUTO runs csrc/duplex_slots.hip wherever it fits): it stays under test."""
+    D.test_duplex_each_kernel_forced(fcd, 1)
+
+
 def test_duplex_glibc235_flavour(fcd):
     """FCD_LOGADD_LOGSUMEXP_GLIBC235 == the oracle on the host's libm (this image: glibc 2.35), every pair"""
     if __import__("platform").libc_ver() != ("glibc", "2.35"):

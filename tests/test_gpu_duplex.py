@@ -181,10 +181,11 @@ def test_duplex_config5_shape_sample(fcd):
 def test_duplex_config5_full_size(fcd, mode):
     """BASELINE config 5 at its stated size: 1024 pairs, T1 = T2 = 2000, band +-64, beam 5, threshold 0.1, both
     log-add modes.  Every pair decodes; reversing the batch reverses the answers (pairs are independent: the
-    property that does not need an oracle); 8 pairs spread over the batch equal the correctly-rounded oracle,
-    strings and tie counters."""
+    property that does not need an oracle); 64 pairs spread over the batch equal the correctly-rounded oracle (r06:
+    eight before), eight of them with their tie counters; the slot-resident kernel (csrc/duplex_slots.hip, what AUTO
+    runs here) and the any-shape kernel (csrc/duplex.hip) agree on every pair."""
     torch = pytest.importorskip("torch")
-    n_pairs, T, n_oracle = 1024, 2000, 8
+    n_pairs, T, n_oracle = 1024, 2000, 64
     x1, x2 = pairs(4, n_pairs, T, T)
     env = band(T, T, 64)
     x1d, x2d = torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()
@@ -197,14 +198,59 @@ def test_duplex_config5_full_size(fcd, mode):
     lens = np.asarray(r.out_len).astype(np.int64)
     mask = np.arange(r.labels.shape[1])[None, :] < lens[:, None]
     assert np.array_equal(np.where(mask, r.labels, 0), np.where(mask, np.asarray(rev.labels)[::-1], 0))
-    for i in np.linspace(0, n_pairs - 1, n_oracle).astype(np.int64):
-        want = oracle.beam_search_duplex(x1[i], x2[i], "NACGT", env, 5, 0.1, True, mode | CR)
+    from concurrent.futures import ThreadPoolExecutor
+    pick = np.linspace(0, n_pairs - 1, n_oracle).astype(np.int64)
+    with ThreadPoolExecutor(32) as pool:  # (the oracle's C routine runs outside the interpreter lock)
+        wants = list(pool.map(lambda i: oracle.beam_search_duplex(x1[i], x2[i], "NACGT", env, 5, 0.1, True, mode | CR), pick))
+    for i, want in zip(pick, wants):
         assert "".join("NACGT"[l] for l in r.labels[i, :lens[i]]) == want, i
+    for i in pick[::8]:  # (the counters are the last call's: one pair at a time)
+        assert oracle.beam_search_duplex(x1[i], x2[i], "NACGT", env, 5, 0.1, True, mode | CR) is not None
         assert tuple(int(v) for v in r.ambiguous[i]) == oracle.duplex_last_ambiguous(), i
+    # the two kernels, every pair
+    from fast_ctc_decode_amd import _native as nat
+    h = nat.default_handle()
+    assert h.lib.fcd_debug_set_duplex_kernel(h.ptr, 1) == 0
+    try:
+        legacy = fcd.beam_search_duplex_batch_raw(x1d, x2d, envd, 5, 0.1, True, logadd_mode=mode, count_ambiguous=True).cpu()
+    finally:
+        assert h.lib.fcd_debug_set_duplex_kernel(h.ptr, 0) == 0
+    assert np.array_equal(np.asarray(legacy.out_len), np.asarray(r.out_len)) and np.array_equal(np.asarray(legacy.status), np.asarray(r.status))
+    assert np.array_equal(np.where(mask, legacy.labels, 0), np.where(mask, r.labels, 0))
+    assert np.array_equal(np.asarray(legacy.ambiguous), np.asarray(r.ambiguous))
     amb = np.asarray(r.ambiguous)
     print("config 5 %s: pairs with a > 20-candidate kept tie %d, with a result-changing tie %d, both %d of %d"
           % ("max" if mode == MAX else "logsumexp", int((amb[:, 0] > 0).sum()), int((amb[:, 1] > 0).sum()),
              int(((amb[:, 0] > 0) & (amb[:, 1] > 0)).sum()), n_pairs))
+
+
+@pytest.mark.parametrize("which", [1, 2], ids=["any-shape", "slot-resident"])
+def test_duplex_each_kernel_forced(fcd, which):
+    """The duplex searches have two kernels since r06 -- csrc/duplex_slots.hip (beam_size * N <= 64 and its rings in LDS:
+    what AUTO picks for every shape of this file but the very wide ones) and csrc/duplex.hip (any shape).  Forced one at
+    a time (fcd_debug_set_duplex_kernel), each passes the exact comparisons with the oracle: banded, special values,
+    shapes, receding bounds, CRF, ties under both orders."""
+    from fast_ctc_decode_amd import _native as nat
+    h = nat.default_handle()
+    assert h.lib.fcd_debug_set_duplex_kernel(h.ptr, which) == 0
+    try:
+        test_duplex_banded_exact(fcd, LSE, True)
+        test_duplex_banded_exact(fcd, MAX, False)
+        test_duplex_special_values_in_wide_windows(fcd, MAX)
+        test_duplex_shapes_exact(fcd, 3, 3)
+        test_duplex_shapes_exact(fcd, 8, 5)
+        test_duplex_receding_upper_bound(fcd, LSE)
+        test_duplex_envelope_errors_and_edges(fcd)
+        test_duplex_tie_counters(fcd, MAX)
+        for seed in (7000, 100369):
+            assert special_values_case(fcd, seed, MAX) and special_values_case(fcd, seed, LSE)
+        x1, i1, x2, i2 = crf_pairs(405, 70, 64)
+        env = band(70, 64, 20)
+        for mode in (LSE, MAX):
+            want = oracle.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, mode | CR)
+            assert fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, logadd_mode=mode) == want
+    finally:
+        assert h.lib.fcd_debug_set_duplex_kernel(h.ptr, 0) == 0
 
 
 def test_duplex_wobbly_envelope_exact(fcd):

@@ -40,6 +40,13 @@ def digest(r):
         (r.status.astype(np.uint64) << np.uint64(60))
 
 
+def digest_arrays(labels, path, lens, status):
+    """digest() of results held as plain arrays (the oracle's batch outputs)"""
+    import types
+    return digest(types.SimpleNamespace(cpu=lambda: types.SimpleNamespace(
+        labels=np.asarray(labels), path=np.asarray(path), out_len=np.asarray(lens), status=np.asarray(status))))
+
+
 def test_four_kernels_agree_on_every_read(fcd, batch):
     """generic (LDS), wave (two reads per wavefront), wave (one read), lane: four independently written
     kernels give the same (labels, path, len, status) on all 4096 BASELINE config-2 reads."""
@@ -134,9 +141,15 @@ def test_config3_lane_and_generic_agree_on_8192_reads(fcd):
     gen = fcd.beam_search_batch_raw(xd[:2048], 32, 0.1, True, kernel=fcd.KERNEL_GENERIC, count_ambiguous=True)
     assert np.array_equal(digest(gen), d_lane[:2048])
     np.testing.assert_array_equal(gen.cpu().ambiguous.astype(np.int64), amb_lane[:2048])
-    want = np.zeros((256, 2), np.int64)
-    oracle.beam_search_batch(x[:256], 32, 0.1, True, n_threads=16, ambiguous=want)
-    np.testing.assert_array_equal(amb_lane[:256], want)
+    # ALL 8192 reads against the oracle under the order in force (the default: Rust 1.78's, as restated), results and
+    # both tie counters -- r06: the shard of the BASELINE multi-GPU config is compared whole, not sampled
+    import os
+    want = np.zeros((8192, 2), np.int64)
+    olab, opath, olen, ostat = oracle.beam_search_batch(x, 32, 0.1, True, n_threads=min(64, os.cpu_count() or 1), ambiguous=want)
+    assert (np.asarray(ostat) == 0).all()
+    mism = np.flatnonzero(digest_arrays(olab, opath, olen, ostat) != d_lane)
+    assert mism.size == 0, mism[:10]
+    np.testing.assert_array_equal(amb_lane, want)
 
 
 def test_oracle_spot_check(fcd, batch):
@@ -211,9 +224,9 @@ def test_viterbi_every_read(fcd, batch):
 def test_crf_full_size_kernels_agree(fcd):
     """BASELINE config 4 at its stated size: 4096 reads x (4000, 4, 5), beam 5, threshold 0 -- the register kernel
     in both packings and the LDS kernel agree on every read, the counting instantiations return the same results
-    and the same counters, and 16 reads equal the oracle (labels, path, counters)."""
+    and the same counters, and 64 reads equal the oracle (labels, path, counters)."""
     torch = pytest.importorskip("torch")
-    n_reads, n_oracle = 4096, 16
+    n_reads, n_oracle = 4096, 64
     g = torch.Generator(device="cuda")
     g.manual_seed(3)
     x = torch.rand((n_reads, 4000, 4, 5), generator=g, device="cuda")
@@ -231,8 +244,13 @@ def test_crf_full_size_kernels_agree(fcd):
     pick = np.linspace(0, n_reads - 1, n_oracle).astype(np.int64)  # spread over the batch, both wavefront halves
     xc, ic = x[pick].cpu().numpy(), init[pick].cpu().numpy()
     assert (np.asarray(ra.status) == 0).all()
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(16) as pool:  # (the oracle's C routines run outside the interpreter lock)
+        wants = list(pool.map(lambda j: oracle.crf_beam_search_ambiguous(xc[j], ic[j], 5, 0.0), range(n_oracle)))
     for j, i in enumerate(pick):
-        want = oracle.crf_beam_search(xc[j], ic[j], "NACGT", 5, 0.0)
+        st, labels, path, n_amb = wants[j]
         n = int(ra.out_len[i])
-        assert ("".join("NACGT"[l] for l in ra.labels[i, :n]), ra.path[i, :n].tolist()) == want
-        assert tuple(amb[i]) == oracle.crf_beam_search_ambiguous(xc[j], ic[j], 5, 0.0)[3]
+        assert st == 0 and n == len(labels), i
+        np.testing.assert_array_equal(ra.labels[i, :n], labels)
+        np.testing.assert_array_equal(ra.path[i, :n], path)
+        assert tuple(amb[i]) == n_amb, i

@@ -215,6 +215,38 @@ def test_beam_nan_and_zero_rows(fcd, kernel):
     check_beam(fcd, x, 1, 0.0, kernel=kernel)  # a lone NaN candidate is never compared
 
 
+@pytest.mark.parametrize("kernel", [0, 1, 2, 3, 4])
+def test_beam_special_posteriors(fcd, kernel):
+    """search.rs:191,201 accept any f32: +inf, values above 1, negative numbers, exact zeros and scattered NaNs among
+    ordinary rows (tools/beam_soak.py's injections, in the driver-run suite since r06) -- every kernel selection, narrow
+    and wide beams, both thresholds; a forced kernel that does not cover a shape says so."""
+    def inject(rng, x, n):
+        for _ in range(n):
+            idx = tuple(int(rng.integers(0, s_)) for s_ in x.shape)
+            x[idx] = [np.nan, np.inf, 1.0 + float(rng.random()), 0.0, -0.25][int(rng.integers(0, 5))]
+        return x
+    rng = np.random.default_rng(9100 + kernel)
+    cases = []
+    for N, beam, T in ((5, 5, 120), (5, 3, 60), (4, 8, 90), (5, 32, 80), (7, 12, 70), (3, 64, 50)):
+        x = reference_style_rows(rng, 6 * T, N).reshape(6, T, N)
+        for b in range(6):  # read 0 stays ordinary; the others get 1 .. 5 special entries, one kind each at least once
+            inject(rng, x[b], b)
+        x[1, T // 2, 1] = np.inf
+        x[2, T // 3, 0] = -0.25
+        x[3, T // 4, 2] = 1.75
+        x[4, T // 5, N - 1] = np.nan
+        cases.append((np.ascontiguousarray(x, np.float32), beam))
+    ran = 0
+    for x, beam in cases:
+        for thr in (0.0, 0.1):
+            try:
+                check_beam(fcd, x, beam, thr, kernel=kernel)
+                ran += 1
+            except RuntimeError as e:
+                assert kernel in (2, 3, 4) and " kernel: " in str(e), str(e)
+    assert ran >= 4, ran
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 def test_beam_ties_and_zeros(fcd, kernel):
     """Exact ties (equal probabilities, zeros) must resolve by ascending node index."""

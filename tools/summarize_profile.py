@@ -19,8 +19,10 @@ WORK_PREFIX = [
     ("viterbi_stream_kernel<5", "16384 reads T=4000 N=5"),
     ("beam_generic_kernel", "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)"),
     ("beam_lane_kernel<5, 2", "8192 reads T=4000 N=5 beam 32 thr 0.1 (config 3, per GPU)"),
-    ("duplex_kernel<0", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 logsumexp (config 5)"),
-    ("duplex_kernel<1", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 max mode (config 5)"),
+    ("duplex_kernel<0", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 logsumexp (config 5), the any-shape kernel"),
+    ("duplex_kernel<1", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 max mode (config 5), the any-shape kernel"),
+    ("duplex_slots_kernel<0", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 logsumexp (config 5)"),
+    ("duplex_slots_kernel<1", "1024 pairs T=2000 band +-64 beam 5 thr 0.1 max mode (config 5)"),
 ]
 
 
@@ -37,7 +39,7 @@ WORK = _Work()
 
 def short(n):
     m = re.search(r"(beam_wave_kernel<[^>]*>|beam_lane_kernel<[^>]*>|beam_generic_kernel|viterbi_stream_kernel<[^>]*>|viterbi_kernel|"
-                  r"duplex_kernel<[^>]*>|crf_greedy_stream_kernel<[^>]*>|crf_greedy_kernel|envelope_kernel|ln_convert_kernel)", n)
+                  r"duplex_slots_kernel<[^>]*>|duplex_kernel<[^>]*>|crf_greedy_stream_kernel<[^>]*>|crf_greedy_kernel|envelope_kernel|ln_convert_kernel)", n)
     return m.group(1) if m else None
 
 
