@@ -1209,18 +1209,39 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
         }
         if (PROF && prof) n_enter += (uint32_t)n_stale;
-        // what leaves: the beam entries that did not survive and the new nodes that did not make it
+        // what leaves: the beam entries that did not survive and the new nodes that did not make it.  A node comes back
+        // only as the child of a beam entry, so it needs a proper ancestor in the beam -- none exists once every entry
+        // of the next beam is at least as deep as the node, and then none ever will (its ancestors have left for good,
+        // top-down from the root: the argument of beam_wave_step.inc's dead-row test).  Such a node leaves its
+        // (parent, label) behind -- the final walk to the root may pass through it -- and nothing else: no ring, no
+        // window record, no child row.
         const bool ev = (act && ck == 0 && !surv && node >= 0) || (is_new && can && !surv);  // (the root has no arena entry)
-        const uint64_t m_ev = ballot(ev);
+        const int my_depth = ck == 0 ? depth : depth + 1;
+        int min_depth = surv ? my_depth : 0x7FFFFFFF;
+#define FCD_DPP_IMIN(CTRL, RM)                                                                                  \
+        {                                                                                                       \
+            const int o_ = __builtin_amdgcn_update_dpp(min_depth, min_depth, CTRL, RM, 0xf, false);             \
+            min_depth = o_ < min_depth ? o_ : min_depth;                                                        \
+        }
+        FCD_DPP_IMIN(0x111, 0xf) FCD_DPP_IMIN(0x112, 0xf) FCD_DPP_IMIN(0x114, 0xf) FCD_DPP_IMIN(0x118, 0xf)
+        FCD_DPP_IMIN(0x142, 0xa) FCD_DPP_IMIN(0x143, 0xc)
+#undef FCD_DPP_IMIN
+        min_depth = rl_i(min_depth, 63);
+        // ... unless one of its children stays: an entry whose parent has left reads the parent's last rows out of the
+        // arena when it is next extended
+        const int pr = ck == 0 ? prank_i : ci;  // rank of my parent in this step's beam (own candidates: if it is there)
+        const int has_kid = __builtin_amdgcn_ds_permute(((surv && pr >= 0) ? pr * N : 63) << 2, 1);
+        const bool dead = ev && my_depth <= min_depth && !(ck == 0 && has_kid != 0);
+        const bool ev_ring = ev && !dead;
+        const uint64_t m_ev = ballot(ev_ring);
         const int n_ev = popc64(m_ev);
-        if (ev) {
+        if (ev_ring) {
             const int qi = popc64(m_ev & lanemask_lt());
             l_bt[qi] = myslot;
             l_pw[qi] = cid;  // (ck == 0: cid is the entry's node)
         }
         // a survivor whose parent sat in this step's beam and is not in the next one remembers the parent's bounds
         {
-            const int pr = ck == 0 ? prank_i : ci;  // rank of my parent in this step's beam (own candidates: if it is there)
             const int prc = (surv && pr >= 0) ? pr : 0;
             const int p_surv = bperm_i(prc * N, surv ? 1 : 0);
             const int p_slot = bperm_i(prc * N, slot_i);
@@ -1303,17 +1324,19 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             for (int j = 0; j < kNLMax; ++j)
                 if (j < NL) fi(F_CHILD0 + j, myslot) = s_rows[j];
         }
-        // ---- evictions: records, one evicted node per lane ----
-        if (lane < n_ev) {
-            const int s_ = l_bt[lane], nd = l_pw[lane];
+        // ---- evictions: records, by the candidate lane whose node leaves ----
+        if (ev) {
+            const int s_ = myslot, nd = cid;
             *g_meta((uint32_t)nd) = make_int4(fi(F_PAR, s_), fi(F_TIP, s_), fi(F_OFF, s_), fi(F_END, s_));
-            *g_aux((uint32_t)nd) = make_int4(fi(F_MX, s_), fi(F_VFROM, s_), fi(F_LLAB, s_), 0);
-            int32_t *rw = g_rows((uint32_t)nd);
-            if (NLp == 4) {
-                *reinterpret_cast<int4 *>(rw) = make_int4(fi(F_CHILD0, s_), NL > 1 ? fi(F_CHILD0 + 1, s_) : -1,
-                                                          NL > 2 ? fi(F_CHILD0 + 2, s_) : -1, NL > 3 ? fi(F_CHILD0 + 3, s_) : -1);
-            } else {
-                for (int j = 0; j < NL; ++j) rw[j] = fi(F_CHILD0 + j, s_);
+            if (!dead) {
+                *g_aux((uint32_t)nd) = make_int4(fi(F_MX, s_), fi(F_VFROM, s_), fi(F_LLAB, s_), 0);
+                int32_t *rw = g_rows((uint32_t)nd);
+                if (NLp == 4) {
+                    *reinterpret_cast<int4 *>(rw) = make_int4(fi(F_CHILD0, s_), NL > 1 ? fi(F_CHILD0 + 1, s_) : -1,
+                                                              NL > 2 ? fi(F_CHILD0 + 2, s_) : -1, NL > 3 ? fi(F_CHILD0 + 3, s_) : -1);
+                } else {
+                    for (int j = 0; j < NL; ++j) rw[j] = fi(F_CHILD0 + j, s_);
+                }
             }
         }
         // ---- evictions: rings, 16 bytes per lane and item, four items in flight per lane (one LDS round trip for the
