@@ -360,6 +360,17 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
 #define FCD_S_SUB_BEGIN() if (PROF && prof) FCD_STAMP(t_sub, stamp_dep);
 #define FCD_S_SUB(k) if (PROF && prof) { FCD_STAMP(t_sub2, stamp_dep); sub[k] += t_sub2 - t_sub; t_sub = t_sub2; }
 #define FCD_S_PHASE(k) if (PROF && prof) { FCD_STAMP(t_now, stamp_dep); acc[k] += t_now - t_prev; t_prev = t_now; }
+    // developer build (-DFCD_SLOTS_FINE, tools/dev/duplex_fine.py): the step cut into 16 consecutive intervals, written
+    // behind the regular account (32 words per pair)
+#ifdef FCD_SLOTS_FINE
+    uint64_t fine[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t_fine = 0, t_fine2 = 0;
+    if (PROF && prof) FCD_STAMP(t_fine, stamp_dep);
+#define FCD_S_FINE(k) if (PROF && prof) { FCD_STAMP(t_fine2, stamp_dep); fine[k] += t_fine2 - t_fine; t_fine = t_fine2; }
+    constexpr int kProfWords = 32;
+#else
+#define FCD_S_FINE(k)
+    constexpr int kProfWords = 16;
+#endif
     if (PROF && prof) FCD_STAMP(t_prev, stamp_dep);
     wave_sync();
 
@@ -441,6 +452,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
         }
         FCD_S_SUB(0)
+        FCD_S_FINE(0)  // envelope + tile
 
         const bool grew = hi > last_hi;
         if (grew) {
@@ -511,6 +523,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 }
             }
             FCD_S_SUB(4)
+            FCD_S_FINE(1)  // sort, parents, extension prologue
             if (ballot(panic) != 0ull) return fail(FCD_ST_BAD_STATE);
             // update_max over the rows that stay, [max(lo, off), end), for every entry that discarded rows: eight lanes per
             // entry, 16-byte reads, all entries at once (NaN rows never replace the maximum).  One LDS round trip where a
@@ -527,10 +540,11 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     if (on && rs && a0 < n2) {
                         const float4 *rg4 = reinterpret_cast<const float4 *>(ring(sl));
                         const int gb = (n2 - 1) >> 2;
-                        for (int g = (a0 >> 2) + r8; g <= gb; g += 32) {  // four 16-byte reads in flight per lane
-                            float4 v[4];
+                        const unsigned span = (unsigned)(n2 - a0);
+                        for (int g = (a0 >> 2) + r8; g <= gb; g += 40) {  // five 16-byte reads in flight per lane: one trip up to 160 rows
+                            float4 v[5];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
+                            for (int u = 0; u < 5; ++u) {
                                 const int gu = g + 8 * u;
                                 int sg = (lo_s >> 2) + (gu - (lo >> 2));
                                 sg = sg < 0 ? sg + G : sg;
@@ -538,12 +552,12 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                                 v[u] = rg4[gu <= gb ? sg : 0];
                             }
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) {
-                                const int t0 = (g + 8 * u) << 2;  // (rows past the window fail `< n2`)
-                                part = lmax(part, (t0 >= a0 && t0 < n2) ? v[u].x : kNegInf);
-                                part = lmax(part, (t0 + 1 >= a0 && t0 + 1 < n2) ? v[u].y : kNegInf);
-                                part = lmax(part, (t0 + 2 >= a0 && t0 + 2 < n2) ? v[u].z : kNegInf);
-                                part = lmax(part, (t0 + 3 >= a0 && t0 + 3 < n2) ? v[u].w : kNegInf);
+                            for (int u = 0; u < 5; ++u) {
+                                const int d0 = ((g + 8 * u) << 2) - a0;  // (rows before a0 wrap round to huge, rows past n2 fail too)
+                                part = vmax_raw(part, (unsigned)d0 < span ? v[u].x : kNegInf);
+                                part = vmax_raw(part, (unsigned)(d0 + 1) < span ? v[u].y : kNegInf);
+                                part = vmax_raw(part, (unsigned)(d0 + 2) < span ? v[u].z : kNegInf);
+                                part = vmax_raw(part, (unsigned)(d0 + 3) < span ? v[u].w : kNegInf);
                             }
                         }
                     }
@@ -556,6 +570,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 }
             }
             FCD_S_SUB(2)
+            FCD_S_FINE(2)  // rescans
             const bool seq = ballot(behind) != 0ull;
             // the recurrence (:361-386) for one entry on its own lane
             const float mx_in = mx;
@@ -626,6 +641,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         last_hi = hi;
         wave_sync();
         FCD_S_PHASE(0)
+        FCD_S_FINE(3)  // extension rows
 
         // the root (in the beam for the first few rows only) has no ring of its own: the rows its children's builds
         // and its children's extensions will ask for, [lo - 1, hi - 1), are staged into slot 0's ring from the
@@ -641,6 +657,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             wave_sync();
         }
         FCD_S_PHASE(1)
+        FCD_S_FINE(4)  // root staging
 
         // ---- expansion (:526-593): lane c = candidate (ci, ck) ----
         const bool act = ci < B;
@@ -759,9 +776,11 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 cgp = kNegInf;
             }
         };
+        FCD_S_FINE(5)  // expansion: entry fields, candidates
         bf_bad = false;
         probabilities(la_fast);
         if (MODE == FCD_LOGADD_LOGSUMEXP && ballot(bf_bad && act) != 0ull) probabilities(la_exact);
+        FCD_S_FINE(6)  // expansion: probabilities
 #ifndef FCD_HIPEMU
         // An existing child outside the beam that passed the threshold may be in the next beam, and then its ring and
         // record come back from the arena -- evicted tens of steps ago, i.e. from HBM (2-4 k cycles on the critical path
@@ -804,6 +823,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             fi(F_CHILD0 + l, slot_i) = cid;
         }
         FCD_S_PHASE(2)
+        FCD_S_FINE(7)  // new-node slots
         if (PROF && prof) {
             n_newnodes += (uint32_t)n_new;
             n_iter += (uint32_t)(W + 1) * (uint32_t)((n_new + 31) / 32);
@@ -1111,6 +1131,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         if (is_new && can) p2 = ff(F_MX, nbuf);
         nn += n_new;
         FCD_S_PHASE(3)
+        FCD_S_FINE(8)  // builds
         if (nn > p.cap_nodes) return fail(FCD_ST_INTERNAL);
 
         // ---- merge is done (own candidates folded the three items); probability (:146-148), keys, exact rank ----
@@ -1133,6 +1154,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             rank = (r0 + r1) + (r2 + r3);
         }
         const int Bn = n_valid < BC ? n_valid : BC;
+        FCD_S_FINE(9)  // probability, keys, exact rank
         // equal probabilities: candidates with one probability occupy consecutive ranks, so a KEPT candidate is tied
         // when ranks i and i + 1 hold one probability word for some i < beam_size; the tie can change the kept set or
         // the best entry when it sits at ranks 0 / 1 or across the truncation boundary
@@ -1168,6 +1190,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             wave_sync();
         }
         FCD_S_SUB_BEGIN()
+        FCD_S_FINE(10)  // ties
 
         // ---- the next beam: survivors keep (or get) a slot, everything else that was live leaves ----
         // All of it batched: a step evicts ~7 nodes and the wavefront is alone on its SIMD, so a loop over the evicted
@@ -1209,6 +1232,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
         }
         if (PROF && prof) n_enter += (uint32_t)n_stale;
+        FCD_S_FINE(11)  // survivors, returning nodes' loads issued
         // what leaves: the beam entries that did not survive and the new nodes that did not make it.  A node comes back
         // only as the child of a beam entry, so it needs a proper ancestor in the beam -- none exists once every entry
         // of the next beam is at least as deep as the node, and then none ever will (its ancestors have left for good,
@@ -1282,6 +1306,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             const bool bs = lane < Bn && fi(F_STATE, slotE) >= S;
             if (ballot(bs) != 0ull) return fail(FCD_ST_BAD_STATE);
         }
+        FCD_S_FINE(12)  // eviction lists, parents' bounds, rank lanes
         // ---- nodes coming back: ring and record from the arena into their slot ----
         // (BEFORE the evictions' stores are issued: a wait on these loads behind the stores would wait for the stores too)
         if (n_stale > 0 && small_ring) {
@@ -1324,6 +1349,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             for (int j = 0; j < kNLMax; ++j)
                 if (j < NL) fi(F_CHILD0 + j, myslot) = s_rows[j];
         }
+        FCD_S_FINE(13)  // returning nodes landed
         // ---- evictions: records, by the candidate lane whose node leaves ----
         if (ev) {
             const int s_ = myslot, nd = cid;
@@ -1371,6 +1397,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
         }
         FCD_S_SUB(1)
+        FCD_S_FINE(14)  // evictions + returning nodes
         // ---- free list of the coming step: the slots no entry of the next beam sits in ----
         {
             bool used = false;
@@ -1386,9 +1413,13 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         B = Bn;
         wave_sync();
         FCD_S_PHASE(4)
+        FCD_S_FINE(15)  // free list, end of step
     }
     if (PROF && prof && lane == 0) {
-        uint32_t *o = p.prof + 16 * r;
+        uint32_t *o = p.prof + kProfWords * r;
+#ifdef FCD_SLOTS_FINE
+        for (int k = 0; k < 16; ++k) o[16 + k] = (uint32_t)(fine[k] >> 6);
+#endif
         for (int k = 0; k < 5; ++k) o[k] = (uint32_t)(acc[k] >> 6);  // units of 64 cycles
         o[5] = n_iter;
         o[6] = n_newnodes;
