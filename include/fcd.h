@@ -250,6 +250,10 @@ int fcd_crf_greedy_search_host(fcd_handle *h, const fcd_batch *in, const float *
                                int64_t n_init, int64_t init_stride, const fcd_result *out);
 
 /* ---- duplex::beam_search (src/duplex.rs:443-650) ----
+ * (Two kernels serve the duplex searches since round 6, with identical results: the slot-resident one --
+ * csrc/duplex_slots.hip -- wherever beam_size * N <= 64 and the live nodes' windows fit the LDS, the any-shape one --
+ * csrc/duplex.hip -- otherwise.  Nothing at this boundary depends on which runs; FCD_DUPLEX_KERNEL=legacy|slots and
+ * fcd_debug_set_duplex_kernel (fcd_debug.h) force one for A/B runs and tests.)
  * in1/in2 describe the two reads of each pair (same n_reads and N); envelope is
  * [n_reads * env_stride] pairs of u64 (lo,hi), row t of pair r at envelope[(r*env_stride + t)*2].
  * Only labels/out_len/status (and the tie counters `ambiguous`, when given) of `out` are written (the reference
