@@ -223,7 +223,12 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     Tmax = __builtin_amdgcn_readfirstlane(Tmax);
 
     const int dt = H16 ? p.in.dtype : (int)kF32;  // element type of the posteriors (f16 / bf16: converted exactly on load)
-    const float *post = post_at(p.in.post, r * p.in.stride_read, dt);
+    // The posteriors of a wavefront's reads: the first read's address is wave-uniform (scalar registers) and the second
+    // read sits one read stride further on -- formed where a block is loaded (once per FIFO rotation), not carried
+    // through the time loop as a 64-bit pointer per lane.
+    const int64_t r_first = p.read_begin + ((int64_t)blockIdx.x * kWavesPerBlock + __builtin_amdgcn_readfirstlane(wave)) * RPW;
+    const float *const post_w = post_at(p.in.post, r_first * p.in.stride_read, dt);
+    const int64_t half_stride = (RPW == 2 && lane >= HALF) ? p.in.stride_read : 0;
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
     // Arena addressing: a wave-uniform base (the slab of the wavefront's first read: scalar registers) plus a
     // 32-bit element offset per lane (the second read's slab starts cap_nodes elements further on), so that
@@ -235,8 +240,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     int32_t *const jmp_w = p.arena.jmp + wslab * p.arena.cap_nodes;
     int32_t *const rows_w = p.arena.rows + wslab * p.arena.cap_nodes * RW;
     const uint32_t hoff = has_read ? (uint32_t)(lane / HALF) * (uint32_t)cap : 0u;  // this half's slab, in nodes
-    int32_t *rec = rec_w + hoff;   // (used by the traceback)
-    int32_t *jmp = jmp_w + hoff;
+    // (the traceback's per-lane pointers are formed AFTER the time loop: four registers the loop need not carry)
 
     // ---- beam state (search.rs:170-175: root, label_prob 0, gap_prob 1) ----
     int node = -1;
@@ -280,7 +284,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const bool f_lane = q < RPR * E;
     auto load_block = [&](int blk) -> float {
         const int row = blk * RPR + fg;
-        return (f_lane && row < T) ? load_post(post, (int64_t)row * st_t + fs * st_s + fc * st_n, dt) : 0.0f;
+        return (f_lane && row < T) ? load_post(post_w, half_stride + (int64_t)row * st_t + fs * st_s + fc * st_n, dt) : 0.0f;
     };
     float win[kFifo];
 #pragma unroll
@@ -295,7 +299,7 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
     const int s_mask = GATHER ? (int)p.in.S - 1 : 0;
     const int kcol = is_child ? k : 0;
     auto gather_row = [&](int tt) -> float {
-        return tt < T ? load_post(post, (int64_t)tt * st_t + (int64_t)state * st_s + kcol * st_n, dt) : 0.0f;
+        return tt < T ? load_post(post_w, half_stride + (int64_t)tt * st_t + (int64_t)state * st_s + kcol * st_n, dt) : 0.0f;
     };
     float rowv = GATHER ? gather_row(0) : 0.0f;
     // Drain the prologue loads HERE, with a wait the compiler's scoreboard sees: otherwise the loop
@@ -349,6 +353,8 @@ __global__ __launch_bounds__(64 * kWavesPerBlock) __attribute__((amdgpu_waves_pe
 
     // ---- walk the best labelling leaf -> root (:285-300), segment-parallel ----
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    const int32_t *rec = rec_w + hoff;
+    const int32_t *jmp = jmp_w + hoff;
     uint8_t *lab = p.out.labels + r * p.out.out_stride;
     uint32_t *pth = p.out.path ? p.out.path + r * p.out.out_stride : nullptr;
     if (q == 0 && alive) {
