@@ -54,13 +54,18 @@ constexpr int kSlots = 64;   // slot-indexed LDS arrays have 64 entries whatever
 constexpr int kNLMax = 7;    // N <= 8
 constexpr int kBeamMax = 32; // beam_size * N <= 64 with N >= 2
 
-// slot fields (one 64-word array each)
+// slot fields, in 16-byte GROUPS (one 64-entry int4 array per group: a slot's four words of a group move with one
+// ds_read_b128 / ds_write_b128; field f is word f & 3 of group f >> 2)
 enum {
-    F_NODE = 0, F_TIP, F_PAR, F_STATE, F_OFF, F_END, F_VFROM, F_MX, F_LLAB, F_XREP, F_DEPTH,
-    F_POFF, F_PEND, F_PVFROM,  // the parent's window bounds as they were when it left the beam (valid while it is out)
-    F_CHILD0,                  // kNLMax arrays
-    F_COUNT = F_CHILD0 + kNLMax
+    F_NODE = 0, F_TIP, F_PAR, F_STATE,       // group 0 (G_ID)
+    F_OFF, F_END, F_VFROM, F_XREP,           // group 1 (G_WIN): the window's bounds, where its run of rows began, the :512 flag
+    F_MX, F_LLAB, F_DEPTH, F_LSUM,           // group 2 (G_VAL): running maximum, last row's label, depth in the tree, last row's sum
+    F_POFF, F_PEND, F_PVFROM, F_SPARE1,      // group 3 (G_PAR): the parent's window bounds as they were when it left the beam
+    F_CHILD0,                                // groups 4, 5 (G_KID, G_KID + 1): kNLMax child ids (+ one spare word)
+    F_COUNT = F_CHILD0 + kNLMax + 1
 };
+enum { G_ID = 0, G_WIN = 1, G_VAL = 2, G_PAR = 3, G_KID = 4, G_COUNT = 6 };
+static_assert(F_COUNT == 4 * G_COUNT, "fields come in groups of four");
 
 struct SlotParams {
     const float *ln1, *ln2;   // log-space posteriors, [pair][Tcap][S][N] contiguous
@@ -75,7 +80,7 @@ struct SlotParams {
     int64_t n_init1, n_init2, init1_stride, init2_stride;
     // arena: ONE slab per pair, below 4 GiB (32-bit byte offsets: base in scalar registers + one vector register):
     //   meta  int4 per node {parent, label, off, end}
-    //   aux   int4 per node {running maximum, vfrom, last label, 0}
+    //   aux   int4 per node {running maximum, vfrom, last row's label, last row's sum}
     //   ring  Wcap4 floats per node: label (+) gap of row t at [t mod Wcap4]
     //   rows  NLp child ids per node
     //   root  T2cap + 1 floats: the root's cumulative blank products
@@ -225,8 +230,9 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
     float *l_zero = reinterpret_cast<float *>(smem + O_ZERO);
     uint64_t *l_pql = reinterpret_cast<uint64_t *>(smem + O_PQL);
     pdq178::Scratch *l_pqs = reinterpret_cast<pdq178::Scratch *>(smem + O_PQS);
-    auto fi = [&](int f, int slot) -> int & { return F[f * kSlots + slot]; };
-    auto ff = [&](int f, int slot) -> float & { return reinterpret_cast<float *>(F)[f * kSlots + slot]; };
+    auto fi = [&](int f, int slot) -> int & { return F[(((f >> 2) * kSlots + slot) << 2) + (f & 3)]; };
+    auto ff = [&](int f, int slot) -> float & { return reinterpret_cast<float *>(F)[(((f >> 2) * kSlots + slot) << 2) + (f & 3)]; };
+    auto fg = [&](int g, int slot) -> int4 & { return reinterpret_cast<int4 *>(F)[g * kSlots + slot]; };  // a whole group
     auto ring = [&](int slot) { return L.rings + (size_t)slot * WC; };
 
     int64_t T1 = p.T1cap, T2 = p.T2cap;
@@ -318,10 +324,11 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         fi(F_VFROM, 0) = -1;
         ff(F_MX, 0) = 0.0f;
         ff(F_LLAB, 0) = kNegInf;
+        ff(F_LSUM, 0) = kNegInf;
         fi(F_XREP, 0) = 0;
         fi(F_DEPTH, 0) = 0;
     }
-    for (int j = lane; j < kNLMax; j += kWave) fi(F_CHILD0 + j, 0) = -1;
+    for (int j = lane; j < kNLMax + 1; j += kWave) fi(F_CHILD0 + j, 0) = -1;
     if (lane < 4) l_keys[kSlots + lane] = 0ull;  // padding of the four-at-a-time rank loop
     if (lane < 4) l_zero[lane] = 0.0f;
     // (rows of read 2 that were never loaded read as a finite number: "zero (x) p" stays zero in the guard rows' sums)
@@ -332,6 +339,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
     l_flist[lane] = lane + 1;                    // free: every slot but 0
     // lane c is candidate (ci, ck) of every step
     const int ci = lane / N, ck = lane - ci * N;
+    // ... word offset (at slot 0) of the child entry candidate `lane` looks at: F_CHILD0 + ck - 1
+    const int kid_off = ((((F_CHILD0 + (ck > 0 ? ck - 1 : 0)) >> 2) * kSlots) << 2) + ((F_CHILD0 + (ck > 0 ? ck - 1 : 0)) & 3);
     // ... item `lane` of a batch of rings copied 16 bytes at a time is piece g_c0 of ring g_q0; 64 items on: + (g_dq, g_dc)
     const int g_q0 = lane / (WC >> 2), g_c0 = lane - g_q0 * (WC >> 2);
     const int g_dq = kWave / (WC >> 2), g_dc = kWave - g_dq * (WC >> 2);
@@ -454,6 +463,19 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         FCD_S_SUB(0)
         FCD_S_FINE(0)  // envelope + tile
 
+        // the root (in the beam for the first few rows only) has no ring of its own: the rows its children's extensions
+        // and its children's builds will ask for, [lo - 1, hi - 1), are staged into slot 0's ring from the cumulative
+        // blank products -- before the extension, which then reads a root parent like any other parent in the beam
+        const bool root_in = ballot(lane < B && nodeE < 0) != 0ull;
+        if (root_in) {
+            float *rg = ring(0);
+            for (int j = lane; j < W; j += kWave) {
+                const int at = lo - 1 + j;
+                if (at < -1) continue;
+                rg[slotn(at)] = at < root_end ? load_f32_l2(rootgap + (at + 1)) : kNegInf;
+            }
+            wave_sync();
+        }
         const bool grew = hi > last_hi;
         if (grew) {
             FCD_S_SUB_BEGIN()
@@ -489,13 +511,14 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             // the reference's parents-first order (:493) is immaterial.  Only a parent that is itself behind takes the
             // one-entry-at-a-time path (entries are in node order: parents first).
             const bool mine = mineE && nodeE >= 0;
-            int off = 0, end = 0, vfrom = 0, lab = 0, tst = 0, p_off = 0, p_end = 0, p_vfrom = 0, xrep = 0;
-            float mx = kNegInf, llab = kNegInf;
+            int off = 0, end = 0, vfrom = 0, lab = 0, tst = 0, p_off = 0, p_end = 0, p_vfrom = 0, xrep = 0, e_depth = 0;
+            float mx = kNegInf, llab = kNegInf, lsum = kNegInf;
             bool rescan = false, panic = false, behind = false;
             if (mine) {
-                off = fi(F_OFF, slotE); end = fi(F_END, slotE); vfrom = fi(F_VFROM, slotE);
-                mx = ff(F_MX, slotE); llab = ff(F_LLAB, slotE);
-                lab = fi(F_TIP, slotE); tst = fi(F_STATE, slotE); xrep = fi(F_XREP, slotE);
+                const int4 g_id = fg(G_ID, slotE), g_win = fg(G_WIN, slotE), g_val = fg(G_VAL, slotE);
+                off = g_win.x; end = g_win.y; vfrom = g_win.z; xrep = g_win.w;
+                mx = __int_as_float(g_val.x); llab = __int_as_float(g_val.y); e_depth = g_val.z; lsum = __int_as_float(g_val.w);
+                lab = g_id.y; tst = g_id.w;
                 if (lo > off) {  // :351-359
                     const int keep = lo - 1;
                     if (keep > off) {
@@ -503,7 +526,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                         else { off = keep; end = keep; }
                     }
                     if (end == off) {  // emptied: a new run of rows starts at lo, below it two guard rows of "zero"
-                        off = lo; end = lo; vfrom = lo; llab = kNegInf;
+                        off = lo; end = lo; vfrom = lo; llab = kNegInf; lsum = kNegInf;
                         float *mw0 = ring(slotE);
                         mw0[slotn(lo - 1)] = kNegInf;
                         mw0[slotn(lo - 2)] = kNegInf;
@@ -511,12 +534,14 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     rescan = true;  // update_max(lo, hi)
                 }
                 panic = end >= hi;  // assert!(current_end < upper_bound) :363-366
-                if (parE >= 0) {
+                if (parE >= 0 || pslotE >= 0) {
                     if (pslotE >= 0) {
-                        p_off = fi(F_OFF, pslotE); p_end = fi(F_END, pslotE); p_vfrom = fi(F_VFROM, pslotE);
+                        const int4 pw_ = fg(G_WIN, pslotE);
+                        p_off = pw_.x; p_end = pw_.y; p_vfrom = pw_.z;
                         behind = p_end < hi - 1;
                     } else {
-                        p_off = fi(F_POFF, slotE); p_end = fi(F_PEND, slotE); p_vfrom = fi(F_PVFROM, slotE);
+                        const int4 pp_ = fg(G_PAR, slotE);
+                        p_off = pp_.x; p_end = pp_.y; p_vfrom = pp_.z;
                     }
                 } else {  // the root's window
                     p_off = -1; p_end = root_end; p_vfrom = -1;
@@ -577,11 +602,10 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             auto extend = [&](auto LA) __attribute__((always_inline)) {
                 mx = mx_in;
                 float *mw = ring(slotE);
-                const float *prg = pslotE >= 0 ? ring(pslotE) : (parE < 0 ? ring(0) : nullptr);
+                const float *prg = pslotE >= 0 ? ring(pslotE) : nullptr;
                 const float *parena = g_ring((uint32_t)(parE < 0 ? 0 : parE));
-                const bool rootpar = parE < 0;
-                float l_lab = llab, l_sum = kNegInf;
-                if (end > off) l_sum = mw[slotn(end - 1)];
+                const bool rootpar = parE < 0 && pslotE < 0;  // (the root has left the beam: its products are in the arena only)
+                float l_lab = llab, l_sum = lsum;  // (the last row's label and sum are fields: no look into the ring)
                 const float *tb = L.tile + (size_t)(tst * N) * WC;        // blank of the entry's state (:725-728)
                 const float *tl = L.tile + (size_t)(tst * N + lab + 1) * WC;
                 for (int idx = end; idx < hi; ++idx) {
@@ -611,11 +635,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     l_lab = lb;
                     l_sum = sm;
                 }
-                fi(F_OFF, slotE) = off;
-                fi(F_END, slotE) = hi;
-                fi(F_VFROM, slotE) = vfrom;
-                ff(F_MX, slotE) = mx;
-                ff(F_LLAB, slotE) = l_lab;
+                fg(G_WIN, slotE) = make_int4(off, hi, vfrom, xrep);
+                fg(G_VAL, slotE) = make_int4(__float_as_int(mx), __float_as_int(l_lab), e_depth, __float_as_int(l_sum));
             };
             if (!seq) {
                 bf_bad = false;
@@ -627,7 +648,10 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 for (int e = 0; e < B; ++e) {
                     if (mine && lane == e) {
                         // the parent may have moved in an earlier trip
-                        if (pslotE >= 0) { p_off = fi(F_OFF, pslotE); p_end = fi(F_END, pslotE); p_vfrom = fi(F_VFROM, pslotE); }
+                        if (pslotE >= 0) {
+                            const int4 pw_ = fg(G_WIN, pslotE);
+                            p_off = pw_.x; p_end = pw_.y; p_vfrom = pw_.z;
+                        }
                         extend(la_exact);
                     }
                     wave_sync();
@@ -643,19 +667,6 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         FCD_S_PHASE(0)
         FCD_S_FINE(3)  // extension rows
 
-        // the root (in the beam for the first few rows only) has no ring of its own: the rows its children's builds
-        // and its children's extensions will ask for, [lo - 1, hi - 1), are staged into slot 0's ring from the
-        // cumulative blank products
-        const bool root_in = ballot(mineE && nodeE < 0) != 0ull;
-        if (root_in) {
-            float *rg = ring(0);
-            for (int j = lane; j < W; j += kWave) {
-                const int at = lo - 1 + j;
-                if (at < -1) continue;
-                rg[slotn(at)] = at < root_end ? load_f32_l2(rootgap + (at + 1)) : kNegInf;
-            }
-            wave_sync();
-        }
         FCD_S_PHASE(1)
         FCD_S_FINE(4)  // root staging
 
@@ -667,10 +678,11 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         const int prank_i = bperm_i(ci, prankE);
         int tip = -1, state = 0, ch = -1, depth = 0;
         if (act) {
-            tip = fi(F_TIP, slot_i);
-            state = fi(F_STATE, slot_i);
+            const int4 g_id = fg(G_ID, slot_i);
+            tip = g_id.y;
+            state = g_id.w;
             depth = fi(F_DEPTH, slot_i);
-            if (ck > 0) ch = fi(F_CHILD0 + ck - 1, slot_i);
+            if (ck > 0) ch = F[kid_off + (slot_i << 2)];
         }
         // is the child a beam entry already?  (then the extension is folded into that entry's own candidate)
         bool ch_inbeam = false;
@@ -810,17 +822,12 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
         const bool can = is_new && cid < p.cap_nodes;
         if (can) {  // add_node (tree.rs:125-145): the new node's slot
             const int l = ck - 1;
-            fi(F_NODE, nbuf) = cid;
-            fi(F_TIP, nbuf) = l;
-            fi(F_PAR, nbuf) = node;
-            fi(F_STATE, nbuf) = crf ? (int)(((int64_t)state * NL) % S) + l : 0;  // :782
-            fi(F_OFF, nbuf) = lo;
-            fi(F_END, nbuf) = hi;
-            fi(F_VFROM, nbuf) = lo;
-            fi(F_XREP, nbuf) = (!crf && node >= 0 && tip == l) ? 1 : 0;  // :512 (no collapse_repeats test there)
-            fi(F_DEPTH, nbuf) = depth + 1;
-            for (int j = 0; j < NL; ++j) fi(F_CHILD0 + j, nbuf) = -1;
-            fi(F_CHILD0 + l, slot_i) = cid;
+            fg(G_ID, nbuf) = make_int4(cid, l, node, crf ? (int)(((int64_t)state * NL) % S) + l : 0);  // :782
+            fg(G_WIN, nbuf) = make_int4(lo, hi, lo, (!crf && node >= 0 && tip == l) ? 1 : 0);  // :512 (no collapse_repeats test there)
+            fi(F_DEPTH, nbuf) = depth + 1;  // (running maximum and last label: by the lane that builds the window)
+            fg(G_KID, nbuf) = make_int4(-1, -1, -1, -1);
+            if (NL > 4) fg(G_KID + 1, nbuf) = make_int4(-1, -1, -1, -1);
+            F[kid_off + (slot_i << 2)] = cid;
         }
         FCD_S_PHASE(2)
         FCD_S_FINE(7)  // new-node slots
@@ -846,8 +853,9 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             if (work) {
                 float *my = ring(q_buf);
                 const float *prg = ring(q_ps);
-                const int p_off = q_node < 0 ? -1 : fi(F_OFF, q_ps), p_end = q_node < 0 ? root_end : fi(F_END, q_ps);
-                const int p_vfrom = q_node < 0 ? -1 : fi(F_VFROM, q_ps);
+                const int4 pw_ = fg(G_WIN, q_ps);
+                const int p_off = q_node < 0 ? -1 : pw_.x, p_end = q_node < 0 ? root_end : pw_.y;
+                const int p_vfrom = q_node < 0 ? -1 : pw_.z;
                 const float *tb = L.tile + (size_t)(q_state * N) * WC;  // crf: tip.state (:772)
                 const float *tl = L.tile + (size_t)(q_state * N + q_l + 1) * WC;
                 for (int idx = lo; idx < hi; ++idx) {
@@ -870,6 +878,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 }
                 ff(F_MX, q_buf) = mx;
                 ff(F_LLAB, q_buf) = lb;
+                ff(F_LSUM, q_buf) = sm;
                 my[slotn(lo - 1)] = kNegInf;  // the guard rows
                 my[slotn(lo - 2)] = kNegInf;
             }
@@ -896,9 +905,10 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                 q.l = q.work ? o_l : 0;
                 q.state = q.work ? o_state : 0;
                 const bool root = !q.work || o_node < 0;
-                q.p_off = root ? -1 : fi(F_OFF, q.ps);
-                q.p_end = root ? root_end : fi(F_END, q.ps);
-                q.p_vfrom = root ? -1 : fi(F_VFROM, q.ps);
+                const int4 pw_ = fg(G_WIN, q.ps < kSlots ? q.ps : 0);
+                q.p_off = root ? -1 : pw_.x;
+                q.p_end = root ? root_end : pw_.y;
+                q.p_vfrom = root ? -1 : pw_.z;
                 return q;
             };
             // The lean passes read a parent's row t - 1 (t - 2 for a repeated label) for every t in [lo, hi) straight
@@ -1000,6 +1010,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                         float *my = ring(q.buf);
                         ff(F_MX, q.buf) = mx;
                         ff(F_LLAB, q.buf) = lkeep;  // label_{hi-1}: what the odd lane combined in its last trip
+                        ff(F_LSUM, q.buf) = sm;      // sum_{hi-1}
                         my[s_m1] = kNegInf;         // the guard rows
                         my[s_m2] = kNegInf;
                     }
@@ -1100,6 +1111,7 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     if (q.work) {
                         ff(F_MX, q.buf) = mx;
                         ff(F_LLAB, q.buf) = lab;
+                        ff(F_LSUM, q.buf) = sum;
                         float *my = ring(q.buf);
                         my[slotn(lo - 1)] = kNegInf;  // the guard rows (the first group's store may have covered them)
                         my[slotn(lo - 2)] = kNegInf;
@@ -1270,24 +1282,10 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             const int p_surv = bperm_i(prc * N, surv ? 1 : 0);
             const int p_slot = bperm_i(prc * N, slot_i);
             const int p_node = bperm_i(prc * N, node);
-            if (surv && pr >= 0 && !p_surv && p_node >= 0 && !stale_in) {
-                fi(F_POFF, myslot) = fi(F_OFF, p_slot);
-                fi(F_PEND, myslot) = fi(F_END, p_slot);
-                fi(F_PVFROM, myslot) = fi(F_VFROM, p_slot);
-            }
+            if (surv && pr >= 0 && !p_surv && p_node >= 0) fg(G_PAR, myslot) = fg(G_WIN, p_slot);  // (word 3 rides along unused)
             if (stale_in) {  // (its slot's fields are all new)
                 const int l = ck - 1;
-                fi(F_NODE, myslot) = cid;
-                fi(F_TIP, myslot) = l;
-                fi(F_PAR, myslot) = node;
-                fi(F_STATE, myslot) = crf ? (int)(((int64_t)state * NL) % S) + l : 0;  // :782
-                fi(F_XREP, myslot) = (!crf && node >= 0 && tip == l) ? 1 : 0;
-                fi(F_DEPTH, myslot) = depth + 1;
-                if (!p_surv && p_node >= 0) {
-                    fi(F_POFF, myslot) = fi(F_OFF, p_slot);
-                    fi(F_PEND, myslot) = fi(F_END, p_slot);
-                    fi(F_PVFROM, myslot) = fi(F_VFROM, p_slot);
-                }
+                fg(G_ID, myslot) = make_int4(cid, l, node, crf ? (int)(((int64_t)state * NL) % S) + l : 0);  // :782
             }
         }
         // rank lanes of the next beam
@@ -1340,29 +1338,23 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
             }
         }
         if (stale_in) {
-            fi(F_OFF, myslot) = s_meta.z;
-            fi(F_END, myslot) = s_meta.w;
-            fi(F_MX, myslot) = s_aux.x;
-            fi(F_VFROM, myslot) = s_aux.y;
-            fi(F_LLAB, myslot) = s_aux.z;
-#pragma unroll
-            for (int j = 0; j < kNLMax; ++j)
-                if (j < NL) fi(F_CHILD0 + j, myslot) = s_rows[j];
+            fg(G_WIN, myslot) = make_int4(s_meta.z, s_meta.w, s_aux.y, (!crf && node >= 0 && tip == ck - 1) ? 1 : 0);
+            fg(G_VAL, myslot) = make_int4(s_aux.x, s_aux.z, depth + 1, s_aux.w);
+            fg(G_KID, myslot) = make_int4(s_rows[0], s_rows[1], s_rows[2], s_rows[3]);
+            if (NL > 4) fg(G_KID + 1, myslot) = make_int4(s_rows[4], s_rows[5], s_rows[6], -1);
         }
         FCD_S_FINE(13)  // returning nodes landed
         // ---- evictions: records, by the candidate lane whose node leaves ----
         if (ev) {
             const int s_ = myslot, nd = cid;
-            *g_meta((uint32_t)nd) = make_int4(fi(F_PAR, s_), fi(F_TIP, s_), fi(F_OFF, s_), fi(F_END, s_));
+            const int4 e_id = fg(G_ID, s_), e_win = fg(G_WIN, s_);
+            *g_meta((uint32_t)nd) = make_int4(e_id.z, e_id.y, e_win.x, e_win.y);
             if (!dead) {
-                *g_aux((uint32_t)nd) = make_int4(fi(F_MX, s_), fi(F_VFROM, s_), fi(F_LLAB, s_), 0);
-                int32_t *rw = g_rows((uint32_t)nd);
-                if (NLp == 4) {
-                    *reinterpret_cast<int4 *>(rw) = make_int4(fi(F_CHILD0, s_), NL > 1 ? fi(F_CHILD0 + 1, s_) : -1,
-                                                              NL > 2 ? fi(F_CHILD0 + 2, s_) : -1, NL > 3 ? fi(F_CHILD0 + 3, s_) : -1);
-                } else {
-                    for (int j = 0; j < NL; ++j) rw[j] = fi(F_CHILD0 + j, s_);
-                }
+                const int4 e_val = fg(G_VAL, s_);
+                *g_aux((uint32_t)nd) = make_int4(e_val.x, e_win.z, e_val.y, e_val.w);
+                int4 *rw = reinterpret_cast<int4 *>(g_rows((uint32_t)nd));  // (NLp = 4 or 8 words, 16-byte aligned)
+                rw[0] = fg(G_KID, s_);
+                if (NLp > 4) rw[1] = fg(G_KID + 1, s_);
             }
         }
         // ---- evictions: rings, 16 bytes per lane and item, four items in flight per lane (one LDS round trip for the
