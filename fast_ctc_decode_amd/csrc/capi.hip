@@ -35,7 +35,13 @@ std::atomic<int> g_tie_order{tie_order_from_env()};
 int pdq178_std_form_from_env() {
     const char *e = getenv("FCD_PDQ178_STD_FORM");
     if (!e || !*e) return 0;
-    if (e[0] >= '0' && e[0] <= '3' && !e[1]) return e[0] - '0';
+    if (e[0] >= '0' && e[0] <= '3' && !e[1]) {
+        // (said once, so that nobody compares a 1-D search under form 3 with a duplex search and wonders)
+        if (e[0] != '0')
+            fprintf(stderr, "fast_ctc_decode (fcd): FCD_PDQ178_STD_FORM=%s applies to the 1-D searches; the duplex searches replay "
+                            "form 0 only (csrc/pdq178.h)\n", e);
+        return e[0] - '0';
+    }
     fprintf(stderr, "fast_ctc_decode (fcd): FCD_PDQ178_STD_FORM=\"%s\" is not 0, 1, 2 or 3; using 0\n", e);
     return 0;
 }
@@ -295,6 +301,12 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
             if (h->retry_host && hipEventCreateWithFlags(&h->retry_ev, hipEventDisableTiming) != hipSuccess) {
                 (void)hipHostFree(h->retry_host);
                 h->retry_host = nullptr;
+            }
+            if (!h->retry_host) {  // (not silently)
+                static std::atomic<bool> said{false};
+                if (!said.exchange(true))
+                    fprintf(stderr, "fast_ctc_decode (fcd): no page-locked word for the overflow count of the wide-beam kernel's first "
+                                    "pass: the first-pass slab size will not adapt (results are unaffected)\n");
             }
         }
     }

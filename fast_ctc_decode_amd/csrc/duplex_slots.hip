@@ -40,6 +40,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "device_utils.h"
 #include "fcd_internal.h"
 #define FCD_PDQ178_FORM0_ONLY 1  // (pdq178.h: the duplex kernels replay the default std form only)
@@ -961,6 +963,8 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                     float mx = kNegInf, lkeep = kNegInf;
                     uint32_t zacc = 0xFFFFFFFFu;  // min over the trips of (dropped bits - (2^28 - 512)) mod 2^32: < 1024 = a Ziv test failed
                     float bmin = __builtin_huge_valf();  // min over the trips of |big|: below 2^-90 = exp(x) under -86 could show in big + ln_1p(exp(x))
+                    // (two copies of the trips: passes without a repeated-label child -- most -- read X with one load)
+                    auto trips = [&](auto with_rep) __attribute__((always_inline)) {
                     int i = 0;
                     for (int seg = 0; seg < 4; ++seg) {
                         const int stop_raw = seg < 3 ? first_wrap + seg : n_trips;
@@ -968,11 +972,11 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                         // fix-ups due before trip i (no pointer wraps before trip 1)
                         pa -= i == wa ? WC : 0;
                         pb -= i == wb ? WC : 0;
-                        pz -= i == wz ? WC : 0;
+                        if (with_rep.value) pz -= i == wz ? WC : 0;
                         pw -= i == ww ? WC : 0;
                         for (; i < stop; ++i) {
                             const float c_nxt = *pa;
-                            const float x_nxt = *pb + *pz;
+                            const float x_nxt = with_rep.value ? *pb + *pz : *pb + 0.0f;
                             const float b = isA ? x_cur : sm + c_cur;  // A: X_{t-1};  B: gap_{t'}
                             // ---- LogSpace::add(lb, b), exits folded ----
                             const bool ab = lb <= b;
@@ -997,15 +1001,18 @@ __global__ __launch_bounds__(64, 2) void duplex_slots_kernel(SlotParams p) {
                             sm = v;
                             mx = vmax_raw(mx, v);  // (LogSpace::max keeps the accumulator against a NaN, as v_max_f32 does)
                             lkeep = lb;
-                            const float lb_out = c_cur + v;  // label_t (even lane)
+                            const int lb_out = __float_as_int(c_cur + v);  // label_t (even lane)
                             // hand label_t to the odd lane for the next trip; the even lane keeps it
-                            lb = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(lb_out), 0xA0 /* quad_perm [0,0,2,2] */,
-                                                                            0xf, 0xf, false));
+                            lb = __int_as_float(__builtin_amdgcn_update_dpp(lb_out, lb_out, 0xA0 /* quad_perm [0,0,2,2] */, 0xf, 0xf, false));
                             c_cur = c_nxt;
                             x_cur = x_nxt;
-                            ++pa; ++pb; pz += zstep; ++pw;
+                            ++pa; ++pb; ++pw;
+                            if (with_rep.value) pz += zstep;
                         }
                     }
+                    };
+                    if (ballot(q.rep) != 0ull) trips(std::true_type{});
+                    else trips(std::false_type{});
                     if (q.work && !isA) {
                         float *my = ring(q.buf);
                         ff(F_MX, q.buf) = mx;
