@@ -4,8 +4,8 @@
 # SIMD their registers allow (512 VGPRs per SIMD lane, granules of 8, at most 8 wavefronts).
 cd "$(dirname "$0")/.."
 echo "# kernel instantiation | VGPR | SGPR | scratch bytes | LDS bytes per workgroup | instructions | wavefronts per SIMD by VGPR"
-echo "# beam_wave_kernel<N, GW, RPW, S, AMB, PROF, UNI, H16, PDQ>; beam_lane_kernel<N, RPW, AMB, CRF, PDQ>; duplex_kernel<MODE, PIN>"
-for f in beam_wave beam_lane beam_generic duplex viterbi; do
+echo "# beam_wave_kernel<N, GW, RPW, S, AMB, PROF, UNI, H16, PDQ>; beam_lane_kernel<N, RPW, AMB, CRF, PDQ>; duplex_slots_kernel<MODE, PROF>; duplex_kernel<MODE, PIN>"
+for f in beam_wave beam_lane beam_generic duplex_slots duplex viterbi; do
   tools/isa.sh fast_ctc_decode_amd/csrc/$f.o | python3 -c '
 import re, subprocess, sys
 for line in sys.stdin:
