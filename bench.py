@@ -42,7 +42,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 
 CONFIGS = {
     2: dict(beam=5, thr=0.1, batch=4096, seed=1, crf=False, kernel_prefix="beam_wave_kernel<5, 6, 2, 0",
             kernel_name="beam_wave_kernel (two reads per wavefront)", baseline="BASELINE.json configs[1]"),
-    3: dict(beam=32, thr=0.1, batch=8192, seed=2, crf=False, compare_all=True, kernel_prefix="beam_lane_kernel<5, 2",
+    3: dict(beam=32, thr=0.1, batch=8192, seed=2, crf=False, compare_all=True, overlap=4, kernel_prefix="beam_lane_kernel<5, 2",
             kernel_name="beam_lane_kernel (one beam entry per lane, two reads per wavefront)",
             baseline="BASELINE.json configs[2]: 64k reads sharded over 8 GPUs = 8192 per rank"),
     4: dict(beam=5, thr=0.0, batch=4096, seed=3, crf=True, kernel_prefix="beam_wave_kernel<5, 6, 2, 4",
@@ -511,6 +511,11 @@ def main():
                     help="0 auto, 1 generic (LDS), 2 wave (two reads/wavefront), 3 wave (one read/wavefront), 4 lane")
     ap.add_argument("--no-viterbi", action="store_true", help="skip the secondary viterbi roofline leg")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-numpy -> Python objects leg")
+    ap.add_argument("--overlap", type=int, default=None,
+                    help="fcd_set_overlap (include/fcd.h): successive steps go round-robin to this many INTERNAL streams of "
+                         "the one handle and share its one tree arena, so that the stragglers of a step (reads that tie at "
+                         "every step) run under the next steps; 0 = every step in stream order.  Default: 4 for --config 3 "
+                         "(the wide-beam kernel), 0 otherwise")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue successive steps round-robin on this many HIP streams (each with its own "
                          "handle and tree arena) so that independent batches overlap on the GPU; 1 = strictly "
@@ -579,6 +584,11 @@ def main():
     n_streams = max(1, args.streams)
     handles = [nat.default_handle(local_rank)] + [nat.Handle(local_rank) for _ in range(n_streams - 1)]
     streams = [torch.cuda.current_stream(dev)] + [torch.cuda.Stream(dev) for _ in range(n_streams - 1)]
+    overlap = cfg.get("overlap", 0) if args.overlap is None else max(0, args.overlap)
+    if n_streams > 1 or overlap < 2 or cfg["crf"]:
+        overlap = 0
+    if overlap:
+        handles[0].set_overlap(overlap)
     step_no = [0]
     # The gather of step i (RCCL over xGMI, the out_len-prefixed payload packed on the GPU: ~6 KB per read into
     # rank 0) runs on its own HIP stream and overlaps the search of step i+1.  Sizing the payload reads two
@@ -595,7 +605,10 @@ def main():
 
     def gather(prev):
         r, ev = prev
-        comm_stream.wait_event(ev)
+        if overlap:  # (the search sits on one of the handle's internal streams: the comm stream waits for those)
+            handles[0].overlap_join(comm_stream.cuda_stream)
+        else:
+            comm_stream.wait_event(ev)
         with torch.cuda.stream(comm_stream):
             for tns in (r.labels, r.path, r.out_len, r.status):
                 tns.record_stream(comm_stream)
@@ -609,6 +622,8 @@ def main():
     def step():
         s = step_no[0] % n_streams
         step_no[0] += 1
+        if overlap and comm_stream is not None:
+            flush()  # (overlap_join waits for every call made so far: the previous step's gather goes first)
         with torch.cuda.stream(streams[s]):
             r = search(s)
             if distributed and comm_stream is None:
@@ -621,9 +636,14 @@ def main():
             pending[0] = (r, ev)
         return r
 
+    def join():
+        if overlap:
+            handles[0].overlap_join()  # torch's current stream waits for the internal streams (and the kept tensors go)
+
     for _ in range(args.warmup):
         r = step()
     flush()
+    join()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -631,6 +651,7 @@ def main():
     if args.warmup == 0:
         step()
         flush()
+        join()
     torch.cuda.synchronize()
     for hh in handles:
         hh.timing_reset()
@@ -638,6 +659,7 @@ def main():
     for _ in range(args.steps):
         r = step()
     flush()  # K searches and K gathers inside the timed region
+    join()
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
@@ -650,6 +672,16 @@ def main():
     tm = [hh.timing_mean_ms() for hh in handles]
     k_calls = sum(n for _, n in tm)
     k_ms = sum(ms * n for ms, n in tm) / max(k_calls, 1)
+
+    # overlapping steps share the chip, so a launch's own duration above is longer than a launch alone: time that too
+    single_ms = None
+    if overlap:
+        handles[0].set_overlap(0)
+        handles[0].timing_reset()
+        for _ in range(min(args.steps, 4)):
+            search(0)
+        torch.cuda.synchronize()
+        single_ms = handles[0].timing_mean_ms()[0]
 
     t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     per_rank = [None]
@@ -708,7 +740,7 @@ def main():
                 alt_ms, alt_calls = handles[0].timing_mean_ms()
                 other_order = {"tie_order": alt, "kernel_ms": alt_ms, "launches_timed": alt_calls,
                                "reads_per_s_by_kernel_time": B / (alt_ms * 1e-3),
-                               "this_order_reads_per_s_by_kernel_time": B / (k_ms * 1e-3)}
+                               "this_order_reads_per_s_by_kernel_time": B / ((single_ms or k_ms) * 1e-3)}
             except Exception as e:  # never at the price of the bench line
                 other_order = {"error": str(e)}
             finally:
@@ -761,6 +793,8 @@ def main():
                 "kernel": cfg["kernel_name"] if args.kernel == 0 else
                           {1: "generic-lds", 2: "wave-registers-2reads", 3: "wave-registers-1read", 4: "lane"}[args.kernel],
                 "reads_ok": ok, "mean_labels_per_read": mean_L, "streams": n_streams,
+                # fcd_set_overlap: steps round-robin on internal streams of ONE handle with ONE tree arena (slab_pool.h)
+                "overlap": overlap,
                 "tie_instrument": ties,
                 "tie_order": fcd.tie_order(),  # include/fcd.h FCD_TIE_*: pdq178 = Rust 1.78's sort_unstable_by (default)
                 "other_tie_order": other_order,
@@ -781,6 +815,13 @@ def main():
                 "secondary_bound": valu if valu is not None else {
                     "bound": "valu_issue", "achieved": None, "peak": simds * 2.4e9 / 2.0,
                     "note": "no SQ counter summary of this kernel / shape on the current kernel sources under profiles/"},
+                # --overlap: `kernel_ms` is a launch's duration while it shares the chip with the launches of the other
+                # internal streams; what the chip sustains is a launch per `sustained_ms_per_launch`
+                "overlap": None if not overlap else {
+                    "streams": overlap, "sustained_ms_per_launch": elapsed / args.steps * 1e3,
+                    "achieved_sustained": B * bytes_per_read / (elapsed / args.steps) / 1e9,
+                    "single_launch_ms": single_ms,
+                    "single_launch_reads_per_s": B / (single_ms * 1e-3) if single_ms else None},
                 "wavefronts_per_simd": B / rpw / simds,
                 # (what the instantiation RESERVES: registers, LDS and the resident wavefronts per SIMD they allow)
                 "occupancy": occupancy,

@@ -23,7 +23,7 @@ TIE_DEFAULT, TIE_PDQ178, TIE_STABLE = -1, 0, 1
 # list AND against the header text)
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
-    "fcd_synchronize", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
+    "fcd_synchronize", "fcd_set_overlap", "fcd_overlap_join", "fcd_overlap_join_stream", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
     "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev", "fcd_debug_pdq178_coop_sort_dev", "fcd_debug_pdq178_coop_profile",
     "fcd_debug_set_pdq178_std_form", "fcd_debug_get_pdq178_std_form",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile", "fcd_debug_set_duplex_kernel",
@@ -117,6 +117,9 @@ def bind(lib):
     lib.fcd_destroy.argtypes = [P]
     lib.fcd_set_stream.argtypes = [P, P]
     lib.fcd_reset_stream.argtypes = [P]
+    lib.fcd_set_overlap.argtypes = [P, i32]
+    lib.fcd_overlap_join.argtypes = [P]
+    lib.fcd_overlap_join_stream.argtypes = [P, P]
     lib.fcd_synchronize.argtypes = [P]
     lib.fcd_last_error.argtypes = [P]
     lib.fcd_last_error.restype = C.c_char_p
@@ -210,6 +213,8 @@ class Handle:
                 "fcd_create(device=%d) failed with %d: no usable gfx950 device -- this library has "
                 "no CPU fallback" % (device, rc))
         self.device = int(device)
+        self.overlap = 0       # set_overlap
+        self._inflight = []    # tensors of overlapping calls not joined yet (api._torch_call)
 
     def check(self, rc):
         if rc != OK:
@@ -225,6 +230,23 @@ class Handle:
 
     def synchronize(self):
         self.check(self.lib.fcd_synchronize(self.ptr))
+        self._inflight = []
+
+    def set_overlap(self, streams):
+        """include/fcd.h, fcd_set_overlap: wide-beam device calls go round-robin to `streams` internal streams (2 .. 8),
+        each behind the handle's stream as it stood at the call and not behind one another -- the stragglers of a batch
+        run under the next batches.  Results are complete after overlap_join() / synchronize(); 0 = stream order."""
+        self.check(self.lib.fcd_set_overlap(self.ptr, int(streams)))
+        self.overlap = int(streams) if int(streams) >= 2 else 0
+        self._inflight = []
+
+    def overlap_join(self, stream_ptr=None):
+        """The handle's stream (stream_ptr=None) or the given hipStream_t waits for every overlapping call made so far."""
+        if stream_ptr is None:
+            self.check(self.lib.fcd_overlap_join(self.ptr))
+            self._inflight = []  # (later work on that stream is ordered behind them: the caching allocator may reuse them)
+        else:
+            self.check(self.lib.fcd_overlap_join_stream(self.ptr, C.c_void_p(stream_ptr)))
 
     def last_kernel_ms(self):
         return float(self.lib.fcd_last_kernel_ms(self.ptr))

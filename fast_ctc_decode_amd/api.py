@@ -748,6 +748,14 @@ class BatchResult:
         self.ambiguous = ambiguous
 
     def cpu(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and h.overlap and not isinstance(self.labels, np.ndarray):
+            # the search may have run on one of the handle's internal streams (Handle.set_overlap): the copies below
+            # are issued on torch's current stream, which waits for every overlapping call first
+            import torch
+            h.set_stream(torch.cuda.current_stream(self.labels.device).cuda_stream)
+            h.overlap_join()
+
         def c(a):
             return a if a is None or isinstance(a, np.ndarray) else a.cpu().numpy()
         return BatchResult(c(self.labels), c(self.path), c(self.out_len), c(self.status), c(self.qual),
@@ -841,6 +849,10 @@ def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path
     r = BatchResult(labels, path, out_len, status, qual, amb)
     r._handle = h
     r._keep = (x, lengths)
+    if h.overlap:
+        # Handle.set_overlap: the call may still run on an internal stream when these tensors lose their last
+        # reference -- the handle keeps them until the next overlap_join() (BatchResult.cpu() joins by itself)
+        h._inflight.append((r._keep, labels, path, qual, out_len, status, amb))
     return r
 
 

@@ -37,6 +37,7 @@
 #define FCD_WAVE_PROF 1
 #endif
 #include "pdq178_wave.h"
+#include "slab_pool.h"
 
 namespace fcd {
 
@@ -213,22 +214,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
     const int dt = p.in.dtype;
     const float *post = post_at(p.in.post, r * p.in.stride_read, dt);
     const int64_t st_t = p.in.stride_t, st_n = p.in.stride_n, st_s = p.in.stride_s;
-    int64_t slab = has_read ? local : 0;
-    if (RPW == 1 && p.arena.retry_counter) {
+    const bool retry = RPW == 1 && p.arena.retry_counter;
+    if (retry) {
         // retry pass (capi.hip): the first pass ran in slabs sized for the usual tree; a read that outgrew its
         // slab was stopped with FCD_ST_INTERNAL and is decoded again here, in a slab that holds the worst case
         const bool mine = has_read && p.out.status[r] == FCD_ST_INTERNAL;  // wave-uniform: one read per wavefront
-        int slot = -1;
-        if (mine && lane == 0) slot = atomicAdd(p.arena.retry_counter, 1);
-        slot = __builtin_amdgcn_readfirstlane(slot);
-        if (!mine || slot >= p.arena.retry_slots) return;  // (left over: the host runs another round)
-        slab = slot;
+        if (!mine) return;
+        if (lane == 0) atomicAdd(p.arena.retry_counter, 1);  // (how many did: it steers the sizing of later jobs)
     }
     // Arena addressing: a wave-uniform base (the slab of the wavefront's first read: scalar registers) plus a
     // 32-bit BYTE offset per lane (the second read's slab starts cap_nodes elements further on; a pair of slabs
-    // stays below 4 GiB: cap_nodes < 2^23), so that no tree access needs 64-bit vector arithmetic.
+    // stays below 4 GiB: cap_nodes < 2^23), so that no tree access needs 64-bit vector arithmetic.  Large jobs
+    // take their (pair of) slab(s) from the device-side pool and hand it back after the traceback (slab_pool.h).
     const int cap = (int)p.arena.cap_nodes;
-    const int64_t wslab = (RPW == 1 && p.arena.retry_counter) ? slab : (int64_t)blockIdx.x * RPW;
+    const int pool_id = p.arena.pool ? slab_pool::pop(p.arena.pool, lane) : 0;
+    const int64_t wslab = p.arena.pool ? (int64_t)pool_id * RPW : (int64_t)blockIdx.x * RPW;
     char *const rec_w = reinterpret_cast<char *>(p.arena.rec + wslab * p.arena.cap_nodes);
     char *const jmp_w = reinterpret_cast<char *>(p.arena.jmp + wslab * p.arena.cap_nodes);
     char *const rows_w = reinterpret_cast<char *>(p.arena.rows + wslab * p.arena.cap_nodes * RW);
@@ -1052,11 +1052,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4))) void be
         h0 = nh;
         d0 = nd;
     }
+    if (p.arena.pool) slab_pool::push(p.arena.pool, pool_id, lane);
 }
 
 template <int N, bool AMB, bool CRF, bool PDQ>
 hipError_t launch_nap(const LaneParams &p, int64_t n_reads, hipStream_t stream) {
-    if (p.a.beam_size <= 32 && !p.arena.retry_counter) {  // two reads per wavefront
+    if (beam_lane_reads_per_wave(p.a.beam_size) == 2 && !p.arena.retry_counter) {  // two reads per wavefront
         hipLaunchKernelGGL((beam_lane_kernel<N, 2, AMB, CRF, PDQ>), dim3((unsigned)((n_reads + 1) / 2)), dim3(64), 0, stream, p);
     } else {
         hipLaunchKernelGGL((beam_lane_kernel<N, 1, AMB, CRF, PDQ>), dim3((unsigned)n_reads), dim3(64), 0, stream, p);
@@ -1091,6 +1092,64 @@ hipError_t lane_tie_prof_read(unsigned long long *out16, bool reset) {
     for (int i = 0; i < 16; ++i) out16[i] = 0;
     return hipSuccess;
 #endif
+}
+
+// ---- the device-side slab pool (slab_pool.h): how many wavefronts of an instantiation the chip holds, and the ring's set-up
+namespace {
+template <int N, bool AMB, bool CRF, bool PDQ>
+const void *kernel_nap(int rpw) {
+    return rpw == 2 ? reinterpret_cast<const void *>(&beam_lane_kernel<N, 2, AMB, CRF, PDQ>)
+                    : reinterpret_cast<const void *>(&beam_lane_kernel<N, 1, AMB, CRF, PDQ>);
+}
+template <int N, bool CRF>
+const void *kernel_n(int rpw, bool amb, bool pdq) {
+    if (amb) return pdq ? kernel_nap<N, true, CRF, true>(rpw) : kernel_nap<N, true, CRF, false>(rpw);
+    return pdq ? kernel_nap<N, false, CRF, true>(rpw) : kernel_nap<N, false, CRF, false>(rpw);
+}
+__global__ void slab_pool_init_kernel(unsigned long long *pool, int slabs) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i == 0) {
+        pool[0] = 0ull;                          // pop tickets
+        pool[1] = (unsigned long long)slabs;     // push tickets: the ring starts full, generation 0
+        pool[2] = (unsigned long long)slabs;
+    }
+    if (i < slabs) reinterpret_cast<uint32_t *>(pool + slab_pool::kHeaderWords)[i] = (uint32_t)i;
+}
+}  // namespace
+
+int beam_lane_reads_per_wave(int beam_size) { return beam_size <= 32 ? 2 : 1; }
+
+int beam_lane_resident_waves(int beam_size, int N, int crf, bool first_pass, bool ambiguous, int tie_order) {
+#ifdef FCD_HIPEMU
+    (void)beam_size, (void)N, (void)crf, (void)first_pass, (void)ambiguous, (void)tie_order;
+    return 3;  // (blocks run one after the other there: a small pool makes every later block reuse a slab)
+#else
+    const int rpw = first_pass ? beam_lane_reads_per_wave(beam_size) : 1;
+    const bool pdq = tie_order == FCD_TIE_PDQ178;
+    const void *k = nullptr;
+    if (crf) k = kernel_n<5, true>(rpw, ambiguous, pdq);
+    else switch (N) {
+        case 2: k = kernel_n<2, false>(rpw, ambiguous, pdq); break;
+        case 3: k = kernel_n<3, false>(rpw, ambiguous, pdq); break;
+        case 4: k = kernel_n<4, false>(rpw, ambiguous, pdq); break;
+        case 5: k = kernel_n<5, false>(rpw, ambiguous, pdq); break;
+        case 6: k = kernel_n<6, false>(rpw, ambiguous, pdq); break;
+        case 7: k = kernel_n<7, false>(rpw, ambiguous, pdq); break;
+        case 8: k = kernel_n<8, false>(rpw, ambiguous, pdq); break;
+    }
+    int dev = 0, cus = 0, per_cu = 0;
+    if (!k || hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64, 0) != hipSuccess || per_cu < 1 || cus < 1)
+        return 256 * 4 * 8;  // (every wave slot of the chip)
+    return cus * per_cu;
+#endif
+}
+
+hipError_t slab_pool_init(unsigned long long *pool, int slabs, hipStream_t stream) {
+    if (slabs < 1 || slabs > slab_pool::kMaxSlabs) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(slab_pool_init_kernel, dim3((unsigned)((slabs + 255) / 256)), dim3(256), 0, stream, pool, slabs);
+    return hipGetLastError();
 }
 
 bool beam_lane_supported(int beam_size, int N, int crf, int S) {

@@ -12,6 +12,7 @@
 
 #include "fcd_internal.h"
 #include "glibc235_math.h"
+#include "slab_pool.h"
 
 using namespace fcd;
 
@@ -56,7 +57,7 @@ hipError_t apply_pdq178_std_form(int bits) {
     return e;
 }
 
-constexpr int64_t kMaxRetryRounds = 4;  // lane kernel, two-pass sizing: retry rounds enqueued without asking (beam_dev)
+constexpr int kRetrySlabs = 256;  // lane kernel, two-pass sizing: worst-case slabs of the retry pass (its wavefronts wait for one)
 
 #define FCD_HIP(h, expr)                                                          \
     do {                                                                          \
@@ -157,7 +158,8 @@ ResultDesc to_desc(const fcd_result *o) {
 struct Timer {
     fcd_handle *h;
     int slot;
-    explicit Timer(fcd_handle *hh) : h(hh) {
+    hipStream_t st;
+    explicit Timer(fcd_handle *hh, hipStream_t on = nullptr, bool given = false) : h(hh), st(given ? on : hh->stream) {
         slot = (int)(h->n_timed % fcd_handle::kTimingRing);
         if ((int)h->ev0.size() <= slot) {
             hipEvent_t a = nullptr, b = nullptr;
@@ -166,10 +168,10 @@ struct Timer {
             h->ev0.push_back(a);
             h->ev1.push_back(b);
         }
-        (void)hipEventRecord(h->ev0[slot], h->stream);
+        (void)hipEventRecord(h->ev0[slot], st);
     }
     void stop() {
-        (void)hipEventRecord(h->ev1[slot], h->stream);
+        (void)hipEventRecord(h->ev1[slot], st);
         h->n_timed++;
     }
 };
@@ -178,7 +180,102 @@ int64_t workspace_budget(fcd_handle *h) {
     if (h->ws_limit > 0) return h->ws_limit;
     size_t free_b = 0, total_b = 0;
     if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) return 8ll << 30;
-    return (int64_t)((free_b + h->arena_bytes) / 2);
+    return (int64_t)((free_b + h->arena_bytes + h->pool_arena_bytes) / 2);
+}
+
+// ---- fcd_set_overlap: wide-beam calls on internal streams ----
+// every internal stream's work is finished (host wait)
+int overlap_drain(fcd_handle *h) {
+    for (int s = 0; s < fcd_handle::kMaxOverlap; ++s) {
+        if (!h->ov_stream[s]) continue;
+        FCD_HIP(h, hipStreamSynchronize(h->ov_stream[s]));
+        h->ov_ranges[s].clear();
+        h->ov_used[s] = false;
+    }
+    return FCD_OK;
+}
+
+// `stream` waits for every call enqueued on the internal streams so far
+int overlap_join(fcd_handle *h, hipStream_t stream) {
+    for (int s = 0; s < fcd_handle::kMaxOverlap; ++s)
+        if (h->ov_stream[s] && h->ov_used[s]) FCD_HIP(h, hipStreamWaitEvent(stream, h->ov_last[s], 0));
+    return FCD_OK;
+}
+
+// `S` (internal stream `own_slot`, or the handle's stream: -1) waits for every overlapping call in flight that writes any
+// of the output arrays of a call about to be enqueued on it; `mine` receives those arrays' address ranges.
+int overlap_order_behind(fcd_handle *h, hipStream_t S, int own_slot, const ResultDesc &o, int64_t n_reads,
+                         fcd_handle::Range mine[6], int *n_mine_out) {
+    int n_mine = 0;
+    auto add = [&](const void *ptr, size_t bytes) {
+        if (ptr && bytes) mine[n_mine++] = {reinterpret_cast<uintptr_t>(ptr), reinterpret_cast<uintptr_t>(ptr) + bytes};
+    };
+    const size_t rows = (size_t)n_reads * (size_t)o.out_stride;
+    add(o.labels, rows);
+    add(o.path, rows * 4);
+    add(o.qual, rows * 4);
+    add(o.out_len, (size_t)n_reads * 4);
+    add(o.status, (size_t)n_reads * 4);
+    add(o.ambiguous, (size_t)n_reads * 8);
+    *n_mine_out = n_mine;
+    for (int s = 0; s < fcd_handle::kMaxOverlap; ++s) {
+        if (!h->ov_stream[s] || !h->ov_used[s]) continue;
+        if (hipEventQuery(h->ov_last[s]) == hipSuccess) {  // nothing in flight there any more
+            h->ov_ranges[s].clear();
+            h->ov_used[s] = false;
+            continue;
+        }
+        if (s == own_slot) continue;  // (stream order)
+        bool clash = false;
+        for (const fcd_handle::Range &r : h->ov_ranges[s])
+            for (int k = 0; k < n_mine && !clash; ++k) clash = r.lo < mine[k].hi && mine[k].lo < r.hi;
+        if (clash) FCD_HIP(h, hipStreamWaitEvent(S, h->ov_last[s], 0));
+    }
+    return FCD_OK;
+}
+
+// every entry point that writes an fcd_result in the handle's stream: behind the overlapping calls that write it too
+int overlap_order_writer(fcd_handle *h, const fcd_result *out, int64_t n_reads) {
+    bool any = false;
+    for (int s = 0; s < fcd_handle::kMaxOverlap; ++s) any = any || h->ov_used[s];
+    if (!any) return FCD_OK;
+    fcd_handle::Range mine[6];
+    int n_mine = 0;
+    return overlap_order_behind(h, h->stream, -1, to_desc(out), n_reads, mine, &n_mine);
+}
+
+// The stream of the next overlapping call: behind the handle's stream as it stands now, and behind every call in flight
+// that writes any of this call's output arrays.
+int overlap_begin(fcd_handle *h, const ResultDesc &o, int64_t n_reads, int *slot_out) {
+    const int n = std::min(h->overlap_n, (int)fcd_handle::kMaxOverlap);
+    if (!h->ov_fork) FCD_HIP(h, hipEventCreateWithFlags(&h->ov_fork, hipEventDisableTiming));
+    for (int s = 0; s < n; ++s) {
+        if (h->ov_stream[s]) continue;
+        // The internal streams are created in the HIGH priority class: the runtime hands out the hardware queues of
+        // a class separately, so they get queues of their own whatever the process's other streams occupy (normal
+        // streams beyond GPU_MAX_HW_QUEUES = 4 share queues, and kernels that share a queue run one after the other:
+        // 262 k reads/s instead of 320 k on BASELINE config 3, profiles/r06v_*).  FCD_OVERLAP_PRIORITY=normal|low: A/B.
+        const char *pr = getenv("FCD_OVERLAP_PRIORITY");
+        int least = 0, greatest = 0;
+        const bool ranged = hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess;
+        if (ranged && (!pr || !strcmp(pr, "high") || !strcmp(pr, "low")))
+            FCD_HIP(h, hipStreamCreateWithPriority(&h->ov_stream[s], hipStreamNonBlocking, (pr && !strcmp(pr, "low")) ? least : greatest));
+        else
+            FCD_HIP(h, hipStreamCreateWithFlags(&h->ov_stream[s], hipStreamNonBlocking));
+        FCD_HIP(h, hipEventCreateWithFlags(&h->ov_last[s], hipEventDisableTiming));
+    }
+    const int slot = (int)(h->ov_seq % (uint64_t)n);
+    hipStream_t S = h->ov_stream[slot];
+    FCD_HIP(h, hipEventRecord(h->ov_fork, h->stream));
+    FCD_HIP(h, hipStreamWaitEvent(S, h->ov_fork, 0));
+    fcd_handle::Range mine[6];
+    int n_mine = 0;
+    int rc = overlap_order_behind(h, S, slot, o, n_reads, mine, &n_mine);
+    if (rc) return rc;
+    for (int k = 0; k < n_mine; ++k) h->ov_ranges[slot].push_back(mine[k]);
+    h->ov_used[slot] = true;
+    *slot_out = slot;
+    return FCD_OK;
 }
 
 // Shared driver of search::beam_search and search::crf_beam_search on device buffers.
@@ -254,9 +351,10 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     // times what trees actually grow to (172 k of 512 k nodes per read at beam 32) and
     // would reserve 117 GB for BASELINE config 3's 8192 reads.  The lane kernel therefore runs in slabs of HALF
     // the worst case; a read that outgrows its slab is stopped (FCD_ST_INTERNAL) and decoded again by a retry
-    // pass in worst-case slabs carved out of the SAME arena (stream order: the first pass has finished with it,
-    // results are already traced back).  The retry rounds are enqueued unconditionally (see below): the entry point
-    // never waits for the device.  Used only when the worst-case arena would exceed 8 GiB (or the workspace limit).
+    // pass in worst-case slabs (stream order: the first pass has finished, results are already traced back).  The
+    // retry pass is enqueued unconditionally (see below): the entry point never waits for the device.  Used only
+    // when the worst-case arena would exceed 8 GiB (or the workspace limit) -- and then the slabs of both passes are
+    // handed out on the device (slab_pool.h), as many as the chip holds wavefronts, whatever the size of the job.
     // A job in which more than a quarter of the reads overflow (dense posteriors: nearly every extension passes
     // the cut) makes this handle size later jobs for the worst case straight away -- one job late.
     // both register kernels keep 4-byte records (parent, label); the creation time is the upper part of the id
@@ -270,47 +368,6 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
     const bool two_pass = use_lane && (worst_total > ((size_t)8 << 30) || (int64_t)worst_total > budget);
     const int64_t cap_worst = cap_nodes;
     const size_t worst_read = (size_t)cap_worst * node_bytes + first_bytes;
-    if (two_pass && h->retry_pending && hipEventQuery(h->retry_ev) == hipSuccess) {
-        // the overflow count of an earlier job has arrived: a job in which more than a quarter of the reads outgrew
-        // their first-pass slabs makes this handle size later jobs for the worst case straight away
-        const int64_t overflowed = *reinterpret_cast<volatile int32_t *>(h->retry_host);
-        if (!h->first_pass_div_pinned && overflowed * 4 > h->retry_n) h->first_pass_div = 1;
-        h->retry_pending = false;
-    }
-    if (two_pass) {
-        cap_nodes = (cap_worst / std::max(h->first_pass_div, 1) + 63) & ~63ll;
-        per_read = (size_t)cap_nodes * node_bytes + first_bytes;
-    }
-    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
-    chunk = std::min<int64_t>(chunk, d.n_reads);
-    // the retry pass needs worst-case slabs out of the same arena: a few of them however small the job, but no more
-    // than the workspace limit allows (never less than one: a read that overflowed must be decodable)
-    const bool retry_needed = two_pass && cap_nodes < cap_worst;  // (divisor 1: the first pass IS the worst case)
-    size_t retry_floor = retry_needed ? 4 * worst_read : 0;
-    if (retry_needed && (int64_t)retry_floor > budget) retry_floor = std::max<size_t>(worst_read, (size_t)budget / worst_read * worst_read);
-    rc = ensure(h, &h->arena, &h->arena_bytes, std::max((size_t)chunk * per_read, retry_floor));
-    if (rc) return rc;
-    const int retry_slots = retry_needed ? (int)std::min<size_t>(h->arena_bytes / worst_read, 1u << 30) : 0;
-    int32_t *d_counter = nullptr;
-    if (retry_needed) {  // the overflow counters of the retry rounds have their own small allocation
-        rc = ensure(h, &h->retry_counter, &h->retry_counter_bytes, 256);
-        if (rc) return rc;
-        d_counter = reinterpret_cast<int32_t *>(h->retry_counter);
-        if (!h->retry_host) {  // (page-locked: the copy back is a DMA nobody waits for)
-            if (hipHostMalloc(&h->retry_host, 64, hipHostMallocDefault) != hipSuccess) h->retry_host = nullptr;
-            if (h->retry_host && hipEventCreateWithFlags(&h->retry_ev, hipEventDisableTiming) != hipSuccess) {
-                (void)hipHostFree(h->retry_host);
-                h->retry_host = nullptr;
-            }
-            if (!h->retry_host) {  // (not silently)
-                static std::atomic<bool> said{false};
-                if (!said.exchange(true))
-                    fprintf(stderr, "fast_ctc_decode (fcd): no page-locked word for the overflow count of the wide-beam kernel's first "
-                                    "pass: the first-pass slab size will not adapt (results are unaffected)\n");
-            }
-        }
-    }
-
     auto wave_arena = [&](char *base, int64_t slabs, int64_t cap) {
         WaveArena ar{};
         ar.cap_nodes = cap;
@@ -322,6 +379,130 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         ar.first_stride = first_stride;
         return ar;
     };
+    if (two_pass) {
+        // ---- slabs from the device-side pool (slab_pool.h): the arena is sized by what the chip holds at once, one
+        // launch takes the whole job, and calls on the overlap streams share it ----
+        if (h->retry_pending && hipEventQuery(h->retry_ev) == hipSuccess) {
+            // the overflow count of an earlier job has arrived: a job in which more than a quarter of the reads outgrew
+            // their first-pass slabs makes this handle size later jobs for the worst case straight away
+            const int64_t overflowed = *reinterpret_cast<volatile int32_t *>(h->retry_host);
+            if (!h->first_pass_div_pinned && overflowed * 4 > h->retry_n) h->first_pass_div = 1;
+            h->retry_pending = false;
+        }
+        cap_nodes = (cap_worst / std::max(h->first_pass_div, 1) + 63) & ~63ll;
+        if (cap_nodes > cap_worst) cap_nodes = cap_worst;
+        const bool retry_needed = cap_nodes < cap_worst;  // (divisor 1: the first pass IS the worst case)
+        const int rpw = beam_lane_reads_per_wave((int)beam);
+        const size_t wave_bytes = (size_t)rpw * ((size_t)cap_nodes * node_bytes + first_bytes);
+        const int64_t waves = (d.n_reads + rpw - 1) / rpw;
+        const bool amb = o.ambiguous != nullptr;
+        int64_t p1_want = std::min<int64_t>(slab_pool::kMaxSlabs, beam_lane_resident_waves((int)beam, N, a.crf, true, amb, args.tie_order));
+        if (h->overlap_n < 2) p1_want = std::min<int64_t>(p1_want, waves);  // (overlapping calls: whatever the chip holds)
+        // the retry pass: a few worst-case slabs however small the job -- never less than one: a read that overflowed
+        // must be decodable -- and no more than a quarter of the workspace limit
+        int64_t p2 = 0;
+        if (retry_needed) {
+            p2 = std::min<int64_t>(std::min<int64_t>(d.n_reads, kRetrySlabs),
+                                   beam_lane_resident_waves((int)beam, N, a.crf, false, amb, args.tie_order));
+            p2 = std::max<int64_t>(1, std::min<int64_t>(p2, budget / 4 / (int64_t)worst_read));
+        }
+        const int64_t left = budget - p2 * (int64_t)worst_read;
+        const int64_t p1 = std::max<int64_t>(1, std::min<int64_t>(p1_want, left / (int64_t)wave_bytes));
+        fcd_handle::PoolGeom &g = h->pool_geom;
+        const bool fits = h->pool_arena && g.cap_nodes == cap_nodes && g.cap_worst == cap_worst && g.first_stride == first_stride &&
+                          g.rpw == rpw && g.row_words == (NL <= 4 ? 4 : 8) && g.p1 >= p1 && g.p2 >= p2 && (g.p2 > 0) == (p2 > 0);
+        if (!fits) {
+            rc = overlap_drain(h);  // calls in flight still use the old slabs
+            if (rc) return rc;
+            FCD_HIP(h, hipStreamSynchronize(h->stream));
+            if (h->pool_arena) FCD_HIP(h, hipFree(h->pool_arena));
+            if (h->pool_ctl) FCD_HIP(h, hipFree(h->pool_ctl));
+            h->pool_arena = h->pool_ctl = nullptr;
+            h->pool_arena_bytes = h->pool_ctl_bytes = 0;
+            g = fcd_handle::PoolGeom();
+            const size_t first_region = ((size_t)p1 * wave_bytes + 255) & ~(size_t)255;
+            size_t dummy = 0;
+            rc = ensure(h, &h->pool_arena, &h->pool_arena_bytes, first_region + (size_t)p2 * worst_read);
+            if (rc) return rc;
+            rc = ensure(h, &h->pool_ctl, &dummy, slab_pool::bytes((int)p1) + slab_pool::bytes((int)std::max<int64_t>(p2, 1)));
+            if (rc) return rc;
+            h->pool_ctl_bytes = dummy;
+            unsigned long long *ring1 = reinterpret_cast<unsigned long long *>(h->pool_ctl);
+            FCD_HIP(h, slab_pool_init(ring1, (int)p1, h->stream));
+            if (p2 > 0) FCD_HIP(h, slab_pool_init(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->pool_ctl) + slab_pool::bytes((int)p1)), (int)p2, h->stream));
+            g.cap_nodes = cap_nodes;
+            g.cap_worst = cap_worst;
+            g.first_stride = first_stride;
+            g.rpw = rpw;
+            g.row_words = NL <= 4 ? 4 : 8;
+            g.p1 = (int)p1;
+            g.p2 = (int)p2;
+        }
+        int32_t *d_counter = nullptr;
+        if (retry_needed) {  // the overflow counters have their own small allocation: one per call, 64 calls round
+            rc = ensure(h, &h->retry_counter, &h->retry_counter_bytes, 256);
+            if (rc) return rc;
+            d_counter = reinterpret_cast<int32_t *>(h->retry_counter) + (h->ov_seq & 63);
+            if (!h->retry_host) {  // (page-locked: the copy back is a DMA nobody waits for)
+                if (hipHostMalloc(&h->retry_host, 64, hipHostMallocDefault) != hipSuccess) h->retry_host = nullptr;
+                if (h->retry_host && hipEventCreateWithFlags(&h->retry_ev, hipEventDisableTiming) != hipSuccess) {
+                    (void)hipHostFree(h->retry_host);
+                    h->retry_host = nullptr;
+                }
+                if (!h->retry_host) {  // (not silently)
+                    static std::atomic<bool> said{false};
+                    if (!said.exchange(true))
+                        fprintf(stderr, "fast_ctc_decode (fcd): no page-locked word for the overflow count of the wide-beam kernel's first "
+                                        "pass: the first-pass slab size will not adapt (results are unaffected)\n");
+                }
+            }
+        }
+        char *const base = reinterpret_cast<char *>(h->pool_arena);
+        const size_t first_region = ((size_t)g.p1 * wave_bytes + 255) & ~(size_t)255;
+        unsigned long long *const ring1 = reinterpret_cast<unsigned long long *>(h->pool_ctl);
+        unsigned long long *const ring2 = reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(h->pool_ctl) + slab_pool::bytes(g.p1));
+        // which stream: the handle's, or -- fcd_set_overlap -- the next internal one, behind the handle's stream as it
+        // stands now and behind whatever still writes this call's outputs
+        hipStream_t S = h->stream;
+        int slot = -1;
+        if (h->overlap_n >= 2) {
+            rc = overlap_begin(h, o, d.n_reads, &slot);
+            if (rc) return rc;
+            S = h->ov_stream[slot];
+        }
+        Timer tm(h, S, true);
+        WaveArena ar = wave_arena(base, (int64_t)g.p1 * rpw, cap_nodes);
+        ar.pool = ring1;
+        FCD_HIP(h, launch_beam_lane(d, 0, d.n_reads, args, ar, o, S));
+        if (retry_needed) {
+            // every read that overflowed is decoded again in a worst-case slab, where it cannot overflow; a wavefront of
+            // this pass that finds no slab free waits for one (the pool is a queue), so ONE launch finishes the job
+            // whatever happened in the first pass -- with nothing to do it is n wavefronts that read one status word and
+            // leave.  Nobody waits for it: this entry point stays enqueue-only.
+            WaveArena rr = wave_arena(base + first_region, g.p2, cap_worst);
+            rr.pool = ring2;
+            rr.retry_counter = d_counter;
+            FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t), S));
+            FCD_HIP(h, launch_beam_lane(d, 0, d.n_reads, args, rr, o, S));
+            // how many reads overflowed is read back ONE CALL LATE: it only steers the sizing of later jobs
+            if (h->retry_host && !h->retry_pending) {
+                FCD_HIP(h, hipMemcpyAsync(h->retry_host, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, S));
+                FCD_HIP(h, hipEventRecord(h->retry_ev, S));
+                h->retry_pending = true;
+                h->retry_n = d.n_reads;
+            }
+        }
+        tm.stop();
+        if (slot >= 0) FCD_HIP(h, hipEventRecord(h->ov_last[slot], S));
+        h->ov_seq++;
+        return FCD_OK;
+    }
+    rc = overlap_order_writer(h, out, d.n_reads);  // (fcd_set_overlap: behind the calls in flight that write these arrays)
+    if (rc) return rc;
+    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
+    chunk = std::min<int64_t>(chunk, d.n_reads);
+    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_read);
+    if (rc) return rc;
 
     Timer tm(h);
     for (int64_t begin = 0; begin < d.n_reads; begin += chunk) {
@@ -332,42 +513,6 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
             e = use_lane ? launch_beam_lane(d, begin, n, args, ar, o, h->stream)
                          : launch_beam_wave(d, begin, n, args, ar, o, h->stream);
             FCD_HIP(h, e);
-            if (retry_needed) {
-                WaveArena rr = wave_arena(reinterpret_cast<char *>(h->arena), retry_slots, cap_worst);
-                rr.retry_slots = retry_slots;
-                // Every round decodes up to retry_slots of the reads that overflowed, and a read decoded in a worst-case
-                // slab cannot overflow again: ceil(n / retry_slots) rounds finish the chunk whatever happened in the first
-                // pass (two rounds with the default sizing -- a round with nothing to do is 8192 wavefronts that read one
-                // status word and leave).  So the rounds are ENQUEUED, each with a counter of its own, and nobody waits:
-                // this entry point stays enqueue-only, and launches on other streams slide under a chunk's stragglers.
-                const int64_t rounds = (n + retry_slots - 1) / retry_slots;
-                if (rounds <= kMaxRetryRounds) {
-                    FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t) * (size_t)rounds, h->stream));
-                    for (int64_t k = 0; k < rounds; ++k) {
-                        rr.retry_counter = d_counter + k;
-                        FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
-                    }
-                    // how many reads overflowed (round 0 counts them all) is read back ONE CALL LATE: it only steers
-                    // the sizing of later jobs
-                    if (h->retry_host && !h->retry_pending) {
-                        FCD_HIP(h, hipMemcpyAsync(h->retry_host, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                        FCD_HIP(h, hipEventRecord(h->retry_ev, h->stream));
-                        h->retry_pending = true;
-                        h->retry_n = n;
-                    }
-                } else {  // (a workspace limit that leaves fewer than n / 4 worst-case slabs: count and repeat)
-                    rr.retry_counter = d_counter;
-                    for (;;) {
-                        int32_t overflowed = 0;
-                        FCD_HIP(h, hipMemsetAsync(d_counter, 0, sizeof(int32_t), h->stream));
-                        FCD_HIP(h, launch_beam_lane(d, begin, n, args, rr, o, h->stream));
-                        FCD_HIP(h, hipMemcpyAsync(&overflowed, d_counter, sizeof(int32_t), hipMemcpyDeviceToHost, h->stream));
-                        FCD_HIP(h, hipStreamSynchronize(h->stream));
-                        if (!h->first_pass_div_pinned && (int64_t)overflowed * 4 > n) h->first_pass_div = 1;
-                        if (overflowed <= retry_slots) break;
-                    }
-                }
-            }
             continue;
         } else {
             GenericArena ar;
@@ -450,7 +595,15 @@ int fcd_destroy(fcd_handle *h) {
     }
     DeviceGuard dev_guard(h->device);
     host_job_release_lanes(h, true);
+    (void)overlap_drain(h);
     (void)hipStreamSynchronize(h->stream);
+    for (int s = 0; s < fcd_handle::kMaxOverlap; ++s) {
+        if (h->ov_last[s]) (void)hipEventDestroy(h->ov_last[s]);
+        if (h->ov_stream[s]) (void)hipStreamDestroy(h->ov_stream[s]);
+    }
+    if (h->ov_fork) (void)hipEventDestroy(h->ov_fork);
+    if (h->pool_arena) (void)hipFree(h->pool_arena);
+    if (h->pool_ctl) (void)hipFree(h->pool_ctl);
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
     if (h->pin) (void)hipHostFree(h->pin);
@@ -487,8 +640,36 @@ int fcd_synchronize(fcd_handle *h) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);
     FCD_DEVICE(h);
+    int rc = overlap_drain(h);  // (fcd_set_overlap: the internal streams first)
+    if (rc) return rc;
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     return FCD_OK;
+}
+
+int fcd_set_overlap(fcd_handle *h, int streams) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (streams < 0 || streams > fcd_handle::kMaxOverlap) return fail(h, FCD_E_INVALID, "fcd_set_overlap: 0 .. 8 streams");
+    FCD_DEVICE(h);
+    // what is in flight joins the handle's stream: from here on the stream order holds again (or a new round starts)
+    int rc = overlap_join(h, h->stream);
+    if (rc) return rc;
+    h->overlap_n = streams < 2 ? 0 : streams;
+    return FCD_OK;
+}
+
+int fcd_overlap_join(fcd_handle *h) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    FCD_DEVICE(h);
+    return overlap_join(h, h->stream);
+}
+
+int fcd_overlap_join_stream(fcd_handle *h, void *hip_stream) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    FCD_DEVICE(h);
+    return overlap_join(h, reinterpret_cast<hipStream_t>(hip_stream));
 }
 
 const char *fcd_last_error(const fcd_handle *h) { return h ? h->err.c_str() : "null handle"; }
@@ -522,6 +703,15 @@ int fcd_release_workspace(fcd_handle *h) {
     FCD_HIP(h, hipStreamSynchronize(h->stream));
     if (h->own_stream && h->own_stream != h->stream) FCD_HIP(h, hipStreamSynchronize(h->own_stream));
     host_job_release_lanes(h, false);
+    {
+        int rc = overlap_drain(h);
+        if (rc) return rc;
+    }
+    if (h->pool_arena) (void)hipFree(h->pool_arena);
+    if (h->pool_ctl) (void)hipFree(h->pool_ctl);
+    h->pool_arena = h->pool_ctl = nullptr;
+    h->pool_arena_bytes = h->pool_ctl_bytes = 0;
+    h->pool_geom = fcd_handle::PoolGeom();
     if (h->arena) (void)hipFree(h->arena);
     if (h->stage) (void)hipFree(h->stage);
     if (h->lnbuf) (void)hipFree(h->lnbuf);
@@ -664,6 +854,8 @@ int fcd_viterbi_search_dev(fcd_handle *h, const fcd_batch *in, int collapse_repe
     if (rc) return rc;
     if (in->n_reads == 0) return FCD_OK;
     FCD_DEVICE(h);
+    rc = overlap_order_writer(h, out, in->n_reads);
+    if (rc) return rc;
     Timer tm(h);
     FCD_HIP(h, launch_viterbi(to_desc(in, false), collapse_repeats, to_desc(out), h->stream));
     tm.stop();
@@ -736,6 +928,8 @@ int fcd_crf_greedy_search_dev(fcd_handle *h, const fcd_batch *in, const float *i
     if (!init || n_init < 1) return fail(h, FCD_E_INVALID, "init_state missing");
     if (in->n_reads == 0) return FCD_OK;
     FCD_DEVICE(h);
+    rc = overlap_order_writer(h, out, in->n_reads);
+    if (rc) return rc;
     Timer tm(h);
     FCD_HIP(h, launch_crf_greedy(to_desc(in, true), init, n_init, init_stride, to_desc(out), h->stream));
     tm.stop();
@@ -781,6 +975,10 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     if (duplex_lds_bytes((int)beam_size, N, 0, S, effective_tie_order(h)) > 64 * 1024)
         return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
     FCD_DEVICE(h);
+    {
+        const int orc = overlap_order_writer(h, out, B);
+        if (orc) return orc;
+    }
 
     // log-space copies + one int for the envelope width
     const int64_t T1 = std::max<int64_t>(in1->T, 1), T2 = std::max<int64_t>(in2->T, 1);
@@ -1309,14 +1507,18 @@ int host_upload(fcd_handle *h, const fcd_batch *in, const fcd_result *shape, con
 // Runs the *_dev search of a staged call on h->stream.
 int host_search(fcd_handle *h, const HostStage &st, const fcd_batch *din, const HostCall &c, const fcd_result *dout) {
     const float *dinit = reinterpret_cast<const float *>(reinterpret_cast<char *>(h->stage) + st.o_init);
+    int rc = FCD_E_INVALID;
     switch (c.op) {
         case HostOp::Viterbi: return fcd_viterbi_search_dev(h, din, c.collapse, dout);
-        case HostOp::Beam: return fcd_beam_search_dev(h, din, c.beam_size, c.thr, c.collapse, c.kernel, dout);
+        case HostOp::Beam: rc = fcd_beam_search_dev(h, din, c.beam_size, c.thr, c.collapse, c.kernel, dout); break;
         case HostOp::CrfBeam:
-            return fcd_crf_beam_search_dev_k(h, din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel, dout);
+            rc = fcd_crf_beam_search_dev_k(h, din, dinit, c.n_init, c.init_stride, c.beam_size, c.thr, c.kernel, dout);
+            break;
         case HostOp::CrfGreedy: return fcd_crf_greedy_search_dev(h, din, dinit, c.n_init, c.init_stride, dout);
     }
-    return FCD_E_INVALID;
+    // (fcd_set_overlap: the search may sit on an internal stream; the download that follows is in the handle's stream)
+    if (rc == FCD_OK && h->overlap_n >= 2) rc = overlap_join(h, h->stream);
+    return rc;
 }
 
 // Copies the fixed-stride device result of a staged call into the caller's arrays and waits.

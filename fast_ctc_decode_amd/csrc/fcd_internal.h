@@ -76,9 +76,11 @@ struct WaveArena {
     int64_t cap_nodes;
     int row_words;  // 4 or 8
     // retry pass of the lane kernel (one read per wavefront): only reads whose first-pass slab overflowed
-    // (status FCD_ST_INTERNAL) run, each claiming one of retry_slots worst-case slabs through the counter
+    // (status FCD_ST_INTERNAL) run, in worst-case slabs; the counter says how many did
     int32_t *retry_counter;  // nullable
-    int retry_slots;
+    // lane kernel, large jobs: the slabs (pairs of slabs at two reads per wavefront) come from a device-side pool,
+    // taken when a wavefront starts and handed back after its traceback (slab_pool.h); null = slab i belongs to read i
+    unsigned long long *pool;
 };
 
 size_t beam_generic_lds_bytes(int beam_size, int N, int tie_order);  // (the quicksort's list and scratch only under FCD_TIE_PDQ178 above 20 candidates)
@@ -86,6 +88,10 @@ hipError_t launch_beam_generic(const BatchDesc &in, int64_t read_begin, int64_t 
                                const BeamArgs &a, const GenericArena &arena, const ResultDesc &out,
                                hipStream_t stream);
 
+int beam_lane_reads_per_wave(int beam_size);  // of a first pass (a retry pass: one)
+// wavefronts of the instantiation the current device holds at once: the size of a slab pool nobody ever waits for
+int beam_lane_resident_waves(int beam_size, int N, int crf, bool first_pass, bool ambiguous, int tie_order);
+hipError_t slab_pool_init(unsigned long long *pool, int slabs, hipStream_t stream);  // `pool`: slab_pool::bytes(slabs) of device memory
 bool beam_wave_supported(int beam_size, int N, int crf, int S);
 // node ids of the wave kernel are (time step << shift) | index among the step's new nodes: slots per step = 1 << shift
 int beam_wave_id_shift(int beam_size, int N, int force_one_read_per_wave);
@@ -258,6 +264,27 @@ struct fcd_handle {
     size_t pin_bytes = 0;
     void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
     size_t lnbuf_bytes = 0;
+    // wide-beam kernel, large jobs: slabs handed out on the device (slab_pool.h).  An allocation of its own: calls in
+    // flight on the overlap streams keep using it while other entry points size `arena` for themselves
+    void *pool_arena = nullptr;
+    size_t pool_arena_bytes = 0;
+    void *pool_ctl = nullptr;  // the two rings: first-pass (pairs of) slabs, worst-case slabs of the retry pass
+    size_t pool_ctl_bytes = 0;
+    struct PoolGeom {
+        int64_t cap_nodes = 0, cap_worst = 0, first_stride = 0;
+        int rpw = 0, row_words = 0, p1 = 0, p2 = 0;
+    } pool_geom;
+    // fcd_set_overlap: wide-beam calls go round-robin to internal streams, ordered after the handle's stream as it stood
+    // at the call and not after one another; what each stream still runs writes the output ranges listed here
+    static constexpr int kMaxOverlap = 8;
+    int overlap_n = 0;
+    hipStream_t ov_stream[kMaxOverlap] = {};
+    hipEvent_t ov_last[kMaxOverlap] = {};  // recorded behind the last call of the stream
+    bool ov_used[kMaxOverlap] = {};
+    hipEvent_t ov_fork = nullptr;
+    uint64_t ov_seq = 0;
+    struct Range { uintptr_t lo, hi; };
+    std::vector<Range> ov_ranges[kMaxOverlap];
     void *retry_counter = nullptr;  // lane kernel, two-pass sizing: overflow counter of the retry rounds
     size_t retry_counter_bytes = 0;
     void *retry_host = nullptr;     // page-locked word the first retry round's overflow count is copied to, read one call late

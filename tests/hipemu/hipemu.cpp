@@ -329,6 +329,8 @@ hipError_t hipMemsetAsync(void *dst, int v, size_t n, hipStream_t st) {
 hipError_t hipMemset(void *dst, int v, size_t n) { memset(dst, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = new hipemu_stream{t_device}; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t s) { delete s; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned f, int) { return hipStreamCreateWithFlags(s, f); }
+hipError_t hipDeviceGetStreamPriorityRange(int *least, int *greatest) { *least = 1; *greatest = -1; return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t st) { check_stream(st, "hipStreamSynchronize"); return hipSuccess; }
 hipError_t hipDeviceSynchronize() { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t *e) { *e = new hipemu_event{0.0}; return hipSuccess; }
@@ -336,6 +338,7 @@ hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { return hipEventCre
 hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 hipError_t hipEventRecord(hipEvent_t e, hipStream_t st) { check_stream(st, "hipEventRecord"); e->t_ms = now_ms(); return hipSuccess; }
 hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipStreamWaitEvent(hipStream_t st, hipEvent_t, unsigned) { check_stream(st, "hipStreamWaitEvent"); return hipSuccess; }  // (nothing is ever pending)
 hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }  // (launches run to completion: whatever was recorded has happened)
 hipError_t hipEventElapsedTime(float *ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t_ms - a->t_ms); return hipSuccess; }
 hipError_t hipGetLastError() { return hipSuccess; }

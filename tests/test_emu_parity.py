@@ -59,6 +59,10 @@ def test_lane_two_pass_retry(fcd):
     P.test_lane_two_pass_retry(fcd)
 
 
+def test_lane_overlapping_calls(fcd):
+    P.test_lane_overlapping_calls(fcd)
+
+
 def test_largest_beam_of_the_lds_kernel(fcd):
     P.test_largest_beam_of_the_lds_kernel(fcd)
 

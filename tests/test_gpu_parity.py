@@ -181,6 +181,67 @@ def test_lane_two_pass_retry(fcd):
         h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
 
 
+def test_lane_overlapping_calls(fcd):
+    """fcd_set_overlap (include/fcd.h): wide-beam calls go round-robin to internal streams and share ONE pool of tree slabs
+    handed out on the device (slab_pool.h) -- here far fewer slabs than reads, so wavefronts wait for one another's.
+    Five calls in flight on three streams must each deliver what the same call delivers in stream order; two calls
+    that write the SAME result arrays must end with the second call's results."""
+    import ctypes as C
+    import torch
+    from fast_ctc_decode_amd import _native as nat
+    xs = [gen_batch(900 + i, 9, 200 + 16 * i, 5) for i in range(5)]
+    h = nat.default_handle()
+    h.set_workspace_limit(6 << 20)  # (the shortest batch fits it whole and takes the plain path: ordered behind the others too)
+    h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 6))
+    on_gpu = torch.cuda.is_available()
+    try:
+        serial = [fcd.beam_search_batch_raw(x, 32, 0.05, True, kernel=fcd.KERNEL_LANE) for x in xs]
+        for x, r in zip(xs[:2], serial[:2]):  # (and those are the oracle's)
+            st, labels, path, _ = oracle.beam_search_raw(np.ascontiguousarray(x[0]), 32, 0.05, True)
+            assert st == 0 and int(r.out_len[0]) == len(labels)
+            np.testing.assert_array_equal(r.path[0, :len(labels)], path)
+        h.set_overlap(3)
+        if on_gpu:
+            xt = [torch.from_numpy(x).cuda() for x in xs]
+            rs = [fcd.beam_search_batch_raw(t, 32, 0.05, True, kernel=fcd.KERNEL_LANE) for t in xt]
+            outs = [r.cpu() for r in rs]
+        else:  # (the emulator: host arrays in, the staged call joins before it copies back)
+            outs = [fcd.beam_search_batch_raw(x, 32, 0.05, True, kernel=fcd.KERNEL_LANE) for x in xs]
+        for a, b in zip(outs, serial):
+            np.testing.assert_array_equal(a.status, b.status)
+            np.testing.assert_array_equal(a.out_len, b.out_len)
+            for i in range(len(a.out_len)):
+                n = int(a.out_len[i])
+                np.testing.assert_array_equal(a.labels[i, :n], b.labels[i, :n])
+                np.testing.assert_array_equal(a.path[i, :n], b.path[i, :n])
+        if on_gpu:
+            # the same result arrays twice: the second call is ordered behind the first although it sits on another stream
+            B, w = xs[0].shape[0], max(x.shape[1] for x in xs)
+            labels = torch.zeros((B, w), dtype=torch.uint8, device="cuda")
+            path = torch.zeros((B, w), dtype=torch.int32, device="cuda")
+            out_len = torch.zeros(B, dtype=torch.int32, device="cuda")
+            status = torch.zeros(B, dtype=torch.int32, device="cuda")
+            res = nat.Result(labels.data_ptr(), path.data_ptr(), None, out_len.data_ptr(), status.data_ptr(), w, None)
+            h.set_stream(torch.cuda.current_stream().cuda_stream)
+            for order in ((4, 1), (4, 3), (4, 4, 0), (3, 4, 2)):  # (the longest reads first: their call would finish last)
+                for k in order:
+                    t = xt[k]
+                    st_ = t.stride()
+                    b = nat.Batch(t.data_ptr(), t.shape[0], t.shape[1], 1, 5, st_[0], st_[1], 0, st_[2], None, nat.DTYPE_F32)
+                    h.check(h.lib.fcd_beam_search_dev(h.ptr, C.byref(b), 32, 0.05, 1, fcd.KERNEL_LANE, C.byref(res)))
+                h.overlap_join()
+                torch.cuda.synchronize()
+                want = serial[order[-1]]
+                np.testing.assert_array_equal(out_len.cpu().numpy(), want.out_len)
+                for i in range(B):
+                    n = int(want.out_len[i])
+                    np.testing.assert_array_equal(path[i, :n].cpu().numpy(), want.path[i, :n])
+    finally:
+        h.set_overlap(0)
+        h.set_workspace_limit(0)
+        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
 def test_beam_thr0(fcd, collapse, kernel):
