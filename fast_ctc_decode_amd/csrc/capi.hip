@@ -244,6 +244,10 @@ int overlap_order_writer(fcd_handle *h, const fcd_result *out, int64_t n_reads) 
     return overlap_order_behind(h, h->stream, -1, to_desc(out), n_reads, mine, &n_mine);
 }
 
+// an entry point about to use the handle's arena from its start, in the handle's stream: behind every overlapping call in
+// flight (they hold regions of it) -- which also covers the calls that write its output arrays
+int arena_exclusive(fcd_handle *h, const fcd_result *, int64_t) { return overlap_join(h, h->stream); }
+
 // The stream of the next overlapping call: behind the handle's stream as it stands now, and behind every call in flight
 // that writes any of this call's output arrays.
 int overlap_begin(fcd_handle *h, const ResultDesc &o, int64_t n_reads, int *slot_out) {
@@ -497,34 +501,57 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         h->ov_seq++;
         return FCD_OK;
     }
-    rc = overlap_order_writer(h, out, d.n_reads);  // (fcd_set_overlap: behind the calls in flight that write these arrays)
-    if (rc) return rc;
-    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_read);
+    // fcd_set_overlap: the call goes to the next internal stream and has a region of the arena to itself (calls on the
+    // same internal stream follow one another, so do their uses of its region)
+    const int regions = h->overlap_n >= 2 ? std::min(h->overlap_n, (int)fcd_handle::kMaxOverlap) : 1;
+    int64_t chunk = std::max<int64_t>(1, budget / regions / (int64_t)per_read);
     chunk = std::min<int64_t>(chunk, d.n_reads);
-    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_read);
-    if (rc) return rc;
+    size_t region = (size_t)chunk * per_read;
+    hipStream_t S = h->stream;
+    int slot = -1;
+    if (regions > 1) {
+        region = (region + 255) & ~(size_t)255;
+        if (region > h->arena_region || h->arena_bytes < (size_t)regions * h->arena_region) {
+            rc = overlap_drain(h);  // (calls in flight count on the old regions)
+            if (rc) return rc;
+            rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)regions * region);
+            if (rc) return rc;
+            h->arena_region = region;
+        }
+        rc = overlap_begin(h, o, d.n_reads, &slot);
+        if (rc) return rc;
+        S = h->ov_stream[slot];
+    } else {
+        rc = arena_exclusive(h, out, d.n_reads);
+        if (rc) return rc;
+        rc = ensure(h, &h->arena, &h->arena_bytes, region);
+        if (rc) return rc;
+    }
+    char *const abase = reinterpret_cast<char *>(h->arena) + (slot >= 0 ? (size_t)slot * h->arena_region : 0);
 
-    Timer tm(h);
+    Timer tm(h, S, true);
     for (int64_t begin = 0; begin < d.n_reads; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, d.n_reads - begin);
         hipError_t e;
         if (use_wave || use_lane) {
-            const WaveArena ar = wave_arena(reinterpret_cast<char *>(h->arena), chunk, cap_nodes);
-            e = use_lane ? launch_beam_lane(d, begin, n, args, ar, o, h->stream)
-                         : launch_beam_wave(d, begin, n, args, ar, o, h->stream);
+            const WaveArena ar = wave_arena(abase, chunk, cap_nodes);
+            e = use_lane ? launch_beam_lane(d, begin, n, args, ar, o, S) : launch_beam_wave(d, begin, n, args, ar, o, S);
             FCD_HIP(h, e);
             continue;
         } else {
             GenericArena ar;
             ar.cap_nodes = cap_nodes;
-            ar.rec = reinterpret_cast<int4 *>(h->arena);
-            ar.rows = reinterpret_cast<int32_t *>(reinterpret_cast<char *>(h->arena) +
-                                                  (size_t)chunk * cap_nodes * sizeof(int4));
-            e = launch_beam_generic(d, begin, n, args, ar, o, h->stream);
+            ar.rec = reinterpret_cast<int4 *>(abase);
+            ar.rows = reinterpret_cast<int32_t *>(abase + (size_t)chunk * cap_nodes * sizeof(int4));
+            e = launch_beam_generic(d, begin, n, args, ar, o, S);
         }
         FCD_HIP(h, e);
     }
     tm.stop();
+    if (slot >= 0) {
+        FCD_HIP(h, hipEventRecord(h->ov_last[slot], S));
+        h->ov_seq++;
+    }
     return FCD_OK;
 }
 
@@ -724,6 +751,7 @@ int fcd_release_workspace(fcd_handle *h) {
         h->retry_pending = false;
     }
     h->arena = h->stage = h->lnbuf = h->pin = h->retry_counter = nullptr;
+    h->arena_region = 0;
     h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = h->retry_counter_bytes = 0;
     return FCD_OK;
 }
@@ -1024,6 +1052,8 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     const int64_t budget = workspace_budget(h);
     int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_pair);
     chunk = std::min<int64_t>(chunk, B);
+    rc = arena_exclusive(h, nullptr, 0);
+    if (rc) return rc;
     rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
     if (rc) return rc;
 
@@ -1239,6 +1269,8 @@ int fcd_duplex_envelope_dev(fcd_handle *h, int64_t n_pairs,
     const size_t per_pair = (size_t)dirs_stride * 8 + anchor_bytes;
     int64_t chunk = std::max<int64_t>(1, workspace_budget(h) / (int64_t)per_pair);
     chunk = std::min<int64_t>(chunk, n_pairs);
+    rc = arena_exclusive(h, nullptr, 0);
+    if (rc) return rc;
     rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
     if (rc) return rc;
     EnvelopeArgs a;

@@ -258,6 +258,7 @@ struct fcd_handle {
     // grow-only device workspace (tree arenas, staging for *_host calls)
     void *arena = nullptr;
     size_t arena_bytes = 0;
+    size_t arena_region = 0;  // fcd_set_overlap: internal stream k's calls use the arena from k * arena_region on
     void *stage = nullptr;
     size_t stage_bytes = 0;
     void *pin = nullptr;  // page-locked host mirror of `stage` for small *_host calls (one DMA each way)

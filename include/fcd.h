@@ -190,19 +190,20 @@ int fcd_destroy(fcd_handle *h);                         /* FCD_E_INVALID while a
 int fcd_set_stream(fcd_handle *h, void *hip_stream);     /* launch on this hipStream_t; NULL = the HIP null (legacy default) stream */
 int fcd_reset_stream(fcd_handle *h);                     /* back to the handle's own non-blocking stream */
 int fcd_synchronize(fcd_handle *h);                      /* waits for the handle's stream (and for overlapping calls, below) */
-/* Overlapping calls (wide beams; no counterpart in the reference, whose searches are synchronous: src/lib.rs:199).
- * A wide-beam batch is as slow as its slowest read -- under FCD_TIE_PDQ178 a read whose every step ties
- * runs 2.3x as long as the rest of its batch, on one wavefront, while the chip idles.  fcd_set_overlap(h, n), n in 2 .. 8:
- * fcd_beam_search_dev / fcd_crf_beam_search_dev calls that take the wide-beam kernel with its device-side slab pool
- * (worst-case tree arena above 8 GiB or the workspace limit) are enqueued round-robin on n internal streams -- each behind
- * the handle's stream AS IT STOOD WHEN THE CALL WAS MADE, not behind one another, so the stragglers of a call run under
- * the next calls; all of them share ONE tree arena, sized by the wavefronts the chip holds.  Their results are complete
- * once fcd_overlap_join(h) has made the handle's stream wait for them (fcd_overlap_join_stream: any other hipStream_t), or
- * after fcd_synchronize.  Any *_dev search on this handle whose output arrays overlap those of a call still in flight is
- * ordered behind it; READERS of such results (fcd_pack_results_dev, the caller's own kernels and copies) need the join, and
- * the inputs of a call must stay untouched until it is joined.  n = 0 (default): every call is in stream order; changing
- * n joins what is in flight.  The internal streams are created in the high priority class, whose hardware queues the
- * runtime hands out separately from those of the process's normal streams. */
+/* Overlapping calls (no counterpart in the reference, whose searches are synchronous: src/lib.rs:199).
+ * A batch is as slow as its slowest read, and a batch of 4096 reads fills half of the chip's wavefront slots: under
+ * FCD_TIE_PDQ178 a wide-beam read whose every step ties runs 2.3x as long as the rest of its batch, on
+ * one wavefront, while the chip idles.  fcd_set_overlap(h, n), n in 2 .. 8: fcd_beam_search_dev / fcd_crf_beam_search_dev
+ * calls are enqueued round-robin on n internal streams -- each behind the handle's stream AS IT STOOD WHEN THE CALL WAS
+ * MADE, not behind one another, so the stragglers of a call run under the next calls.  Wide-beam jobs share ONE tree
+ * arena whose slabs are handed out on the device, as many as the chip holds wavefronts (csrc/slab_pool.h); the other
+ * kernels' calls get a region of the workspace per internal stream.  Results are complete once fcd_overlap_join(h) has
+ * made the handle's stream wait for them (fcd_overlap_join_stream: any other hipStream_t), or after fcd_synchronize.
+ * Any *_dev search on this handle whose output arrays overlap those of a call still in flight is ordered behind it;
+ * READERS of such results (fcd_pack_results_dev, the caller's own kernels and copies) need the join, and the inputs of a
+ * call must stay untouched until it is joined.  n = 0 (default): every call is in stream order; changing n joins what is
+ * in flight.  The internal streams are created in the high priority class, whose hardware queues the runtime hands out
+ * separately from those of the process's normal streams. */
 int fcd_set_overlap(fcd_handle *h, int streams);
 int fcd_overlap_join(fcd_handle *h);
 int fcd_overlap_join_stream(fcd_handle *h, void *hip_stream);

@@ -63,6 +63,10 @@ def test_lane_overlapping_calls(fcd):
     P.test_lane_overlapping_calls(fcd)
 
 
+def test_overlapping_calls_plain_kernels(fcd):
+    P.test_overlapping_calls_every_kernel(fcd, 0, 5)
+
+
 def test_largest_beam_of_the_lds_kernel(fcd):
     P.test_largest_beam_of_the_lds_kernel(fcd)
 

@@ -242,6 +242,49 @@ def test_lane_overlapping_calls(fcd):
         h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
 
 
+@pytest.mark.parametrize("kernel,beam", [(0, 5), (1, 7), (3, 8), (4, 16)])
+def test_overlapping_calls_every_kernel(fcd, kernel, beam):
+    """fcd_set_overlap with the kernels that keep one tree slab per read: every internal stream has a region of the
+    workspace to itself.  Six calls of different shapes on three streams (the workspace grows on the way: calls in flight
+    are waited for first) deliver what they deliver in stream order."""
+    import torch
+    from fast_ctc_decode_amd import _native as nat
+    xs = [gen_batch(950 + i, 5 + 3 * (i % 3), 150 + 40 * i, 5) for i in range(6)]
+    h = nat.default_handle()
+    on_gpu = torch.cuda.is_available()
+    serial = [fcd.beam_search_batch_raw(x, beam, 0.05, True, kernel=kernel) for x in xs]
+    st, labels, path, _ = oracle.beam_search_raw(np.ascontiguousarray(xs[5][0]), beam, 0.05, True)
+    assert st == 0 and int(serial[5].out_len[0]) == len(labels)
+    np.testing.assert_array_equal(serial[5].path[0, :len(labels)], path)
+    h.set_overlap(3)
+    try:
+        if on_gpu:
+            xt = [torch.from_numpy(x).cuda() for x in xs]
+            outs = [fcd.beam_search_batch_raw(t, beam, 0.05, True, kernel=kernel) for t in xt]
+            outs = [r.cpu() for r in outs]
+        else:
+            outs = [fcd.beam_search_batch_raw(x, beam, 0.05, True, kernel=kernel) for x in xs]
+        for a, b in zip(outs, serial):
+            np.testing.assert_array_equal(a.status, b.status)
+            np.testing.assert_array_equal(a.out_len, b.out_len)
+            for i in range(len(a.out_len)):
+                n = int(a.out_len[i])
+                np.testing.assert_array_equal(a.labels[i, :n], b.labels[i, :n])
+                np.testing.assert_array_equal(a.path[i, :n], b.path[i, :n])
+        # another entry point in between: it takes the workspace from its start, behind everything in flight
+        if on_gpu:
+            ra = fcd.beam_search_batch_raw(xt[5], beam, 0.05, True, kernel=kernel)
+            rv = fcd.viterbi_search_batch_raw(xt[0], True)
+            rb = fcd.beam_search_batch_raw(xt[4], beam, 0.05, True, kernel=kernel)
+            for r, want in ((ra, serial[5]), (rb, serial[4])):
+                c = r.cpu()
+                np.testing.assert_array_equal(c.out_len, want.out_len)
+                np.testing.assert_array_equal(c.path[0, :int(c.out_len[0])], want.path[0, :int(c.out_len[0])])
+            assert int(rv.cpu().out_len[0]) > 0
+    finally:
+        h.set_overlap(0)
+
+
 @pytest.mark.parametrize("kernel", KERNELS)
 @pytest.mark.parametrize("collapse", [True, False])
 def test_beam_thr0(fcd, collapse, kernel):
