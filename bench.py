@@ -595,7 +595,11 @@ def main():
     # been queued -- and never leaves the GPU without work; it only reads step i's result tensors, which every
     # call allocates afresh.  flush() issues the last one; all gathers have completed before the closing synchronize.
     comm_stream = torch.cuda.Stream(dev) if distributed and not args.no_overlap else None
-    pending = [None]
+    # (overlapping steps: the gather lags as many steps behind as there are further internal streams, so that the host's
+    # read-back of the payload size waits for a search that has very likely finished, not for the one just queued)
+    from collections import deque
+    pending = deque()
+    lag = max(1, overlap - 1) if overlap else 1
 
     def search(s):
         if cfg["crf"]:
@@ -603,9 +607,9 @@ def main():
         return fcd.beam_search_batch_raw(x, beam, thr, True, kernel=args.kernel, handle=handles[s])
 
     def gather(prev):
-        r, ev = prev
-        if overlap:  # (the search sits on one of the handle's internal streams: the comm stream waits for those)
-            handles[0].overlap_join(comm_stream.cuda_stream)
+        r, ev, slot = prev
+        if slot >= 0:  # (the search sat on an internal stream of the handle: the comm stream waits for that one)
+            handles[0].overlap_join_slot(slot, comm_stream.cuda_stream)
         else:
             comm_stream.wait_event(ev)
         with torch.cuda.stream(comm_stream):
@@ -613,16 +617,13 @@ def main():
                 tns.record_stream(comm_stream)
             fdist.gather_batch_result(r, counts, dst=0, scratch=scratch)
 
-    def flush():
-        if pending[0] is not None:
-            gather(pending[0])
-            pending[0] = None
+    def flush(keep=0):
+        while len(pending) > keep:
+            gather(pending.popleft())
 
     def step():
         s = step_no[0] % n_streams
         step_no[0] += 1
-        if overlap and comm_stream is not None:
-            flush()  # (overlap_join waits for every call made so far: the previous step's gather goes first)
         with torch.cuda.stream(streams[s]):
             r = search(s)
             if distributed and comm_stream is None:
@@ -633,8 +634,8 @@ def main():
         if comm_stream is not None:
             ev = torch.cuda.Event()
             ev.record(streams[s])
-            flush()  # the previous step's results, while this step's search runs
-            pending[0] = (r, ev)
+            pending.append((r, ev, handles[0].overlap_last_slot() if overlap else -1))
+            flush(lag)  # earlier steps' results, while this step's search runs
         return r
 
     def join():

@@ -19,6 +19,8 @@ from .api import (  # noqa: F401
     set_duplex_logadd_mode,
     set_tie_order,
     tie_order,
+    set_overlap,
+    overlap_join,
     set_coalescing,
     coalescing_stats,
     crf_beam_search,

@@ -23,7 +23,7 @@ TIE_DEFAULT, TIE_PDQ178, TIE_STABLE = -1, 0, 1
 # list AND against the header text)
 SYMBOLS = [
     "fcd_version", "fcd_device_count", "fcd_create", "fcd_destroy", "fcd_set_stream", "fcd_reset_stream",
-    "fcd_synchronize", "fcd_set_overlap", "fcd_overlap_join", "fcd_overlap_join_stream", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
+    "fcd_synchronize", "fcd_set_overlap", "fcd_overlap_join", "fcd_overlap_join_stream", "fcd_overlap_last_slot", "fcd_overlap_join_slot", "fcd_last_error", "fcd_status_string", "fcd_set_workspace_limit", "fcd_release_workspace",
     "fcd_set_tie_order", "fcd_get_tie_order", "fcd_set_default_tie_order", "fcd_debug_pdq178_sort_dev", "fcd_debug_pdq178_coop_sort_dev", "fcd_debug_pdq178_coop_profile",
     "fcd_debug_set_pdq178_std_form", "fcd_debug_get_pdq178_std_form",
     "fcd_last_kernel_ms", "fcd_timing_reset", "fcd_timing_mean_ms", "fcd_debug_set_first_pass_divisor", "fcd_debug_set_duplex_profile", "fcd_debug_set_duplex_kernel",
@@ -120,6 +120,8 @@ def bind(lib):
     lib.fcd_set_overlap.argtypes = [P, i32]
     lib.fcd_overlap_join.argtypes = [P]
     lib.fcd_overlap_join_stream.argtypes = [P, P]
+    lib.fcd_overlap_last_slot.argtypes = [P]
+    lib.fcd_overlap_join_slot.argtypes = [P, i32, P]
     lib.fcd_synchronize.argtypes = [P]
     lib.fcd_last_error.argtypes = [P]
     lib.fcd_last_error.restype = C.c_char_p
@@ -247,6 +249,14 @@ class Handle:
             self._inflight = []  # (later work on that stream is ordered behind them: the caching allocator may reuse them)
         else:
             self.check(self.lib.fcd_overlap_join_stream(self.ptr, C.c_void_p(stream_ptr)))
+
+    def overlap_last_slot(self):
+        """The internal stream the latest overlapping call went to (-1: none); see overlap_join_slot."""
+        return int(self.lib.fcd_overlap_last_slot(self.ptr))
+
+    def overlap_join_slot(self, slot, stream_ptr):
+        """`stream_ptr` waits for what internal stream `slot` has been given so far (include/fcd.h)."""
+        self.check(self.lib.fcd_overlap_join_slot(self.ptr, int(slot), C.c_void_p(stream_ptr)))
 
     def last_kernel_ms(self):
         return float(self.lib.fcd_last_kernel_ms(self.ptr))

@@ -380,6 +380,24 @@ def tie_order():
     return nat.default_tie_order()
 
 
+def set_overlap(streams, device=0):
+    """Device-tensor batches only: let successive beam_search_batch_raw / crf_beam_search_batch_raw calls of this thread
+    overlap on `streams` (2 .. 8) internal HIP streams of the thread's handle (include/fcd.h, fcd_set_overlap).  A batch is
+    as slow as its slowest read and 4096 reads fill half the chip, so independent batches issued back to back finish
+    sooner when they share it (BASELINE config 2: 0.94 M -> 1.4 M reads/s; config 3 under the default tie order: 141 k ->
+    300 k).  Each call still starts behind everything torch's current stream held when it was made; a result is
+    complete when its `.cpu()` / `.sequences()` has run (they join first) or after overlap_join().  0 = off (default)."""
+    nat.default_handle(device).set_overlap(streams)
+
+
+def overlap_join(device=0):
+    """torch's current stream waits for every overlapping call made so far (set_overlap)."""
+    import torch
+    h = nat.default_handle(device)
+    h.set_stream(torch.cuda.current_stream(device).cuda_stream)
+    h.overlap_join()
+
+
 import os as _os
 if _os.environ.get("FCD_DUPLEX_LOGADD"):   # the same switch the compiled module reads at import
     set_duplex_logadd_mode(_os.environ["FCD_DUPLEX_LOGADD"])
@@ -456,6 +474,8 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
             C.byref(res)))
         r = BatchResult(labels, None, out_len, status, ambiguous=amb)
         r._handle, r._keep = h, keep
+        if h.overlap:  # (see _torch_call)
+            h._inflight.append((keep, labels, out_len, status, amb))
         return r
     x1 = _stack_host(network_outputs_1, 3)
     x2 = _stack_host(network_outputs_2, 3)
@@ -649,6 +669,8 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
             int(env.shape[1]), int(beam_size), float(beam_cut_threshold), int(mode), C.byref(res)))
         r = BatchResult(labels, None, out_len, status, ambiguous=amb)
         r._handle, r._keep = h, keep
+        if h.overlap:  # (see _torch_call)
+            h._inflight.append((keep, labels, out_len, status, amb))
         return r
     x1 = _stack_host(network_outputs_1, 4)
     x2 = _stack_host(network_outputs_2, 4)

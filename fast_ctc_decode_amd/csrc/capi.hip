@@ -276,9 +276,27 @@ int overlap_begin(fcd_handle *h, const ResultDesc &o, int64_t n_reads, int *slot
     int n_mine = 0;
     int rc = overlap_order_behind(h, S, slot, o, n_reads, mine, &n_mine);
     if (rc) return rc;
-    for (int k = 0; k < n_mine; ++k) h->ov_ranges[slot].push_back(mine[k]);
-    h->ov_used[slot] = true;
     *slot_out = slot;
+    return FCD_OK;
+}
+
+// ... and the call has been enqueued on internal stream `slot`: from here on it counts as in flight (not earlier: a
+// call that has to grow a buffer waits for the others in between, which forgets what was in flight)
+int overlap_end(fcd_handle *h, int slot, const ResultDesc &o, int64_t n_reads) {
+    FCD_HIP(h, hipEventRecord(h->ov_last[slot], h->ov_stream[slot]));
+    auto add = [&](const void *ptr, size_t bytes) {
+        if (ptr && bytes) h->ov_ranges[slot].push_back({reinterpret_cast<uintptr_t>(ptr), reinterpret_cast<uintptr_t>(ptr) + bytes});
+    };
+    const size_t rows = (size_t)n_reads * (size_t)o.out_stride;
+    add(o.labels, rows);
+    add(o.path, rows * 4);
+    add(o.qual, rows * 4);
+    add(o.out_len, (size_t)n_reads * 4);
+    add(o.status, (size_t)n_reads * 4);
+    add(o.ambiguous, (size_t)n_reads * 8);
+    h->ov_used[slot] = true;
+    h->ov_last_slot = slot;
+    h->ov_seq++;
     return FCD_OK;
 }
 
@@ -497,7 +515,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
             }
         }
         tm.stop();
-        if (slot >= 0) FCD_HIP(h, hipEventRecord(h->ov_last[slot], S));
+        if (slot >= 0) return overlap_end(h, slot, o, d.n_reads);
         h->ov_seq++;
         return FCD_OK;
     }
@@ -548,10 +566,7 @@ int beam_dev(fcd_handle *h, const fcd_batch *in, const BeamArgs &a, int kernel,
         FCD_HIP(h, e);
     }
     tm.stop();
-    if (slot >= 0) {
-        FCD_HIP(h, hipEventRecord(h->ov_last[slot], S));
-        h->ov_seq++;
-    }
+    if (slot >= 0) return overlap_end(h, slot, o, d.n_reads);
     return FCD_OK;
 }
 
@@ -692,6 +707,21 @@ int fcd_overlap_join(fcd_handle *h) {
     return overlap_join(h, h->stream);
 }
 
+int fcd_overlap_last_slot(fcd_handle *h) {
+    if (!h) return -1;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    return h->overlap_n >= 2 ? h->ov_last_slot : -1;
+}
+
+int fcd_overlap_join_slot(fcd_handle *h, int slot, void *hip_stream) {
+    if (!h) return FCD_E_INVALID;
+    std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (slot < 0 || slot >= fcd_handle::kMaxOverlap) return fail(h, FCD_E_INVALID, "fcd_overlap_join_slot: no such internal stream");
+    FCD_DEVICE(h);
+    if (h->ov_stream[slot] && h->ov_used[slot]) FCD_HIP(h, hipStreamWaitEvent(reinterpret_cast<hipStream_t>(hip_stream), h->ov_last[slot], 0));
+    return FCD_OK;
+}
+
 int fcd_overlap_join_stream(fcd_handle *h, void *hip_stream) {
     if (!h) return FCD_E_INVALID;
     std::lock_guard<std::recursive_mutex> g(h->mu);
@@ -751,7 +781,7 @@ int fcd_release_workspace(fcd_handle *h) {
         h->retry_pending = false;
     }
     h->arena = h->stage = h->lnbuf = h->pin = h->retry_counter = nullptr;
-    h->arena_region = 0;
+    h->arena_region = h->lnbuf_region = 0;
     h->arena_bytes = h->stage_bytes = h->lnbuf_bytes = h->pin_bytes = h->retry_counter_bytes = 0;
     return FCD_OK;
 }
@@ -1003,30 +1033,47 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     if (duplex_lds_bytes((int)beam_size, N, 0, S, effective_tie_order(h)) > 64 * 1024)
         return fail(h, FCD_E_UNSUPPORTED, "beam_size * alphabet too large for the LDS-resident kernel");
     FCD_DEVICE(h);
-    {
-        const int orc = overlap_order_writer(h, out, B);
-        if (orc) return orc;
-    }
 
-    // log-space copies + one int for the envelope width
+    // log-space copies + one int for the envelope width.  fcd_set_overlap: the call goes to the next internal stream, with
+    // a region of the log-space buffer and of the arena to itself (beam_dev)
     const int64_t T1 = std::max<int64_t>(in1->T, 1), T2 = std::max<int64_t>(in2->T, 1);
     const size_t n1 = (size_t)B * T1 * S * N, n2 = (size_t)B * T2 * S * N;
-    rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, (n1 + n2) * 4 + 256);
-    if (rc) return rc;
-    float *ln1 = reinterpret_cast<float *>(h->lnbuf);
+    const int regions = h->overlap_n >= 2 ? std::min(h->overlap_n, (int)fcd_handle::kMaxOverlap) : 1;
+    size_t ln_need = (n1 + n2) * 4 + 256;
+    hipStream_t St = h->stream;
+    int slot = -1;
+    if (regions > 1) {
+        ln_need = (ln_need + 255) & ~(size_t)255;
+        if (ln_need > h->lnbuf_region || h->lnbuf_bytes < (size_t)regions * h->lnbuf_region) {
+            rc = overlap_drain(h);
+            if (rc) return rc;
+            rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, (size_t)regions * ln_need);
+            if (rc) return rc;
+            h->lnbuf_region = ln_need;
+        }
+        rc = overlap_begin(h, to_desc(out), B, &slot);
+        if (rc) return rc;
+        St = h->ov_stream[slot];
+    } else {
+        rc = arena_exclusive(h, out, B);  // (behind every overlapping call in flight: they hold regions of both buffers)
+        if (rc) return rc;
+        rc = ensure(h, &h->lnbuf, &h->lnbuf_bytes, ln_need);
+        if (rc) return rc;
+    }
+    float *ln1 = reinterpret_cast<float *>(reinterpret_cast<char *>(h->lnbuf) + (slot >= 0 ? (size_t)slot * h->lnbuf_region : 0));
     float *ln2 = ln1 + n1;
     int *d_width = reinterpret_cast<int *>(ln2 + n2);
-    Timer tm(h);
+    Timer tm(h, St, true);
     FCD_HIP(h, launch_ln_convert(static_cast<const float *>(in1->post), in1->dtype, B, in1->T, S, N, in1->stride_read, in1->stride_t,
-                                 is_crf ? in1->stride_s : 0, in1->stride_n, ln1, logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235, h->stream));
+                                 is_crf ? in1->stride_s : 0, in1->stride_n, ln1, logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235, St));
     FCD_HIP(h, launch_ln_convert(static_cast<const float *>(in2->post), in2->dtype, B, in2->T, S, N, in2->stride_read, in2->stride_t,
-                                 is_crf ? in2->stride_s : 0, in2->stride_n, ln2, logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235, h->stream));
-    FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), h->stream));
+                                 is_crf ? in2->stride_s : 0, in2->stride_n, ln2, logadd_mode == FCD_LOGADD_LOGSUMEXP_GLIBC235, St));
+    FCD_HIP(h, hipMemsetAsync(d_width, 0, sizeof(int), St));
     FCD_HIP(h, launch_env_width(envelope, B, env_stride, in1->T, in2->T, in1->lengths,
-                                in2->lengths, d_width, h->stream));
+                                in2->lengths, d_width, St));
     int width = 0;
-    FCD_HIP(h, hipMemcpyAsync(&width, d_width, sizeof(int), hipMemcpyDeviceToHost, h->stream));
-    FCD_HIP(h, hipStreamSynchronize(h->stream));  // ring capacity is needed to size the arena
+    FCD_HIP(h, hipMemcpyAsync(&width, d_width, sizeof(int), hipMemcpyDeviceToHost, St));
+    FCD_HIP(h, hipStreamSynchronize(St));  // ring capacity is needed to size the arena
     // Which kernel: the slot-resident one (duplex_slots.hip) wherever it fits -- beam_size * N <= 64 and the live nodes'
     // rings next to the read-2 tile in 64 KiB of LDS -- the any-shape one (duplex.hip) otherwise.
     const int tie = effective_tie_order(h);
@@ -1050,12 +1097,22 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
                                   : (size_t)cap_nodes * (sizeof(int4) + 8 + (size_t)NL * 4 + (size_t)Wcap * 12) +
                                         (((size_t)(in2->T + 1) * 4 + 64 + 15) & ~(size_t)15);
     const int64_t budget = workspace_budget(h);
-    int64_t chunk = std::max<int64_t>(1, budget / (int64_t)per_pair);
+    int64_t chunk = std::max<int64_t>(1, budget / regions / (int64_t)per_pair);
     chunk = std::min<int64_t>(chunk, B);
-    rc = arena_exclusive(h, nullptr, 0);
-    if (rc) return rc;
-    rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
-    if (rc) return rc;
+    if (regions > 1) {
+        const size_t region = ((size_t)chunk * per_pair + 255) & ~(size_t)255;
+        if (region > h->arena_region || h->arena_bytes < (size_t)regions * h->arena_region) {
+            rc = overlap_drain(h);
+            if (rc) return rc;
+            rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)regions * region);
+            if (rc) return rc;
+            h->arena_region = region;
+        }
+    } else {
+        rc = ensure(h, &h->arena, &h->arena_bytes, (size_t)chunk * per_pair);
+        if (rc) return rc;
+    }
+    char *const abase = reinterpret_cast<char *>(h->arena) + (slot >= 0 ? (size_t)slot * h->arena_region : 0);
 
     DuplexArgs a;
     a.ln1 = ln1; a.ln2 = ln2; a.T1cap = in1->T; a.T2cap = in2->T;
@@ -1069,11 +1126,11 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.init1 = is_crf ? crf->init1 : nullptr; a.init2 = is_crf ? crf->init2 : nullptr;
     a.n_init1 = is_crf ? crf->n1 : 0; a.n_init2 = is_crf ? crf->n2 : 0;
     a.init1_stride = is_crf ? crf->s1 : 0; a.init2_stride = is_crf ? crf->s2 : 0;
-    char *base = reinterpret_cast<char *>(h->arena);
+    char *base = abase;
     a.meta = reinterpret_cast<int4 *>(base); base += (size_t)chunk * cap_nodes * sizeof(int4);
     a.aux = nullptr; a.nmax = nullptr; a.rlo = nullptr; a.NLp = NLp; a.pair_stride = (int64_t)per_pair;
     if (slots) {
-        a.meta = reinterpret_cast<int4 *>(h->arena);  // (one slab per pair: duplex_slots.hip)
+        a.meta = reinterpret_cast<int4 *>(abase);  // (one slab per pair: duplex_slots.hip)
         a.vec = nullptr; a.rows = nullptr;
     } else {
         a.nmax = reinterpret_cast<float *>(base); base += (size_t)chunk * cap_nodes * 4;
@@ -1091,9 +1148,10 @@ int duplex_dev(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const 
     a.tie_order = tie;
     for (int64_t begin = 0; begin < B; begin += chunk) {
         const int64_t n = std::min<int64_t>(chunk, B - begin);
-        FCD_HIP(h, slots ? launch_duplex_slots(a, begin, n, h->stream) : launch_duplex(a, begin, n, h->stream));
+        FCD_HIP(h, slots ? launch_duplex_slots(a, begin, n, St) : launch_duplex(a, begin, n, St));
     }
     tm.stop();
+    if (slot >= 0) return overlap_end(h, slot, to_desc(out), B);
     return FCD_OK;
 }
 }  // namespace
@@ -1202,6 +1260,10 @@ int duplex_host(fcd_handle *h, const fcd_batch *in1, const fcd_batch *in2, const
                         env_stride, beam_size, beam_cut_threshold, collapse_repeats, logadd_mode, &dout);
     if (rc) return rc;
     std::lock_guard<std::recursive_mutex> g(h->mu);
+    if (h->overlap_n >= 2) {  // (fcd_set_overlap: the search may sit on an internal stream; the copies below are in the handle's)
+        rc = overlap_join(h, h->stream);
+        if (rc) return rc;
+    }
     FCD_HIP(h, hipMemcpyAsync(out->labels, dout.labels, n_out, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipMemcpyAsync(out->out_len, dout.out_len, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));
     FCD_HIP(h, hipMemcpyAsync(out->status, dout.status, (size_t)B * 4, hipMemcpyDeviceToHost, h->stream));

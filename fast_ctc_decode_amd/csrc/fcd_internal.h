@@ -265,6 +265,7 @@ struct fcd_handle {
     size_t pin_bytes = 0;
     void *lnbuf = nullptr;  // duplex: log-space copies of both reads + scalars
     size_t lnbuf_bytes = 0;
+    size_t lnbuf_region = 0;  // (fcd_set_overlap: as arena_region)
     // wide-beam kernel, large jobs: slabs handed out on the device (slab_pool.h).  An allocation of its own: calls in
     // flight on the overlap streams keep using it while other entry points size `arena` for themselves
     void *pool_arena = nullptr;
@@ -284,6 +285,7 @@ struct fcd_handle {
     bool ov_used[kMaxOverlap] = {};
     hipEvent_t ov_fork = nullptr;
     uint64_t ov_seq = 0;
+    int ov_last_slot = -1;  // the internal stream the latest overlapping call went to
     struct Range { uintptr_t lo, hi; };
     std::vector<Range> ov_ranges[kMaxOverlap];
     void *retry_counter = nullptr;  // lane kernel, two-pass sizing: overflow counter of the retry rounds

@@ -193,8 +193,8 @@ int fcd_synchronize(fcd_handle *h);                      /* waits for the handle
 /* Overlapping calls (no counterpart in the reference, whose searches are synchronous: src/lib.rs:199).
  * A batch is as slow as its slowest read, and a batch of 4096 reads fills half of the chip's wavefront slots: under
  * FCD_TIE_PDQ178 a wide-beam read whose every step ties runs 2.3x as long as the rest of its batch, on
- * one wavefront, while the chip idles.  fcd_set_overlap(h, n), n in 2 .. 8: fcd_beam_search_dev / fcd_crf_beam_search_dev
- * calls are enqueued round-robin on n internal streams -- each behind the handle's stream AS IT STOOD WHEN THE CALL WAS
+ * one wavefront, while the chip idles.  fcd_set_overlap(h, n), n in 2 .. 8: the *_dev beam searches (1-D and duplex)
+ * are enqueued round-robin on n internal streams -- each behind the handle's stream AS IT STOOD WHEN THE CALL WAS
  * MADE, not behind one another, so the stragglers of a call run under the next calls.  Wide-beam jobs share ONE tree
  * arena whose slabs are handed out on the device, as many as the chip holds wavefronts (csrc/slab_pool.h); the other
  * kernels' calls get a region of the workspace per internal stream.  Results are complete once fcd_overlap_join(h) has
@@ -207,6 +207,12 @@ int fcd_synchronize(fcd_handle *h);                      /* waits for the handle
 int fcd_set_overlap(fcd_handle *h, int streams);
 int fcd_overlap_join(fcd_handle *h);
 int fcd_overlap_join_stream(fcd_handle *h, void *hip_stream);
+/* One call at a time: fcd_overlap_last_slot = the internal stream (0 .. n-1) the latest overlapping call went to, -1 if
+ * none; fcd_overlap_join_slot makes `hip_stream` wait for what THAT internal stream has been given so far -- the call
+ * itself as long as fewer than n further calls have been made since.  (A consumer that lags n - 1 calls behind -- a
+ * gather of results on a communication stream -- waits for exactly the call it consumes.) */
+int fcd_overlap_last_slot(fcd_handle *h);
+int fcd_overlap_join_slot(fcd_handle *h, int slot, void *hip_stream);
 const char *fcd_last_error(const fcd_handle *h);         /* text of the last failure on this handle */
 const char *fcd_status_string(int status);               /* exact SearchError Display text, src/lib.rs:46-53 */
 /* cap (bytes) on the per-call tree-arena workspace; batches needing more are decoded in chunks */

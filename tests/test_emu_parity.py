@@ -117,6 +117,10 @@ def test_duplex(fcd):
         assert fcd.crf_beam_search_duplex(x1, i1, x2, i2, "NACGT", env, 5, 0.1, logadd_mode=mode) == want
 
 
+def test_duplex_overlapping_calls(fcd):
+    D.test_duplex_overlapping_calls(fcd, D.LSE)
+
+
 def test_duplex_any_shape_kernel_forced(fcd):
     """csrc/duplex.hip is the fallback since r06 (AUTO runs csrc/duplex_slots.hip wherever it fits): it stays under test."""
     D.test_duplex_each_kernel_forced(fcd, 1)

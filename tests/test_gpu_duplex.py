@@ -510,6 +510,40 @@ def test_duplex_fuzz(fcd, mode):
         duplex_fuzz_seed(fcd, seed, mode)
 
 
+@pytest.mark.parametrize("mode", [LSE, MAX], ids=["logsumexp", "max"])
+def test_duplex_overlapping_calls(fcd, mode):
+    """fcd_set_overlap (include/fcd.h) with the 2-D searches: every internal stream has its own region of the log-space
+    buffer and of the arena.  Five batches of different shapes in flight on three streams deliver what they deliver in
+    stream order (and the first of them the oracle's strings)."""
+    import torch
+    from fast_ctc_decode_amd import _native as nat
+    shapes = [(4, 120, 110, 16), (7, 90, 100, 12), (3, 150, 150, 20), (6, 60, 64, 8), (5, 130, 120, 16)]
+    data = []
+    for k, (B, T1, T2, w) in enumerate(shapes):
+        x1, x2 = pairs(700 + 10 * mode + k, B, T1, T2)
+        data.append((x1, x2, np.stack([band(T1, T2, w)] * B)))
+    serial = [fcd.beam_search_duplex_batch_raw(x1, x2, e, 5, 0.1, True, logadd_mode=mode).cpu() for x1, x2, e in data]
+    x1, x2, e = data[0]
+    assert gpu_strings(fcd, x1, x2, "NACGT", e, 5, 0.1, True, mode) == oracle_strings(x1, x2, "NACGT", e, 5, 0.1, True, mode | CR)
+    h = nat.default_handle()
+    h.set_overlap(3)
+    try:
+        if torch.cuda.is_available():
+            dev = [(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda(), c) for a, b, c in data]
+            rs = [fcd.beam_search_duplex_batch_raw(a, b, c, 5, 0.1, True, logadd_mode=mode) for a, b, c in dev]
+            outs = [r.cpu() for r in rs]
+        else:  # (the emulator: host arrays, the staged call joins before it copies back)
+            outs = [fcd.beam_search_duplex_batch_raw(a, b, c, 5, 0.1, True, logadd_mode=mode).cpu() for a, b, c in data]
+        for got, want in zip(outs, serial):
+            np.testing.assert_array_equal(got.status, want.status)
+            np.testing.assert_array_equal(got.out_len, want.out_len)
+            for i in range(len(got.out_len)):
+                n = int(got.out_len[i])
+                np.testing.assert_array_equal(got.labels[i, :n], want.labels[i, :n])
+    finally:
+        h.set_overlap(0)
+
+
 def test_crf_duplex_device_tensors(fcd):
     """The zero-copy (torch ROCm tensor) entry of the CRF duplex search equals the host entry."""
     torch = pytest.importorskip("torch")
