@@ -15,8 +15,16 @@ bash tools/profile_sq.sh $TAG beam > $O/${TAG}_profile_sq.log 2>&1
 # the default command, as the driver runs it (with the e2e leg)
 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err
 # the BASELINE multi-GPU config's per-rank shard and the CRF config under the same contract
-python bench.py --config 3 --no-viterbi --steps 5 > $O/${TAG}_bench_config3.json 2> $O/${TAG}_bench_config3.err
+python bench.py --config 3 --no-viterbi > $O/${TAG}_bench_config3.json 2> $O/${TAG}_bench_config3.err
 python bench.py --config 4 --no-viterbi > $O/${TAG}_bench_config4.json 2> $O/${TAG}_bench_config4.err
+# round 6: bench.py overlaps its steps on the handle's internal streams by default (fcd_set_overlap) -- the same lines with
+# every step in stream order: one launch at a time, what the kernel-level roofline and the counters are quoted on
+python bench.py --overlap 0 --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_line_overlap0.json 2> $O/${TAG}_bench_overlap0.err
+python bench.py --config 3 --overlap 0 --no-viterbi --steps 5 --cpu-seconds 1 > $O/${TAG}_bench_config3_overlap0.json 2>> $O/${TAG}_bench_overlap0.err
+python bench.py --config 4 --overlap 0 --no-viterbi --cpu-seconds 1 > $O/${TAG}_bench_config4_overlap0.json 2>> $O/${TAG}_bench_overlap0.err
+for n in 2 3 4 6 8; do python bench.py --config 3 --overlap $n --no-viterbi --steps 24 --warmup 8 --cpu-seconds 0.5 2>> $O/${TAG}_bench_config3_by_overlap.err; done > $O/${TAG}_bench_config3_by_overlap.txt
+for n in 2 3 4 8; do python bench.py --overlap $n --no-viterbi --no-e2e --steps 40 --warmup 8 --cpu-seconds 0.5 2>> $O/${TAG}_bench_line_by_overlap.err; done > $O/${TAG}_bench_line_by_overlap.txt
+python tools/duplex_overlap.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_duplex_overlap.txt
 # the RCCL path of the bench at world size 1 (communicator, pack, ONE gather, one-launch unpack)
 python bench.py --force-dist --no-viterbi --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_rccl_world1.json 2> $O/${TAG}_bench_rccl_world1.err
 python tools/probe_e2e.py 4096 --grid > $O/${TAG}_e2e_probe.txt 2>&1
@@ -30,16 +38,15 @@ bash tools/viterbi_clock.sh $TAG > $O/${TAG}_viterbi_clock.log 2>&1
 cp $O/viterbi_clock_$TAG/summary.json $O/${TAG}_viterbi_clock_summary.json
 cp $(find $O/viterbi_clock_$TAG -name '*kernel_stats.csv' | head -n 1) $O/${TAG}_viterbi_clock_kernel_stats.csv
 FCD_TIE_ORDER=stable python bench.py --no-viterbi --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_line_stable_order.json 2> $O/${TAG}_bench_stable.err
-FCD_TIE_ORDER=stable python bench.py --config 3 --no-viterbi --steps 5 --cpu-seconds 1 > $O/${TAG}_bench_config3_stable_order.json 2>> $O/${TAG}_bench_stable.err
-( python bench.py --streams 2 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --batch 16384 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --data peaky --no-viterbi --no-e2e --cpu-seconds 1 ) > $O/${TAG}_bench_variants.txt 2> $O/${TAG}_bench_variants.err
+FCD_TIE_ORDER=stable python bench.py --config 3 --no-viterbi --cpu-seconds 1 > $O/${TAG}_bench_config3_stable_order.json 2>> $O/${TAG}_bench_stable.err
+( python bench.py --batch 16384 --no-viterbi --no-e2e --cpu-seconds 1; python bench.py --data peaky --no-viterbi --no-e2e --cpu-seconds 1 ) > $O/${TAG}_bench_variants.txt 2> $O/${TAG}_bench_variants.err
 # ---- round 5: the tie order's cost by beam (both orders, reference-style and peaky rows), its cycle account in place
 # (a -DFCD_LANE_TIE_PROF build: tools/dev/lane_tie_prof.sh, made before the call), the replay's dynamic instruction
 # counts, config 3 on 1 / 2 / 3 streams, the lane kernel's SQ counters, per-pair duplex callers through the coalescer
-( for b in 5 8 12; do BEAM=$b REPS=5 python tools/dev/time_variant.py; done; BEAM=32 BATCH=8192 REPS=3 python tools/dev/time_variant.py ) 2>&1 | grep -v amdgpu.ids > $O/${TAG}_tie_order_by_beam.txt
+python tools/tie_order_by_beam.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_tie_order_by_beam.txt
 python tools/dev/lane_tie_prof.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_lane_tie_prof.txt
 python tools/dev/time_coop.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_replay_probe.txt
 bash tools/dev/probe_sort_sq.sh 2>&1 | grep "per wavefront" > $O/${TAG}_replay_instruction_counts.txt
-for s in 1 2 3; do python bench.py --config 3 --streams $s --no-viterbi --steps 12 --warmup 6 --cpu-seconds 0.5 2>> $O/${TAG}_bench_config3_streams.err; done > $O/${TAG}_bench_config3_streams.txt
 FCD_TIE_ORDER=stable bash tools/profile_sq.sh ${TAG}_lane_stable beam32 > $O/${TAG}_sq_lane_stable.log 2>&1
 bash tools/profile_sq.sh ${TAG}_lane beam32 > $O/${TAG}_sq_lane.log 2>&1
 python tools/probe_threads.py pairs 2000 3 1 16 64 2>&1 | grep -v amdgpu.ids > $O/${TAG}_pair_callers.txt
