@@ -500,8 +500,8 @@ def stub_main(args):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
                     help="BASELINE.json config: 2 = beam 5, 4096 reads per GPU (the metric; default), 3 = beam 32, "
                          "8192 reads per GPU (the multi-GPU config's shard), 4 = CRF beam 5, 4096 reads")

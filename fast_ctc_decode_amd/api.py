@@ -476,6 +476,8 @@ def beam_search_duplex_batch_raw(network_outputs_1, network_outputs_2, envelopes
         r._handle, r._keep = h, keep
         if h.overlap:  # (see _torch_call)
             h._inflight.append((keep, labels, out_len, status, amb))
+            if len(h._inflight) > 256:
+                h.overlap_join()
         return r
     x1 = _stack_host(network_outputs_1, 3)
     x2 = _stack_host(network_outputs_2, 3)
@@ -671,6 +673,8 @@ def crf_beam_search_duplex_batch_raw(network_outputs_1, init_states_1, network_o
         r._handle, r._keep = h, keep
         if h.overlap:  # (see _torch_call)
             h._inflight.append((keep, labels, out_len, status, amb))
+            if len(h._inflight) > 256:
+                h.overlap_join()
         return r
     x1 = _stack_host(network_outputs_1, 4)
     x2 = _stack_host(network_outputs_2, 4)
@@ -859,8 +863,11 @@ def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path
     labels = torch.empty((B, w), dtype=torch.uint8, device=x.device)
     path = torch.empty((B, w), dtype=torch.int32, device=x.device) if want_path else None
     qual = torch.empty((B, w), dtype=torch.float32, device=x.device) if want_qual else None
-    out_len = torch.zeros(B, dtype=torch.int32, device=x.device)
-    status = torch.zeros(B, dtype=torch.int32, device=x.device)
+    # (the beam kernels write out_len and status of EVERY read on every way out -- no fill kernels in front of them, which
+    # under Handle.set_overlap would wait for a free wavefront slot behind the internal streams' high-priority launches)
+    beam = fn_name in ("fcd_beam_search_dev", "fcd_crf_beam_search_dev", "fcd_crf_beam_search_dev_k")
+    meta = (torch.empty if beam else torch.zeros)((2, B), dtype=torch.int32, device=x.device)
+    out_len, status = meta[0], meta[1]
     amb = torch.zeros((B, 2), dtype=torch.int32, device=x.device) if want_amb else None
     res = nat.Result(labels.data_ptr(), path.data_ptr() if want_path else None,
                      qual.data_ptr() if want_qual else None, out_len.data_ptr(),
@@ -875,6 +882,8 @@ def _torch_call(fn_name, x, crf, lengths, extra_args, want_qual=False, want_path
         # Handle.set_overlap: the call may still run on an internal stream when these tensors lose their last
         # reference -- the handle keeps them until the next overlap_join() (BatchResult.cpu() joins by itself)
         h._inflight.append((r._keep, labels, path, qual, out_len, status, amb))
+        if len(h._inflight) > 256:  # (a caller that never joins: bound what is kept -- the current stream waits, they go)
+            h.overlap_join()
     return r
 
 

@@ -30,6 +30,11 @@
 #include <stdio.h>
 #include <stdlib.h>
 #endif
+
+#include <map>
+#include <mutex>
+#include <utility>
+
 #include "device_utils.h"
 #include "fcd_internal.h"
 #include "pdq178.h"
@@ -1137,12 +1142,22 @@ int beam_lane_resident_waves(int beam_size, int N, int crf, bool first_pass, boo
         case 7: k = kernel_n<7, false>(rpw, ambiguous, pdq); break;
         case 8: k = kernel_n<8, false>(rpw, ambiguous, pdq); break;
     }
-    int dev = 0, cus = 0, per_cu = 0;
-    if (!k || hipGetDevice(&dev) != hipSuccess ||
-        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64, 0) != hipSuccess || per_cu < 1 || cus < 1)
-        return 256 * 4 * 8;  // (every wave slot of the chip)
-    return cus * per_cu;
+    int dev = 0;
+    if (!k || hipGetDevice(&dev) != hipSuccess) return 256 * 4 * 8;  // (every wave slot of the chip)
+    // (asked once per instantiation and device: the answer does not change, and every wide-beam call needs it)
+    static std::mutex mu;
+    static std::map<std::pair<const void *, int>, int> known;
+    std::lock_guard<std::mutex> g(mu);
+    const auto key = std::make_pair(k, dev);
+    const auto it = known.find(key);
+    if (it != known.end()) return it->second;
+    int cus = 0, per_cu = 0;
+    int waves = 256 * 4 * 8;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, 64, 0) == hipSuccess && per_cu >= 1 && cus >= 1)
+        waves = cus * per_cu;
+    known[key] = waves;
+    return waves;
 #endif
 }
 

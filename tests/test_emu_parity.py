@@ -63,6 +63,10 @@ def test_lane_overlapping_calls(fcd):
     P.test_lane_overlapping_calls(fcd)
 
 
+def test_lane_slab_pool_reuse(fcd):
+    P.test_lane_slab_pool_under_contention(fcd, 32)
+
+
 def test_overlapping_calls_plain_kernels(fcd):
     P.test_overlapping_calls_every_kernel(fcd, 0, 5)
 

@@ -242,6 +242,39 @@ def test_lane_overlapping_calls(fcd):
         h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
 
 
+@pytest.mark.parametrize("beam", [32, 40])
+def test_lane_slab_pool_under_contention(fcd, beam):
+    """The device-side slab pool (csrc/slab_pool.h) with far fewer slabs than wavefronts: a workspace limit leaves a
+    handful of (pairs of) slabs for several hundred reads, so most wavefronts of the launch wait for a slab another one
+    hands back -- and the retry pass (first-pass slabs of a sixth of the worst case: most reads overflow) queues for two or
+    three worst-case slabs.  Same results as with a slab per read."""
+    import torch
+    from fast_ctc_decode_amd import _native as nat
+    n = 640 if torch.cuda.is_available() else 48
+    x = gen_batch(4100 + beam, n, 96, 5)
+    lengths = np.full(n, 96, np.int64)
+    lengths[::7] = np.arange(len(lengths[::7])) % 97
+    want = fcd.beam_search_batch_raw(x, beam, 0.02, True, lengths=lengths, kernel=fcd.KERNEL_LANE)  # (fits: a slab per read)
+    st, labels, path, _ = oracle.beam_search_raw(np.ascontiguousarray(x[1, :lengths[1]]), beam, 0.02, True)
+    assert st == 0 and int(want.out_len[1]) == len(labels)
+    np.testing.assert_array_equal(want.path[1, :len(labels)], path)
+    h = nat.default_handle()
+    h.set_workspace_limit(3 << 20)
+    h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 6))
+    try:
+        for _ in range(2):  # (the second call finds the pool as the first one left it)
+            got = fcd.beam_search_batch_raw(x, beam, 0.02, True, lengths=lengths, kernel=fcd.KERNEL_LANE)
+            np.testing.assert_array_equal(got.status, want.status)
+            np.testing.assert_array_equal(got.out_len, want.out_len)
+            for i in range(n):
+                k = int(want.out_len[i])
+                np.testing.assert_array_equal(got.labels[i, :k], want.labels[i, :k])
+                np.testing.assert_array_equal(got.path[i, :k], want.path[i, :k])
+    finally:
+        h.set_workspace_limit(0)
+        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
+
+
 @pytest.mark.parametrize("kernel,beam", [(0, 5), (1, 7), (3, 8), (4, 16)])
 def test_overlapping_calls_every_kernel(fcd, kernel, beam):
     """fcd_set_overlap with the kernels that keep one tree slab per read: every internal stream has a region of the

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 6: the evidence set on the round's kernels in ONE GPU call -- the -m gpu suite, smoke(), tools/round_profiles.sh
 cd "$GRAFT_REPO_ROOT" || exit 1
-TAG=${TAG:-r06p}; O=gpurun_out; mkdir -p $O
+TAG=${TAG:-r06z}; O=gpurun_out; mkdir -p $O
 python -c "import torch" 2>/dev/null
 timeout 1500 python -m pytest tests -m gpu -q > $O/${TAG}_pytest_gpu.log 2>&1; tail -2 $O/${TAG}_pytest_gpu.log
 python -c "import __graft_entry__ as g; g.smoke()" > $O/${TAG}_smoke.log 2>&1; tail -1 $O/${TAG}_smoke.log

@@ -12,6 +12,10 @@ bash tools/profile_sq.sh $TAG beam > $O/${TAG}_profile_sq.log 2>&1
 # (--no-e2e: the host-batch leg launches the same kernel on 1024-read chunks, which would blur the average)
 ( export TMPDIR=/tmp; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_bench -o bench -- \
     python $R/bench.py --no-e2e > $O/${TAG}_bench_line_rocprof.json 2> $O/${TAG}_bench_rocprof.err )
+# (bench.py overlaps its steps and then times a few launches alone: the summary above averages both kinds -- the same
+# command with every step in stream order, whose kernel average is a launch alone)
+( export TMPDIR=/tmp; cd /tmp; rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_${TAG}_bench_overlap0 -o bench -- \
+    python $R/bench.py --no-e2e --overlap 0 --cpu-seconds 1 > $O/${TAG}_bench_line_overlap0_rocprof.json 2> $O/${TAG}_bench_overlap0_rocprof.err )
 # the default command, as the driver runs it (with the e2e leg)
 python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err
 # the BASELINE multi-GPU config's per-rank shard and the CRF config under the same contract
