@@ -189,7 +189,8 @@ int overlap_drain(fcd_handle *h) {
     for (int s = 0; s < fcd_handle::kMaxOverlap; ++s) {
         if (!h->ov_stream[s]) continue;
         FCD_HIP(h, hipStreamSynchronize(h->ov_stream[s]));
-        h->ov_ranges[s].clear();
+        for (fcd_handle::Flight &f : h->ov_flights[s]) h->ov_event_pool.push_back(f.done);
+        h->ov_flights[s].clear();
         h->ov_used[s] = false;
     }
     return FCD_OK;
@@ -220,16 +221,25 @@ int overlap_order_behind(fcd_handle *h, hipStream_t S, int own_slot, const Resul
     *n_mine_out = n_mine;
     for (int s = 0; s < fcd_handle::kMaxOverlap; ++s) {
         if (!h->ov_stream[s] || !h->ov_used[s]) continue;
-        if (hipEventQuery(h->ov_last[s]) == hipSuccess) {  // nothing in flight there any more
-            h->ov_ranges[s].clear();
+        std::deque<fcd_handle::Flight> &fl = h->ov_flights[s];
+        while (!fl.empty() && hipEventQuery(fl.front().done) == hipSuccess) {  // finished calls go
+            h->ov_event_pool.push_back(fl.front().done);
+            fl.pop_front();
+        }
+        if (fl.empty()) {  // nothing in flight there any more
             h->ov_used[s] = false;
             continue;
         }
         if (s == own_slot) continue;  // (stream order)
-        bool clash = false;
-        for (const fcd_handle::Range &r : h->ov_ranges[s])
-            for (int k = 0; k < n_mine && !clash; ++k) clash = r.lo < mine[k].hi && mine[k].lo < r.hi;
-        if (clash) FCD_HIP(h, hipStreamWaitEvent(S, h->ov_last[s], 0));
+        // the YOUNGEST call in flight there that writes any of these arrays: the stream runs them in order
+        hipEvent_t wait_for = nullptr;
+        for (const fcd_handle::Flight &f : fl) {
+            bool clash = false;
+            for (int i = 0; i < f.n && !clash; ++i)
+                for (int k = 0; k < n_mine && !clash; ++k) clash = f.r[i].lo < mine[k].hi && mine[k].lo < f.r[i].hi;
+            if (clash) wait_for = f.done;
+        }
+        if (wait_for) FCD_HIP(h, hipStreamWaitEvent(S, wait_for, 0));
     }
     return FCD_OK;
 }
@@ -284,8 +294,16 @@ int overlap_begin(fcd_handle *h, const ResultDesc &o, int64_t n_reads, int *slot
 // call that has to grow a buffer waits for the others in between, which forgets what was in flight)
 int overlap_end(fcd_handle *h, int slot, const ResultDesc &o, int64_t n_reads) {
     FCD_HIP(h, hipEventRecord(h->ov_last[slot], h->ov_stream[slot]));
+    fcd_handle::Flight f;
+    if (!h->ov_event_pool.empty()) {
+        f.done = h->ov_event_pool.back();
+        h->ov_event_pool.pop_back();
+    } else {
+        FCD_HIP(h, hipEventCreateWithFlags(&f.done, hipEventDisableTiming));
+    }
+    FCD_HIP(h, hipEventRecord(f.done, h->ov_stream[slot]));
     auto add = [&](const void *ptr, size_t bytes) {
-        if (ptr && bytes) h->ov_ranges[slot].push_back({reinterpret_cast<uintptr_t>(ptr), reinterpret_cast<uintptr_t>(ptr) + bytes});
+        if (ptr && bytes && f.n < 6) f.r[f.n++] = {reinterpret_cast<uintptr_t>(ptr), reinterpret_cast<uintptr_t>(ptr) + bytes};
     };
     const size_t rows = (size_t)n_reads * (size_t)o.out_stride;
     add(o.labels, rows);
@@ -294,6 +312,7 @@ int overlap_end(fcd_handle *h, int slot, const ResultDesc &o, int64_t n_reads) {
     add(o.out_len, (size_t)n_reads * 4);
     add(o.status, (size_t)n_reads * 4);
     add(o.ambiguous, (size_t)n_reads * 8);
+    h->ov_flights[slot].push_back(f);
     h->ov_used[slot] = true;
     h->ov_last_slot = slot;
     h->ov_seq++;
@@ -644,6 +663,7 @@ int fcd_destroy(fcd_handle *h) {
         if (h->ov_stream[s]) (void)hipStreamDestroy(h->ov_stream[s]);
     }
     if (h->ov_fork) (void)hipEventDestroy(h->ov_fork);
+    for (hipEvent_t e : h->ov_event_pool) (void)hipEventDestroy(e);  // (overlap_drain above returned every flight's)
     if (h->pool_arena) (void)hipFree(h->pool_arena);
     if (h->pool_ctl) (void)hipFree(h->pool_ctl);
     if (h->arena) (void)hipFree(h->arena);

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <deque>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -287,7 +288,15 @@ struct fcd_handle {
     uint64_t ov_seq = 0;
     int ov_last_slot = -1;  // the internal stream the latest overlapping call went to
     struct Range { uintptr_t lo, hi; };
-    std::vector<Range> ov_ranges[kMaxOverlap];
+    // the calls each internal stream has not finished yet, oldest first: what they write, and an event behind each (so that
+    // a stream that never idles does not accumulate ranges: finished calls are dropped from the front)
+    struct Flight {
+        hipEvent_t done = nullptr;
+        Range r[6];
+        int n = 0;
+    };
+    std::deque<Flight> ov_flights[kMaxOverlap];
+    std::vector<hipEvent_t> ov_event_pool;
     void *retry_counter = nullptr;  // lane kernel, two-pass sizing: overflow counter of the retry rounds
     size_t retry_counter_bytes = 0;
     void *retry_host = nullptr;     // page-locked word the first retry round's overflow count is copied to, read one call late
