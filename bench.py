@@ -47,6 +47,10 @@ CONFIGS = {
             baseline="BASELINE.json configs[2]: 64k reads sharded over 8 GPUs = 8192 per rank"),
     4: dict(beam=5, thr=0.0, batch=4096, seed=3, crf=True, overlap=4, kernel_prefix="beam_wave_kernel<5, 6, 2, 4",
             kernel_name="beam_wave_kernel (CRF, 4 states, two reads per wavefront)", baseline="BASELINE.json configs[3]"),
+    # BASELINE.json configs[4]: the 2-D pair consensus (src/duplex.rs); the metric is pairs/s, `--mode` picks the log-add
+    5: dict(beam=5, thr=0.1, batch=1024, seed=4, crf=False, duplex=True, T=2000, band=64, overlap=4,
+            kernel_prefix="duplex_slots_kernel<", kernel_name="duplex_slots_kernel (one pair per wavefront, live nodes in LDS slots)",
+            baseline="BASELINE.json configs[4]"),
 }
 
 
@@ -167,7 +171,7 @@ def cpu_baseline(cfg, x_host, init_host, gpu_labels, gpu_path, gpu_len, budget_s
 
 KERNEL_SOURCES = {  # the files a kernel's instruction stream and memory traffic depend on
     "beam_wave_kernel": ("beam_wave.hip", "beam_wave_step.inc", "pdq178.h", "pdq178_wave.h", "pdq178_reg.h", "device_utils.h"),
-    "beam_lane_kernel": ("beam_lane.hip", "pdq178.h", "pdq178_wave.h", "pdq178_reg.h", "device_utils.h"),
+    "beam_lane_kernel": ("beam_lane.hip", "slab_pool.h", "pdq178.h", "pdq178_wave.h", "pdq178_reg.h", "device_utils.h"),
     "beam_generic_kernel": ("beam_generic.hip", "pdq178.h", "device_utils.h"),
     "viterbi": ("viterbi.hip", "device_utils.h"),
     "crf_greedy": ("viterbi.hip", "device_utils.h"),
@@ -497,6 +501,152 @@ def stub_main(args):
     return 0
 
 
+def duplex_main(args, cfg, torch, dist, fcd, world, rank, local_rank, dev, distributed):
+    """--config 5: duplex::beam_search (src/duplex.rs:443-650) on 1024 pairs of T = 2000 rows, band +-64 around the
+    diagonal, beam 5, threshold 0.1 -- the same contract as the 1-D line (a step = one batch of pairs resident in HBM; steps
+    overlap on the handle's internal streams unless --overlap 0; `value` = pairs/s over the K timed steps).  Pairs are
+    independent: N > 1 runs a shard per rank, no collective in the timed region."""
+    from fast_ctc_decode_amd import _native as nat
+    Td, band_w, beam, thr = cfg["T"], cfg["band"], cfg["beam"], cfg["thr"]
+    B = args.batch or cfg["batch"]
+    mode = {"logsumexp": nat.LOGADD_LOGSUMEXP, "max": nat.LOGADD_MAX}[args.mode]
+    rng = np.random.default_rng(cfg["seed"] + rank)
+
+    def rows(n):
+        x = rng.random((n, N), dtype=np.float32)
+        x /= np.linalg.norm(x, ord=2, axis=1, keepdims=True)
+        return x.astype(np.float32)
+
+    x1_host = rows(B * Td).reshape(B, Td, N)
+    x2_host = rows(B * Td).reshape(B, Td, N)
+    i = np.arange(Td)
+    env_host = np.stack([np.maximum(0, i - band_w), np.minimum(Td, i + band_w)], 1).astype(np.uint64)
+    x1, x2 = torch.from_numpy(x1_host).to(dev), torch.from_numpy(x2_host).to(dev)
+    envs = torch.from_numpy(np.broadcast_to(env_host, (B, Td, 2)).copy().view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+    h = nat.default_handle(local_rank)
+    overlap = cfg.get("overlap", 0) if args.overlap is None else max(0, args.overlap)
+    if overlap < 2:
+        overlap = 0
+    h.set_overlap(overlap)
+
+    def step():
+        return fcd.beam_search_duplex_batch_raw(x1, x2, envs, beam, thr, True, logadd_mode=mode)
+
+    def join():
+        if overlap:
+            h.set_stream(torch.cuda.current_stream(dev).cuda_stream)
+            h.overlap_join()
+
+    r = None
+    for _ in range(max(args.warmup, 1)):
+        r = step()
+    join()
+    torch.cuda.synchronize()
+    if overlap:  # (bench main: the caching allocator gets the K sets of result tensors before the clock starts)
+        prime = [[torch.empty_like(t) for t in (r.labels, r.out_len, r.status)] for _ in range(args.steps + 1)]
+        del prime
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    h.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step()
+    join()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    k_ms, k_calls = h.timing_mean_ms()
+    single_ms = None
+    if overlap:
+        h.set_overlap(0)
+        h.timing_reset()
+        for _ in range(min(args.steps, 3)):
+            step()
+        torch.cuda.synchronize()
+        single_ms = h.timing_mean_ms()[0]
+    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if distributed:
+        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
+    elapsed = float(t_max.item())
+    if rank == 0:
+        rc = r.cpu()
+        ok = int((np.asarray(rc.status) == 0).sum())
+        lens = np.asarray(rc.out_len).astype(np.int64)
+        mean_L = float(lens.mean())
+        # the CPU leg: the oracle (correctly rounded log-add, as the kernels define it) on a bounded sample, a pair per thread
+        cpu = None
+        if world == 1:
+            from concurrent.futures import ThreadPoolExecutor
+            from oracle import oracle
+            omode = (oracle.LOGSUMEXP if args.mode == "logsumexp" else oracle.MAXMODE) | oracle.MATH_CR
+            oracle.lib.fcdo_set_unstable_sort(0 if fcd.tie_order() == "stable" else 1)
+            threads = min(os.cpu_count() or 1, 32)
+
+            def one(j):
+                return oracle.beam_search_duplex(x1_host[j], x2_host[j], "NACGT", env_host, beam, thr, True, omode)
+
+            t1 = time.perf_counter()
+            one(0)
+            per_pair = time.perf_counter() - t1
+            n = int(max(threads, min(B, args.cpu_seconds * threads / max(per_pair, 1e-3))))
+            pick = np.linspace(0, B - 1, min(n, B)).astype(np.int64)
+            t1 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as pool:  # (the C routine runs outside the interpreter lock)
+                wants = list(pool.map(one, pick))
+            dt = time.perf_counter() - t1
+            mism = sum(1 for j, want in zip(pick, wants)
+                       if int(rc.status[j]) != 0 or "".join("NACGT"[l] for l in rc.labels[j, :lens[j]]) != want)
+            cpu = {"value": len(pick) / dt, "unit": "pairs/s", "cores": threads, "kind": "port",
+                   "sample": "%d pairs spread over rank 0's batch (T1=T2=%d N=%d band +-%d beam=%d thr=%.1f, %s), oracle C "
+                             "restatement of src/duplex.rs with correctly rounded ln / exp / ln_1p, %d threads (a pair each), "
+                             "%.1f s" % (len(pick), Td, N, band_w, beam, thr, args.mode, threads, dt),
+                   "single_thread_pairs_per_s": 1.0 / per_pair,
+                   "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": int(len(pick))}
+        bytes_per_pair = 2 * Td * N * 4 + mean_L  # both reads' posteriors in, u8 labels out
+        achieved = B * bytes_per_pair / (k_ms * 1e-3) / 1e9
+        prefix = "duplex_slots_kernel<%d" % (0 if args.mode == "logsumexp" else 1)
+        traffic, traffic_note = pmc_traffic(prefix) if (B == cfg["batch"]) else (None, None)
+        out = {
+            "metric": "pairs/s (2-D pair consensus, T=%d, N=5, beam=%d, band +-%d, %s)" % (Td, beam, band_w, args.mode),
+            "value": world * B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world, "steps": args.steps,
+            "warmup": max(args.warmup, 1), "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "beam_search_duplex beam_size=%d beam_cut_threshold=%.1f collapse_repeats logadd=%s, "
+                                   "batch=%d pairs T1=T2=%d N=5 per GPU (%s), envelope = band +-%d around the diagonal, "
+                                   "reference-style rows numpy default_rng(%d+rank)"
+                                   % (beam, thr, args.mode, B, Td, cfg["baseline"], band_w, cfg["seed"]),
+                       "baseline_config": 5, "pairs_per_gpu": B, "T": Td, "N": N, "beam_size": beam, "beam_cut_threshold": thr,
+                       "logadd_mode": args.mode, "kernel": cfg["kernel_name"], "pairs_ok": ok, "mean_labels_per_pair": mean_L,
+                       "overlap": overlap, "tie_order": fcd.tie_order(),
+                       "parallelism": "pairs sharded x%d, no collective" % world if world > 1 else "single GPU"},
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                "traffic": traffic, "traffic_source": traffic_note,
+                "kernel": "duplex search (log-space copies + kernel), %.3f ms per call (HIP events), %d pairs x %.0f "
+                          "algorithmic B/pair" % (k_ms, B, bytes_per_pair),
+                "kernel_ms": k_ms, "launches_timed": k_calls,
+                "overlap": None if not overlap else {
+                    "streams": overlap, "sustained_ms_per_launch": elapsed / args.steps * 1e3,
+                    "achieved_sustained": B * bytes_per_pair / (elapsed / args.steps) / 1e9,
+                    "single_launch_ms": single_ms, "single_launch_pairs_per_s": B / (single_ms * 1e-3) if single_ms else None},
+                # the search is bound by a serial chain, not by HBM: (band + 1) dependent, correctly rounded log-adds per
+                # step and pair -- tools/duplex_account.py prices the kernel against THAT (DESIGN.md section 4)
+                "secondary_bound": {"bound": "dependent log-add chain per step", "see": "tools/duplex_account.py -> "
+                                    "profiles/*_duplex_account.jsonl (chain_roofline.frac)"},
+                "wavefronts_per_simd": B / (torch.cuda.get_device_properties(dev).multi_processor_count * 4),
+            },
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -504,7 +654,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS),
                     help="BASELINE.json config: 2 = beam 5, 4096 reads per GPU (the metric; default), 3 = beam 32, "
-                         "8192 reads per GPU (the multi-GPU config's shard), 4 = CRF beam 5, 4096 reads")
+                         "8192 reads per GPU (the multi-GPU config's shard), 4 = CRF beam 5, 4096 reads, 5 = the 2-D pair "
+                         "consensus on 1024 pairs of 2000 rows (pairs/s)")
     ap.add_argument("--batch", type=int, default=0, help="reads per GPU per step (0 = the config's)")
     ap.add_argument("--cpu-seconds", type=float, default=4.0, help="wall budget of the CPU baseline leg")
     ap.add_argument("--kernel", type=int, default=0,
@@ -515,6 +666,9 @@ def main():
                     help="fcd_set_overlap (include/fcd.h): successive steps go round-robin to this many INTERNAL streams of "
                          "the one handle and share its one tree arena, so that the stragglers of a step (reads that tie at "
                          "every step) run under the next steps; 0 = every step in stream order.  Default: 4")
+    ap.add_argument("--mode", choices=("logsumexp", "max"), default="logsumexp",
+                    help="--config 5: LogSpace::add as the reference computes it without its default `fastexp` feature "
+                         "(logsumexp: BASELINE.json's north star) or with it (max: what the PyPI wheels compute)")
     ap.add_argument("--streams", type=int, default=1,
                     help="issue successive steps round-robin on this many HIP streams (each with its own "
                          "handle and tree arena) so that independent batches overlap on the GPU; 1 = strictly "
@@ -560,6 +714,9 @@ def main():
         os.environ.setdefault("RANK", str(rank))
         os.environ.setdefault("WORLD_SIZE", str(world))
         dist.init_process_group(backend="nccl", device_id=dev)
+
+    if cfg.get("duplex"):
+        return duplex_main(args, cfg, torch, dist, fcd, world, rank, local_rank, dev, distributed)
 
     B = args.batch or cfg["batch"]
     default_shape = B == cfg["batch"] and args.data == "reference"

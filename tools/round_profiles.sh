@@ -21,6 +21,11 @@ python bench.py > $O/${TAG}_bench_line.json 2> $O/${TAG}_bench.err
 # the BASELINE multi-GPU config's per-rank shard and the CRF config under the same contract
 python bench.py --config 3 --no-viterbi > $O/${TAG}_bench_config3.json 2> $O/${TAG}_bench_config3.err
 python bench.py --config 4 --no-viterbi > $O/${TAG}_bench_config4.json 2> $O/${TAG}_bench_config4.err
+# BASELINE config 5 (the 2-D pair consensus) under the same contract: pairs/s, both log-add flavours
+python bench.py --config 5 > $O/${TAG}_bench_config5.json 2> $O/${TAG}_bench_config5.err
+python bench.py --config 5 --mode max > $O/${TAG}_bench_config5_max.json 2>> $O/${TAG}_bench_config5.err
+python bench.py --config 5 --overlap 0 --steps 5 --warmup 1 --cpu-seconds 1 > $O/${TAG}_bench_config5_overlap0.json 2>> $O/${TAG}_bench_config5.err
+python bench.py --config 5 --mode max --overlap 0 --steps 5 --warmup 1 --cpu-seconds 1 > $O/${TAG}_bench_config5_max_overlap0.json 2>> $O/${TAG}_bench_config5.err
 # round 6: bench.py overlaps its steps on the handle's internal streams by default (fcd_set_overlap) -- the same lines with
 # every step in stream order: one launch at a time, what the kernel-level roofline and the counters are quoted on
 python bench.py --overlap 0 --no-e2e --cpu-seconds 1 > $O/${TAG}_bench_line_overlap0.json 2> $O/${TAG}_bench_overlap0.err
