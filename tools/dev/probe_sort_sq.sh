@@ -2,8 +2,8 @@
 # developer scratch: dynamic instruction counts of the quicksort probe kernel (per wavefront = per list)
 set -u
 R=$PWD; O=$R/gpurun_out/prof_sortsq; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
-for cfg in "25 1 32" "64 3 32" "130 3 32"; do
-  tag=$(echo $cfg | tr ' ' '_')
+for tag in ${SORTSQ_CFGS:-25_1_32 64_3_32 130_3_32}; do  # n_planes_keep
+  cfg=$(echo $tag | tr '_' ' ')
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $O -o s_$tag -- python $R/tools/dev/probe_sort_workload.py $cfg > $O/s_$tag.log 2>&1
   python - $O $tag <<'PY'
 import csv, glob, sys, collections

@@ -7,6 +7,8 @@ import torch
 from fast_ctc_decode_amd import _native as nat
 from test_pdq178 import orderable
 
+if os.environ.get("FCD_LIB"):  # an A/B candidate of tools/dev/mk_variant.sh
+    nat.LIB_PATH = os.path.abspath(os.environ["FCD_LIB"])
 lib = nat.load()
 h = nat.default_handle(0)
 h.set_stream(torch.cuda.current_stream().cuda_stream)
@@ -51,6 +53,11 @@ def run(n, planes, keep, pairs=1024, serial=False):
               "; segments per call %.2f; total %.0f" % (cyc[10] / calls, sum(cyc[:10]) / calls), flush=True)
 
 
+if os.environ.get("REG_ONLY"):  # (a -DFCD_REG_PROF build: slots 1 .. 6 are the phases of a partition in registers)
+    for n in (25, 40, 64):
+        for keep in (1 << 20, 32):
+            run(n, 1, keep)
+    sys.exit(0)
 for n, planes in ((25, 1), (128, 3), (64, 3), (160, 3), (130, 5)):
     for keep in (1 << 20, 32, 5):
         run(n, planes, keep)
