@@ -607,7 +607,9 @@ def duplex_main(args, cfg, torch, dist, fcd, world, rank, local_rank, dev, distr
                    "single_thread_pairs_per_s": 1.0 / per_pair,
                    "gpu_vs_oracle_mismatches": mism, "gpu_vs_oracle_compared": int(len(pick))}
         bytes_per_pair = 2 * Td * N * 4 + mean_L  # both reads' posteriors in, u8 labels out
-        achieved = B * bytes_per_pair / (k_ms * 1e-3) / 1e9
+        in_flight = k_ms * args.steps / (elapsed * 1e3) if overlap else 1.0  # (bench main: a call's share of the chip)
+        k_eff_ms = k_ms / in_flight if overlap else k_ms
+        achieved = B * bytes_per_pair / (k_eff_ms * 1e-3) / 1e9
         prefix = "duplex_slots_kernel<%d" % (0 if args.mode == "logsumexp" else 1)
         traffic, traffic_note = pmc_traffic(prefix) if (B == cfg["batch"]) else (None, None)
         out = {
@@ -626,12 +628,13 @@ def duplex_main(args, cfg, torch, dist, fcd, world, rank, local_rank, dev, distr
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic, "traffic_source": traffic_note,
-                "kernel": "duplex search (log-space copies + kernel), %.3f ms per call (HIP events), %d pairs x %.0f "
-                          "algorithmic B/pair" % (k_ms, B, bytes_per_pair),
-                "kernel_ms": k_ms, "launches_timed": k_calls,
+                "kernel": "duplex search (log-space copies + kernel), %.3f ms per call (HIP events)%s, %d pairs x %.0f "
+                          "algorithmic B/pair" % (k_ms, " with %.2f calls in flight on average = %.3f ms of the chip per call"
+                                                  % (in_flight, k_eff_ms) if overlap else "", B, bytes_per_pair),
+                "kernel_ms": k_ms, "launches_timed": k_calls, "launches_in_flight": in_flight,
                 "overlap": None if not overlap else {
                     "streams": overlap, "sustained_ms_per_launch": elapsed / args.steps * 1e3,
-                    "achieved_sustained": B * bytes_per_pair / (elapsed / args.steps) / 1e9,
+                    "achieved_one_launch_at_a_time": B * bytes_per_pair / (single_ms * 1e-3) / 1e9 if single_ms else None,
                     "single_launch_ms": single_ms, "single_launch_pairs_per_s": B / (single_ms * 1e-3) if single_ms else None},
                 # the search is bound by a serial chain, not by HBM: (band + 1) dependent, correctly rounded log-adds per
                 # step and pair -- tools/duplex_account.py prices the kernel against THAT
@@ -866,7 +869,12 @@ def main():
         mean_L = float(rc.out_len.astype(np.float64).mean())
         # posteriors in, u8 label + u32 time out (CRF: the dense T*S*N figure)
         bytes_per_read = T * N * 4 * (4 if cfg["crf"] else 1) + 5.0 * mean_L
-        achieved = B * bytes_per_read / (k_ms * 1e-3) / 1e9
+        # Overlapping steps (fcd_set_overlap): `k_ms` is a launch's duration WHILE it shares the chip with the launches of the
+        # other internal streams -- on average k_ms * steps / elapsed of them at once -- so the kernel's rate is a launch's
+        # bytes over its share of that time, k_ms / launches_in_flight = elapsed / steps.  One launch at a time: k_ms itself.
+        in_flight = k_ms * args.steps / (elapsed * 1e3) if overlap else 1.0
+        k_eff_ms = k_ms / in_flight if overlap else k_ms
+        achieved = B * bytes_per_read / (k_eff_ms * 1e-3) / 1e9
         # the CPU leg (and its output cross-check) runs on rank 0 at N = 1 only, as the contract asks
         cpu = cpu_baseline(cfg, x_host, init_host, rc.labels, rc.path, rc.out_len, args.cpu_seconds) if world == 1 else None
         # (the names carry further template arguments after S: counting / profiling / one-length flags)
@@ -919,7 +927,7 @@ def main():
         occupancy = kernel_occupancy(symbol) if (symbol and args.kernel == 0) else None
         vit = viterbi_roofline(fcd, torch, dev) if not args.no_viterbi else None
         vit16 = viterbi_roofline(fcd, torch, dev, half=True) if not args.no_viterbi else None
-        valu = valu_issue_roofline(prefix, k_ms, simds) if default_shape else None
+        valu = valu_issue_roofline(prefix, k_eff_ms, simds) if default_shape else None
         e2e = None
         if world == 1 and not args.no_e2e and args.streams == 1:
             e2e = e2e_leg(fcd, cfg, x_host, init_host, rc)
@@ -973,9 +981,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_note,
-                "kernel": "beam search kernel, %.3f ms per launch (HIP events), %d reads x %.0f "
-                          "algorithmic B/read" % (k_ms, B, bytes_per_read),
-                "kernel_ms": k_ms, "launches_timed": k_calls,
+                "kernel": "beam search kernel, %.3f ms per launch (HIP events)%s, %d reads x %.0f "
+                          "algorithmic B/read" % (k_ms, " with %.2f launches in flight on average = %.3f ms of the chip per launch"
+                                                  % (in_flight, k_eff_ms) if overlap else "", B, bytes_per_read),
+                "kernel_ms": k_ms, "launches_timed": k_calls, "launches_in_flight": in_flight,
                 # The search is a serial chain of T dependent steps per read: it is bound by instruction
                 # issue, not by HBM (SURVEY.md finding 5) -- priced here against the VALU issue peak.
                 "secondary_bound": valu if valu is not None else {
@@ -985,13 +994,13 @@ def main():
                 # internal streams; what the chip sustains is a launch per `sustained_ms_per_launch`
                 "overlap": None if not overlap else {
                     "streams": overlap, "sustained_ms_per_launch": elapsed / args.steps * 1e3,
-                    "achieved_sustained": B * bytes_per_read / (elapsed / args.steps) / 1e9,
+                    "achieved_one_launch_at_a_time": B * bytes_per_read / (single_ms * 1e-3) / 1e9 if single_ms else None,
                     "single_launch_ms": single_ms,
                     "single_launch_reads_per_s": B / (single_ms * 1e-3) if single_ms else None},
                 "wavefronts_per_simd": B / rpw / simds,
                 # (what the instantiation RESERVES: registers, LDS and the resident wavefronts per SIMD they allow)
                 "occupancy": occupancy,
-                "step_latency_us": k_ms * 1e3 / T,
+                "step_latency_us": (single_ms or k_ms) * 1e3 / T,  # (of a launch alone)
             },
             "cpu_baseline": cpu,
             "e2e": e2e,
