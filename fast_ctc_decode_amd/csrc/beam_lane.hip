@@ -1115,10 +1115,11 @@ __global__ void slab_pool_init_kernel(unsigned long long *pool, int slabs) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i == 0) {
         pool[0] = 0ull;                          // pop tickets
-        pool[1] = (unsigned long long)slabs;     // push tickets: the ring starts full, generation 0
+        pool[1] = (unsigned long long)slabs;     // push tickets: the queue starts full
         pool[2] = (unsigned long long)slabs;
     }
-    if (i < slabs) reinterpret_cast<uint32_t *>(pool + slab_pool::kHeaderWords)[i] = (uint32_t)i;
+    if (i < slabs)  // slab i sits in cell i as if push ticket i had stored it: sequence i + 1
+        pool[slab_pool::kHeaderWords + i] = ((unsigned long long)(uint32_t)(i + 1) << 32) | (uint32_t)i;
 }
 }  // namespace
 

@@ -44,10 +44,20 @@ def main():
     first = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
     n = int(sys.argv[2]) if len(sys.argv) > 2 else 500
     cases = bad = 0
+    from fast_ctc_decode_amd import _native as nat
+    h = nat.default_handle()
     for seed in budgeted(first, n):
         x, beam, thr, collapse, lengths = P._fuzz_case(seed)
         rng = np.random.default_rng(seed + 7)
         x = inject(rng, x)
+        # r06: half the seeds under a small workspace limit with first-pass slabs of a sixth of the worst case (the wide-beam
+        # kernel then takes its slabs from the device-side pool, a handful of them, and most reads go through the retry
+        # pass; the other kernels run in chunks), a third with the handle's calls on internal streams (fcd_set_overlap)
+        knobs = np.random.default_rng(seed + 29)
+        limited = knobs.random() < 0.5
+        h.set_workspace_limit(int(knobs.integers(1, 9)) << 20 if limited else 0)
+        h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 6 if limited else 0))
+        h.set_overlap(int(knobs.integers(2, 6)) if knobs.random() < 0.33 else 0)
         for kernel in (0, 1, 2, 3, 4):
             cases += 1
             try:
