@@ -242,6 +242,32 @@ def test_lane_overlapping_calls(fcd):
         h.check(h.lib.fcd_debug_set_first_pass_divisor(h.ptr, 0))
 
 
+def test_module_level_overlap_switch(fcd):
+    """fast_ctc_decode_amd.set_overlap / overlap_join (the thread's handle): results read through BatchResult.cpu() --
+    which joins by itself -- and through tensors used directly after overlap_join() are those of stream order."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("device tensors only")
+    xs = [torch.from_numpy(gen_batch(980 + i, 6, 180 + 20 * i, 5)).cuda() for i in range(4)]
+    want = [fcd.beam_search_batch_raw(x, 5, 0.1, True).cpu() for x in xs]
+    fcd.set_overlap(3)
+    try:
+        rs = [fcd.beam_search_batch_raw(x, 5, 0.1, True) for x in xs]
+        fcd.overlap_join()                       # torch's current stream waits: the tensors themselves are good now
+        lens = [r.out_len.clone() for r in rs]
+        torch.cuda.synchronize()
+        for ln, r, w in zip(lens, rs, want):
+            np.testing.assert_array_equal(ln.cpu().numpy(), w.out_len)
+            c = r.cpu()
+            for i in range(len(w.out_len)):
+                n = int(w.out_len[i])
+                np.testing.assert_array_equal(c.path[i, :n], w.path[i, :n])
+        seqs = fcd.beam_search_batch(xs[0], "NACGT", 5, 0.1)   # (the string-returning entry point joins too)
+        assert [len(s) for s, _ in seqs] == [int(v) for v in want[0].out_len]
+    finally:
+        fcd.set_overlap(0)
+
+
 @pytest.mark.parametrize("beam", [32, 40])
 def test_lane_slab_pool_under_contention(fcd, beam):
     """The device-side slab pool (csrc/slab_pool.h) with far fewer slabs than wavefronts: a workspace limit leaves a
